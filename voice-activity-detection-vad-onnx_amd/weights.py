@@ -1,0 +1,168 @@
+"""Weight containers for the VAD nets + seeded synthetic initialisers.
+
+No trained checkpoint ships with the reference (every script points at
+/home/DakeQQ/Downloads/..., e.g. FSMN/Export_FSMN_VAD.py:14-15), so kernels are validated and
+benchmarked on SEEDED SYNTHETIC weights of the real architecture; a real checkpoint drops in
+through the same dict keys (`load_*` helpers take a state-dict-like mapping of numpy arrays).
+
+All tensors are float32 numpy arrays on the host; `Session` objects upload them once.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _rng(seed, tag):
+    # independent stream per tensor so that adding a tensor never shifts the others
+    return np.random.default_rng([seed, sum(ord(c) * (i + 1) for i, c in enumerate(tag)) & 0x7FFFFFFF])
+
+
+def _normal(seed, tag, shape, std):
+    return (_rng(seed, tag).standard_normal(shape) * std).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- Silero v5 (16 kHz)
+SILERO_ENC = ((129, 128, 1), (128, 64, 2), (64, 64, 2), (64, 128, 1))   # (c_in, c_out, stride), k=3, pad=1
+
+
+def silero_stft_basis():
+    """[258,256] hann-windowed real DFT basis, filter 256 / hop 128 (published silero-vad v5
+    `forward_basis_buffer`): rows 0..128 = cos, rows 129..257 = -sin... sign of the imaginary
+    part does not matter to |.|; we use +imag(fft(eye)) like the published STFT module."""
+    n = 256
+    k = np.arange(129, dtype=np.float64)[:, None]
+    t = np.arange(n, dtype=np.float64)[None, :]
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n, dtype=np.float64) / n)     # periodic hann
+    ang = 2.0 * np.pi * k * t / n
+    basis = np.concatenate([np.cos(ang), -np.sin(ang)], axis=0) * win[None, :]
+    return basis.astype(np.float32)
+
+
+def silero_synthetic(seed=1234):
+    """Seeded weights of the silero-vad v5 architecture (see oracle/silero.py header)."""
+    w = {"stft_basis": silero_stft_basis()}
+    for i, (ci, co, _s) in enumerate(SILERO_ENC):
+        w[f"enc{i}_w"] = _normal(seed, f"enc{i}_w", (co, ci, 3), 1.6 / np.sqrt(3 * ci))
+        w[f"enc{i}_b"] = _normal(seed, f"enc{i}_b", (co,), 0.05)
+    # the first conv sees |STFT| of +-1-scaled audio (speech-level bursts ~0.1 rms -> |X| ~ 1)
+    w["enc0_w"] *= np.float32(2.0)
+    h = 128
+    w["lstm_w_ih"] = _normal(seed, "lstm_w_ih", (4 * h, h), 1.0 / np.sqrt(h))
+    w["lstm_w_hh"] = _normal(seed, "lstm_w_hh", (4 * h, h), 1.0 / np.sqrt(h))
+    w["lstm_b_ih"] = _normal(seed, "lstm_b_ih", (4 * h,), 0.1)
+    w["lstm_b_hh"] = _normal(seed, "lstm_b_hh", (4 * h,), 0.1)
+    # decoder: positive taps + negative bias so louder input -> higher speech probability,
+    # which makes the synthetic burst clips cross both the 0.5 and 0.35 thresholds.
+    w["dec_w"] = np.abs(_normal(seed, "dec_w", (h,), 0.25)).astype(np.float32)
+    w["dec_b"] = np.array([-2.0], dtype=np.float32)
+    return w
+
+
+def silero_check(w):
+    """Shape/dtype validation of a Silero weight dict (raises ValueError)."""
+    want = {"stft_basis": (258, 256), "lstm_w_ih": (512, 128), "lstm_w_hh": (512, 128),
+            "lstm_b_ih": (512,), "lstm_b_hh": (512,), "dec_w": (128,), "dec_b": (1,)}
+    for i, (ci, co, _s) in enumerate(SILERO_ENC):
+        want[f"enc{i}_w"] = (co, ci, 3)
+        want[f"enc{i}_b"] = (co,)
+    for k, shp in want.items():
+        if k not in w:
+            raise ValueError(f"silero weights: missing '{k}'")
+        a = np.asarray(w[k])
+        if tuple(a.shape) != shp or a.dtype != np.float32:
+            raise ValueError(f"silero weights: '{k}' must be float32{shp}, got {a.dtype}{a.shape}")
+    return True
+
+
+# --------------------------------------------------------------------------- synthetic audio
+def burst_clips(batch, num_samples, seed=1234, loud=3000.0, quiet=30.0, sample_rate=16000):
+    """int16 [batch, num_samples]: 0.5-2 s segments alternating N(0,loud) / N(0,quiet) so every
+    branch of the decision state machines fires (SURVEY §8d synthetic-input recipe)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((batch, num_samples), dtype=np.int16)
+    for b in range(batch):
+        pos = 0
+        is_loud = bool(rng.integers(0, 2))
+        while pos < num_samples:
+            seg = int(rng.uniform(0.5, 2.0) * sample_rate)
+            seg = min(seg, num_samples - pos)
+            sigma = loud if is_loud else quiet
+            x = rng.standard_normal(seg) * sigma
+            out[b, pos:pos + seg] = np.clip(x, -32768, 32767).astype(np.int16)
+            pos += seg
+            is_loud = not is_loud
+    return out
+
+
+# --------------------------------------------------------------------------- FSMN-VAD (FunASR)
+# Layer widths of speech_fsmn_vad_zh-cn-16k-common (external FunASR config; the cache shape
+# [1,128,19,1] and input 400 are pinned in-tree: FSMN/Export_FSMN_VAD.py:116, :82-86).
+FSMN_DIMS = dict(input_dim=400, input_affine_dim=140, fsmn_layers=4, linear_dim=250, proj_dim=128,
+                 lorder=20, output_affine_dim=140, output_dim=248)
+
+
+_FSMN_SIL_BIAS = {1234: 7.2, 7: 8.4}
+
+
+def fsmn_synthetic(seed=1234, dims=None):
+    d = dict(FSMN_DIMS if dims is None else dims)
+    D, A, L, P, K, A2, O = (d["input_dim"], d["input_affine_dim"], d["linear_dim"], d["proj_dim"],
+                            d["lorder"], d["output_affine_dim"], d["output_dim"])
+    w = {
+        "in1_w": _normal(seed, "in1_w", (A, D), 1.0 / np.sqrt(D)), "in1_b": _normal(seed, "in1_b", (A,), 0.05),
+        "in2_w": _normal(seed, "in2_w", (L, A), 1.4 / np.sqrt(A)), "in2_b": _normal(seed, "in2_b", (L,), 0.05),
+        "out1_w": _normal(seed, "out1_w", (A2, L), 1.0 / np.sqrt(L)), "out1_b": _normal(seed, "out1_b", (A2,), 0.05),
+        "out2_w": _normal(seed, "out2_w", (O, A2), 2.0 / np.sqrt(A2)), "out2_b": _normal(seed, "out2_b", (O,), 0.05),
+    }
+    for l in range(d["fsmn_layers"]):
+        w[f"l{l}_lin_w"] = _normal(seed, f"l{l}_lin_w", (P, L), 1.0 / np.sqrt(L))
+        w[f"l{l}_fir_w"] = _normal(seed, f"l{l}_fir_w", (P, K), 0.6 / np.sqrt(K))
+        w[f"l{l}_aff_w"] = _normal(seed, f"l{l}_aff_w", (L, P), 1.4 / np.sqrt(P))
+        w[f"l{l}_aff_b"] = _normal(seed, f"l{l}_aff_b", (L,), 0.05)
+    # class 0 = silence: bias it so P(silence) hovers around 0.5 and the score gate toggles
+    # (offsets found offline for the seeds the tests/bench use; other seeds get the generic one)
+    w["out2_b"][0] += np.float32(5.5 + _FSMN_SIL_BIAS.get(seed, 7.0))
+    # CMVN of the LFR'd log-mel (log of int16-scale power ~ 10..25): centre and scale it
+    w["cmvn_means"] = (-(14.0 + _rng(seed, "cmvn_means").standard_normal(D))).astype(np.float32)
+    w["cmvn_vars"] = (0.25 + 0.02 * _rng(seed, "cmvn_vars").standard_normal(D)).astype(np.float32)
+    return w
+
+
+# --------------------------------------------------------------------------- FireRedVAD DFSMN
+# R/M/H/P/N1/S1/N2/S2/odim come from the checkpoint's `args` (FireRedVAD/Export_FireRedVAD.py:336-337);
+# these are the placeholders SURVEY Appendix B uses.
+FIRERED_CFG = dict(idim=80, R=8, M=1, H=256, P=128, N1=20, S1=1, N2=20, S2=1, odim=1)
+
+
+_FIRERED_OUT_CALIB = {1234: (1.21, -3.97), 7: (-7.55, -9.13)}
+
+
+def firered_synthetic(seed=1234, cfg=None):
+    c = dict(FIRERED_CFG if cfg is None else cfg)
+    D, R, M, H, P = c["idim"], c["R"], c["M"], c["H"], c["P"]
+    w = {"cfg": c}
+    # CMVN is folded into fc1 by the reference loader (:350-360): log-mel of int16-scale audio
+    # sits around 10..25, so the synthetic fc1 carries a centring bias.
+    w["fc1_w"] = _normal(seed, "fc1_w", (H, D), 0.3 / np.sqrt(D))
+    w["fc1_b"] = (-14.0 * w["fc1_w"].sum(axis=1) + _normal(seed, "fc1_b", (H,), 0.05)).astype(np.float32)
+    w["fc2_w"] = _normal(seed, "fc2_w", (P, H), 1.4 / np.sqrt(H))
+    w["fc2_b"] = _normal(seed, "fc2_b", (P,), 0.05)
+    for r in range(R):
+        w[f"fsmn{r}_lb"] = _normal(seed, f"fsmn{r}_lb", (P, c["N1"]), 0.5 / np.sqrt(c["N1"]))
+        if c["N2"] > 0:
+            w[f"fsmn{r}_la"] = _normal(seed, f"fsmn{r}_la", (P, c["N2"]), 0.5 / np.sqrt(c["N2"]))
+        if r > 0:
+            w[f"blk{r}_fc1_w"] = _normal(seed, f"blk{r}_fc1_w", (H, P), 1.0 / np.sqrt(P))
+            w[f"blk{r}_fc1_b"] = _normal(seed, f"blk{r}_fc1_b", (H,), 0.05)
+            w[f"blk{r}_fc2_w"] = _normal(seed, f"blk{r}_fc2_w", (P, H), 0.5 / np.sqrt(H))
+    for m in range(M):
+        w[f"dnn{m}_w"] = _normal(seed, f"dnn{m}_w", (H, P if m == 0 else H), 1.0 / np.sqrt(P if m == 0 else H))
+        w[f"dnn{m}_b"] = _normal(seed, f"dnn{m}_b", (H,), 0.05)
+    w["out_w"] = _normal(seed, "out_w", (c["odim"], H), 1.0 / np.sqrt(H))
+    w["out_b"] = _normal(seed, "out_b", (c["odim"],), 0.05)
+    # output affine (scale, shift) found offline so loud bursts sit near logit +2 and quiet
+    # stretches near -2 for the seeds the tests/bench use (random nets have a random polarity)
+    s, t = _FIRERED_OUT_CALIB.get(seed, (1.0, 0.0))
+    w["out_w"] = (w["out_w"] * np.float32(s)).astype(np.float32)
+    w["out_b"] = (w["out_b"] * np.float32(s) + np.float32(t)).astype(np.float32)
+    return w
