@@ -1,0 +1,430 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Inputs are seeded, weights are the seeded synthetic ones from vadx.weights (pushed into the
+reference nn.Modules through their state dicts), outputs are whatever the reference code computes.
+Only numbers are stored (fixtures are data; no reference text).  The GPU box never runs this.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _refload as R                      # noqa: E402
+import vadx                               # noqa: E402,F401
+from vadx import weights                  # noqa: E402
+from oracle import mel as omel            # noqa: E402  (torchaudio stand-in: melscale_fbanks is un-vendored)
+
+R.install_stubs(omel.melscale_fbanks)
+torch.set_num_threads(4)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+# ------------------------------------------------------------------------------------ STFT
+def gen_stft():
+    print("STFT variants")
+    out = {}
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(1, 1, 2400, generator=g)
+    out["x"] = x.numpy()
+    v1 = R.load_module("FSMN/STFT_Process.py", "ref_stft_v1")
+    v1b = R.load_module("DFSMN/near_and_far_end_audio/STFT_Process.py", "ref_stft_v1b")
+    v2 = R.load_module("NVIDIA_Frame_VAD_Multilingual_MarbleNet/STFT_Process.py", "ref_stft_v2")
+    v2f = R.load_module("FireRedVAD/STFT_Process.py", "ref_stft_v2f")
+
+    def rec(tag, mod_out, kern):
+        re, im = mod_out
+        out[tag + "_re"] = re.numpy()
+        out[tag + "_im"] = im.numpy()
+        for k, v in kern.items():          # tables: a few rows verbatim + sha256 of all bytes
+            a = np.ascontiguousarray(v.numpy())
+            rows = sorted({0, 1, 2, 37, a.shape[0] // 2, a.shape[0] - 2, a.shape[0] - 1})
+            out[f"{tag}_{k}_rowidx"] = np.array(rows)
+            out[f"{tag}_{k}_rows"] = a[rows]
+            out[f"{tag}_{k}_sha256"] = np.array(__import__("hashlib").sha256(a.tobytes()).hexdigest())
+            out[f"{tag}_{k}_shape"] = np.array(a.shape)
+
+    with torch.no_grad():
+        m = v1.STFT_Process("stft_B", n_fft=512, win_length=400, hop_len=160, max_frames=0, window_type="hamming").eval()
+        rec("fsmn", m(x, "constant"), {"cos": m.cos_kernel[:, 0, :], "sin": m.sin_kernel[:, 0, :]})
+        m = v1b.STFT_Process("stft_B", n_fft=319, win_length=319, hop_len=160, max_frames=0, window_type="hamming", center_pad=True).eval()
+        rec("dfsmn_b", m(x, "constant"), {"cos": m.cos_kernel[:, 0, :], "sin": m.sin_kernel[:, 0, :]})
+        m = v1b.STFT_Process("stft_B", n_fft=1024, win_length=640, hop_len=320, max_frames=0, window_type="hamming", center_pad=True).eval()
+        rec("dfsmn_a", m(x, "constant"), {"cos": m.cos_kernel[:, 0, :], "sin": m.sin_kernel[:, 0, :]})
+        m = v2.STFT_Process("stft_B", n_fft=512, win_length=400, hop_len=160, max_frames=0, window_type="hann_sym", center_pad=True, pad_mode="constant").eval()
+        rec("marble", m(x), {"kernel": m.stft_kernel[:, 0, :]})
+        m = v2f.STFT_Process("stft_B", n_fft=400, win_length=400, hop_len=160, max_frames=0, window_type="povey", center_pad=False, pad_mode="constant").eval()
+        rec("firered", m(x), {"kernel": m.stft_kernel[:, 0, :]})
+    save("stft", **out)
+
+
+# ------------------------------------------------------------------------------------ host helpers
+def gen_host():
+    print("host helpers (vad_to_timestamps / process_timestamps / format_time)")
+    ns = {"timedelta": __import__("datetime").timedelta, "np": np}
+    R.select_nodes("FSMN/Inference_FSMN_VAD_ONNX.py",
+                   {"process_timestamps", "vad_to_timestamps", "format_time", "normalize_to_int16"}, ns)
+    rng = np.random.default_rng(1234)
+    flags, raw_ts, proc_ts, fmt_in, fmt_out = [], [], [], [], []
+    for case in range(24):
+        n = int(rng.integers(0, 400))
+        p = rng.uniform(0.02, 0.5)
+        f = np.zeros(n, dtype=bool)
+        state = bool(rng.integers(0, 2))
+        for i in range(n):
+            if rng.uniform() < p * 0.2:
+                state = not state
+            f[i] = state
+        fd = [0.01, 0.02][case % 2]
+        ts = ns["vad_to_timestamps"](list(f), fd)
+        pt = ns["process_timestamps"](list(ts), 0.3, [0.2, 0.25][case % 2])
+        flags.append(f)
+        raw_ts.append(np.array(ts, dtype=np.float64).reshape(-1, 2))
+        proc_ts.append(np.array(pt, dtype=np.float64).reshape(-1, 2))
+    for v in list(rng.uniform(0, 5000, 64)) + [2.28, 2.74, 0.0, 3599.9996, 5.9, 19.46, 0.5, 2.5, 5.599]:
+        fmt_in.append(float(v))
+        fmt_out.append(ns["format_time"](float(v)))
+    aud = (rng.standard_normal(4000) * 1234.5).astype(np.float32)
+    save("host", n_cases=np.array(len(flags)),
+         **{f"flags_{i}": a for i, a in enumerate(flags)},
+         **{f"raw_{i}": a for i, a in enumerate(raw_ts)},
+         **{f"proc_{i}": a for i, a in enumerate(proc_ts)},
+         fmt_in=np.array(fmt_in), fmt_out=np.array(fmt_out),
+         norm_in=aud, norm_out=ns["normalize_to_int16"](aud))
+    # the only checked-in expected output of the reference (DFSMN near+far on *1.wav): data fixture
+    with open(os.path.join(R.REF, "DFSMN/near_and_far_end_audio/timestamps_indices.txt")) as fh:
+        idx = np.array([[int(t) for t in ln.split("-->")] for ln in fh if ln.strip()], dtype=np.int64)
+    with open(os.path.join(R.REF, "DFSMN/near_and_far_end_audio/timestamps_second.txt")) as fh:
+        sec = np.array([ln.strip() for ln in fh if ln.strip()])
+    save("dfsmn_golden_txt", indices=idx, seconds=sec)
+
+
+# ------------------------------------------------------------------------------------ VadPostprocessor
+def prob_tracks(rng):
+    tracks = []
+    for case in range(14):
+        n = [0, 1, 3, 7, 98, 280, 980, 2500, 5000, 980, 980, 600, 333, 4100][case]
+        if n == 0:
+            tracks.append(np.zeros(0, np.float32))
+            continue
+        kind = case % 4
+        if kind == 0:
+            p = rng.uniform(0, 1, n)
+        elif kind == 1:                                  # bursty
+            p = np.zeros(n)
+            pos, hot = 0, False
+            while pos < n:
+                seg = int(rng.integers(2, 120))
+                p[pos:pos + seg] = rng.uniform(0.55, 1.0, min(seg, n - pos)) if hot else rng.uniform(0, 0.45, min(seg, n - pos))
+                pos += seg
+                hot = not hot
+        elif kind == 2:                                  # all speech, longer than max_speech_frame
+            p = rng.uniform(0.6, 1.0, n)
+        else:
+            p = np.clip(0.5 + 0.3 * np.sin(np.arange(n) / 9.0) + 0.15 * rng.standard_normal(n), 0, 1)
+        tracks.append(p.astype(np.float32))
+    return tracks
+
+
+def gen_vadpost():
+    print("VadPostprocessor (FireRed + MarbleNet flavours)")
+    rng = np.random.default_rng(1234)
+    tracks = prob_tracks(rng)
+    out = {"n_cases": np.array(len(tracks))}
+    ns_f = {"np": np}
+    R.select_nodes("FireRedVAD/Inference_FireRed_ONNX.py", {"VadPostprocessor"}, ns_f,
+                   consts={"_VAD_SILENCE", "_VAD_POSSIBLE_SPEECH", "_VAD_SPEECH", "_VAD_POSSIBLE_SILENCE",
+                           "FRAME_SHIFT_MS", "FRAME_LENGTH_MS", "FRAME_SHIFT_S", "FRAME_LENGTH_S",
+                           "_FRAME_SHIFT_F32", "_FRAME_LENGTH_F32"})
+    ns_m = {"np": np}
+    R.select_nodes("NVIDIA_Frame_VAD_Multilingual_MarbleNet/Inference_NVIDIA_MarbleNet_VAD_ONNX.py",
+                   {"VadPostprocessor"}, ns_m,
+                   consts={"_VAD_SILENCE", "_VAD_POSSIBLE_SPEECH", "_VAD_SPEECH", "_VAD_POSSIBLE_SILENCE"})
+    cfgs_f = [(5, 0.4, 20, 2000, 20, 5, 0), (3, 0.5, 8, 300, 10, 4, 2), (1, 0.5, 0, 100, 0, 0, 0)]
+    cfgs_m = [(3, 0.5, 10, 1000, 10, 3, 0, 0.02), (5, 0.45, 5, 200, 6, 2, 1, 0.02)]
+    out["cfgs_f"] = np.array(cfgs_f, dtype=np.float64)
+    out["cfgs_m"] = np.array(cfgs_m, dtype=np.float64)
+    for i, p in enumerate(tracks):
+        out[f"probs_{i}"] = p
+        for c, cfg in enumerate(cfgs_f):
+            pp = ns_f["VadPostprocessor"](*cfg)
+            dec = pp.process(p.copy())
+            wav = [None, len(p) * 0.01 + 0.013, len(p) * 0.01 + 0.5][c % 3] if len(p) else None
+            seg = pp.decision_to_segment(dec, wav)
+            out[f"f{c}_dec_{i}"] = np.asarray(dec, np.int8)
+            out[f"f{c}_seg_{i}"] = np.array(seg, dtype=np.float64).reshape(-1, 2)
+            out[f"f{c}_wav_{i}"] = np.array(-1.0 if wav is None else wav)
+        for c, cfg in enumerate(cfgs_m):
+            pp = ns_m["VadPostprocessor"](*cfg[:7], frame_shift_s=cfg[7])
+            dec = pp.process(p.copy())
+            wav = [len(p) * 0.02 - 0.007, None][c % 2] if len(p) else None
+            seg = pp.decision_to_segment(dec, wav)
+            out[f"m{c}_dec_{i}"] = np.asarray(dec, np.int8)
+            out[f"m{c}_seg_{i}"] = np.array(seg, dtype=np.float64).reshape(-1, 2)
+            out[f"m{c}_wav_{i}"] = np.array(-1.0 if wav is None else wav)
+    save("vadpost", **out)
+
+
+# ------------------------------------------------------------------------------------ Silero host side
+def gen_silero_host():
+    print("Silero get_speech_timestamps + OnnxWrapper (network replaced by a replay / the oracle net)")
+    ns = {"torch": torch, "warnings": __import__("warnings"), "Callable": __import__("typing").Callable,
+          "List": __import__("typing").List}
+    R.select_nodes("Silero/modeling_modified/utils_vad.py", {"get_speech_timestamps", "OnnxWrapper"}, ns)
+
+    class Replay:
+        def __init__(self, probs):
+            self.probs, self.i = probs, 0
+
+        def reset_states(self):
+            self.i = 0
+
+        def __call__(self, chunk, sr):
+            assert chunk.shape[-1] == 512
+            v = self.probs[self.i]
+            self.i += 1
+            return torch.tensor([[v]], dtype=torch.float32)
+
+    rng = np.random.default_rng(1234)
+    out = {}
+    cases = []
+    for case in range(16):
+        n_samples = int([160000, 89431, 512, 100, 700, 160000, 400000, 33000, 160000, 48000,
+                         800000, 160000, 5120, 160000, 250000, 160000][case])
+        n_win = (n_samples + 511) // 512
+        kind = case % 4
+        if kind == 0:
+            p = rng.uniform(0, 1, n_win)
+        elif kind == 1:
+            p = np.zeros(n_win)
+            pos, hot = 0, bool(case & 4)
+            while pos < n_win:
+                seg = int(rng.integers(3, 90))
+                p[pos:pos + seg] = rng.uniform(0.5, 1.0, min(seg, n_win - pos)) if hot else rng.uniform(0, 0.4, min(seg, n_win - pos))
+                pos += seg
+                hot = not hot
+        elif kind == 2:                                   # long speech with short dips -> max_speech split
+            p = rng.uniform(0.55, 1.0, n_win)
+            for _ in range(max(1, n_win // 60)):
+                a = int(rng.integers(0, n_win))
+                p[a:a + int(rng.integers(2, 7))] = rng.uniform(0.0, 0.3)
+        else:
+            p = np.clip(0.45 + 0.35 * np.sin(np.arange(n_win) / 7.0) + 0.1 * rng.standard_normal(n_win), 0, 1)
+        p = p.astype(np.float32)
+        kw = [dict(threshold=0.5, max_speech_duration_s=20, min_speech_duration_ms=250, min_silence_duration_ms=250, return_seconds=True),
+              dict(threshold=0.5, max_speech_duration_s=6, min_speech_duration_ms=250, min_silence_duration_ms=100, return_seconds=False),
+              dict(threshold=0.6, max_speech_duration_s=4, min_speech_duration_ms=100, min_silence_duration_ms=250, return_seconds=True,
+                   use_max_poss_sil_at_max_speech=False),
+              dict(threshold=0.5, return_seconds=False)][case % 4 if case < 12 else (case + 1) % 4]
+        audio = torch.zeros(n_samples)
+        res = ns["get_speech_timestamps"](audio, Replay([float(v) for v in p]), **kw)
+        out[f"probs_{case}"] = p
+        out[f"nsamp_{case}"] = np.array(n_samples)
+        out[f"res_{case}"] = np.array([[d["start"], d["end"]] for d in res], dtype=np.float64).reshape(-1, 2)
+        cases.append(repr(sorted(kw.items())))
+    out["kwargs"] = np.array(cases)
+    out["n_cases"] = np.array(len(cases))
+
+    # OnnxWrapper state/context carry: onnxruntime stub whose session.run is the ORACLE network
+    from oracle import silero as osil
+    w = {k: T(v) for k, v in weights.silero_synthetic(1234).items()}
+    calls = []
+
+    class FakeSession:
+        def run(self, _names, feeds):
+            x, st = T(feeds["input"]), T(feeds["state"])
+            assert int(feeds["sr"]) == 16000 and feeds["sr"].dtype == np.int64
+            calls.append((feeds["input"].copy(), feeds["state"].copy()))
+            o, s = osil.net_forward(w, x, st)
+            return [o.numpy(), s.numpy()]
+
+    wrapper = ns["OnnxWrapper"].__new__(ns["OnnxWrapper"])
+    ns["np"] = np
+    wrapper.session = FakeSession()
+    wrapper.sample_rates = [16000]
+    wrapper.reset_states()
+    clip = weights.burst_clips(2, 8000, seed=11).astype(np.float32) * 0.000030517578
+    probs = wrapper.audio_forward(torch.from_numpy(clip), 16000).numpy()
+    out["wrap_audio"] = clip
+    out["wrap_probs"] = probs
+    out["wrap_inputs"] = np.stack([c[0] for c in calls])
+    out["wrap_states"] = np.stack([c[1] for c in calls])
+    out["wrap_final_state"] = wrapper._state.numpy()
+    out["wrap_final_context"] = wrapper._context.numpy()
+    save("silero_host", **out)
+
+
+# ------------------------------------------------------------------------------------ FSMN
+def gen_fsmn():
+    print("FSMN_VAD wrapper + encoder + host loop")
+    enc = R.load_module("FSMN/modeling_modified/encoder.py", "ref_fsmn_encoder")
+    stft_mod = R.load_module("FSMN/STFT_Process.py", "ref_stft_v1")
+    import torchaudio
+    ns = {"torch": torch, "torchaudio": torchaudio, "math": __import__("math"), "np": np}
+    R.select_nodes("FSMN/Export_FSMN_VAD.py", {"FSMN_VAD"}, ns)
+    d = weights.FSMN_DIMS
+    out = {}
+    for seed in (1234, 7):
+        w = weights.fsmn_synthetic(seed)
+        net = enc.FSMN(d["input_dim"], d["input_affine_dim"], d["fsmn_layers"], d["linear_dim"], d["proj_dim"],
+                       d["lorder"], 0, 1, 0, d["output_affine_dim"], d["output_dim"]).eval()
+        sd = {"in_linear1.linear.weight": w["in1_w"], "in_linear1.linear.bias": w["in1_b"],
+              "in_linear2.linear.weight": w["in2_w"], "in_linear2.linear.bias": w["in2_b"],
+              "out_linear1.linear.weight": w["out1_w"], "out_linear1.linear.bias": w["out1_b"],
+              "out_linear2.linear.weight": w["out2_w"], "out_linear2.linear.bias": w["out2_b"]}
+        for l in range(4):
+            sd[f"fsmn.{l}.linear.linear.weight"] = w[f"l{l}_lin_w"]
+            sd[f"fsmn.{l}.fsmn_block.conv_left.weight"] = w[f"l{l}_fir_w"].reshape(128, 1, 20, 1)
+            sd[f"fsmn.{l}.affine.linear.weight"] = w[f"l{l}_aff_w"]
+            sd[f"fsmn.{l}.affine.linear.bias"] = w[f"l{l}_aff_b"]
+        net.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+        stft = stft_mod.STFT_Process(model_type="stft_B", n_fft=512, hop_len=160, win_length=400, max_frames=0, window_type="hamming").eval()
+        L = 16000
+        model = ns["FSMN_VAD"](net, stft, 512, L // 160 + 1, 80, 16000, 0.97, 5, 1, (L // 160 + 1), 1.0, L, 160,
+                               T(w["cmvn_means"]).reshape(1, 1, -1), T(w["cmvn_vars"]).reshape(1, 1, -1))
+        clip = weights.burst_clips(1, 3 * 11040 + 16000, seed=seed + 100)[0]
+        peak = np.max(np.abs(clip.astype(np.float32)))
+        clip = (clip.astype(np.float32) * float(32767.0 / peak)).astype(np.int16)
+        caches = [torch.zeros(1, 128, 19, 1) for _ in range(4)]
+        noise = np.array([4.0], dtype=np.float32)
+        with torch.no_grad():
+            for k in range(4):
+                a = T(clip[k * 11040:k * 11040 + L].copy()).reshape(1, 1, -1)
+                # raw encoder output (pre-threshold), for the float tolerance check
+                aa = a.float()
+                aa = aa - torch.mean(aa)
+                aa = torch.cat([aa[:, :, :1], aa[:, :, 1:] - 0.97 * aa[:, :, :-1]], dim=-1)
+                score, c0, c1, c2, c3, noisy = model(a, *caches, torch.tensor([1.0]), T(noise))
+                out[f"s{seed}_score_{k}"] = score.numpy()
+                out[f"s{seed}_noisy_{k}"] = np.array(noisy.numpy())
+                out[f"s{seed}_noise_in_{k}"] = noise.copy()
+                for ci, c in enumerate((c0, c1, c2, c3)):
+                    out[f"s{seed}_cache{ci}_{k}"] = c.numpy()[0, :, :, 0]
+                caches = [c0, c1, c2, c3]
+                nd = noisy.numpy()
+                if nd > 0.0:
+                    noise = (0.5 * (noise + nd + 1.0)).astype(np.float32)
+        out[f"s{seed}_clip"] = clip
+    save("fsmn_forward", **out)
+
+    # host loop: replay seeded uint8 score chunks through the reference's own module-level loop
+    rng = np.random.default_rng(1234)
+    hl = {}
+    for case in range(6):
+        n_chunks = [1, 2, 5, 15, 15, 3][case]
+        scores = []
+        for k in range(n_chunks):
+            p = [0.5, 0.2, 0.8, 0.5, 0.35, 0.65][case]
+            s = np.zeros(101, np.uint8)
+            st = int(rng.integers(0, 2))
+            for i in range(101):
+                if rng.uniform() < 0.15:
+                    st = 1 - st
+                s[i] = st if rng.uniform() < 0.85 else int(rng.uniform() < p)
+            scores.append(s)
+        noisy_seq = [float(v) for v in rng.uniform(-0.5, 2.0, n_chunks)]
+
+        class FakeSess:
+            def __init__(self):
+                self.k = 0
+
+            def run(self, names, feeds):
+                k = self.k
+                self.k += 1
+                z = np.zeros((1, 128, 19, 1), np.float32)
+                return scores[k], z, z, z, z, np.float32(noisy_seq[k])
+
+        aligned = (n_chunks - 1) * 11040 + 16000
+        env = dict(np=np, time=__import__("time"), ort_session_A=FakeSess(), model_type="tensor(float)",
+                   BACKGROUND_NOISE_dB_INIT=30.0, SNR_THRESHOLD=10.0, ONE_MINUS_SPEECH_THRESHOLD=1.0,
+                   INPUT_AUDIO_LENGTH=16000, aligned_len=aligned, audio=np.zeros((1, 1, aligned), np.int16),
+                   slide_range=71, look_backward=30, inv_look_backward=float(1.0 / 30), SPEAKING_SCORE=0.5,
+                   SILENCE_SCORE=0.5, inv_audio_len=0.0, stride_step=11040, score_len=101,
+                   print=lambda *a, **k: None)
+        for i in range(7):
+            env[f"in_name_A{i}"] = f"i{i}"
+        for i in range(6):
+            env[f"out_name_A{i}"] = f"o{i}"
+        R.select_lines("FSMN/Inference_FSMN_VAD_ONNX.py", 156, 234, env)
+        hl[f"scores_{case}"] = np.stack(scores)
+        hl[f"noisy_{case}"] = np.array(noisy_seq, np.float32)
+        hl[f"saved_{case}"] = np.array(env["saved"], dtype=bool)
+        hl[f"noise_final_{case}"] = np.asarray(env["noise_average_dB"], np.float32)
+    hl["n_cases"] = np.array(6)
+    save("fsmn_hostloop", **hl)
+
+
+# ------------------------------------------------------------------------------------ FireRed
+def gen_firered():
+    print("FireRedVAD_ONNX wrapper + DetectModel")
+    stft_mod = R.load_module("FireRedVAD/STFT_Process.py", "ref_stft_v2f")
+    ns = {"torch": torch, "math": __import__("math"), "np": np, "STFT_Process": stft_mod.STFT_Process}
+    R.select_nodes("FireRedVAD/Export_FireRedVAD.py",
+                   {"FSMN", "DFSMNBlock", "DFSMN", "DetectModel", "FireRedVAD_ONNX", "build_kaldi_mel_filterbank"}, ns)
+    out = {}
+    cfgs = {1234: weights.FIRERED_CFG, 7: dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=2, N2=4, S2=3),
+            9: dict(weights.FIRERED_CFG, R=2, M=1, H=48, P=24, N1=5, S1=1, N2=0, S2=0, odim=3)}
+    for seed, cfg in cfgs.items():
+        w = weights.firered_synthetic(seed, cfg)
+        args = types.SimpleNamespace(**cfg)
+        dm = ns["DetectModel"](args).eval()
+        sd = {"dfsmn.fc1.0.weight": w["fc1_w"][:, :, None], "dfsmn.fc1.0.bias": w["fc1_b"],
+              "dfsmn.fc2.0.weight": w["fc2_w"][:, :, None], "dfsmn.fc2.0.bias": w["fc2_b"],
+              "dfsmn.fsmn1.lookback_filter.weight": w["fsmn0_lb"][:, None, :],
+              "out.weight": w["out_w"][:, :, None], "out.bias": w["out_b"]}
+        if cfg["N2"] > 0:
+            sd["dfsmn.fsmn1.lookahead_filter.weight"] = w["fsmn0_la"][:, None, :]
+        for r in range(1, cfg["R"]):
+            p = f"dfsmn.fsmns.{r - 1}."
+            sd[p + "fc1.0.weight"] = w[f"blk{r}_fc1_w"][:, :, None]
+            sd[p + "fc1.0.bias"] = w[f"blk{r}_fc1_b"]
+            sd[p + "fc2.weight"] = w[f"blk{r}_fc2_w"][:, :, None]
+            sd[p + "fsmn.lookback_filter.weight"] = w[f"fsmn{r}_lb"][:, None, :]
+            if cfg["N2"] > 0:
+                sd[p + "fsmn.lookahead_filter.weight"] = w[f"fsmn{r}_la"][:, None, :]
+        for m in range(cfg["M"]):
+            sd[f"dfsmn.dnns.{2 * m}.weight"] = w[f"dnn{m}_w"][:, :, None]
+            sd[f"dfsmn.dnns.{2 * m}.bias"] = w[f"dnn{m}_b"]
+        dm.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+        model = ns["FireRedVAD_ONNX"](dm, 400, 160, 400, 80, 16000, 0.97, "povey", 16000).eval()
+        if seed == 1234:
+            np.random.seed(1234)      # the reference's own validate_export input recipe (:1539-1543)
+            a = np.random.randint(-8000, 8000, (1, 1, 16000)).astype(np.int16)
+        else:
+            a = weights.burst_clips(1, 16000, seed=seed)[0].reshape(1, 1, -1)
+        with torch.no_grad():
+            probs = model(T(a)).numpy()
+        out[f"s{seed}_audio"] = a
+        out[f"s{seed}_probs"] = probs
+        if seed == 1234:
+            out["kaldi_fbank"] = model.fbank_conv[:, :, 0].numpy()
+    save("firered_forward", **out)
+
+
+if __name__ == "__main__":
+    which = set(sys.argv[1:])
+    gens = dict(stft=gen_stft, host=gen_host, vadpost=gen_vadpost, silero_host=gen_silero_host,
+                fsmn=gen_fsmn, firered=gen_firered)
+    for name, fn in gens.items():
+        if not which or name in which:
+            fn()

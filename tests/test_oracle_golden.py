@@ -1,0 +1,200 @@
+"""CPU: the oracle restatement vs fixtures produced by RUNNING the reference (tests/golden/make_golden.py)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import vadx  # noqa: F401
+from vadx import weights
+from oracle import firered as ofr
+from oracle import fsmn as ofs
+from oracle import mel as omel
+from oracle import postproc as opp
+from oracle import silero as osil
+from oracle import stft as ostft
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def _sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
+
+
+# ------------------------------------------------------------------ a1-a3: tables are BIT-identical
+@pytest.mark.parametrize("tag,n_fft,win,hop,wtype,variant,center", [
+    ("fsmn", 512, 400, 160, "hamming", "v1", True),
+    ("dfsmn_b", 319, 319, 160, "hamming", "v1b", True),
+    ("dfsmn_a", 1024, 640, 320, "hamming", "v1b", True),
+    ("marble", 512, 400, 160, "hann_sym", "v2", True),
+    ("firered", 400, 400, 160, "povey", "v2", False),
+])
+def test_stft_tables_and_transform(golden, tag, n_fft, win, hop, wtype, variant, center):
+    g = golden("stft")
+    w = ostft.padded_window(win, n_fft, wtype, variant)
+    cos_k, sin_k = ostft.dft_tables(n_fft, w, variant)
+    if variant == "v2":
+        assert _sha(torch.cat([cos_k, sin_k], 0)) == str(g[f"{tag}_kernel_sha256"])
+    else:
+        assert _sha(cos_k) == str(g[f"{tag}_cos_sha256"])
+        assert _sha(sin_k) == str(g[f"{tag}_sin_sha256"])
+    re, im = ostft.stft(T(g["x"]), cos_k, sin_k, hop, center_pad=center)
+    # same table, same conv1d => agreement to float32 round-off of the accumulation order
+    np.testing.assert_allclose(re.numpy(), g[f"{tag}_re"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(im.numpy(), g[f"{tag}_im"], rtol=0, atol=2e-5)
+
+
+# ------------------------------------------------------------------ a10, a22
+def test_host_helpers(golden):
+    g = golden("host")
+    for i in range(int(g["n_cases"])):
+        fd = [0.01, 0.02][i % 2]
+        raw = opp.vad_to_timestamps(list(g[f"flags_{i}"]), fd)
+        assert np.array_equal(np.array(raw, dtype=np.float64).reshape(-1, 2), g[f"raw_{i}"])
+        proc = opp.process_timestamps(raw, 0.3, [0.2, 0.25][i % 2])
+        assert np.array_equal(np.array(proc, dtype=np.float64).reshape(-1, 2), g[f"proc_{i}"])
+    for v, s in zip(g["fmt_in"], g["fmt_out"]):
+        assert opp.format_time(float(v)) == str(s)
+    assert np.array_equal(opp.normalize_to_int16(g["norm_in"]), g["norm_out"])
+
+
+def test_reference_checked_in_timestamps(golden):
+    """The only expected output the reference ships (DFSMN near+far): pins formatter + int() truncation."""
+    g = golden("dfsmn_golden_txt")
+    idx, sec = g["indices"], [str(s) for s in g["seconds"]]
+    # every index is int(seconds * 16000) of a 20 ms-grid time; reconstruct the grid time and re-format
+    for (a, b), line in zip(idx, sec):
+        for val, txt in ((a, line.split(" --> ")[0]), (b, line.split(" --> ")[1])):
+            # starts are i*0.02, ends are i*0.02+0.02 (vad_to_timestamps) -- e.g. 294*0.02+0.02 -> 94399
+            ks = range(int(val // 320) - 1, int(val // 320) + 3)
+            cand = [k * 0.02 for k in ks] + [k * 0.02 + 0.02 for k in ks]
+            hits = [c for c in cand if int(c * 16000) == val]
+            assert hits, (val, cand)
+            assert opp.format_time(hits[0]) == txt
+    assert opp.format_time(2.28) == "00:00:02.279"
+    assert int((294 * 0.02 + 0.02) * 16000) == 94399
+
+
+# ------------------------------------------------------------------ a16
+def test_vadpostprocessor(golden):
+    g = golden("vadpost")
+    for c, cfg in enumerate(g["cfgs_f"]):
+        pp = opp.VadPostprocessor(int(cfg[0]), float(cfg[1]), *[int(v) for v in cfg[2:7]])
+        for i in range(int(g["n_cases"])):
+            dec = pp.process(g[f"probs_{i}"])
+            assert np.array_equal(dec, g[f"f{c}_dec_{i}"]), (c, i)
+            wav = float(g[f"f{c}_wav_{i}"])
+            seg = pp.decision_to_segment(dec, None if wav < 0 else wav)
+            assert np.array_equal(np.array(seg, dtype=np.float64).reshape(-1, 2), g[f"f{c}_seg_{i}"]), (c, i)
+    for c, cfg in enumerate(g["cfgs_m"]):
+        pp = opp.VadPostprocessor(int(cfg[0]), float(cfg[1]), *[int(v) for v in cfg[2:7]],
+                                  frame_shift_s=float(cfg[7]), frame_length_s=None)
+        for i in range(int(g["n_cases"])):
+            dec = pp.process(g[f"probs_{i}"])
+            assert np.array_equal(dec, g[f"m{c}_dec_{i}"]), (c, i)
+            wav = float(g[f"m{c}_wav_{i}"])
+            seg = pp.decision_to_segment(dec, None if wav < 0 else wav)
+            assert np.array_equal(np.array(seg, dtype=np.float64).reshape(-1, 2), g[f"m{c}_seg_{i}"]), (c, i)
+
+
+# ------------------------------------------------------------------ a13, a11
+def test_silero_segmenter(golden):
+    g = golden("silero_host")
+    for i in range(int(g["n_cases"])):
+        kw = dict(eval(str(g["kwargs"][i])))
+        res = opp.silero_segments([float(v) for v in g[f"probs_{i}"]], int(g[f"nsamp_{i}"]), **kw)
+        got = np.array([[d["start"], d["end"]] for d in res], dtype=np.float64).reshape(-1, 2)
+        assert np.array_equal(got, g[f"res_{i}"]), i
+
+
+def test_silero_wrapper_state_and_context(golden):
+    g = golden("silero_host")
+    w = {k: T(v) for k, v in weights.silero_synthetic(1234).items()}
+    m = osil.OnnxWrapperOracle(w)
+    probs = m.audio_forward(T(g["wrap_audio"]), 16000).numpy()
+    np.testing.assert_allclose(probs, g["wrap_probs"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(m._state.numpy(), g["wrap_final_state"], rtol=0, atol=1e-6)
+    assert np.array_equal(m._context.numpy(), g["wrap_final_context"])
+    # what the reference wrapper actually fed the session: [B,576] = 64 context + 512 new samples
+    audio = g["wrap_audio"]
+    pad = (-audio.shape[1]) % 512
+    ap = np.pad(audio, ((0, 0), (0, pad)))
+    for k, x in enumerate(g["wrap_inputs"]):
+        ctx = np.zeros((2, 64), np.float32) if k == 0 else ap[:, 512 * k - 64:512 * k]
+        assert np.array_equal(x, np.concatenate([ctx, ap[:, 512 * k:512 * k + 512]], axis=1))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 100), 16000)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 512), 44100)
+
+
+# ------------------------------------------------------------------ a4-a8
+@pytest.mark.parametrize("seed", [1234, 7])
+def test_fsmn_forward(golden, seed):
+    g = golden("fsmn_forward")
+    fe = ofs.Frontend()
+    w = {k: T(v) for k, v in weights.fsmn_synthetic(seed).items()}
+    clip = g[f"s{seed}_clip"]
+    caches = [torch.zeros(1, 128, 19, 1) for _ in range(4)]
+    for k in range(4):
+        a = T(clip[k * 11040:k * 11040 + 16000].copy()).reshape(1, 1, -1)
+        noise = g[f"s{seed}_noise_in_{k}"]
+        score, caches, noisy, raw, db = ofs.forward(fe, w, a, caches, np.array([1.0], np.float32), noise, return_raw=True)
+        want = g[f"s{seed}_score_{k}"]
+        # uint8 gate: identical except where the float score/dB sits within round-off of a threshold
+        diff = np.flatnonzero(score[0].numpy() != want)
+        for i in diff:
+            assert abs(float(raw[0, i]) - 1.0) < 1e-4 or abs(float(db[0, i]) - float(noise[0])) < 1e-4
+        assert len(diff) <= 1
+        for ci in range(4):
+            np.testing.assert_allclose(caches[ci][0, :, :, 0].numpy(), g[f"s{seed}_cache{ci}_{k}"], rtol=0, atol=2e-4)
+        if np.isnan(g[f"s{seed}_noisy_{k}"]):
+            assert np.isnan(noisy.numpy()[0])
+        elif len(diff) == 0:
+            np.testing.assert_allclose(noisy.numpy()[0], g[f"s{seed}_noisy_{k}"], rtol=0, atol=1e-4)
+
+
+def test_fsmn_hostloop(golden):
+    g = golden("fsmn_hostloop")
+    for c in range(int(g["n_cases"])):
+        scores, noisy = g[f"scores_{c}"], g[f"noisy_{c}"]
+        silence, saved = True, []
+        noise = np.array([40.0], np.float32) * np.float32(0.1)
+        for k in range(scores.shape[0]):
+            flags, silence = opp.lookahead_vote(scores[k], 71, 30, 0.5, 0.5, silence)
+            saved += flags
+            if noisy[k] > 0.0:
+                noise = 0.5 * (noise + noisy[k] + 1.0)
+        flags, silence = opp.tail_flags_fsmn(scores[-1], 71, 101, silence)
+        saved += flags
+        assert np.array_equal(np.array(saved, bool), g[f"saved_{c}"]), c
+        np.testing.assert_array_equal(np.asarray(noise, np.float32), g[f"noise_final_{c}"])
+
+
+# ------------------------------------------------------------------ a21 + FireRed front-end
+@pytest.mark.parametrize("seed", [1234, 7, 9])
+def test_firered_forward(golden, seed):
+    g = golden("firered_forward")
+    cfgs = {1234: weights.FIRERED_CFG, 7: dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=2, N2=4, S2=3),
+            9: dict(weights.FIRERED_CFG, R=2, M=1, H=48, P=24, N1=5, S1=1, N2=0, S2=0, odim=3)}
+    fe = ofr.Frontend()
+    if seed == 1234:
+        assert np.array_equal(fe.fbank[0].numpy(), g["kaldi_fbank"])
+    w = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in weights.firered_synthetic(seed, cfgs[seed]).items()}
+    probs = ofr.forward(fe, w, T(g[f"s{seed}_audio"])).numpy()
+    # the reference's own PyTorch-vs-ORT bar for this graph is rtol=atol=1e-5 (Export_FireRedVAD.py:1560)
+    np.testing.assert_allclose(probs, g[f"s{seed}_probs"], rtol=1e-5, atol=1e-5)
+
+
+def test_melscale_fbanks_properties():
+    """torchaudio is un-vendored (parity unpinned): check the published algorithm's invariants."""
+    for scale, norm, fmin in (("htk", None, 20.0), ("slaney", "slaney", 0.0)):
+        fb = omel.melscale_fbanks(257, fmin, 8000, 80, 16000, norm, scale)
+        assert fb.shape == (257, 80) and fb.dtype == torch.float32
+        assert float(fb.min()) >= 0.0
+        peaks = fb.argmax(0)
+        assert bool((peaks[1:] >= peaks[:-1]).all())
+        if norm is None:
+            assert float(fb.max()) <= 1.0 + 1e-6
