@@ -1,0 +1,116 @@
+/* vadx.h -- C ABI of the MI355X-native batched VAD engine (libvadx.so).
+ *
+ * The reference (DakeQQ/Voice-Activity-Detection-VAD-ONNX) has no native FFI: its drop-in seam is
+ * the ONNX-Runtime Python session object (`session.run(output_names, feeds)`), plus for Silero the
+ * `OnnxWrapper` object.  Each entry point below is what a binding for that seam calls; the
+ * comment on each names the reference interface it replaces (file:line under the reference root).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / hip types in signatures (`stream` is a hipStream_t
+ *     passed as void*; NULL = the default stream);
+ *   - all data pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - caller-owned buffers, no hidden allocation, stream-ordered (no device sync inside);
+ *   - return 0 on success, a negative VADX_E* code otherwise; `vadx_last_error()` gives the text.
+ */
+#ifndef VADX_H
+#define VADX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VADX_OK          0
+#define VADX_EINVAL     -1   /* bad argument (shape, NULL pointer, unsupported sample rate ...) */
+#define VADX_ENOSPACE   -2   /* workspace / output capacity too small */
+#define VADX_EHIP       -3   /* a HIP runtime call failed */
+
+int         vadx_abi_version(void);
+const char *vadx_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Silero
+ * ------------------------------------------------------------------------------------------- */
+
+/* Original-layout float32 weights on the HOST (same tensors as the ONNX initialisers):
+ * stft_basis [258][256]; enc_w[i] [c_out][c_in][3], enc_b[i] [c_out] for the four encoder convs
+ * (129->128 s1, 128->64 s2, 64->64 s2, 64->128 s1); LSTM cell [512][128] x2 + biases [512] x2 in
+ * torch gate order (i,f,g,o); decoder conv [128] + bias [1]. */
+typedef struct vadx_silero_weights_host {
+    const float *stft_basis;
+    const float *enc_w[4];
+    const float *enc_b[4];
+    const float *lstm_w_ih, *lstm_w_hh, *lstm_b_ih, *lstm_b_hh;
+    const float *dec_w, *dec_b;
+} vadx_silero_weights_host;
+
+/* Number of floats of the packed (kernel-layout) weight blob. */
+size_t vadx_silero_packed_floats(void);
+/* Repack on the host (init time only); the caller uploads `packed_host` to the device once.
+ * Replaces: onnxruntime.InferenceSession(path) construction, Silero/modeling_modified/utils_vad.py:39. */
+int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *packed_host);
+
+/* Scratch needed by the two calls below, in bytes. `steps` = windows per clip (1 for vadx_silero_step). */
+size_t vadx_silero_workspace_bytes(int batch, int steps);
+
+/* One ORT-boundary call, batched:
+ *   feeds  {'input': f32 [B,576], 'state': f32 [2,B,128], 'sr': int64 scalar}
+ *   fetches(out f32 [B,1], stateN f32 [2,B,128])
+ * Replaces: self.session.run(None, ort_inputs), Silero/modeling_modified/utils_vad.py:116-119.
+ * sr must be 16000 (the reference wrapper's '16k' model path, utils_vad.py:62-64). */
+int vadx_silero_step(const float *packed, const float *input, const float *state, int64_t sr,
+                     int batch, float *out, float *state_n,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Whole clips, batched: audio f32 [B][row_stride] (first n_samples valid per row, +-1 scale),
+ * zero state and zero context at t=0, last window zero-padded; probs f32 [B][T], T = ceil(n/512).
+ * state_n (optional, may be NULL) receives the final [2,B,128].
+ * Replaces the window loop of get_speech_timestamps, utils_vad.py:350,359-372, and
+ * OnnxWrapper.audio_forward, utils_vad.py:130-146 (context carry :111-114,:123 is done in-kernel). */
+int vadx_silero_clips(const float *packed, const float *audio, int batch, int64_t n_samples,
+                      int64_t row_stride, float *probs, float *state_n,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* The two halves of vadx_silero_clips as separate launches (same buffers, same results), so a
+ * harness can time the state-independent encoder (STFT conv + conv stack + W_ih, the dominant
+ * kernel) and the recurrent kernel separately.  `steps` = ceil(n_samples/512). */
+int vadx_silero_encode(const float *packed, const float *audio, int batch, int64_t n_samples,
+                       int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream);
+int vadx_silero_recur(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
+                      int steps, const float *state0, float *probs, float *state_n, void *stream);
+
+/* Parameters of the segmenter; defaults of get_speech_timestamps (utils_vad.py:248-263). */
+typedef struct vadx_silero_seg_params {
+    double threshold;                 /* 0.5 */
+    double neg_threshold;             /* <0 => max(threshold-0.15, 0.01) */
+    int    sampling_rate;             /* 16000 */
+    double min_speech_duration_ms;    /* 250 */
+    double max_speech_duration_s;     /* inf */
+    double min_silence_duration_ms;   /* 100 */
+    double speech_pad_ms;             /* 30 */
+    double min_silence_at_max_speech; /* 98 */
+    int    use_max_poss_sil_at_max_speech; /* 1 */
+} vadx_silero_seg_params;
+
+/* Device-side dual-threshold segmenter, one clip per thread: probs f32 [B][T] -> padded sample
+ * index pairs int64 [B][cap][2] + counts int32 [B] (count > cap => truncated, VADX_ENOSPACE is NOT
+ * raised on device; the host checks counts).  n_samples int64 [B] = true clip lengths.
+ * Replaces: the state machine + padding of get_speech_timestamps, utils_vad.py:374-476
+ * (the seconds rounding :478-482 stays on the host: it is Python round()). */
+int vadx_silero_segments(const float *probs, int batch, int steps, const int64_t *n_samples,
+                         const vadx_silero_seg_params *params, int64_t *segments, int32_t *counts,
+                         int cap, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Test hooks (used by tests/ only)
+ * ------------------------------------------------------------------------------------------- */
+/* C[M][N] = A[M][K] * W[N][K]^T through the same LDS/MFMA tile helper the nets use.
+ * M multiple of 16 (<=64), N multiple of 16, K multiple of 16. */
+int vadx_test_gemm(const float *a, const float *w, float *c, int m, int n, int k, int swap, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VADX_H */

@@ -1,0 +1,93 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/vadx.h declares
+(no compute calls -- there is no GPU here), and host-only logic of the product package."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import vadx  # noqa: F401
+from vadx import _lib, build, timestamps, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)
+    return _lib.lib()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "vadx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vadx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libvadx.so does not export {name}"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert lib.vadx_abi_version() == 1
+
+
+def test_pack_host_layout(lib):
+    """Host-only repack (no GPU): spot-check the packed blob against the documented layout."""
+    w = weights.silero_synthetic(3)
+    hw = _lib.SileroWeightsHost()
+    hw.stft_basis = w["stft_basis"].ctypes.data
+    for i in range(4):
+        hw.enc_w[i] = w[f"enc{i}_w"].ctypes.data
+        hw.enc_b[i] = w[f"enc{i}_b"].ctypes.data
+    for k in ("lstm_w_ih", "lstm_w_hh", "lstm_b_ih", "lstm_b_hh", "dec_w", "dec_b"):
+        setattr(hw, k, w[k].ctypes.data)
+    n = lib.vadx_silero_packed_floats()
+    p = np.zeros(n, np.float32)
+    assert lib.vadx_silero_pack_host(ctypes.byref(hw), p.ctypes.data) == 0
+    # STFT rows regrouped per wave: [wave][re|im][16][256]
+    stft = p[:256 * 256].reshape(8, 2, 16, 256)
+    assert np.array_equal(stft[3, 0, 5], w["stft_basis"][3 * 16 + 5])
+    assert np.array_equal(stft[3, 1, 5], w["stft_basis"][129 + 3 * 16 + 5])
+    nyq = p[65536:65536 + 512].reshape(2, 256)
+    assert np.array_equal(nyq[0], w["stft_basis"][128]) and np.array_equal(nyq[1], w["stft_basis"][257])
+    c1 = p[66048:66048 + 128 * 3 * 144].reshape(128, 3, 144)
+    assert np.array_equal(c1[7, 2, :129], w["enc0_w"][7, :, 2]) and not c1[:, :, 129:].any()
+    # NULL pointer -> EINVAL with a message
+    assert lib.vadx_silero_pack_host(None, p.ctypes.data) == -1
+    assert b"NULL" in lib.vadx_last_error()
+
+
+def test_weight_validation():
+    w = weights.silero_synthetic(1)
+    assert weights.silero_check(w)
+    bad = dict(w)
+    bad["enc1_w"] = bad["enc1_w"][:, :, :2]
+    with pytest.raises(ValueError):
+        weights.silero_check(bad)
+    del bad["enc1_w"]
+    with pytest.raises(ValueError):
+        weights.silero_check(bad)
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vadx import silero
+    with pytest.raises(_lib.VadxError):
+        silero.SileroEngine(None)
+
+
+def test_host_timestamp_helpers_match_golden(golden):
+    g = golden("host")
+    for i in range(int(g["n_cases"])):
+        fd = [0.01, 0.02][i % 2]
+        raw = timestamps.vad_to_timestamps(list(g[f"flags_{i}"]), fd)
+        assert np.array_equal(np.array(raw, dtype=np.float64).reshape(-1, 2), g[f"raw_{i}"])
+        proc = timestamps.process_timestamps(raw, 0.3, [0.2, 0.25][i % 2])
+        assert np.array_equal(np.array(proc, dtype=np.float64).reshape(-1, 2), g[f"proc_{i}"])
+    for v, s in zip(g["fmt_in"], g["fmt_out"]):
+        assert timestamps.format_time(float(v)) == str(s)
+    assert np.array_equal(timestamps.normalize_to_int16(g["norm_in"]), g["norm_out"])
+    t = golden("dfsmn_golden_txt")
+    assert timestamps.indices([(5.42, 294 * 0.02 + 0.02)], 16000)[0][1] == 94399
+    assert timestamps.format_time(2.28) == str(t["seconds"][0]).split(" --> ")[0]

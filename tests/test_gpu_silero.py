@@ -1,0 +1,201 @@
+"""GPU parity: the HIP Silero path (through the C ABI in libvadx.so) vs the CPU oracle.
+
+Tolerances: frame scores within 1e-4 f32 (north_star); integer sample indices / segment tables
+bit-exact.  Everything here needs a real MI355X."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import vadx  # noqa: F401
+from vadx import _lib, silero, weights
+from oracle import postproc as opp
+from oracle import silero as osil
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    return silero.SileroEngine(weights.silero_synthetic(1234))
+
+
+@pytest.fixture(scope="module")
+def oracle_w():
+    return {k: T(v) for k, v in weights.silero_synthetic(1234).items()}
+
+
+# ------------------------------------------------------------------ the MFMA tile helper in isolation
+@pytest.mark.parametrize("m,n,k", [(16, 16, 16), (64, 32, 48), (32, 128, 256), (48, 16, 144)])
+@pytest.mark.parametrize("swap", [0, 1])
+def test_mfma_tile_helper(m, n, k, swap):
+    rng = np.random.default_rng(m * 1000 + n * 10 + k + swap)
+    a = rng.standard_normal((m, k)).astype(np.float32)          # asymmetric, catches transposes
+    w = rng.standard_normal((n, k)).astype(np.float32)
+    da, dw = T(a).cuda(), T(w).cuda()
+    dc = torch.zeros((m, n), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().vadx_test_gemm(da.data_ptr(), dw.data_ptr(), dc.data_ptr(), m, n, k, swap, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = a.astype(np.float64) @ w.astype(np.float64).T
+    np.testing.assert_allclose(dc.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.sqrt(k))
+
+
+# ------------------------------------------------------------------ a12 through the ORT-boundary call
+@pytest.mark.parametrize("batch", [1, 5, 16, 37])
+def test_step_matches_oracle(engine, oracle_w, batch):
+    rng = np.random.default_rng(batch)
+    x = (rng.standard_normal((batch, 576)) * rng.uniform(0.001, 0.3, (batch, 1))).astype(np.float32)
+    st = (rng.standard_normal((2, batch, 128)) * 0.5).astype(np.float32)
+    out, st_n = engine.step(x, st)
+    o_ref, s_ref = osil.net_forward(oracle_w, T(x), T(st))
+    np.testing.assert_allclose(out.cpu().numpy(), o_ref.numpy(), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(st_n.cpu().numpy(), s_ref.numpy(), rtol=0, atol=ATOL)
+
+
+def test_step_rejects_bad_arguments(engine):
+    with pytest.raises(ValueError):
+        engine.step(np.zeros((2, 500), np.float32), np.zeros((2, 2, 128), np.float32))
+    with pytest.raises(ValueError):
+        engine.step(np.zeros((2, 576), np.float32), np.zeros((2, 3, 128), np.float32))
+    L = _lib.lib()
+    x = torch.zeros((1, 576), device="cuda")
+    s = torch.zeros((2, 1, 128), device="cuda")
+    o = torch.zeros((1, 1), device="cuda")
+    ws = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    rc = L.vadx_silero_step(engine.packed.data_ptr(), x.data_ptr(), s.data_ptr(), 8000, 1, o.data_ptr(), s.data_ptr(),
+                            ws.data_ptr(), ws.numel(), None)
+    assert rc == -1 and b"16000" in L.vadx_last_error()
+    rc = L.vadx_silero_step(engine.packed.data_ptr(), x.data_ptr(), s.data_ptr(), 16000, 1, o.data_ptr(), s.data_ptr(),
+                            ws.data_ptr(), 16, None)
+    assert rc == -2
+
+
+# ------------------------------------------------------------------ whole clips (context carry in-kernel)
+@pytest.mark.parametrize("batch,n", [(3, 20000), (17, 5120), (2, 700), (1, 89431)])
+def test_clips_match_oracle(engine, oracle_w, batch, n):
+    clips = weights.burst_clips(batch, n, seed=batch + n).astype(np.float32) * np.float32(0.000030517578)
+    probs, state = engine.clips(clips, return_state=True)
+    m = osil.OnnxWrapperOracle(oracle_w)
+    ref = m.audio_forward(T(clips), 16000).numpy()
+    assert probs.shape == ref.shape
+    np.testing.assert_allclose(probs.cpu().numpy(), ref, rtol=0, atol=ATOL)
+    np.testing.assert_allclose(state.cpu().numpy(), m._state.numpy(), rtol=0, atol=ATOL)
+
+
+def test_wrapper_matches_reference_fixture(golden):
+    """OnnxWrapper semantics vs what the REFERENCE wrapper produced around the oracle network."""
+    g = golden("silero_host")
+    m = silero.OnnxWrapper(weights.silero_synthetic(1234))
+    audio = T(g["wrap_audio"])
+    probs = m.audio_forward(audio, 16000).numpy()
+    np.testing.assert_allclose(probs, g["wrap_probs"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(m._state.cpu().numpy(), g["wrap_final_state"], rtol=0, atol=ATOL)
+    assert np.array_equal(m._context.cpu().numpy(), g["wrap_final_context"])
+    # window-by-window calls (the reference's own loop) give the same numbers as the fused clip call
+    m.reset_states()
+    pad = (-audio.shape[1]) % 512
+    ap = torch.nn.functional.pad(audio, (0, pad))
+    outs = [m(ap[:, i:i + 512], 16000) for i in range(0, ap.shape[1], 512)]
+    np.testing.assert_allclose(torch.cat(outs, dim=1).numpy(), probs, rtol=0, atol=2e-6)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 100), 16000)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 512), 44100)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 2, 512), 16000)
+    # sr multiple of 16000 decimates (utils_vad.py:75-78)
+    o48 = m(torch.zeros(1, 1536), 48000)
+    assert tuple(o48.shape) == (1, 1)
+
+
+# ------------------------------------------------------------------ a13 segmenter: bit-exact vs reference fixtures
+def test_device_segmenter_matches_reference(engine, golden):
+    g = golden("silero_host")
+    for i in range(int(g["n_cases"])):
+        kw = dict(eval(str(g["kwargs"][i])))
+        probs = g[f"probs_{i}"][None, :]
+        n = int(g[f"nsamp_{i}"])
+        ret_s = kw.pop("return_seconds", False)
+        segs, counts = engine.segments(probs, [n], **kw)
+        got = silero._finish(segs, counts, [n], 16000, ret_s, 1, 1)[0]
+        got = np.array([[d["start"], d["end"]] for d in got], dtype=np.float64).reshape(-1, 2)
+        assert np.array_equal(got, g[f"res_{i}"]), (i, got, g[f"res_{i}"])
+
+
+def test_device_segmenter_batch_and_capacity(engine):
+    rng = np.random.default_rng(5)
+    B, Tn = 70, 400
+    probs = rng.uniform(0, 1, (B, Tn)).astype(np.float32)
+    probs[3] = 0.0                                              # empty result
+    probs[4] = 1.0                                              # one segment covering everything
+    lens = rng.integers(Tn * 512 - 511, Tn * 512 + 1, B)
+    kw = dict(threshold=0.5, min_speech_duration_ms=30, min_silence_duration_ms=30, max_speech_duration_s=3)
+    segs, counts = engine.segments(probs, lens, cap=2, **kw)    # cap too small on purpose -> transparently re-run
+    got = silero._finish(segs, counts, lens, 16000, False, 1, 1)
+    for b in range(B):
+        want = opp.silero_segments([float(v) for v in probs[b]], int(lens[b]), **kw)
+        assert got[b] == [{"start": d["start"], "end": d["end"]} for d in want], b
+    assert got[3] == [] and len(got[4]) >= 1
+
+
+# ------------------------------------------------------------------ end to end, reference call signature
+def test_get_speech_timestamps_end_to_end(oracle_w):
+    model = silero.load_silero_vad(onnx=True, use_cpu=True, path="synthetic:1234")
+    clips = weights.burst_clips(6, 160000, seed=21)
+    kw = dict(threshold=0.5, max_speech_duration_s=20, min_speech_duration_ms=250, min_silence_duration_ms=250,
+              return_seconds=True)
+    audio = clips.astype(np.float32) * 0.000030517578          # Silero/Inference_Silero_VAD_ONNX.py:83
+    batch, probs = silero.get_speech_timestamps_batch(audio, model, return_probs=True, **kw)
+    om = osil.OnnxWrapperOracle(oracle_w)
+    for b in range(clips.shape[0]):
+        ref_probs = np.array(osil.speech_probs(T(audio[b]), om), dtype=np.float32)
+        np.testing.assert_allclose(probs[b].cpu().numpy(), ref_probs, rtol=0, atol=ATOL)
+        want = opp.silero_segments([float(v) for v in ref_probs], audio.shape[1], **kw)
+        single = silero.get_speech_timestamps(torch.from_numpy(audio[b]), model, **kw)
+        assert single == batch[b]
+        # bit-exact timestamps unless a score sits within tolerance of a threshold
+        near = np.min(np.abs(ref_probs[:, None] - np.array([0.5, 0.35])[None, :]))
+        if near > 2 * ATOL:
+            assert batch[b] == want, b
+        assert len(want) >= 2                                   # the synthetic clips do exercise the state machine
+
+
+def test_ragged_lengths_and_tail_padding(oracle_w):
+    eng = silero.SileroEngine(weights.silero_synthetic(1234))
+    lens = np.array([16000, 8191, 512, 700, 12345])
+    clips = weights.burst_clips(5, 16000, seed=3).astype(np.float32) * np.float32(0.000030517578)
+    res, probs = silero.get_speech_timestamps_batch(clips, eng, lengths=lens, return_probs=True,
+                                                    min_speech_duration_ms=100, min_silence_duration_ms=60)
+    om = osil.OnnxWrapperOracle(oracle_w)
+    for b, n in enumerate(lens):
+        ref = np.array(osil.speech_probs(T(clips[b, :n]), om), dtype=np.float32)
+        np.testing.assert_allclose(probs[b, :len(ref)].cpu().numpy(), ref, rtol=0, atol=ATOL)
+        want = opp.silero_segments([float(v) for v in ref], int(n), min_speech_duration_ms=100, min_silence_duration_ms=60)
+        if np.min(np.abs(ref[:, None] - np.array([0.5, 0.35])[None, :])) > 2 * ATOL:
+            assert res[b] == want
+
+
+# ------------------------------------------------------------------ full-size property checks (BASELINE config 2 shape)
+def test_full_size_batch_invariance():
+    """B=1024 x 10 s: every clip's scores are independent of its batch neighbours and position
+    (bitwise), and agree with the oracle on a sample of clips."""
+    eng = silero.SileroEngine(weights.silero_synthetic(1234))
+    base = weights.burst_clips(32, 160000, seed=99).astype(np.float32) * np.float32(0.000030517578)
+    big = torch.from_numpy(base).cuda().repeat(32, 1)           # [1024,160000], clip i == clip i % 32
+    probs = eng.clips(big)
+    assert probs.shape == (1024, 313)
+    p = probs.view(32, 32, 313)
+    assert torch.equal(p[0], p[17]) and torch.equal(p[0], p[31])
+    small = eng.clips(torch.from_numpy(base[5:8]).cuda())       # different tile composition
+    assert torch.equal(small, probs[5:8])
+    assert bool(torch.isfinite(probs).all()) and float(probs.min()) >= 0 and float(probs.max()) <= 1
+    w = {k: T(v) for k, v in weights.silero_synthetic(1234).items()}
+    om = osil.OnnxWrapperOracle(w)
+    ref = np.array(osil.speech_probs(T(base[7]), om), dtype=np.float32)
+    np.testing.assert_allclose(probs[7].cpu().numpy(), ref, rtol=0, atol=ATOL)

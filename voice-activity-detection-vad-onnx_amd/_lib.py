@@ -1,0 +1,82 @@
+"""ctypes binding of libvadx.so (the C ABI declared in include/vadx.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a GPU call fails this
+module raises -- it never silently routes anywhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvadx.so")
+
+
+class VadxError(RuntimeError):
+    pass
+
+
+class SileroWeightsHost(C.Structure):
+    _fields_ = [("stft_basis", C.c_void_p), ("enc_w", C.c_void_p * 4), ("enc_b", C.c_void_p * 4),
+                ("lstm_w_ih", C.c_void_p), ("lstm_w_hh", C.c_void_p), ("lstm_b_ih", C.c_void_p),
+                ("lstm_b_hh", C.c_void_p), ("dec_w", C.c_void_p), ("dec_b", C.c_void_p)]
+
+
+class SileroSegParams(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("neg_threshold", C.c_double), ("sampling_rate", C.c_int),
+                ("min_speech_duration_ms", C.c_double), ("max_speech_duration_s", C.c_double),
+                ("min_silence_duration_ms", C.c_double), ("speech_pad_ms", C.c_double),
+                ("min_silence_at_max_speech", C.c_double), ("use_max_poss_sil_at_max_speech", C.c_int)]
+
+
+_P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/vadx.h declares
+SIGNATURES = {
+    "vadx_abi_version": (_I, []),
+    "vadx_last_error": (C.c_char_p, []),
+    "vadx_silero_packed_floats": (_Z, []),
+    "vadx_silero_pack_host": (_I, [C.POINTER(SileroWeightsHost), _P]),
+    "vadx_silero_workspace_bytes": (_Z, [_I, _I]),
+    "vadx_silero_step": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _Z, _P]),
+    "vadx_silero_clips": (_I, [_P, _P, _I, _L, _L, _P, _P, _P, _Z, _P]),
+    "vadx_silero_encode": (_I, [_P, _P, _I, _L, _L, _P, _Z, _P]),
+    "vadx_silero_recur": (_I, [_P, _P, _Z, _I, _I, _P, _P, _P, _P]),
+    "vadx_silero_segments": (_I, [_P, _I, _I, _P, C.POINTER(SileroSegParams), _P, _P, _I, _P]),
+    "vadx_test_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libvadx.so (built in-tree by `python -m vadx.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VadxError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the .so does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, exc=VadxError):
+    if rc != 0:
+        msg = lib().vadx_last_error().decode("utf-8", "replace")
+        raise (ValueError if rc == -1 else exc)(msg or f"libvadx error {rc}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise VadxError("no HIP device visible: the vadx product path runs only on an MI355X (no CPU fallback)")
+    return torch
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,89 @@
+// common.h -- shared device helpers for libvadx (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/vadx.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace vadx {
+
+void set_error(const char *fmt, ...);
+
+#define VADX_HIP_TRY(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            vadx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                            __LINE__);                                                       \
+            return VADX_EHIP;                                                                \
+        }                                                                                    \
+    } while (0)
+
+#define VADX_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            vadx::set_error(__VA_ARGS__);  \
+            return VADX_EINVAL;            \
+        }                                  \
+    } while (0)
+
+// v_mfma_f32_16x16x4_f32: exact f32 FMA chain (A: lane l holds A[l&15][l>>4], B: B[l>>4][l&15],
+// D: lane l reg r holds D[4*(l>>4)+r][l&15]).  32-cycle issue, 40-cycle dependent latency.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_pass: acc[nt][mt] += ACT x W^T over KB blocks of 16 k.
+//
+//   ACT lives in LDS "k-major": element (k, col) at act[k*lda + col]; for m-tile mt this lane's
+//       column is moff[mt] + (lane & 15).  lda % 8 == 4 makes the ds_read_b32 pattern below
+//       bank-conflict free (rows 4 apart land 16 banks apart).
+//   W   lives in global/L2, K contiguous: wrow[nt] points at THIS LANE's row (tile row lane&15),
+//       16-byte aligned.  Each lane pulls 16 B = 4 consecutive k per block, so the k consumed
+//       by (block S, sub-step j, lane quarter q) is 16*S + 4*q + j  -- a fixed permutation of
+//       the contraction index applied to both operands.
+//   SWAP=false: D rows = ACT columns (m), D cols = W rows (n)   -> next layer's k-major LDS
+//   SWAP=true : D rows = W rows (n),      D cols = ACT columns  -> e.g. gate-major LSTM input
+// Weights for block S+1 are requested before block S's MFMAs issue (L2 latency hiding).
+// ---------------------------------------------------------------------------------------------
+template <int NT, int MT, int KB, bool SWAP>
+__device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NT][MT], const float *act, int lda,
+                                          const int (&moff)[MT], const float *const (&wrow)[NT],
+                                          int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    const float *ap = act + (4 * q) * lda + i;
+    f32x4 wcur[NT], wnxt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 4 * q);
+#pragma unroll 2
+    for (int S = 0; S < KB; ++S) {
+        const int Sn = (S + 1 < KB) ? S + 1 : S;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
+        const float *aps = ap + 16 * S * lda;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = aps[j * lda + moff[mt]];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float wj = wcur[nt][j];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = SWAP ? mfma16(wj, av[mt], acc[nt][mt]) : mfma16(av[mt], wj, acc[nt][mt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wcur[nt] = wnxt[nt];
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace vadx

@@ -1,0 +1,636 @@
+// silero.hip -- Silero-VAD v5 (16 kHz) for gfx950: encoder tile kernel + persistent LSTM kernel +
+// device segmenter.  See DESIGN.md "Silero path" for the layout rationale.
+//
+// Work decomposition (B clips, T windows of 512 samples per clip):
+//   silero_encode_kernel : one workgroup per (16 clips) x (1 window).  Everything that does NOT
+//       depend on the recurrent state runs here as a chain of f32-MFMA GEMMs over LDS-resident
+//       activations (k-major), weights streamed from L2 straight into MFMA operand registers:
+//       STFT conv (258x256 basis, 4 frames) -> |.| -> conv1..conv4 (+ReLU) -> W_ih x + b.
+//       Output gx[T][B/16][wave][gate][lane][4] in exactly the register order the LSTM kernel reads.
+//   silero_lstm_kernel   : one persistent workgroup per 16 clips; W_hh (512x128 f32 = 256 KB) lives
+//       in the VGPRs of its 8 waves for all T steps; h is exchanged through double-buffered LDS.
+//   silero_segments_kernel: get_speech_timestamps' state machine, one clip per thread.
+#include "common.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace vadx {
+namespace silero {
+
+// ---- packed weight blob (float offsets) -------------------------------------------------------
+constexpr int OFF_STFT = 0;                        // [8 waves][re16|im16][256]  (bins 0..127)
+constexpr int OFF_NYQ = OFF_STFT + 256 * 256;      // [2][256]                   (bin 128 re, im)
+constexpr int C1_KP = 144;                         // 129 input channels padded to 9 blocks of 16
+constexpr int OFF_C1 = OFF_NYQ + 2 * 256;          // [128][3][144]
+constexpr int OFF_B1 = OFF_C1 + 128 * 3 * C1_KP;   // [128]
+constexpr int OFF_C2 = OFF_B1 + 128;               // [64][3][128]
+constexpr int OFF_B2 = OFF_C2 + 64 * 3 * 128;      // [64]
+constexpr int OFF_C3 = OFF_B2 + 64;                // [64][2][64]   taps 1,2 (tap 0 only sees padding)
+constexpr int OFF_B3 = OFF_C3 + 64 * 2 * 64;       // [64]
+constexpr int OFF_C4 = OFF_B3 + 64;                // [128][64]     tap 1 only
+constexpr int OFF_B4 = OFF_C4 + 128 * 64;          // [128]
+constexpr int OFF_IH = OFF_B4 + 128;               // [512][128]
+constexpr int OFF_BG = OFF_IH + 512 * 128;         // [512] b_ih + b_hh
+constexpr int OFF_HH = OFF_BG + 512;               // [512][128]
+constexpr int OFF_DW = OFF_HH + 512 * 128;         // [128]
+constexpr int OFF_DB = OFF_DW + 128;               // [1] (+3 pad)
+constexpr int PACKED_FLOATS = OFF_DB + 4;
+
+// ---- encoder LDS map (floats) -----------------------------------------------------------------
+constexpr int X_LD = 20;     // X  [640 positions][16 clips]      (+4 pad)
+constexpr int MG_LD = 100;   // Mg [144 ch][6 frame slots x 16]   (+4 pad) slot s <-> frame s-1
+constexpr int A1_LD = 84;    // A1 [128 ch][5 slots x 16]         (+4 pad) slot s <-> frame s-1
+constexpr int A2_LD = 36;    // A2 [64 ch][2 frames x 16]
+constexpr int A3_LD = 20;    // A3 [64 ch][16]
+constexpr int A4_LD = 20;    // A4 [128 ch][16]
+constexpr int R0_FLOATS = 640 * X_LD;              // X, later A1 (128*84 = 10752 <= 12800)
+constexpr int MG_FLOATS = 144 * MG_LD;
+constexpr int A2_FLOATS = 64 * A2_LD;
+constexpr int A3_FLOATS = 64 * A3_LD;
+constexpr int A4_FLOATS = 128 * A4_LD;
+constexpr int ENC_LDS_FLOATS = R0_FLOATS + MG_FLOATS + A2_FLOATS + A3_FLOATS + A4_FLOATS;
+constexpr int ENC_THREADS = 512;
+
+// gx: per (t, group) 8 waves x 4 gates x 64 lanes x 4 floats
+constexpr int GX_TILE_FLOATS = 8 * 4 * 256;
+
+__global__ __launch_bounds__(ENC_THREADS, 2) void silero_encode_kernel(
+    const float *__restrict__ P, const float *__restrict__ audio, long long n_samples,
+    long long row_stride, long long origin, int B, int G, int T, float *__restrict__ gx) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *X = lds;                 // phase 0-1
+    float *A1 = lds;                // phase 2-3 (aliases X)
+    float *Mg = lds + R0_FLOATS;
+    float *A2 = Mg + MG_FLOATS;
+    float *A3 = A2 + A2_FLOATS;
+    float *A4 = A3 + A3_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, i = lane & 15;
+    const int grp = blockIdx.x % G, t = blockIdx.x / G;
+
+    // ---------------- phase 0: stage the 16 windows (k-major: position x clip), zero conv pads
+    for (int e = tid; e < 15 * MG_LD; e += ENC_THREADS) Mg[129 * MG_LD + e] = 0.f;
+    for (int e = tid; e < 129 * 32; e += ENC_THREADS) {
+        const int r = e >> 5, c = e & 31;
+        Mg[r * MG_LD + (c < 16 ? c : 64 + c)] = 0.f;          // frame slots 0 and 5
+    }
+    {
+        const int c = tid & 15, pq = tid >> 4;
+        const long long b = (long long)grp * 16 + c;
+        const bool bvalid = b < B;
+        const float *src = audio + (bvalid ? b : 0) * row_stride;
+        const long long base = (long long)t * 512 + origin;
+        const bool vec_ok = ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(audio) & 15) == 0);
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int p = 4 * (pq + 32 * it);
+            if (p < 576) {
+                const long long idx = base + p;
+                float v[4];
+                if (bvalid && vec_ok && idx >= 0 && idx + 3 < n_samples) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4 *>(src + idx);
+                    v[0] = x4[0]; v[1] = x4[1]; v[2] = x4[2]; v[3] = x4[3];
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        v[jj] = (bvalid && idx + jj >= 0 && idx + jj < n_samples) ? src[idx + jj] : 0.f;
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int pp = p + jj;
+                    X[pp * X_LD + c] = v[jj];
+                    if (pp >= 511 && pp <= 574) X[(1150 - pp) * X_LD + c] = v[jj];   // reflect pad (0,64)
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 1: STFT conv (bins 0..127 on MFMA, bin 128 on VALU) -> magnitude
+    {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *const wrow[2] = {P + OFF_STFT + (wave * 32 + i) * 256,
+                                      P + OFF_STFT + (wave * 32 + 16 + i) * 256};
+        const int moff[4] = {0, 128 * X_LD, 256 * X_LD, 384 * X_LD};
+        gemm_pass<2, 4, 16, false>(acc, X, X_LD, moff, wrow, lane);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            f32x4 m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = sqrtf(acc[0][f][r] * acc[0][f][r] + acc[1][f][r] * acc[1][f][r]);
+            *reinterpret_cast<f32x4 *>(&Mg[(wave * 16 + i) * MG_LD + (f + 1) * 16 + 4 * q]) = m;
+        }
+        if (wave < 4) {   // Nyquist bin: frame f = wave, lane = (clip i, k-quarter q)
+            const int f = wave;
+            const float *nre = P + OFF_NYQ + q * 64, *nim = P + OFF_NYQ + 256 + q * 64;
+            const float *xp = X + (128 * f + q * 64) * X_LD + i;
+            float sre = 0.f, sim = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) {
+                const float x = xp[k * X_LD];
+                sre = fmaf(x, nre[k], sre);
+                sim = fmaf(x, nim[k], sim);
+            }
+            sre += __shfl_xor(sre, 16); sre += __shfl_xor(sre, 32);
+            sim += __shfl_xor(sim, 16); sim += __shfl_xor(sim, 32);
+            if (q == 0) Mg[128 * MG_LD + (f + 1) * 16 + i] = sqrtf(sre * sre + sim * sim);
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU  (out frames 0..3 -> A1 slots 1..4)
+    {
+        for (int e = tid; e < 128 * 16; e += ENC_THREADS) A1[(e >> 4) * A1_LD + (e & 15)] = 0.f;   // slot 0
+        f32x4 acc[1][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[0][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const float *const wrow[1] = {P + OFF_C1 + ((wave * 16 + i) * 3 + kk) * C1_KP};
+            const int moff[4] = {(0 + kk) * 16, (1 + kk) * 16, (2 + kk) * 16, (3 + kk) * 16};
+            gemm_pass<1, 4, 9, false>(acc, Mg, MG_LD, moff, wrow, lane);
+        }
+        const float bias = P[OFF_B1 + wave * 16 + i];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[0][f][r] + bias, 0.f);
+            *reinterpret_cast<f32x4 *>(&A1[(wave * 16 + i) * A1_LD + (f + 1) * 16 + 4 * q]) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 3: conv2 128->64, k3 s2 p1, ReLU (out frames 0,1)
+    {
+        const int nt = wave & 3, fp = wave >> 2;
+        f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const float *const wrow[1] = {P + OFF_C2 + ((nt * 16 + i) * 3 + kk) * 128};
+            const int moff[1] = {(2 * fp + kk) * 16};
+            gemm_pass<1, 1, 8, false>(acc, A1, A1_LD, moff, wrow, lane);
+        }
+        const float bias = P[OFF_B2 + nt * 16 + i];
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[0][0][r] + bias, 0.f);
+        *reinterpret_cast<f32x4 *>(&A2[(nt * 16 + i) * A2_LD + fp * 16 + 4 * q]) = v;
+    }
+    __syncthreads();
+
+    // ---------------- phase 4: conv3 64->64, k3 s2 p1, ReLU (1 out frame; tap 0 reads padding)
+    if (wave < 4) {
+        f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const float *const wrow[1] = {P + OFF_C3 + ((wave * 16 + i) * 2 + ps) * 64};
+            const int moff[1] = {ps * 16};
+            gemm_pass<1, 1, 4, false>(acc, A2, A2_LD, moff, wrow, lane);
+        }
+        const float bias = P[OFF_B3 + wave * 16 + i];
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[0][0][r] + bias, 0.f);
+        *reinterpret_cast<f32x4 *>(&A3[(wave * 16 + i) * A3_LD + 4 * q]) = v;
+    }
+    __syncthreads();
+
+    // ---------------- phase 5: conv4 64->128, k3 s1 p1, ReLU (1 frame in/out; centre tap only)
+    {
+        f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+        const float *const wrow[1] = {P + OFF_C4 + (wave * 16 + i) * 64};
+        const int moff[1] = {0};
+        gemm_pass<1, 1, 4, false>(acc, A3, A3_LD, moff, wrow, lane);
+        const float bias = P[OFF_B4 + wave * 16 + i];
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[0][0][r] + bias, 0.f);
+        *reinterpret_cast<f32x4 *>(&A4[(wave * 16 + i) * A4_LD + 4 * q]) = v;
+    }
+    __syncthreads();
+
+    // ---------------- phase 6: LSTM input projection, gate-major (D rows = hidden units)
+    {
+        f32x4 acc[4][1];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            acc[g][0] = *reinterpret_cast<const f32x4 *>(P + OFF_BG + g * 128 + wave * 16 + 4 * q);
+        const float *const wrow[4] = {P + OFF_IH + (0 * 128 + wave * 16 + i) * 128,
+                                      P + OFF_IH + (1 * 128 + wave * 16 + i) * 128,
+                                      P + OFF_IH + (2 * 128 + wave * 16 + i) * 128,
+                                      P + OFF_IH + (3 * 128 + wave * 16 + i) * 128};
+        const int moff[1] = {0};
+        gemm_pass<4, 1, 8, true>(acc, A4, A4_LD, moff, wrow, lane);
+        float *dst = gx + ((size_t)t * G + grp) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = acc[g][0];
+    }
+}
+
+// ---- persistent LSTM --------------------------------------------------------------------------
+constexpr int HS_LD = 136;                       // h [16 clips][128] (+8 pad: conflict-free b128)
+constexpr int LSTM_LDS_FLOATS = 2 * 16 * HS_LD + 2 * 8 * 16;
+constexpr int LSTM_THREADS = 512;
+
+__global__ __launch_bounds__(LSTM_THREADS, 2) void silero_lstm_kernel(
+    const float *__restrict__ P, const float *__restrict__ gx, const float *__restrict__ state0,
+    int B, int G, int T, float *__restrict__ probs, long long probs_stride,
+    float *__restrict__ state_n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Hs = lds;                              // [2][16][HS_LD]
+    float *part = lds + 2 * 16 * HS_LD;           // [2][8][16]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int grp = blockIdx.x;
+    const long long b = (long long)grp * 16 + n;
+    const bool bvalid = b < B;
+    const int u0 = wave * 16 + 4 * q;             // this lane's 4 hidden units
+
+    // W_hh rows of this wave's 4 gate tiles, resident for the whole clip: 128 VGPRs
+    float a[4][32];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float *row = P + OFF_HH + (g * 128 + wave * 16 + n) * 128 + 4 * q;
+#pragma unroll
+        for (int S = 0; S < 8; ++S) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(row + 16 * S);
+            a[g][4 * S + 0] = w4[0]; a[g][4 * S + 1] = w4[1]; a[g][4 * S + 2] = w4[2]; a[g][4 * S + 3] = w4[3];
+        }
+    }
+    f32x4 dw = *reinterpret_cast<const f32x4 *>(P + OFF_DW + u0);
+    const float db = P[OFF_DB];
+
+    f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
+    if (state0 != nullptr && bvalid) {
+        h = *reinterpret_cast<const f32x4 *>(state0 + b * 128 + u0);
+        c = *reinterpret_cast<const f32x4 *>(state0 + ((long long)B + b) * 128 + u0);
+    }
+    *reinterpret_cast<f32x4 *>(&Hs[n * HS_LD + u0]) = h;
+    __syncthreads();
+
+    const float *gsrc = gx + (size_t)grp * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
+    const size_t gstep = (size_t)G * GX_TILE_FLOATS;
+    f32x4 gcur[4], gnxt[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gcur[g] = *reinterpret_cast<const f32x4 *>(gsrc + g * 256);
+
+    int cur = 0;
+    for (int t = 0; t < T; ++t) {
+        const int tn = (t + 1 < T) ? t + 1 : t;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gnxt[g] = *reinterpret_cast<const f32x4 *>(gsrc + tn * gstep + g * 256);
+
+        f32x4 acc[4] = {gcur[0], gcur[1], gcur[2], gcur[3]};
+        const float *hb = Hs + cur * 16 * HS_LD + n * HS_LD + 4 * q;
+#pragma unroll
+        for (int S = 0; S < 8; ++S) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(hb + 16 * S);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[g][4 * S + j], b4[j], acc[g]);
+        }
+        float dpart = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
+            const float gg = tanhf(acc[2][r]), og = sigmoidf_(acc[3][r]);
+            c[r] = fg * c[r] + ig * gg;
+            h[r] = og * tanhf(c[r]);
+            dpart = fmaf(dw[r], fmaxf(h[r], 0.f), dpart);
+        }
+        const int nxt = cur ^ 1;
+        *reinterpret_cast<f32x4 *>(&Hs[nxt * 16 * HS_LD + n * HS_LD + u0]) = h;
+        dpart += __shfl_xor(dpart, 16);
+        dpart += __shfl_xor(dpart, 32);
+        if (q == 0) part[(nxt * 8 + wave) * 16 + n] = dpart;
+        __syncthreads();
+        if (wave == 0 && lane < 16 && bvalid) {
+            float s = db;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += part[(nxt * 8 + w) * 16 + lane];
+            probs[b * probs_stride + t] = sigmoidf_(s);
+        }
+        cur = nxt;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gcur[g] = gnxt[g];
+    }
+    if (state_n != nullptr && bvalid) {
+        *reinterpret_cast<f32x4 *>(state_n + b * 128 + u0) = h;
+        *reinterpret_cast<f32x4 *>(state_n + ((long long)B + b) * 128 + u0) = c;
+    }
+}
+
+// ---- segmenter: get_speech_timestamps' state machine (utils_vad.py:374-476), one clip/thread ----
+__global__ void silero_segments_kernel(const float *__restrict__ probs, int B, int T,
+                                       const long long *__restrict__ n_samples,
+                                       vadx_silero_seg_params prm, long long *__restrict__ segs,
+                                       int *__restrict__ counts, int cap) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double sr = (double)prm.sampling_rate;
+    const long long W = (prm.sampling_rate == 16000) ? 512 : 256;
+    const double thr = prm.threshold;
+    const double neg = (prm.neg_threshold < 0.0) ? fmax(thr - 0.15, 0.01) : prm.neg_threshold;
+    const double min_speech = sr * prm.min_speech_duration_ms / 1000.0;
+    const double pad = sr * prm.speech_pad_ms / 1000.0;
+    const double max_speech = sr * prm.max_speech_duration_s - (double)W - 2.0 * pad;
+    const double min_sil = sr * prm.min_silence_duration_ms / 1000.0;
+    const double min_sil_at_max = sr * prm.min_silence_at_max_speech / 1000.0;
+    const long long L = n_samples[b];
+    const int nwin = (int)((L + W - 1) / W) < T ? (int)((L + W - 1) / W) : T;
+    long long *out = segs + (size_t)b * cap * 2;
+    int ns = 0;
+    auto push = [&](long long s, long long e) {
+        if (ns < cap) { out[2 * ns] = s; out[2 * ns + 1] = e; }
+        ++ns;
+    };
+
+    bool triggered = false, have_cur = false, have_possible = false;
+    long long cur_start = 0, temp_end = 0, prev_end = 0, next_start = 0;
+    long long best_end = 0, best_dur = 0;
+    const float *pr = probs + (size_t)b * T;
+    for (int k = 0; k < nwin; ++k) {
+        const double p = (double)pr[k];
+        const long long pos = W * k;
+        if (p >= thr && temp_end) {
+            const long long gap = pos - temp_end;
+            if ((double)gap > min_sil_at_max) {
+                if (!have_possible || gap > best_dur) { best_end = temp_end; best_dur = gap; }
+                have_possible = true;
+            }
+            temp_end = 0;
+            if (next_start < prev_end) next_start = pos;
+        }
+        if (p >= thr && !triggered) {
+            triggered = true; cur_start = pos; have_cur = true;
+            continue;
+        }
+        if (triggered && (double)(pos - cur_start) > max_speech) {
+            if (prm.use_max_poss_sil_at_max_speech && have_possible) {
+                prev_end = best_end;
+                push(cur_start, prev_end);
+                have_cur = false;
+                next_start = prev_end + best_dur;
+                if (next_start < prev_end + pos) { cur_start = next_start; have_cur = true; }
+                else triggered = false;
+                prev_end = next_start = temp_end = 0;
+                have_possible = false;
+            } else if (prev_end) {
+                push(cur_start, prev_end);
+                have_cur = false;
+                if (next_start < prev_end) triggered = false;
+                else { cur_start = next_start; have_cur = true; }
+                prev_end = next_start = temp_end = 0;
+                have_possible = false;
+            } else {
+                push(cur_start, pos);
+                have_cur = false;
+                prev_end = next_start = temp_end = 0;
+                triggered = false;
+                have_possible = false;
+                continue;
+            }
+        }
+        if (p < neg && triggered) {
+            if (!temp_end) temp_end = pos;
+            const long long sil_now = pos - temp_end;
+            if (!prm.use_max_poss_sil_at_max_speech && (double)sil_now > min_sil_at_max) prev_end = temp_end;
+            if ((double)sil_now < min_sil) continue;
+            if ((double)(temp_end - cur_start) > min_speech) push(cur_start, temp_end);
+            have_cur = false;
+            prev_end = next_start = temp_end = 0;
+            triggered = false;
+            have_possible = false;
+            continue;
+        }
+    }
+    if (have_cur && (double)(L - cur_start) > min_speech) push(cur_start, L);
+
+    // +-speech_pad with midpoint split of short gaps (utils_vad.py:464-476)
+    const int m = ns < cap ? ns : cap;
+    for (int s = 0; s < m; ++s) {
+        if (s == 0) out[0] = (long long)fmax(0.0, (double)out[0] - pad);
+        if (s != m - 1) {
+            const long long gap = out[2 * (s + 1)] - out[2 * s + 1];
+            if ((double)gap < 2.0 * pad) {
+                const long long half = gap >= 0 ? gap / 2 : -((-gap + 1) / 2);   // Python floor //
+                out[2 * s + 1] += half;
+                const long long ns0 = out[2 * (s + 1)] - half;
+                out[2 * (s + 1)] = ns0 > 0 ? ns0 : 0;
+            } else {
+                out[2 * s + 1] = (long long)fmin((double)L, (double)out[2 * s + 1] + pad);
+                out[2 * (s + 1)] = (long long)fmax(0.0, (double)out[2 * (s + 1)] - pad);
+            }
+        } else {
+            out[2 * s + 1] = (long long)fmin((double)L, (double)out[2 * s + 1] + pad);
+        }
+    }
+    counts[b] = ns;
+}
+
+// ---- test hook: C = A * W^T through gemm_pass ---------------------------------------------------
+__global__ void test_gemm_kernel(const float *A, const float *W, float *C, int M, int N, int K, int swap) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lda = M + 4;                        // M in {16,32,48,64}: (M+4) % 8 == 4
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int e = tid; e < M * K; e += blockDim.x) {
+        const int m = e / K, k = e % K;
+        lds[k * lda + m] = A[e];
+    }
+    __syncthreads();
+    const int q = lane >> 4, i = lane & 15;
+    for (int nt = wave; nt < N / 16; nt += nw) {
+        for (int mt = 0; mt < M / 16; ++mt) {
+            f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+            const float *const wrow[1] = {W + (size_t)(nt * 16 + i) * K};
+            const int moff[1] = {mt * 16};
+            for (int kb = 0; kb < K / 16; ++kb) {
+                const float *const wr[1] = {wrow[0] + kb * 16};
+                if (swap) gemm_pass<1, 1, 1, true>(acc, lds + kb * 16 * lda, lda, moff, wr, lane);
+                else gemm_pass<1, 1, 1, false>(acc, lds + kb * 16 * lda, lda, moff, wr, lane);
+            }
+            for (int r = 0; r < 4; ++r) {
+                if (swap) C[(size_t)(mt * 16 + i) * N + nt * 16 + 4 * q + r] = acc[0][0][r];
+                else C[(size_t)(mt * 16 + 4 * q + r) * N + nt * 16 + i] = acc[0][0][r];
+            }
+        }
+    }
+}
+
+}  // namespace silero
+}  // namespace vadx
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace vadx::silero;
+
+extern "C" size_t vadx_silero_packed_floats(void) { return (size_t)PACKED_FLOATS; }
+
+extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p) {
+    VADX_REQUIRE(w && p, "vadx_silero_pack_host: NULL argument");
+    VADX_REQUIRE(w->stft_basis && w->lstm_w_ih && w->lstm_w_hh && w->lstm_b_ih && w->lstm_b_hh && w->dec_w && w->dec_b,
+                 "vadx_silero_pack_host: NULL weight pointer");
+    for (int k = 0; k < 4; ++k) VADX_REQUIRE(w->enc_w[k] && w->enc_b[k], "vadx_silero_pack_host: NULL encoder weight %d", k);
+    memset(p, 0, sizeof(float) * PACKED_FLOATS);
+    // STFT basis rows regrouped per wave: [wave][re 16 bins | im 16 bins][256]
+    for (int wv = 0; wv < 8; ++wv)
+        for (int part = 0; part < 2; ++part)
+            for (int i = 0; i < 16; ++i)
+                memcpy(p + OFF_STFT + (size_t)(wv * 32 + part * 16 + i) * 256,
+                       w->stft_basis + (size_t)(part * 129 + wv * 16 + i) * 256, 256 * sizeof(float));
+    memcpy(p + OFF_NYQ, w->stft_basis + (size_t)128 * 256, 256 * sizeof(float));
+    memcpy(p + OFF_NYQ + 256, w->stft_basis + (size_t)257 * 256, 256 * sizeof(float));
+    for (int co = 0; co < 128; ++co)
+        for (int kk = 0; kk < 3; ++kk)
+            for (int ci = 0; ci < 129; ++ci)
+                p[OFF_C1 + ((size_t)co * 3 + kk) * C1_KP + ci] = w->enc_w[0][((size_t)co * 129 + ci) * 3 + kk];
+    memcpy(p + OFF_B1, w->enc_b[0], 128 * sizeof(float));
+    for (int co = 0; co < 64; ++co)
+        for (int kk = 0; kk < 3; ++kk)
+            for (int ci = 0; ci < 128; ++ci)
+                p[OFF_C2 + ((size_t)co * 3 + kk) * 128 + ci] = w->enc_w[1][((size_t)co * 128 + ci) * 3 + kk];
+    memcpy(p + OFF_B2, w->enc_b[1], 64 * sizeof(float));
+    for (int co = 0; co < 64; ++co)
+        for (int ps = 0; ps < 2; ++ps)
+            for (int ci = 0; ci < 64; ++ci)
+                p[OFF_C3 + ((size_t)co * 2 + ps) * 64 + ci] = w->enc_w[2][((size_t)co * 64 + ci) * 3 + (ps + 1)];
+    memcpy(p + OFF_B3, w->enc_b[2], 64 * sizeof(float));
+    for (int co = 0; co < 128; ++co)
+        for (int ci = 0; ci < 64; ++ci) p[OFF_C4 + (size_t)co * 64 + ci] = w->enc_w[3][((size_t)co * 64 + ci) * 3 + 1];
+    memcpy(p + OFF_B4, w->enc_b[3], 128 * sizeof(float));
+    memcpy(p + OFF_IH, w->lstm_w_ih, 512 * 128 * sizeof(float));
+    for (int r = 0; r < 512; ++r) p[OFF_BG + r] = w->lstm_b_ih[r] + w->lstm_b_hh[r];
+    memcpy(p + OFF_HH, w->lstm_w_hh, 512 * 128 * sizeof(float));
+    memcpy(p + OFF_DW, w->dec_w, 128 * sizeof(float));
+    p[OFF_DB] = w->dec_b[0];
+    return VADX_OK;
+}
+
+extern "C" size_t vadx_silero_workspace_bytes(int batch, int steps) {
+    if (batch <= 0 || steps <= 0) return 0;
+    const size_t G = ((size_t)batch + 15) / 16;
+    return G * (size_t)steps * GX_TILE_FLOATS * sizeof(float);
+}
+
+static int silero_encode_launch(const float *packed, const float *src, long long n_valid, long long row_stride,
+                                long long origin, int batch, int steps, void *ws, size_t ws_bytes, void *stream) {
+    VADX_REQUIRE(packed && src && ws, "silero: NULL pointer argument");
+    VADX_REQUIRE(batch > 0 && steps > 0, "silero: batch=%d steps=%d must be positive", batch, steps);
+    VADX_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+                 "silero: packed weights and workspace must be 16-byte aligned");
+    if (ws_bytes < vadx_silero_workspace_bytes(batch, steps)) {
+        vadx::set_error("silero: workspace %zu B < required %zu B", ws_bytes, vadx_silero_workspace_bytes(batch, steps));
+        return VADX_ENOSPACE;
+    }
+    const int G = (batch + 15) / 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(silero_encode_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_FLOATS * sizeof(float)));
+        attr_done = true;
+    }
+    const long long nblk = (long long)G * steps;
+    VADX_REQUIRE(nblk < (1LL << 31), "silero: too many tiles (%lld)", nblk);
+    hipLaunchKernelGGL(silero_encode_kernel, dim3((unsigned)nblk), dim3(ENC_THREADS), ENC_LDS_FLOATS * sizeof(float),
+                       static_cast<hipStream_t>(stream), packed, src, n_valid, row_stride, origin, batch, G, steps,
+                       static_cast<float *>(ws));
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+static int silero_recur_launch(const float *packed, const void *ws, size_t ws_bytes, int batch, int steps,
+                               const float *state0, float *probs, long long probs_stride, float *state_n, void *stream) {
+    VADX_REQUIRE(packed && ws && probs, "silero: NULL pointer argument");
+    VADX_REQUIRE(batch > 0 && steps > 0, "silero: batch=%d steps=%d must be positive", batch, steps);
+    if (ws_bytes < vadx_silero_workspace_bytes(batch, steps)) {
+        vadx::set_error("silero: workspace %zu B < required %zu B", ws_bytes, vadx_silero_workspace_bytes(batch, steps));
+        return VADX_ENOSPACE;
+    }
+    const int G = (batch + 15) / 16;
+    hipLaunchKernelGGL(silero_lstm_kernel, dim3(G), dim3(LSTM_THREADS), LSTM_LDS_FLOATS * sizeof(float),
+                       static_cast<hipStream_t>(stream), packed, static_cast<const float *>(ws), state0, batch, G, steps,
+                       probs, probs_stride, state_n);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+static int silero_run(const float *packed, const float *src, long long n_valid, long long row_stride,
+                      long long origin, int batch, int steps, const float *state0, float *probs,
+                      long long probs_stride, float *state_n, void *ws, size_t ws_bytes, void *stream) {
+    int rc = silero_encode_launch(packed, src, n_valid, row_stride, origin, batch, steps, ws, ws_bytes, stream);
+    if (rc != VADX_OK) return rc;
+    return silero_recur_launch(packed, ws, ws_bytes, batch, steps, state0, probs, probs_stride, state_n, stream);
+}
+
+extern "C" int vadx_silero_encode(const float *packed, const float *audio, int batch, int64_t n_samples,
+                                  int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream) {
+    VADX_REQUIRE(n_samples > 0 && row_stride >= n_samples, "vadx_silero_encode: n_samples=%lld row_stride=%lld",
+                 (long long)n_samples, (long long)row_stride);
+    const long long steps = (n_samples + 511) / 512;
+    VADX_REQUIRE(steps < (1LL << 30), "vadx_silero_encode: clip too long");
+    return silero_encode_launch(packed, audio, n_samples, row_stride, -64, batch, (int)steps, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vadx_silero_recur(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
+                                 int steps, const float *state0, float *probs, float *state_n, void *stream) {
+    return silero_recur_launch(packed, workspace, workspace_bytes, batch, steps, state0, probs, steps, state_n, stream);
+}
+
+extern "C" int vadx_silero_step(const float *packed, const float *input, const float *state, int64_t sr,
+                                int batch, float *out, float *state_n, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    VADX_REQUIRE(sr == 16000, "Supported sampling rates: [16000] (got %lld)", (long long)sr);
+    VADX_REQUIRE(state && state_n, "vadx_silero_step: state / state_n must not be NULL");
+    return silero_run(packed, input, 576, 576, 0, batch, 1, state, out, 1, state_n, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vadx_silero_clips(const float *packed, const float *audio, int batch, int64_t n_samples,
+                                 int64_t row_stride, float *probs, float *state_n, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    VADX_REQUIRE(n_samples > 0 && row_stride >= n_samples, "vadx_silero_clips: n_samples=%lld row_stride=%lld",
+                 (long long)n_samples, (long long)row_stride);
+    const long long steps = (n_samples + 511) / 512;
+    VADX_REQUIRE(steps < (1LL << 30), "vadx_silero_clips: clip too long");
+    return silero_run(packed, audio, n_samples, row_stride, -64, batch, (int)steps, nullptr, probs, steps,
+                      state_n, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vadx_silero_segments(const float *probs, int batch, int steps, const int64_t *n_samples,
+                                    const vadx_silero_seg_params *params, int64_t *segments,
+                                    int32_t *counts, int cap, void *stream) {
+    VADX_REQUIRE(probs && n_samples && params && segments && counts, "vadx_silero_segments: NULL pointer argument");
+    VADX_REQUIRE(batch > 0 && steps > 0 && cap > 0, "vadx_silero_segments: batch/steps/cap must be positive");
+    VADX_REQUIRE(params->sampling_rate == 16000 || params->sampling_rate == 8000,
+                 "Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates");
+    hipLaunchKernelGGL(silero_segments_kernel, dim3((batch + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       probs, batch, steps, reinterpret_cast<const long long *>(n_samples), *params,
+                       reinterpret_cast<long long *>(segments), counts, cap);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+extern "C" int vadx_test_gemm(const float *a, const float *w, float *c, int m, int n, int k, int swap, void *stream) {
+    VADX_REQUIRE(a && w && c, "vadx_test_gemm: NULL pointer");
+    VADX_REQUIRE(m > 0 && m <= 64 && m % 16 == 0 && n > 0 && n % 16 == 0 && k > 0 && k % 16 == 0 && (size_t)(m + 4) * k * 4 <= 160 * 1024,
+                 "vadx_test_gemm: unsupported shape %dx%dx%d", m, n, k);
+    const size_t lds = (size_t)(m + 4) * k * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(test_gemm_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(test_gemm_kernel, dim3(1), dim3(256), lds, static_cast<hipStream_t>(stream), a, w, c, m, n, k, swap);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}

@@ -1,0 +1,353 @@
+"""Silero-VAD on MI355X: drop-in for the reference's Silero boundary objects.
+
+Mirrors (same names / arguments / error behaviour):
+  * `OnnxWrapper`            -- Silero/modeling_modified/utils_vad.py:10-146
+  * `load_silero_vad`        -- Silero/modeling_modified/model.py:9-41
+  * `get_speech_timestamps`  -- Silero/modeling_modified/utils_vad.py:248-491
+plus the batched entry points the reference does not have (`SileroEngine.clips`,
+`get_speech_timestamps_batch`).  All arithmetic runs in libvadx.so (HIP, gfx950); this file is
+plumbing: tensors in, C-ABI call, tensors out.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib
+from . import weights as _weights
+
+CONTEXT_SIZE = 64
+NUM_SAMPLES = 512
+HIDDEN = 128
+
+
+def _as_weight_dict(path_or_weights):
+    if isinstance(path_or_weights, dict):
+        w = path_or_weights
+    elif path_or_weights is None or path_or_weights == "" or str(path_or_weights).startswith("synthetic"):
+        seed = 1234
+        s = str(path_or_weights or "")
+        if ":" in s:
+            seed = int(s.split(":", 1)[1])
+        w = _weights.silero_synthetic(seed)
+    else:
+        with np.load(str(path_or_weights)) as z:      # .npz with the keys of weights.silero_synthetic()
+            w = {k: z[k] for k in z.files}
+    w = {k: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in w.items()}
+    _weights.silero_check(w)
+    return w
+
+
+class SileroEngine:
+    """Device-resident packed weights + workspace; thin wrappers over the C ABI."""
+
+    def __init__(self, path_or_weights=None, device="cuda:0"):
+        torch = _lib.require_gpu()
+        self.torch = torch
+        self.device = torch.device(device)
+        L = _lib.lib()
+        w = _as_weight_dict(path_or_weights)
+        hw = _lib.SileroWeightsHost()
+        keep = []
+
+        def ptr(a):
+            keep.append(a)
+            return a.ctypes.data_as(C.c_void_p)
+
+        hw.stft_basis = ptr(w["stft_basis"])
+        for i in range(4):
+            hw.enc_w[i] = ptr(w[f"enc{i}_w"]).value
+            hw.enc_b[i] = ptr(w[f"enc{i}_b"]).value
+        hw.lstm_w_ih, hw.lstm_w_hh = ptr(w["lstm_w_ih"]), ptr(w["lstm_w_hh"])
+        hw.lstm_b_ih, hw.lstm_b_hh = ptr(w["lstm_b_ih"]), ptr(w["lstm_b_hh"])
+        hw.dec_w, hw.dec_b = ptr(w["dec_w"]), ptr(w["dec_b"])
+        packed = np.zeros(L.vadx_silero_packed_floats(), dtype=np.float32)
+        _lib.check(L.vadx_silero_pack_host(C.byref(hw), packed.ctypes.data_as(C.c_void_p)))
+        self.packed = torch.from_numpy(packed).to(self.device)
+        self._ws = None
+
+    # -- scratch (gx tiles) grows on demand and is reused
+    def _workspace(self, batch, steps):
+        need = _lib.lib().vadx_silero_workspace_bytes(int(batch), int(steps))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+        return self._ws
+
+    def _dev_f32(self, x):
+        t = self.torch
+        if not t.is_tensor(x):
+            x = t.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        return x.to(device=self.device, dtype=t.float32).contiguous()
+
+    def step(self, x, state):
+        """session.run equivalent: x [B,576], state [2,B,128] -> (out [B,1], stateN [2,B,128]) on device."""
+        t = self.torch
+        x = self._dev_f32(x)
+        state = self._dev_f32(state)
+        if x.dim() != 2 or x.shape[1] != CONTEXT_SIZE + NUM_SAMPLES:
+            raise ValueError(f"input must be [B,{CONTEXT_SIZE + NUM_SAMPLES}], got {tuple(x.shape)}")
+        B = x.shape[0]
+        if tuple(state.shape) != (2, B, HIDDEN):
+            raise ValueError(f"state must be [2,{B},{HIDDEN}], got {tuple(state.shape)}")
+        out = t.empty((B, 1), dtype=t.float32, device=self.device)
+        state_n = t.empty_like(state)
+        ws = self._workspace(B, 1)
+        with t.cuda.device(self.device):
+            _lib.check(_lib.lib().vadx_silero_step(self.packed.data_ptr(), x.data_ptr(), state.data_ptr(), 16000, B,
+                                                   out.data_ptr(), state_n.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   _lib.stream_ptr()))
+        return out, state_n
+
+    def clips(self, audio, n_samples=None, return_state=False):
+        """audio f32 [B,N] (+-1 scale) -> probs [B, ceil(n/512)] on device (zero state/context at t=0)."""
+        t = self.torch
+        audio = self._dev_f32(audio)
+        if audio.dim() == 1:
+            audio = audio.unsqueeze(0)
+        if audio.dim() != 2:
+            raise ValueError(f"Too many dimensions for input audio {audio.dim()}")
+        B, N = audio.shape
+        n = int(N if n_samples is None else n_samples)
+        if n <= 0 or n > N:
+            raise ValueError(f"n_samples={n} outside (0,{N}]")
+        steps = (n + NUM_SAMPLES - 1) // NUM_SAMPLES
+        probs = t.empty((B, steps), dtype=t.float32, device=self.device)
+        state_n = t.empty((2, B, HIDDEN), dtype=t.float32, device=self.device) if return_state else None
+        ws = self._workspace(B, steps)
+        with t.cuda.device(self.device):
+            _lib.check(_lib.lib().vadx_silero_clips(self.packed.data_ptr(), audio.data_ptr(), B, n, audio.stride(0),
+                                                    probs.data_ptr(), None if state_n is None else state_n.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        return (probs, state_n) if return_state else probs
+
+    def encode(self, audio, n_samples=None):
+        """First half of `clips` as its own launch (fills the workspace); returns (batch, steps)."""
+        t = self.torch
+        B, N = audio.shape
+        n = int(N if n_samples is None else n_samples)
+        steps = (n + NUM_SAMPLES - 1) // NUM_SAMPLES
+        ws = self._workspace(B, steps)
+        with t.cuda.device(self.device):
+            _lib.check(_lib.lib().vadx_silero_encode(self.packed.data_ptr(), audio.data_ptr(), B, n, audio.stride(0),
+                                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        return B, steps
+
+    def recur(self, batch, steps, probs):
+        """Second half of `clips`: workspace -> probs [B,steps] (zero initial state)."""
+        t = self.torch
+        ws = self._workspace(batch, steps)
+        with t.cuda.device(self.device):
+            _lib.check(_lib.lib().vadx_silero_recur(self.packed.data_ptr(), ws.data_ptr(), ws.numel(), batch, steps,
+                                                    None, probs.data_ptr(), None, _lib.stream_ptr()))
+        return probs
+
+    def segments(self, probs, n_samples, cap=64, **kw):
+        """Device segmenter: probs [B,T] -> (int64 [B,cap,2] sample indices, int32 [B] counts)."""
+        t = self.torch
+        probs = self._dev_f32(probs)
+        B, T = probs.shape
+        lens = t.as_tensor(np.broadcast_to(np.asarray(n_samples, dtype=np.int64), (B,)).copy(), device=self.device)
+        prm = seg_params(**kw)
+        while True:
+            segs = t.empty((B, cap, 2), dtype=t.int64, device=self.device)
+            counts = t.empty((B,), dtype=t.int32, device=self.device)
+            with t.cuda.device(self.device):
+                _lib.check(_lib.lib().vadx_silero_segments(probs.data_ptr(), B, T, lens.data_ptr(), C.byref(prm),
+                                                           segs.data_ptr(), counts.data_ptr(), cap, _lib.stream_ptr()))
+            worst = int(counts.max().item())
+            if worst <= cap:
+                return segs, counts
+            cap = worst          # rare: a clip produced more segments than the table holds -> rerun
+
+
+def seg_params(threshold=0.5, sampling_rate=16000, min_speech_duration_ms=250,
+               max_speech_duration_s=float("inf"), min_silence_duration_ms=100, speech_pad_ms=30,
+               neg_threshold=None, min_silence_at_max_speech=98, use_max_poss_sil_at_max_speech=True, **_ignored):
+    p = _lib.SileroSegParams()
+    p.threshold = float(threshold)
+    p.neg_threshold = -1.0 if neg_threshold is None else float(neg_threshold)
+    p.sampling_rate = int(sampling_rate)
+    p.min_speech_duration_ms = float(min_speech_duration_ms)
+    p.max_speech_duration_s = float(max_speech_duration_s)
+    p.min_silence_duration_ms = float(min_silence_duration_ms)
+    p.speech_pad_ms = float(speech_pad_ms)
+    p.min_silence_at_max_speech = float(min_silence_at_max_speech)
+    p.use_max_poss_sil_at_max_speech = 1 if use_max_poss_sil_at_max_speech else 0
+    return p
+
+
+class OnnxWrapper:
+    """Stateful per-window model object with the reference wrapper's interface; `path` may be a
+    weight dict, an .npz of the same keys, or 'synthetic[:seed]'."""
+
+    def __init__(self, path=None, force_onnx_cpu=True, device="cuda:0"):
+        self.engine = path if isinstance(path, SileroEngine) else SileroEngine(path, device)
+        self.torch = self.engine.torch
+        self.reset_states()
+        if isinstance(path, str) and "16k" in path:
+            warnings.warn("This model support only 16000 sampling rate!")
+        self.sample_rates = [16000]      # the 8 kHz branch of the upstream graph is not built
+
+    def _validate_input(self, x, sr: int):
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        if x.dim() > 2:
+            raise ValueError(f"Too many dimensions for input audio chunk {x.dim()}")
+        if sr != 16000 and (sr % 16000 == 0):
+            x = x[:, ::sr // 16000]
+            sr = 16000
+        if sr not in self.sample_rates:
+            raise ValueError(f"Supported sampling rates: {self.sample_rates} (or multiply of 16000)")
+        if sr / x.shape[1] > 31.25:
+            raise ValueError("Input audio chunk is too short")
+        return x, sr
+
+    def reset_states(self, batch_size=1):
+        t = self.torch
+        self._state = t.zeros((2, batch_size, HIDDEN), dtype=t.float32, device=self.engine.device)
+        self._context = t.zeros(0)
+        self._last_sr = 0
+        self._last_batch_size = 0
+
+    def __call__(self, x, sr: int):
+        t = self.torch
+        if not t.is_tensor(x):
+            x = t.as_tensor(np.asarray(x, dtype=np.float32))
+        x, sr = self._validate_input(x, sr)
+        if x.shape[-1] != NUM_SAMPLES:
+            raise ValueError(f"Provided number of samples is {x.shape[-1]} "
+                             "(Supported values: 256 for 8000 sample rate, 512 for 16000)")
+        batch_size = x.shape[0]
+        if not self._last_batch_size:
+            self.reset_states(batch_size)
+        if self._last_sr and self._last_sr != sr:
+            self.reset_states(batch_size)
+        if self._last_batch_size and self._last_batch_size != batch_size:
+            self.reset_states(batch_size)
+        x = x.to(device=self.engine.device, dtype=t.float32)
+        if not len(self._context):
+            self._context = t.zeros(batch_size, CONTEXT_SIZE, device=self.engine.device)
+        x = t.cat([self._context, x], dim=1)
+        out, self._state = self.engine.step(x, self._state)
+        self._context = x[..., -CONTEXT_SIZE:]
+        self._last_sr = sr
+        self._last_batch_size = batch_size
+        return out.cpu()
+
+    def audio_forward(self, x, sr: int):
+        """Whole clips in ONE device call (the reference loops window by window)."""
+        t = self.torch
+        if not t.is_tensor(x):
+            x = t.as_tensor(np.asarray(x, dtype=np.float32))
+        x, sr = self._validate_input(x, sr)
+        self.reset_states()
+        probs, state = self.engine.clips(x, return_state=True)
+        # leave the wrapper exactly where the reference's loop would: last state + last 64 samples
+        pad = (-x.shape[1]) % NUM_SAMPLES
+        xp = t.nn.functional.pad(x.to(self.engine.device, t.float32), (0, pad))
+        self._state, self._context = state, xp[:, -CONTEXT_SIZE:]
+        self._last_sr, self._last_batch_size = sr, x.shape[0]
+        return probs.cpu()
+
+
+def load_silero_vad(onnx=True, opset_version=16, use_cpu=True, path="", device="cuda:0"):
+    """Constructor of the boundary object (reference signature; `use_cpu` is accepted and ignored:
+    this build runs on the MI355X only)."""
+    if onnx and opset_version not in (15, 16):
+        raise Exception("Available ONNX opset_version: [15, 16]")
+    return OnnxWrapper(path or None, force_onnx_cpu=use_cpu, device=device)
+
+
+def _finish(segs, counts, lengths, sampling_rate, return_seconds, time_resolution, step):
+    out = []
+    segs = segs.cpu().numpy()
+    counts = counts.cpu().numpy()
+    for b in range(segs.shape[0]):
+        row = []
+        for s, e in segs[b, :counts[b]].tolist():
+            if return_seconds:
+                dur = int(lengths[b]) / sampling_rate
+                row.append({"start": max(round(s / sampling_rate, time_resolution), 0),
+                            "end": min(round(e / sampling_rate, time_resolution), dur)})
+            elif step > 1:
+                row.append({"start": s * step, "end": e * step})
+            else:
+                row.append({"start": s, "end": e})
+        out.append(row)
+    return out
+
+
+def get_speech_timestamps_batch(audio, model, lengths=None, threshold: float = 0.5, sampling_rate: int = 16000,
+                                min_speech_duration_ms: int = 250, max_speech_duration_s: float = float("inf"),
+                                min_silence_duration_ms: int = 100, speech_pad_ms: int = 30,
+                                return_seconds: bool = False, time_resolution: int = 1,
+                                neg_threshold: float = None, min_silence_at_max_speech: int = 98,
+                                use_max_poss_sil_at_max_speech: bool = True, return_probs: bool = False):
+    """Batched get_speech_timestamps: audio f32 [B,N] (equal length, or `lengths` per clip with
+    zero padding beyond) -> list (per clip) of lists of {'start','end'} dicts."""
+    engine = model.engine if isinstance(model, OnnxWrapper) else model
+    t = engine.torch
+    audio = engine._dev_f32(audio)
+    if audio.dim() == 1:
+        audio = audio.unsqueeze(0)
+    step = 1
+    if sampling_rate > 16000 and sampling_rate % 16000 == 0:
+        step = sampling_rate // 16000
+        sampling_rate = 16000
+        audio = audio[:, ::step].contiguous()
+        warnings.warn("Sampling rate is a multiply of 16000, casting to 16000 manually!")
+    if sampling_rate != 16000:
+        raise ValueError("Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates"
+                         if sampling_rate != 8000 else "this build supports 16000 Hz (or a multiple) only")
+    B, N = audio.shape
+    if lengths is None:
+        lens = np.full((B,), N, dtype=np.int64)
+    else:
+        lens = np.asarray(lengths, dtype=np.int64)
+        if step > 1:
+            lens = (lens + step - 1) // step
+        if lens.shape != (B,) or lens.min() <= 0 or lens.max() > N:
+            raise ValueError("lengths must be B positive values <= audio.shape[1]")
+        if lens.min() != N:      # zero everything past each clip's end (the reference zero-pads the last window)
+            mask = t.arange(N, device=engine.device).unsqueeze(0) < t.as_tensor(lens, device=engine.device).unsqueeze(1)
+            audio = audio * mask
+    probs = engine.clips(audio, n_samples=int(lens.max()))
+    segs, counts = engine.segments(probs, lens, threshold=threshold, sampling_rate=sampling_rate,
+                                   min_speech_duration_ms=min_speech_duration_ms,
+                                   max_speech_duration_s=max_speech_duration_s,
+                                   min_silence_duration_ms=min_silence_duration_ms, speech_pad_ms=speech_pad_ms,
+                                   neg_threshold=neg_threshold, min_silence_at_max_speech=min_silence_at_max_speech,
+                                   use_max_poss_sil_at_max_speech=use_max_poss_sil_at_max_speech)
+    res = _finish(segs, counts, lens, sampling_rate, return_seconds, time_resolution, step)
+    return (res, probs) if return_probs else res
+
+
+def get_speech_timestamps(audio, model, threshold: float = 0.5, sampling_rate: int = 16000,
+                          min_speech_duration_ms: int = 250, max_speech_duration_s: float = float("inf"),
+                          min_silence_duration_ms: int = 100, speech_pad_ms: int = 30, return_seconds: bool = False,
+                          time_resolution: int = 1, visualize_probs: bool = False, progress_tracking_callback=None,
+                          neg_threshold: float = None, window_size_samples: int = 512,
+                          min_silence_at_max_speech: int = 98, use_max_poss_sil_at_max_speech: bool = True):
+    """Single-clip reference signature (utils_vad.py:248-263); runs the whole clip in one device pass."""
+    torch = _lib.require_gpu()
+    if not torch.is_tensor(audio):
+        try:
+            audio = torch.Tensor(audio)
+        except Exception:
+            raise TypeError("Audio cannot be casted to tensor. Cast it manually")
+    if len(audio.shape) > 1:
+        for _ in range(len(audio.shape)):
+            audio = audio.squeeze(0)
+        if len(audio.shape) > 1:
+            raise ValueError("More than one dimension in audio. Are you trying to process audio with 2 channels?")
+    if visualize_probs:
+        raise NotImplementedError("visualize_probs is outside the hot path (SURVEY §2 row 10)")
+    res = get_speech_timestamps_batch(audio.unsqueeze(0), model, None, threshold, sampling_rate,
+                                      min_speech_duration_ms, max_speech_duration_s, min_silence_duration_ms,
+                                      speech_pad_ms, return_seconds, time_resolution, neg_threshold,
+                                      min_silence_at_max_speech, use_max_poss_sil_at_max_speech)[0]
+    if progress_tracking_callback:
+        progress_tracking_callback(100.0)
+    return res
