@@ -104,6 +104,42 @@ int vadx_silero_segments(const float *probs, int batch, int steps, const int64_t
                          int cap, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused signal front-end: int16 PCM -> prep -> framed windowed DFT against the
+ * reference's own float32 table -> |.|^2 -> mel -> log.
+ * Replaces the graph prefix every exported model starts with:
+ *   FSMN      FSMN/Export_FSMN_VAD.py:76-81      + FSMN/STFT_Process.py:144-157
+ *   MarbleNet Export_NVIDIA_MarbleNet_VAD.py:236-262 + NVIDIA_.../STFT_Process.py:265-279
+ *   FireRed   FireRedVAD/Export_FireRedVAD.py:428-461 + FireRedVAD/STFT_Process.py (same class)
+ *   DFSMN     DFSMN/.../Export_DFSMN_VAD.py:318-325,342-348 + DFSMN/.../STFT_Process.py:154-172
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vadx_frontend_cfg {
+    int   prep;        /* 0: x-mean(window), then y[n]=a[n]-0.97*a[n-1], y[0]=a[0]        (FSMN)
+                          1: y[n]=k0*x[n-1]+k1*x[n], x[-1]=0                             (MarbleNet, FireRed)
+                          2: y = k1*x - mean(k1*x)                                       (DFSMN) */
+    float k0, k1;
+    int   center_pad;  /* zeros on each side of the window (n_fft/2, or 0 for snip-edges) */
+    int   tap0, taps;  /* non-zero span of the centre-padded analysis window inside n_fft */
+    int   hop;         /* multiple of 16 */
+    int   n_bins;      /* n_fft/2+1 */
+    int   n_mels;      /* multiple of 16 */
+    int   log_mode;    /* 0: log(max(x,floor))   1: log(x+floor) */
+    float log_floor;
+    int   frames;      /* frames per window */
+    int   window_len;  /* samples per window */
+} vadx_frontend_cfg;
+
+size_t vadx_frontend_packed_floats(const vadx_frontend_cfg *cfg);
+/* Host repack of the reference tables (cos/sin [n_bins][n_fft] windowed, fbank [n_mels][n_bins]);
+ * mel_kb receives 2*n_mels/16 ints (banded mel ranges) that vadx_frontend_logmel wants back. */
+int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float *cos_tab, const float *sin_tab,
+                            int n_fft, const float *fbank, float *packed_host, int32_t *mel_kb);
+/* audio int16 [batch][row_stride]; window w of clip b starts at b*row_stride + w*win_stride;
+ * out f32 [batch*windows_per_clip][frames][n_mels]; means_ws: batch*windows floats (prep 0/2). */
+int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host,
+                         const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
+                         int windows_per_clip, float *means_ws, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Test hooks (used by tests/ only)
  * ------------------------------------------------------------------------------------------- */
 /* C[M][N] = A[M][K] * W[N][K]^T through the same LDS/MFMA tile helper the nets use.

@@ -20,24 +20,35 @@ run sq    2 1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LD
 run sq2   2 1 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys, collections
+csv.field_size_limit(1 << 30)
 out = sys.argv[1]
 summ = open(os.path.join(out, "SUMMARY.txt"), "w")
 def p(*a):
     s = " ".join(str(x) for x in a); print(s); summ.write(s + "\n")
+def short(k):
+    k = k.split("(")[0]
+    return k[-44:]
 for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
-    p("# kernel stats:", os.path.relpath(f, out))
+    p("# rocprofv3 --kernel-trace --stats :", os.path.relpath(f, out))
     for row in csv.reader(open(f)):
-        if any("vadx" in c or "Name" in c for c in row): p(",".join(row))
+        if any("vadx" in c or c == "Name" for c in row): p(",".join(row))
+for f in glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True):
+    acc = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if "vadx" not in row["Kernel_Name"]: continue
+        acc[(short(row["Kernel_Name"]), int(row["Grid_Size_X"]))].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    p("# per (kernel, grid) dispatch durations from the kernel trace [ns]: n, mean, min, max")
+    for (k, g), v in sorted(acc.items()): p(f"{k:46s} grid={g:10d} n={len(v):3d} mean={sum(v)/len(v):14.1f} min={min(v):12d} max={max(v):12d}")
 for name in ("fetch", "write", "sq", "sq2"):
     for f in glob.glob(out + f"/{name}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "")
             if "vadx" not in k: continue
-            key = (k.split("(")[0][-40:], row["Counter_Name"])
+            key = (short(k), int(row["Grid_Size"]), row["Counter_Name"])
             acc[key][0] += float(row["Counter_Value"]); acc[key][1] += 1
-        p("# pmc pass", name, "(mean per dispatch)")
-        for (k, c), (v, n) in sorted(acc.items()): p(f"{k:42s} {c:28s} {v / n:18.1f}  n={n}")
+        p("# pmc pass", name, "(mean per dispatch, grouped by grid size)")
+        for (k, g, c), (v, n) in sorted(acc.items()): p(f"{k:46s} grid={g:10d} {c:26s} {v / n:18.1f}  n={n}")
 summ.close()
 PY
 # keep only small text artefacts

@@ -29,6 +29,13 @@ class SileroSegParams(C.Structure):
                 ("min_silence_at_max_speech", C.c_double), ("use_max_poss_sil_at_max_speech", C.c_int)]
 
 
+class FrontendCfg(C.Structure):
+    _fields_ = [("prep", C.c_int), ("k0", C.c_float), ("k1", C.c_float), ("center_pad", C.c_int),
+                ("tap0", C.c_int), ("taps", C.c_int), ("hop", C.c_int), ("n_bins", C.c_int),
+                ("n_mels", C.c_int), ("log_mode", C.c_int), ("log_floor", C.c_float), ("frames", C.c_int),
+                ("window_len", C.c_int)]
+
+
 _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/vadx.h declares
@@ -43,6 +50,9 @@ SIGNATURES = {
     "vadx_silero_encode": (_I, [_P, _P, _I, _L, _L, _P, _Z, _P]),
     "vadx_silero_recur": (_I, [_P, _P, _Z, _I, _I, _P, _P, _P, _P]),
     "vadx_silero_segments": (_I, [_P, _I, _I, _P, C.POINTER(SileroSegParams), _P, _P, _I, _P]),
+    "vadx_frontend_packed_floats": (_Z, [C.POINTER(FrontendCfg)]),
+    "vadx_frontend_pack_host": (_I, [C.POINTER(FrontendCfg), _P, _P, _I, _P, _P, _P]),
+    "vadx_frontend_logmel": (_I, [C.POINTER(FrontendCfg), _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
     "vadx_test_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
 }
 

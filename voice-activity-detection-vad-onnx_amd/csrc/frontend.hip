@@ -1,0 +1,345 @@
+// frontend.hip -- fused signal front-end for gfx950 (reference: the five STFT_Process.py copies +
+// the wrapper code around them): int16 PCM -> prep (DC / pre-emphasis / scaling) -> framed
+// windowed DFT against the REFERENCE'S OWN float32 table -> |.|^2 -> mel -> log, one kernel.
+//
+// Tile = one analysis window of one clip x 32 (or 16) consecutive frames; 512 threads.
+//   * The PCM span of the tile is read from HBM once (coalesced int16), prepped in registers and
+//     laid out in LDS as the hop-polyphase matrix  X2[r][g] = s'[g*hop + r]  (r < hop): frame f,
+//     tap k = a*hop + r is then X2[r][f + a], i.e. the framed DFT becomes ceil(taps/hop) GEMM
+//     passes that differ only by a COLUMN offset a -- overlapping frames are served from LDS and
+//     every sample is stored exactly once.
+//   * DFT = f32 MFMA GEMM [frames x taps] x [taps x 2F]; table rows stream from L2 into operand
+//     registers (each wave owns whole bin tiles, re+im accumulate side by side so |.|^2 is lane-local).
+//   * power spectrum goes to LDS k-major [bin][frame]; mel = second MFMA GEMM that only visits the
+//     16-bin blocks each 16-mel tile actually touches (triangular filters are banded); log epilogue,
+//     time-major output [window][frame][mel] (mel contiguous: LFR rows are contiguous slices).
+#include "common.h"
+
+#include <string.h>
+
+namespace vadx {
+namespace frontend {
+
+constexpr int THREADS = 512;
+constexpr int TF = 32;            // frames per full tile (2 m-tiles); a 16-frame variant handles tails
+constexpr int X_LD = 36;          // X2 row stride  (>= TF + max passes, % 8 == 4)
+constexpr int P_LD = 36;          // power row stride (>= TF, % 8 == 4, 16-B aligned rows)
+constexpr int MAX_PASSES = 4;
+constexpr int MAX_MEL_TILES = 8;
+
+struct Dev {
+    // geometry
+    int prep, center_pad, tap0, taps, hop, n_bins, n_mels, log_mode, frames, window_len;
+    float k0, k1, log_floor;
+    // derived
+    int passes, pass_kb[MAX_PASSES], pass_koff[MAX_PASSES];   // 16-blocks per pass, k offset in table row
+    int Kp;                 // padded taps per table row
+    int nbt;                // MFMA bin tiles (16 bins each)
+    int nyq;                // 1 => bin n_bins-1 handled on the VALU (n_bins % 16 == 1)
+    int Fp;                 // padded bins (power rows)
+    int nmt, mel_kb_lo[MAX_MEL_TILES], mel_kb_hi[MAX_MEL_TILES];
+    int off_dft, off_nyq, off_mel;    // float offsets in the packed blob
+    int tiles32, tiles16;   // per window: number of 32-frame tiles, then 16-frame tiles
+};
+
+static int round16(int x) { return (x + 15) & ~15; }
+
+static int derive(const vadx_frontend_cfg *c, Dev *d) {
+    memset(d, 0, sizeof(*d));
+    d->prep = c->prep; d->center_pad = c->center_pad; d->tap0 = c->tap0; d->taps = c->taps; d->hop = c->hop;
+    d->n_bins = c->n_bins; d->n_mels = c->n_mels; d->log_mode = c->log_mode; d->frames = c->frames;
+    d->window_len = c->window_len; d->k0 = c->k0; d->k1 = c->k1; d->log_floor = c->log_floor;
+    if (c->hop <= 0 || c->hop % 16 || c->taps <= 0 || c->n_bins <= 0 || c->n_mels <= 0 || c->n_mels % 16 ||
+        c->frames <= 0 || c->window_len <= 0)
+        return -1;
+    d->passes = (c->taps + c->hop - 1) / c->hop;
+    if (d->passes > MAX_PASSES || c->n_mels / 16 > MAX_MEL_TILES) return -1;
+    int koff = 0;
+    for (int a = 0; a < d->passes; ++a) {
+        const int rows = (a + 1) * c->hop <= c->taps ? c->hop : c->taps - a * c->hop;
+        d->pass_kb[a] = round16(rows) / 16;
+        d->pass_koff[a] = koff;
+        koff += round16(rows);
+    }
+    d->Kp = koff;
+    d->nyq = (c->n_bins % 16 == 1) ? 1 : 0;
+    d->nbt = d->nyq ? c->n_bins / 16 : (c->n_bins + 15) / 16;
+    d->Fp = round16(c->n_bins);
+    d->nmt = c->n_mels / 16;
+    d->off_dft = 0;
+    d->off_nyq = d->off_dft + d->nbt * 32 * d->Kp;
+    d->off_mel = d->off_nyq + 2 * d->Kp;
+    d->tiles32 = c->frames / TF;
+    const int rem = c->frames - d->tiles32 * TF;
+    d->tiles16 = (rem + 15) / 16;
+    if (rem > 16) { d->tiles32 += 1; d->tiles16 = 0; }
+    return 0;
+}
+
+// acc[nt][mt] += X(k-major LDS) x W^T, runtime block count (see gemm_pass in common.h)
+template <int NT, int MT, bool SWAP>
+__device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, int lda, const int (&moff)[MT],
+                                        const float *const (&wrow)[NT], int kb, int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    const float *ap = act + (4 * q) * lda + i;
+    f32x4 wcur[NT], wnxt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 4 * q);
+    for (int S = 0; S < kb; ++S) {
+        const int Sn = (S + 1 < kb) ? S + 1 : S;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
+        const float *aps = ap + 16 * S * lda;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = aps[j * lda + moff[mt]];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float wj = wcur[nt][j];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = SWAP ? mfma16(wj, av[mt], acc[nt][mt]) : mfma16(av[mt], wj, acc[nt][mt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wcur[nt] = wnxt[nt];
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict__ P, const int16_t *__restrict__ win,
+                                          float mean, int f0, float *__restrict__ out_win, float *X2, float *PW) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, i = lane & 15;
+    constexpr int NF = MT * 16;
+    const int cols = NF + d.passes - 1;
+
+    // ---- phase 0: prep + polyphase staging  X2[r][g] = s'[(f0+g)*hop + r]
+    for (int e = tid; e < cols * d.hop; e += THREADS) {
+        const int g = e / d.hop, r = e - g * d.hop;
+        const int n = (f0 + g) * d.hop + r + d.tap0 - d.center_pad;      // index into the window
+        float v = 0.f;
+        if (n >= 0 && n < d.window_len) {
+            const float x = (float)win[n];
+            const float xm = (n > 0) ? (float)win[n - 1] : 0.f;
+            if (d.prep == 0) {            // FSMN: (x-mean) - 0.97*(x[-1]-mean), first sample kept
+                const float a = __fsub_rn(x, mean);
+                v = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn(xm, mean))) : a;
+            } else if (d.prep == 1) {     // two-tap conv with zero history
+                v = __fadd_rn(__fmul_rn(xm, d.k0), __fmul_rn(x, d.k1));
+            } else {                      // scale, then remove the window mean (mean is of the scaled signal)
+                v = __fsub_rn(__fmul_rn(x, d.k1), mean);
+            }
+        }
+        X2[r * X_LD + g] = v;
+    }
+    // rows hop..round16 of a partial last pass never exist in X2; the table is zero there but the
+    // activations must be finite: they alias rows of the NEXT column block, which are finite.
+    __syncthreads();
+
+    // ---- phase 1: DFT GEMM, |.|^2 -> PW[bin][frame]
+    for (int bt = wave; bt < d.nbt; bt += THREADS / 64) {
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *re_row = P + d.off_dft + (size_t)(bt * 32 + i) * d.Kp;
+        const float *im_row = re_row + (size_t)16 * d.Kp;
+        for (int a = 0; a < d.passes; ++a) {
+            const float *const wrow[2] = {re_row + d.pass_koff[a], im_row + d.pass_koff[a]};
+            int moff[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16 + a;
+            gemm_rt<2, MT, false>(acc, X2, X_LD, moff, wrow, d.pass_kb[a], lane);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 pw;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                pw[r] = __fadd_rn(__fmul_rn(acc[0][mt][r], acc[0][mt][r]), __fmul_rn(acc[1][mt][r], acc[1][mt][r]));
+            *reinterpret_cast<f32x4 *>(&PW[(bt * 16 + i) * P_LD + mt * 16 + 4 * q]) = pw;
+        }
+    }
+    if (d.nyq) {            // last bin (n_bins % 16 == 1): frames x taps dot products on the VALU
+        const float *nre = P + d.off_nyq, *nim = nre + d.Kp;
+        for (int e = tid; e < NF * 4; e += THREADS) {       // (frame, k-quarter)
+            const int f = e >> 2, kq = e & 3;
+            float sre = 0.f, sim = 0.f;
+            for (int a = 0; a < d.passes; ++a) {
+                const int rows = d.pass_kb[a] * 16;
+                for (int r = kq; r < rows; r += 4) {
+                    const float x = X2[r * X_LD + f + a];
+                    sre = fmaf(x, nre[d.pass_koff[a] + r], sre);
+                    sim = fmaf(x, nim[d.pass_koff[a] + r], sim);
+                }
+            }
+            sre += __shfl_xor(sre, 1); sre += __shfl_xor(sre, 2);
+            sim += __shfl_xor(sim, 1); sim += __shfl_xor(sim, 2);
+            if (kq == 0) PW[(d.n_bins - 1) * P_LD + f] = __fadd_rn(__fmul_rn(sre, sre), __fmul_rn(sim, sim));
+        }
+    }
+    // zero the padded power rows (bins n_bins..Fp-1) so the mel GEMM multiplies 0 x 0
+    for (int e = tid; e < (d.Fp - d.n_bins) * NF; e += THREADS) {
+        const int r = e / NF, c = e - r * NF;
+        PW[(d.n_bins + r) * P_LD + c] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- phase 2: banded mel GEMM + log, D rows = mel (SWAP) so each lane stores 4 consecutive mels
+    for (int mtile = wave; mtile < d.nmt; mtile += THREADS / 64) {
+        f32x4 acc[1][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int lo = d.mel_kb_lo[mtile], hi = d.mel_kb_hi[mtile];
+        const float *const wrow[1] = {P + d.off_mel + (size_t)(mtile * 16 + i) * d.Fp + lo * 16};
+        int moff[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16;
+        if (hi > lo) gemm_rt<1, MT, true>(acc, PW + lo * 16 * P_LD, P_LD, moff, wrow, hi - lo, lane);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int f = f0 + mt * 16 + i;
+            if (f < d.frames) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m = acc[0][mt][r];
+                    v[r] = logf(d.log_mode ? __fadd_rn(m, d.log_floor) : fmaxf(m, d.log_floor));
+                }
+                *reinterpret_cast<f32x4 *>(out_win + (size_t)f * d.n_mels + mtile * 16 + 4 * q) = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(THREADS, 4) void frontend_logmel_kernel(
+    Dev d, const float *__restrict__ P, const int16_t *__restrict__ audio, long long row_stride,
+    long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *X2 = lds;
+    float *PW = lds + d.hop * X_LD + 16 * X_LD;       // +16 rows: partial last pass reads past hop
+    const int tiles = d.tiles32 + d.tiles16;
+    const int widx = blockIdx.x / tiles, tile = blockIdx.x - widx * tiles;
+    const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
+    const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
+    float *out_win = out + (size_t)widx * d.frames * d.n_mels;
+    const float mean = means ? means[widx] : 0.f;
+    if (tile < d.tiles32) tile_body<2>(d, P, win, mean, tile * TF, out_win, X2, PW);
+    else tile_body<1>(d, P, win, mean, d.tiles32 * TF + (tile - d.tiles32) * 16, out_win, X2, PW);
+}
+
+// window means for the DC-removing preps: exact integer sum -> float (one wave per window)
+__global__ void window_mean_kernel(const int16_t *__restrict__ audio, long long row_stride, long long win_stride,
+                                   int windows_per_clip, int n_windows, int window_len, float scale,
+                                   float *__restrict__ means) {
+    const int widx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (widx >= n_windows) return;
+    const int lane = threadIdx.x & 63;
+    const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
+    const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
+    long long s = 0;
+    for (int n = lane; n < window_len; n += 64) s += win[n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) means[widx] = (float)((double)s * (double)scale / (double)window_len);
+}
+
+}  // namespace frontend
+}  // namespace vadx
+
+using namespace vadx::frontend;
+
+extern "C" size_t vadx_frontend_packed_floats(const vadx_frontend_cfg *cfg) {
+    Dev d;
+    if (!cfg || derive(cfg, &d)) return 0;
+    return (size_t)d.off_mel + (size_t)d.n_mels * d.Fp;
+}
+
+// Tables on the host in the reference's own layout: cos_tab/sin_tab [n_bins][n_fft] (windowed, the
+// float32 values the reference registers as conv kernels), fbank [n_mels][n_bins].
+extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float *cos_tab, const float *sin_tab,
+                                       int n_fft, const float *fbank, float *packed_host, int32_t *mel_kb) {
+    Dev d;
+    VADX_REQUIRE(cfg && cos_tab && sin_tab && fbank && packed_host && mel_kb, "vadx_frontend_pack_host: NULL argument");
+    VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_frontend_pack_host: unsupported geometry (hop %% 16, n_mels %% 16, passes <= 4)");
+    VADX_REQUIRE(cfg->tap0 >= 0 && cfg->tap0 + cfg->taps <= n_fft, "vadx_frontend_pack_host: taps outside n_fft");
+    const size_t total = (size_t)d.off_mel + (size_t)d.n_mels * d.Fp;
+    memset(packed_host, 0, total * sizeof(float));
+    // taps outside [tap0, tap0+taps) must be zero in the reference table (centre-padded window)
+    for (int f = 0; f < d.n_bins; ++f)
+        for (int t = 0; t < n_fft; ++t)
+            if ((t < cfg->tap0 || t >= cfg->tap0 + cfg->taps) && (cos_tab[(size_t)f * n_fft + t] != 0.f || sin_tab[(size_t)f * n_fft + t] != 0.f)) {
+                vadx::set_error("vadx_frontend_pack_host: table has a non-zero tap %d outside [%d,%d)", t, cfg->tap0, cfg->tap0 + cfg->taps);
+                return VADX_EINVAL;
+            }
+    auto put_row = [&](float *dst, const float *src_row) {     // [Kp] <- taps regrouped per pass
+        for (int a = 0; a < d.passes; ++a) {
+            const int rows = (a + 1) * d.hop <= d.taps ? d.hop : d.taps - a * d.hop;
+            memcpy(dst + d.pass_koff[a], src_row + cfg->tap0 + a * d.hop, rows * sizeof(float));
+        }
+    };
+    for (int bt = 0; bt < d.nbt; ++bt)
+        for (int i = 0; i < 16; ++i) {
+            const int f = bt * 16 + i;
+            if (f >= d.n_bins) continue;
+            put_row(packed_host + d.off_dft + (size_t)(bt * 32 + i) * d.Kp, cos_tab + (size_t)f * n_fft);
+            put_row(packed_host + d.off_dft + (size_t)(bt * 32 + 16 + i) * d.Kp, sin_tab + (size_t)f * n_fft);
+        }
+    if (d.nyq) {
+        put_row(packed_host + d.off_nyq, cos_tab + (size_t)(d.n_bins - 1) * n_fft);
+        put_row(packed_host + d.off_nyq + d.Kp, sin_tab + (size_t)(d.n_bins - 1) * n_fft);
+    }
+    for (int m = 0; m < d.n_mels; ++m)
+        memcpy(packed_host + d.off_mel + (size_t)m * d.Fp, fbank + (size_t)m * d.n_bins, d.n_bins * sizeof(float));
+    for (int mt = 0; mt < d.nmt; ++mt) {       // banded: first/last 16-bin block with a non-zero weight
+        int lo = d.Fp / 16, hi = 0;
+        for (int m = mt * 16; m < mt * 16 + 16; ++m)
+            for (int f = 0; f < d.n_bins; ++f)
+                if (fbank[(size_t)m * d.n_bins + f] != 0.f) {
+                    if (f / 16 < lo) lo = f / 16;
+                    if (f / 16 + 1 > hi) hi = f / 16 + 1;
+                }
+        if (hi < lo) { lo = 0; hi = 0; }
+        mel_kb[2 * mt] = lo;
+        mel_kb[2 * mt + 1] = hi;
+    }
+    return VADX_OK;
+}
+
+extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host,
+                                    const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
+                                    int windows_per_clip, float *means_ws, float *out, void *stream) {
+    Dev d;
+    VADX_REQUIRE(cfg && packed && mel_kb_host && audio && out, "vadx_frontend_logmel: NULL argument");
+    VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_frontend_logmel: unsupported geometry");
+    VADX_REQUIRE(batch > 0 && windows_per_clip > 0, "vadx_frontend_logmel: batch/windows must be positive");
+    VADX_REQUIRE((windows_per_clip - 1) * win_stride + cfg->window_len <= row_stride,
+                 "vadx_frontend_logmel: windows run past the clip row (pad the clip to the window grid first)");
+    VADX_REQUIRE(cfg->prep == 1 || means_ws, "vadx_frontend_logmel: this prep mode needs a means workspace of batch*windows floats");
+    VADX_REQUIRE(TF + d.passes - 1 <= X_LD, "vadx_frontend_logmel: too many passes");
+    for (int mt = 0; mt < d.nmt; ++mt) { d.mel_kb_lo[mt] = mel_kb_host[2 * mt]; d.mel_kb_hi[mt] = mel_kb_host[2 * mt + 1]; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long nwin = (long long)batch * windows_per_clip;
+    VADX_REQUIRE(nwin * (d.tiles32 + d.tiles16) < (1LL << 31), "vadx_frontend_logmel: too many tiles");
+    const float *means = nullptr;
+    if (cfg->prep != 1) {
+        const float scale = (cfg->prep == 2) ? cfg->k1 : 1.0f;
+        hipLaunchKernelGGL(window_mean_kernel, dim3((unsigned)((nwin + 3) / 4)), dim3(256), 0, st, audio, (long long)row_stride,
+                           (long long)win_stride, windows_per_clip, (int)nwin, cfg->window_len, scale, means_ws);
+        VADX_HIP_TRY(hipGetLastError());
+        means = means_ws;
+    }
+    const size_t lds = ((size_t)(d.hop + 16) * X_LD + (size_t)d.Fp * P_LD) * sizeof(float);
+    VADX_REQUIRE(lds <= 160 * 1024, "vadx_frontend_logmel: geometry needs %zu B of LDS", lds);
+    if (lds > 64 * 1024)
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(frontend_logmel_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(frontend_logmel_kernel, dim3((unsigned)(nwin * (d.tiles32 + d.tiles16))), dim3(THREADS), lds, st, d,
+                       packed, audio, (long long)row_stride, (long long)win_stride, windows_per_clip, means, out);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}

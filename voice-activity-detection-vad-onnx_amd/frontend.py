@@ -1,0 +1,95 @@
+"""Fused signal front-end (int16 PCM -> log-mel) for every model family: host-side presets + the
+thin wrapper over `vadx_frontend_logmel` (csrc/frontend.hip).  Reference rows a1-a5."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import tables
+
+# name -> (n_fft, win_length, hop, window kind, STFT_Process variant, centre pad?, prep, (k0,k1),
+#          mel builder, log mode, log floor)
+PRESETS = {
+    # FSMN/Export_FSMN_VAD.py:25-29,63,76-81,106
+    "fsmn": dict(n_fft=512, win=400, hop=160, window="hamming", variant="v1", center=True, prep=0, k=(0.0, 1.0),
+                 mel=("torchaudio", 20, 8000, None, "htk"), log_mode=0, log_floor=1e-5),
+    # Export_NVIDIA_MarbleNet_VAD.py:30-34,186-204,245-262 (int16 scale folded into the 2-tap kernel)
+    "marblenet": dict(n_fft=512, win=400, hop=160, window="hann_sym", variant="v2", center=True, prep=1,
+                      k=(-0.97 * (1.0 / 32768.0), 1.0 / 32768.0), mel=("torchaudio", 0, 8000, "slaney", "slaney"),
+                      log_mode=1, log_floor=1e-7),
+    # FireRedVAD/Export_FireRedVAD.py:42-47,396-418,428-461 (snip_edges: no centre pad)
+    "firered": dict(n_fft=400, win=400, hop=160, window="povey", variant="v2", center=False, prep=1, k=(-0.97, 1.0),
+                    mel=("kaldi", 20.0, 0.0), log_mode=0, log_floor=1e-7),
+}
+
+
+class Frontend:
+    """Device-resident packed tables for one preset and one window length."""
+
+    def __init__(self, preset, window_len, device="cuda:0", n_mels=80, sample_rate=16000):
+        torch = _lib.require_gpu()
+        self.torch = torch
+        self.device = torch.device(device)
+        p = dict(PRESETS[preset]) if isinstance(preset, str) else dict(preset)
+        self.p = p
+        n_fft, win, hop = p["n_fft"], p["win"], p["hop"]
+        half = n_fft // 2
+        self.window_len = int(window_len)
+        self.frames = (self.window_len // hop + 1) if p["center"] else ((self.window_len - n_fft) // hop + 1)
+        w = tables.analysis_window(p["window"], win, n_fft, p["variant"])
+        cos_t, sin_t = tables.windowed_dft(n_fft, w, p["variant"])
+        if p["mel"][0] == "torchaudio":
+            _, fmin, fmax, norm, scale = p["mel"]
+            fb = tables.mel_filters_torchaudio(half + 1, fmin, fmax, n_mels, sample_rate, norm, scale)
+        else:
+            fb = tables.mel_filters_kaldi(n_fft, n_mels, sample_rate, p["mel"][1], p["mel"][2])
+        cfg = _lib.FrontendCfg()
+        cfg.prep, cfg.k0, cfg.k1 = p["prep"], p["k"][0], p["k"][1]
+        cfg.center_pad = half if p["center"] else 0
+        cfg.tap0 = (n_fft - win) // 2 if win < n_fft else 0
+        cfg.taps = min(win, n_fft)
+        cfg.hop, cfg.n_bins, cfg.n_mels = hop, half + 1, n_mels
+        cfg.log_mode, cfg.log_floor = p["log_mode"], p["log_floor"]
+        cfg.frames, cfg.window_len = self.frames, self.window_len
+        self.cfg = cfg
+        self.n_mels = n_mels
+        L = _lib.lib()
+        n = L.vadx_frontend_packed_floats(C.byref(cfg))
+        if n == 0:
+            raise ValueError("front-end geometry not supported by the HIP kernel (hop % 16, n_mels % 16, <= 4 passes)")
+        packed = np.zeros(n, dtype=np.float32)
+        self.mel_kb = np.zeros(2 * (n_mels // 16), dtype=np.int32)
+        cos_n, sin_n, fb_n = tables.as_np(cos_t), tables.as_np(sin_t), tables.as_np(fb)
+        _lib.check(L.vadx_frontend_pack_host(C.byref(cfg), cos_n.ctypes.data, sin_n.ctypes.data, n_fft,
+                                             fb_n.ctypes.data, packed.ctypes.data, self.mel_kb.ctypes.data))
+        self.packed = torch.from_numpy(packed).to(self.device)
+
+    def logmel(self, audio_i16, windows_per_clip=1, win_stride=None, out=None):
+        """audio int16 [B, N] (device) -> log-mel f32 [B*W, frames, n_mels] (device)."""
+        t = self.torch
+        if not t.is_tensor(audio_i16):
+            audio_i16 = t.from_numpy(np.ascontiguousarray(audio_i16, dtype=np.int16))
+        a = audio_i16.to(self.device)
+        if a.dtype != t.int16:
+            raise ValueError(f"audio must be int16, got {a.dtype}")
+        if a.dim() == 3 and a.shape[1] == 1:
+            a = a[:, 0]
+        if a.dim() != 2:
+            raise ValueError("audio must be [B, N] (or [B,1,N])")
+        a = a.contiguous()
+        B, N = a.shape
+        W = int(windows_per_clip)
+        ws = self.window_len if win_stride is None else int(win_stride)
+        if (W - 1) * ws + self.window_len > N:
+            raise ValueError("windows run past the clip: pad the clip to the window grid first")
+        if out is None:
+            out = t.empty((B * W, self.frames, self.n_mels), dtype=t.float32, device=self.device)
+        means = t.empty((B * W,), dtype=t.float32, device=self.device) if self.cfg.prep != 1 else None
+        with t.cuda.device(self.device):
+            _lib.check(_lib.lib().vadx_frontend_logmel(C.byref(self.cfg), self.packed.data_ptr(), self.mel_kb.ctypes.data,
+                                                       a.data_ptr(), a.stride(0), ws, B, W,
+                                                       None if means is None else means.data_ptr(), out.data_ptr(),
+                                                       _lib.stream_ptr()))
+        return out
