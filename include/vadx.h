@@ -140,6 +140,58 @@ int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *packed, cons
                          int windows_per_clip, float *means_ws, float *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * FSMN-VAD
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vadx_fsmn_dims {          /* FunASR FSMN(input 400, proj 128, lorder 20, 4 layers pinned in-tree) */
+    int   input_affine_dim, linear_dim, output_affine_dim, output_dim;   /* external config: 140/250/140/248 */
+    int   frames;                         /* T = window_len // 160 + 1 (101) */
+    float speech_2_noise_ratio;           /* FSMN/Export_FSMN_VAD.py:34,87-92 */
+} vadx_fsmn_dims;
+
+typedef struct vadx_fsmn_weights_host {  /* torch layouts: Linear weight [out][in]; conv_left [128][20] */
+    const float *in1_w, *in1_b, *in2_w, *in2_b;
+    const float *lin_w[4], *fir_w[4], *aff_w[4], *aff_b[4];
+    const float *out1_w, *out1_b, *out2_w, *out2_b;
+    const float *cmvn_means, *cmvn_vars;  /* [400] each, (x + means) * vars */
+} vadx_fsmn_weights_host;
+
+size_t vadx_fsmn_packed_floats(const vadx_fsmn_dims *dims);
+int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_weights_host *w, float *packed_host);
+
+/* Per-frame energy term of the score gate: log10(sum_512 (y/(sqrt(L)*2e-5))^2 + 2e-5) of the prepped
+ * window, 97 real frames + last value repeated to `frames`; means = per-window DC (from
+ * vadx_frontend_logmel's means workspace).  Replaces FSMN/Export_FSMN_VAD.py:93-97. */
+int vadx_fsmn_energy(const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
+                     int windows_per_clip, int window_len, int frames, const float *means, float *db,
+                     void *stream);
+
+/* One ORT-boundary call for `batch` independent streams, after the front-end:
+ *   feeds   audio -> (logmel [B][T][80], db [B][T]); cache_0..3 f32 [B][128][19];
+ *           one_minus_speech_threshold f32 [B]; noise_average_dB f32 [B]
+ *   fetches score u8 [B][T]; cache_0..3; noisy_dB f32 [B]      (+ optional P(silence) f32 [B][T])
+ * Replaces ort_session_A.run(...), FSMN/Inference_FSMN_VAD_ONNX.py:177-187 (graph :75-101). */
+int vadx_fsmn_run(const vadx_fsmn_dims *dims, const float *packed, const float *logmel, const float *db,
+                  const float *const cache_in[4], float *const cache_out[4], const float *thr,
+                  const float *noise_db, int batch, uint8_t *score, float *noisy_db, float *psil,
+                  void *stream);
+
+typedef struct vadx_fsmn_loop_params {   /* FSMN/Inference_FSMN_VAD_ONNX.py:16-23,79-81,159-171 */
+    int    look_backward;                 /* frames: int(LOOK_BACKWARD*16000 // 160) = 30 */
+    float  one_minus_speech_threshold;    /* 1.0 */
+    float  noise_db_init;                 /* (BACKGROUND_NOISE_dB_INIT + SNR_THRESHOLD) * 0.1 */
+    float  snr_threshold;                 /* SNR_THRESHOLD * 0.1 */
+    double speaking_score, silence_score; /* 0.5, 0.5 */
+} vadx_fsmn_loop_params;
+
+/* Whole clips: every clip's windows in order with cache + noise-floor carry and the look-ahead
+ * vote; flags u8 [B][W*(T-lb) + lb] = the reference's `saved` list (1 = silence).
+ * cache_ws: scratch of B*4*128*19 floats.  noise_trace (optional) [B][W] = noise floor after each window.
+ * Replaces the while-loop + tail, FSMN/Inference_FSMN_VAD_ONNX.py:176-234. */
+int vadx_fsmn_clips(const vadx_fsmn_dims *dims, const float *packed, const float *logmel, const float *db,
+                    int batch, int windows_per_clip, const vadx_fsmn_loop_params *lp, float *cache_ws,
+                    uint8_t *flags, float *noise_trace, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Test hooks (used by tests/ only)
  * ------------------------------------------------------------------------------------------- */
 /* C[M][N] = A[M][K] * W[N][K]^T through the same LDS/MFMA tile helper the nets use.

@@ -1,0 +1,115 @@
+"""GPU parity: FSMN-VAD HIP path (front-end + energy + encoder + gate + host-loop kernels through
+the C ABI) vs the reference's own outputs (fixtures) and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import vadx  # noqa: F401
+from vadx import fsmn, weights
+from oracle import fsmn as ofs
+from oracle import postproc as opp
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+@pytest.mark.parametrize("seed", [1234, 7])
+def test_run_matches_reference_fixture(golden, seed):
+    """Four overlapping windows with cache + noise-floor carry, exactly as the reference drove them."""
+    g = golden("fsmn_forward")
+    eng = fsmn.FsmnEngine(weights.fsmn_synthetic(seed))
+    fe = ofs.Frontend()
+    ow = {k: T(v) for k, v in weights.fsmn_synthetic(seed).items()}
+    clip = g[f"s{seed}_clip"]
+    caches = [torch.zeros(1, 128, 19) for _ in range(4)]
+    ocaches = [torch.zeros(1, 128, 19, 1) for _ in range(4)]
+    for k in range(4):
+        a = T(clip[k * 11040:k * 11040 + 16000].copy()).reshape(1, -1)
+        noise = g[f"s{seed}_noise_in_{k}"]
+        score, caches, noisy, psil = eng.run(a, caches, np.array([1.0], np.float32), noise, return_psil=True)
+        _, ocaches, onoisy, oraw, odb = ofs.forward(fe, ow, a.reshape(1, 1, -1), ocaches, np.array([1.0], np.float32), noise,
+                                                    return_raw=True)
+        # frame scores (P(silence)) within 1e-4 of the oracle
+        np.testing.assert_allclose(psil.cpu().numpy()[0], oraw.numpy()[0] / 2, rtol=0, atol=ATOL)
+        want = g[f"s{seed}_score_{k}"]
+        got = score.cpu().numpy()[0]
+        bad = np.flatnonzero(got != want)
+        for i in bad:                  # only frames whose float score/energy sits on a threshold may differ
+            assert abs(float(oraw[0, i]) - 1.0) < 2 * ATOL or abs(float(odb[0, i]) - float(noise[0])) < 2 * ATOL, (k, i)
+        for ci in range(4):
+            np.testing.assert_allclose(caches[ci].cpu().numpy()[0], g[f"s{seed}_cache{ci}_{k}"], rtol=0, atol=5e-4)
+        if np.isnan(g[f"s{seed}_noisy_{k}"]):
+            assert np.isnan(noisy.cpu().numpy()[0])
+        elif len(bad) == 0:
+            np.testing.assert_allclose(noisy.cpu().numpy()[0], g[f"s{seed}_noisy_{k}"], rtol=0, atol=ATOL)
+
+
+def test_run_batched_streams_match_oracle():
+    seed, B = 1234, 5
+    eng = fsmn.FsmnEngine(weights.fsmn_synthetic(seed))
+    fe = ofs.Frontend()
+    ow = {k: T(v) for k, v in weights.fsmn_synthetic(seed).items()}
+    rng = np.random.default_rng(3)
+    clips = weights.burst_clips(B, 16000, seed=77)
+    caches = [T((rng.standard_normal((B, 128, 19)) * 0.3).astype(np.float32)) for _ in range(4)]
+    noise = rng.uniform(1.0, 1.4, B).astype(np.float32)
+    thr = np.full(B, 1.0, np.float32)
+    score, cout, noisy, psil = eng.run(T(clips), caches, thr, noise, return_psil=True)
+    osc, oc, onz, oraw, odb = ofs.forward(fe, ow, T(clips).unsqueeze(1), [c.unsqueeze(-1) for c in caches], thr, noise,
+                                          return_raw=True)
+    np.testing.assert_allclose(psil.cpu().numpy(), oraw.numpy() / 2, rtol=0, atol=ATOL)
+    for ci in range(4):
+        np.testing.assert_allclose(cout[ci].cpu().numpy(), oc[ci][..., 0].numpy(), rtol=0, atol=5e-4)
+    got, want = score.cpu().numpy(), osc.numpy()
+    for b, i in zip(*np.nonzero(got != want)):
+        assert abs(float(oraw[b, i]) - 1.0) < 2 * ATOL or abs(float(odb[b, i]) - float(noise[b])) < 2 * ATOL
+
+
+def test_session_named_tensor_contract():
+    sess = fsmn.FsmnSession(weights.fsmn_synthetic(1234))
+    ins, outs = sess.get_inputs(), sess.get_outputs()
+    assert [m.name for m in ins] == ["audio", "cache_0", "cache_1", "cache_2", "cache_3",
+                                     "one_minus_speech_threshold", "noise_average_dB"]
+    assert sess._inputs_meta[0].shape[-1] == 16000 and sess._outputs_meta[0].shape[-1] == 101
+    assert "float16" not in sess._inputs_meta[1].type
+    audio = weights.burst_clips(1, 16000, seed=1).reshape(1, 1, -1)
+    z = np.zeros((1, 128, 19, 1), np.float32)
+    res = sess.run([o.name for o in outs], {"audio": audio, "cache_0": z, "cache_1": z, "cache_2": z, "cache_3": z,
+                                            "one_minus_speech_threshold": np.array([1.0], np.float32),
+                                            "noise_average_dB": np.array([4.0], np.float32)})
+    assert res[0].dtype == np.uint8 and res[0].shape == (101,)
+    assert res[1].shape == (1, 128, 19, 1) and res[5].shape == ()
+    with pytest.raises(ValueError):
+        sess.run(None, {"audio": audio.astype(np.float32), "cache_0": z, "cache_1": z, "cache_2": z, "cache_3": z,
+                        "one_minus_speech_threshold": np.array([1.0], np.float32),
+                        "noise_average_dB": np.array([4.0], np.float32)})
+
+
+@pytest.mark.parametrize("seed,n", [(1234, 160000), (7, 89431), (1234, 9000), (7, 16000)])
+def test_whole_clip_flags_and_timestamps(seed, n):
+    """raw audio in -> `saved` flags and final (start,end) pairs identical to the oracle's restatement
+    of the reference loop (same explicit tail-padding noise on both sides)."""
+    eng = fsmn.FsmnEngine(weights.fsmn_synthetic(seed))
+    fe = ofs.Frontend()
+    ow = {k: T(v) for k, v in weights.fsmn_synthetic(seed).items()}
+    B = 3
+    clips = weights.burst_clips(B, n, seed=seed + n)
+    noise = np.random.default_rng(9).standard_normal((B, 20000))
+    got = eng.detect(clips, pad_noise=noise)
+    for b in range(B):
+        a = opp.normalize_to_int16(clips[b].astype(np.float32))
+        want_ts, want_flags = ofs.run_clip(fe, ow, a, noise[b])
+        lb, stride = eng.grid()
+        padded = fsmn.pad_to_window_grid(a, 16000, stride, noise[b])
+        W = (padded.shape[0] - 16000) // stride + 1
+        flags, trace = eng.flags(torch.from_numpy(padded[None]), W, return_noise=True)
+        flags = flags.cpu().numpy()[0].astype(bool)
+        assert flags.shape[0] == len(want_flags)
+        mism = np.flatnonzero(flags != np.array(want_flags, bool))
+        assert len(mism) == 0, (b, mism[:10])
+        assert got[b] == want_ts
+        assert [(int(s * 16000), int(e * 16000)) for s, e in got[b]] == [(int(s * 16000), int(e * 16000)) for s, e in want_ts]

@@ -36,6 +36,25 @@ class FrontendCfg(C.Structure):
                 ("window_len", C.c_int)]
 
 
+class FsmnDims(C.Structure):
+    _fields_ = [("input_affine_dim", C.c_int), ("linear_dim", C.c_int), ("output_affine_dim", C.c_int),
+                ("output_dim", C.c_int), ("frames", C.c_int), ("speech_2_noise_ratio", C.c_float)]
+
+
+class FsmnWeightsHost(C.Structure):
+    _fields_ = [("in1_w", C.c_void_p), ("in1_b", C.c_void_p), ("in2_w", C.c_void_p), ("in2_b", C.c_void_p),
+                ("lin_w", C.c_void_p * 4), ("fir_w", C.c_void_p * 4), ("aff_w", C.c_void_p * 4),
+                ("aff_b", C.c_void_p * 4), ("out1_w", C.c_void_p), ("out1_b", C.c_void_p),
+                ("out2_w", C.c_void_p), ("out2_b", C.c_void_p), ("cmvn_means", C.c_void_p),
+                ("cmvn_vars", C.c_void_p)]
+
+
+class FsmnLoopParams(C.Structure):
+    _fields_ = [("look_backward", C.c_int), ("one_minus_speech_threshold", C.c_float),
+                ("noise_db_init", C.c_float), ("snr_threshold", C.c_float), ("speaking_score", C.c_double),
+                ("silence_score", C.c_double)]
+
+
 _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/vadx.h declares
@@ -53,6 +72,12 @@ SIGNATURES = {
     "vadx_frontend_packed_floats": (_Z, [C.POINTER(FrontendCfg)]),
     "vadx_frontend_pack_host": (_I, [C.POINTER(FrontendCfg), _P, _P, _I, _P, _P, _P]),
     "vadx_frontend_logmel": (_I, [C.POINTER(FrontendCfg), _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
+    "vadx_fsmn_packed_floats": (_Z, [C.POINTER(FsmnDims)]),
+    "vadx_fsmn_pack_host": (_I, [C.POINTER(FsmnDims), C.POINTER(FsmnWeightsHost), _P]),
+    "vadx_fsmn_energy": (_I, [_P, _L, _L, _I, _I, _I, _I, _P, _P, _P]),
+    "vadx_fsmn_run": (_I, [C.POINTER(FsmnDims), _P, _P, _P, C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p * 4),
+                           _P, _P, _I, _P, _P, _P, _P]),
+    "vadx_fsmn_clips": (_I, [C.POINTER(FsmnDims), _P, _P, _P, _I, _I, C.POINTER(FsmnLoopParams), _P, _P, _P, _P]),
     "vadx_test_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
 }
 

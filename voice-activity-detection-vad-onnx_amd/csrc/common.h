@@ -84,6 +84,49 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NT][MT], const float *act
     }
 }
 
+// Runtime-length variant (kb blocks of 16 k).  AFFINE=true applies (a + add[k]) * mul[k] to the LDS
+// operand before the multiply (FSMN's CMVN on the LFR features, FSMN/Export_FSMN_VAD.py:86), with
+// add/mul indexed like the weight row (K contiguous, this lane's 4 k per block).
+template <int NT, int MT, bool SWAP, bool AFFINE = false>
+__device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, int lda, const int (&moff)[MT],
+                                        const float *const (&wrow)[NT], int kb, int lane,
+                                        const float *add = nullptr, const float *mul = nullptr) {
+    const int q = lane >> 4, i = lane & 15;
+    const float *ap = act + (4 * q) * lda + i;
+    f32x4 wcur[NT], wnxt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 4 * q);
+    for (int S = 0; S < kb; ++S) {
+        const int Sn = (S + 1 < kb) ? S + 1 : S;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
+        f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, m4 = {1.f, 1.f, 1.f, 1.f};
+        if (AFFINE) {
+            a4 = *reinterpret_cast<const f32x4 *>(add + 16 * S + 4 * q);
+            m4 = *reinterpret_cast<const f32x4 *>(mul + 16 * S + 4 * q);
+        }
+        const float *aps = ap + 16 * S * lda;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                av[mt] = aps[j * lda + moff[mt]];
+                if (AFFINE) av[mt] = __fmul_rn(__fadd_rn(av[mt], a4[j]), m4[j]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float wj = wcur[nt][j];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = SWAP ? mfma16(wj, av[mt], acc[nt][mt]) : mfma16(av[mt], wj, acc[nt][mt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wcur[nt] = wnxt[nt];
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 }  // namespace vadx

@@ -76,38 +76,6 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     return 0;
 }
 
-// acc[nt][mt] += X(k-major LDS) x W^T, runtime block count (see gemm_pass in common.h)
-template <int NT, int MT, bool SWAP>
-__device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, int lda, const int (&moff)[MT],
-                                        const float *const (&wrow)[NT], int kb, int lane) {
-    const int q = lane >> 4, i = lane & 15;
-    const float *ap = act + (4 * q) * lda + i;
-    f32x4 wcur[NT], wnxt[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 4 * q);
-    for (int S = 0; S < kb; ++S) {
-        const int Sn = (S + 1 < kb) ? S + 1 : S;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
-        const float *aps = ap + 16 * S * lda;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float av[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = aps[j * lda + moff[mt]];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float wj = wcur[nt][j];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = SWAP ? mfma16(wj, av[mt], acc[nt][mt]) : mfma16(av[mt], wj, acc[nt][mt]);
-            }
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wcur[nt] = wnxt[nt];
-    }
-}
-
 template <int MT>
 __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict__ P, const int16_t *__restrict__ win,
                                           float mean, int f0, float *__restrict__ out_win, float *X2, float *PW) {
@@ -153,7 +121,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
             int moff[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16 + a;
-            gemm_rt<2, MT, false>(acc, X2, X_LD, moff, wrow, d.pass_kb[a], lane);
+            vadx::gemm_rt<2, MT, false>(acc, X2, X_LD, moff, wrow, d.pass_kb[a], lane);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -199,7 +167,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
         int moff[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16;
-        if (hi > lo) gemm_rt<1, MT, true>(acc, PW + lo * 16 * P_LD, P_LD, moff, wrow, hi - lo, lane);
+        if (hi > lo) vadx::gemm_rt<1, MT, true>(acc, PW + lo * 16 * P_LD, P_LD, moff, wrow, hi - lo, lane);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int f = f0 + mt * 16 + i;

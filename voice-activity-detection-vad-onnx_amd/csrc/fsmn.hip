@@ -1,0 +1,485 @@
+// fsmn.hip -- FSMN-VAD (FunASR encoder, explicit 4-cache signature) for gfx950.
+// Reference: FSMN/Export_FSMN_VAD.py:75-101 (wrapper), FSMN/modeling_modified/encoder.py:78-83,
+// 108-110,139-144,208-217 (encoder), FSMN/Inference_FSMN_VAD_ONNX.py:156-234 (host loop).
+//
+// One workgroup (8 waves) owns one analysis window (chunk) of one clip at a time and keeps every
+// activation of a 64-frame (then 48-frame) tile in LDS, k-major [feature][frame]:
+//   LFR x5 + CMVN (applied on the MFMA operand) -> Affine 400->A -> Affine A->L, ReLU
+//   -> 4 x [ Linear L->128 | 20-tap causal depthwise FIR over (19-frame cache ++ tile) + skip |
+//            Affine 128->L, ReLU ] -> Affine L->A' -> Affine A'->O -> softmax[:,0]
+// All dense layers are f32-MFMA GEMMs with weights streamed from L2 (gemm_rt); the FIR, softmax,
+// energy gate and the look-ahead vote are VALU/LDS work.  In "clips" mode the workgroup walks the
+// overlapping windows of its clip in order, carrying the four FIR caches (global scratch = the
+// reference's cache_0..3 tensors) and the adaptive noise floor exactly like the reference loop.
+#include "common.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace vadx {
+namespace fsmn {
+
+constexpr int THREADS = 512, NW = 8;
+constexpr int PROJ = 128, LORDER = 20, HIST = LORDER - 1, NLAYER = 4, NMEL = 80, LFR_M = 5;
+constexpr int A_LD = 68;                 // bufA / bufB row stride: 64 frames + 4 (% 8 == 4)
+constexpr int P_LD = 84;                 // bufP row stride: 1 unused + 19 history + 64 frames
+constexpr int P_CUR = 20;                // first "current frame" column of bufP (16-B aligned)
+constexpr int BUFA_ROWS = 256, BUFB_ROWS = 144;
+constexpr int BUFA = BUFA_ROWS * A_LD, BUFB = BUFB_ROWS * A_LD, BUFP = PROJ * P_LD;
+constexpr int SMALL = 1024;              // ps[128] | red[512] | sc[128] | misc
+constexpr int LDS_FLOATS = BUFA + BUFB + BUFP + SMALL;
+
+struct Dev {
+    int A, L, A2, O, Ap, Lp, A2p, Op, T;
+    float ratio;
+    int off_in1, off_b1, off_mean, off_var, off_in2, off_b2;
+    int off_lin[NLAYER], off_fir[NLAYER], off_aff[NLAYER], off_baff[NLAYER];
+    int off_out1, off_bo1, off_out2, off_bo2, total;
+};
+
+static int r16(int x) { return (x + 15) & ~15; }
+
+static int derive(const vadx_fsmn_dims *c, Dev *d) {
+    memset(d, 0, sizeof(*d));
+    if (c->input_affine_dim <= 0 || c->linear_dim <= 0 || c->output_affine_dim <= 0 || c->output_dim <= 0 || c->frames <= 0) return -1;
+    d->A = c->input_affine_dim; d->L = c->linear_dim; d->A2 = c->output_affine_dim; d->O = c->output_dim; d->T = c->frames;
+    d->Ap = r16(d->A); d->Lp = r16(d->L); d->A2p = r16(d->A2); d->Op = r16(d->O);
+    d->ratio = c->speech_2_noise_ratio;
+    if (d->Ap > BUFB_ROWS || d->A2p > BUFB_ROWS || d->Lp > BUFA_ROWS || d->Op > BUFA_ROWS) return -1;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    d->off_in1 = take(d->Ap * 400); d->off_b1 = take(d->Ap); d->off_mean = take(400); d->off_var = take(400);
+    d->off_in2 = take(d->Lp * d->Ap); d->off_b2 = take(d->Lp);
+    for (int l = 0; l < NLAYER; ++l) {
+        d->off_lin[l] = take(PROJ * d->Lp); d->off_fir[l] = take(PROJ * LORDER);
+        d->off_aff[l] = take(d->Lp * PROJ); d->off_baff[l] = take(d->Lp);
+    }
+    d->off_out1 = take(d->A2p * d->Lp); d->off_bo1 = take(d->A2p);
+    d->off_out2 = take(d->Op * d->A2p); d->off_bo2 = take(d->Op);
+    d->total = o;
+    return 0;
+}
+
+struct LayerArgs {
+    const float *W; int ldw, ntiles;
+    int npass, kb, kstep, cstep;          // K passes: weights advance kstep floats, act columns cstep
+    const float *bias; int relu;
+    const float *act; int lda, acol0;
+    float *dst; int ldd, dcol0;
+    const float *add, *mul;               // CMVN (AFFINE only)
+};
+
+// dst[n][m] = act[k][m] x W[n][k] (+bias, ReLU).  Work items: whole n-tiles (all m-tiles of the tile)
+// when the n-tile count fills the 8 waves evenly, otherwise (n-tile, m-tile) pairs.
+template <int MTT, bool AFFINE>
+__device__ __noinline__ void layer(const LayerArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    if (a.ntiles % NW == 0) {
+        for (int nt = wave; nt < a.ntiles; nt += NW) {
+            f32x4 acc[1][MTT];
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *row = a.W + (size_t)(nt * 16 + i) * a.ldw;
+            for (int ps = 0; ps < a.npass; ++ps) {
+                const float *const wrow[1] = {row + ps * a.kstep};
+                int moff[MTT];
+#pragma unroll
+                for (int mt = 0; mt < MTT; ++mt) moff[mt] = a.acol0 + mt * 16 + ps * a.cstep;
+                gemm_rt<1, MTT, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
+                                               AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
+            }
+            const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = acc[0][mt][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
+                *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i) * a.ldd + a.dcol0 + mt * 16 + 4 * q) = v;
+            }
+        }
+    } else {
+        for (int item = wave; item < a.ntiles * MTT; item += NW) {
+            const int nt = item / MTT, mt = item - nt * MTT;
+            f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+            const float *row = a.W + (size_t)(nt * 16 + i) * a.ldw;
+            for (int ps = 0; ps < a.npass; ++ps) {
+                const float *const wrow[1] = {row + ps * a.kstep};
+                const int moff[1] = {a.acol0 + mt * 16 + ps * a.cstep};
+                gemm_rt<1, 1, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
+                                             AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
+            }
+            const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[0][0][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
+            *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i) * a.ldd + a.dcol0 + mt * 16 + 4 * q) = v;
+        }
+    }
+}
+
+// One tile of MTT*16 frames starting at frame f0 (nvalid of them inside the chunk).
+//   lm     : this chunk's log-mel [T][80] (global)
+//   cin/cout: FIR caches of this stream, [layer][128][19] (global); cout may alias cin
+//   ps     : LDS, receives P(silence) for frames f0 .. f0+nvalid-1
+template <int MTT>
+__device__ __forceinline__ void tile(const Dev &d, const float *__restrict__ Pk, const float *__restrict__ lm,
+                                     int f0, int nvalid, const float *const *cin, float *const *cout,
+                                     float *bufA, float *bufB, float *bufP, float *ps, float *red) {
+    const int tid = threadIdx.x;
+    constexpr int NF = MTT * 16;
+
+    // ---- stage log-mel with LFR edge replication: bufB[mel][c] = lm[clamp(f0 + c - 2, 0, T-1)][mel]
+    for (int e = tid; e < (NF + 4) * NMEL; e += THREADS) {
+        const int c = e / NMEL, mel = e - c * NMEL;
+        int fr = f0 + c - 2;
+        fr = fr < 0 ? 0 : (fr > d.T - 1 ? d.T - 1 : fr);
+        bufB[mel * A_LD + c] = lm[(size_t)fr * NMEL + mel];
+    }
+    __syncthreads();
+
+    LayerArgs a;
+    // in_linear1: K = 5 passes x 80 (LFR concat: frame offset j -> column offset j), CMVN on the operand
+    a = LayerArgs{Pk + d.off_in1, 400, d.Ap / 16, LFR_M, NMEL / 16, NMEL, 1, Pk + d.off_b1, 0,
+                  bufB, A_LD, 0, bufP, A_LD, 0, Pk + d.off_mean, Pk + d.off_var};
+    layer<MTT, true>(a);
+    __syncthreads();
+    // in_linear2 + ReLU
+    a = LayerArgs{Pk + d.off_in2, d.Ap, d.Lp / 16, 1, d.Ap / 16, 0, 0, Pk + d.off_b2, 1,
+                  bufP, A_LD, 0, bufA, A_LD, 0, nullptr, nullptr};
+    layer<MTT, false>(a);
+    __syncthreads();
+
+    for (int l = 0; l < NLAYER; ++l) {
+        // history columns 1..19 of bufP <- cache (previous tile / previous chunk)
+        for (int e = tid; e < PROJ * HIST; e += THREADS) {
+            const int ch = e / HIST, h = e - ch * HIST;
+            bufP[ch * P_LD + 1 + h] = cin[l][e];
+        }
+        a = LayerArgs{Pk + d.off_lin[l], d.Lp, PROJ / 16, 1, d.Lp / 16, 0, 0, nullptr, 0,
+                      bufA, A_LD, 0, bufP, P_LD, P_CUR, nullptr, nullptr};
+        layer<MTT, false>(a);
+        __syncthreads();
+        {   // FIR + skip: thread = (channel, quarter of the tile's frames)
+            const int ch = tid >> 2, fq = tid & 3;
+            constexpr int FPT = NF / 4;
+            const float *wf = Pk + d.off_fir[l] + ch * LORDER;
+            float w[LORDER];
+#pragma unroll
+            for (int k = 0; k < LORDER; ++k) w[k] = wf[k];
+            const float *seq = bufP + ch * P_LD + 1 + fq * FPT;       // seq[s], s = t + k
+            float win[FPT + HIST];
+#pragma unroll
+            for (int s = 0; s < FPT + HIST; ++s) win[s] = seq[s];
+#pragma unroll
+            for (int t = 0; t < FPT; ++t) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < LORDER; ++k) s = fmaf(w[k], win[t + k], s);
+                bufB[ch * A_LD + fq * FPT + t] = win[t + HIST] + s;
+            }
+            // new cache = last 19 entries of (history ++ valid frames)
+            for (int e = tid; e < PROJ * HIST; e += THREADS) {
+                const int c2 = e / HIST, h = e - c2 * HIST;
+                cout[l][e] = bufP[c2 * P_LD + 1 + nvalid + h];
+            }
+        }
+        __syncthreads();
+        a = LayerArgs{Pk + d.off_aff[l], PROJ, d.Lp / 16, 1, PROJ / 16, 0, 0, Pk + d.off_baff[l], 1,
+                      bufB, A_LD, 0, bufA, A_LD, 0, nullptr, nullptr};
+        layer<MTT, false>(a);
+        __syncthreads();
+    }
+    a = LayerArgs{Pk + d.off_out1, d.Lp, d.A2p / 16, 1, d.Lp / 16, 0, 0, Pk + d.off_bo1, 0,
+                  bufA, A_LD, 0, bufB, A_LD, 0, nullptr, nullptr};
+    layer<MTT, false>(a);
+    __syncthreads();
+    a = LayerArgs{Pk + d.off_out2, d.A2p, d.Op / 16, 1, d.A2p / 16, 0, 0, Pk + d.off_bo2, 0,
+                  bufB, A_LD, 0, bufA, A_LD, 0, nullptr, nullptr};
+    layer<MTT, false>(a);
+    __syncthreads();
+
+    // ---- softmax over the O logits of each frame, keep class 0: thread = (part 0..7, frame 0..63)
+    {
+        const int m = tid & 63, part = tid >> 6;
+        float mx = -INFINITY;
+        if (m < NF) for (int n = part; n < d.O; n += NW) mx = fmaxf(mx, bufA[n * A_LD + m]);
+        red[part * 64 + m] = mx;
+        __syncthreads();
+        float gm = red[m];
+#pragma unroll
+        for (int p2 = 1; p2 < NW; ++p2) gm = fmaxf(gm, red[p2 * 64 + m]);
+        __syncthreads();
+        float sm = 0.f;
+        if (m < NF) for (int n = part; n < d.O; n += NW) sm += expf(bufA[n * A_LD + m] - gm);
+        red[part * 64 + m] = sm;
+        __syncthreads();
+        if (part == 0 && m < nvalid) {
+            float tot = 0.f;
+#pragma unroll
+            for (int p2 = 0; p2 < NW; ++p2) tot += red[p2 * 64 + m];
+            ps[f0 + m] = expf(bufA[m] - gm) / tot;
+        }
+        __syncthreads();
+    }
+}
+
+// score gate of one chunk (FSMN/Export_FSMN_VAD.py:87-101): returns noisy_dB (NaN if no frame is "noise")
+__device__ __forceinline__ float gate(const Dev &d, const float *ps, const float *__restrict__ db, float thr,
+                                      float noise_db, unsigned char *__restrict__ score_out, float *__restrict__ psil_out,
+                                      float *sc, float *red) {
+    const int tid = threadIdx.x;
+    float part_sum = 0.f, part_cnt = 0.f;
+    if (tid < 128) {
+        for (int t = tid; t < d.T; t += 128) {
+            const float p = ps[t];
+            float s;
+            if (d.ratio > 1.0f) s = p + powf(p, d.ratio);
+            else if (d.ratio < 1.0f) s = p + 1.0f;
+            else s = p + p;
+            const float e = db[t];
+            const bool cond = (s <= thr) && (e >= noise_db);
+            sc[t] = cond ? 1.f : 0.f;
+            if (score_out) score_out[t] = cond ? 1 : 0;
+            if (psil_out) psil_out[t] = p;
+            if (!cond) { part_sum += e; part_cnt += 1.f; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { part_sum += __shfl_xor(part_sum, o); part_cnt += __shfl_xor(part_cnt, o); }
+        if ((tid & 63) == 0) { red[(tid >> 6) * 2] = part_sum; red[(tid >> 6) * 2 + 1] = part_cnt; }
+    }
+    __syncthreads();
+    const float tot = red[0] + red[2], cnt = red[1] + red[3];
+    __syncthreads();
+    return tot / cnt;                      // 0/0 -> NaN like torch's mean of an empty tensor
+}
+
+__device__ __forceinline__ void run_chunk(const Dev &d, const float *Pk, const float *lm, const float *const *cin,
+                                          float *const *cout, float *lds) {
+    float *bufA = lds, *bufB = lds + BUFA, *bufP = bufB + BUFB, *small = bufP + BUFP;
+    float *ps = small, *red = small + 128;
+    int f0 = 0;
+    bool first = true;
+    while (f0 < d.T) {
+        const int left = d.T - f0;
+        const float *const *ci = first ? cin : cout;         // later tiles continue from the updated cache
+        if (left > 48) tile<4>(d, Pk, lm, f0, left < 64 ? left : 64, ci, cout, bufA, bufB, bufP, ps, red), f0 += 64;
+        else if (left > 32) tile<3>(d, Pk, lm, f0, left, ci, cout, bufA, bufB, bufP, ps, red), f0 += 48;
+        else if (left > 16) tile<2>(d, Pk, lm, f0, left, ci, cout, bufA, bufB, bufP, ps, red), f0 += 32;
+        else tile<1>(d, Pk, lm, f0, left, ci, cout, bufA, bufB, bufP, ps, red), f0 += 16;
+        first = false;
+    }
+}
+
+struct RunArgs {
+    const float *logmel, *db;             // [B][T][80], [B][T]
+    const float *cin[NLAYER]; float *cout[NLAYER];   // each [B][128][19]
+    const float *thr, *noise_db;          // [B]
+    unsigned char *score; float *noisy_db, *psil;    // [B][T], [B], [B][T] (psil optional)
+};
+
+// ORT-boundary equivalent: one chunk per stream, B independent streams.
+__global__ __launch_bounds__(THREADS, 2) void fsmn_run_kernel(Dev d, const float *__restrict__ Pk, RunArgs r) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x;
+    const float *cin[NLAYER]; float *cout[NLAYER];
+#pragma unroll
+    for (int l = 0; l < NLAYER; ++l) { cin[l] = r.cin[l] + (size_t)b * PROJ * HIST; cout[l] = r.cout[l] + (size_t)b * PROJ * HIST; }
+    run_chunk(d, Pk, r.logmel + (size_t)b * d.T * NMEL, cin, cout, lds);
+    float *small = lds + BUFA + BUFB + BUFP;
+    const float noisy = gate(d, small, r.db + (size_t)b * d.T, r.thr[b], r.noise_db[b], r.score + (size_t)b * d.T,
+                             r.psil ? r.psil + (size_t)b * d.T : nullptr, small + 640, small + 128);
+    if (threadIdx.x == 0) r.noisy_db[b] = noisy;
+}
+
+struct ClipArgs {
+    const float *logmel, *db;             // [B*W][T][80], [B*W][T]
+    float *cache;                         // scratch [B][4][128][19]
+    int W, slide, lb;                     // windows per clip, slide_range, look_backward
+    float thr, noise0, snr;               // one_minus_speech_threshold, initial noise floor (x0.1), SNR (x0.1)
+    double speaking, silence_score;
+    unsigned char *flags;                 // [B][W*slide + (T - slide)] silence flags
+    float *noise_trace;                   // optional [B][W]
+};
+
+// Whole clips: the reference's while-loop (Inference_FSMN_VAD_ONNX.py:176-234), one workgroup per clip.
+__global__ __launch_bounds__(THREADS, 2) void fsmn_clips_kernel(Dev d, const float *__restrict__ Pk, ClipArgs c) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float *small = lds + BUFA + BUFB + BUFP;
+    float *ps = small, *red = small + 128, *sc = small + 640, *cnt = small + 768;
+    float *cbase = c.cache + (size_t)b * NLAYER * PROJ * HIST;
+    for (int e = tid; e < NLAYER * PROJ * HIST; e += THREADS) cbase[e] = 0.f;
+    __syncthreads();
+    const float *cin[NLAYER]; float *cout[NLAYER];
+#pragma unroll
+    for (int l = 0; l < NLAYER; ++l) { cin[l] = cbase + l * PROJ * HIST; cout[l] = cbase + l * PROJ * HIST; }
+    float noise = c.noise0;
+    int silence = 1;                       // carried by thread 0
+    const int nflags = c.W * c.slide + (d.T - c.slide);
+    unsigned char *fl = c.flags + (size_t)b * nflags;
+    for (int k = 0; k < c.W; ++k) {
+        const size_t widx = (size_t)b * c.W + k;
+        run_chunk(d, Pk, c.logmel + widx * d.T * NMEL, cin, cout, lds);
+        const float noisy = gate(d, ps, c.db + widx * d.T, c.thr, noise, nullptr, nullptr, sc, red);
+        // look-ahead vote: cnt[i] = #{ j in [1,lb) : sc[i+j] != 0 }
+        if (tid < c.slide) {
+            float s = 0.f;
+            for (int j = 1; j < c.lb; ++j) s += sc[tid + j];
+            cnt[tid] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double inv_lb = 1.0 / (double)c.lb;
+            for (int i = 0; i < c.slide; ++i) {
+                if (silence) {
+                    if (sc[i] != 0.f) silence = !((1.0 + (double)cnt[i]) * inv_lb >= c.speaking);
+                    else silence = 1;
+                } else {
+                    if (sc[i] != 1.f) silence = !((1.0 + (double)((c.lb - 1) - cnt[i])) * inv_lb <= c.silence_score);
+                    else silence = 0;
+                }
+                fl[k * c.slide + i] = (unsigned char)silence;
+            }
+            if (k == c.W - 1)              // tail of the final chunk: plain rule (:223-234)
+                for (int i = c.slide; i < d.T; ++i) {
+                    silence = silence ? !(sc[i] != 0.f) : (sc[i] != 1.f);
+                    fl[c.W * c.slide + (i - c.slide)] = (unsigned char)silence;
+                }
+        }
+        if (noisy > 0.0f) noise = 0.5f * ((noise + noisy) + c.snr);
+        if (c.noise_trace && tid == 0) c.noise_trace[widx] = noise;
+        __syncthreads();
+    }
+}
+
+// frame energy in dB/10 of the prepped window (FSMN/Export_FSMN_VAD.py:93-97): one workgroup per window
+__global__ void fsmn_energy_kernel(const int16_t *__restrict__ audio, long long row_stride, long long win_stride,
+                                   int windows_per_clip, int window_len, int n_fft, int hop, int T,
+                                   const float *__restrict__ means, float inv_ref, float *__restrict__ db) {
+    const int widx = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
+    const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
+    const float mean = means[widx];
+    const int nfr = (window_len - n_fft) / hop + 1;
+    float *out = db + (size_t)widx * T;
+    for (int f = wave; f < T; f += nw) {
+        const int ff = f < nfr ? f : nfr - 1;          // last value repeated up to T frames
+        float s = 0.f;
+        for (int k = lane; k < n_fft; k += 64) {
+            const int n = ff * hop + k;
+            const float a = __fsub_rn((float)win[n], mean);
+            float y = a;
+            if (n > 0) y = __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn((float)win[n - 1], mean)));
+            y = __fmul_rn(y, inv_ref);
+            s = fmaf(y, y, s);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) out[f] = log10f(s + 0.00002f);
+    }
+}
+
+}  // namespace fsmn
+}  // namespace vadx
+
+using namespace vadx::fsmn;
+
+extern "C" size_t vadx_fsmn_packed_floats(const vadx_fsmn_dims *dims) {
+    Dev d;
+    if (!dims || derive(dims, &d)) return 0;
+    return (size_t)d.total;
+}
+
+extern "C" int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_weights_host *w, float *p) {
+    Dev d;
+    VADX_REQUIRE(dims && w && p, "vadx_fsmn_pack_host: NULL argument");
+    VADX_REQUIRE(derive(dims, &d) == 0, "vadx_fsmn_pack_host: unsupported dims (affine <= 144, linear/output <= 256)");
+    memset(p, 0, sizeof(float) * d.total);
+    auto mat = [&](int off, const float *src, int rows, int cols, int ld) {
+        for (int r = 0; r < rows; ++r) memcpy(p + off + (size_t)r * ld, src + (size_t)r * cols, cols * sizeof(float));
+    };
+    VADX_REQUIRE(w->in1_w && w->in1_b && w->in2_w && w->in2_b && w->out1_w && w->out1_b && w->out2_w && w->out2_b &&
+                 w->cmvn_means && w->cmvn_vars, "vadx_fsmn_pack_host: NULL weight pointer");
+    mat(d.off_in1, w->in1_w, d.A, 400, 400); memcpy(p + d.off_b1, w->in1_b, d.A * sizeof(float));
+    memcpy(p + d.off_mean, w->cmvn_means, 400 * sizeof(float)); memcpy(p + d.off_var, w->cmvn_vars, 400 * sizeof(float));
+    mat(d.off_in2, w->in2_w, d.L, d.A, d.Ap); memcpy(p + d.off_b2, w->in2_b, d.L * sizeof(float));
+    for (int l = 0; l < NLAYER; ++l) {
+        VADX_REQUIRE(w->lin_w[l] && w->fir_w[l] && w->aff_w[l] && w->aff_b[l], "vadx_fsmn_pack_host: NULL layer %d weight", l);
+        mat(d.off_lin[l], w->lin_w[l], PROJ, d.L, d.Lp);
+        memcpy(p + d.off_fir[l], w->fir_w[l], PROJ * LORDER * sizeof(float));
+        mat(d.off_aff[l], w->aff_w[l], d.L, PROJ, PROJ); memcpy(p + d.off_baff[l], w->aff_b[l], d.L * sizeof(float));
+    }
+    mat(d.off_out1, w->out1_w, d.A2, d.L, d.Lp); memcpy(p + d.off_bo1, w->out1_b, d.A2 * sizeof(float));
+    mat(d.off_out2, w->out2_w, d.O, d.A2, d.A2p); memcpy(p + d.off_bo2, w->out2_b, d.O * sizeof(float));
+    return VADX_OK;
+}
+
+static int set_lds_attr() {
+    static bool done = false;
+    if (!done) {
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fsmn_run_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fsmn_clips_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));
+        done = true;
+    }
+    return VADX_OK;
+}
+
+extern "C" int vadx_fsmn_energy(const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
+                                int windows_per_clip, int window_len, int frames, const float *means, float *db,
+                                void *stream) {
+    VADX_REQUIRE(audio && means && db, "vadx_fsmn_energy: NULL argument");
+    VADX_REQUIRE(batch > 0 && windows_per_clip > 0 && window_len >= 512 && frames > 0, "vadx_fsmn_energy: bad shape");
+    const float inv_ref = (float)(1.0 / (sqrt((double)window_len) * 2e-5));
+    hipLaunchKernelGGL(fsmn_energy_kernel, dim3((unsigned)(batch * windows_per_clip)), dim3(512), 0,
+                       static_cast<hipStream_t>(stream), audio, (long long)row_stride, (long long)win_stride,
+                       windows_per_clip, window_len, 512, 160, frames, means, inv_ref, db);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+extern "C" int vadx_fsmn_run(const vadx_fsmn_dims *dims, const float *packed, const float *logmel, const float *db,
+                             const float *const cache_in[4], float *const cache_out[4], const float *thr,
+                             const float *noise_db, int batch, uint8_t *score, float *noisy_db, float *psil,
+                             void *stream) {
+    Dev d;
+    VADX_REQUIRE(dims && packed && logmel && db && cache_in && cache_out && thr && noise_db && score && noisy_db,
+                 "vadx_fsmn_run: NULL argument");
+    VADX_REQUIRE(derive(dims, &d) == 0, "vadx_fsmn_run: unsupported dims");
+    VADX_REQUIRE(batch > 0, "vadx_fsmn_run: batch must be positive");
+    int rc = set_lds_attr();
+    if (rc) return rc;
+    RunArgs r;
+    r.logmel = logmel; r.db = db; r.thr = thr; r.noise_db = noise_db; r.score = score; r.noisy_db = noisy_db; r.psil = psil;
+    for (int l = 0; l < NLAYER; ++l) {
+        VADX_REQUIRE(cache_in[l] && cache_out[l], "vadx_fsmn_run: NULL cache %d", l);
+        r.cin[l] = cache_in[l]; r.cout[l] = cache_out[l];
+    }
+    hipLaunchKernelGGL(fsmn_run_kernel, dim3(batch), dim3(THREADS), LDS_FLOATS * sizeof(float),
+                       static_cast<hipStream_t>(stream), d, packed, r);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+extern "C" int vadx_fsmn_clips(const vadx_fsmn_dims *dims, const float *packed, const float *logmel, const float *db,
+                               int batch, int windows_per_clip, const vadx_fsmn_loop_params *lp, float *cache_ws,
+                               uint8_t *flags, float *noise_trace, void *stream) {
+    Dev d;
+    VADX_REQUIRE(dims && packed && logmel && db && lp && cache_ws && flags, "vadx_fsmn_clips: NULL argument");
+    VADX_REQUIRE(derive(dims, &d) == 0, "vadx_fsmn_clips: unsupported dims");
+    VADX_REQUIRE(batch > 0 && windows_per_clip > 0, "vadx_fsmn_clips: batch/windows must be positive");
+    VADX_REQUIRE(lp->look_backward >= 1 && lp->look_backward < d.T && d.T - lp->look_backward <= 128 && d.T <= 112,
+                 "vadx_fsmn_clips: look_backward=%d frames=%d unsupported", lp->look_backward, d.T);
+    int rc = set_lds_attr();
+    if (rc) return rc;
+    ClipArgs c;
+    c.logmel = logmel; c.db = db; c.cache = cache_ws; c.W = windows_per_clip; c.lb = lp->look_backward;
+    c.slide = d.T - lp->look_backward; c.thr = lp->one_minus_speech_threshold; c.noise0 = lp->noise_db_init;
+    c.snr = lp->snr_threshold; c.speaking = lp->speaking_score; c.silence_score = lp->silence_score;
+    c.flags = flags; c.noise_trace = noise_trace;
+    hipLaunchKernelGGL(fsmn_clips_kernel, dim3(batch), dim3(THREADS), LDS_FLOATS * sizeof(float),
+                       static_cast<hipStream_t>(stream), d, packed, c);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
