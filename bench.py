@@ -185,7 +185,7 @@ def main():
     def step(ev=None):
         if ev:
             ev[0].record()
-        _lib.check(L.vadx_silero_encode(eng.packed.data_ptr(), audio.data_ptr(), B, SAMPLES, audio.stride(0),
+        _lib.check(L.vadx_silero_encode(eng.packed.data_ptr(), audio.data_ptr(), B, SAMPLES, _lib.row_stride(audio),
                                         ws.data_ptr(), ws.numel(), st))
         if ev:
             ev[1].record()

@@ -115,3 +115,8 @@ def require_gpu():
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def row_stride(t):
+    """Element stride between rows of a contiguous [B, N] tensor (size-1 dims may report any stride)."""
+    return int(t.stride(0)) if t.shape[0] > 1 and t.stride(0) >= t.shape[1] else int(t.shape[1])

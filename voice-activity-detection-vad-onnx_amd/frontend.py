@@ -89,7 +89,7 @@ class Frontend:
         means = t.empty((B * W,), dtype=t.float32, device=self.device) if self.cfg.prep != 1 else None
         with t.cuda.device(self.device):
             _lib.check(_lib.lib().vadx_frontend_logmel(C.byref(self.cfg), self.packed.data_ptr(), self.mel_kb.ctypes.data,
-                                                       a.data_ptr(), a.stride(0), ws, B, W,
+                                                       a.data_ptr(), _lib.row_stride(a), ws, B, W,
                                                        None if means is None else means.data_ptr(), out.data_ptr(),
                                                        _lib.stream_ptr()))
         return out

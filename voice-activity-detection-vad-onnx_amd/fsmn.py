@@ -70,9 +70,9 @@ class FsmnEngine:
         L = _lib.lib()
         with t.cuda.device(self.device):
             _lib.check(L.vadx_frontend_logmel(C.byref(fe.cfg), fe.packed.data_ptr(), fe.mel_kb.ctypes.data, a.data_ptr(),
-                                              a.stride(0), int(stride), B, W, means.data_ptr(), logmel.data_ptr(),
+                                              _lib.row_stride(a), int(stride), B, W, means.data_ptr(), logmel.data_ptr(),
                                               _lib.stream_ptr()))
-            _lib.check(L.vadx_fsmn_energy(a.data_ptr(), a.stride(0), int(stride), B, W, self.L, self.T, means.data_ptr(),
+            _lib.check(L.vadx_fsmn_energy(a.data_ptr(), _lib.row_stride(a), int(stride), B, W, self.L, self.T, means.data_ptr(),
                                           db.data_ptr(), _lib.stream_ptr()))
         return logmel, db
 

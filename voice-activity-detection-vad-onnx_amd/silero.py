@@ -117,7 +117,7 @@ class SileroEngine:
         state_n = t.empty((2, B, HIDDEN), dtype=t.float32, device=self.device) if return_state else None
         ws = self._workspace(B, steps)
         with t.cuda.device(self.device):
-            _lib.check(_lib.lib().vadx_silero_clips(self.packed.data_ptr(), audio.data_ptr(), B, n, audio.stride(0),
+            _lib.check(_lib.lib().vadx_silero_clips(self.packed.data_ptr(), audio.data_ptr(), B, n, _lib.row_stride(audio),
                                                     probs.data_ptr(), None if state_n is None else state_n.data_ptr(),
                                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
         return (probs, state_n) if return_state else probs
@@ -130,7 +130,7 @@ class SileroEngine:
         steps = (n + NUM_SAMPLES - 1) // NUM_SAMPLES
         ws = self._workspace(B, steps)
         with t.cuda.device(self.device):
-            _lib.check(_lib.lib().vadx_silero_encode(self.packed.data_ptr(), audio.data_ptr(), B, n, audio.stride(0),
+            _lib.check(_lib.lib().vadx_silero_encode(self.packed.data_ptr(), audio.data_ptr(), B, n, _lib.row_stride(audio),
                                                      ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
         return B, steps
 
