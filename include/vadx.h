@@ -192,6 +192,46 @@ int vadx_fsmn_clips(const vadx_fsmn_dims *dims, const float *packed, const float
                     uint8_t *flags, float *noise_trace, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * FireRedVAD / FireRedAED DetectModel and VadPostprocessor (row a16)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vadx_firered_cfg {        /* checkpoint `args` (FireRedVAD/Export_FireRedVAD.py:336-337) */
+    int idim, R, M, H, P, N1, S1, N2, S2, odim;
+    int frames;                           /* frames per window: (L-400)//160+1 = 98 */
+} vadx_firered_cfg;
+
+typedef struct vadx_firered_weights_host {   /* torch layouts, 1x1 convs as [out][in] */
+    const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;          /* dfsmn.fc1 (CMVN already folded), dfsmn.fc2 */
+    const float *fsmn_lb[16], *fsmn_la[16];              /* [P][N1], [P][N2] depthwise filters per FSMN */
+    const float *blk_fc1_w[16], *blk_fc1_b[16], *blk_fc2_w[16];   /* DFSMNBlock r = 1..R-1 (index 0 unused) */
+    const float *dnn_w[4], *dnn_b[4];
+    const float *out_w, *out_b;
+} vadx_firered_weights_host;
+
+size_t vadx_firered_packed_floats(const vadx_firered_cfg *cfg);
+int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_firered_weights_host *w, float *packed_host);
+/* logmel f32 [windows][frames][80] (vadx_frontend_logmel, 'firered' geometry) -> probs f32 [windows][odim][frames].
+ * Replaces ort_session_A.run([probs], {audio}), FireRedVAD/Inference_FireRed_ONNX.py:567-572
+ * (graph: FireRedVAD/Export_FireRedVAD.py:420-467 after the front-end). */
+int vadx_firered_run(const vadx_firered_cfg *cfg, const float *packed, const float *logmel, int windows,
+                     float *probs, void *stream);
+
+typedef struct vadx_vadpost_params {     /* VadPostprocessor.__init__, Inference_FireRed_ONNX.py:108-120 */
+    int   smooth_window_size;
+    float prob_threshold;
+    int   min_speech_frame, max_speech_frame, min_silence_frame, merge_silence_frame, extend_speech_frame;
+} vadx_vadpost_params;
+
+size_t vadx_vadpost_workspace_bytes(int batch, int stride);
+/* probs f32 [B][stride] (n_frames[b] valid) -> decisions i8 [B][stride] + (start_frame, end_frame)
+ * int32 pairs [B][cap][2] + counts [B]; one clip per thread.
+ * Replaces VadPostprocessor.process + the edge extraction of decision_to_segment
+ * (Inference_FireRed_ONNX.py:122-168, 181-304; MarbleNet copy Inference_NVIDIA_...:160-353);
+ * the float32 seconds arithmetic + round(,3) of decision_to_segment :169-179 stays on the host. */
+int vadx_vadpost(const vadx_vadpost_params *prm, const float *probs, int stride, const int32_t *n_frames,
+                 int batch, int8_t *decisions, int32_t *segments, int32_t *counts, int cap,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Test hooks (used by tests/ only)
  * ------------------------------------------------------------------------------------------- */
 /* C[M][N] = A[M][K] * W[N][K]^T through the same LDS/MFMA tile helper the nets use.

@@ -1,0 +1,88 @@
+"""GPU parity: FireRed DetectModel + device VadPostprocessor vs reference fixtures / oracle."""
+import numpy as np
+import pytest
+import torch
+
+import vadx  # noqa: F401
+from vadx import firered, vadpost, weights
+from oracle import firered as ofr
+from oracle import postproc as opp
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+CFGS = {1234: weights.FIRERED_CFG, 7: dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=2, N2=4, S2=3),
+        9: dict(weights.FIRERED_CFG, R=2, M=1, H=48, P=24, N1=5, S1=1, N2=0, S2=0, odim=3)}
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+@pytest.mark.parametrize("seed", [1234, 7, 9])
+def test_session_matches_reference_fixture(golden, seed):
+    """The reference's own validate_export input (randint(-8000,8000), seed 1234) and two other
+    architectures (dilated taps, no look-ahead, 3 output heads = AED)."""
+    g = golden("firered_forward")
+    sess = firered.FireRedSession(weights.firered_synthetic(seed, CFGS[seed]))
+    assert sess.get_inputs()[0].name == "audio" and sess._inputs_meta[0].shape[-1] == 16000
+    probs = sess.run([sess.get_outputs()[0].name], {"audio": g[f"s{seed}_audio"]})[0]
+    assert probs.shape == g[f"s{seed}_probs"].shape
+    np.testing.assert_allclose(probs, g[f"s{seed}_probs"], rtol=0, atol=ATOL)
+    with pytest.raises(ValueError):
+        sess.run(None, {"audio": g[f"s{seed}_audio"].astype(np.float32)})
+
+
+def test_vadpostprocessor_matches_reference(golden):
+    g = golden("vadpost")
+    n_cases = int(g["n_cases"])
+    for c, cfg in enumerate(g["cfgs_f"]):
+        pp = vadpost.VadPostprocessor(int(cfg[0]), float(cfg[1]), *[int(v) for v in cfg[2:7]])
+        for i in range(n_cases):
+            dec = pp.process(g[f"probs_{i}"])
+            assert np.array_equal(dec, g[f"f{c}_dec_{i}"]), (c, i)
+            wav = float(g[f"f{c}_wav_{i}"])
+            seg = pp.decision_to_segment(dec, None if wav < 0 else wav)
+            assert np.array_equal(np.array(seg, dtype=np.float64).reshape(-1, 2), g[f"f{c}_seg_{i}"]), (c, i)
+    for c, cfg in enumerate(g["cfgs_m"]):
+        pp = vadpost.VadPostprocessor(int(cfg[0]), float(cfg[1]), *[int(v) for v in cfg[2:7]],
+                                      frame_shift_s=float(cfg[7]), frame_length_s=None)
+        for i in range(n_cases):
+            dec = pp.process(g[f"probs_{i}"])
+            assert np.array_equal(dec, g[f"m{c}_dec_{i}"]), (c, i)
+            wav = float(g[f"m{c}_wav_{i}"])
+            seg = pp.decision_to_segment(dec, None if wav < 0 else wav)
+            assert np.array_equal(np.array(seg, dtype=np.float64).reshape(-1, 2), g[f"m{c}_seg_{i}"]), (c, i)
+    # ragged batch in one launch == the single-track results
+    tracks = [g[f"probs_{i}"] for i in range(n_cases) if len(g[f"probs_{i}"])]
+    S = max(len(p) for p in tracks)
+    batch = np.zeros((len(tracks), S), np.float32)
+    for k, p in enumerate(tracks):
+        batch[k, :len(p)] = p
+    pp = vadpost.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0)
+    dec, segs, counts = pp.process_batch(batch, [len(p) for p in tracks], cap=1)
+    for k, p in enumerate(tracks):
+        want = opp.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0).process(p)
+        assert np.array_equal(dec[k, :len(p)].cpu().numpy(), want), k
+
+
+@pytest.mark.parametrize("n", [160000, 89431, 5000, 300])
+def test_whole_clip_segments(n):
+    eng = firered.FireRedEngine(weights.firered_synthetic(1234))
+    fe = ofr.Frontend()
+    ow = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in weights.firered_synthetic(1234).items()}
+    B = 3
+    clips = weights.burst_clips(B, n, seed=n)
+    noise = np.random.default_rng(4).standard_normal((B, 20000))
+    got, track, dec = eng.detect(clips, pad_noise=noise, return_probs=True) if firered.valid_frame_count(n) else (eng.detect(clips, pad_noise=noise), None, None)
+    for b in range(B):
+        want_seg, want_p, want_dec = ofr.run_clip(fe, ow, clips[b], noise[b])
+        if track is not None:
+            np.testing.assert_allclose(track[b].cpu().numpy(), want_p, rtol=0, atol=ATOL)
+            # decisions bit-exact when the device scores are post-processed by the oracle too
+            d2 = opp.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0).process(track[b].cpu().numpy())
+            assert np.array_equal(dec[b].cpu().numpy(), d2)
+            if np.array_equal(d2, want_dec):
+                assert got[b] == want_seg
+                assert [(int(s * 16000), int(e * 16000)) for s, e in got[b]] == [(int(s * 16000), int(e * 16000)) for s, e in want_seg]
+        else:
+            assert got[b] == want_seg == []

@@ -55,6 +55,23 @@ class FsmnLoopParams(C.Structure):
                 ("silence_score", C.c_double)]
 
 
+class FireRedCfg(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("idim", "R", "M", "H", "P", "N1", "S1", "N2", "S2", "odim", "frames")]
+
+
+class FireRedWeightsHost(C.Structure):
+    _fields_ = [("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p), ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p),
+                ("fsmn_lb", C.c_void_p * 16), ("fsmn_la", C.c_void_p * 16), ("blk_fc1_w", C.c_void_p * 16),
+                ("blk_fc1_b", C.c_void_p * 16), ("blk_fc2_w", C.c_void_p * 16), ("dnn_w", C.c_void_p * 4),
+                ("dnn_b", C.c_void_p * 4), ("out_w", C.c_void_p), ("out_b", C.c_void_p)]
+
+
+class VadPostParams(C.Structure):
+    _fields_ = [("smooth_window_size", C.c_int), ("prob_threshold", C.c_float), ("min_speech_frame", C.c_int),
+                ("max_speech_frame", C.c_int), ("min_silence_frame", C.c_int), ("merge_silence_frame", C.c_int),
+                ("extend_speech_frame", C.c_int)]
+
+
 _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/vadx.h declares
@@ -78,6 +95,11 @@ SIGNATURES = {
     "vadx_fsmn_run": (_I, [C.POINTER(FsmnDims), _P, _P, _P, C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p * 4),
                            _P, _P, _I, _P, _P, _P, _P]),
     "vadx_fsmn_clips": (_I, [C.POINTER(FsmnDims), _P, _P, _P, _I, _I, C.POINTER(FsmnLoopParams), _P, _P, _P, _P]),
+    "vadx_firered_packed_floats": (_Z, [C.POINTER(FireRedCfg)]),
+    "vadx_firered_pack_host": (_I, [C.POINTER(FireRedCfg), C.POINTER(FireRedWeightsHost), _P]),
+    "vadx_firered_run": (_I, [C.POINTER(FireRedCfg), _P, _P, _I, _P, _P]),
+    "vadx_vadpost_workspace_bytes": (_Z, [_I, _I]),
+    "vadx_vadpost": (_I, [C.POINTER(VadPostParams), _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "vadx_test_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
 }
 

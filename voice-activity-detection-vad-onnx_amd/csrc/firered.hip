@@ -1,0 +1,340 @@
+// firered.hip -- FireRedVAD / FireRedAED DetectModel (channel-first DFSMN) for gfx950, plus the
+// VadPostprocessor decision kernel shared with MarbleNet.
+// Reference: FireRedVAD/Export_FireRedVAD.py:185-326 (FSMN / DFSMNBlock / DFSMN / DetectModel),
+// :420-467 (wrapper), FireRedVAD/Inference_FireRed_ONNX.py:102-304 (VadPostprocessor).
+//
+// One workgroup owns one stateless analysis window (T <= 112 frames, 98 for 16000 samples).
+// Activations stay in LDS k-major [channel][frame] for the whole stack:
+//   mem [P][T] (block input / FSMN output, updated in place), p [P][T] (FSMN input), h [H][32] tile.
+// Pointwise convs = f32-MFMA GEMMs over 32-frame tiles (weights streamed from L2); the dilated
+// depthwise look-back / look-ahead FIRs + skip run on the VALU over the whole window once per block.
+#include "common.h"
+#include "layers.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace vadx {
+namespace firered {
+
+constexpr int THREADS = 512;
+constexpr int NMEL = 80, MAX_R = 16, MAX_M = 4, MAX_ODIM = 4, MAX_T = 112;
+constexpr int M_LD = 116;               // mem / p row stride (112 + 4)
+constexpr int H_LD = 36;                // h tile row stride (32 + 4)
+constexpr int MAXP = 128, MAXH = 256;
+constexpr int MEM_F = MAXP * M_LD, P_F = MAXP * M_LD, H_F = MAXH * H_LD;
+constexpr int LDS_FLOATS = MEM_F + P_F + H_F;
+
+struct Dev {
+    int R, M, H, P, N1, S1, N2, S2, odim, T, Hp, Pp;
+    int off_fc1, off_fc1b, off_fc2, off_fc2b;
+    int off_lb[MAX_R], off_la[MAX_R], off_bfc1[MAX_R], off_bfc1b[MAX_R], off_bfc2[MAX_R];
+    int off_dnn[MAX_M], off_dnnb[MAX_M], off_out, off_outb, total;
+};
+
+static int r16(int x) { return (x + 15) & ~15; }
+
+static int derive(const vadx_firered_cfg *c, Dev *d) {
+    memset(d, 0, sizeof(*d));
+    if (c->idim != NMEL || c->R < 1 || c->R > MAX_R || c->M < 1 || c->M > MAX_M || c->H < 1 || c->P < 1 ||
+        c->N1 < 1 || c->N1 > 64 || c->S1 < 1 || c->N2 < 0 || c->N2 > 64 || (c->N2 > 0 && c->S2 < 1) ||
+        c->odim < 1 || c->odim > MAX_ODIM || c->frames < 1 || c->frames > MAX_T)
+        return -1;
+    d->R = c->R; d->M = c->M; d->H = c->H; d->P = c->P; d->N1 = c->N1; d->S1 = c->S1; d->N2 = c->N2; d->S2 = c->S2;
+    d->odim = c->odim; d->T = c->frames; d->Hp = r16(c->H); d->Pp = r16(c->P);
+    if (d->Hp > MAXH || d->Pp > MAXP) return -1;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    d->off_fc1 = take(d->Hp * NMEL); d->off_fc1b = take(d->Hp);
+    d->off_fc2 = take(d->Pp * d->Hp); d->off_fc2b = take(d->Pp);
+    for (int r = 0; r < d->R; ++r) {
+        d->off_lb[r] = take(d->Pp * d->N1);
+        d->off_la[r] = take(d->Pp * (d->N2 > 0 ? d->N2 : 1));
+        if (r > 0) { d->off_bfc1[r] = take(d->Hp * d->Pp); d->off_bfc1b[r] = take(d->Hp); d->off_bfc2[r] = take(d->Pp * d->Hp); }
+    }
+    for (int m = 0; m < d->M; ++m) { d->off_dnn[m] = take(d->Hp * (m == 0 ? d->Pp : d->Hp)); d->off_dnnb[m] = take(d->Hp); }
+    d->off_out = take(d->odim * d->Hp); d->off_outb = take(4);
+    d->total = o;
+    return 0;
+}
+
+// memory = p + lookback(p) + lookahead(p) (+ mem)   -- Export_FireRedVAD.py:213-236, :255-264
+__device__ __forceinline__ void fsmn_memory(const Dev &d, const float *__restrict__ Pk, int r, bool skip,
+                                            const float *p, float *mem) {
+    const float *wlb = Pk + d.off_lb[r], *wla = Pk + d.off_la[r];
+    for (int e = threadIdx.x; e < d.Pp * d.T; e += THREADS) {
+        const int ch = e / d.T, t = e - ch * d.T;
+        const float *row = p + ch * M_LD;
+        float lb = 0.f;
+        for (int k = 0; k < d.N1; ++k) {
+            const int idx = t + (k - (d.N1 - 1)) * d.S1;
+            if (idx >= 0) lb = fmaf(wlb[ch * d.N1 + k], row[idx], lb);
+        }
+        float s = row[t] + lb;
+        if (d.N2 > 0 && d.T > 1) {
+            float la = 0.f;
+            for (int k = 0; k < d.N2; ++k) {
+                const int idx = t + d.S2 + k * d.S2;
+                if (idx < d.T) la = fmaf(wla[ch * d.N2 + k], row[idx], la);
+            }
+            s += la;
+        }
+        if (skip) s += mem[ch * M_LD + t];
+        mem[ch * M_LD + t] = s;
+    }
+}
+
+// pointwise pair on every 32-frame tile of the window: h = relu(W1 x src + b1); dst = W2 x h (+b2, relu)
+__device__ __forceinline__ void pointwise_pair(const Dev &d, const float *W1, const float *b1, int k1b, const float *src,
+                                               const float *W2, const float *b2, int relu2, float *dst, float *h) {
+    for (int f0 = 0; f0 < d.T; f0 += 32) {
+        const bool half = (d.T - f0) <= 16;
+        LayerArgs a{W1, k1b * 16, d.Hp / 16, 1, k1b, 0, 0, b1, 1, src, M_LD, f0, h, H_LD, 0, nullptr, nullptr};
+        if (half) layer<1, false>(a); else layer<2, false>(a);
+        __syncthreads();
+        if (W2) {
+            LayerArgs c{W2, d.Hp, d.Pp / 16, 1, d.Hp / 16, 0, 0, b2, relu2, h, H_LD, 0, dst, M_LD, f0, nullptr, nullptr};
+            if (half) layer<1, false>(c); else layer<2, false>(c);
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float *__restrict__ Pk,
+                                                             const float *__restrict__ logmel, float *__restrict__ probs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *mem = lds, *p = lds + MEM_F, *h = p + P_F;
+    const int tid = threadIdx.x;
+    const float *lm = logmel + (size_t)blockIdx.x * d.T * NMEL;
+    // stage log-mel channel-first into `mem` rows 0..79; frames >= T are zero (finite operands)
+    for (int e = tid; e < MAX_T * NMEL; e += THREADS) {
+        const int t = e / NMEL, mel = e - t * NMEL;
+        mem[mel * M_LD + t] = t < d.T ? lm[(size_t)t * NMEL + mel] : 0.f;
+    }
+    for (int e = tid; e < MAXP * M_LD; e += THREADS) p[e] = 0.f;
+    __syncthreads();
+    // dfsmn.fc1 (80->H, ReLU) ; dfsmn.fc2 (H->P, bias, ReLU) ; fsmn1
+    pointwise_pair(d, Pk + d.off_fc1, Pk + d.off_fc1b, NMEL / 16, mem, Pk + d.off_fc2, Pk + d.off_fc2b, 1, p, h);
+    for (int e = tid; e < MAXP * M_LD; e += THREADS) mem[e] = 0.f;        // log-mel rows are dead now
+    __syncthreads();
+    fsmn_memory(d, Pk, 0, false, p, mem);
+    __syncthreads();
+    for (int r = 1; r < d.R; ++r) {      // DFSMNBlock: fc1 (P->H, ReLU) ; fc2 (H->P, no bias) ; fsmn + skip
+        pointwise_pair(d, Pk + d.off_bfc1[r], Pk + d.off_bfc1b[r], d.Pp / 16, mem, Pk + d.off_bfc2[r], nullptr, 0, p, h);
+        fsmn_memory(d, Pk, r, true, p, mem);
+        __syncthreads();
+    }
+    // dnns (P->H ReLU, then M-1 x H->H ReLU) and the 1x1 output conv + sigmoid, tile by tile
+    float *h2 = p;                        // p is dead: second H-tile buffer for M > 1
+    for (int f0 = 0; f0 < d.T; f0 += 32) {
+        const bool half = (d.T - f0) <= 16;
+        LayerArgs a{Pk + d.off_dnn[0], d.Pp, d.Hp / 16, 1, d.Pp / 16, 0, 0, Pk + d.off_dnnb[0], 1, mem, M_LD, f0, h, H_LD, 0, nullptr, nullptr};
+        if (half) layer<1, false>(a); else layer<2, false>(a);
+        __syncthreads();
+        float *cur = h, *nxt = h2;
+        for (int m = 1; m < d.M; ++m) {
+            LayerArgs c{Pk + d.off_dnn[m], d.Hp, d.Hp / 16, 1, d.Hp / 16, 0, 0, Pk + d.off_dnnb[m], 1, cur, H_LD, 0, nxt, H_LD, 0, nullptr, nullptr};
+            if (half) layer<1, false>(c); else layer<2, false>(c);
+            __syncthreads();
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        if (tid < 32 * d.odim) {
+            const int t = tid & 31, o = tid >> 5;
+            if (f0 + t < d.T) {
+                const float *wo = Pk + d.off_out + o * d.Hp;
+                float s = 0.f;
+                for (int c2 = 0; c2 < d.H; ++c2) s = fmaf(wo[c2], cur[c2 * H_LD + t], s);
+                s += Pk[d.off_outb + o];
+                probs[((size_t)blockIdx.x * d.odim + o) * d.T + f0 + t] = sigmoidf_(s);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- VadPostprocessor: one clip per thread, working arrays laid out [frame][clip] (coalesced) -------
+struct PostDev {
+    int ws, min_sp, max_sp, min_si, merge, extend;
+    float thr, inv_ws;
+};
+
+__global__ void vadpost_kernel(PostDev q, const float *__restrict__ probs, int stride, const int *__restrict__ nframes,
+                               int B, float *__restrict__ wsm, signed char *__restrict__ wdec,
+                               signed char *__restrict__ decisions, int *__restrict__ segs, int *__restrict__ counts, int cap) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n = nframes[b];
+    const float *pr = probs + (size_t)b * stride;
+#define SM(i) wsm[(size_t)(i) * B + b]
+#define DEC(i) wdec[(size_t)(i) * B + b]
+    counts[b] = 0;
+    if (n <= 0) return;
+    // smoothing: float32 running sum exactly like np.cumsum, expanding mean on the first ws-1 frames
+    if (q.ws > 1) {
+        float cs = 0.f;
+        for (int i = 0; i < n; ++i) { cs = __fadd_rn(cs, pr[i]); SM(i) = cs; }      // SM(i) = cumsum[i+1]
+        for (int i = n - 1; i >= 0; --i) {
+            float v;
+            if (i < q.ws - 1) v = __fdiv_rn(SM(i), (float)(i + 1));
+            else v = __fmul_rn(__fsub_rn(SM(i), (i - q.ws >= 0) ? SM(i - q.ws) : 0.f), q.inv_ws);
+            SM(i) = v;                    // descending order: SM(i - ws) is still a cumsum when read
+        }
+    } else {
+        for (int i = 0; i < n; ++i) SM(i) = pr[i];
+    }
+    // threshold + 4-state machine
+    if (q.min_sp <= 0 && q.min_si <= 0) {
+        for (int t = 0; t < n; ++t) DEC(t) = SM(t) >= q.thr ? 1 : 0;
+    } else {
+        int state = 0, t0 = 0, s0 = 0;
+        for (int t = 0; t < n; ++t) {
+            const bool hot = SM(t) >= q.thr;
+            if (state == 0) { if (hot) { state = 1; t0 = t; } }
+            else if (state == 1) {
+                if (hot) { if (t - t0 >= q.min_sp) { state = 2; for (int u = t0; u < t; ++u) DEC(u) = 1; } }
+                else state = 0;
+            } else if (state == 2) { if (!hot) { state = 3; s0 = t; } }
+            else { if (!hot) { if (t - s0 >= q.min_si) state = 0; } else state = 2; }
+            DEC(t) = state >= 2 ? 1 : 0;
+        }
+    }
+    // extend each rising edge left by the smoothing window
+    if (q.ws > 1)
+        for (int t = 1; t < n; ++t)
+            if (DEC(t) == 1 && DEC(t - 1) == 0) { for (int u = (t >= q.ws ? t - q.ws : 0); u < t; ++u) DEC(u) = 1; }
+    if (q.merge > 0) {
+        int g0 = -1;
+        for (int t = 1; t < n; ++t) {
+            const int a = DEC(t - 1), c = DEC(t);
+            if (a == 1 && c == 0 && g0 < 0) g0 = t;
+            else if (a == 0 && c == 1 && g0 >= 0) { if (t - g0 < q.merge) for (int u = g0; u < t; ++u) DEC(u) = 1; g0 = -1; }
+        }
+    }
+    if (q.extend > 0) {
+        int dist = q.extend + 1;
+        for (int t = 0; t < n; ++t) { if (DEC(t)) dist = 0; else if (++dist <= q.extend) DEC(t) = 1; }
+        dist = q.extend + 1;
+        for (int t = n - 1; t >= 0; --t) { if (DEC(t)) dist = 0; else if (++dist <= q.extend) DEC(t) = 1; }
+    }
+    // split segments longer than max_speech at the lowest raw probability of [pos+max/2, pos+max)
+    {
+        const int half = q.max_sp >> 1;
+        int t = 0;
+        while (t < n) {
+            if (!DEC(t)) { ++t; continue; }
+            const int a = t;
+            while (t < n && DEC(t)) ++t;
+            if (t - a > q.max_sp) {
+                int pos = a;
+                const int e = t;
+                while (pos + q.max_sp < e) {
+                    const int lo = pos + half, hi = (pos + q.max_sp < e) ? pos + q.max_sp : e;
+                    if (lo >= hi) break;
+                    int arg = lo;
+                    float best = pr[lo];
+                    for (int u = lo + 1; u < hi; ++u) if (pr[u] < best) { best = pr[u]; arg = u; }
+                    DEC(arg) = 0;
+                    pos = arg + 1;
+                }
+            }
+        }
+    }
+    // decisions out + (start_frame, end_frame) pairs (end = first frame after the run)
+    int ns = 0, start = -1;
+    for (int t = 0; t < n; ++t) {
+        const int v = DEC(t);
+        decisions[(size_t)b * stride + t] = (signed char)v;
+        if (v && start < 0) start = t;
+        if (!v && start >= 0) { if (ns < cap) { segs[((size_t)b * cap + ns) * 2] = start; segs[((size_t)b * cap + ns) * 2 + 1] = t; } ++ns; start = -1; }
+    }
+    if (start >= 0) { if (ns < cap) { segs[((size_t)b * cap + ns) * 2] = start; segs[((size_t)b * cap + ns) * 2 + 1] = n; } ++ns; }
+    counts[b] = ns;
+#undef SM
+#undef DEC
+}
+
+}  // namespace firered
+}  // namespace vadx
+
+using namespace vadx::firered;
+
+extern "C" size_t vadx_firered_packed_floats(const vadx_firered_cfg *cfg) {
+    Dev d;
+    if (!cfg || derive(cfg, &d)) return 0;
+    return (size_t)d.total;
+}
+
+extern "C" int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_firered_weights_host *w, float *p) {
+    Dev d;
+    VADX_REQUIRE(cfg && w && p, "vadx_firered_pack_host: NULL argument");
+    VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_firered_pack_host: unsupported config (idim 80, H<=256, P<=128, frames<=112, odim<=4)");
+    memset(p, 0, sizeof(float) * d.total);
+    auto mat = [&](int off, const float *src, int rows, int cols, int ld) {
+        for (int r = 0; r < rows; ++r) memcpy(p + off + (size_t)r * ld, src + (size_t)r * cols, cols * sizeof(float));
+    };
+    VADX_REQUIRE(w->fc1_w && w->fc1_b && w->fc2_w && w->fc2_b && w->out_w && w->out_b, "vadx_firered_pack_host: NULL weight pointer");
+    mat(d.off_fc1, w->fc1_w, d.H, NMEL, NMEL); memcpy(p + d.off_fc1b, w->fc1_b, d.H * sizeof(float));
+    mat(d.off_fc2, w->fc2_w, d.P, d.H, d.Hp); memcpy(p + d.off_fc2b, w->fc2_b, d.P * sizeof(float));
+    for (int r = 0; r < d.R; ++r) {
+        VADX_REQUIRE(w->fsmn_lb[r] && (d.N2 == 0 || w->fsmn_la[r]), "vadx_firered_pack_host: NULL FSMN filter %d", r);
+        memcpy(p + d.off_lb[r], w->fsmn_lb[r], (size_t)d.P * d.N1 * sizeof(float));
+        if (d.N2 > 0) memcpy(p + d.off_la[r], w->fsmn_la[r], (size_t)d.P * d.N2 * sizeof(float));
+        if (r > 0) {
+            VADX_REQUIRE(w->blk_fc1_w[r] && w->blk_fc1_b[r] && w->blk_fc2_w[r], "vadx_firered_pack_host: NULL block %d weight", r);
+            mat(d.off_bfc1[r], w->blk_fc1_w[r], d.H, d.P, d.Pp); memcpy(p + d.off_bfc1b[r], w->blk_fc1_b[r], d.H * sizeof(float));
+            mat(d.off_bfc2[r], w->blk_fc2_w[r], d.P, d.H, d.Hp);
+        }
+    }
+    for (int m = 0; m < d.M; ++m) {
+        VADX_REQUIRE(w->dnn_w[m] && w->dnn_b[m], "vadx_firered_pack_host: NULL dnn %d weight", m);
+        mat(d.off_dnn[m], w->dnn_w[m], d.H, m == 0 ? d.P : d.H, m == 0 ? d.Pp : d.Hp);
+        memcpy(p + d.off_dnnb[m], w->dnn_b[m], d.H * sizeof(float));
+    }
+    mat(d.off_out, w->out_w, d.odim, d.H, d.Hp); memcpy(p + d.off_outb, w->out_b, d.odim * sizeof(float));
+    return VADX_OK;
+}
+
+extern "C" int vadx_firered_run(const vadx_firered_cfg *cfg, const float *packed, const float *logmel, int windows,
+                                float *probs, void *stream) {
+    Dev d;
+    VADX_REQUIRE(cfg && packed && logmel && probs, "vadx_firered_run: NULL argument");
+    VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_firered_run: unsupported config");
+    VADX_REQUIRE(windows > 0, "vadx_firered_run: windows must be positive");
+    static bool done = false;
+    if (!done) {
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(firered_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));
+        done = true;
+    }
+    hipLaunchKernelGGL(firered_kernel, dim3(windows), dim3(THREADS), LDS_FLOATS * sizeof(float),
+                       static_cast<hipStream_t>(stream), d, packed, logmel, probs);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+extern "C" size_t vadx_vadpost_workspace_bytes(int batch, int stride) {
+    if (batch <= 0 || stride <= 0) return 0;
+    return (size_t)batch * stride * (sizeof(float) + 1) + 64;
+}
+
+extern "C" int vadx_vadpost(const vadx_vadpost_params *prm, const float *probs, int stride, const int32_t *n_frames,
+                            int batch, int8_t *decisions, int32_t *segments, int32_t *counts, int cap,
+                            void *workspace, size_t workspace_bytes, void *stream) {
+    VADX_REQUIRE(prm && probs && n_frames && decisions && segments && counts && workspace, "vadx_vadpost: NULL argument");
+    VADX_REQUIRE(batch > 0 && stride > 0 && cap > 0, "vadx_vadpost: batch/stride/cap must be positive");
+    if (workspace_bytes < vadx_vadpost_workspace_bytes(batch, stride)) {
+        vadx::set_error("vadx_vadpost: workspace %zu B < required %zu B", workspace_bytes, vadx_vadpost_workspace_bytes(batch, stride));
+        return VADX_ENOSPACE;
+    }
+    PostDev q;
+    q.ws = prm->smooth_window_size < 1 ? 1 : prm->smooth_window_size;
+    q.thr = prm->prob_threshold; q.min_sp = prm->min_speech_frame; q.max_sp = prm->max_speech_frame;
+    q.min_si = prm->min_silence_frame; q.merge = prm->merge_silence_frame; q.extend = prm->extend_speech_frame;
+    q.inv_ws = (float)(1.0 / (double)q.ws);
+    float *wsm = static_cast<float *>(workspace);
+    signed char *wdec = reinterpret_cast<signed char *>(wsm + (size_t)batch * stride);
+    hipLaunchKernelGGL(vadpost_kernel, dim3((batch + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), q, probs,
+                       stride, n_frames, batch, wsm, wdec, reinterpret_cast<signed char *>(decisions), segments, counts, cap);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}

@@ -12,6 +12,7 @@
 // overlapping windows of its clip in order, carrying the four FIR caches (global scratch = the
 // reference's cache_0..3 tensors) and the adaptive noise floor exactly like the reference loop.
 #include "common.h"
+#include "layers.h"
 
 #include <math.h>
 #include <string.h>
@@ -58,63 +59,6 @@ static int derive(const vadx_fsmn_dims *c, Dev *d) {
     d->off_out2 = take(d->Op * d->A2p); d->off_bo2 = take(d->Op);
     d->total = o;
     return 0;
-}
-
-struct LayerArgs {
-    const float *W; int ldw, ntiles;
-    int npass, kb, kstep, cstep;          // K passes: weights advance kstep floats, act columns cstep
-    const float *bias; int relu;
-    const float *act; int lda, acol0;
-    float *dst; int ldd, dcol0;
-    const float *add, *mul;               // CMVN (AFFINE only)
-};
-
-// dst[n][m] = act[k][m] x W[n][k] (+bias, ReLU).  Work items: whole n-tiles (all m-tiles of the tile)
-// when the n-tile count fills the 8 waves evenly, otherwise (n-tile, m-tile) pairs.
-template <int MTT, bool AFFINE>
-__device__ __noinline__ void layer(const LayerArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
-    if (a.ntiles % NW == 0) {
-        for (int nt = wave; nt < a.ntiles; nt += NW) {
-            f32x4 acc[1][MTT];
-#pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float *row = a.W + (size_t)(nt * 16 + i) * a.ldw;
-            for (int ps = 0; ps < a.npass; ++ps) {
-                const float *const wrow[1] = {row + ps * a.kstep};
-                int moff[MTT];
-#pragma unroll
-                for (int mt = 0; mt < MTT; ++mt) moff[mt] = a.acol0 + mt * 16 + ps * a.cstep;
-                gemm_rt<1, MTT, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
-                                               AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
-            }
-            const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) {
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = acc[0][mt][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
-                *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i) * a.ldd + a.dcol0 + mt * 16 + 4 * q) = v;
-            }
-        }
-    } else {
-        for (int item = wave; item < a.ntiles * MTT; item += NW) {
-            const int nt = item / MTT, mt = item - nt * MTT;
-            f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-            const float *row = a.W + (size_t)(nt * 16 + i) * a.ldw;
-            for (int ps = 0; ps < a.npass; ++ps) {
-                const float *const wrow[1] = {row + ps * a.kstep};
-                const int moff[1] = {a.acol0 + mt * 16 + ps * a.cstep};
-                gemm_rt<1, 1, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
-                                             AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
-            }
-            const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = acc[0][0][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
-            *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i) * a.ldd + a.dcol0 + mt * 16 + 4 * q) = v;
-        }
-    }
 }
 
 // One tile of MTT*16 frames starting at frame f0 (nvalid of them inside the chunk).

@@ -1,0 +1,93 @@
+"""VadPostprocessor on device (reference row a16): batched `process` + `decision_to_segment`.
+
+Same constructor arguments and results as the reference classes
+(FireRedVAD/Inference_FireRed_ONNX.py:102-304 -- frame shift 0.01 s and +0.025 s frame length at the
+end of audio; NVIDIA_.../Inference_NVIDIA_MarbleNet_VAD_ONNX.py:160-353 -- takes frame_shift_s, no
+frame-length term).  The decision passes run in libvadx (one clip per thread); only the float32
+seconds arithmetic and Python round(,3) of decision_to_segment stay on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class VadPostprocessor:
+    def __init__(self, smooth_window_size, prob_threshold, min_speech_frame, max_speech_frame, min_silence_frame,
+                 merge_silence_frame, extend_speech_frame, frame_shift_s=0.01, frame_length_s=0.025, device="cuda:0"):
+        self.torch = _lib.require_gpu()
+        self.device = self.torch.device(device)
+        p = _lib.VadPostParams()
+        p.smooth_window_size = max(1, int(smooth_window_size))
+        p.prob_threshold = float(np.float32(prob_threshold))
+        p.min_speech_frame, p.max_speech_frame = int(min_speech_frame), int(max_speech_frame)
+        p.min_silence_frame, p.merge_silence_frame = int(min_silence_frame), int(merge_silence_frame)
+        p.extend_speech_frame = int(extend_speech_frame)
+        self.params = p
+        self.frame_shift = np.float32(frame_shift_s)
+        self.frame_length = None if frame_length_s is None else np.float32(frame_length_s)
+
+    def process_batch(self, probs, n_frames=None, cap=64):
+        """probs f32 [B, S] (device or host), n_frames [B] -> (decisions i8 [B,S], segs i32 [B,cap,2], counts)."""
+        t = self.torch
+        if not t.is_tensor(probs):
+            probs = t.from_numpy(np.ascontiguousarray(probs, dtype=np.float32))
+        probs = probs.to(self.device, t.float32).contiguous()
+        if probs.dim() == 1:
+            probs = probs.unsqueeze(0)
+        B, S = probs.shape
+        nf = np.full((B,), S, dtype=np.int32) if n_frames is None else np.asarray(n_frames, dtype=np.int32)
+        dec = t.zeros((B, max(S, 1)), dtype=t.int8, device=self.device)
+        if S == 0:
+            return dec[:, :0], t.zeros((B, cap, 2), dtype=t.int32, device=self.device), t.zeros((B,), dtype=t.int32, device=self.device)
+        nfd = t.from_numpy(nf).to(self.device)
+        L = _lib.lib()
+        ws = t.empty(L.vadx_vadpost_workspace_bytes(B, S), dtype=t.uint8, device=self.device)
+        while True:
+            segs = t.empty((B, cap, 2), dtype=t.int32, device=self.device)
+            counts = t.empty((B,), dtype=t.int32, device=self.device)
+            with t.cuda.device(self.device):
+                _lib.check(L.vadx_vadpost(C.byref(self.params), probs.data_ptr(), S, nfd.data_ptr(), B, dec.data_ptr(),
+                                          segs.data_ptr(), counts.data_ptr(), cap, ws.data_ptr(), ws.numel(),
+                                          _lib.stream_ptr()))
+            worst = int(counts.max().item())
+            if worst <= cap:
+                return dec, segs, counts
+            cap = worst
+
+    def process(self, raw_probs):
+        """Single-track reference signature: probabilities -> int8 decision array (host numpy)."""
+        p = np.asarray(raw_probs, dtype=np.float32)
+        if p.shape[0] == 0:
+            return np.empty(0, dtype=np.int8)
+        dec, _, _ = self.process_batch(p[None, :])
+        return dec[0].cpu().numpy()
+
+    def segments_to_seconds(self, seg_frames, n, wav_dur=None):
+        """float32 seconds + round(,3), exactly the tail of decision_to_segment (:169-179)."""
+        if len(seg_frames) == 0:
+            return []
+        seg = np.empty((len(seg_frames), 2), dtype=np.float32)
+        fr = np.asarray(seg_frames, dtype=np.float32)
+        seg[:, 0] = fr[:, 0] * self.frame_shift
+        seg[:, 1] = fr[:, 1] * self.frame_shift
+        if int(seg_frames[-1][1]) == n:              # last decision frame is speech
+            end_t = n * self.frame_shift
+            if self.frame_length is not None:
+                end_t = end_t + self.frame_length
+            if wav_dur is not None and wav_dur < end_t:
+                end_t = wav_dur
+            seg[-1, 1] = end_t
+        return [(round(s, 3), round(e, 3)) for s, e in seg.tolist()]
+
+    def decision_to_segment(self, decisions, wav_dur=None):
+        dec = np.asarray(decisions, dtype=np.int8)
+        n = dec.shape[0]
+        if n == 0:
+            return []
+        edges = np.diff(np.concatenate(([0], dec, [0])).astype(np.int8))
+        starts, ends = np.flatnonzero(edges == 1), np.flatnonzero(edges == -1)
+        return self.segments_to_seconds(list(zip(starts.tolist(), ends.tolist())), n, wav_dur)
