@@ -87,7 +87,8 @@ class FireRedEngine:
             return (out, track) if return_probs else out
         dec, segs, counts = pp.process_batch(track)
         segs, counts = segs.cpu().numpy(), counts.cpu().numpy()
-        out = [pp.segments_to_seconds(segs[b, :counts[b]].tolist(), nvalid, n / SAMPLE_RATE) for b in range(B)]
+        nfr = track.shape[1]     # min(valid frames, W*T): 10 s clips give 980 of the 998 snip-edge frames
+        out = [pp.segments_to_seconds(segs[b, :counts[b]].tolist(), nfr, n / SAMPLE_RATE) for b in range(B)]
         return (out, track, dec) if return_probs else out
 
 
