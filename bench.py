@@ -148,21 +148,16 @@ def main():
 
     import torch
     import vadx  # noqa: F401
-    from vadx import _lib, silero, weights
+    from vadx import _lib, shard, silero, weights
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = shard.env_rank()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the vadx product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+    dist = shard.init("nccl", device)        # None for a single process; RCCL otherwise (barrier/timing only)
 
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(device)}; torch imported")
     B = args.clips
@@ -204,10 +199,7 @@ def main():
     log("warm-up done")
 
     def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.fence(dist, torch.cuda.synchronize)
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     fence()
@@ -216,10 +208,7 @@ def main():
         step(events[k])
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = shard.max_over_ranks(dist, elapsed, device)
 
     log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
