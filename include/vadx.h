@@ -232,6 +232,30 @@ int vadx_vadpost(const vadx_vadpost_params *prm, const float *probs, int stride,
                  void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * MarbleNet building blocks: one fused launch per Jasper sub-block
+ * (depthwise conv -> pointwise 1x1 + folded BatchNorm [-> + residual 1x1] -> ReLU) and the frame
+ * classifier head.  Replaces the encoder/decoder calls of NVIDIA_VAD_Optimized.forward,
+ * Export_NVIDIA_MarbleNet_VAD.py:265-274 (BatchNorm folded on the host as in :58-151).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vadx_sepconv_cfg {
+    int cin, cout;            /* <= 128 */
+    int kernel, stride, dilation;   /* 'same' padding = dilation*(kernel-1)/2 */
+    int depthwise;            /* 0: plain 1x1 conv (kernel must be 1) */
+    int residual_cin;         /* 0: no residual branch; else channels of the block input */
+    int relu;
+} vadx_sepconv_cfg;
+
+/* x: element (b, c, t) at x[b*xs_b + c*xs_c + t*xs_t] (lets the first block read the time-major
+ * log-mel directly); xres [B][residual_cin][t_out]; y [B][cout][t_out].  Weights on the device:
+ * dw_w [cin][kernel]; pw_w [cout_pad16][cin_pad16], pw_b [cout_pad16]; res_w [cout_pad16][rescin_pad16]. */
+int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w, const float *pw_w, const float *pw_b,
+                       const float *res_w, const float *res_b, const float *x, int64_t xs_b, int64_t xs_c,
+                       int64_t xs_t, int t_in, const float *xres, float *y, int batch, int t_out, void *stream);
+/* enc [B][C][T] -> softmax(Linear(C->2)) split into score0 / score1 [B][T]. */
+int vadx_frame_classifier(const float *enc, const float *dec_w, const float *dec_b, int batch, int channels,
+                          int frames, float *score0, float *score1, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Test hooks (used by tests/ only)
  * ------------------------------------------------------------------------------------------- */
 /* C[M][N] = A[M][K] * W[N][K]^T through the same LDS/MFMA tile helper the nets use.

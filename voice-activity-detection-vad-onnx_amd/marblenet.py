@@ -1,0 +1,150 @@
+"""NVIDIA Frame-VAD MarbleNet v2.0 on MI355X: ORT-session boundary + the window loop of
+NVIDIA_.../Inference_NVIDIA_MarbleNet_VAD_ONNX.py:130-147,369-402.
+
+The encoder/decoder classes live in NeMo (not in the reference tree); weights come as the
+checkpoint's conv + BatchNorm tensors and are BN-folded at load exactly like the reference's
+`fold_bn_into_conv1d` (Export_NVIDIA_MarbleNet_VAD.py:58-105)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import frontend as _frontend
+from . import vadpost as _vadpost
+from . import weights as _weights
+from .fsmn import _Meta, pad_to_window_grid
+
+SAMPLE_RATE = 16000
+OUTPUT_FRAME_SHIFT_S = 320 / 16000
+
+
+def _pad16(a, axes):
+    pads = [(0, 0)] * a.ndim
+    for ax in axes:
+        pads[ax] = (0, (-a.shape[ax]) % 16)
+    return np.ascontiguousarray(np.pad(a, pads), dtype=np.float32)
+
+
+class MarbleNetEngine:
+    def __init__(self, weights=None, device="cuda:0", blocks=None, bn_eps=None):
+        torch = _lib.require_gpu()
+        self.torch = torch
+        self.device = torch.device(device)
+        w = _weights.marblenet_synthetic(1234) if weights is None else weights
+        blocks = _weights.MARBLENET_BLOCKS if blocks is None else blocks
+        eps = _weights.MARBLENET_BN_EPS if bn_eps is None else bn_eps
+        self.stages = []          # (cfg, dev tensors..., block_start flag)
+        cin = 80
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)   # noqa: E731
+        for bi, (filt, rep, k, stride, dil, residual, sep) in enumerate(blocks):
+            block_cin = cin
+            for r in range(rep):
+                p = f"b{bi}r{r}"
+                pw, pb = _weights.fold_bn(np.asarray(w[p + "_pw"])[:, :, None], None, w[p + "_gamma"], w[p + "_beta"],
+                                          w[p + "_mean"], w[p + "_var"], eps)
+                last = r == rep - 1
+                cfg = _lib.SepConvCfg(cin, filt, k, stride, dil, 1 if sep else 0, block_cin if (residual and last) else 0, 1)
+                st = {"cfg": cfg, "dw": dev(w[p + "_dw"]) if sep else None, "pw": dev(_pad16(pw[:, :, 0], (0, 1))),
+                      "pb": dev(_pad16(pb, (0,))), "rw": None, "rb": None, "first": r == 0, "res": residual and last}
+                if residual and last:
+                    rw, rb = _weights.fold_bn(np.asarray(w[f"b{bi}res_pw"])[:, :, None], None, w[f"b{bi}res_gamma"],
+                                              w[f"b{bi}res_beta"], w[f"b{bi}res_mean"], w[f"b{bi}res_var"], eps)
+                    st["rw"], st["rb"] = dev(_pad16(rw[:, :, 0], (0, 1))), dev(_pad16(rb, (0,)))
+                self.stages.append(st)
+                cin = filt
+        self.cout = cin
+        self.dec_w, self.dec_b = dev(w["dec_w"]), dev(w["dec_b"])
+        self._fe = {}
+
+    def frontend(self, L):
+        if L not in self._fe:
+            self._fe[L] = _frontend.Frontend("marblenet", L, device=self.device)
+        return self._fe[L]
+
+    def run(self, audio_i16, windows_per_clip=1, window_len=None):
+        """audio int16 [B, W*L] -> (score_silence, score_active f32 [B*W, T'], signal_len = T' - 1)."""
+        t = self.torch
+        if not t.is_tensor(audio_i16):
+            audio_i16 = t.from_numpy(np.ascontiguousarray(audio_i16, dtype=np.int16))
+        a = audio_i16.to(self.device)
+        L = int(a.shape[-1] // windows_per_clip if window_len is None else window_len)
+        fe = self.frontend(L)
+        x = fe.logmel(a, windows_per_clip, L)               # [N, T, 80] time-major
+        N, T = x.shape[0], x.shape[1]
+        xs = (T * 80, 1, 80)
+        cur, cur_T = x, T
+        block_in = None
+        lib = _lib.lib()
+        with t.cuda.device(self.device):
+            for st in self.stages:
+                cfg = st["cfg"]
+                if st["first"]:
+                    block_in = cur
+                pad = (cfg.dilation * (cfg.kernel - 1)) // 2
+                t_out = (cur_T + 2 * pad - cfg.dilation * (cfg.kernel - 1) - 1) // cfg.stride + 1
+                y = t.empty((N, cfg.cout, t_out), dtype=t.float32, device=self.device)
+                _lib.check(lib.vadx_sepconv_block(C.byref(cfg), None if st["dw"] is None else st["dw"].data_ptr(),
+                                                  st["pw"].data_ptr(), st["pb"].data_ptr(),
+                                                  None if st["rw"] is None else st["rw"].data_ptr(),
+                                                  None if st["rb"] is None else st["rb"].data_ptr(),
+                                                  cur.data_ptr(), xs[0], xs[1], xs[2], cur_T,
+                                                  block_in.data_ptr() if st["res"] else None, y.data_ptr(), N, t_out,
+                                                  _lib.stream_ptr()))
+                cur, cur_T = y, t_out
+                xs = (cfg.cout * t_out, t_out, 1)
+            s0 = t.empty((N, cur_T), dtype=t.float32, device=self.device)
+            s1 = t.empty((N, cur_T), dtype=t.float32, device=self.device)
+            _lib.check(lib.vadx_frame_classifier(cur.data_ptr(), self.dec_w.data_ptr(), self.dec_b.data_ptr(), N, self.cout,
+                                                 cur_T, s0.data_ptr(), s1.data_ptr(), _lib.stream_ptr()))
+        return s0, s1, cur_T - 1
+
+    def detect(self, clips_i16, window_len=None, pad_noise=None, post=(3, 0.5, 10, 1000, 10, 3, 0), return_probs=False):
+        """Equal-length clips int16 [B,N] (host) -> per clip [(start_s, end_s)].  window_len None = the
+        dynamic-axis mode (one window = the whole clip, up to 3600 s, :130-135)."""
+        clips = np.asarray(clips_i16)
+        B, n = clips.shape
+        L = min(SAMPLE_RATE * 3600, n) if window_len is None else int(window_len)
+        rows = [pad_to_window_grid(clips[b], L, L, None if pad_noise is None else pad_noise[b]) for b in range(B)]
+        padded = np.stack(rows)
+        W = padded.shape[1] // L
+        s0, s1, slen = self.run(padded, W, L)
+        valid = min(slen, s1.shape[1])
+        track = s1.view(B, W, -1)[:, :, :valid].reshape(B, W * valid).contiguous()
+        pp = _vadpost.VadPostprocessor(*post, frame_shift_s=OUTPUT_FRAME_SHIFT_S, frame_length_s=None, device=self.device)
+        dec, segs, counts = pp.process_batch(track)
+        segs, counts = segs.cpu().numpy(), counts.cpu().numpy()
+        out = [pp.segments_to_seconds(segs[b, :counts[b]].tolist(), track.shape[1], n / SAMPLE_RATE) for b in range(B)]
+        return (out, track, dec) if return_probs else out
+
+
+class MarbleNetSession:
+    """{'audio': int16 [1,1,L]} -> [score_silence [1,T,1], score_active [1,T,1], signal_len int32 [1]]
+    (Export_NVIDIA_MarbleNet_VAD.py:436-457; dynamic audio length)."""
+
+    def __init__(self, weights=None, device="cuda:0"):
+        self.engine = MarbleNetEngine(weights, device)
+        self._inputs_meta = [_Meta("audio", [1, 1, "audio_len"], "tensor(int16)")]
+        self._outputs_meta = [_Meta("score_silence", [1, "signal_len", 1], "tensor(float)"),
+                              _Meta("score_active", [1, "signal_len", 1], "tensor(float)"),
+                              _Meta("signal_len", [1], "tensor(int32)")]
+
+    def get_inputs(self):
+        return list(self._inputs_meta)
+
+    def get_outputs(self):
+        return list(self._outputs_meta)
+
+    def get_providers(self):
+        return ["VadxMI355XExecutionProvider"]
+
+    def run(self, output_names, feeds):
+        audio = np.asarray(feeds["audio"])
+        if audio.dtype != np.int16:
+            raise ValueError("Unexpected input data type. Actual: (%s) , expected: (tensor(int16))" % audio.dtype)
+        s0, s1, slen = self.engine.run(audio.reshape(-1, audio.shape[-1]))
+        res = {"score_silence": s0.cpu().numpy()[:, :, None], "score_active": s1.cpu().numpy()[:, :, None],
+               "signal_len": np.array([slen], dtype=np.int32)}
+        names = ["score_silence", "score_active", "signal_len"] if output_names is None else output_names
+        return [res[n] for n in names]

@@ -166,3 +166,57 @@ def firered_synthetic(seed=1234, cfg=None):
     w["out_w"] = (w["out_w"] * np.float32(s)).astype(np.float32)
     w["out_b"] = (w["out_b"] * np.float32(s) + np.float32(t)).astype(np.float32)
     return w
+
+
+# --------------------------------------------------------------------------- MarbleNet (NeMo 3x2x64, 20 ms)
+MARBLENET_BLOCKS = (  # (filters, repeat, kernel, stride, dilation, residual, separable)
+    (128, 1, 11, 2, 1, False, True), (64, 2, 13, 1, 1, True, True), (64, 2, 15, 1, 1, True, True),
+    (64, 2, 17, 1, 1, True, True), (128, 1, 29, 1, 2, False, True), (128, 1, 1, 1, 1, False, False))
+MARBLENET_BN_EPS = 1e-3
+
+
+def marblenet_synthetic(seed=1234):
+    """Unfolded (conv + BatchNorm statistics) weights of the published MarbleNet 3x2x64 layout."""
+    w = {}
+    cin = 80
+
+    def bn(prefix, c):
+        w[prefix + "_gamma"] = (1.0 + 0.1 * _rng(seed, prefix + "g").standard_normal(c)).astype(np.float32)
+        w[prefix + "_beta"] = _normal(seed, prefix + "b", (c,), 0.1)
+        w[prefix + "_mean"] = _normal(seed, prefix + "m", (c,), 0.2)
+        w[prefix + "_var"] = (0.5 + _rng(seed, prefix + "v").uniform(0, 1, c)).astype(np.float32)
+
+    for bi, (filt, rep, k, _s, _d, residual, sep) in enumerate(MARBLENET_BLOCKS):
+        block_cin = cin
+        for r in range(rep):
+            p = f"b{bi}r{r}"
+            if sep:
+                w[p + "_dw"] = _normal(seed, p + "_dw", (cin, k), 1.0 / np.sqrt(k))
+            w[p + "_pw"] = _normal(seed, p + "_pw", (filt, cin), 1.0 / np.sqrt(cin))
+            bn(p, filt)
+            cin = filt
+        if residual:
+            w[f"b{bi}res_pw"] = _normal(seed, f"b{bi}res_pw", (filt, block_cin), 0.7 / np.sqrt(block_cin))
+            bn(f"b{bi}res", filt)
+    # log-mel of 1/32768-scaled audio sits around -12..-3: centre the first depthwise/pointwise pair
+    w["b0r0_mean"] = (w["b0r0_mean"] + (-8.0 * (w["b0r0_pw"] * w["b0r0_dw"].sum(axis=1)[None, :]).sum(axis=1))).astype(np.float32)
+    w["dec_w"] = _normal(seed, f"dec_w_mb{_MARBLENET_DEC_TAG.get(seed, 0)}", (2, 128), 1.0 / np.sqrt(128))
+    w["dec_b"] = _normal(seed, "dec_b_mb", (2,), 0.05)
+    s, t = _MARBLENET_DEC_CALIB.get(seed, (1.0, 0.0))
+    w["dec_w"][1] = w["dec_w"][0] + (w["dec_w"][1] - w["dec_w"][0]) * np.float32(s)
+    w["dec_b"][1] = w["dec_b"][0] + (w["dec_b"][1] - w["dec_b"][0]) * np.float32(s) + np.float32(t)
+    return w
+
+
+# decoder draw + output affine found offline so that loud bursts / quiet stretches straddle 0.5
+_MARBLENET_DEC_TAG = {1234: 16, 7: 0}
+_MARBLENET_DEC_CALIB = {1234: (5.6, -0.26), 7: (5.9, 9.9)}
+
+
+def fold_bn(conv_w, conv_b, gamma, beta, mean, var, eps):
+    """BatchNorm (eval) folded into the preceding conv: W' = W*g/sqrt(v+eps), b' = (b-mean)*g/sqrt(v+eps)+beta
+    (Export_NVIDIA_MarbleNet_VAD.py:58-105).  float32 numpy, same op order as the reference."""
+    scale = (gamma * (np.float32(1.0) / np.sqrt(var + np.float32(eps)))).astype(np.float32)
+    new_w = (conv_w * scale.reshape((-1,) + (1,) * (conv_w.ndim - 1))).astype(np.float32)
+    base = (conv_b - mean) if conv_b is not None else (-mean)
+    return new_w, (base * scale + beta).astype(np.float32)
