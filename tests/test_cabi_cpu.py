@@ -45,8 +45,9 @@ def test_pack_host_layout(lib):
     assert lib.vadx_silero_pack_host(ctypes.byref(hw), p.ctypes.data) == 0
     # STFT rows regrouped per wave: [wave][re|im][16][256]
     stft = p[:256 * 256].reshape(8, 2, 16, 256)
-    assert np.array_equal(stft[3, 0, 5], w["stft_basis"][3 * 16 + 5])
-    assert np.array_equal(stft[3, 1, 5], w["stft_basis"][129 + 3 * 16 + 5])
+    perm = np.array([16 * S + q + 4 * j for S in range(16) for q in range(4) for j in range(4)])   # slot 16S+4q+j <- k
+    assert np.array_equal(stft[3, 0, 5], w["stft_basis"][3 * 16 + 5][perm])
+    assert np.array_equal(stft[3, 1, 5], w["stft_basis"][129 + 3 * 16 + 5][perm])
     nyq = p[65536:65536 + 512].reshape(2, 256)
     assert np.array_equal(nyq[0], w["stft_basis"][128]) and np.array_equal(nyq[1], w["stft_basis"][257])
     c1 = p[66048:66048 + 128 * 3 * 144].reshape(128, 3, 144)

@@ -19,7 +19,7 @@ namespace vadx {
 namespace silero {
 
 // ---- packed weight blob (float offsets) -------------------------------------------------------
-constexpr int OFF_STFT = 0;                        // [8 waves][re16|im16][256]  (bins 0..127)
+constexpr int OFF_STFT = 0;                        // [8 waves][re16|im16][256]  (bins 0..127), k-permuted per 16
 constexpr int OFF_NYQ = OFF_STFT + 256 * 256;      // [2][256]                   (bin 128 re, im)
 constexpr int C1_KP = 144;                         // 129 input channels padded to 9 blocks of 16
 constexpr int OFF_C1 = OFF_NYQ + 2 * 256;          // [128][3][144]
@@ -37,56 +37,105 @@ constexpr int OFF_DW = OFF_HH + 512 * 128;         // [128]
 constexpr int OFF_DB = OFF_DW + 128;               // [1] (+3 pad)
 constexpr int PACKED_FLOATS = OFF_DB + 4;
 
-// ---- encoder LDS map (floats) -----------------------------------------------------------------
-constexpr int X_LD = 20;     // X  [640 positions][16 clips]      (+4 pad)
-constexpr int MG_LD = 100;   // Mg [144 ch][6 frame slots x 16]   (+4 pad) slot s <-> frame s-1
-constexpr int A1_LD = 84;    // A1 [128 ch][5 slots x 16]         (+4 pad) slot s <-> frame s-1
-constexpr int A2_LD = 36;    // A2 [64 ch][2 frames x 16]
-constexpr int A3_LD = 20;    // A3 [64 ch][16]
-constexpr int A4_LD = 20;    // A4 [128 ch][16]
-constexpr int R0_FLOATS = 640 * X_LD;              // X, later A1 (128*84 = 10752 <= 12800)
-constexpr int MG_FLOATS = 144 * MG_LD;
-constexpr int A2_FLOATS = 64 * A2_LD;
-constexpr int A3_FLOATS = 64 * A3_LD;
-constexpr int A4_FLOATS = 128 * A4_LD;
-constexpr int ENC_LDS_FLOATS = R0_FLOATS + MG_FLOATS + A2_FLOATS + A3_FLOATS + A4_FLOATS;
+// ---- encoder LDS map (floats): 80 256 B per workgroup => TWO workgroups per CU ---------------------
+// region 0: X  [16 clips][642]  raw windows in their global layout (row stride 642 = 2 mod 32: with the
+//              STFT's k permutation k = 16S + q + 4j the half-wave (clip i, q) hits bank 2i+q -> conflict free)
+//           then A1 [128 ch][4 frames x 16 (+4)]  conv1 output (X is dead after the STFT)
+// region 1: Mg [144 ch][4 frames x 16 (+4)]       |STFT|, k-major
+//           then A2 [64][2x16 (+4)], A3 [64][16 (+4)], A4 [128][16 (+4)]   (Mg is dead after conv1)
+// Conv zero padding is never stored: taps that would read frame -1 / 4 are simply not issued.
+constexpr int X_LDM = 642;
+constexpr int MG_LD = 68, A1_LD = 68, A2_LD = 36, A3_LD = 20, A4_LD = 20;
+constexpr int R0_FLOATS = 16 * X_LDM;              // 10272  (A1: 128*68 = 8704)
+constexpr int R1_FLOATS = 144 * MG_LD;             //  9792  (A2+A3+A4 = 2304+1280+2560)
+constexpr int A2_OFF = 0, A3_OFF = 64 * A2_LD, A4_OFF = A3_OFF + 64 * A3_LD;
+constexpr int ENC_LDS_FLOATS = R0_FLOATS + R1_FLOATS;
 constexpr int ENC_THREADS = 512;
 
 // gx: per (t, group) 8 waves x 4 gates x 64 lanes x 4 floats
 constexpr int GX_TILE_FLOATS = 8 * 4 * 256;
 
-__global__ __launch_bounds__(ENC_THREADS, 2) void silero_encode_kernel(
+// m-major operand variant of gemm_pass for the STFT: act element (m, k) at act[m*ldm + k], this lane's
+// m = lane&15, the k consumed by (block S, sub-step j, quarter q) is 16S + q + 4j (the basis rows are
+// packed with the matching permutation, so weights still arrive as one 16-B load per block).
+template <int NT, int MT, int KB>
+__device__ __forceinline__ void gemm_pass_mmajor(f32x4 (&acc)[NT][MT], const float *act, int ldm,
+                                                 const int (&koff)[MT], const float *const (&wrow)[NT], int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    const float *ap = act + i * ldm + q;
+    f32x4 wcur[NT], wnxt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 4 * q);
+#pragma unroll 1
+    for (int S = 0; S < KB; ++S) {
+        const int Sn = (S + 1 < KB) ? S + 1 : S;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
+        const float *aps = ap + 16 * S;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = aps[4 * j + koff[mt]];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float wj = wcur[nt][j];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(av[mt], wj, acc[nt][mt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wcur[nt] = wnxt[nt];
+    }
+}
+
+// k-major pass that accumulates into acc[0][A0 .. A0+MT) of a wider accumulator array
+template <int MT, int KB, int A0, int AN>
+__device__ __forceinline__ void gemm_pass_sub(f32x4 (&acc)[1][AN], const float *act, int lda, const int (&moff)[MT],
+                                              const float *wrow, int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    const float *ap = act + (4 * q) * lda + i;
+    f32x4 wcur = *reinterpret_cast<const f32x4 *>(wrow + 4 * q), wnxt;
+#pragma unroll 1
+    for (int S = 0; S < KB; ++S) {
+        const int Sn = (S + 1 < KB) ? S + 1 : S;
+        wnxt = *reinterpret_cast<const f32x4 *>(wrow + 16 * Sn + 4 * q);
+        const float *aps = ap + 16 * S * lda;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float wj = wcur[j];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[0][A0 + mt] = mfma16(aps[j * lda + moff[mt]], wj, acc[0][A0 + mt]);
+        }
+        wcur = wnxt;
+    }
+}
+
+__global__ __launch_bounds__(ENC_THREADS, 4) void silero_encode_kernel(
     const float *__restrict__ P, const float *__restrict__ audio, long long n_samples,
     long long row_stride, long long origin, int B, int G, int T, float *__restrict__ gx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *X = lds;                 // phase 0-1
     float *A1 = lds;                // phase 2-3 (aliases X)
-    float *Mg = lds + R0_FLOATS;
-    float *A2 = Mg + MG_FLOATS;
-    float *A3 = A2 + A2_FLOATS;
-    float *A4 = A3 + A3_FLOATS;
+    float *Mg = lds + R0_FLOATS;    // phase 1-2
+    float *A2 = Mg + A2_OFF, *A3 = Mg + A3_OFF, *A4 = Mg + A4_OFF;      // phase 3-6 (alias Mg)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, i = lane & 15;
     const int grp = blockIdx.x % G, t = blockIdx.x / G;
 
-    // ---------------- phase 0: stage the 16 windows (k-major: position x clip), zero conv pads
-    for (int e = tid; e < 15 * MG_LD; e += ENC_THREADS) Mg[129 * MG_LD + e] = 0.f;
-    for (int e = tid; e < 129 * 32; e += ENC_THREADS) {
-        const int r = e >> 5, c = e & 31;
-        Mg[r * MG_LD + (c < 16 ? c : 64 + c)] = 0.f;          // frame slots 0 and 5
-    }
+    // ---------------- phase 0: copy the 16 windows (576 samples each) + right reflect pad of 64
     {
-        const int c = tid & 15, pq = tid >> 4;
-        const long long b = (long long)grp * 16 + c;
-        const bool bvalid = b < B;
-        const float *src = audio + (bvalid ? b : 0) * row_stride;
         const long long base = (long long)t * 512 + origin;
         const bool vec_ok = ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(audio) & 15) == 0);
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
-            const int p = 4 * (pq + 32 * it);
-            if (p < 576) {
+            const int e = tid + ENC_THREADS * it;            // 16 clips x 144 float4
+            if (e < 16 * 144) {
+                const int c = e / 144, p = 4 * (e - c * 144);
+                const long long b = (long long)grp * 16 + c;
+                const bool bvalid = b < B;
+                const float *src = audio + (bvalid ? b : 0) * row_stride;
                 const long long idx = base + p;
                 float v[4];
                 if (bvalid && vec_ok && idx >= 0 && idx + 3 < n_samples) {
@@ -97,14 +146,16 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void silero_encode_kernel(
                     for (int jj = 0; jj < 4; ++jj)
                         v[jj] = (bvalid && idx + jj >= 0 && idx + jj < n_samples) ? src[idx + jj] : 0.f;
                 }
+                float *row = X + c * X_LDM;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int pp = p + jj;
-                    X[pp * X_LD + c] = v[jj];
-                    if (pp >= 511 && pp <= 574) X[(1150 - pp) * X_LD + c] = v[jj];   // reflect pad (0,64)
+                    row[pp] = v[jj];
+                    if (pp >= 511 && pp <= 574) row[1150 - pp] = v[jj];       // reflect pad (0,64)
                 }
             }
         }
+        for (int e = tid; e < 15 * MG_LD; e += ENC_THREADS) Mg[129 * MG_LD + e] = 0.f;     // K padding rows 129..143
     }
     __syncthreads();
 
@@ -117,65 +168,64 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void silero_encode_kernel(
             for (int f = 0; f < 4; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float *const wrow[2] = {P + OFF_STFT + (wave * 32 + i) * 256,
                                       P + OFF_STFT + (wave * 32 + 16 + i) * 256};
-        const int moff[4] = {0, 128 * X_LD, 256 * X_LD, 384 * X_LD};
-        gemm_pass<2, 4, 16, false>(acc, X, X_LD, moff, wrow, lane);
+        const int koff[4] = {0, 128, 256, 384};
+        gemm_pass_mmajor<2, 4, 16>(acc, X, X_LDM, koff, wrow, lane);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             f32x4 m;
 #pragma unroll
             for (int r = 0; r < 4; ++r) m[r] = sqrtf(acc[0][f][r] * acc[0][f][r] + acc[1][f][r] * acc[1][f][r]);
-            *reinterpret_cast<f32x4 *>(&Mg[(wave * 16 + i) * MG_LD + (f + 1) * 16 + 4 * q]) = m;
+            *reinterpret_cast<f32x4 *>(&Mg[(wave * 16 + i) * MG_LD + f * 16 + 4 * q]) = m;
         }
         if (wave < 4) {   // Nyquist bin: frame f = wave, lane = (clip i, k-quarter q)
             const int f = wave;
             const float *nre = P + OFF_NYQ + q * 64, *nim = P + OFF_NYQ + 256 + q * 64;
-            const float *xp = X + (128 * f + q * 64) * X_LD + i;
+            const float *xp = X + i * X_LDM + 128 * f + q * 64;
             float sre = 0.f, sim = 0.f;
 #pragma unroll 8
             for (int k = 0; k < 64; ++k) {
-                const float x = xp[k * X_LD];
+                const float x = xp[k];
                 sre = fmaf(x, nre[k], sre);
                 sim = fmaf(x, nim[k], sim);
             }
             sre += __shfl_xor(sre, 16); sre += __shfl_xor(sre, 32);
             sim += __shfl_xor(sim, 16); sim += __shfl_xor(sim, 32);
-            if (q == 0) Mg[128 * MG_LD + (f + 1) * 16 + i] = sqrtf(sre * sre + sim * sim);
+            if (q == 0) Mg[128 * MG_LD + f * 16 + i] = sqrtf(sre * sre + sim * sim);
         }
     }
     __syncthreads();
 
-    // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU  (out frames 0..3 -> A1 slots 1..4)
+    // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU (taps on frame -1 / 4 are skipped)
     {
-        for (int e = tid; e < 128 * 16; e += ENC_THREADS) A1[(e >> 4) * A1_LD + (e & 15)] = 0.f;   // slot 0
         f32x4 acc[1][4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) acc[0][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            const float *const wrow[1] = {P + OFF_C1 + ((wave * 16 + i) * 3 + kk) * C1_KP};
-            const int moff[4] = {(0 + kk) * 16, (1 + kk) * 16, (2 + kk) * 16, (3 + kk) * 16};
-            gemm_pass<1, 4, 9, false>(acc, Mg, MG_LD, moff, wrow, lane);
-        }
+        const float *w0 = P + OFF_C1 + (wave * 16 + i) * 3 * C1_KP;
+        {   const int moff[3] = {0, 16, 32};          // tap 0: out frames 1..3 read in frames 0..2
+            gemm_pass_sub<3, 9, 1, 4>(acc, Mg, MG_LD, moff, w0, lane); }
+        {   const int moff[4] = {0, 16, 32, 48};      // tap 1: out frames 0..3 read in frames 0..3
+            gemm_pass_sub<4, 9, 0, 4>(acc, Mg, MG_LD, moff, w0 + C1_KP, lane); }
+        {   const int moff[3] = {16, 32, 48};         // tap 2: out frames 0..2 read in frames 1..3
+            gemm_pass_sub<3, 9, 0, 4>(acc, Mg, MG_LD, moff, w0 + 2 * C1_KP, lane); }
         const float bias = P[OFF_B1 + wave * 16 + i];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[0][f][r] + bias, 0.f);
-            *reinterpret_cast<f32x4 *>(&A1[(wave * 16 + i) * A1_LD + (f + 1) * 16 + 4 * q]) = v;
+            *reinterpret_cast<f32x4 *>(&A1[(wave * 16 + i) * A1_LD + f * 16 + 4 * q]) = v;
         }
     }
     __syncthreads();
 
-    // ---------------- phase 3: conv2 128->64, k3 s2 p1, ReLU (out frames 0,1)
+    // ---------------- phase 3: conv2 128->64, k3 s2 p1, ReLU (out frame fp reads in frames 2fp-1..2fp+1)
     {
         const int nt = wave & 3, fp = wave >> 2;
         f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            const float *const wrow[1] = {P + OFF_C2 + ((nt * 16 + i) * 3 + kk) * 128};
-            const int moff[1] = {(2 * fp + kk) * 16};
-            gemm_pass<1, 1, 8, false>(acc, A1, A1_LD, moff, wrow, lane);
+        const float *w0 = P + OFF_C2 + (nt * 16 + i) * 3 * 128;
+        for (int kk = (fp == 0 ? 1 : 0); kk < 3; ++kk) {
+            const int moff[1] = {(2 * fp + kk - 1) * 16};
+            gemm_pass_sub<1, 8, 0, 1>(acc, A1, A1_LD, moff, w0 + kk * 128, lane);
         }
         const float bias = P[OFF_B2 + nt * 16 + i];
         f32x4 v;
@@ -190,9 +240,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void silero_encode_kernel(
         f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            const float *const wrow[1] = {P + OFF_C3 + ((wave * 16 + i) * 2 + ps) * 64};
             const int moff[1] = {ps * 16};
-            gemm_pass<1, 1, 4, false>(acc, A2, A2_LD, moff, wrow, lane);
+            gemm_pass_sub<1, 4, 0, 1>(acc, A2, A2_LD, moff, P + OFF_C3 + ((wave * 16 + i) * 2 + ps) * 64, lane);
         }
         const float bias = P[OFF_B3 + wave * 16 + i];
         f32x4 v;
@@ -205,9 +254,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void silero_encode_kernel(
     // ---------------- phase 5: conv4 64->128, k3 s1 p1, ReLU (1 frame in/out; centre tap only)
     {
         f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-        const float *const wrow[1] = {P + OFF_C4 + (wave * 16 + i) * 64};
         const int moff[1] = {0};
-        gemm_pass<1, 1, 4, false>(acc, A3, A3_LD, moff, wrow, lane);
+        gemm_pass_sub<1, 4, 0, 1>(acc, A3, A3_LD, moff, P + OFF_C4 + (wave * 16 + i) * 64, lane);
         const float bias = P[OFF_B4 + wave * 16 + i];
         f32x4 v;
 #pragma unroll
@@ -486,8 +534,11 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
     for (int wv = 0; wv < 8; ++wv)
         for (int part = 0; part < 2; ++part)
             for (int i = 0; i < 16; ++i)
-                memcpy(p + OFF_STFT + (size_t)(wv * 32 + part * 16 + i) * 256,
-                       w->stft_basis + (size_t)(part * 129 + wv * 16 + i) * 256, 256 * sizeof(float));
+                for (int S = 0; S < 16; ++S)          // k permutation of the m-major STFT pass: slot 4q+j <- k = q+4j
+                    for (int qq = 0; qq < 4; ++qq)
+                        for (int j = 0; j < 4; ++j)
+                            p[OFF_STFT + (size_t)(wv * 32 + part * 16 + i) * 256 + 16 * S + 4 * qq + j] =
+                                w->stft_basis[(size_t)(part * 129 + wv * 16 + i) * 256 + 16 * S + qq + 4 * j];
     memcpy(p + OFF_NYQ, w->stft_basis + (size_t)128 * 256, 256 * sizeof(float));
     memcpy(p + OFF_NYQ + 256, w->stft_basis + (size_t)257 * 256, 256 * sizeof(float));
     for (int co = 0; co < 128; ++co)
