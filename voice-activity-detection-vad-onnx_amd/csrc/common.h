@@ -65,6 +65,7 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NT][MT], const float *act
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
+        __builtin_amdgcn_sched_barrier(0);      // keep the next block's weight loads ahead of this block's MFMAs
         const float *aps = ap + 16 * S * lda;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -100,6 +101,7 @@ __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, 
         const int Sn = (S + 1 < kb) ? S + 1 : S;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
+        __builtin_amdgcn_sched_barrier(0);      // keep the next block's weight loads ahead of this block's MFMAs
         f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, m4 = {1.f, 1.f, 1.f, 1.f};
         if (AFFINE) {
             a4 = *reinterpret_cast<const f32x4 *>(add + 16 * S + 4 * q);
