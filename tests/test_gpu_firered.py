@@ -86,3 +86,24 @@ def test_whole_clip_segments(n):
                 assert [(int(s * 16000), int(e * 16000)) for s, e in got[b]] == [(int(s * 16000), int(e * 16000)) for s, e in want_seg]
         else:
             assert got[b] == want_seg == []
+
+
+def test_full_size_config5_properties():
+    """BASELINE config 5 (FireRed half): B=2048 x 10 s -- batch-position invariance + oracle spot check."""
+    import time
+    eng = firered.FireRedEngine(weights.firered_synthetic(1234))
+    base = weights.burst_clips(32, 160000, seed=321)
+    big = np.tile(base, (64, 1))                                   # 2048 clips
+    t0 = time.perf_counter()
+    got, track, dec = eng.detect(big, return_probs=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert track.shape == (2048, 980)
+    tr = track.view(64, 32, -1)
+    assert torch.equal(tr[0], tr[41]) and torch.equal(tr[0], tr[63])
+    assert got[5] == got[32 * 7 + 5]
+    fe = ofr.Frontend()
+    ow = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in weights.firered_synthetic(1234).items()}
+    want_seg, want_p, want_dec = ofr.run_clip(fe, ow, base[5], np.zeros(10))
+    np.testing.assert_allclose(track[5].cpu().numpy(), want_p, rtol=0, atol=ATOL)
+    print(f"FireRed config-5 pass (incl. host pad/upload): {dt * 1e3:.1f} ms for 2048 x 10 s")

@@ -113,3 +113,35 @@ def test_whole_clip_flags_and_timestamps(seed, n):
         assert len(mism) == 0, (b, mism[:10])
         assert got[b] == want_ts
         assert [(int(s * 16000), int(e * 16000)) for s, e in got[b]] == [(int(s * 16000), int(e * 16000)) for s, e in want_ts]
+
+
+def test_full_size_config3_properties():
+    """BASELINE config 3: B=4096 x 10 s.  Batch-position invariance (bitwise) + agreement with the
+    oracle on sampled clips + sane flag statistics."""
+    import time
+    eng = fsmn.FsmnEngine(weights.fsmn_synthetic(1234))
+    lb, stride = eng.grid()
+    base = weights.burst_clips(64, 160000, seed=123)
+    noise = np.random.default_rng(1).standard_normal((64, 20000))
+    rows = np.stack([fsmn.pad_to_window_grid(opp.normalize_to_int16(base[b].astype(np.float32)), 16000, stride, noise[b])
+                     for b in range(64)])
+    W = (rows.shape[1] - 16000) // stride + 1
+    assert W == 15
+    big = torch.from_numpy(rows).cuda().repeat(64, 1)            # 4096 clips
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    flags = eng.flags(big, W)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert flags.shape == (4096, 15 * 71 + 30)
+    f = flags.view(64, 64, -1)
+    assert torch.equal(f[0], f[37]) and torch.equal(f[0], f[63])
+    frac = float(flags.float().mean())
+    assert 0.2 < frac < 0.8, frac                                  # both speech and silence are present
+    fe = ofs.Frontend()
+    ow = {k: T(v) for k, v in weights.fsmn_synthetic(1234).items()}
+    for b in (0, 17):
+        a = opp.normalize_to_int16(base[b].astype(np.float32))
+        _, want = ofs.run_clip(fe, ow, a, noise[b])
+        assert np.array_equal(flags[b].cpu().numpy().astype(bool), np.array(want, bool))
+    print(f"FSMN config-3 pass: {dt * 1e3:.1f} ms for 4096 x 10 s ({4096 * 313 / dt / 1e6:.1f} M 512-hop frames/s)")

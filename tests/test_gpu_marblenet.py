@@ -53,3 +53,24 @@ def test_whole_clip_segments(n, window):
         got, track, dec = eng.detect(clips, window_len=window, pad_noise=noise, return_probs=True)
         assert track.shape[1] == 3 * (window // 160 // 2 + 0) or track.shape[1] > 0
         assert all(isinstance(s, list) for s in got)
+
+
+def test_full_size_config4_properties():
+    """BASELINE config 4 shape on one GPU: B=8192 clips of 89,431 samples (one window each)."""
+    import time
+    eng = marblenet.MarbleNetEngine(weights.marblenet_synthetic(1234))
+    base = weights.burst_clips(64, 89431, seed=55)
+    big = torch.from_numpy(base).cuda().repeat(128, 1)             # 8192 clips
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s0, s1, slen = eng.run(big)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert s1.shape == (8192, 280) and slen == 279
+    v = s1.view(128, 64, -1)
+    assert torch.equal(v[0], v[77]) and torch.equal(v[0], v[127])
+    assert bool(torch.isfinite(s1).all()) and float((s0 + s1 - 1).abs().max()) < 1e-5
+    ow = {k: T(v2) for k, v2 in weights.marblenet_synthetic(1234).items()}
+    _, oact, _ = omb.forward(omb.Frontend(), ow, T(base[9]).reshape(1, 1, -1))
+    np.testing.assert_allclose(s1[9].cpu().numpy(), oact[0, :, 0].numpy(), rtol=0, atol=ATOL)
+    print(f"MarbleNet config-4 pass: {dt * 1e3:.1f} ms for 8192 x 5.59 s ({8192 * 89431 / 512 / dt / 1e6:.1f} M 512-hop frames/s)")
