@@ -92,3 +92,12 @@ def test_host_timestamp_helpers_match_golden(golden):
     t = golden("dfsmn_golden_txt")
     assert timestamps.indices([(5.42, 294 * 0.02 + 0.02)], 16000)[0][1] == 94399
     assert timestamps.format_time(2.28) == str(t["seconds"][0]).split(" --> ")[0]
+
+
+def test_wav_ingest_matches_reference_sample_length():
+    """vad_sample.wav (48 kHz stereo s16, 268,292 frames) -> 89,431 mono samples at 16 kHz through
+    audioop.tomono + ratecv, the path pydub takes in every reference driver."""
+    from vadx import audio_io
+    a = audio_io.load_wav(os.path.join(ROOT, "tests", "golden", "vad_sample.wav"))
+    assert a.dtype == np.int16 and a.shape == (89431,)
+    assert int(np.abs(a).max()) == 4220

@@ -1,0 +1,117 @@
+"""Script-level drop-ins for the reference's `Inference_*_VAD_ONNX.py` programs: raw audio file(s) in,
+`timestamps_second.txt` / `timestamps_indices.txt` out, same constants (as keyword arguments instead
+of module-level globals), same stdout summary.  Each function also accepts a LIST of files and runs
+them as one device batch (equal-length files; ragged lists are grouped by length)."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from . import audio_io, timestamps
+
+
+def _as_list(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def _finish(all_ts, sample_rate, save_second, save_indices, single, elapsed, echo):
+    if single:
+        timestamps.write_timestamp_files(all_ts[0], sample_rate, save_second, save_indices, echo)
+    else:
+        for k, ts in enumerate(all_ts):
+            timestamps.write_timestamp_files(ts, sample_rate, f"{save_second}.{k}", f"{save_indices}.{k}", lambda *_: None)
+    echo(f"\nVAD Process Complete.\n\nTime Cost: {elapsed:.3f} Seconds")
+    return all_ts[0] if single else all_ts
+
+
+def inference_silero(test_vad_audio="./vad_sample.wav", model=None, save_timestamps_second="./timestamps_second.txt",
+                     save_timestamps_indices="./timestamps_indices.txt", ACTIVATE_THRESHOLD=0.5, FUSION_THRESHOLD=0.3,
+                     MIN_SPEECH_DURATION=0.25, MAX_SPEECH_DURATION=20, MIN_SILENCE_DURATION=250, SAMPLE_RATE=16000,
+                     echo=print):
+    """Silero/Inference_Silero_VAD_ONNX.py:80-120."""
+    from . import silero
+    files = _as_list(test_vad_audio)
+    model = silero.load_silero_vad(onnx=True, use_cpu=True, path="synthetic:1234") if model is None else model
+    clips = [audio_io.load_wav(f, SAMPLE_RATE).astype(np.float32) * np.float32(0.000030517578) for f in files]
+    echo("\nStart to run the VAD process.")
+    t0 = time.time()
+    n = max(len(c) for c in clips)
+    batch = np.zeros((len(clips), n), np.float32)
+    for k, c in enumerate(clips):
+        batch[k, :len(c)] = c
+    res = silero.get_speech_timestamps_batch(batch, model, lengths=[len(c) for c in clips], threshold=ACTIVATE_THRESHOLD,
+                                             max_speech_duration_s=MAX_SPEECH_DURATION,
+                                             min_speech_duration_ms=int(MIN_SPEECH_DURATION * 1000),
+                                             min_silence_duration_ms=MIN_SILENCE_DURATION, return_seconds=True)
+    elapsed = time.time() - t0
+    echo(f"\nVAD Complete. Time Cost: {elapsed:.3f} seconds.")
+    all_ts = [timestamps.process_timestamps([(d["start"], d["end"]) for d in r], FUSION_THRESHOLD, MIN_SPEECH_DURATION) for r in res]
+    return _finish(all_ts, SAMPLE_RATE, save_timestamps_second, save_timestamps_indices, not isinstance(test_vad_audio, (list, tuple)), elapsed, echo)
+
+
+def inference_fsmn(test_vad_audio="./vad_sample.wav", engine=None, save_timestamps_second="./timestamps_second.txt",
+                   save_timestamps_indices="./timestamps_indices.txt", FUSION_THRESHOLD=0.3, MIN_SPEECH_DURATION=0.2,
+                   SPEAKING_SCORE=0.5, SILENCE_SCORE=0.5, LOOK_BACKWARD=0.3, SNR_THRESHOLD=10.0,
+                   BACKGROUND_NOISE_dB_INIT=30.0, ONE_MINUS_SPEECH_THRESHOLD=1.0, pad_noise=None, echo=print):
+    """FSMN/Inference_FSMN_VAD_ONNX.py:66-260."""
+    from . import fsmn
+    files = _as_list(test_vad_audio)
+    engine = fsmn.FsmnEngine() if engine is None else engine
+    clips = [audio_io.load_wav(f, 16000) for f in files]
+    echo("\nRunning the FSMN_VAD by ONNX Runtime.")
+    t0 = time.time()
+    all_ts = []
+    for c, nz in zip(clips, pad_noise if pad_noise is not None else [None] * len(clips)):
+        all_ts += engine.detect(c[None, :].astype(np.float32), pad_noise=None if nz is None else nz[None, :],
+                                fusion_threshold=FUSION_THRESHOLD, min_speech_duration=MIN_SPEECH_DURATION,
+                                look_backward_s=LOOK_BACKWARD, speaking_score=SPEAKING_SCORE, silence_score=SILENCE_SCORE,
+                                snr_threshold=SNR_THRESHOLD, noise_init_dB=BACKGROUND_NOISE_dB_INIT,
+                                one_minus_speech_threshold=ONE_MINUS_SPEECH_THRESHOLD)
+    elapsed = time.time() - t0
+    return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_vad_audio, (list, tuple)), elapsed, echo)
+
+
+def inference_firered(test_vad_audio="./vad_sample.wav", engine=None, save_timestamps_second="./timestamps_second.txt",
+                      save_timestamps_indices="./timestamps_indices.txt", NORMALIZE_AUDIO=False, SMOOTH_WINDOW_SIZE=5,
+                      SPEAKING_SCORE=0.4, MIN_SPEECH_FRAME=20, MAX_SPEECH_FRAME=2000, MIN_SILENCE_FRAME=20,
+                      MERGE_SILENCE_FRAME=5, EXTEND_SPEECH_FRAME=0, pad_noise=None, echo=print):
+    """FireRedVAD/Inference_FireRed_ONNX.py:523-613 (RUN_VAD)."""
+    from . import firered
+    files = _as_list(test_vad_audio)
+    engine = firered.FireRedEngine() if engine is None else engine
+    clips = [audio_io.load_wav(f, 16000) for f in files]
+    if NORMALIZE_AUDIO:
+        clips = [timestamps.normalise_audio(c) for c in clips]
+    echo("\nRunning the FireRedVAD by ONNX Runtime.")
+    t0 = time.time()
+    post = (SMOOTH_WINDOW_SIZE, SPEAKING_SCORE, MIN_SPEECH_FRAME, MAX_SPEECH_FRAME, MIN_SILENCE_FRAME,
+            MERGE_SILENCE_FRAME, EXTEND_SPEECH_FRAME)
+    all_ts = []
+    for c, nz in zip(clips, pad_noise if pad_noise is not None else [None] * len(clips)):
+        all_ts += engine.detect(c[None, :], pad_noise=None if nz is None else nz[None, :], post=post)
+    elapsed = time.time() - t0
+    echo(f"RTF: {elapsed / (len(clips[0]) / 16000):.4f}")
+    return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_vad_audio, (list, tuple)), elapsed, echo)
+
+
+def inference_marblenet(test_vad_audio="./vad_sample.wav", engine=None, save_timestamps_second="./timestamps_second.txt",
+                        save_timestamps_indices="./timestamps_indices.txt", NORMALIZE_AUDIO=False, SMOOTH_WINDOW_SIZE=3,
+                        SPEAKING_SCORE=0.5, MIN_SPEECH_FRAME=10, MAX_SPEECH_FRAME=1000, MIN_SILENCE_FRAME=10,
+                        MERGE_SILENCE_FRAME=3, EXTEND_SPEECH_FRAME=0, INPUT_AUDIO_LENGTH=None, pad_noise=None, echo=print):
+    """NVIDIA_.../Inference_NVIDIA_MarbleNet_VAD_ONNX.py:120-422 (dynamic axis: one window per clip)."""
+    from . import marblenet
+    files = _as_list(test_vad_audio)
+    engine = marblenet.MarbleNetEngine() if engine is None else engine
+    clips = [audio_io.load_wav(f, 16000) for f in files]
+    if NORMALIZE_AUDIO:
+        clips = [timestamps.normalise_audio(c) for c in clips]
+    echo("\nRunning the NVIDIA_VAD by ONNX Runtime.")
+    t0 = time.time()
+    post = (SMOOTH_WINDOW_SIZE, SPEAKING_SCORE, MIN_SPEECH_FRAME, MAX_SPEECH_FRAME, MIN_SILENCE_FRAME,
+            MERGE_SILENCE_FRAME, EXTEND_SPEECH_FRAME)
+    all_ts = []
+    for c, nz in zip(clips, pad_noise if pad_noise is not None else [None] * len(clips)):
+        all_ts += engine.detect(c[None, :], window_len=INPUT_AUDIO_LENGTH, pad_noise=None if nz is None else nz[None, :], post=post)
+    elapsed = time.time() - t0
+    return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_vad_audio, (list, tuple)), elapsed, echo)
