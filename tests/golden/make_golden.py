@@ -421,6 +421,102 @@ def gen_firered():
     save("firered_forward", **out)
 
 
+# ------------------------------------------------------------------------------------ DFSMN near+far
+def gen_dfsmn():
+    print("DFSMN_VAD wrapper + ICCRN + UniDeepFsmn (near+far)")
+    import types as _t
+    import torchaudio
+    stft_mod = R.load_module("DFSMN/near_and_far_end_audio/STFT_Process.py", "ref_stft_v1b")
+    # fake parent package so uni_deep_fsmn's relative import resolves
+    pkg = _t.ModuleType("aecpkg")
+    pkg.__path__ = []
+    sys.modules["aecpkg"] = pkg
+    lb = _t.ModuleType("aecpkg.layer_base")
+
+    class LayerBase(torch.nn.Module):
+        pass
+    lb.LayerBase = LayerBase
+    lb.expect_token_number = lb.expect_kaldi_matrix = lb.to_kaldi_matrix = lambda *a, **k: None
+    sys.modules["aecpkg.layer_base"] = lb
+    spec = __import__("importlib.util").util.spec_from_file_location(
+        "aecpkg.uni_deep_fsmn", os.path.join(R.REF, "DFSMN/near_and_far_end_audio/modeling_modified/uni_deep_fsmn.py"))
+    udf = __import__("importlib.util").util.module_from_spec(spec)
+    sys.modules["aecpkg.uni_deep_fsmn"] = udf
+    spec.loader.exec_module(udf)
+    ns = {"torch": torch, "torchaudio": torchaudio, "np": np}
+    R.select_nodes("DFSMN/near_and_far_end_audio/Export_DFSMN_VAD.py",
+                   {"AlphaPredictor", "CFB", "CepsUnit", "LayerNorm", "NET", "CH_LSTM_T", "CH_LSTM_F", "DFSMN_VAD"}, ns,
+                   consts={"NFFT_B", "WINDOW_LENGTH_B", "HOP_LENGTH_B", "ALPHA_K"})
+    out = {}
+    for seed in (1234, 7):
+        w = weights.dfsmn_synthetic(seed)
+        m = weights.DFSMN_MASK
+        torch.manual_seed(0)
+        net = ns["NET"](max_frames=200)
+        missing = net.load_state_dict({k[len("iccrn."):]: T(v) for k, v in w.items() if k.startswith("iccrn.")}, strict=False)
+        assert not missing.unexpected_keys and all(("kernel" in k or "basis" in k or "window_sum" in k) for k in missing.missing_keys), missing
+        net = net.float().eval()
+        alpha = ns["AlphaPredictor"](10)
+        alpha.load_state_dict({k[len("alpha."):]: T(v) for k, v in w.items() if k.startswith("alpha.")}, strict=True)
+        alpha = alpha.float().eval()
+
+        class Mask(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.linear1 = torch.nn.Linear(240, m["hidden"])
+                self.relu = torch.nn.ReLU()
+                self.deepfsmn = torch.nn.Sequential(*[udf.UniDeepFsmn(m["hidden"], m["hidden"], m["lorder"], m["fsmn_hidden"])
+                                                       for _ in range(m["layers"])])
+                self.linear3 = torch.nn.Linear(m["hidden"], 1)
+        mask = Mask()
+        mask.load_state_dict({k[len("mask."):]: T(v) for k, v in w.items() if k.startswith("mask.") and k not in ("mask.shift", "mask.scale")}, strict=True)
+        holder = _t.SimpleNamespace(model=mask.eval(), preprocessor=_t.SimpleNamespace(
+            feature=_t.SimpleNamespace(shift=T(w["mask.shift"]), scale=T(w["mask.scale"]))))
+        mk = lambda n, h, wl: stft_mod.STFT_Process(model_type="stft_B", n_fft=n, hop_len=h, win_length=wl, max_frames=0, window_type="hamming").eval()   # noqa: E731
+        model = ns["DFSMN_VAD"](holder, net, alpha, mk(1024, 320, 640), mk(640, 320, 640), mk(319, 160, 319),
+                                1024, 319, 10, 200, 0.97, 16000, 80)
+        cap = {}
+        net.register_forward_hook(lambda mod, inp, res: cap.update(x=inp[0].detach().clone(), y=res[0].detach().clone()))
+        near = weights.burst_clips(1, 16001, seed=seed + 1)[0].reshape(1, 1, -1)
+        far = weights.burst_clips(1, 16001, seed=seed + 2)[0].reshape(1, 1, -1)
+        with torch.no_grad():
+            vad = model(T(near), T(far))
+        out[f"s{seed}_near"], out[f"s{seed}_far"] = near, far
+        out[f"s{seed}_vad"] = vad.numpy()
+        out[f"s{seed}_aec"] = cap["y"].numpy()[0, 0]
+        out[f"s{seed}_iccrn_in_ds"] = cap["x"].numpy()[0, :, ::8, ::5]          # subsampled ICCRN input (alpha-scaled far)
+    save("dfsmn_forward", **out)
+
+    # host loop of the DFSMN driver on replayed float scores
+    rng = np.random.default_rng(1234)
+    hl = {}
+    for case in range(5):
+        n_chunks = [1, 2, 6, 15, 3][case]
+        scores = [np.clip(0.5 + 0.4 * np.sin(np.arange(51) / (2.0 + case) + k) + 0.2 * rng.standard_normal(51), 0, 1).astype(np.float32)
+                  for k in range(n_chunks)]
+        if case == 4:
+            scores[1][:] = 0.5                                         # exactly on both thresholds
+
+        class FakeSess:
+            def __init__(self):
+                self.k = 0
+
+            def run(self, names, feeds):
+                self.k += 1
+                return [scores[self.k - 1]]
+        L, stride = 16001, 16001 - 16 * 320
+        aligned = (n_chunks - 1) * stride + L
+        env = dict(np=np, time=__import__("time"), ort_session_A=FakeSess(), out_name_A0="o", in_name_A0="a", in_name_A1="b",
+                   near_end_audio=np.zeros((1, 1, aligned), np.int16), far_end_audio=np.zeros((1, 1, aligned), np.int16),
+                   INPUT_AUDIO_LENGTH=L, aligned_len=aligned, look_backward=15, stride_step=stride, SPEAKING_SCORE=0.5,
+                   SILENCE_SCORE=0.5, inv_audio_len=0.0, print=lambda *a, **k: None)
+        R.select_lines("DFSMN/near_and_far_end_audio/Inference_DFSMN_VAD_ONNX.py", 221, 273, env)
+        hl[f"scores_{case}"] = np.stack(scores)
+        hl[f"saved_{case}"] = np.array(env["saved"], dtype=bool)
+    hl["n_cases"] = np.array(5)
+    save("dfsmn_hostloop", **hl)
+
+
 # ------------------------------------------------------------------------------------ MarbleNet BN fold
 def gen_marblenet_fold():
     print("MarbleNet fold_bn_into_conv1d")
@@ -451,7 +547,7 @@ def gen_marblenet_fold():
 if __name__ == "__main__":
     which = set(sys.argv[1:])
     gens = dict(stft=gen_stft, host=gen_host, vadpost=gen_vadpost, silero_host=gen_silero_host,
-                fsmn=gen_fsmn, firered=gen_firered, marblenet_fold=gen_marblenet_fold)
+                fsmn=gen_fsmn, firered=gen_firered, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn)
     for name, fn in gens.items():
         if not which or name in which:
             fn()

@@ -212,3 +212,29 @@ def test_marblenet_bn_fold(golden):
         w3, b3 = weights.fold_bn(g[f"w_{i}"], g[f"b_{i}"] if has_b else None, *args, float(g[f"eps_{i}"]))      # product (numpy)
         np.testing.assert_allclose(w3, g[f"fw_{i}"], rtol=3e-7, atol=0)
         np.testing.assert_allclose(b3, g[f"fb_{i}"], rtol=3e-6, atol=2e-7)
+
+
+# ------------------------------------------------------------------ a18-a20 (DFSMN near+far, ICCRN, UniDeepFsmn)
+@pytest.mark.parametrize("seed", [1234, 7])
+def test_dfsmn_forward(golden, seed):
+    from oracle import dfsmn as od
+    g = golden("dfsmn_forward")
+    w = {k: T(v) for k, v in weights.dfsmn_synthetic(seed).items()}
+    w["mask.shift"] = w["mask.shift"] + torch.log(torch.tensor(32768 ** 2, dtype=torch.float32))   # wrapper __init__ :291
+    vad, aec = od.forward(od.Frontend(), w, T(g[f"s{seed}_near"]), T(g[f"s{seed}_far"]), weights.DFSMN_MASK["layers"])
+    np.testing.assert_allclose(aec.numpy()[0, 0], g[f"s{seed}_aec"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(vad.numpy(), g[f"s{seed}_vad"], rtol=0, atol=2e-5)
+
+
+def test_dfsmn_hostloop(golden):
+    from oracle import dfsmn as od
+    g = golden("dfsmn_hostloop")
+    for c in range(int(g["n_cases"])):
+        scores = g[f"scores_{c}"]
+        silence, saved = True, []
+        for k in range(scores.shape[0]):
+            flags, silence = opp.lookahead_vote(scores[k], 51 - 15, 15, 0.5, 0.5, silence, thresholds=(0.5, 0.5))
+            saved += flags
+        flags, silence = od.tail_flags(scores[-1], 51 - 15, 51, silence)
+        saved += flags
+        assert np.array_equal(np.array(saved, bool), g[f"saved_{c}"]), c

@@ -220,3 +220,82 @@ def fold_bn(conv_w, conv_b, gamma, beta, mean, var, eps):
     new_w = (conv_w * scale.reshape((-1,) + (1,) * (conv_w.ndim - 1))).astype(np.float32)
     base = (conv_b - mean) if conv_b is not None else (-mean)
     return new_w, (base * scale + beta).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- DFSMN near+far (SDAEC ICCRN + mask-net)
+DFSMN_MASK = dict(hidden=128, fsmn_hidden=256, layers=4, lorder=20)     # modelscope container dims are external: stand-in
+
+
+def _lstm_keys(prefix, in_dim, hid, layers, bi):
+    out = {}
+    for l in range(layers):
+        d_in = in_dim if l == 0 else hid * (2 if bi else 1)
+        for suf in ([""] + (["_reverse"] if bi else [])):
+            out[f"{prefix}weight_ih_l{l}{suf}"] = (4 * hid, d_in)
+            out[f"{prefix}weight_hh_l{l}{suf}"] = (4 * hid, hid)
+            out[f"{prefix}bias_ih_l{l}{suf}"] = (4 * hid,)
+            out[f"{prefix}bias_hh_l{l}{suf}"] = (4 * hid,)
+    return out
+
+
+def dfsmn_shapes(ch=20, mask=None):
+    """state_dict names -> shapes of AlphaPredictor ('alpha.'), ICCRN NET ('iccrn.') and the mask-net
+    stand-in ('mask.') (DFSMN/near_and_far_end_audio/Export_DFSMN_VAD.py:65-284)."""
+    m = dict(DFSMN_MASK if mask is None else mask)
+    s = {"alpha.linear1.weight": (1, 2), "alpha.linear1.bias": (1,), "alpha.linear2.weight": (1, 10), "alpha.linear2.bias": (1,)}
+    ic = {}
+    ic.update(_lstm_keys("in_ch_lstm.lstm2.", 4, ch, 1, True))
+    ic.update({"in_ch_lstm.linear.weight": (ch, 2 * ch), "in_ch_lstm.linear.bias": (ch,),
+               "in_conv.weight": (ch, 4 + ch, 1, 1), "in_conv.bias": (ch,)})
+    for name, cin in (("cfb_e1", ch), ("cfb_e2", ch), ("cfb_e3", ch), ("cfb_e4", ch), ("cfb_e5", ch), ("cfb_d5", ch),
+                      ("cfb_d4", 2 * ch), ("cfb_d3", 2 * ch), ("cfb_d2", 2 * ch), ("cfb_d1", 2 * ch)):
+        ic.update({f"{name}.conv_gate.weight": (ch, cin, 1, 1), f"{name}.conv_gate.bias": (ch,),
+                   f"{name}.conv_input.weight": (ch, cin, 1, 1), f"{name}.conv_input.bias": (ch,),
+                   f"{name}.conv.weight": (ch, ch, 3, 1), f"{name}.conv.bias": (ch,),
+                   f"{name}.LN0.w": (1, cin, 160, 1), f"{name}.LN0.b": (1, cin, 160, 1),
+                   f"{name}.LN1.w": (1, ch, 160, 1), f"{name}.LN1.b": (1, ch, 160, 1),
+                   f"{name}.LN2.w": (1, ch, 160, 1), f"{name}.LN2.b": (1, ch, 160, 1),
+                   f"{name}.ceps_unit.LN.w": (1, 2 * ch, 81, 1), f"{name}.ceps_unit.LN.b": (1, 2 * ch, 81, 1),
+                   f"{name}.ceps_unit.ch_lstm_f.linear.weight": (2 * ch, 2 * ch), f"{name}.ceps_unit.ch_lstm_f.linear.bias": (2 * ch,)})
+        ic.update(_lstm_keys(f"{name}.ceps_unit.ch_lstm_f.lstm2.", 2 * ch, ch, 1, True))
+    ic.update({"ln.w": (1, ch, 160, 1), "ln.b": (1, ch, 160, 1)})
+    ic.update(_lstm_keys("ch_lstm.lstm2.", ch, 2 * ch, 2, False))
+    ic.update({"ch_lstm.linear.weight": (ch, 2 * ch), "ch_lstm.linear.bias": (ch,)})
+    ic.update(_lstm_keys("out_ch_lstm.lstm2.", 2 * ch, ch, 1, False))
+    ic.update({"out_ch_lstm.linear.weight": (2 * ch, ch), "out_ch_lstm.linear.bias": (2 * ch,),
+               "out_conv.weight": (2, 3 * ch, 1, 1), "out_conv.bias": (2,)})
+    s.update({"iccrn." + k: v for k, v in ic.items()})
+    H, H2 = m["hidden"], m["fsmn_hidden"]
+    s.update({"mask.shift": (240,), "mask.scale": (240,), "mask.linear1.weight": (H, 240), "mask.linear1.bias": (H,),
+              "mask.linear3.weight": (1, H), "mask.linear3.bias": (1,)})
+    for i in range(m["layers"]):
+        s.update({f"mask.deepfsmn.{i}.linear.weight": (H2, H), f"mask.deepfsmn.{i}.linear.bias": (H2,),
+                  f"mask.deepfsmn.{i}.project.weight": (H, H2), f"mask.deepfsmn.{i}.conv1.weight": (H, 1, m["lorder"], 1)})
+    return s
+
+
+def dfsmn_synthetic(seed=1234, mask=None):
+    w = {}
+    for k, shp in dfsmn_shapes(mask=mask).items():
+        if k.endswith(".w"):                                     # LayerNorm gain
+            w[k] = (1.0 + 0.1 * _rng(seed, k).standard_normal(shp)).astype(np.float32)
+        elif k.endswith(".b") and ".LN" in k or k.endswith("ln.b"):
+            w[k] = (_rng(seed, k).uniform(0, 1, shp) * 1e-4).astype(np.float32)
+        elif "bias" in k:
+            w[k] = _normal(seed, k, shp, 0.05)
+        elif k == "mask.shift":
+            w[k] = (13.0 + 0.5 * _rng(seed, k).standard_normal(shp)).astype(np.float32)   # + log(32768^2) is added at load
+        elif k == "mask.scale":
+            w[k] = (0.3 + 0.02 * _rng(seed, k).standard_normal(shp)).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else shp[0]
+            w[k] = _normal(seed, k, shp, 1.0 / np.sqrt(max(fan_in, 1)))
+    w["alpha.linear1.weight"] = np.array([[0.6, -0.3]], np.float32)
+    w["alpha.linear2.weight"] = np.full((1, 10), 0.1, np.float32)
+    s, t = _DFSMN_OUT_CALIB.get(seed, (1.0, 0.0))
+    w["mask.linear3.weight"] = (w["mask.linear3.weight"] * np.float32(s)).astype(np.float32)
+    w["mask.linear3.bias"] = (w["mask.linear3.bias"] * np.float32(s) + np.float32(t)).astype(np.float32)
+    return w
+
+
+_DFSMN_OUT_CALIB = {}
