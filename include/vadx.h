@@ -256,6 +256,34 @@ int vadx_frame_classifier(const float *enc, const float *dec_w, const float *dec
                           int frames, float *score0, float *score1, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DFSMN near+far: ICCRN building blocks on frame-tiled ("FT") activations
+ *   [tile = chunk*NT + t/16][C][F][16]  -- element (c,f,t) at ((tile*C + c)*F + f)*16 + t%16.
+ * Reference: DFSMN/near_and_far_end_audio/Export_DFSMN_VAD.py (LayerNorm :157-167, CFB :76-93,
+ * CepsUnit :96-154, CH_LSTM_F :270-284, CH_LSTM_T :252-267, NET :170-249, DFSMN_VAD :287-354).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vadx_ft_view { const float *ptr; int c_total, c_off, c; } vadx_ft_view;   /* channel slice */
+typedef struct vadx_ft_ln { const float *stats, *w, *b; } vadx_ft_ln;                    /* LayerNorm on the fly */
+
+/* stats[tile][16][2] = (mean, 1/(unbiased std + 1e-6)) over (C,F) of cat(a, b) per frame. */
+int vadx_dfsmn_frame_stats(const vadx_ft_view *a, const vadx_ft_view *b, int F, int tiles, float *stats, void *stream);
+/* mode 0: out0 = act(conv(cat(a,b)) + bias)        (kf taps along F, weights [ceil16(co)][kf*cin])
+ * mode 1: CFB front: g = sigmoid(convG(LN(x)) + bias); xi = convI(x) + bias2; out0 = g*xi; out1 = xi - g*xi
+ * mode 2: CFB back : out0 = conv31(LN(x)) + bias + add */
+int vadx_dfsmn_pw_conv(int mode, const vadx_ft_view *a, const vadx_ft_view *b, const vadx_ft_ln *ln,
+                       const float *w, const float *bias, const float *w2, const float *bias2,
+                       const vadx_ft_view *add, const vadx_ft_view *out0, const vadx_ft_view *out1,
+                       int F, int co, int kf, int act, int tiles, void *stream);
+/* CepsUnit's length-160 real DFT along F (inverse=0: in C ch x 160 -> out 2C ch x 81, LayerNorm on the
+ * input) and its pinv-based inverse fused with the complex product (inverse=1: in = spectrum, lo = LSTM
+ * output, both 2C ch x 81 -> out C ch x 160).  tbl = [192][160] (cos|sin rows, padded) / [160][164]. */
+int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_ft_view *lo, const vadx_ft_ln *ln,
+                     const float *tbl, const vadx_ft_view *out, int C, int tiles, void *stream);
+/* bi-LSTM (hidden 20) along F with the tile's 16 frames as the batch; in->c = 4 or 40; out 40 ch. */
+int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2],
+                      const float *const w_hh[2], const float *const b_ih[2], const float *const b_hh[2],
+                      const vadx_ft_view *out, int F, int tiles, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Test hooks (used by tests/ only)
  * ------------------------------------------------------------------------------------------- */
 /* C[M][N] = A[M][K] * W[N][K]^T through the same LDS/MFMA tile helper the nets use.

@@ -76,6 +76,14 @@ class SepConvCfg(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("cin", "cout", "kernel", "stride", "dilation", "depthwise", "residual_cin", "relu")]
 
 
+class FtView(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("c_total", C.c_int), ("c_off", C.c_int), ("c", C.c_int)]
+
+
+class FtLn(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p)]
+
+
 _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/vadx.h declares
@@ -106,6 +114,12 @@ SIGNATURES = {
     "vadx_vadpost": (_I, [C.POINTER(VadPostParams), _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "vadx_sepconv_block": (_I, [C.POINTER(SepConvCfg), _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _I, _I, _P]),
     "vadx_frame_classifier": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "vadx_dfsmn_frame_stats": (_I, [C.POINTER(FtView), C.POINTER(FtView), _I, _I, _P, _P]),
+    "vadx_dfsmn_pw_conv": (_I, [_I, C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtLn), _P, _P, _P, _P,
+                                C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtView), _I, _I, _I, _I, _I, _P]),
+    "vadx_dfsmn_dft_f": (_I, [_I, C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtLn), _P, C.POINTER(FtView), _I, _I, _P]),
+    "vadx_dfsmn_lstm_f": (_I, [C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
+                               C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), C.POINTER(FtView), _I, _I, _P]),
     "vadx_test_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
 }
 
