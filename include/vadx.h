@@ -115,7 +115,8 @@ int vadx_silero_segments(const float *probs, int batch, int steps, const int64_t
 typedef struct vadx_frontend_cfg {
     int   prep;        /* 0: x-mean(window), then y[n]=a[n]-0.97*a[n-1], y[0]=a[0]        (FSMN)
                           1: y[n]=k0*x[n-1]+k1*x[n], x[-1]=0                             (MarbleNet, FireRed)
-                          2: y = k1*x - mean(k1*x)                                       (DFSMN) */
+                          2: y = k1*x - mean(k1*x)                                       (DFSMN STFT-B)
+                          3/4/5: DFSMN feature streams, see vadx_frontend_logmel_ex */
     float k0, k1;
     int   center_pad;  /* zeros on each side of the window (n_fft/2, or 0 for snip-edges) */
     int   tap0, taps;  /* non-zero span of the centre-padded analysis window inside n_fft */
@@ -138,6 +139,21 @@ int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float *cos_tab, 
 int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host,
                          const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
                          int windows_per_clip, float *means_ws, float *out, void *stream);
+
+/* DFSMN variants of the fused front-end (DFSMN/.../Export_DFSMN_VAD.py:322-325, 338-348):
+ *   prep 3: near stream  a = k1*x - mean, pre-emphasis 0.97 keeping a[0]        (int16 source + means)
+ *   prep 4: AEC stream   pre-emphasis of the float waveform `faux` [windows][window_len]
+ *   prep 5: echo stream  near_pe - k0 * aec_pe                                  (both sources)
+ * Each call writes n_mels columns at `out_off` of rows of `out_stride` floats (3 calls fill the 240-dim row). */
+int vadx_frontend_logmel_ex(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host,
+                            const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
+                            int windows_per_clip, const float *means, const float *faux, int out_stride,
+                            int out_off, float *out, void *stream);
+/* Raw complex STFT (prep 2) into a frame-tiled tensor [window*ceil(frames/16) + t/16][c_total][n_bins][16]:
+ * real part at channel c_off, imaginary at c_off+1 (the two-stream STFT-B of DFSMN_VAD.forward :322-325). */
+int vadx_frontend_stft_ft(const vadx_frontend_cfg *cfg, const float *packed, const int16_t *audio,
+                          int64_t row_stride, int64_t win_stride, int batch, int windows_per_clip,
+                          float *means_ws, float *ft_out, int c_total, int c_off, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * FSMN-VAD
@@ -282,6 +298,36 @@ int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_ft_view *lo
 int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2],
                       const float *const w_hh[2], const float *const b_ih[2], const float *const b_hh[2],
                       const vadx_ft_view *out, int F, int tiles, void *stream);
+
+/* x4 = [mix_re, mix_im, |alpha| far_re, |alpha| far_im] (FT, 4 ch x 160), DFSMN_VAD.forward :326-335. */
+int vadx_dfsmn_alpha_scale(const float *in, float *out, int chunks, int nt, const float *w1, const float *b1,
+                           const float *w2, const float *b2, void *stream);
+/* LSTM along time, 16 bins per workgroup.  which = 0: NET.ch_lstm (in 20, hidden 40, 2 layers, Linear 40->20,
+ * output multiplied element-wise with `mul` = e5);  which = 1: NET.out_ch_lstm (in 40, hidden 20, Linear 20->40).
+ * wl rows zero-padded to a multiple of 16. */
+int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2], const float *const w_hh[2],
+                      const float *const b_ih[2], const float *const b_hh[2], const float *wl, const float *bl,
+                      const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, void *stream);
+/* NET.istft :220-224: y_ft FT [2 ch x 160] -> out f32 [chunks][(frames-1)*160 + 1]; basis_t [320 j][320 ch]
+ * (transposed inverse basis, row 319 zero), wsum_inv = the reference's window_sum_inv buffer; z_ws scratch
+ * of chunks*frames*320 floats. */
+int vadx_dfsmn_istft(const float *y_ft, const float *basis_t, const float *wsum_inv, float *z_ws, float *out,
+                     int chunks, int frames, void *stream);
+/* mask-net head: device pointers; linear weights zero-padded to multiples of 16 in BOTH dims
+ * ([Hp][240], [H2p][Hp], [Hp][H2p]); conv1 [hidden][lorder]; shift already includes log(32768^2). */
+typedef struct vadx_dfsmn_mask_weights {
+    int hidden, fsmn_hidden, layers, lorder;
+    const float *shift, *scale, *linear1_w, *linear1_b, *linear3_w, *linear3_b;
+    const float *fsmn_linear_w[8], *fsmn_linear_b[8], *fsmn_project_w[8], *fsmn_conv_w[8];
+} vadx_dfsmn_mask_weights;
+/* feat f32 [chunks][frames][240] (3 x 80 log-fbank streams) -> vad f32 [chunks][frames]
+ * (DFSMN_VAD.forward :349-353 + UniDeepFsmn.compute1, uni_deep_fsmn.py:311-329). */
+int vadx_dfsmn_mask_net(const vadx_dfsmn_mask_weights *w, const float *feat, int chunks, int frames, float *vad,
+                        void *stream);
+/* Look-ahead vote + tail of the DFSMN driver (Inference_DFSMN_VAD_ONNX.py:231-273): vad f32 [B][W][frames]
+ * -> flags u8 [B][W*(frames-lb) + lb] (1 = silence). */
+int vadx_dfsmn_vote(const float *vad, int batch, int windows, int frames, int look_backward, double speaking_score,
+                    double silence_score, uint8_t *flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Test hooks (used by tests/ only)

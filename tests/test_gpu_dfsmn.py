@@ -39,3 +39,32 @@ def test_cfb_block(wts, name, cin, frames, chunks):
     got = dfsmn.from_ft(out, chunks).cpu()
     err = (got - want).abs().max().item()
     assert err < 2e-4 * max(1.0, want.abs().max().item()), err
+
+
+@pytest.mark.parametrize("seed", [1234, 7])
+def test_session_matches_reference_fixture(golden, seed):
+    """Whole graph, two streams in -> vad_results, against what the REFERENCE classes produced."""
+    g = golden("dfsmn_forward")
+    sess = dfsmn.DfsmnSession(weights.dfsmn_synthetic(seed))
+    assert [m.name for m in sess.get_inputs()] == ["near_end_audio", "far_end_audio"]
+    vad, aec = sess.engine.run(g[f"s{seed}_near"].reshape(1, -1), g[f"s{seed}_far"].reshape(1, -1), return_aec=True)
+    a = aec.cpu().numpy()[0]
+    assert np.abs(a - g[f"s{seed}_aec"]).max() < 2e-4 * max(1.0, np.abs(g[f"s{seed}_aec"]).max())
+    np.testing.assert_allclose(vad.cpu().numpy()[0], g[f"s{seed}_vad"], rtol=0, atol=1e-4)
+    out = sess.run(None, {"near_end_audio": g[f"s{seed}_near"], "far_end_audio": g[f"s{seed}_far"]})[0]
+    assert out.shape == (51,) and out.dtype == np.float32
+
+
+def test_whole_clip_pair_segments():
+    seed = 1234
+    eng = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(seed))
+    w = {k: T(v) for k, v in weights.dfsmn_synthetic(seed).items()}
+    w["mask.shift"] = w["mask.shift"] + torch.log(torch.tensor(32768 ** 2, dtype=torch.float32))
+    fe = od.Frontend()
+    B, n = 2, 40000
+    near, far = weights.burst_clips(B, n, seed=3), weights.burst_clips(B, n + 500, seed=4)
+    nz1, nz2 = np.random.default_rng(5).standard_normal((B, 20000)), np.random.default_rng(6).standard_normal((B, 20000))
+    got = eng.detect(near, far, nz1, nz2)
+    for b in range(B):
+        want, _ = od.run_clip(fe, w, near[b], far[b], nz1[b], nz2[b], weights.DFSMN_MASK["layers"])
+        assert got[b] == want

@@ -84,6 +84,13 @@ class FtLn(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p)]
 
 
+class DfsmnMaskWeights(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("fsmn_hidden", C.c_int), ("layers", C.c_int), ("lorder", C.c_int),
+                ("shift", C.c_void_p), ("scale", C.c_void_p), ("linear1_w", C.c_void_p), ("linear1_b", C.c_void_p),
+                ("linear3_w", C.c_void_p), ("linear3_b", C.c_void_p), ("fsmn_linear_w", C.c_void_p * 8),
+                ("fsmn_linear_b", C.c_void_p * 8), ("fsmn_project_w", C.c_void_p * 8), ("fsmn_conv_w", C.c_void_p * 8)]
+
+
 _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/vadx.h declares
@@ -120,6 +127,15 @@ SIGNATURES = {
     "vadx_dfsmn_dft_f": (_I, [_I, C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtLn), _P, C.POINTER(FtView), _I, _I, _P]),
     "vadx_dfsmn_lstm_f": (_I, [C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
                                C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), C.POINTER(FtView), _I, _I, _P]),
+    "vadx_dfsmn_alpha_scale": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "vadx_dfsmn_lstm_t": (_I, [_I, C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
+                               C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), _P, _P, C.POINTER(FtView),
+                               C.POINTER(FtView), _I, _I, _I, _P]),
+    "vadx_dfsmn_istft": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "vadx_dfsmn_vote": (_I, [_P, _I, _I, _I, _I, C.c_double, C.c_double, _P, _P]),
+    "vadx_frontend_logmel_ex": (_I, [C.POINTER(FrontendCfg), _P, _P, _P, _L, _L, _I, _I, _P, _P, _I, _I, _P, _P]),
+    "vadx_frontend_stft_ft": (_I, [C.POINTER(FrontendCfg), _P, _P, _L, _L, _I, _I, _P, _P, _I, _I, _P]),
+    "vadx_dfsmn_mask_net": (_I, [C.POINTER(DfsmnMaskWeights), _P, _I, _I, _P, _P]),
     "vadx_test_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
 }
 

@@ -10,6 +10,7 @@
 // LSTM recurrences keep h and c in registers: with gate rows ordered (unit-quad q, gate r) the D
 // fragment of step t is exactly the B fragment of step t+1 -- no LDS, no shuffles.
 #include "common.h"
+#include "layers.h"
 
 #include <math.h>
 #include <string.h>
@@ -295,6 +296,279 @@ __global__ __launch_bounds__(128) void lstm_f_kernel(LstmFArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// alpha_scale (DFSMN_VAD.forward :326-335): x4 = [mix_re, mix_im, |alpha| * far_re, |alpha| * far_im] with
+//   alpha[f][t] = linear2_j( linear1( [pow_far, pow_mix][t-9+j] ) ),  pow = re^2 + im^2, zero history.
+// in: FT [4 ch] (mix re, mix im, far re, far im) of NT tiles per chunk; one thread per (tile, f, t16).
+// ---------------------------------------------------------------------------------------------
+__global__ void alpha_scale_kernel(const float *__restrict__ in, float *__restrict__ out, int nt, long long total,
+                                   const float *__restrict__ w1, const float *__restrict__ b1,
+                                   const float *__restrict__ w2, const float *__restrict__ b2) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int t16 = (int)(e & 15), f = (int)((e >> 4) % 160);
+    const int tile = (int)(e / (160 * 16)), chunk = tile / nt, tl = tile - chunk * nt;
+    const int t = tl * 16 + t16;
+    float alpha = b2[0];
+    for (int j = 0; j < 10; ++j) {
+        const int tt = t - 9 + j;
+        float pf = 0.f, pm = 0.f;
+        if (tt >= 0) {
+            const size_t base = ft_idx(chunk * nt + (tt >> 4), 4, 0, 160, f) + (tt & 15);
+            const float mr = in[base], mi = in[base + 160 * 16], fr = in[base + 2 * 160 * 16], fi = in[base + 3 * 160 * 16];
+            pm = mr * mr + mi * mi;
+            pf = fr * fr + fi * fi;
+        }
+        const float a1 = w1[0] * pf + w1[1] * pm + b1[0];
+        alpha = fmaf(w2[j], a1, alpha);
+    }
+    const float sc = fabsf(alpha);
+    const size_t o = ft_idx(tile, 4, 0, 160, f) + t16;
+    out[o] = in[o];
+    out[o + 160 * 16] = in[o + 160 * 16];
+    out[o + 2 * 160 * 16] = in[o + 2 * 160 * 16] * sc;
+    out[o + 3 * 160 * 16] = in[o + 3 * 160 * 16] * sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lstm_t: LSTM ALONG TIME (CH_LSTM_T :252-267), one sequence per bin, batch = 16 bins of one chunk.
+//   LAYERS = 2 (hidden 40, the bottleneck `ch_lstm`): wave 0 runs layer 0, wave 1 runs layer 1 one step
+//   behind, h0 handed over through double-buffered LDS (one barrier per step).
+//   The output Linear is applied per step from the register-resident h; MODE 0 multiplies it with a
+//   second tensor (d5 input = e5 * lstm_out, NET.forward :236), MODE 1 stores it (out_ch_lstm).
+// ---------------------------------------------------------------------------------------------
+struct LstmTArgs {
+    View in;
+    LN ln;                                                   // LayerNorm on the layer-0 input (NET.ln before ch_lstm)
+    const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];      // per layer
+    const float *wl, *bl;                                    // Linear [OUTP][HID] (rows zero padded), [OUTP]
+    View mul;                                                // MODE 0
+    ViewW out;
+    int F, T, nt, out_ch;
+};
+
+template <int IN, int HID, int LAYERS, int OUT_MT, int MODE>
+__global__ __launch_bounds__(64 * LAYERS) void lstm_t_kernel(LstmTArgs p) {
+    constexpr int MT = HID / 4, KI0 = IN / 4;
+    __shared__ float hs[2][HID * 16];
+    const int lane = threadIdx.x & 63, layer = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    const int groups = p.F / 16, chunk = blockIdx.x / groups, f0 = (blockIdx.x - chunk * groups) * 16;
+    const int grow = (i & 3) * HID + (i >> 2);
+    constexpr int KI = (LAYERS == 2) ? (KI0 > MT ? KI0 : MT) : KI0;       // register array bound
+    const int ki = layer == 0 ? KI0 : MT, in_dim = layer == 0 ? IN : HID;
+    float wi[MT][KI], wh[MT][MT], bias[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = grow + 4 * mt;
+#pragma unroll
+        for (int s = 0; s < KI; ++s) wi[mt][s] = s < ki ? p.w_ih[layer][(size_t)row * in_dim + 4 * s + q] : 0.f;
+#pragma unroll
+        for (int s = 0; s < MT; ++s) wh[mt][s] = p.w_hh[layer][(size_t)row * HID + 4 * s + q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[mt][r] = p.b_ih[layer][r * HID + 4 * mt + q] + p.b_hh[layer][r * HID + 4 * mt + q];
+    }
+    float wl[OUT_MT][MT];
+#pragma unroll
+    for (int om = 0; om < OUT_MT; ++om)
+#pragma unroll
+        for (int s = 0; s < MT; ++s) wl[om][s] = p.wl[(size_t)(om * 16 + i) * HID + 4 * s + q];
+    float h[MT], c[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { h[mt] = 0.f; c[mt] = 0.f; }
+    const bool last = layer == LAYERS - 1;
+    for (int it = 0; it < p.T + LAYERS - 1; ++it) {
+        const int t = it - layer;                            // this wave's time step
+        if (t >= 0 && t < p.T) {
+            const int tile = chunk * p.nt + (t >> 4), t16 = t & 15;
+            float x[KI];
+#pragma unroll
+            for (int s = 0; s < KI; ++s) {
+                x[s] = 0.f;
+                if (s < ki) {
+                    if (layer == 0) {
+                        const float v = p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + 4 * s + q, p.F, f0 + i) + t16];
+                        x[s] = p.ln.stats ? ln_apply(p.ln, tile, t16, (4 * s + q) * p.F + f0 + i, v) : v;
+                    }
+                    else x[s] = hs[t & 1][(4 * s + q) * 16 + i];
+                }
+            }
+            f32x4 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
+#pragma unroll
+            for (int s = 0; s < KI; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wi[mt][s], x[s], acc[mt]);
+#pragma unroll
+            for (int s = 0; s < MT; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wh[mt][s], h[s], acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float ig = sigmoidf_(acc[mt][0]), fg = sigmoidf_(acc[mt][1]), gg = tanhf(acc[mt][2]), og = sigmoidf_(acc[mt][3]);
+                c[mt] = fg * c[mt] + ig * gg;
+                h[mt] = og * tanhf(c[mt]);
+                if (!last) hs[t & 1][(4 * mt + q) * 16 + i] = h[mt];
+            }
+            if (last) {
+#pragma unroll
+                for (int om = 0; om < OUT_MT; ++om) {
+                    f32x4 y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < MT; ++s) y = mfma16(wl[om][s], h[s], y);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = om * 16 + 4 * q + r;
+                        if (o < p.out_ch) {
+                            float v = y[r] + p.bl[o];
+                            if (MODE == 0) v *= p.mul.ptr[ft_idx(tile, p.mul.c_total, p.mul.c_off + o, p.F, f0 + i) + t16];
+                            p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + o, p.F, f0 + i) + t16] = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (LAYERS > 1) __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ISTFT of the ICCRN output (NET.istft :220-224): conv_transpose1d(Y[320][T], basis[320][319], stride 160)
+// = per-frame GEMM Z[t][j] = sum_ch Y[ch][t] * basis[ch][j]  followed by overlap-add, crop of 159
+// samples each side and the precomputed window_sum_inv scaling.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void istft_gemm_kernel(const float *__restrict__ Y, const float *__restrict__ basisT,
+                                                         float *__restrict__ Z, int nt, int T) {
+    // Y: FT [2 ch][160]; basisT: [320 j][320 ch] (row j = 319 is zero); Z: [chunk][T][320]
+    __shared__ float Bs[320 * 16];
+    const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
+    const int chunk = tile / nt, tl = tile - chunk * nt;
+    for (int e = tid; e < 320 * 16; e += 256) Bs[e] = Y[(size_t)tile * 320 * 16 + e];      // [ch][16] contiguous in FT
+    __syncthreads();
+    for (int mt = wave; mt < 20; mt += 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float *arow = basisT + (size_t)(mt * 16 + i) * 320 + q;
+#pragma unroll 8
+        for (int s = 0; s < 80; ++s) acc = mfma16(arow[4 * s], Bs[(4 * s + q) * 16 + i], acc);
+        const int t = tl * 16 + i;
+        if (t < T) {
+            float *z = Z + ((size_t)chunk * T + t) * 320 + mt * 16 + 4 * q;
+            *reinterpret_cast<f32x4 *>(z) = acc;
+        }
+    }
+}
+
+__global__ void istft_ola_kernel(const float *__restrict__ Z, const float *__restrict__ wsum_inv, float *__restrict__ out,
+                                 int T, int L, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int chunk = (int)(e / L), n = (int)(e - (long long)chunk * L) + 159;         // position in the uncropped signal
+    const int t1 = n / 160, j1 = n - t1 * 160;
+    float v = 0.f;
+    if (t1 < T) v = Z[((size_t)chunk * T + t1) * 320 + j1];
+    if (t1 >= 1 && j1 + 160 < 319) v += Z[((size_t)chunk * T + t1 - 1) * 320 + j1 + 160];
+    out[e] = v * wsum_inv[n];
+}
+
+// ---------------------------------------------------------------------------------------------
+// look-ahead vote of the DFSMN driver on float scores (Inference_DFSMN_VAD_ONNX.py:231-273), one clip/thread
+// ---------------------------------------------------------------------------------------------
+__global__ void dfsmn_vote_kernel(const float *__restrict__ vad, int B, int W, int Tn, int lb, double speaking,
+                                  double silence_score, unsigned char *__restrict__ flags) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int slide = Tn - lb, nflags = W * slide + lb;
+    const double inv_lb = 1.0 / (double)lb;
+    const float hi = (float)speaking, lo = (float)silence_score;
+    int silence = 1;
+    unsigned char *fl = flags + (size_t)b * nflags;
+    const float *sc = nullptr;
+    for (int k = 0; k < W; ++k) {
+        sc = vad + ((size_t)b * W + k) * Tn;
+        for (int i2 = 0; i2 < slide; ++i2) {
+            if (silence) {
+                if ((double)sc[i2] >= speaking) {
+                    int act = 1;
+                    for (int j = 1; j < lb; ++j) act += ((double)sc[i2 + j] >= speaking) ? 1 : 0;
+                    silence = !((double)act * inv_lb >= speaking);
+                } else silence = 1;
+            } else {
+                if ((double)sc[i2] <= silence_score) {
+                    int act = 1;
+                    for (int j = 1; j < lb; ++j) act += ((double)sc[i2 + j] <= silence_score) ? 1 : 0;
+                    silence = !((double)act * inv_lb <= silence_score);
+                } else silence = 0;
+            }
+            fl[k * slide + i2] = (unsigned char)silence;
+        }
+    }
+    (void)hi; (void)lo;
+    for (int i2 = slide; i2 < Tn; ++i2) {
+        if (silence) silence = !((double)sc[i2] >= speaking);
+        else silence = ((double)sc[i2] <= silence_score) ? 1 : 0;
+        fl[W * slide + (i2 - slide)] = (unsigned char)silence;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// mask-net head (DFSMN_VAD.forward :349-353 + UniDeepFsmn.compute1, uni_deep_fsmn.py:311-329):
+//   x = relu(linear1((feat + shift) * scale)); N x [ p = project(relu(linear(x))); x += conv1(0^19 ++ p) + p ];
+//   vad = sigmoid(linear3(x)).   One workgroup per chunk, T <= 64 frames, activations k-major in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int MK_LD = 68, MKP_LD = 84, MKP_CUR = 20;
+constexpr int MK_A = 256 * MK_LD, MK_B = 128 * MK_LD, MK_P = 128 * MKP_LD;
+constexpr int MK_LDS_FLOATS = MK_A + MK_B + MK_P;
+
+struct MaskArgs {
+    const float *feat;            // [chunks][T][240]
+    const float *shift, *scale;   // [240]
+    const float *w1, *b1;         // [Hp][240], [Hp]
+    const float *wl[8], *bl[8], *wp[8], *wc[8];   // per layer: linear [H2p][Hp], bias, project [Hp][H2p], conv1 [H][lorder]
+    const float *w3, *b3;         // [H], [1]
+    float *vad;                   // [chunks][T]
+    int T, H, Hp, H2p, layers, lorder;
+};
+
+__global__ __launch_bounds__(512, 2) void mask_net_kernel(MaskArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *bufA = lds, *bufB = lds + MK_A, *bufP = bufB + MK_B;
+    const int tid = threadIdx.x, chunk = blockIdx.x;
+    const float *feat = p.feat + (size_t)chunk * p.T * 240;
+    for (int e = tid; e < 64 * 240; e += 512) {
+        const int t = e / 240, k = e - t * 240;
+        bufA[k * MK_LD + t] = t < p.T ? (feat[(size_t)t * 240 + k] + p.shift[k]) * p.scale[k] : 0.f;
+    }
+    for (int e = tid; e < 128 * MKP_LD; e += 512) bufP[e] = 0.f;          // zero FIR history (stateless per chunk)
+    __syncthreads();
+    LayerArgs a{p.w1, 240, p.Hp / 16, 1, 15, 0, 0, p.b1, 1, bufA, MK_LD, 0, bufB, MK_LD, 0, nullptr, nullptr};
+    layer<4, false>(a);
+    __syncthreads();
+    for (int l = 0; l < p.layers; ++l) {
+        LayerArgs b{p.wl[l], p.Hp, p.H2p / 16, 1, p.Hp / 16, 0, 0, p.bl[l], 1, bufB, MK_LD, 0, bufA, MK_LD, 0, nullptr, nullptr};
+        layer<4, false>(b);
+        __syncthreads();
+        LayerArgs c{p.wp[l], p.H2p, p.Hp / 16, 1, p.H2p / 16, 0, 0, nullptr, 0, bufA, MK_LD, 0, bufP, MKP_LD, MKP_CUR, nullptr, nullptr};
+        layer<4, false>(c);
+        __syncthreads();
+        for (int e = tid; e < p.H * 64; e += 512) {       // depthwise causal FIR (zero left pad) + skip + residual
+            const int ch = e >> 6, t = e & 63;
+            const float *seq = bufP + ch * MKP_LD + MKP_CUR - (p.lorder - 1) + t;      // seq[k] = p[t - (lorder-1) + k]
+            const float *wk = p.wc[l] + ch * p.lorder;
+            float sfir = 0.f;
+            for (int k = 0; k < p.lorder; ++k) sfir = fmaf(wk[k], seq[k], sfir);
+            bufB[ch * MK_LD + t] += sfir + bufP[ch * MKP_LD + MKP_CUR + t];
+        }
+        __syncthreads();
+    }
+    if (tid < 64 && tid < p.T) {
+        float sres = p.b3[0];
+        for (int ch = 0; ch < p.H; ++ch) sres = fmaf(p.w3[ch], bufB[ch * MK_LD + tid], sres);
+        p.vad[(size_t)chunk * p.T + tid] = sigmoidf_(sres);
+    }
+}
+
 }  // namespace dfsmn
 }  // namespace vadx
 
@@ -364,6 +638,86 @@ extern "C" int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, c
     if (in->c == 4) hipLaunchKernelGGL(lstm_f_kernel<4>, dim3(tiles), dim3(128), 0, static_cast<hipStream_t>(stream), p);
     else if (in->c == 40) hipLaunchKernelGGL(lstm_f_kernel<40>, dim3(tiles), dim3(128), 0, static_cast<hipStream_t>(stream), p);
     else { vadx::set_error("vadx_dfsmn_lstm_f: input channels must be 4 or 40"); return VADX_EINVAL; }
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+
+extern "C" int vadx_dfsmn_alpha_scale(const float *in, float *out, int chunks, int nt, const float *w1, const float *b1,
+                                      const float *w2, const float *b2, void *stream) {
+    VADX_REQUIRE(in && out && w1 && b1 && w2 && b2 && chunks > 0 && nt > 0, "vadx_dfsmn_alpha_scale: bad argument");
+    const long long total = (long long)chunks * nt * 160 * 16;
+    hipLaunchKernelGGL(alpha_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       in, out, nt, total, w1, b1, w2, b2);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+extern "C" int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2], const float *const w_hh[2],
+                                 const float *const b_ih[2], const float *const b_hh[2], const float *wl, const float *bl,
+                                 const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, void *stream) {
+    VADX_REQUIRE(in && in->ptr && out && out->ptr && w_ih && w_hh && b_ih && b_hh && wl && bl, "vadx_dfsmn_lstm_t: bad argument");
+    VADX_REQUIRE(F % 16 == 0 && frames > 0 && chunks > 0, "vadx_dfsmn_lstm_t: F must be a multiple of 16");
+    LstmTArgs p;
+    p.in = mkview(in); p.ln = mkln(ln); p.mul = mkview(mul); p.out = mkvieww(out); p.F = F; p.T = frames; p.nt = (frames + 15) / 16;
+    p.wl = wl; p.bl = bl;
+    for (int l = 0; l < 2; ++l) { p.w_ih[l] = w_ih[l]; p.w_hh[l] = w_hh[l]; p.b_ih[l] = b_ih[l]; p.b_hh[l] = b_hh[l]; }
+    const unsigned grid = (unsigned)(chunks * (F / 16));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (which == 0) {            // bottleneck ch_lstm: in 20, hidden 40, 2 layers, Linear 40->20, multiplied with `mul`
+        VADX_REQUIRE(in->c == 20 && mul && mul->ptr, "vadx_dfsmn_lstm_t(0): in must have 20 channels and mul is required");
+        p.out_ch = 20;
+        hipLaunchKernelGGL((lstm_t_kernel<20, 40, 2, 2, 0>), dim3(grid), dim3(128), 0, st, p);
+    } else {                     // out_ch_lstm: in 40, hidden 20, 1 layer, Linear 20->40
+        VADX_REQUIRE(in->c == 40, "vadx_dfsmn_lstm_t(1): in must have 40 channels");
+        p.out_ch = 40;
+        hipLaunchKernelGGL((lstm_t_kernel<40, 20, 1, 3, 1>), dim3(grid), dim3(64), 0, st, p);
+    }
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+extern "C" int vadx_dfsmn_istft(const float *y_ft, const float *basis_t, const float *wsum_inv, float *z_ws, float *out,
+                                int chunks, int frames, void *stream) {
+    VADX_REQUIRE(y_ft && basis_t && wsum_inv && z_ws && out && chunks > 0 && frames > 0, "vadx_dfsmn_istft: bad argument");
+    const int nt = (frames + 15) / 16, L = (frames - 1) * 160 + 319 - 318;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(istft_gemm_kernel, dim3((unsigned)(chunks * nt)), dim3(256), 0, st, y_ft, basis_t, z_ws, nt, frames);
+    VADX_HIP_TRY(hipGetLastError());
+    const long long total = (long long)chunks * L;
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z_ws, wsum_inv, out, frames, L, total);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+extern "C" int vadx_dfsmn_vote(const float *vad, int batch, int windows, int frames, int look_backward, double speaking_score,
+                               double silence_score, uint8_t *flags, void *stream) {
+    VADX_REQUIRE(vad && flags && batch > 0 && windows > 0 && look_backward >= 1 && look_backward < frames, "vadx_dfsmn_vote: bad argument");
+    hipLaunchKernelGGL(dfsmn_vote_kernel, dim3((batch + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), vad, batch,
+                       windows, frames, look_backward, speaking_score, silence_score, flags);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+
+extern "C" int vadx_dfsmn_mask_net(const vadx_dfsmn_mask_weights *w, const float *feat, int chunks, int frames, float *vad,
+                                   void *stream) {
+    VADX_REQUIRE(w && feat && vad && chunks > 0, "vadx_dfsmn_mask_net: NULL argument");
+    VADX_REQUIRE(frames > 0 && frames <= 64, "vadx_dfsmn_mask_net: frames must be <= 64 (got %d)", frames);
+    VADX_REQUIRE(w->hidden > 0 && w->hidden <= 128 && w->fsmn_hidden > 0 && w->fsmn_hidden <= 256 && w->layers >= 0 && w->layers <= 8 &&
+                 w->lorder >= 1 && w->lorder <= 20, "vadx_dfsmn_mask_net: unsupported dims");
+    MaskArgs p;
+    p.feat = feat; p.shift = w->shift; p.scale = w->scale; p.w1 = w->linear1_w; p.b1 = w->linear1_b; p.w3 = w->linear3_w; p.b3 = w->linear3_b;
+    p.vad = vad; p.T = frames; p.H = w->hidden; p.Hp = (w->hidden + 15) & ~15; p.H2p = (w->fsmn_hidden + 15) & ~15;
+    p.layers = w->layers; p.lorder = w->lorder;
+    for (int l = 0; l < w->layers; ++l) { p.wl[l] = w->fsmn_linear_w[l]; p.bl[l] = w->fsmn_linear_b[l]; p.wp[l] = w->fsmn_project_w[l]; p.wc[l] = w->fsmn_conv_w[l]; }
+    static bool done = false;
+    if (!done) {
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mask_net_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         MK_LDS_FLOATS * sizeof(float)));
+        done = true;
+    }
+    hipLaunchKernelGGL(mask_net_kernel, dim3(chunks), dim3(512), MK_LDS_FLOATS * sizeof(float), static_cast<hipStream_t>(stream), p);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }

@@ -40,6 +40,7 @@ struct Dev {
     int nmt, mel_kb_lo[MAX_MEL_TILES], mel_kb_hi[MAX_MEL_TILES];
     int off_dft, off_nyq, off_mel;    // float offsets in the packed blob
     int tiles32, tiles16;   // per window: number of 32-frame tiles, then 16-frame tiles
+    int out_stride, out_off; // floats per output frame row / first column (lets several streams share one row)
 };
 
 static int round16(int x) { return (x + 15) & ~15; }
@@ -73,12 +74,16 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     const int rem = c->frames - d->tiles32 * TF;
     d->tiles16 = (rem + 15) / 16;
     if (rem > 16) { d->tiles32 += 1; d->tiles16 = 0; }
+    d->out_stride = c->n_mels; d->out_off = 0;
     return 0;
 }
 
-template <int MT>
+struct FtOut { float *ptr; int tile0, c_total, c_off; };      // COMPLEX: FT destination (re -> c_off, im -> c_off+1)
+
+template <int MT, bool COMPLEX = false>
 __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict__ P, const int16_t *__restrict__ win,
-                                          float mean, int f0, float *__restrict__ out_win, float *X2, float *PW) {
+                                          const float *__restrict__ fwin, float mean, int f0, float *__restrict__ out_win,
+                                          float *X2, float *PW, FtOut ft = FtOut{nullptr, 0, 0, 0}) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, i = lane & 15;
     constexpr int NF = MT * 16;
@@ -90,15 +95,26 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
         const int n = (f0 + g) * d.hop + r + d.tap0 - d.center_pad;      // index into the window
         float v = 0.f;
         if (n >= 0 && n < d.window_len) {
-            const float x = (float)win[n];
-            const float xm = (n > 0) ? (float)win[n - 1] : 0.f;
+            const float x = win ? (float)win[n] : 0.f;
+            const float xm = (win && n > 0) ? (float)win[n - 1] : 0.f;
             if (d.prep == 0) {            // FSMN: (x-mean) - 0.97*(x[-1]-mean), first sample kept
                 const float a = __fsub_rn(x, mean);
                 v = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn(xm, mean))) : a;
             } else if (d.prep == 1) {     // two-tap conv with zero history
                 v = __fadd_rn(__fmul_rn(xm, d.k0), __fmul_rn(x, d.k1));
-            } else {                      // scale, then remove the window mean (mean is of the scaled signal)
+            } else if (d.prep == 2) {     // scale, then remove the window mean (mean is of the scaled signal)
                 v = __fsub_rn(__fmul_rn(x, d.k1), mean);
+            } else {                      // DFSMN feature streams (Export_DFSMN_VAD.py:338-341)
+                float npe = 0.f, ape = 0.f;
+                if (d.prep != 4) {        // near: a = k1*x - mean, pre-emphasis keeping a[0]
+                    const float a = __fsub_rn(__fmul_rn(x, d.k1), mean);
+                    npe = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn(__fmul_rn(xm, d.k1), mean))) : a;
+                }
+                if (d.prep != 3) {        // AEC output (float source), same pre-emphasis
+                    const float a = fwin[n];
+                    ape = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, fwin[n - 1])) : a;
+                }
+                v = d.prep == 3 ? npe : (d.prep == 4 ? ape : __fsub_rn(npe, __fmul_rn(d.k0, ape)));   // 5: echo = near - k0*aec
             }
         }
         X2[r * X_LD + g] = v;
@@ -125,6 +141,15 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            if (COMPLEX) {           // raw spectrum into the frame-tiled layout [tile][c][bin][16 frames]
+                const int bin = bt * 16 + i;
+                if (bin < d.n_bins) {
+                    const size_t base = (((size_t)(ft.tile0 + (f0 >> 4) + mt) * ft.c_total + ft.c_off) * d.n_bins + bin) * 16 + 4 * q;
+                    *reinterpret_cast<f32x4 *>(ft.ptr + base) = acc[0][mt];
+                    *reinterpret_cast<f32x4 *>(ft.ptr + base + (size_t)d.n_bins * 16) = acc[1][mt];
+                }
+                continue;
+            }
             f32x4 pw;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -132,6 +157,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
             *reinterpret_cast<f32x4 *>(&PW[(bt * 16 + i) * P_LD + mt * 16 + 4 * q]) = pw;
         }
     }
+    if (COMPLEX) return;
     if (d.nyq) {            // last bin (n_bins % 16 == 1): frames x taps dot products on the VALU
         const float *nre = P + d.off_nyq, *nim = nre + d.Kp;
         for (int e = tid; e < NF * 4; e += THREADS) {       // (frame, k-quarter)
@@ -178,7 +204,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
                     const float m = acc[0][mt][r];
                     v[r] = logf(d.log_mode ? __fadd_rn(m, d.log_floor) : fmaxf(m, d.log_floor));
                 }
-                *reinterpret_cast<f32x4 *>(out_win + (size_t)f * d.n_mels + mtile * 16 + 4 * q) = v;
+                *reinterpret_cast<f32x4 *>(out_win + (size_t)f * d.out_stride + d.out_off + mtile * 16 + 4 * q) = v;
             }
         }
     }
@@ -186,18 +212,38 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
 
 __global__ __launch_bounds__(THREADS, 4) void frontend_logmel_kernel(
     Dev d, const float *__restrict__ P, const int16_t *__restrict__ audio, long long row_stride,
-    long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ out) {
+    long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ out,
+    const float *__restrict__ faux) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *X2 = lds;
     float *PW = lds + d.hop * X_LD + 16 * X_LD;       // +16 rows: partial last pass reads past hop
     const int tiles = d.tiles32 + d.tiles16;
     const int widx = blockIdx.x / tiles, tile = blockIdx.x - widx * tiles;
     const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
-    const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
-    float *out_win = out + (size_t)widx * d.frames * d.n_mels;
+    const int16_t *win = audio ? audio + (long long)b * row_stride + (long long)w * win_stride : nullptr;
+    const float *fwin = faux ? faux + (size_t)widx * d.window_len : nullptr;      // float source: [window][window_len]
+    float *out_win = out + (size_t)widx * d.frames * d.out_stride;
     const float mean = means ? means[widx] : 0.f;
-    if (tile < d.tiles32) tile_body<2>(d, P, win, mean, tile * TF, out_win, X2, PW);
-    else tile_body<1>(d, P, win, mean, d.tiles32 * TF + (tile - d.tiles32) * 16, out_win, X2, PW);
+    if (tile < d.tiles32) tile_body<2>(d, P, win, fwin, mean, tile * TF, out_win, X2, PW);
+    else tile_body<1>(d, P, win, fwin, mean, d.tiles32 * TF + (tile - d.tiles32) * 16, out_win, X2, PW);
+}
+
+// raw complex STFT into the FT layout (DFSMN's two-stream STFT-B): every tile is 32 frames = 2 FT tiles
+__global__ __launch_bounds__(THREADS, 4) void stft_complex_kernel(
+    Dev d, const float *__restrict__ P, const int16_t *__restrict__ audio, long long row_stride,
+    long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ ft_out,
+    int ft_nt, int ft_ctotal, int ft_coff) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *X2 = lds;
+    float *PW = lds + d.hop * X_LD + 16 * X_LD;
+    const int tiles = (d.frames + TF - 1) / TF;
+    const int widx = blockIdx.x / tiles, tile = blockIdx.x - widx * tiles;
+    const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
+    const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
+    const float mean = means ? means[widx] : 0.f;
+    FtOut ft{ft_out, widx * ft_nt, ft_ctotal, ft_coff};
+    if (tile * TF + 16 < ft_nt * 16) tile_body<2, true>(d, P, win, nullptr, mean, tile * TF, nullptr, X2, PW, ft);
+    else tile_body<1, true>(d, P, win, nullptr, mean, tile * TF, nullptr, X2, PW, ft);
 }
 
 // window means for the DC-removing preps: exact integer sum -> float (one wave per window)
@@ -307,7 +353,59 @@ extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *p
         VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(frontend_logmel_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(frontend_logmel_kernel, dim3((unsigned)(nwin * (d.tiles32 + d.tiles16))), dim3(THREADS), lds, st, d,
-                       packed, audio, (long long)row_stride, (long long)win_stride, windows_per_clip, means, out);
+                       packed, audio, (long long)row_stride, (long long)win_stride, windows_per_clip, means, out,
+                       static_cast<const float *>(nullptr));
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+
+// DFSMN feature streams: same fused kernel, sources = int16 near window (+ its scaled mean) and/or the float AEC
+// waveform [windows][window_len]; writes n_mels columns at out_off of rows of out_stride floats.
+extern "C" int vadx_frontend_logmel_ex(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host,
+                                       const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
+                                       int windows_per_clip, const float *means, const float *faux, int out_stride,
+                                       int out_off, float *out, void *stream) {
+    Dev d;
+    VADX_REQUIRE(cfg && packed && mel_kb_host && out, "vadx_frontend_logmel_ex: NULL argument");
+    VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_frontend_logmel_ex: unsupported geometry");
+    VADX_REQUIRE(cfg->prep >= 3 && cfg->prep <= 5, "vadx_frontend_logmel_ex: prep must be 3 (near), 4 (aec) or 5 (echo)");
+    VADX_REQUIRE((cfg->prep == 4 || (audio && means)) && (cfg->prep == 3 || faux), "vadx_frontend_logmel_ex: missing source");
+    VADX_REQUIRE(out_stride >= out_off + cfg->n_mels && out_stride % 4 == 0 && out_off % 4 == 0, "vadx_frontend_logmel_ex: bad output stride/offset");
+    for (int mt = 0; mt < d.nmt; ++mt) { d.mel_kb_lo[mt] = mel_kb_host[2 * mt]; d.mel_kb_hi[mt] = mel_kb_host[2 * mt + 1]; }
+    d.out_stride = out_stride; d.out_off = out_off;
+    const long long nwin = (long long)batch * windows_per_clip;
+    const size_t lds = ((size_t)(d.hop + 16) * X_LD + (size_t)d.Fp * P_LD) * sizeof(float);
+    VADX_REQUIRE(lds <= 160 * 1024, "vadx_frontend_logmel_ex: geometry needs %zu B of LDS", lds);
+    if (lds > 64 * 1024)
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(frontend_logmel_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(frontend_logmel_kernel, dim3((unsigned)(nwin * (d.tiles32 + d.tiles16))), dim3(THREADS), lds,
+                       static_cast<hipStream_t>(stream), d, packed, audio, (long long)row_stride, (long long)win_stride,
+                       windows_per_clip, means, out, faux);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+// Raw complex STFT of int16 windows into an FT tensor [window*ft_nt + t/16][c_total][n_bins][16] at channels
+// c_off (re) and c_off+1 (im); prep 2 (scale + window-mean removal).  means_ws as in vadx_frontend_logmel.
+extern "C" int vadx_frontend_stft_ft(const vadx_frontend_cfg *cfg, const float *packed, const int16_t *audio,
+                                     int64_t row_stride, int64_t win_stride, int batch, int windows_per_clip,
+                                     float *means_ws, float *ft_out, int c_total, int c_off, void *stream) {
+    Dev d;
+    VADX_REQUIRE(cfg && packed && audio && means_ws && ft_out, "vadx_frontend_stft_ft: NULL argument");
+    VADX_REQUIRE(derive(cfg, &d) == 0 && d.nyq == 0, "vadx_frontend_stft_ft: unsupported geometry");
+    VADX_REQUIRE(cfg->prep == 2, "vadx_frontend_stft_ft: prep must be 2");
+    VADX_REQUIRE((windows_per_clip - 1) * win_stride + cfg->window_len <= row_stride, "vadx_frontend_stft_ft: windows run past the clip row");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long nwin = (long long)batch * windows_per_clip;
+    hipLaunchKernelGGL(window_mean_kernel, dim3((unsigned)((nwin + 3) / 4)), dim3(256), 0, st, audio, (long long)row_stride,
+                       (long long)win_stride, windows_per_clip, (int)nwin, cfg->window_len, cfg->k1, means_ws);
+    VADX_HIP_TRY(hipGetLastError());
+    const int ft_nt = (d.frames + 15) / 16, tiles = (d.frames + TF - 1) / TF;
+    const size_t lds = ((size_t)(d.hop + 16) * X_LD) * sizeof(float);
+    hipLaunchKernelGGL(stft_complex_kernel, dim3((unsigned)(nwin * tiles)), dim3(THREADS), lds, st, d, packed, audio,
+                       (long long)row_stride, (long long)win_stride, windows_per_clip, means_ws, ft_out, ft_nt, c_total, c_off);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }

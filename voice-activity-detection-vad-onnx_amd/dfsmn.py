@@ -150,3 +150,220 @@ class Iccrn:
         self.pw(2, gx.view(), None, self._ln(s1, name + ".LN1"), name + ".conv.weight", name + ".conv.bias", out, F_BINS, CH, kf=3,
                 add=ceps.view(), tiles=tiles)
         return sc
+
+    # ---- LSTMs along time (:252-267) ------------------------------------------------------------
+    def lstm_t(self, which, prefix, inp, ln, mul, out, frames, n_chunks):
+        layers = 2 if which == 0 else 1
+        arr = lambda n: (C.c_void_p * 2)(*[self._p(f"{prefix}.lstm2.{n}_l{l}") if l < layers else None for l in range(2)])   # noqa: E731
+        wi, wh, bi, bh = arr("weight_ih"), arr("weight_hh"), arr("bias_ih"), arr("bias_hh")
+        _lib.check(self.lib.vadx_dfsmn_lstm_t(which, C.byref(inp), None if ln is None else C.byref(ln), C.byref(wi), C.byref(wh),
+                                              C.byref(bi), C.byref(bh), self._p(prefix + ".linear.weight"),
+                                              self._p(prefix + ".linear.bias"), None if mul is None else C.byref(mul),
+                                              C.byref(out), F_BINS, frames, n_chunks, _lib.stream_ptr()))
+
+    # ---- NET.forward (:226-249) without the ISTFT ------------------------------------------------
+    def forward(self, x4, n_chunks, frames):
+        """x4: FT (4 ch: mix re, mix im, scaled far re, scaled far im) -> Y FT (2 ch: re, im of the AEC spectrum)."""
+        t, dev = self.torch, self.device
+        tiles = n_chunks * ft_tiles(frames)
+        new = lambda ch, bins=F_BINS: FT(t, dev, n_chunks, frames, ch, bins)      # noqa: E731
+        hf0, e0l = new(2 * CH), new(CH)
+        cats = [new(2 * CH) for _ in range(5)]          # [e0|d1], [e1|d2], [e2|d3], [e3|d4], [e4|d5]
+        e5, p5, d0, y = new(CH), new(CH), new(2 * CH), new(2)
+        self.lstm_f("in_ch_lstm", x4.view(), None, hf0.view(), F_BINS, tiles)
+        self.pw(0, hf0.view(), None, None, "in_ch_lstm.linear.weight", "in_ch_lstm.linear.bias", e0l.view(), F_BINS, CH, tiles=tiles)
+        self.pw(0, e0l.view(), x4.view(), None, "in_conv.weight", "in_conv.bias", cats[0].view(0, CH), F_BINS, CH, tiles=tiles)
+        sc = {}
+        for k in range(1, 5):                           # e1..e4
+            self.cfb(f"cfb_e{k}", cats[k - 1].view(0, CH), None, cats[k].view(0, CH), n_chunks, frames, sc)
+        self.cfb("cfb_e5", cats[4].view(0, CH), None, e5.view(), n_chunks, frames, sc)
+        s5 = self.stats(e5.view(), None, F_BINS, tiles)
+        self.lstm_t(0, "ch_lstm", e5.view(), self._ln(s5, "ln"), e5.view(), p5.view(), frames, n_chunks)
+        self.cfb("cfb_d5", p5.view(), None, cats[4].view(CH, CH), n_chunks, frames, sc)
+        for k in range(4, 0, -1):                       # d4..d1: cfb_dk(cat[e_k, d_{k+1}]) -> second half of cats[k-1]
+            self.cfb(f"cfb_d{k}", cats[k].view(0, CH), cats[k].view(CH, CH), cats[k - 1].view(CH, CH), n_chunks, frames, sc)
+        self.lstm_t(1, "out_ch_lstm", cats[0].view(), None, None, d0.view(), frames, n_chunks)
+        self.pw(0, d0.view(), cats[0].view(CH, CH), None, "out_conv.weight", "out_conv.bias", y.view(), F_BINS, 2, tiles=tiles)
+        return y
+
+
+class DfsmnEngine:
+    """Batched DFSMN near+far VAD: two int16 streams in, vad_results [51] per 16001-sample window out."""
+
+    L, T_B, T_A, LOOK_BACKWARD, FRAME = 16001, 101, 51, 0.3, 320
+
+    def __init__(self, weights=None, device="cuda:0", sub_batch=256):
+        from . import tables, weights as _w, frontend as _fe
+        self.torch = t = _lib.require_gpu()
+        self.device = t.device(device)
+        self.lib = _lib.lib()
+        w = _w.dfsmn_synthetic(1234) if weights is None else weights
+        w = {k: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in w.items()}
+        self.sub_batch = int(sub_batch)
+        self.iccrn = Iccrn(w, device)
+        dev = lambda a: t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)     # noqa: E731
+        self.alpha = [dev(w[k]) for k in ("alpha.linear1.weight", "alpha.linear1.bias", "alpha.linear2.weight", "alpha.linear2.bias")]
+        # ISTFT buffers of NET.__init__ (:183-207), float32 torch ops in the reference's order
+        n, hop, half = 319, 160, 159
+        window = t.hamming_window(n)
+        fe_ = t.fft.fft(t.eye(n, dtype=t.float32))
+        fb = t.vstack([t.real(fe_[:half + 1]), t.imag(fe_[:half + 1])]).float()
+        inverse_basis = t.linalg.pinv((fb * n) / hop).T * window.view(1, -1)          # [320 ch][319]
+        bt = t.zeros((320, 320), dtype=t.float32)
+        bt[:319, :] = inverse_basis.t()
+        max_frames = 200
+        out_len = (max_frames - 1) * hop + n
+        ws = t.zeros(out_len, dtype=t.float32)
+        wsq = window ** 2
+        for i in range(max_frames):
+            s0 = i * hop
+            ln_ = min(n, out_len - s0)
+            if ln_ <= 0:
+                break
+            ws[s0:s0 + ln_] += wsq[:ln_]
+        self.basis_t, self.wsum_inv = bt.to(self.device), (n / (ws * hop + 1e-6)).to(self.device)
+        # front-ends: STFT-B (hamming 319/319/160, centre pad 159) raw complex; STFT-A (hamming 640 in 1024, hop 320) + htk fbank
+        inv = 1.0 / 32768.0
+        self.fe_b = _fe.Frontend(dict(n_fft=319, win=319, hop=160, window="hamming", variant="v1b", center=True, prep=2,
+                                      k=(0.0, inv), mel=("zeros",), log_mode=0, log_floor=1e-6), self.L, device=device)
+        mk = lambda prep: _fe.Frontend(dict(n_fft=1024, win=640, hop=320, window="hamming", variant="v1b", center=True, prep=prep,   # noqa: E731
+                                            k=(1.15, inv), mel=("torchaudio", 20, 8000, None, "htk"), log_mode=0, log_floor=1e-6),
+                                       self.L, device=device)
+        self.fe_a = {3: mk(3), 4: mk(4), 5: mk(5)}
+        m = dict(_w.DFSMN_MASK)
+        m["hidden"] = w["mask.linear1.weight"].shape[0]
+        m["layers"] = len([k for k in w if k.startswith("mask.deepfsmn.") and k.endswith(".linear.weight")])
+        if m["layers"]:
+            m["fsmn_hidden"] = w["mask.deepfsmn.0.linear.weight"].shape[0]
+            m["lorder"] = w["mask.deepfsmn.0.conv1.weight"].shape[2]
+        mw = _lib.DfsmnMaskWeights()
+        mw.hidden, mw.fsmn_hidden, mw.layers, mw.lorder = m["hidden"], m["fsmn_hidden"], m["layers"], m["lorder"]
+        self._mask_keep = []
+
+        def mdev(a, pad_axes=()):
+            a = np.asarray(a, dtype=np.float32)
+            pads = [(0, (-a.shape[ax]) % 16 if ax in pad_axes else 0) for ax in range(a.ndim)]
+            d_ = dev(np.pad(a, pads))
+            self._mask_keep.append(d_)
+            return d_.data_ptr()
+        shift = w["mask.shift"] + np.float32(np.log(np.float32(32768.0 ** 2)))      # wrapper __init__ :291
+        mw.shift, mw.scale = mdev(shift), mdev(w["mask.scale"])
+        mw.linear1_w, mw.linear1_b = mdev(w["mask.linear1.weight"], (0,)), mdev(w["mask.linear1.bias"], (0,))
+        mw.linear3_w, mw.linear3_b = mdev(w["mask.linear3.weight"].reshape(-1)), mdev(w["mask.linear3.bias"])
+        for l in range(m["layers"]):
+            mw.fsmn_linear_w[l] = mdev(w[f"mask.deepfsmn.{l}.linear.weight"], (0, 1))
+            mw.fsmn_linear_b[l] = mdev(w[f"mask.deepfsmn.{l}.linear.bias"], (0,))
+            mw.fsmn_project_w[l] = mdev(w[f"mask.deepfsmn.{l}.project.weight"], (0, 1))
+            mw.fsmn_conv_w[l] = mdev(w[f"mask.deepfsmn.{l}.conv1.weight"][:, 0, :, 0])
+        self.mask = mw
+
+    def run(self, near_i16, far_i16, windows_per_clip=1, win_stride=None, return_aec=False):
+        """near/far int16 [B, N] on the window grid -> vad f32 [B*W, 51] (each window stateless, as the reference)."""
+        t = self.torch
+        to_dev = lambda a: (a if t.is_tensor(a) else t.from_numpy(np.ascontiguousarray(a, dtype=np.int16))).to(self.device).contiguous()   # noqa: E731
+        near, far = to_dev(near_i16), to_dev(far_i16)
+        B, W = near.shape[0], int(windows_per_clip)
+        ws = self.L if win_stride is None else int(win_stride)
+        n_chunks = B * W
+        vad = t.empty((n_chunks, self.T_A), dtype=t.float32, device=self.device)
+        aec_all = t.empty((n_chunks, self.L), dtype=t.float32, device=self.device) if return_aec else None
+        per = max(1, self.sub_batch // W)                  # clips per sub-batch (activations are ~30 MB per window)
+        for b0 in range(0, B, per):
+            nb = min(per, B - b0)
+            v, a = self._run_sub(near[b0:b0 + nb], far[b0:b0 + nb], W, ws)
+            vad[b0 * W:(b0 + nb) * W] = v
+            if return_aec:
+                aec_all[b0 * W:(b0 + nb) * W] = a
+        return (vad, aec_all) if return_aec else vad
+
+    def _run_sub(self, near, far, W, ws):
+        t, lib = self.torch, self.lib
+        B = near.shape[0]
+        n = B * W
+        nt = ft_tiles(self.T_B)
+        xraw = FT(t, self.device, n, self.T_B, 4, F_BINS)
+        x4 = FT(t, self.device, n, self.T_B, 4, F_BINS)
+        mean_near = t.empty((n,), dtype=t.float32, device=self.device)
+        mean_far = t.empty((n,), dtype=t.float32, device=self.device)
+        st = _lib.stream_ptr()
+        with t.cuda.device(self.device):
+            for src, means, coff in ((near, mean_near, 0), (far, mean_far, 2)):
+                _lib.check(lib.vadx_frontend_stft_ft(C.byref(self.fe_b.cfg), self.fe_b.packed.data_ptr(), src.data_ptr(),
+                                                     _lib.row_stride(src), ws, B, W, means.data_ptr(), xraw.data.data_ptr(), 4, coff, st))
+            _lib.check(lib.vadx_dfsmn_alpha_scale(xraw.data.data_ptr(), x4.data.data_ptr(), n, nt, *[a.data_ptr() for a in self.alpha], st))
+            y = self.iccrn.forward(x4, n, self.T_B)
+            z = t.empty((n, self.T_B, 320), dtype=t.float32, device=self.device)
+            aec = t.empty((n, self.L), dtype=t.float32, device=self.device)
+            _lib.check(lib.vadx_dfsmn_istft(y.data.data_ptr(), self.basis_t.data_ptr(), self.wsum_inv.data_ptr(), z.data_ptr(),
+                                            aec.data_ptr(), n, self.T_B, st))
+            feat = t.empty((n, self.T_A, 240), dtype=t.float32, device=self.device)
+            for prep, off in ((3, 0), (4, 80), (5, 160)):
+                fe = self.fe_a[prep]
+                _lib.check(lib.vadx_frontend_logmel_ex(C.byref(fe.cfg), fe.packed.data_ptr(), fe.mel_kb.ctypes.data,
+                                                       None if prep == 4 else near.data_ptr(), _lib.row_stride(near), ws, B, W,
+                                                       None if prep == 4 else mean_near.data_ptr(),
+                                                       None if prep == 3 else aec.data_ptr(), 240, off, feat.data_ptr(), st))
+            vad = t.empty((n, self.T_A), dtype=t.float32, device=self.device)
+            _lib.check(lib.vadx_dfsmn_mask_net(C.byref(self.mask), feat.data_ptr(), n, self.T_A, vad.data_ptr(), st))
+        return vad, aec
+
+    def grid(self):
+        lb = int(self.LOOK_BACKWARD * 16000 // self.FRAME)
+        return lb, self.L - (lb + 1) * self.FRAME
+
+    def detect(self, near_clips, far_clips, pad_noise_near=None, pad_noise_far=None, fusion_threshold=0.3,
+               min_speech_duration=0.2, speaking_score=0.5, silence_score=0.5):
+        """Equal-length clip pairs (host, any numeric dtype) [B,N] -> per clip [(start_s, end_s)]
+        (Inference_DFSMN_VAD_ONNX.py:124-163 prep, :221-278 loop)."""
+        from . import timestamps as ts
+        from .fsmn import pad_to_window_grid
+        t = self.torch
+        near_clips, far_clips = np.asarray(near_clips), np.asarray(far_clips)
+        B = near_clips.shape[0]
+        n = min(near_clips.shape[1], far_clips.shape[1])
+        lb, stride = self.grid()
+        rows_n, rows_f = [], []
+        for b in range(B):
+            a = ts.normalize_to_int16(near_clips[b, :n].astype(np.float32))
+            f = ts.normalize_to_int16(far_clips[b, :n].astype(np.float32))
+            rows_n.append(pad_to_window_grid(a, self.L, stride, None if pad_noise_near is None else pad_noise_near[b]))
+            rows_f.append(pad_to_window_grid(f, self.L, stride, None if pad_noise_far is None else pad_noise_far[b]))
+        near, far = np.stack(rows_n), np.stack(rows_f)
+        W = (near.shape[1] - self.L) // stride + 1
+        vad = self.run(near, far, W, stride)
+        flags = t.empty((B, W * (self.T_A - lb) + lb), dtype=t.uint8, device=self.device)
+        with t.cuda.device(self.device):
+            _lib.check(self.lib.vadx_dfsmn_vote(vad.data_ptr(), B, W, self.T_A, lb, float(speaking_score), float(silence_score),
+                                                flags.data_ptr(), _lib.stream_ptr()))
+        fl = flags.cpu().numpy().astype(bool)
+        return [ts.process_timestamps(ts.vad_to_timestamps(fl[b], self.FRAME / 16000), fusion_threshold, min_speech_duration)
+                for b in range(B)]
+
+
+class DfsmnSession:
+    """{'near_end_audio','far_end_audio': int16 [1,1,16001]} -> [vad_results f32 [51]]
+    (DFSMN/near_and_far_end_audio/Export_DFSMN_VAD.py:377-393)."""
+
+    def __init__(self, weights=None, device="cuda:0"):
+        from .fsmn import _Meta
+        self.engine = DfsmnEngine(weights, device)
+        self._inputs_meta = [_Meta("near_end_audio", [1, 1, 16001], "tensor(int16)"), _Meta("far_end_audio", [1, 1, 16001], "tensor(int16)")]
+        self._outputs_meta = [_Meta("vad_results", [51], "tensor(float)")]
+
+    def get_inputs(self):
+        return list(self._inputs_meta)
+
+    def get_outputs(self):
+        return list(self._outputs_meta)
+
+    def get_providers(self):
+        return ["VadxMI355XExecutionProvider"]
+
+    def run(self, output_names, feeds):
+        near, far = np.asarray(feeds["near_end_audio"]), np.asarray(feeds["far_end_audio"])
+        if near.dtype != np.int16 or far.dtype != np.int16:
+            raise ValueError("Unexpected input data type, expected: (tensor(int16))")
+        if near.shape[-1] != 16001 or far.shape[-1] != 16001:
+            raise ValueError("Got invalid dimensions for input: expected last dim 16001")
+        vad = self.engine.run(near.reshape(-1, 16001), far.reshape(-1, 16001)).cpu().numpy()
+        return [vad.reshape(-1) if vad.shape[0] == 1 else vad]

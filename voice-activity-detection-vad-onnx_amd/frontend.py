@@ -43,6 +43,8 @@ class Frontend:
         if p["mel"][0] == "torchaudio":
             _, fmin, fmax, norm, scale = p["mel"]
             fb = tables.mel_filters_torchaudio(half + 1, fmin, fmax, n_mels, sample_rate, norm, scale)
+        elif p["mel"][0] == "zeros":          # raw-spectrum users (vadx_frontend_stft_ft) never touch the mel stage
+            fb = torch.zeros((n_mels, half + 1), dtype=torch.float32)
         else:
             fb = tables.mel_filters_kaldi(n_fft, n_mels, sample_rate, p["mel"][1], p["mel"][2])
         cfg = _lib.FrontendCfg()
