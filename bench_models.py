@@ -69,6 +69,18 @@ def main():
     out["firered_config5"] = {"clips": 2048, "seconds_per_clip": 10, "ms_frontend": ms_fe, "ms_total": ms_all,
                               "hop512_frames_per_s": 2048 * 313 / (ms_all * 1e-3),
                               "net_TFLOPs": 2048 * 980 * 1.09e6 / ((ms_all - ms_fe) * 1e-3) / 1e12}
+    # ---- config 5 (DFSMN near+far half): measured on 128 clip pairs x 10 s (1920 windows), scaled to 2048
+    from vadx import dfsmn
+    de = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234), sub_batch=960)
+    lb, stride = de.grid()
+    W = 15
+    n = (W - 1) * stride + de.L
+    near = torch.from_numpy(weights.burst_clips(16, n, seed=11)).cuda().repeat(8, 1)
+    far = torch.from_numpy(weights.burst_clips(16, n, seed=12)).cuda().repeat(8, 1)
+    ms = timed(torch, lambda: de.run(near, far, W, stride), max(2, args.reps // 2))
+    out["dfsmn_config5"] = {"clip_pairs_measured": 128, "windows": 128 * W, "ms_measured": ms,
+                            "ms_scaled_to_2048_pairs": ms * 16, "hop512_frames_per_s": 128 * 313 / (ms * 1e-3),
+                            "approx_TFLOPs": 128 * W * 4.8e9 / (ms * 1e-3) / 1e12}
     print(json.dumps(out, indent=1))
 
 

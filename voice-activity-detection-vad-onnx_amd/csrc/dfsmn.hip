@@ -76,6 +76,10 @@ __device__ __forceinline__ float ln_apply(const LN &ln, int tile, int t, int cf,
     return (x - mean) * inv * ln.w[cf] + ln.b[cf];
 }
 
+__device__ __forceinline__ float ln_apply2(const LN &ln, float mean, float inv, int cf, float x) {
+    return (x - mean) * inv * ln.w[cf] + ln.b[cf];
+}
+
 // ---------------------------------------------------------------------------------------------
 // pw_conv: convolution over channels with KF (1 or 3) taps along F ('same' zero padding), per frame.
 //   rows = output channels (MT tiles of 16, zero padded), K = KF * C_in (KS k-steps of 4), cols = frames.
@@ -110,6 +114,8 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
             wa[mt][s] = p.W[(size_t)(mt * 16 + i) * K + 4 * s + q];
             if (MODE == 1) wb[mt][s] = p.W2[(size_t)(mt * 16 + i) * K + 4 * s + q];
         }
+    const float ln_mean = p.ln.stats ? p.ln.stats[((size_t)tile * 16 + i) * 2] : 0.f;          // this lane's frame is fixed
+    const float ln_inv = p.ln.stats ? p.ln.stats[((size_t)tile * 16 + i) * 2 + 1] : 1.f;
     for (int f = wave; f < p.F; f += nw) {
         f32x4 acc[MT], acc2[MODE == 1 ? MT : 1];
 #pragma unroll
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
             if (ff >= 0 && ff < p.F) {
                 raw = c < p.a.c ? p.a.ptr[ft_idx(tile, p.a.c_total, p.a.c_off + c, p.F, ff) + i]
                                 : p.b.ptr[ft_idx(tile, p.b.c_total, p.b.c_off + c - p.a.c, p.F, ff) + i];
-                lnv = p.ln.stats ? ln_apply(p.ln, tile, i, c * p.F + ff, raw) : raw;
+                lnv = p.ln.stats ? ln_apply2(p.ln, ln_mean, ln_inv, c * p.F + ff, raw) : raw;
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -181,12 +187,14 @@ __global__ __launch_bounds__(INV ? 320 : 384) void dft_f_kernel(DftArgs p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int s = 0; s < KS; ++s) ta[h][s] = p.tbl[(size_t)((wave * 2 + h) * 16 + i) * KROWS + 4 * s + q];
+    const float ln_mean = (!INV && p.ln.stats) ? p.ln.stats[((size_t)tile * 16 + (tid & 15)) * 2] : 0.f;
+    const float ln_inv = (!INV && p.ln.stats) ? p.ln.stats[((size_t)tile * 16 + (tid & 15)) * 2 + 1] : 1.f;
     auto stage = [&](int c, float *dst) {
         for (int e = tid; e < KROWS * 16; e += NWAVE * 64) {
             const int k = e >> 4, t = e & 15;
             float v = 0.f;
             if (!INV) {
-                if (k < 160) v = ln_apply(p.ln, tile, t, c * 160 + k, p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + c, 160, k) + t]);
+                if (k < 160) v = ln_apply2(p.ln, ln_mean, ln_inv, c * 160 + k, p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + c, 160, k) + t]);
             } else if (k < 162) {
                 const int kk = k < 81 ? k : k - 81;
                 const float re = p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + c, 81, kk) + t];
@@ -260,12 +268,14 @@ __global__ __launch_bounds__(128) void lstm_f_kernel(LstmFArgs p) {
     float h[MT], c[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { h[mt] = 0.f; c[mt] = 0.f; }
+    const float ln_mean = p.ln.stats ? p.ln.stats[((size_t)tile * 16 + i) * 2] : 0.f;
+    const float ln_inv = p.ln.stats ? p.ln.stats[((size_t)tile * 16 + i) * 2 + 1] : 1.f;
     auto load_x = [&](int f, float (&x)[KI]) {
 #pragma unroll
         for (int s = 0; s < KI; ++s) {
             const int ch = 4 * s + q;
             const float v = p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + ch, p.F, f) + i];
-            x[s] = p.ln.stats ? ln_apply(p.ln, tile, i, ch * p.F + f, v) : v;
+            x[s] = p.ln.stats ? ln_apply2(p.ln, ln_mean, ln_inv, ch * p.F + f, v) : v;
         }
     };
     float xc[KI], xn[KI];
