@@ -1,0 +1,34 @@
+"""Run one secondary model a few times (for `rocprofv3 --kernel-trace [--pmc ...] -- python3 tools/prof_model.py <model>`)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vadx  # noqa: E402,F401
+from vadx import firered, fsmn, marblenet, weights  # noqa: E402
+from vadx import timestamps as ts  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "firered"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+if which == "firered":
+    eng = firered.FireRedEngine(weights.firered_synthetic(1234))
+    big = torch.from_numpy(weights.burst_clips(32, 160000, seed=321)).cuda().repeat(16, 1)       # 512 clips
+    fn = lambda: eng.run(big, 10)      # noqa: E731
+elif which == "fsmn":
+    eng = fsmn.FsmnEngine(weights.fsmn_synthetic(1234))
+    lb, stride = eng.grid()
+    base = weights.burst_clips(32, 160000, seed=123)
+    rows = np.stack([fsmn.pad_to_window_grid(ts.normalize_to_int16(base[b].astype(np.float32)), 16000, stride, np.zeros(20000)) for b in range(32)])
+    W = (rows.shape[1] - 16000) // stride + 1
+    big = torch.from_numpy(rows).cuda().repeat(32, 1)                                              # 1024 clips
+    fn = lambda: eng.flags(big, W)     # noqa: E731
+else:
+    eng = marblenet.MarbleNetEngine(weights.marblenet_synthetic(1234))
+    big = torch.from_numpy(weights.burst_clips(64, 89431, seed=55)).cuda().repeat(32, 1)          # 2048 clips
+    fn = lambda: eng.run(big)          # noqa: E731
+for _ in range(reps):
+    fn()
+torch.cuda.synchronize()
+print("done")

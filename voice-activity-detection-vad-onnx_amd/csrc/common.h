@@ -92,40 +92,56 @@ template <int NT, int MT, bool SWAP, bool AFFINE = false>
 __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, int lda, const int (&moff)[MT],
                                         const float *const (&wrow)[NT], int kb, int lane,
                                         const float *add = nullptr, const float *mul = nullptr) {
+    // Software pipeline, one block (16 k) deep on BOTH operands: the LDS activations and the L2 weights of
+    // block S+1 are requested before block S's MFMAs issue (with few m-tiles a block is only 4*MT*NT MFMAs, so
+    // un-pipelined ds_read latency -- not bandwidth -- is what idles the matrix pipe).  Two register sets
+    // alternate (loop unrolled by two) so no copies are needed.
     const int q = lane >> 4, i = lane & 15;
     const float *ap = act + (4 * q) * lda + i;
-    f32x4 wcur[NT], wnxt[NT];
+    f32x4 w0[NT], w1[NT];
+    float a0[4][MT], a1[4][MT];
+    auto fetch = [&](int S, f32x4 (&w)[NT], float (&a)[4][MT]) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 4 * q);
-    for (int S = 0; S < kb; ++S) {
-        const int Sn = (S + 1 < kb) ? S + 1 : S;
+        for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * S + 4 * q);
+        const float *aps = ap + 16 * S * lda;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
-        __builtin_amdgcn_sched_barrier(0);      // keep the next block's weight loads ahead of this block's MFMAs
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[j][mt] = aps[j * lda + moff[mt]];
+    };
+    auto compute = [&](int S, const f32x4 (&w)[NT], const float (&a)[4][MT]) {
         f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, m4 = {1.f, 1.f, 1.f, 1.f};
         if (AFFINE) {
             a4 = *reinterpret_cast<const f32x4 *>(add + 16 * S + 4 * q);
             m4 = *reinterpret_cast<const f32x4 *>(mul + 16 * S + 4 * q);
         }
-        const float *aps = ap + 16 * S * lda;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float av[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                av[mt] = aps[j * lda + moff[mt]];
+                av[mt] = a[j][mt];
                 if (AFFINE) av[mt] = __fmul_rn(__fadd_rn(av[mt], a4[j]), m4[j]);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const float wj = wcur[nt][j];
+                const float wj = w[nt][j];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = SWAP ? mfma16(wj, av[mt], acc[nt][mt]) : mfma16(av[mt], wj, acc[nt][mt]);
             }
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wcur[nt] = wnxt[nt];
+    };
+    fetch(0, w0, a0);
+    for (int S = 0; S < kb; S += 2) {
+        fetch(S + 1 < kb ? S + 1 : S, w1, a1);
+        __builtin_amdgcn_sched_barrier(0);      // next block's operands stay ahead of this block's MFMAs
+        compute(S, w0, a0);
+        if (S + 1 < kb) {
+            fetch(S + 2 < kb ? S + 2 : S + 1, w0, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(S + 1, w1, a1);
+        }
     }
 }
 

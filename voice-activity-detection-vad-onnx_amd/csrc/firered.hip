@@ -37,7 +37,7 @@ static int r16(int x) { return (x + 15) & ~15; }
 static int derive(const vadx_firered_cfg *c, Dev *d) {
     memset(d, 0, sizeof(*d));
     if (c->idim != NMEL || c->R < 1 || c->R > MAX_R || c->M < 1 || c->M > MAX_M || c->H < 1 || c->P < 1 ||
-        c->N1 < 1 || c->N1 > 64 || c->S1 < 1 || c->N2 < 0 || c->N2 > 64 || (c->N2 > 0 && c->S2 < 1) ||
+        c->N1 < 1 || c->N1 > 32 || c->S1 < 1 || c->N2 < 0 || c->N2 > 32 || (c->N2 > 0 && c->S2 < 1) ||
         c->odim < 1 || c->odim > MAX_ODIM || c->frames < 1 || c->frames > MAX_T)
         return -1;
     d->R = c->R; d->M = c->M; d->H = c->H; d->P = c->P; d->N1 = c->N1; d->S1 = c->S1; d->N2 = c->N2; d->S2 = c->S2;
@@ -59,29 +59,87 @@ static int derive(const vadx_firered_cfg *c, Dev *d) {
 }
 
 // memory = p + lookback(p) + lookahead(p) (+ mem)   -- Export_FireRedVAD.py:213-236, :255-264
-__device__ __forceinline__ void fsmn_memory(const Dev &d, const float *__restrict__ Pk, int r, bool skip,
+// thread = (channel, quarter of the window); the channel's taps sit in registers (loops fully unrolled
+// to MAXTAP with guards: a runtime-indexed tap array would live in scratch and serialise on latency).
+constexpr int MAXTAP = 32;
+
+// Fast path for undilated filters with <= 20 taps each (the shipped FireRedVAD/AED configs): the
+// look-back and look-ahead filters merge into one 40-tap window c[-19..20] around t; each thread slides
+// it over 28 frames held in registers -- no guards, no address math in the inner loop.
+__device__ __forceinline__ void fsmn_memory_fast(const Dev &d, const float *__restrict__ Pk, int r, bool skip,
+                                                 const float *p, float *mem) {
+    constexpr int LB = 19, LA = 20, SEG = 28, WIN = SEG + LB + LA;
+    const int ch = threadIdx.x >> 2, part = threadIdx.x & 3;
+    if (ch >= d.Pp) return;
+    float c[LB + 1 + LA];                       // c[j + LB], j = -19..20 ; c[LB] (j = 0) unused
+#pragma unroll
+    for (int j = -LB; j <= LA; ++j) {
+        float v = 0.f;
+        if (j <= 0) { const int k = j + d.N1 - 1; if (k >= 0 && k < d.N1) v = Pk[d.off_lb[r] + ch * d.N1 + k]; }
+        else if (d.N2 > 0 && d.T > 1) { const int k = j - 1; if (k < d.N2) v = Pk[d.off_la[r] + ch * d.N2 + k]; }
+        c[j + LB] = v;
+    }
+    const float *row = p + ch * M_LD;
+    const int t0 = part * SEG;
+    float win[WIN];
+#pragma unroll
+    for (int u = 0; u < WIN; ++u) {
+        const int t = t0 - LB + u;
+        win[u] = (t >= 0 && t < d.T) ? row[t] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+        const int t = t0 + u;
+        float lb = 0.f, la = 0.f;
+#pragma unroll
+        for (int j = -LB; j <= 0; ++j) lb = fmaf(c[j + LB], win[u + LB + j], lb);      // same order as the generic path
+#pragma unroll
+        for (int j = 1; j <= LA; ++j) la = fmaf(c[j + LB], win[u + LB + j], la);
+        if (t < d.T) {
+            float s2 = (win[u + LB] + lb) + la;
+            if (skip) s2 += mem[ch * M_LD + t];
+            mem[ch * M_LD + t] = s2;
+        }
+    }
+}
+
+__device__ __forceinline__ void fsmn_memory_generic(const Dev &d, const float *__restrict__ Pk, int r, bool skip,
                                             const float *p, float *mem) {
-    const float *wlb = Pk + d.off_lb[r], *wla = Pk + d.off_la[r];
-    for (int e = threadIdx.x; e < d.Pp * d.T; e += THREADS) {
-        const int ch = e / d.T, t = e - ch * d.T;
-        const float *row = p + ch * M_LD;
-        float lb = 0.f;
-        for (int k = 0; k < d.N1; ++k) {
+    const int ch = threadIdx.x >> 2, part = threadIdx.x & 3;
+    if (ch >= d.Pp) return;
+    float wlb[MAXTAP], wla[MAXTAP];
+#pragma unroll
+    for (int k = 0; k < MAXTAP; ++k) {
+        wlb[k] = k < d.N1 ? Pk[d.off_lb[r] + ch * d.N1 + k] : 0.f;
+        wla[k] = k < d.N2 ? Pk[d.off_la[r] + ch * d.N2 + k] : 0.f;
+    }
+    const float *row = p + ch * M_LD;
+    const int per = (d.T + 3) >> 2, t0 = part * per, t1 = (t0 + per < d.T) ? t0 + per : d.T;
+    const bool ahead = d.N2 > 0 && d.T > 1;
+    for (int t = t0; t < t1; ++t) {
+        float lb = 0.f, la = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXTAP; ++k) {
             const int idx = t + (k - (d.N1 - 1)) * d.S1;
-            if (idx >= 0) lb = fmaf(wlb[ch * d.N1 + k], row[idx], lb);
+            if (k < d.N1 && idx >= 0) lb = fmaf(wlb[k], row[idx], lb);
         }
         float s = row[t] + lb;
-        if (d.N2 > 0 && d.T > 1) {
-            float la = 0.f;
-            for (int k = 0; k < d.N2; ++k) {
+        if (ahead) {
+#pragma unroll
+            for (int k = 0; k < MAXTAP; ++k) {
                 const int idx = t + d.S2 + k * d.S2;
-                if (idx < d.T) la = fmaf(wla[ch * d.N2 + k], row[idx], la);
+                if (k < d.N2 && idx < d.T) la = fmaf(wla[k], row[idx], la);
             }
             s += la;
         }
         if (skip) s += mem[ch * M_LD + t];
         mem[ch * M_LD + t] = s;
     }
+}
+
+__device__ __forceinline__ void fsmn_memory(const Dev &d, const float *__restrict__ Pk, int r, bool skip, const float *p, float *mem) {
+    if (d.S1 == 1 && d.N1 <= 20 && (d.N2 == 0 || d.S2 == 1) && d.N2 <= 20 && d.T <= 112) fsmn_memory_fast(d, Pk, r, skip, p, mem);
+    else fsmn_memory_generic(d, Pk, r, skip, p, mem);
 }
 
 // pointwise pair on every 32-frame tile of the window: h = relu(W1 x src + b1); dst = W2 x h (+b2, relu)

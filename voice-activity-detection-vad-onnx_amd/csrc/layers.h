@@ -18,7 +18,7 @@ struct LayerArgs {
 // dst[n][m] = act[k][m] x W[n][k] (+bias, ReLU).  Work items: whole n-tiles (all m-tiles of the tile)
 // when the n-tile count fills the 8 waves evenly, otherwise (n-tile, m-tile) pairs.
 template <int MTT, bool AFFINE>
-__device__ __noinline__ void layer(const LayerArgs a) {
+__device__ __forceinline__ void layer(const LayerArgs &a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
     if (a.ntiles % LAYER_NW == 0) {
         for (int nt = wave; nt < a.ntiles; nt += LAYER_NW) {
