@@ -145,6 +145,39 @@ __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, 
     }
 }
 
+// Plain one-block look-ahead variant (weights only): measured faster than the operand-pipelined gemm_rt
+// for the front-end's NT=2 x MT=2 DFT tiles, where a block already carries 16 MFMAs per 8 ds_reads.
+template <int NT, int MT, bool SWAP>
+__device__ __forceinline__ void gemm_rt_simple(f32x4 (&acc)[NT][MT], const float *act, int lda, const int (&moff)[MT],
+                                               const float *const (&wrow)[NT], int kb, int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    const float *ap = act + (4 * q) * lda + i;
+    f32x4 wcur[NT], wnxt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 4 * q);
+    for (int S = 0; S < kb; ++S) {
+        const int Sn = (S + 1 < kb) ? S + 1 : S;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
+        const float *aps = ap + 16 * S * lda;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = aps[j * lda + moff[mt]];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float wj = wcur[nt][j];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = SWAP ? mfma16(wj, av[mt], acc[nt][mt]) : mfma16(av[mt], wj, acc[nt][mt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wcur[nt] = wnxt[nt];
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 }  // namespace vadx

@@ -137,7 +137,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
             int moff[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16 + a;
-            vadx::gemm_rt<2, MT, false>(acc, X2, X_LD, moff, wrow, d.pass_kb[a], lane);
+            vadx::gemm_rt_simple<2, MT, false>(acc, X2, X_LD, moff, wrow, d.pass_kb[a], lane);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -193,7 +193,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
         int moff[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16;
-        if (hi > lo) vadx::gemm_rt<1, MT, true>(acc, PW + lo * 16 * P_LD, P_LD, moff, wrow, hi - lo, lane);
+        if (hi > lo) vadx::gemm_rt_simple<1, MT, true>(acc, PW + lo * 16 * P_LD, P_LD, moff, wrow, hi - lo, lane);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int f = f0 + mt * 16 + i;
