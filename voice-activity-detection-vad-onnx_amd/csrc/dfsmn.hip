@@ -35,35 +35,40 @@ __device__ __forceinline__ size_t ft_idx(int tile, int c_total, int c, int F, in
 // LayerNorm statistics over (C, F) per frame: stats[tile][16][2] = (mean, 1/(std_unbiased + 1e-6))
 // (LayerNorm.forward, Export_DFSMN_VAD.py:163-167).  Two passes (mean, then centred squares).
 // ---------------------------------------------------------------------------------------------
-__global__ void frame_stats_kernel(View a, View b, int F, float *__restrict__ stats) {
-    __shared__ float red[16][17];
-    const int tile = blockIdx.x, tid = threadIdx.x, t = tid & 15, part = tid >> 4;     // 256 threads: 16 parts
+__global__ __launch_bounds__(256) void frame_stats_kernel(View a, View b, int F, float *__restrict__ stats) {
+    // thread = (row group tid>>2, frame quad tid&3): 16-B loads, a wave reads 1 KiB contiguous
+    __shared__ f32x4 red[64][4];
+    __shared__ float mean_s[16];
+    const int tile = blockIdx.x, tid = threadIdx.x, tq = tid & 3, rg = tid >> 2;
     const int n = (a.c + b.c) * F;
-    auto at = [&](int e) -> float {
+    auto at = [&](int e) -> f32x4 {
         const int c = e / F, f = e - c * F;
-        return c < a.c ? a.ptr[ft_idx(tile, a.c_total, a.c_off + c, F, f) + t]
-                       : b.ptr[ft_idx(tile, b.c_total, b.c_off + c - a.c, F, f) + t];
+        const float *ptr = c < a.c ? a.ptr + ft_idx(tile, a.c_total, a.c_off + c, F, f)
+                                   : b.ptr + ft_idx(tile, b.c_total, b.c_off + c - a.c, F, f);
+        return *reinterpret_cast<const f32x4 *>(ptr + 4 * tq);
     };
-    float s = 0.f;
-    for (int e = part; e < n; e += 16) s += at(e);
-    red[part][t] = s;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int e = rg; e < n; e += 64) s += at(e);
+    red[rg][tq] = s;
     __syncthreads();
-    float mean = 0.f;
-#pragma unroll
-    for (int p2 = 0; p2 < 16; ++p2) mean += red[p2][t];
-    mean /= (float)n;
+    if (tid < 16) {
+        float m = 0.f;
+        for (int g = 0; g < 64; ++g) m += red[g][tid >> 2][tid & 3];
+        mean_s[tid] = m / (float)n;
+    }
     __syncthreads();
-    float v = 0.f;
-    for (int e = part; e < n; e += 16) { const float d = at(e) - mean; v = fmaf(d, d, v); }
-    red[part][t] = v;
+    const f32x4 mean = {mean_s[4 * tq], mean_s[4 * tq + 1], mean_s[4 * tq + 2], mean_s[4 * tq + 3]};
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int e = rg; e < n; e += 64) { const f32x4 d = at(e) - mean; v += d * d; }
     __syncthreads();
-    if (part == 0) {
+    red[rg][tq] = v;
+    __syncthreads();
+    if (tid < 16) {
         float var = 0.f;
-#pragma unroll
-        for (int p2 = 0; p2 < 16; ++p2) var += red[p2][t];
+        for (int g = 0; g < 64; ++g) var += red[g][tid >> 2][tid & 3];
         const float sd = sqrtf(var / (float)(n - 1));
-        stats[((size_t)tile * 16 + t) * 2] = mean;
-        stats[((size_t)tile * 16 + t) * 2 + 1] = 1.0f / (sd + 1e-6f);
+        stats[((size_t)tile * 16 + tid) * 2] = mean_s[tid];
+        stats[((size_t)tile * 16 + tid) * 2 + 1] = 1.0f / (sd + 1e-6f);
     }
 }
 
