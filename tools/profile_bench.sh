@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile bench.py under rocprofv3 (run on the GPU box via gpurun): kernel-trace stats + separate PMC passes.
-# usage: bash tools_profile.sh <tag>
+# usage: bash tools/profile_bench.sh <tag>
 set -u
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
