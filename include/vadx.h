@@ -231,6 +231,13 @@ int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_firered_weigh
 int vadx_firered_run(const vadx_firered_cfg *cfg, const float *packed, const float *logmel, int windows,
                      float *probs, void *stream);
 
+/* Streaming variant (FireRed Stream-VAD): one chunk of cfg->frames frames for `streams`
+ * independent streams; caches f32 [R][streams][P][(N1-1)*S1] in -> out (must not alias); cfg->N2 == 0.
+ * Replaces ort_session_C.run([probs, caches_out], {audio, caches_in}), Inference_FireRed_ONNX.py:798-801
+ * (graph FireRedVAD/Export_FireRedVAD.py:479-612, 656-749 after the front-end). */
+int vadx_firered_stream_run(const vadx_firered_cfg *cfg, const float *packed, const float *logmel, int streams,
+                            const float *caches_in, float *caches_out, float *probs, void *stream);
+
 typedef struct vadx_vadpost_params {     /* VadPostprocessor.__init__, Inference_FireRed_ONNX.py:108-120 */
     int   smooth_window_size;
     float prob_threshold;

@@ -421,6 +421,73 @@ def gen_firered():
     save("firered_forward", **out)
 
 
+def gen_firered_stream():
+    print("FireRedStreamVAD_ONNX wrapper + DetectModel_Streaming + StreamVadPostprocessor")
+    stft_mod = R.load_module("FireRedVAD/STFT_Process.py", "ref_stft_v2s")
+    ns = {"torch": torch, "math": __import__("math"), "np": np, "STFT_Process": stft_mod.STFT_Process}
+    R.select_nodes("FireRedVAD/Export_FireRedVAD.py",
+                   {"FSMN_Streaming", "DFSMNBlock_Streaming", "DFSMN_Streaming", "DetectModel_Streaming",
+                    "FireRedStreamVAD_ONNX", "StreamVadPostprocessor", "build_kaldi_mel_filterbank"}, ns,
+                   consts={"_VAD_SILENCE", "_VAD_POSSIBLE_SPEECH", "_VAD_SPEECH", "_VAD_POSSIBLE_SILENCE",
+                           "FRAME_PER_SECONDS", "FRAME_SHIFT_MS", "FRAME_LENGTH_MS"})
+    out = {}
+    cfgs = {1234: dict(weights.FIRERED_CFG, N2=0, S2=0), 7: dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=2, N2=0, S2=0)}
+    for seed, cfg in cfgs.items():
+        w = weights.firered_synthetic(seed, cfg)
+        dm = ns["DetectModel_Streaming"](types.SimpleNamespace(**cfg)).eval()
+        sd = {"dfsmn.fc1.0.weight": w["fc1_w"][:, :, None], "dfsmn.fc1.0.bias": w["fc1_b"],
+              "dfsmn.fc2.0.weight": w["fc2_w"][:, :, None], "dfsmn.fc2.0.bias": w["fc2_b"],
+              "dfsmn.fsmn1.lookback_filter.weight": w["fsmn0_lb"][:, None, :],
+              "out.weight": w["out_w"][:, :, None], "out.bias": w["out_b"]}
+        for r in range(1, cfg["R"]):
+            p = f"dfsmn.fsmns.{r - 1}."
+            sd[p + "fc1.0.weight"] = w[f"blk{r}_fc1_w"][:, :, None]
+            sd[p + "fc1.0.bias"] = w[f"blk{r}_fc1_b"]
+            sd[p + "fc2.weight"] = w[f"blk{r}_fc2_w"][:, :, None]
+            sd[p + "fsmn.lookback_filter.weight"] = w[f"fsmn{r}_lb"][:, None, :]
+        for m in range(cfg["M"]):
+            sd[f"dfsmn.dnns.{2 * m}.weight"] = w[f"dnn{m}_w"][:, :, None]
+            sd[f"dfsmn.dnns.{2 * m}.bias"] = w[f"dnn{m}_b"]
+        dm.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+        model = ns["FireRedStreamVAD_ONNX"](dm, 400, 160, 400, 80, 16000, 0.97, "povey", 16000).eval()
+        # the chunk loop of the stream driver (Inference_FireRed_ONNX.py:788-808) on a ragged-length clip
+        n = 2 * 16000 + 2560 * 3 + (300 if seed == 1234 else 1111)
+        clip = weights.burst_clips(1, n, seed=seed)[0]
+        caches = torch.zeros((cfg["R"], 1, cfg["P"], (cfg["N1"] - 1) * cfg["S1"]))
+        probs, pos, first = [], 0, None
+        with torch.no_grad():
+            while pos < n:
+                end = min(pos + 2560, n)
+                chunk = clip[pos:end]
+                if len(chunk) < 400:
+                    chunk = np.pad(chunk, (0, 400 - len(chunk)), mode="constant")
+                pr, caches = model(T(chunk.reshape(1, 1, -1).astype(np.int16)), caches)
+                if first is None:
+                    first = caches.numpy().copy()
+                probs.append(pr[0, 0].numpy())
+                pos = end
+        out[f"s{seed}_clip"] = clip
+        out[f"s{seed}_probs"] = np.concatenate(probs)
+        out[f"s{seed}_caches_first"] = first
+        out[f"s{seed}_caches_last"] = caches.numpy()
+    # StreamVadPostprocessor on the shared probability tracks (+ max-speech split and chunked feeding)
+    rng = np.random.default_rng(4321)
+    tracks = prob_tracks(rng)
+    pcfgs = [(5, 0.4, 5, 8, 2000, 20), (3, 0.5, 2, 4, 60, 6), (1, 0.5, 0, 1, 25, 1)]
+    out["post_cfgs"] = np.array(pcfgs, dtype=np.float64)
+    out["post_n"] = np.array(len(tracks))
+    for i, p in enumerate(tracks):
+        out[f"post_probs_{i}"] = p
+        for c, cfg in enumerate(pcfgs):
+            seg = ns["StreamVadPostprocessor"](*cfg).process_batch(p.copy())
+            out[f"post{c}_seg_{i}"] = np.array(seg, dtype=np.float64).reshape(-1, 2)
+            pp = ns["StreamVadPostprocessor"](*cfg)         # fed in 14-frame pieces: state carries over
+            pieces = [np.array(pp.process_batch(p[k:k + 14].copy()), dtype=np.float64).reshape(-1, 2)
+                      for k in range(0, len(p), 14)]
+            out[f"post{c}_chunked_{i}"] = np.concatenate(pieces) if pieces else np.zeros((0, 2))
+    save("firered_stream", **out)
+
+
 # ------------------------------------------------------------------------------------ DFSMN near+far
 def gen_dfsmn():
     print("DFSMN_VAD wrapper + ICCRN + UniDeepFsmn (near+far)")
@@ -547,7 +614,7 @@ def gen_marblenet_fold():
 if __name__ == "__main__":
     which = set(sys.argv[1:])
     gens = dict(stft=gen_stft, host=gen_host, vadpost=gen_vadpost, silero_host=gen_silero_host,
-                fsmn=gen_fsmn, firered=gen_firered, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn)
+                fsmn=gen_fsmn, firered=gen_firered, firered_stream=gen_firered_stream, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn)
     for name, fn in gens.items():
         if not which or name in which:
             fn()

@@ -49,3 +49,46 @@ def test_fsmn_on_vad_sample(tmp_path):
     want, _ = ofs.run_clip(ofs.Frontend(), ow, a, noise[0])
     assert got == want
     assert open(idx).read() == "".join(opp.timestamp_lines(want, 16000)[1])
+
+
+def test_firered_aed_on_vad_sample():
+    """RUN_AED drop-in: three event tracks, one device postprocessor per event, ratios of frames over threshold."""
+    from vadx import firered
+    from oracle import firered as ofr
+    cfg = dict(weights.FIRERED_CFG, odim=3)
+    wts = weights.firered_synthetic(1234, cfg)
+    noise = np.random.default_rng(5).standard_normal((1, 20000))
+    lines = []
+    ts, ratio = drivers.inference_firered_aed(WAV, firered.FireRedEngine(wts), pad_noise=noise, echo=lines.append)
+    wt = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in wts.items()}
+    a = audio_io.load_wav(WAV)
+    ots, oratio, oprobs = ofr.run_clip_aed(ofr.Frontend(), wt, a, noise[0])
+    assert list(ts) == ["speech", "singing", "music"] == list(oratio)
+    thr = {"speech": 0.4, "singing": 0.5, "music": 0.5}
+    for i, ev in enumerate(ts):
+        near = int(np.sum(np.abs(oprobs[i] - thr[ev]) < 2e-4))      # frames that may legitimately flip
+        assert abs(ratio[ev] - oratio[ev]) <= near / oprobs.shape[1] + 1e-3
+        if near == 0:
+            assert ts[ev] == ots[ev], ev
+    assert any("AED Results" in str(l) for l in lines)
+    with pytest.raises(ValueError):
+        firered.FireRedEngine(weights.firered_synthetic(1234)).detect_events(a[None, :])
+
+
+def test_firered_stream_on_vad_sample():
+    from vadx import firered
+    from oracle import firered as ofr
+    cfg = dict(weights.FIRERED_CFG, N2=0, S2=0)
+    wts = weights.firered_synthetic(1234, cfg)
+    eng = firered.FireRedEngine(wts, firered.STREAM_CHUNK_SAMPLES)
+    got = drivers.inference_firered_stream(WAV, eng, STREAM_VAD_THRESHOLD=0.3, echo=lambda *_: None)
+    wt = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in wts.items()}
+    a = audio_io.load_wav(WAV)
+    want, oprobs = ofr.run_clip_stream(ofr.Frontend(), wt, a, post=(5, 0.3, 5, 8, 2000, 20))
+    _, track = eng.stream_detect(a[None, :], post=(5, 0.3, 5, 8, 2000, 20), return_probs=True)
+    np.testing.assert_allclose(track[0], oprobs, rtol=0, atol=1e-4)
+    csum = np.concatenate([[0.0], np.cumsum(oprobs, dtype=np.float64)])
+    k = np.arange(1, len(oprobs) + 1)
+    smooth = (csum[k] - csum[np.maximum(k - 5, 0)]) / np.minimum(k, 5)
+    if np.min(np.abs(smooth - 0.3)) > 1e-3:
+        assert got == want

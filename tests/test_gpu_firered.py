@@ -107,3 +107,67 @@ def test_full_size_config5_properties():
     want_seg, want_p, want_dec = ofr.run_clip(fe, ow, base[5], np.zeros(10))
     np.testing.assert_allclose(track[5].cpu().numpy(), want_p, rtol=0, atol=ATOL)
     print(f"FireRed config-5 pass (incl. host pad/upload): {dt * 1e3:.1f} ms for 2048 x 10 s")
+
+
+# ------------------------------------------------------------------ Stream-VAD (cache-carrying chunk kernel)
+STREAM_CFGS = {1234: dict(weights.FIRERED_CFG, N2=0, S2=0),
+               7: dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=2, N2=0, S2=0)}
+
+
+@pytest.mark.parametrize("seed", [1234, 7])
+def test_stream_session_matches_reference_fixture(golden, seed):
+    """The reference's chunk loop (2560-sample chunks, caches fed back, short tail zero-padded) through the
+    session boundary, against probabilities / caches produced by the reference modules."""
+    g = golden("firered_stream")
+    cfg = STREAM_CFGS[seed]
+    sess = firered.FireRedStreamSession(weights.firered_synthetic(seed, cfg))
+    names = [m.name for m in sess.get_inputs()], [m.name for m in sess.get_outputs()]
+    assert names == (["audio", "caches_in"], ["probs", "caches_out"])
+    clip = g[f"s{seed}_clip"]
+    n = len(clip)
+    caches = np.zeros(sess._inputs_meta[1].shape, np.float32)
+    probs, pos = [], 0
+    while pos < n:
+        end = min(pos + 2560, n)
+        chunk = clip[pos:end]
+        if len(chunk) < 400:
+            chunk = np.pad(chunk, (0, 400 - len(chunk)), mode="constant")
+        pr, caches = sess.run(["probs", "caches_out"], {"audio": chunk.reshape(1, 1, -1), "caches_in": caches})
+        if pos == 0:
+            np.testing.assert_allclose(caches, g[f"s{seed}_caches_first"], rtol=0, atol=1e-3)
+        probs.append(pr[0, 0])
+        pos = end
+    got = np.concatenate(probs)
+    assert got.shape == g[f"s{seed}_probs"].shape
+    np.testing.assert_allclose(got, g[f"s{seed}_probs"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(caches, g[f"s{seed}_caches_last"], rtol=0, atol=1e-3)
+    with pytest.raises(ValueError):
+        sess.run(None, {"audio": clip[:2560].reshape(1, 1, -1), "caches_in": caches[:, :, :, :-1]})
+    with pytest.raises(ValueError):
+        sess.run(None, {"audio": clip[:300].reshape(1, 1, -1), "caches_in": caches})
+
+
+def test_stream_detect_batch_vs_oracle():
+    """Many streams advance together, one chunk per launch: probabilities within 1e-4 of the oracle loop run
+    clip by clip, identical segments, and every stream independent of its neighbours."""
+    cfg = STREAM_CFGS[1234]
+    wts = weights.firered_synthetic(1234, cfg)
+    eng = firered.FireRedEngine(wts, firered.STREAM_CHUNK_SAMPLES)
+    n = 3 * 16000 + 777
+    clips = weights.burst_clips(5, n, seed=31)
+    post = (5, 0.3, 5, 8, 2000, 20)      # the look-back-only synthetic net sits lower than the calibrated one
+    segs, track = eng.stream_detect(clips, post=post, return_probs=True)
+    fe = ofr.Frontend()
+    wt = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in wts.items()}
+    for b in range(clips.shape[0]):
+        oseg, oprobs = ofr.run_clip_stream(fe, wt, clips[b], post=post)
+        assert track[b].shape == oprobs.shape
+        np.testing.assert_allclose(track[b], oprobs, rtol=0, atol=ATOL)
+        csum = np.concatenate([[0.0], np.cumsum(oprobs, dtype=np.float64)])
+        k = np.arange(1, len(oprobs) + 1)
+        smooth = (csum[k] - csum[np.maximum(k - 5, 0)]) / np.minimum(k, 5)
+        if np.min(np.abs(smooth - 0.3)) > 1e-3:          # no smoothed frame within tolerance of the threshold
+            assert segs[b] == oseg, b
+    solo, solo_track = eng.stream_detect(clips[2:3], post=post, return_probs=True)
+    assert np.array_equal(solo_track[0], track[2]) and solo[0] == segs[2]
+    assert any(len(s) for s in segs)

@@ -188,6 +188,53 @@ def test_firered_forward(golden, seed):
     np.testing.assert_allclose(probs, g[f"s{seed}_probs"], rtol=1e-5, atol=1e-5)
 
 
+# ------------------------------------------------------------------ f1: FireRed Stream-VAD (cache-carrying chunks)
+STREAM_CFGS = {1234: dict(weights.FIRERED_CFG, N2=0, S2=0),
+               7: dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=2, N2=0, S2=0)}
+
+
+@pytest.mark.parametrize("seed", [1234, 7])
+def test_firered_stream_forward(golden, seed):
+    g = golden("firered_stream")
+    fe = ofr.Frontend()
+    cfg = STREAM_CFGS[seed]
+    w = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in weights.firered_synthetic(seed, cfg).items()}
+    clip = g[f"s{seed}_clip"]
+    # first chunk: probabilities and the updated caches
+    caches0 = torch.zeros(cfg["R"], 1, cfg["P"], (cfg["N1"] - 1) * cfg["S1"])
+    pr, c1 = ofr.forward_stream(fe, w, T(clip[:2560]).reshape(1, 1, -1), caches0)
+    np.testing.assert_allclose(pr[0, 0].numpy(), g[f"s{seed}_probs"][:14], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c1.numpy(), g[f"s{seed}_caches_first"], rtol=1e-5, atol=1e-5)
+    # whole ragged clip through the chunk loop (short last chunk zero-padded to 400 samples)
+    _, allp = ofr.run_clip_stream(fe, w, clip)
+    ref = g[f"s{seed}_probs"][:ofr.valid_frame_count(len(clip))]
+    assert allp.shape == ref.shape
+    np.testing.assert_allclose(allp, ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_stream_vadpostprocessor(golden, impl):
+    """Bit-exact segment boundaries for the streaming state machine, whole-track and fed 14 frames at a time
+    (host code on both sides: the product class runs without a GPU)."""
+    from vadx import vadpost
+    cls = ofr.StreamVadPostprocessor if impl == "oracle" else vadpost.StreamVadPostprocessor
+    g = golden("firered_stream")
+    for c, cfg in enumerate(g["post_cfgs"]):
+        args = (int(cfg[0]), float(cfg[1]), *[int(v) for v in cfg[2:]])
+        for i in range(int(g["post_n"])):
+            p = g[f"post_probs_{i}"]
+            seg = np.array(cls(*args).process_batch(p.copy()), dtype=np.float64).reshape(-1, 2)
+            assert np.array_equal(seg, g[f"post{c}_seg_{i}"]), (c, i)
+            pp = cls(*args)
+            pieces = [np.array(pp.process_batch(p[k:k + 14].copy()), dtype=np.float64).reshape(-1, 2)
+                      for k in range(0, len(p), 14)]
+            got = np.concatenate(pieces) if pieces else np.zeros((0, 2))
+            assert np.array_equal(got, g[f"post{c}_chunked_{i}"]), (c, i)
+            pp.reset()
+            again = np.array(pp.process_batch(p.copy()), dtype=np.float64).reshape(-1, 2)
+            assert np.array_equal(again, g[f"post{c}_seg_{i}"]), (c, i)
+
+
 def test_melscale_fbanks_properties():
     """torchaudio is un-vendored (parity unpinned): check the published algorithm's invariants."""
     for scale, norm, fmin in (("htk", None, 20.0), ("slaney", "slaney", 0.0)):

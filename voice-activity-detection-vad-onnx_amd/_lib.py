@@ -117,6 +117,7 @@ SIGNATURES = {
     "vadx_firered_packed_floats": (_Z, [C.POINTER(FireRedCfg)]),
     "vadx_firered_pack_host": (_I, [C.POINTER(FireRedCfg), C.POINTER(FireRedWeightsHost), _P]),
     "vadx_firered_run": (_I, [C.POINTER(FireRedCfg), _P, _P, _I, _P, _P]),
+    "vadx_firered_stream_run": (_I, [C.POINTER(FireRedCfg), _P, _P, _I, _P, _P, _P, _P]),
     "vadx_vadpost_workspace_bytes": (_Z, [_I, _I]),
     "vadx_vadpost": (_I, [C.POINTER(VadPostParams), _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "vadx_sepconv_block": (_I, [C.POINTER(SepConvCfg), _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _I, _I, _P]),

@@ -210,6 +210,84 @@ __global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float 
     }
 }
 
+// ---- streaming variant (FireRedVAD/Export_FireRedVAD.py:479-612): no look-ahead, the look-back context
+// of every FSMN comes from an explicit cache [R][B][P][(N1-1)*S1] that is returned updated ---------------
+__device__ __forceinline__ void fsmn_memory_stream(const Dev &d, const float *__restrict__ Pk, int r, bool skip,
+                                                   const float *p, float *mem, const float *__restrict__ cin,
+                                                   float *__restrict__ cout) {
+    const int pad = (d.N1 - 1) * d.S1;
+    for (int e = threadIdx.x; e < d.P * d.T; e += THREADS) {
+        const int ch = e / d.T, t = e - ch * d.T;
+        const float *row = p + ch * M_LD, *crow = cin + (size_t)ch * pad, *w = Pk + d.off_lb[r] + ch * d.N1;
+        float lb = 0.f;
+        for (int k = 0; k < d.N1; ++k) {
+            const int j = t + k * d.S1;                       // index into cache ++ p
+            lb = fmaf(w[k], j < pad ? crow[j] : row[j - pad], lb);
+        }
+        float s2 = row[t] + lb;
+        if (skip) s2 += mem[ch * M_LD + t];
+        mem[ch * M_LD + t] = s2;
+    }
+    for (int e = threadIdx.x; e < d.P * pad; e += THREADS) {      // new cache = last `pad` entries of cache ++ p
+        const int ch = e / pad, j = e - ch * pad, src = d.T + j;
+        cout[e] = src < pad ? cin[(size_t)ch * pad + src] : p[ch * M_LD + src - pad];
+    }
+}
+
+__global__ __launch_bounds__(THREADS, 2) void firered_stream_kernel(Dev d, const float *__restrict__ Pk,
+                                                                    const float *__restrict__ logmel,
+                                                                    const float *__restrict__ caches_in,
+                                                                    float *__restrict__ caches_out, int B,
+                                                                    float *__restrict__ probs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *mem = lds, *p = lds + MEM_F, *h = p + P_F;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int pad = (d.N1 - 1) * d.S1;
+    const float *lm = logmel + (size_t)b * d.T * NMEL;
+    for (int e = tid; e < MAX_T * NMEL; e += THREADS) {
+        const int t = e / NMEL, mel = e - t * NMEL;
+        mem[mel * M_LD + t] = t < d.T ? lm[(size_t)t * NMEL + mel] : 0.f;
+    }
+    for (int e = tid; e < MAXP * M_LD; e += THREADS) p[e] = 0.f;
+    __syncthreads();
+    pointwise_pair(d, Pk + d.off_fc1, Pk + d.off_fc1b, NMEL / 16, mem, Pk + d.off_fc2, Pk + d.off_fc2b, 1, p, h);
+    for (int e = tid; e < MAXP * M_LD; e += THREADS) mem[e] = 0.f;
+    __syncthreads();
+    auto cache = [&](const float *base, int r) { return base + ((size_t)r * B + b) * d.P * pad; };
+    fsmn_memory_stream(d, Pk, 0, false, p, mem, cache(caches_in, 0), const_cast<float *>(cache(caches_out, 0)));
+    __syncthreads();
+    for (int r = 1; r < d.R; ++r) {
+        pointwise_pair(d, Pk + d.off_bfc1[r], Pk + d.off_bfc1b[r], d.Pp / 16, mem, Pk + d.off_bfc2[r], nullptr, 0, p, h);
+        fsmn_memory_stream(d, Pk, r, true, p, mem, cache(caches_in, r), const_cast<float *>(cache(caches_out, r)));
+        __syncthreads();
+    }
+    float *h2 = p;
+    for (int f0 = 0; f0 < d.T; f0 += 32) {
+        const bool half = (d.T - f0) <= 16;
+        LayerArgs a{Pk + d.off_dnn[0], d.Pp, d.Hp / 16, 1, d.Pp / 16, 0, 0, Pk + d.off_dnnb[0], 1, mem, M_LD, f0, h, H_LD, 0, nullptr, nullptr};
+        if (half) layer<1, false>(a); else layer<2, false>(a);
+        __syncthreads();
+        float *cur = h, *nxt = h2;
+        for (int m = 1; m < d.M; ++m) {
+            LayerArgs c{Pk + d.off_dnn[m], d.Hp, d.Hp / 16, 1, d.Hp / 16, 0, 0, Pk + d.off_dnnb[m], 1, cur, H_LD, 0, nxt, H_LD, 0, nullptr, nullptr};
+            if (half) layer<1, false>(c); else layer<2, false>(c);
+            __syncthreads();
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        if (tid < 32 * d.odim) {
+            const int t = tid & 31, o = tid >> 5;
+            if (f0 + t < d.T) {
+                const float *wo = Pk + d.off_out + o * d.Hp;
+                float s2 = 0.f;
+                for (int c2 = 0; c2 < d.H; ++c2) s2 = fmaf(wo[c2], cur[c2 * H_LD + t], s2);
+                s2 += Pk[d.off_outb + o];
+                probs[((size_t)b * d.odim + o) * d.T + f0 + t] = sigmoidf_(s2);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- VadPostprocessor: one clip per thread, working arrays laid out [frame][clip] (coalesced) -------
 struct PostDev {
     int ws, min_sp, max_sp, min_si, merge, extend;
@@ -393,6 +471,26 @@ extern "C" int vadx_vadpost(const vadx_vadpost_params *prm, const float *probs, 
     signed char *wdec = reinterpret_cast<signed char *>(wsm + (size_t)batch * stride);
     hipLaunchKernelGGL(vadpost_kernel, dim3((batch + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), q, probs,
                        stride, n_frames, batch, wsm, wdec, reinterpret_cast<signed char *>(decisions), segments, counts, cap);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+
+extern "C" int vadx_firered_stream_run(const vadx_firered_cfg *cfg, const float *packed, const float *logmel, int streams,
+                                       const float *caches_in, float *caches_out, float *probs, void *stream) {
+    Dev d;
+    VADX_REQUIRE(cfg && packed && logmel && caches_in && caches_out && probs, "vadx_firered_stream_run: NULL argument");
+    VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_firered_stream_run: unsupported config");
+    VADX_REQUIRE(cfg->N2 == 0, "vadx_firered_stream_run: the streaming model has no look-ahead filter (N2 must be 0)");
+    VADX_REQUIRE(streams > 0 && caches_in != caches_out, "vadx_firered_stream_run: streams must be positive, caches must not alias");
+    static bool done = false;
+    if (!done) {
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(firered_stream_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));
+        done = true;
+    }
+    hipLaunchKernelGGL(firered_stream_kernel, dim3(streams), dim3(THREADS), LDS_FLOATS * sizeof(float),
+                       static_cast<hipStream_t>(stream), d, packed, logmel, caches_in, caches_out, streams, probs);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }

@@ -95,6 +95,66 @@ def inference_firered(test_vad_audio="./vad_sample.wav", engine=None, save_times
     return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_vad_audio, (list, tuple)), elapsed, echo)
 
 
+def inference_firered_aed(test_aed_audio="./vad_sample.wav", engine=None, NORMALIZE_AUDIO=False, SMOOTH_WINDOW_SIZE=5,
+                          SPEAKING_SCORE=0.4, SINGING_THRESHOLD=0.5, MUSIC_THRESHOLD=0.5, MIN_EVENT_FRAME=20,
+                          MAX_EVENT_FRAME=2000, MIN_SILENCE_FRAME=20, MERGE_SILENCE_FRAME=5, EXTEND_SPEECH_FRAME=0,
+                          pad_noise=None, echo=print):
+    """FireRedVAD/Inference_FireRed_ONNX.py:620-742 (RUN_AED): -> (event2timestamps, event2ratio) per file."""
+    from . import firered
+    files = _as_list(test_aed_audio)
+    if engine is None:
+        from . import weights
+        engine = firered.FireRedEngine(weights.firered_synthetic(1234, dict(weights.FIRERED_CFG, odim=3)))
+    clips = [audio_io.load_wav(f, 16000) for f in files]
+    if NORMALIZE_AUDIO:
+        clips = [timestamps.normalise_audio(c) for c in clips]
+    echo("\nRunning the FireRedAED by ONNX Runtime.")
+    t0 = time.time()
+    post = (SMOOTH_WINDOW_SIZE, MIN_EVENT_FRAME, MAX_EVENT_FRAME, MIN_SILENCE_FRAME, MERGE_SILENCE_FRAME, EXTEND_SPEECH_FRAME)
+    results = []
+    for c, nz in zip(clips, pad_noise if pad_noise is not None else [None] * len(clips)):
+        results += engine.detect_events(c[None, :], pad_noise=None if nz is None else nz[None, :],
+                                        thresholds=(SPEAKING_SCORE, SINGING_THRESHOLD, MUSIC_THRESHOLD), post=post)
+    elapsed = time.time() - t0
+    for (ts, ratio), c in zip(results, clips):
+        echo(f"\nAED Results:\n  Audio duration: {len(c) / 16000:.3f}s\n  Event ratios: {ratio}")
+        for event, seg in ts.items():
+            echo(f"\n  [{event}] segments ({len(seg)}):")
+            for a, b in seg:
+                echo(f"    {timestamps.format_time(a)} --> {timestamps.format_time(b)}")
+    echo(f"\nAED Process Complete.\n\nTime Cost: {elapsed:.3f} Seconds\nRTF: {elapsed / (len(clips[0]) / 16000):.4f}")
+    return results[0] if not isinstance(test_aed_audio, (list, tuple)) else results
+
+
+def inference_firered_stream(test_vad_audio="./vad_sample.wav", engine=None, NORMALIZE_AUDIO=False, SMOOTH_WINDOW_SIZE=5,
+                             STREAM_VAD_THRESHOLD=0.4, PAD_START_FRAME=5, MIN_SPEECH_FRAME_STREAM=8,
+                             MAX_SPEECH_FRAME_STREAM=2000, MIN_SILENCE_FRAME_STREAM=20, STREAM_CHUNK_SAMPLES=2560, echo=print):
+    """FireRedVAD/Inference_FireRed_ONNX.py:744-840 (RUN_STREAM_VAD): -> [(start_s, end_s)] per file."""
+    from . import firered
+    files = _as_list(test_vad_audio)
+    if engine is None:
+        from . import weights
+        engine = firered.FireRedEngine(weights.firered_synthetic(1234, dict(weights.FIRERED_CFG, N2=0, S2=0)),
+                                       STREAM_CHUNK_SAMPLES)
+    clips = [audio_io.load_wav(f, 16000) for f in files]
+    if NORMALIZE_AUDIO:
+        clips = [timestamps.normalise_audio(c) for c in clips]
+    echo("\nRunning the FireRedStreamVAD by ONNX Runtime.")
+    t0 = time.time()
+    post = (SMOOTH_WINDOW_SIZE, STREAM_VAD_THRESHOLD, PAD_START_FRAME, MIN_SPEECH_FRAME_STREAM, MAX_SPEECH_FRAME_STREAM,
+            MIN_SILENCE_FRAME_STREAM)
+    results = []
+    for c in clips:
+        results += engine.stream_detect(c[None, :], chunk=STREAM_CHUNK_SAMPLES, post=post)
+    elapsed = time.time() - t0
+    for seg, c in zip(results, clips):
+        echo(f"\nStream-VAD Results:\n  Audio duration: {len(c) / 16000:.3f}s\n  Segments detected: {len(seg)}\n\n  Timestamps in Second:")
+        for a, b in seg:
+            echo(f"    {timestamps.format_time(a)} --> {timestamps.format_time(b)}")
+    echo(f"\nStream-VAD Process Complete.\n\nTime Cost: {elapsed:.3f} Seconds\nRTF: {elapsed / (len(clips[0]) / 16000):.4f}")
+    return results[0] if not isinstance(test_vad_audio, (list, tuple)) else results
+
+
 def inference_marblenet(test_vad_audio="./vad_sample.wav", engine=None, save_timestamps_second="./timestamps_second.txt",
                         save_timestamps_indices="./timestamps_indices.txt", NORMALIZE_AUDIO=False, SMOOTH_WINDOW_SIZE=3,
                         SPEAKING_SCORE=0.5, MIN_SPEECH_FRAME=10, MAX_SPEECH_FRAME=1000, MIN_SILENCE_FRAME=10,

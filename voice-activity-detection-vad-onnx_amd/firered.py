@@ -1,5 +1,6 @@
-"""FireRedVAD / FireRedAED (non-stream) on MI355X: ORT-session boundary + the non-overlapping
-window loop of FireRedVAD/Inference_FireRed_ONNX.py:523-613 (VAD) / :620-742 (AED, odim = 3)."""
+"""FireRedVAD / FireRedAED (non-stream) and FireRed Stream-VAD on MI355X: ORT-session boundary + the
+non-overlapping window loop of FireRedVAD/Inference_FireRed_ONNX.py:523-613 (VAD) / :620-742 (AED, odim = 3)
+and the cache-carrying chunk loop of :744-822 (Stream-VAD)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -13,6 +14,7 @@ from . import weights as _weights
 from .fsmn import _Meta, pad_to_window_grid
 
 SAMPLE_RATE, WINDOW_LENGTH, HOP_LENGTH = 16000, 400, 160
+STREAM_CHUNK_SAMPLES = 2560          # 160 ms (Export_FireRedVAD.py:52-53)
 
 
 def valid_frame_count(num_samples):
@@ -30,8 +32,10 @@ class FireRedEngine:
         w = {k: (np.ascontiguousarray(np.asarray(v), dtype=np.float32) if k != "cfg" else v) for k, v in w.items()}
         self.L = int(input_audio_length)
         self.fe = _frontend.Frontend("firered", self.L, device=device)
+        self._fes = {self.L: self.fe}
         self.T = self.fe.frames
         self.odim = c["odim"]
+        self.cache_shape = (c["R"], 1, c["P"], (c["N1"] - 1) * c["S1"])
         cfg = _lib.FireRedCfg()
         for k in ("idim", "R", "M", "H", "P", "N1", "S1", "N2", "S2", "odim"):
             setattr(cfg, k, int(c[k]))
@@ -70,6 +74,68 @@ class FireRedEngine:
                                                    probs.data_ptr(), _lib.stream_ptr()))
         return probs
 
+    def _frontend_for(self, length):
+        fe = self._fes.get(length)
+        if fe is None:
+            if len(self._fes) >= 8:                      # chunk length + a few tail lengths; keep it bounded
+                self._fes.pop(next(k for k in self._fes if k != self.L))
+            fe = self._fes[length] = _frontend.Frontend("firered", length, device=self.device)
+        return fe
+
+    def new_caches(self, streams=1):
+        """zeros [R, streams, P, (N1-1)*S1] (Inference_FireRed_ONNX.py:775)"""
+        R, _, P, pad = self.cache_shape
+        return self.torch.zeros((R, streams, P, pad), dtype=self.torch.float32, device=self.device)
+
+    def stream_run(self, audio_i16, caches_in):
+        """One chunk of `streams` independent streams: audio int16 [streams, n] (400 <= n, any length),
+        caches_in f32 [R, streams, P, pad] -> (probs f32 [streams, odim, T], caches_out); T = (n-400)//160+1.
+        Look-back only (N2 == 0), as the Stream-VAD checkpoint (Export_FireRedVAD.py:479-612)."""
+        t = self.torch
+        if not t.is_tensor(audio_i16):
+            audio_i16 = t.from_numpy(np.ascontiguousarray(audio_i16, dtype=np.int16))
+        audio_i16 = audio_i16.to(self.device)
+        S, n = audio_i16.shape
+        if n < WINDOW_LENGTH:
+            raise ValueError(f"a stream chunk needs at least {WINDOW_LENGTH} samples, got {n}")
+        R, _, P, pad = self.cache_shape
+        if tuple(caches_in.shape) != (R, S, P, pad) or caches_in.dtype != t.float32:
+            raise ValueError(f"caches_in must be float32 {[R, S, P, pad]}, got {list(caches_in.shape)}")
+        fe = self._frontend_for(n)
+        logmel = fe.logmel(audio_i16, 1, n)
+        cfg = _lib.FireRedCfg.from_buffer_copy(self.cfg)
+        cfg.frames = fe.frames
+        caches_in = caches_in.to(self.device).contiguous()
+        caches_out = t.empty_like(caches_in)
+        probs = t.empty((S, self.odim, fe.frames), dtype=t.float32, device=self.device)
+        with t.cuda.device(self.device):
+            _lib.check(_lib.lib().vadx_firered_stream_run(C.byref(cfg), self.packed.data_ptr(), logmel.data_ptr(), S,
+                                                          caches_in.data_ptr(), caches_out.data_ptr(), probs.data_ptr(),
+                                                          _lib.stream_ptr()))
+        return probs, caches_out
+
+    def stream_detect(self, clips_i16, chunk=STREAM_CHUNK_SAMPLES, post=(5, 0.4, 5, 8, 2000, 20), return_probs=False):
+        """Equal-length clips int16 [B,N] (host): every clip is one stream, all streams advance one chunk per
+        launch (Inference_FireRed_ONNX.py:788-822) -> per clip [(start_s, end_s)]."""
+        t = self.torch
+        clips = np.asarray(clips_i16)
+        B, n = clips.shape
+        dev = t.from_numpy(np.ascontiguousarray(clips, dtype=np.int16)).to(self.device)
+        caches = self.new_caches(B)
+        parts, pos = [], 0
+        while pos < n:
+            end = min(pos + chunk, n)
+            x = dev[:, pos:end]
+            if end - pos < WINDOW_LENGTH:
+                x = t.nn.functional.pad(x, (0, WINDOW_LENGTH - (end - pos)))
+            pr, caches = self.stream_run(x.contiguous(), caches)
+            parts.append(pr[:, 0, :])
+            pos = end
+        nvalid = valid_frame_count(n)
+        track = t.cat(parts, dim=1)[:, :nvalid].cpu().numpy() if parts else np.zeros((B, 0), np.float32)
+        out = [_vadpost.StreamVadPostprocessor(*post).process_batch(track[b]) for b in range(B)]
+        return (out, track) if return_probs else out
+
     def detect(self, clips_i16, pad_noise=None, post=(5, 0.4, 20, 2000, 20, 5, 0), return_probs=False):
         """Equal-length clips int16 [B,N] (host) -> per clip [(start_s, end_s)] for output channel 0
         (VAD driver :535-591).  pad_noise: standard-normal [B, >= pad] for the tail padding."""
@@ -90,6 +156,46 @@ class FireRedEngine:
         nfr = track.shape[1]     # min(valid frames, W*T): 10 s clips give 980 of the 998 snip-edge frames
         out = [pp.segments_to_seconds(segs[b, :counts[b]].tolist(), nfr, n / SAMPLE_RATE) for b in range(B)]
         return (out, track, dec) if return_probs else out
+
+
+IDX2EVENT = {0: "speech", 1: "singing", 2: "music"}      # Inference_FireRed_ONNX.py:632
+
+
+def _detect_events(self, clips_i16, pad_noise=None, thresholds=(0.4, 0.5, 0.5), post=(5, 20, 2000, 20, 5, 0),
+                   return_probs=False):
+    """FireRedAED driver (Inference_FireRed_ONNX.py:620-742): equal-length clips int16 [B,N] through an
+    odim == 3 model -> per clip (event2timestamps, event2ratio).  `post` = (smooth, min_event, max_event,
+    min_silence, merge_silence, extend); `thresholds` per event in IDX2EVENT order."""
+    if self.odim != len(IDX2EVENT):
+        raise ValueError(f"the AED driver needs a {len(IDX2EVENT)}-output model, this one has odim = {self.odim}")
+    clips = np.asarray(clips_i16)
+    B, n = clips.shape
+    rows = [pad_to_window_grid(clips[b], self.L, self.L, None if pad_noise is None else pad_noise[b]) for b in range(B)]
+    padded = np.stack(rows)
+    W = padded.shape[1] // self.L
+    probs = self.run(padded, W).view(B, W, self.odim, self.T)
+    nvalid = valid_frame_count(n)
+    tracks = probs.permute(0, 2, 1, 3).reshape(B, self.odim, W * self.T)[:, :, :nvalid].contiguous()
+    nfr = tracks.shape[2]
+    out = [({}, {}) for _ in range(B)]
+    for idx, event in IDX2EVENT.items():
+        thr = thresholds[idx]
+        pp = _vadpost.VadPostprocessor(post[0], thr, *post[1:], device=self.device)
+        track = tracks[:, idx, :].contiguous()
+        if nfr == 0:
+            for b in range(B):
+                out[b][0][event], out[b][1][event] = [], 0.0
+            continue
+        _, segs, counts = pp.process_batch(track)
+        segs, counts = segs.cpu().numpy(), counts.cpu().numpy()
+        ratio = (track >= np.float32(thr)).float().mean(dim=1).cpu().numpy()
+        for b in range(B):
+            out[b][0][event] = pp.segments_to_seconds(segs[b, :counts[b]].tolist(), nfr, n / SAMPLE_RATE)
+            out[b][1][event] = round(float(ratio[b]), 3)
+    return (out, tracks) if return_probs else out
+
+
+FireRedEngine.detect_events = _detect_events
 
 
 class FireRedSession:
@@ -118,3 +224,38 @@ class FireRedSession:
             raise ValueError(f"Got invalid dimensions for input: audio, expected last dim {self.engine.L}")
         probs = self.engine.run(audio.reshape(-1, audio.shape[-1])).cpu().numpy()
         return [probs]
+
+
+class FireRedStreamSession:
+    """Stream-VAD session look-alike: {'audio': int16 [1,1,n], 'caches_in': f32 [R,1,P,pad]} ->
+    [probs f32 [1,odim,T], caches_out] (FireRedVAD/Export_FireRedVAD.py:848-872; 'audio' axis 2 is dynamic).
+    The weights must have no look-ahead filter (cfg N2 == 0)."""
+
+    def __init__(self, weights=None, device="cuda:0"):
+        w = _weights.firered_synthetic(1234, dict(_weights.FIRERED_CFG, N2=0)) if weights is None else weights
+        self.engine = FireRedEngine(w, STREAM_CHUNK_SAMPLES, device)
+        e = self.engine
+        self._inputs_meta = [_Meta("audio", [1, 1, "audio_len"], "tensor(int16)"),
+                             _Meta("caches_in", list(e.cache_shape), "tensor(float)")]
+        self._outputs_meta = [_Meta("probs", [1, e.odim, "signal_len"], "tensor(float)"),
+                              _Meta("caches_out", list(e.cache_shape), "tensor(float)")]
+
+    def get_inputs(self):
+        return list(self._inputs_meta)
+
+    def get_outputs(self):
+        return list(self._outputs_meta)
+
+    def get_providers(self):
+        return ["VadxMI355XExecutionProvider"]
+
+    def run(self, output_names, feeds):
+        audio, caches = np.asarray(feeds["audio"]), np.asarray(feeds["caches_in"])
+        if audio.dtype != np.int16:
+            raise ValueError("Unexpected input data type. Actual: (%s) , expected: (tensor(int16))" % audio.dtype)
+        if caches.dtype != np.float32 or caches.shape != self.engine.cache_shape:
+            raise ValueError(f"Got invalid dimensions for input: caches_in, expected {list(self.engine.cache_shape)}")
+        t = self.engine.torch
+        probs, cout = self.engine.stream_run(audio.reshape(1, -1), t.from_numpy(np.ascontiguousarray(caches)))
+        outs = {"probs": probs.cpu().numpy(), "caches_out": cout.cpu().numpy()}
+        return [outs[k] for k in (output_names or ["probs", "caches_out"])]

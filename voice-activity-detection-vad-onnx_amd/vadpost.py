@@ -91,3 +91,98 @@ class VadPostprocessor:
         edges = np.diff(np.concatenate(([0], dec, [0])).astype(np.int8))
         starts, ends = np.flatnonzero(edges == 1), np.flatnonzero(edges == -1)
         return self.segments_to_seconds(list(zip(starts.tolist(), ends.tolist())), n, wav_dur)
+
+
+class StreamVadPostprocessor:
+    """Streaming (frame-by-frame, stateful) decision logic of FireRed Stream-VAD:
+    same constructor / `reset` / `process_batch` as FireRedVAD/Export_FireRedVAD.py:1161-1339.
+    Host Python like the reference: it is an O(frames) scalar state machine fed by the device probabilities."""
+
+    _SIL, _MAYBE_SP, _SP, _MAYBE_SIL = 0, 1, 2, 3
+
+    def __init__(self, smooth_window_size, speech_threshold, pad_start_frame, min_speech_frame,
+                 max_speech_frame, min_silence_frame, frames_per_second=100):
+        self.smooth_window_size = max(1, smooth_window_size)
+        self.speech_threshold = np.float32(speech_threshold)
+        self.pad_start_frame = max(self.smooth_window_size, pad_start_frame)
+        self.min_speech_frame, self.max_speech_frame = min_speech_frame, max_speech_frame
+        self.min_silence_frame = min_silence_frame
+        self.frames_per_second = frames_per_second
+        self._window_buf = np.zeros(self.smooth_window_size, dtype=np.float32)
+        self.reset()
+
+    def reset(self):
+        self._window_buf[:] = 0.0
+        self._window_sum = np.float32(0.0)
+        self._window_pos = self._window_count = 0
+        self.frame_cnt, self.state = 0, self._SIL
+        self.speech_cnt = self.silence_cnt = 0
+        self.hit_max_speech = False
+        self.last_speech_start_frame = self.last_speech_end_frame = -1
+
+    def _smooth(self, p):
+        if self.smooth_window_size <= 1:
+            return p
+        k = self._window_pos
+        self._window_sum += p - self._window_buf[k]
+        self._window_buf[k] = p
+        self._window_pos = (k + 1) % self.smooth_window_size
+        if self._window_count < self.smooth_window_size:
+            self._window_count += 1
+        return self._window_sum / self._window_count
+
+    def _close(self, fc):
+        """a segment ends at frame fc: returns its (start, end) and records the end"""
+        seg = (self.last_speech_start_frame, fc)
+        self.last_speech_start_frame, self.last_speech_end_frame = -1, fc
+        return seg
+
+    def process_batch(self, raw_probs):
+        probs = raw_probs if isinstance(raw_probs, np.ndarray) else np.asarray(raw_probs, dtype=np.float32)
+        if probs.shape[0] == 0:
+            return []
+        inv_fps = 1.0 / self.frames_per_second
+        found = []
+        for p in probs:
+            self.frame_cnt += 1
+            fc = self.frame_cnt
+            speech = self._smooth(p) >= self.speech_threshold
+            ended = None
+            if self.hit_max_speech:                      # a forced split re-opens a segment on the next frame
+                self.last_speech_start_frame, self.hit_max_speech = fc, False
+            st = self.state
+            if st == self._SIL:
+                if speech:
+                    self.state, self.speech_cnt = self._MAYBE_SP, 1
+                else:
+                    self.silence_cnt += 1
+                    self.speech_cnt = 0
+            elif st == self._MAYBE_SP:
+                if speech:
+                    self.speech_cnt += 1
+                    if self.speech_cnt >= self.min_speech_frame:
+                        self.state = self._SP
+                        self.last_speech_start_frame = max(1, fc - self.speech_cnt + 1 - self.pad_start_frame,
+                                                           self.last_speech_end_frame + 1)
+                        self.silence_cnt = 0
+                else:
+                    self.state, self.silence_cnt, self.speech_cnt = self._SIL, 1, 0
+            else:
+                self.speech_cnt += 1
+                if speech:
+                    self.state, self.silence_cnt = self._SP, 0
+                    if self.speech_cnt >= self.max_speech_frame:
+                        self.hit_max_speech, self.speech_cnt = True, 0
+                        ended = self._close(fc)
+                elif st == self._SP:
+                    self.state, self.silence_cnt = self._MAYBE_SIL, 1
+                else:
+                    self.silence_cnt += 1
+                    if self.silence_cnt >= self.min_silence_frame:
+                        self.state, self.speech_cnt = self._SIL, 0
+                        ended = self._close(fc)
+            if ended is not None and ended[0] > 0:
+                found.append((max(0, ended[0] - 1) * inv_fps, max(0, ended[1] - 1) * inv_fps))
+        if self.last_speech_start_frame > 0:             # unterminated segment at the end of the stream
+            found.append((max(0, self.last_speech_start_frame - 1) * inv_fps, (self.frame_cnt - 1) * inv_fps))
+        return found
