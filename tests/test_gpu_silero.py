@@ -58,6 +58,22 @@ def test_step_matches_oracle(engine, oracle_w, batch):
     np.testing.assert_allclose(st_n.cpu().numpy(), s_ref.numpy(), rtol=0, atol=ATOL)
 
 
+def test_step_with_asymmetric_basis_takes_dense_pass():
+    """The folded STFT pass needs the DFT's time symmetry; a basis without it (here: a perturbed table) must
+    be detected at pack time and go through the dense 258x256 pass, to the same tolerance."""
+    w = weights.silero_synthetic(1234)
+    rng = np.random.default_rng(77)
+    w["stft_basis"] = (w["stft_basis"] + 0.02 * rng.standard_normal(w["stft_basis"].shape)).astype(np.float32)
+    eng = silero.SileroEngine(w)
+    ow = {k: T(v) for k, v in w.items()}
+    x = (rng.standard_normal((19, 576)) * rng.uniform(0.001, 0.3, (19, 1))).astype(np.float32)
+    st = (rng.standard_normal((2, 19, 128)) * 0.5).astype(np.float32)
+    out, st_n = eng.step(x, st)
+    o_ref, s_ref = osil.net_forward(ow, T(x), T(st))
+    np.testing.assert_allclose(out.cpu().numpy(), o_ref.numpy(), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(st_n.cpu().numpy(), s_ref.numpy(), rtol=0, atol=ATOL)
+
+
 def test_step_rejects_bad_arguments(engine):
     with pytest.raises(ValueError):
         engine.step(np.zeros((2, 500), np.float32), np.zeros((2, 2, 128), np.float32))

@@ -21,9 +21,10 @@ namespace silero {
 // ---- packed weight blob (float offsets) -------------------------------------------------------
 constexpr int OFF_STFT = 0;                        // [8 waves][re16|im16][256]  (bins 0..127), k-permuted per 16
 constexpr int OFF_NYQ = OFF_STFT + 256 * 256;      // [2][256]                   (bin 128 re, im)
-constexpr int C1_KP = 144;                         // 129 input channels padded to 9 blocks of 16
-constexpr int OFF_C1 = OFF_NYQ + 2 * 256;          // [128][3][144]
-constexpr int OFF_B1 = OFF_C1 + 128 * 3 * C1_KP;   // [128]
+constexpr int C1_KP = 128;                         // input channels 0..127 on MFMA; channel 128 (Nyquist) on VALU
+constexpr int OFF_C1 = OFF_NYQ + 2 * 256;          // [128][3][128]
+constexpr int OFF_C1N = OFF_C1 + 128 * 3 * C1_KP;  // [128][4]  the three taps of input channel 128 (+1 pad)
+constexpr int OFF_B1 = OFF_C1N + 128 * 4;          // [128]
 constexpr int OFF_C2 = OFF_B1 + 128;               // [64][3][128]
 constexpr int OFF_B2 = OFF_C2 + 64 * 3 * 128;      // [64]
 constexpr int OFF_C3 = OFF_B2 + 64;                // [64][2][64]   taps 1,2 (tap 0 only sees padding)
@@ -35,20 +36,28 @@ constexpr int OFF_BG = OFF_IH + 512 * 128;         // [512] b_ih + b_hh
 constexpr int OFF_HH = OFF_BG + 512;               // [512][128]
 constexpr int OFF_DW = OFF_HH + 512 * 128;         // [128]
 constexpr int OFF_DB = OFF_DW + 128;               // [1] (+3 pad)
-constexpr int PACKED_FLOATS = OFF_DB + 4;
+// Folded STFT basis (used when the basis has the DFT's time symmetry, see pack_host): for n = 1..128
+// re rows hold (c[n] + c[256-n]) / 2, im rows (s[n] - s[256-n]) / 2 (n = 128: c[128] / 2 and 0), k-permuted per 16.
+constexpr int OFF_SF = OFF_DB + 4;                 // [8 waves][re16|im16][128]
+constexpr int OFF_S0 = OFF_SF + 256 * 128;         // [2][128]  the n = 0 column (re, im) of bins 0..127
+constexpr int OFF_FOLD = OFF_S0 + 256;             // [1] (+3 pad)  1.0 = folded pass valid
+constexpr int PACKED_FLOATS = OFF_FOLD + 4;
 
-// ---- encoder LDS map (floats): 80 256 B per workgroup => TWO workgroups per CU ---------------------
-// region 0: X  [16 clips][642]  raw windows in their global layout (row stride 642 = 2 mod 32: with the
-//              STFT's k permutation k = 16S + q + 4j the half-wave (clip i, q) hits bank 2i+q -> conflict free)
-//           then A1 [128 ch][4 frames x 16 (+4)]  conv1 output (X is dead after the STFT)
-// region 1: Mg [144 ch][4 frames x 16 (+4)]       |STFT|, k-major
-//           then A2 [64][2x16 (+4)], A3 [64][16 (+4)], A4 [128][16 (+4)]   (Mg is dead after conv1)
+// ---- encoder LDS map (floats): 50 304 B per workgroup => THREE workgroups per CU ------------------
+// One main region is reused by every phase; a phase whose output would overwrite its own input keeps the
+// result in registers across a barrier before storing it (STFT -> Mg, conv1 -> A1):
+//   main : X  [16 clips][642]  raw windows in their global layout (row stride 642 = 2 mod 32: with the
+//              STFT's k permutation the half-wave (clip i, q) hits bank 2i+q -> conflict free)
+//          -> Mg [129 ch][4 frames x 16 (+4)]  |STFT|, k-major
+//          -> A1 [128 ch][4 frames x 16 (+4)]  conv1 output
+//          -> A3 [64][16 (+4)], A4 [128][16 (+4)]   (A1 is dead after conv2)
+//   side : A2 [64][2x16 (+4)]                  conv2 output
 // Conv zero padding is never stored: taps that would read frame -1 / 4 are simply not issued.
 constexpr int X_LDM = 642;
 constexpr int MG_LD = 68, A1_LD = 68, A2_LD = 36, A3_LD = 20, A4_LD = 20;
-constexpr int R0_FLOATS = 16 * X_LDM;              // 10272  (A1: 128*68 = 8704)
-constexpr int R1_FLOATS = 144 * MG_LD;             //  9792  (A2+A3+A4 = 2304+1280+2560)
-constexpr int A2_OFF = 0, A3_OFF = 64 * A2_LD, A4_OFF = A3_OFF + 64 * A3_LD;
+constexpr int R0_FLOATS = 16 * X_LDM;              // 10272  (Mg: 129*68 = 8772, A1: 128*68 = 8704)
+constexpr int R1_FLOATS = 64 * A2_LD;              //  2304
+constexpr int A3_OFF = 0, A4_OFF = 64 * A3_LD;     // inside main
 constexpr int ENC_LDS_FLOATS = R0_FLOATS + R1_FLOATS;
 constexpr int ENC_THREADS = 512;
 
@@ -89,6 +98,41 @@ __device__ __forceinline__ void gemm_pass_mmajor(f32x4 (&acc)[NT][MT], const flo
     }
 }
 
+// Folded STFT pass.  A real DFT basis with a symmetric window obeys c[k][256-n] = c[k][n], s[k][256-n] = -s[k][n],
+// so  re = sum_{n=1..128} cF[n] (x[n] + x[256-n]),  im = sum_{n=1..127} sF[n] (x[n] - x[256-n])  (+ the n = 0 column,
+// preloaded into the accumulators by the caller): half the MFMAs of the dense pass for two extra VALU adds per
+// operand pair.  Contraction slot (block S, sub-step j, quarter q) <-> n = 16S + q + 4j + 1.
+__device__ __forceinline__ void stft_fold_pass(f32x4 (&are)[4], f32x4 (&aim)[4], const float *X, const float *wre,
+                                               const float *wim, int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    const float *af = X + i * X_LDM + q + 1;          // x[n]
+    const float *ar = X + i * X_LDM + 255 - q;        // x[256 - n]
+    f32x4 cre = *reinterpret_cast<const f32x4 *>(wre + 4 * q), cim = *reinterpret_cast<const f32x4 *>(wim + 4 * q);
+#pragma unroll 1
+    for (int S = 0; S < 8; ++S) {
+        const int Sn = (S + 1 < 8) ? S + 1 : S;
+        const f32x4 nre = *reinterpret_cast<const f32x4 *>(wre + 16 * Sn + 4 * q);
+        const f32x4 nim = *reinterpret_cast<const f32x4 *>(wim + 16 * Sn + 4 * q);
+        const float *pf = af + 16 * S, *pr = ar - 16 * S;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float e[4], o[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const float a = pf[4 * j + 128 * f], b = pr[128 * f - 4 * j];
+                e[f] = a + b;
+                o[f] = a - b;
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) are[f] = mfma16(e[f], cre[j], are[f]);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) aim[f] = mfma16(o[f], cim[j], aim[f]);
+        }
+        cre = nre;
+        cim = nim;
+    }
+}
+
 // k-major pass that accumulates into acc[0][A0 .. A0+MT) of a wider accumulator array
 template <int MT, int KB, int A0, int AN>
 __device__ __forceinline__ void gemm_pass_sub(f32x4 (&acc)[1][AN], const float *act, int lda, const int (&moff)[MT],
@@ -111,14 +155,13 @@ __device__ __forceinline__ void gemm_pass_sub(f32x4 (&acc)[1][AN], const float *
     }
 }
 
-__global__ __launch_bounds__(ENC_THREADS, 4) void silero_encode_kernel(
+__global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
     const float *__restrict__ P, const float *__restrict__ audio, long long n_samples,
     long long row_stride, long long origin, int B, int G, int T, float *__restrict__ gx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *X = lds;                 // phase 0-1
-    float *A1 = lds;                // phase 2-3 (aliases X)
-    float *Mg = lds + R0_FLOATS;    // phase 1-2
-    float *A2 = Mg + A2_OFF, *A3 = Mg + A3_OFF, *A4 = Mg + A4_OFF;      // phase 3-6 (alias Mg)
+    float *X = lds, *Mg = lds, *A1 = lds;          // main region, one tenant per phase
+    float *A3 = lds + A3_OFF, *A4 = lds + A4_OFF;
+    float *A2 = lds + R0_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, i = lane & 15;
@@ -155,28 +198,34 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void silero_encode_kernel(
                 }
             }
         }
-        for (int e = tid; e < 15 * MG_LD; e += ENC_THREADS) Mg[129 * MG_LD + e] = 0.f;     // K padding rows 129..143
     }
     __syncthreads();
 
     // ---------------- phase 1: STFT conv (bins 0..127 on MFMA, bin 128 on VALU) -> magnitude
     {
         f32x4 acc[2][4];
+        if (P[OFF_FOLD] != 0.f) {      // uniform: the basis has the DFT time symmetry -> folded pass (half the MFMAs)
+            const float c0 = P[OFF_S0 + wave * 16 + i], s0 = P[OFF_S0 + 128 + wave * 16 + i];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float *const wrow[2] = {P + OFF_STFT + (wave * 32 + i) * 256,
-                                      P + OFF_STFT + (wave * 32 + 16 + i) * 256};
-        const int koff[4] = {0, 128, 256, 384};
-        gemm_pass_mmajor<2, 4, 16>(acc, X, X_LDM, koff, wrow, lane);
+                for (int r = 0; r < 4; ++r) {
+                    const float x0 = X[(4 * q + r) * X_LDM + 128 * f];
+                    acc[0][f][r] = c0 * x0;
+                    acc[1][f][r] = s0 * x0;
+                }
+            stft_fold_pass(acc[0], acc[1], X, P + OFF_SF + (wave * 32 + i) * 128, P + OFF_SF + (wave * 32 + 16 + i) * 128, lane);
+        } else {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            f32x4 m;
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m[r] = sqrtf(acc[0][f][r] * acc[0][f][r] + acc[1][f][r] * acc[1][f][r]);
-            *reinterpret_cast<f32x4 *>(&Mg[(wave * 16 + i) * MG_LD + f * 16 + 4 * q]) = m;
+                for (int f = 0; f < 4; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *const wrow[2] = {P + OFF_STFT + (wave * 32 + i) * 256,
+                                          P + OFF_STFT + (wave * 32 + 16 + i) * 256};
+            const int koff[4] = {0, 128, 256, 384};
+            gemm_pass_mmajor<2, 4, 16>(acc, X, X_LDM, koff, wrow, lane);
         }
+        float nyq = 0.f;
         if (wave < 4) {   // Nyquist bin: frame f = wave, lane = (clip i, k-quarter q)
             const int f = wave;
             const float *nre = P + OFF_NYQ + q * 64, *nim = P + OFF_NYQ + 256 + q * 64;
@@ -190,24 +239,45 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void silero_encode_kernel(
             }
             sre += __shfl_xor(sre, 16); sre += __shfl_xor(sre, 32);
             sim += __shfl_xor(sim, 16); sim += __shfl_xor(sim, 32);
-            if (q == 0) Mg[128 * MG_LD + f * 16 + i] = sqrtf(sre * sre + sim * sim);
+            nyq = sqrtf(sre * sre + sim * sim);
         }
+        __syncthreads();          // every wave is done reading X: Mg may now overwrite it
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            f32x4 m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = sqrtf(acc[0][f][r] * acc[0][f][r] + acc[1][f][r] * acc[1][f][r]);
+            *reinterpret_cast<f32x4 *>(&Mg[(wave * 16 + i) * MG_LD + f * 16 + 4 * q]) = m;
+        }
+        if (wave < 4 && q == 0) Mg[128 * MG_LD + wave * 16 + i] = nyq;
     }
     __syncthreads();
 
     // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU (taps on frame -1 / 4 are skipped)
     {
         f32x4 acc[1][4];
+        {   // input channel 128 (the Nyquist bin) on VALU: acc[f] = sum_tap w[tap] * Mg[128][f + tap - 1]
+            const f32x4 wn = *reinterpret_cast<const f32x4 *>(P + OFF_C1N + (wave * 16 + i) * 4);
+            f32x4 mg[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) acc[0][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < 4; ++f) mg[f] = *reinterpret_cast<const f32x4 *>(&Mg[128 * MG_LD + f * 16 + 4 * q]);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                f32x4 v = mg[f] * wn[1];
+                if (f > 0) v += mg[f - 1] * wn[0];
+                if (f < 3) v += mg[f + 1] * wn[2];
+                acc[0][f] = v;
+            }
+        }
         const float *w0 = P + OFF_C1 + (wave * 16 + i) * 3 * C1_KP;
         {   const int moff[3] = {0, 16, 32};          // tap 0: out frames 1..3 read in frames 0..2
-            gemm_pass_sub<3, 9, 1, 4>(acc, Mg, MG_LD, moff, w0, lane); }
+            gemm_pass_sub<3, 8, 1, 4>(acc, Mg, MG_LD, moff, w0, lane); }
         {   const int moff[4] = {0, 16, 32, 48};      // tap 1: out frames 0..3 read in frames 0..3
-            gemm_pass_sub<4, 9, 0, 4>(acc, Mg, MG_LD, moff, w0 + C1_KP, lane); }
+            gemm_pass_sub<4, 8, 0, 4>(acc, Mg, MG_LD, moff, w0 + C1_KP, lane); }
         {   const int moff[3] = {16, 32, 48};         // tap 2: out frames 0..2 read in frames 1..3
-            gemm_pass_sub<3, 9, 0, 4>(acc, Mg, MG_LD, moff, w0 + 2 * C1_KP, lane); }
+            gemm_pass_sub<3, 8, 0, 4>(acc, Mg, MG_LD, moff, w0 + 2 * C1_KP, lane); }
         const float bias = P[OFF_B1 + wave * 16 + i];
+        __syncthreads();          // every wave is done reading Mg: A1 may now overwrite it
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             f32x4 v;
@@ -541,10 +611,45 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
                                 w->stft_basis[(size_t)(part * 129 + wv * 16 + i) * 256 + 16 * S + qq + 4 * j];
     memcpy(p + OFF_NYQ, w->stft_basis + (size_t)128 * 256, 256 * sizeof(float));
     memcpy(p + OFF_NYQ + 256, w->stft_basis + (size_t)257 * 256, 256 * sizeof(float));
+    {   // folded basis: valid when c[k][256-n] == c[k][n] and s[k][256-n] == -s[k][n] (n = 1..127) and s[k][128] == 0
+        // up to f32 rounding of the table (1e-6 of the largest entry), which every windowed real-DFT basis satisfies
+        const float *re = w->stft_basis, *im = w->stft_basis + (size_t)129 * 256;
+        float amax = 0.f, dev = 0.f;
+        for (size_t e = 0; e < (size_t)258 * 256; ++e) amax = fmaxf(amax, fabsf(w->stft_basis[e]));
+        for (int k = 0; k < 128; ++k) {
+            for (int n = 1; n < 128; ++n) {
+                dev = fmaxf(dev, fabsf(re[k * 256 + n] - re[k * 256 + 256 - n]));
+                dev = fmaxf(dev, fabsf(im[k * 256 + n] + im[k * 256 + 256 - n]));
+            }
+            dev = fmaxf(dev, fabsf(im[k * 256 + 128]));
+        }
+        const bool fold = dev <= 1e-6f * amax;
+        p[OFF_FOLD] = fold ? 1.f : 0.f;
+        if (fold) {
+            for (int wv = 0; wv < 8; ++wv)
+                for (int part = 0; part < 2; ++part)
+                    for (int i = 0; i < 16; ++i) {
+                        const float *row = (part ? im : re) + (size_t)(wv * 16 + i) * 256;
+                        float *dst = p + OFF_SF + (size_t)(wv * 32 + part * 16 + i) * 128;
+                        for (int S = 0; S < 8; ++S)
+                            for (int qq = 0; qq < 4; ++qq)
+                                for (int j = 0; j < 4; ++j) {
+                                    const int n = 16 * S + qq + 4 * j + 1;
+                                    float v;
+                                    if (n == 128) v = part ? 0.f : 0.5f * row[128];        // x[128] is added to itself
+                                    else v = part ? 0.5f * (row[n] - row[256 - n]) : 0.5f * (row[n] + row[256 - n]);
+                                    dst[16 * S + 4 * qq + j] = v;
+                                }
+                        p[OFF_S0 + part * 128 + wv * 16 + i] = row[0];
+                    }
+        }
+    }
     for (int co = 0; co < 128; ++co)
-        for (int kk = 0; kk < 3; ++kk)
-            for (int ci = 0; ci < 129; ++ci)
+        for (int kk = 0; kk < 3; ++kk) {
+            for (int ci = 0; ci < 128; ++ci)
                 p[OFF_C1 + ((size_t)co * 3 + kk) * C1_KP + ci] = w->enc_w[0][((size_t)co * 129 + ci) * 3 + kk];
+            p[OFF_C1N + co * 4 + kk] = w->enc_w[0][((size_t)co * 129 + 128) * 3 + kk];
+        }
     memcpy(p + OFF_B1, w->enc_b[0], 128 * sizeof(float));
     for (int co = 0; co < 64; ++co)
         for (int kk = 0; kk < 3; ++kk)
