@@ -1,0 +1,85 @@
+"""Encoder what-if timing (development aid, not part of the product or the tests).
+
+build : python tools/exp_encoder.py build 0 1 2 ...   -> voice-activity-detection-vad-onnx_amd/_exp/libvadx_expN.so
+        (silero.hip compiled with -DVADX_EXP=N; the variants skip or alter parts of silero_encode_kernel, so their
+        RESULTS ARE WRONG on purpose -- only the kernel time is of interest)
+run   : python tools/exp_encoder.py run 0 1 2 ...     (on the GPU box) -> one line per variant with the mean
+        silero_encode_kernel time at the bench shape.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "voice-activity-detection-vad-onnx_amd")
+EXP = os.path.join(PKG, "_exp")
+SRC = ["capi.hip", "silero.hip"]
+
+
+def build(ids):
+    os.makedirs(EXP, exist_ok=True)
+    for n in ids:
+        out = os.path.join(EXP, f"libvadx_exp{n}.so")
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-DVADX_EXP={n}"]
+        cmd += [os.path.join(PKG, "csrc", s) for s in SRC] + ["-o", out]
+        subprocess.check_call(cmd)
+        print("built", out)
+
+
+CHILD = r"""
+import ctypes as C, os, sys, torch
+sys.path.insert(0, %r)
+import vadx
+from vadx import _lib, silero, weights
+import bench
+h = C.CDLL(os.environ["VADX_LIBRARY"])
+B, T, N = 4096, 313, 160000
+w = weights.silero_synthetic(1234)
+# minimal binding: only the symbols this library has
+h.vadx_silero_packed_floats.restype = C.c_size_t
+h.vadx_silero_workspace_bytes.restype = C.c_size_t
+h.vadx_silero_workspace_bytes.argtypes = [C.c_int, C.c_int]
+h.vadx_last_error.restype = C.c_char_p
+import numpy as np
+hw = _lib.SileroWeightsHost()
+keep = []
+def ptr(a):
+    a = np.ascontiguousarray(a, dtype=np.float32); keep.append(a); return a.ctypes.data
+hw.stft_basis = ptr(w["stft_basis"])
+for k in range(4):
+    hw.enc_w[k] = ptr(w[f"enc{k}_w"]); hw.enc_b[k] = ptr(w[f"enc{k}_b"])
+hw.lstm_w_ih, hw.lstm_w_hh, hw.lstm_b_ih, hw.lstm_b_hh = (ptr(w[k]) for k in ("lstm_w_ih", "lstm_w_hh", "lstm_b_ih", "lstm_b_hh"))
+hw.dec_w, hw.dec_b = ptr(w["dec_w"]), ptr(w["dec_b"])
+packed = np.zeros(h.vadx_silero_packed_floats(), np.float32)
+assert h.vadx_silero_pack_host(C.byref(hw), C.c_void_p(packed.ctypes.data)) == 0
+pk = torch.from_numpy(packed).cuda()
+audio = bench.synth_batch(torch, torch.device("cuda:0"), B, N, 1234)
+nws = h.vadx_silero_workspace_bytes(B, T)
+ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+h.vadx_silero_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_size_t, C.c_void_p]
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def enc():
+    rc = h.vadx_silero_encode(pk.data_ptr(), audio.data_ptr(), B, N, audio.stride(0), ws.data_ptr(), nws, st)
+    assert rc == 0, h.vadx_last_error()
+for _ in range(2): enc()
+torch.cuda.synchronize()
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+for a, b in ev:
+    a.record(); enc(); b.record()
+torch.cuda.synchronize()
+ts = [a.elapsed_time(b) for a, b in ev]
+print("EXP", os.path.basename(os.environ["VADX_LIBRARY"]), "encode ms mean %%.3f min %%.3f" %% (sum(ts) / len(ts), min(ts)))
+"""
+
+
+def run(ids):
+    for n in ids:
+        env = dict(os.environ, VADX_LIBRARY=os.path.join(EXP, f"libvadx_exp{n}.so"))
+        r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("EXP")]
+        print(line[0] if line else f"EXP {n} FAILED rc={r.returncode}\n{r.stderr[-800:]}", flush=True)
+
+
+if __name__ == "__main__":
+    ids = [int(a) for a in sys.argv[2:]]
+    {"build": build, "run": run}[sys.argv[1]](ids)

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvadx.so")
+LIB_PATH = os.environ.get("VADX_LIBRARY") or os.path.join(HERE, "libvadx.so")     # override: a differently built libvadx
 
 
 class VadxError(RuntimeError):

@@ -15,30 +15,45 @@
 #include <math.h>
 #include <string.h>
 
+// VADX_EXP: development-only what-if switches for tools/exp_encoder.py (results are wrong when set).
+#ifndef VADX_EXP
+#define VADX_EXP 0
+#endif
+#define ENC_SKIP(n) (VADX_EXP == (n))
+#if VADX_EXP == 2
+#define ENC_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define ENC_SYNC() __syncthreads()
+#endif
+
 namespace vadx {
 namespace silero {
 
 // ---- packed weight blob (float offsets) -------------------------------------------------------
+// Encoder GEMM weights are stored FRAGMENT-MAJOR: [16-row tile][16-k block S][lane = 16q+i][4], i.e. exactly the
+// f32x4 each lane feeds to the four MFMAs of block S (row 16*tile+i, k = 16S+4q+j).  One wave-wide load is then
+// one contiguous 1 KB run (8 full cache lines) instead of 16 half-used lines of a row-major matrix.
+constexpr int FRAG = 256;                          // floats per (tile, block)
 constexpr int OFF_STFT = 0;                        // [8 waves][re16|im16][256]  (bins 0..127), k-permuted per 16
 constexpr int OFF_NYQ = OFF_STFT + 256 * 256;      // [2][256]                   (bin 128 re, im)
 constexpr int C1_KP = 128;                         // input channels 0..127 on MFMA; channel 128 (Nyquist) on VALU
-constexpr int OFF_C1 = OFF_NYQ + 2 * 256;          // [128][3][128]
+constexpr int OFF_C1 = OFF_NYQ + 2 * 256;          // [8 oc tiles][3 taps][8 blocks][FRAG]
 constexpr int OFF_C1N = OFF_C1 + 128 * 3 * C1_KP;  // [128][4]  the three taps of input channel 128 (+1 pad)
 constexpr int OFF_B1 = OFF_C1N + 128 * 4;          // [128]
-constexpr int OFF_C2 = OFF_B1 + 128;               // [64][3][128]
+constexpr int OFF_C2 = OFF_B1 + 128;               // [4 oc tiles][3 taps x 8 blocks][FRAG]
 constexpr int OFF_B2 = OFF_C2 + 64 * 3 * 128;      // [64]
-constexpr int OFF_C3 = OFF_B2 + 64;                // [64][2][64]   taps 1,2 (tap 0 only sees padding)
+constexpr int OFF_C3 = OFF_B2 + 64;                // [4 oc tiles][2 taps x 4 blocks][FRAG]  taps 1,2 (tap 0 only sees padding)
 constexpr int OFF_B3 = OFF_C3 + 64 * 2 * 64;       // [64]
-constexpr int OFF_C4 = OFF_B3 + 64;                // [128][64]     tap 1 only
+constexpr int OFF_C4 = OFF_B3 + 64;                // [8 oc tiles][4 blocks][FRAG]  tap 1 only
 constexpr int OFF_B4 = OFF_C4 + 128 * 64;          // [128]
-constexpr int OFF_IH = OFF_B4 + 128;               // [512][128]
+constexpr int OFF_IH = OFF_B4 + 128;               // [4 gates][8 unit tiles][8 blocks][FRAG]
 constexpr int OFF_BG = OFF_IH + 512 * 128;         // [512] b_ih + b_hh
 constexpr int OFF_HH = OFF_BG + 512;               // [512][128]
 constexpr int OFF_DW = OFF_HH + 512 * 128;         // [128]
 constexpr int OFF_DB = OFF_DW + 128;               // [1] (+3 pad)
 // Folded STFT basis (used when the basis has the DFT's time symmetry, see pack_host): for n = 1..128
 // re rows hold (c[n] + c[256-n]) / 2, im rows (s[n] - s[256-n]) / 2 (n = 128: c[128] / 2 and 0), k-permuted per 16.
-constexpr int OFF_SF = OFF_DB + 4;                 // [8 waves][re16|im16][128]
+constexpr int OFF_SF = OFF_DB + 4;                 // [8 waves][re|im][8 blocks][FRAG]
 constexpr int OFF_S0 = OFF_SF + 256 * 128;         // [2][128]  the n = 0 column (re, im) of bins 0..127
 constexpr int OFF_FOLD = OFF_S0 + 256;             // [1] (+3 pad)  1.0 = folded pass valid
 constexpr int PACKED_FLOATS = OFF_FOLD + 4;
@@ -107,12 +122,12 @@ __device__ __forceinline__ void stft_fold_pass(f32x4 (&are)[4], f32x4 (&aim)[4],
     const int q = lane >> 4, i = lane & 15;
     const float *af = X + i * X_LDM + q + 1;          // x[n]
     const float *ar = X + i * X_LDM + 255 - q;        // x[256 - n]
-    f32x4 cre = *reinterpret_cast<const f32x4 *>(wre + 4 * q), cim = *reinterpret_cast<const f32x4 *>(wim + 4 * q);
+    f32x4 cre = *reinterpret_cast<const f32x4 *>(wre), cim = *reinterpret_cast<const f32x4 *>(wim);
 #pragma unroll 1
     for (int S = 0; S < 8; ++S) {
         const int Sn = (S + 1 < 8) ? S + 1 : S;
-        const f32x4 nre = *reinterpret_cast<const f32x4 *>(wre + 16 * Sn + 4 * q);
-        const f32x4 nim = *reinterpret_cast<const f32x4 *>(wim + 16 * Sn + 4 * q);
+        const f32x4 nre = *reinterpret_cast<const f32x4 *>(wre + FRAG * Sn);
+        const f32x4 nim = *reinterpret_cast<const f32x4 *>(wim + FRAG * Sn);
         const float *pf = af + 16 * S, *pr = ar - 16 * S;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -139,11 +154,11 @@ __device__ __forceinline__ void gemm_pass_sub(f32x4 (&acc)[1][AN], const float *
                                               const float *wrow, int lane) {
     const int q = lane >> 4, i = lane & 15;
     const float *ap = act + (4 * q) * lda + i;
-    f32x4 wcur = *reinterpret_cast<const f32x4 *>(wrow + 4 * q), wnxt;
+    f32x4 wcur = *reinterpret_cast<const f32x4 *>(wrow), wnxt;
 #pragma unroll 1
     for (int S = 0; S < KB; ++S) {
         const int Sn = (S + 1 < KB) ? S + 1 : S;
-        wnxt = *reinterpret_cast<const f32x4 *>(wrow + 16 * Sn + 4 * q);
+        wnxt = *reinterpret_cast<const f32x4 *>(wrow + FRAG * Sn);
         const float *aps = ap + 16 * S * lda;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -153,6 +168,41 @@ __device__ __forceinline__ void gemm_pass_sub(f32x4 (&acc)[1][AN], const float *
         }
         wcur = wnxt;
     }
+}
+
+// Single-tile chain (one 16x16 output tile per wave, K = 16*NB): the weights of blocks B0..NB-1 sit contiguously in
+// this lane's row; activations for block b come from column offset coff(b) and k-row 16*(b % KPB).  With one MFMA
+// per ds_read there is nothing to hide an L2 round trip behind, so the weight stream runs DEPTH blocks ahead, and
+// two accumulators alternate so consecutive MFMAs are independent (32- instead of 40-cycle cadence).
+template <int B0, int NB, int KPB, int DEPTH, typename ColOff>
+__device__ __forceinline__ f32x4 gemm_chain(const float *act, int lda, const float *wrow, int lane, ColOff coff) {
+    const int q = lane >> 4, i = lane & 15;
+    const float *ap = act + (4 * q) * lda + i;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 w[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (B0 + d < NB) w[d] = *reinterpret_cast<const f32x4 *>(wrow + FRAG * (B0 + d));
+    float a[2][4];
+    auto fetch_act = [&](int b, float (&dst)[4]) {
+        const float *aps = ap + 16 * (b % KPB) * lda + coff(b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = aps[j * lda];
+    };
+    fetch_act(B0, a[0]);
+#pragma unroll
+    for (int b = B0; b < NB; ++b) {
+        const f32x4 wc = w[(b - B0) % DEPTH];
+        if (b + DEPTH < NB) w[(b - B0) % DEPTH] = *reinterpret_cast<const f32x4 *>(wrow + FRAG * (b + DEPTH));
+        if (b + 1 < NB) fetch_act(b + 1, a[(b - B0 + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);          // requests above stay ahead of this block's MFMAs; bounded registers
+        const float (&ac)[4] = a[(b - B0) & 1];
+        acc0 = mfma16(ac[0], wc[0], acc0);
+        acc1 = mfma16(ac[1], wc[1], acc1);
+        acc0 = mfma16(ac[2], wc[2], acc0);
+        acc1 = mfma16(ac[3], wc[3], acc1);
+    }
+    return acc0 + acc1;
 }
 
 __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
@@ -181,7 +231,9 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                 const float *src = audio + (bvalid ? b : 0) * row_stride;
                 const long long idx = base + p;
                 float v[4];
-                if (bvalid && vec_ok && idx >= 0 && idx + 3 < n_samples) {
+                if (ENC_SKIP(1)) {
+                    v[0] = v[1] = v[2] = v[3] = 1e-3f * (float)(p & 63);
+                } else if (bvalid && vec_ok && idx >= 0 && idx + 3 < n_samples) {
                     const f32x4 x4 = *reinterpret_cast<const f32x4 *>(src + idx);
                     v[0] = x4[0]; v[1] = x4[1]; v[2] = x4[2]; v[3] = x4[3];
                 } else {
@@ -199,7 +251,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             }
         }
     }
-    __syncthreads();
+    ENC_SYNC();
 
     // ---------------- phase 1: STFT conv (bins 0..127 on MFMA, bin 128 on VALU) -> magnitude
     {
@@ -214,7 +266,8 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                     acc[0][f][r] = c0 * x0;
                     acc[1][f][r] = s0 * x0;
                 }
-            stft_fold_pass(acc[0], acc[1], X, P + OFF_SF + (wave * 32 + i) * 128, P + OFF_SF + (wave * 32 + 16 + i) * 128, lane);
+            if (!ENC_SKIP(4)) stft_fold_pass(acc[0], acc[1], X, P + OFF_SF + (wave * 2 + 0) * 8 * FRAG + lane * 4,
+                                              P + OFF_SF + (wave * 2 + 1) * 8 * FRAG + lane * 4, lane);
         } else {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -226,7 +279,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             gemm_pass_mmajor<2, 4, 16>(acc, X, X_LDM, koff, wrow, lane);
         }
         float nyq = 0.f;
-        if (wave < 4) {   // Nyquist bin: frame f = wave, lane = (clip i, k-quarter q)
+        if (wave < 4 && !ENC_SKIP(7)) {   // Nyquist bin: frame f = wave, lane = (clip i, k-quarter q)
             const int f = wave;
             const float *nre = P + OFF_NYQ + q * 64, *nim = P + OFF_NYQ + 256 + q * 64;
             const float *xp = X + i * X_LDM + 128 * f + q * 64;
@@ -241,7 +294,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             sim += __shfl_xor(sim, 16); sim += __shfl_xor(sim, 32);
             nyq = sqrtf(sre * sre + sim * sim);
         }
-        __syncthreads();          // every wave is done reading X: Mg may now overwrite it
+        ENC_SYNC();          // every wave is done reading X: Mg may now overwrite it
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             f32x4 m;
@@ -251,7 +304,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
         }
         if (wave < 4 && q == 0) Mg[128 * MG_LD + wave * 16 + i] = nyq;
     }
-    __syncthreads();
+    ENC_SYNC();
 
     // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU (taps on frame -1 / 4 are skipped)
     {
@@ -269,15 +322,17 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                 acc[0][f] = v;
             }
         }
-        const float *w0 = P + OFF_C1 + (wave * 16 + i) * 3 * C1_KP;
+        const float *w0 = P + OFF_C1 + wave * 3 * 8 * FRAG + lane * 4;      // [oc tile][tap][8 blocks]
+        if (!ENC_SKIP(5)) {
         {   const int moff[3] = {0, 16, 32};          // tap 0: out frames 1..3 read in frames 0..2
             gemm_pass_sub<3, 8, 1, 4>(acc, Mg, MG_LD, moff, w0, lane); }
         {   const int moff[4] = {0, 16, 32, 48};      // tap 1: out frames 0..3 read in frames 0..3
-            gemm_pass_sub<4, 8, 0, 4>(acc, Mg, MG_LD, moff, w0 + C1_KP, lane); }
+            gemm_pass_sub<4, 8, 0, 4>(acc, Mg, MG_LD, moff, w0 + 8 * FRAG, lane); }
         {   const int moff[3] = {16, 32, 48};         // tap 2: out frames 0..2 read in frames 1..3
-            gemm_pass_sub<3, 8, 0, 4>(acc, Mg, MG_LD, moff, w0 + 2 * C1_KP, lane); }
+            gemm_pass_sub<3, 8, 0, 4>(acc, Mg, MG_LD, moff, w0 + 16 * FRAG, lane); }
+        }
         const float bias = P[OFF_B1 + wave * 16 + i];
-        __syncthreads();          // every wave is done reading Mg: A1 may now overwrite it
+        ENC_SYNC();          // every wave is done reading Mg: A1 may now overwrite it
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             f32x4 v;
@@ -286,53 +341,47 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             *reinterpret_cast<f32x4 *>(&A1[(wave * 16 + i) * A1_LD + f * 16 + 4 * q]) = v;
         }
     }
-    __syncthreads();
+    ENC_SYNC();
 
     // ---------------- phase 3: conv2 128->64, k3 s2 p1, ReLU (out frame fp reads in frames 2fp-1..2fp+1)
     {
         const int nt = wave & 3, fp = wave >> 2;
-        f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-        const float *w0 = P + OFF_C2 + (nt * 16 + i) * 3 * 128;
-        for (int kk = (fp == 0 ? 1 : 0); kk < 3; ++kk) {
-            const int moff[1] = {(2 * fp + kk - 1) * 16};
-            gemm_pass_sub<1, 8, 0, 1>(acc, A1, A1_LD, moff, w0 + kk * 128, lane);
-        }
+        const float *w0 = P + OFF_C2 + nt * 24 * FRAG + lane * 4;      // [oc tile][tap*8 + S]: 24 blocks of 16 k
+        f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+        if (ENC_SKIP(3)) {} else
+        if (fp == 0) a2 = gemm_chain<8, 24, 8, 4>(A1, A1_LD, w0, lane, [](int b) { return (b / 8 - 1) * 16; });
+        else a2 = gemm_chain<0, 24, 8, 4>(A1, A1_LD, w0, lane, [](int b) { return (b / 8 + 1) * 16; });
         const float bias = P[OFF_B2 + nt * 16 + i];
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[0][0][r] + bias, 0.f);
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(a2[r] + bias, 0.f);
         *reinterpret_cast<f32x4 *>(&A2[(nt * 16 + i) * A2_LD + fp * 16 + 4 * q]) = v;
     }
-    __syncthreads();
+    ENC_SYNC();
 
     // ---------------- phase 4: conv3 64->64, k3 s2 p1, ReLU (1 out frame; tap 0 reads padding)
     if (wave < 4) {
-        f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int moff[1] = {ps * 16};
-            gemm_pass_sub<1, 4, 0, 1>(acc, A2, A2_LD, moff, P + OFF_C3 + ((wave * 16 + i) * 2 + ps) * 64, lane);
-        }
+        // [2 taps][64] contiguous: 8 blocks; tap ps reads A2 frame ps
+        const f32x4 a3 = ENC_SKIP(3) ? f32x4{0.f, 0.f, 0.f, 0.f} : gemm_chain<0, 8, 4, 4>(A2, A2_LD, P + OFF_C3 + wave * 8 * FRAG + lane * 4, lane,
+                                                [](int b) { return (b / 4) * 16; });
         const float bias = P[OFF_B3 + wave * 16 + i];
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[0][0][r] + bias, 0.f);
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(a3[r] + bias, 0.f);
         *reinterpret_cast<f32x4 *>(&A3[(wave * 16 + i) * A3_LD + 4 * q]) = v;
     }
-    __syncthreads();
+    ENC_SYNC();
 
     // ---------------- phase 5: conv4 64->128, k3 s1 p1, ReLU (1 frame in/out; centre tap only)
     {
-        f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-        const int moff[1] = {0};
-        gemm_pass_sub<1, 4, 0, 1>(acc, A3, A3_LD, moff, P + OFF_C4 + (wave * 16 + i) * 64, lane);
+        const f32x4 a4 = ENC_SKIP(3) ? f32x4{0.f, 0.f, 0.f, 0.f} : gemm_chain<0, 4, 4, 4>(A3, A3_LD, P + OFF_C4 + wave * 4 * FRAG + lane * 4, lane, [](int) { return 0; });
         const float bias = P[OFF_B4 + wave * 16 + i];
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[0][0][r] + bias, 0.f);
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(a4[r] + bias, 0.f);
         *reinterpret_cast<f32x4 *>(&A4[(wave * 16 + i) * A4_LD + 4 * q]) = v;
     }
-    __syncthreads();
+    ENC_SYNC();
 
     // ---------------- phase 6: LSTM input projection, gate-major (D rows = hidden units)
     {
@@ -340,12 +389,29 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             acc[g][0] = *reinterpret_cast<const f32x4 *>(P + OFF_BG + g * 128 + wave * 16 + 4 * q);
-        const float *const wrow[4] = {P + OFF_IH + (0 * 128 + wave * 16 + i) * 128,
-                                      P + OFF_IH + (1 * 128 + wave * 16 + i) * 128,
-                                      P + OFF_IH + (2 * 128 + wave * 16 + i) * 128,
-                                      P + OFF_IH + (3 * 128 + wave * 16 + i) * 128};
-        const int moff[1] = {0};
-        gemm_pass<4, 1, 8, true>(acc, A4, A4_LD, moff, wrow, lane);
+        if (!ENC_SKIP(6)) {        // W_ih tiles [gate][wave][8 blocks]; D rows = hidden units (gate-major for the LSTM kernel)
+            const float *wl = P + OFF_IH + wave * 8 * FRAG + lane * 4;
+            const float *ap = A4 + (4 * q) * A4_LD + i;
+            f32x4 wcur[4], wnxt[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wcur[g] = *reinterpret_cast<const f32x4 *>(wl + g * 64 * FRAG);
+#pragma unroll 2
+            for (int S = 0; S < 8; ++S) {
+                const int Sn = (S + 1 < 8) ? S + 1 : S;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) wnxt[g] = *reinterpret_cast<const f32x4 *>(wl + g * 64 * FRAG + Sn * FRAG);
+                __builtin_amdgcn_sched_barrier(0);
+                const float *aps = ap + 16 * S * A4_LD;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float av = aps[j * A4_LD];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g][0] = mfma16(wcur[g][j], av, acc[g][0]);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) wcur[g] = wnxt[g];
+            }
+        }
         float *dst = gx + ((size_t)t * G + grp) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = acc[g][0];
@@ -630,7 +696,7 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
                 for (int part = 0; part < 2; ++part)
                     for (int i = 0; i < 16; ++i) {
                         const float *row = (part ? im : re) + (size_t)(wv * 16 + i) * 256;
-                        float *dst = p + OFF_SF + (size_t)(wv * 32 + part * 16 + i) * 128;
+                        float *dst = p + OFF_SF + (size_t)(wv * 2 + part) * 8 * FRAG;
                         for (int S = 0; S < 8; ++S)
                             for (int qq = 0; qq < 4; ++qq)
                                 for (int j = 0; j < 4; ++j) {
@@ -638,33 +704,37 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
                                     float v;
                                     if (n == 128) v = part ? 0.f : 0.5f * row[128];        // x[128] is added to itself
                                     else v = part ? 0.5f * (row[n] - row[256 - n]) : 0.5f * (row[n] + row[256 - n]);
-                                    dst[16 * S + 4 * qq + j] = v;
+                                    dst[(S * 64 + qq * 16 + i) * 4 + j] = v;
                                 }
                         p[OFF_S0 + part * 128 + wv * 16 + i] = row[0];
                     }
         }
     }
+    // fragment-major slot of element (row i of its tile, contraction index k) inside a tile that starts at `base`
+    auto frag = [](size_t base, int i, int k) { return base + ((size_t)(k / 16) * 64 + ((k % 16) / 4) * 16 + i) * 4 + (k % 4); };
     for (int co = 0; co < 128; ++co)
         for (int kk = 0; kk < 3; ++kk) {
             for (int ci = 0; ci < 128; ++ci)
-                p[OFF_C1 + ((size_t)co * 3 + kk) * C1_KP + ci] = w->enc_w[0][((size_t)co * 129 + ci) * 3 + kk];
+                p[frag(OFF_C1 + (size_t)((co / 16) * 3 + kk) * 8 * FRAG, co % 16, ci)] = w->enc_w[0][((size_t)co * 129 + ci) * 3 + kk];
             p[OFF_C1N + co * 4 + kk] = w->enc_w[0][((size_t)co * 129 + 128) * 3 + kk];
         }
     memcpy(p + OFF_B1, w->enc_b[0], 128 * sizeof(float));
     for (int co = 0; co < 64; ++co)
         for (int kk = 0; kk < 3; ++kk)
             for (int ci = 0; ci < 128; ++ci)
-                p[OFF_C2 + ((size_t)co * 3 + kk) * 128 + ci] = w->enc_w[1][((size_t)co * 128 + ci) * 3 + kk];
+                p[frag(OFF_C2 + (size_t)(co / 16) * 24 * FRAG, co % 16, kk * 128 + ci)] = w->enc_w[1][((size_t)co * 128 + ci) * 3 + kk];
     memcpy(p + OFF_B2, w->enc_b[1], 64 * sizeof(float));
     for (int co = 0; co < 64; ++co)
         for (int ps = 0; ps < 2; ++ps)
             for (int ci = 0; ci < 64; ++ci)
-                p[OFF_C3 + ((size_t)co * 2 + ps) * 64 + ci] = w->enc_w[2][((size_t)co * 64 + ci) * 3 + (ps + 1)];
+                p[frag(OFF_C3 + (size_t)(co / 16) * 8 * FRAG, co % 16, ps * 64 + ci)] = w->enc_w[2][((size_t)co * 64 + ci) * 3 + (ps + 1)];
     memcpy(p + OFF_B3, w->enc_b[2], 64 * sizeof(float));
     for (int co = 0; co < 128; ++co)
-        for (int ci = 0; ci < 64; ++ci) p[OFF_C4 + (size_t)co * 64 + ci] = w->enc_w[3][((size_t)co * 64 + ci) * 3 + 1];
+        for (int ci = 0; ci < 64; ++ci)
+            p[frag(OFF_C4 + (size_t)(co / 16) * 4 * FRAG, co % 16, ci)] = w->enc_w[3][((size_t)co * 64 + ci) * 3 + 1];
     memcpy(p + OFF_B4, w->enc_b[3], 128 * sizeof(float));
-    memcpy(p + OFF_IH, w->lstm_w_ih, 512 * 128 * sizeof(float));
+    for (int r = 0; r < 512; ++r)          // row r = gate*128 + unit; tile = gate*8 + unit/16
+        for (int k = 0; k < 128; ++k) p[frag(OFF_IH + (size_t)(r / 16) * 8 * FRAG, r % 16, k)] = w->lstm_w_ih[(size_t)r * 128 + k];
     for (int r = 0; r < 512; ++r) p[OFF_BG + r] = w->lstm_b_ih[r] + w->lstm_b_hh[r];
     memcpy(p + OFF_HH, w->lstm_w_hh, 512 * 128 * sizeof(float));
     memcpy(p + OFF_DW, w->dec_w, 128 * sizeof(float));
