@@ -419,6 +419,12 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
 }
 
 // ---- persistent LSTM --------------------------------------------------------------------------
+// Gate non-linearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): the recurrent step is
+// a serial chain MFMA -> gates -> LDS -> barrier, so libm's branchy expf/tanhf (~140 VALU instructions per unit)
+// sat directly on the critical path of all 313 steps.  |error| < 3e-7 per gate, far inside the 1e-4 score bar.
+__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
 constexpr int HS_LD = 136;                       // h [16 clips][128] (+8 pad: conflict-free b128)
 constexpr int LSTM_LDS_FLOATS = 2 * 16 * HS_LD + 2 * 8 * 16;
 constexpr int LSTM_THREADS = 512;
@@ -485,10 +491,10 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void silero_lstm_kernel(
         float dpart = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
-            const float gg = tanhf(acc[2][r]), og = sigmoidf_(acc[3][r]);
+            const float ig = gate_sigmoid(acc[0][r]), fg = gate_sigmoid(acc[1][r]);
+            const float gg = gate_tanh(acc[2][r]), og = gate_sigmoid(acc[3][r]);
             c[r] = fg * c[r] + ig * gg;
-            h[r] = og * tanhf(c[r]);
+            h[r] = og * gate_tanh(c[r]);
             dpart = fmaf(dw[r], fmaxf(h[r], 0.f), dpart);
         }
         const int nxt = cur ^ 1;
