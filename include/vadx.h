@@ -339,8 +339,18 @@ int vadx_dfsmn_vote(const float *vad, int batch, int windows, int frames, int lo
 /* ---------------------------------------------------------------------------------------------
  * Test hooks (used by tests/ only)
  * ------------------------------------------------------------------------------------------- */
+/* Weight layout of every GEMM operand the kernels stream from L2 ("fragment-major"): a row-major
+ * [rows][cols] matrix, zero-padded to multiples of 16 both ways, stored as
+ * [rows/16 tiles][cols/16 blocks][64 lanes][4]: the float4 of (tile, block S, lane 16q+i) holds
+ * W[16*tile + i][16*S + 4*q + 0..3], so one wave-wide load is one contiguous 1 KB run.  The *_pack_host
+ * functions produce it themselves; entry points that take bare weight pointers (vadx_sepconv_block's
+ * pw_w / res_w, vadx_dfsmn_mask_weights' linear1_w / fsmn_linear_w / fsmn_project_w, vadx_test_gemm's w)
+ * expect buffers converted with this helper.  dst holds vadx_frag_major_floats(rows, cols) floats. */
+size_t vadx_frag_major_floats(int rows, int cols);
+int vadx_frag_major_host(const float *src, int rows, int cols, float *dst);
+
 /* C[M][N] = A[M][K] * W[N][K]^T through the same LDS/MFMA tile helper the nets use.
- * M multiple of 16 (<=64), N multiple of 16, K multiple of 16. */
+ * M multiple of 16 (<=64), N multiple of 16, K multiple of 16; w fragment-major. */
 int vadx_test_gemm(const float *a, const float *w, float *c, int m, int n, int k, int swap, void *stream);
 
 #ifdef __cplusplus

@@ -50,8 +50,17 @@ def test_pack_host_layout(lib):
     assert np.array_equal(stft[3, 1, 5], w["stft_basis"][129 + 3 * 16 + 5][perm])
     nyq = p[65536:65536 + 512].reshape(2, 256)
     assert np.array_equal(nyq[0], w["stft_basis"][128]) and np.array_equal(nyq[1], w["stft_basis"][257])
-    c1 = p[66048:66048 + 128 * 3 * 144].reshape(128, 3, 144)
-    assert np.array_equal(c1[7, 2, :129], w["enc0_w"][7, :, 2]) and not c1[:, :, 129:].any()
+    # conv1 (input channels 0..127) is fragment-major: [8 oc tiles][3 taps][8 blocks][64 lanes][4]
+    c1 = p[66048:66048 + 128 * 3 * 128].reshape(8, 3, 8, 4, 16, 4)          # tile, tap, S, q, i, j
+    rows = c1.transpose(0, 4, 1, 2, 3, 5).reshape(128, 3, 128)              # -> [oc][tap][k = 16S + 4q + j]
+    assert np.array_equal(rows[7, 2], w["enc0_w"][7, :128, 2]) and np.array_equal(rows[100, 0], w["enc0_w"][100, :128, 0])
+    c1n = p[66048 + 128 * 3 * 128:66048 + 128 * 3 * 128 + 512].reshape(128, 4)   # Nyquist input channel, 3 taps (+pad)
+    assert np.array_equal(c1n[:, :3], w["enc0_w"][:, 128, :]) and not c1n[:, 3].any()
+    # the generic helper produces the same layout
+    a = np.arange(20 * 37, dtype=np.float32).reshape(20, 37)
+    fm = _lib.frag_major(a).reshape(2, 3, 4, 16, 4)                         # tile, S, q, i, j  (32 x 48 padded)
+    back = fm.transpose(0, 3, 1, 2, 4).reshape(32, 48)
+    assert np.array_equal(back[:20, :37], a) and not back[20:].any() and not back[:, 37:].any()
     # NULL pointer -> EINVAL with a message
     assert lib.vadx_silero_pack_host(None, p.ctypes.data) == -1
     assert b"NULL" in lib.vadx_last_error()

@@ -38,7 +38,7 @@ def test_mfma_tile_helper(m, n, k, swap):
     rng = np.random.default_rng(m * 1000 + n * 10 + k + swap)
     a = rng.standard_normal((m, k)).astype(np.float32)          # asymmetric, catches transposes
     w = rng.standard_normal((n, k)).astype(np.float32)
-    da, dw = T(a).cuda(), T(w).cuda()
+    da, dw = T(a).cuda(), T(_lib.frag_major(w)).cuda()        # weights in the kernels' fragment-major layout
     dc = torch.zeros((m, n), dtype=torch.float32, device="cuda")
     _lib.check(_lib.lib().vadx_test_gemm(da.data_ptr(), dw.data_ptr(), dc.data_ptr(), m, n, k, swap, _lib.stream_ptr()))
     torch.cuda.synchronize()

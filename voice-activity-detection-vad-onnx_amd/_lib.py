@@ -117,6 +117,8 @@ SIGNATURES = {
     "vadx_firered_packed_floats": (_Z, [C.POINTER(FireRedCfg)]),
     "vadx_firered_pack_host": (_I, [C.POINTER(FireRedCfg), C.POINTER(FireRedWeightsHost), _P]),
     "vadx_firered_run": (_I, [C.POINTER(FireRedCfg), _P, _P, _I, _P, _P]),
+    "vadx_frag_major_floats": (C.c_size_t, [_I, _I]),
+    "vadx_frag_major_host": (_I, [_P, _I, _I, _P]),
     "vadx_firered_stream_run": (_I, [C.POINTER(FireRedCfg), _P, _P, _I, _P, _P, _P, _P]),
     "vadx_vadpost_workspace_bytes": (_Z, [_I, _I]),
     "vadx_vadpost": (_I, [C.POINTER(VadPostParams), _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
@@ -162,6 +164,18 @@ def check(rc, exc=VadxError):
     if rc != 0:
         msg = lib().vadx_last_error().decode("utf-8", "replace")
         raise (ValueError if rc == -1 else exc)(msg or f"libvadx error {rc}")
+
+
+def frag_major(a):
+    """row-major float32 [rows][cols] -> the fragment-major buffer (1-D, zero-padded to multiples of 16)
+    the GEMM kernels stream their weights from (include/vadx.h: vadx_frag_major_host)."""
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError("frag_major expects a 2-D matrix")
+    out = np.empty(lib().vadx_frag_major_floats(a.shape[0], a.shape[1]), dtype=np.float32)
+    check(lib().vadx_frag_major_host(a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data))
+    return out
 
 
 def require_gpu():

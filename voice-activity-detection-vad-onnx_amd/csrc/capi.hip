@@ -1,4 +1,4 @@
-// capi.hip -- error plumbing shared by every libvadx entry point.
+// capi.hip -- error plumbing and the weight-layout helper shared by every libvadx entry point.
 #include "common.h"
 
 namespace vadx {
@@ -14,3 +14,18 @@ void set_error(const char *fmt, ...) {
 
 extern "C" int vadx_abi_version(void) { return 1; }
 extern "C" const char *vadx_last_error(void) { return vadx::g_err; }
+
+extern "C" size_t vadx_frag_major_floats(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (size_t)((rows + 15) & ~15) * (size_t)((cols + 15) & ~15);
+}
+
+extern "C" int vadx_frag_major_host(const float *src, int rows, int cols, float *dst) {
+    VADX_REQUIRE(src && dst && rows > 0 && cols > 0, "vadx_frag_major_host: bad argument");
+    const int ldw = (cols + 15) & ~15;
+    const size_t n = vadx_frag_major_floats(rows, cols);
+    for (size_t e = 0; e < n; ++e) dst[e] = 0.f;
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < cols; ++k) dst[vadx::frag_index(ldw, r, k)] = src[(size_t)r * cols + k];
+    return VADX_OK;
+}

@@ -42,14 +42,40 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 //   ACT lives in LDS "k-major": element (k, col) at act[k*lda + col]; for m-tile mt this lane's
 //       column is moff[mt] + (lane & 15).  lda % 8 == 4 makes the ds_read_b32 pattern below
 //       bank-conflict free (rows 4 apart land 16 banks apart).
-//   W   lives in global/L2, K contiguous: wrow[nt] points at THIS LANE's row (tile row lane&15),
-//       16-byte aligned.  Each lane pulls 16 B = 4 consecutive k per block, so the k consumed
-//       by (block S, sub-step j, lane quarter q) is 16*S + 4*q + j  -- a fixed permutation of
-//       the contraction index applied to both operands.
+//   W   lives in global/L2 FRAGMENT-MAJOR: a [N][K] matrix (N, K multiples of 16) is stored as
+//       [N/16 tiles][K/16 blocks][64 lanes][4], the f32x4 of (tile, block S, lane 16q+i) holding
+//       W[16*tile + i][16S + 4q + j], j = 0..3 -- exactly what that lane feeds to the 4 MFMAs of block S,
+//       so a wave-wide weight load is ONE contiguous 1 KB run (8 full cache lines; a row-major
+//       matrix costs 16 half-used lines per load, which made the L1/L2 path the limiter).
+//       wrow[nt] = tile base + 4*lane (+ FRAG per 16 k of column offset); tile nt of a matrix with
+//       leading dimension ldw starts at W + nt*16*ldw (same footprint as row-major).  The k consumed
+//       by (block S, sub-step j, lane quarter q) is 16*S + 4*q + j -- a fixed permutation of the
+//       contraction index applied to both operands.
 //   SWAP=false: D rows = ACT columns (m), D cols = W rows (n)   -> next layer's k-major LDS
 //   SWAP=true : D rows = W rows (n),      D cols = ACT columns  -> e.g. gate-major LSTM input
 // Weights for block S+1 are requested before block S's MFMAs issue (L2 latency hiding).
 // ---------------------------------------------------------------------------------------------
+constexpr int FRAG = 256;     // floats per (16-row tile, 16-k block) fragment
+
+// this lane's pointer into tile `tile` of a fragment-major matrix with leading dimension ldw, at k offset k0
+__device__ __forceinline__ const float *frag_ptr(const float *W, int ldw, int tile, int k0, int lane) {
+    return W + (size_t)tile * 16 * ldw + (size_t)k0 * 16 + lane * 4;
+}
+
+// host: element (row r, column k) of a fragment-major [rows][ldw] matrix
+inline size_t frag_index(int ldw, int r, int k) {
+    return (size_t)(r / 16) * 16 * ldw + (size_t)(k / 16) * FRAG + (size_t)(((k % 16) / 4) * 16 + (r % 16)) * 4 + (k % 4);
+}
+
+// host: convert a row-major [rows][ldw] block (rows, ldw multiples of 16) to fragment-major in place
+inline void frag_major_inplace(float *w, int rows, int ldw) {
+    float *tmp = new float[(size_t)rows * ldw];
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < ldw; ++k) tmp[frag_index(ldw, r, k)] = w[(size_t)r * ldw + k];
+    for (size_t e = 0; e < (size_t)rows * ldw; ++e) w[e] = tmp[e];
+    delete[] tmp;
+}
+
 template <int NT, int MT, int KB, bool SWAP>
 __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NT][MT], const float *act, int lda,
                                           const int (&moff)[MT], const float *const (&wrow)[NT],
@@ -58,13 +84,13 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NT][MT], const float *act
     const float *ap = act + (4 * q) * lda + i;
     f32x4 wcur[NT], wnxt[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 4 * q);
+    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt]);
 #pragma unroll 2
     for (int S = 0; S < KB; ++S) {
         const int Sn = (S + 1 < KB) ? S + 1 : S;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
+            wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + FRAG * Sn);
         __builtin_amdgcn_sched_barrier(0);      // keep the next block's weight loads ahead of this block's MFMAs
         const float *aps = ap + 16 * S * lda;
 #pragma unroll
@@ -102,7 +128,7 @@ __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, 
     float a0[4][MT], a1[4][MT];
     auto fetch = [&](int S, f32x4 (&w)[NT], float (&a)[4][MT]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * S + 4 * q);
+        for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + FRAG * S);
         const float *aps = ap + 16 * S * lda;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -154,11 +180,11 @@ __device__ __forceinline__ void gemm_rt_simple(f32x4 (&acc)[NT][MT], const float
     const float *ap = act + (4 * q) * lda + i;
     f32x4 wcur[NT], wnxt[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 4 * q);
+    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt]);
     for (int S = 0; S < kb; ++S) {
         const int Sn = (S + 1 < kb) ? S + 1 : S;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
+        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + FRAG * Sn);
         const float *aps = ap + 16 * S * lda;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -427,6 +427,14 @@ extern "C" int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_fi
         memcpy(p + d.off_dnnb[m], w->dnn_b[m], d.H * sizeof(float));
     }
     mat(d.off_out, w->out_w, d.odim, d.H, d.Hp); memcpy(p + d.off_outb, w->out_b, d.odim * sizeof(float));
+    // GEMM operands go fragment-major (common.h); the FIR taps and the tiny output head stay row-major (VALU)
+    vadx::frag_major_inplace(p + d.off_fc1, d.Hp, NMEL);
+    vadx::frag_major_inplace(p + d.off_fc2, d.Pp, d.Hp);
+    for (int r = 1; r < d.R; ++r) {
+        vadx::frag_major_inplace(p + d.off_bfc1[r], d.Hp, d.Pp);
+        vadx::frag_major_inplace(p + d.off_bfc2[r], d.Pp, d.Hp);
+    }
+    for (int m = 0; m < d.M; ++m) vadx::frag_major_inplace(p + d.off_dnn[m], d.Hp, m == 0 ? d.Pp : d.Hp);
     return VADX_OK;
 }
 

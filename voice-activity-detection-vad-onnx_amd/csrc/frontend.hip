@@ -130,10 +130,10 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float *re_row = P + d.off_dft + (size_t)(bt * 32 + i) * d.Kp;
-        const float *im_row = re_row + (size_t)16 * d.Kp;
+        const float *re_row = vadx::frag_ptr(P + d.off_dft, d.Kp, bt * 2, 0, lane);      // tiles: [bt][re | im]
+        const float *im_row = vadx::frag_ptr(P + d.off_dft, d.Kp, bt * 2 + 1, 0, lane);
         for (int a = 0; a < d.passes; ++a) {
-            const float *const wrow[2] = {re_row + d.pass_koff[a], im_row + d.pass_koff[a]};
+            const float *const wrow[2] = {re_row + d.pass_koff[a] * 16, im_row + d.pass_koff[a] * 16};
             int moff[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16 + a;
@@ -189,7 +189,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int lo = d.mel_kb_lo[mtile], hi = d.mel_kb_hi[mtile];
-        const float *const wrow[1] = {P + d.off_mel + (size_t)(mtile * 16 + i) * d.Fp + lo * 16};
+        const float *const wrow[1] = {vadx::frag_ptr(P + d.off_mel, d.Fp, mtile, lo * 16, lane)};
         int moff[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16;
@@ -321,6 +321,9 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
         mel_kb[2 * mt] = lo;
         mel_kb[2 * mt + 1] = hi;
     }
+    // GEMM operands go fragment-major (common.h); the Nyquist rows stay row-major (VALU)
+    vadx::frag_major_inplace(packed_host + d.off_dft, d.nbt * 32, d.Kp);
+    vadx::frag_major_inplace(packed_host + d.off_mel, d.n_mels, d.Fp);
     return VADX_OK;
 }
 

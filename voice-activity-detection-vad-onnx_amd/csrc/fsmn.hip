@@ -355,6 +355,15 @@ extern "C" int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_w
     }
     mat(d.off_out1, w->out1_w, d.A2, d.L, d.Lp); memcpy(p + d.off_bo1, w->out1_b, d.A2 * sizeof(float));
     mat(d.off_out2, w->out2_w, d.O, d.A2, d.A2p); memcpy(p + d.off_bo2, w->out2_b, d.O * sizeof(float));
+    // GEMM operands go fragment-major (common.h): one contiguous 1 KB run per wave-wide weight load
+    vadx::frag_major_inplace(p + d.off_in1, d.Ap, 400);
+    vadx::frag_major_inplace(p + d.off_in2, d.Lp, d.Ap);
+    for (int l = 0; l < NLAYER; ++l) {
+        vadx::frag_major_inplace(p + d.off_lin[l], PROJ, d.Lp);
+        vadx::frag_major_inplace(p + d.off_aff[l], d.Lp, PROJ);
+    }
+    vadx::frag_major_inplace(p + d.off_out1, d.A2p, d.Lp);
+    vadx::frag_major_inplace(p + d.off_out2, d.Op, d.A2p);
     return VADX_OK;
 }
 

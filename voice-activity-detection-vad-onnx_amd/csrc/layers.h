@@ -7,7 +7,7 @@ namespace vadx {
 constexpr int LAYER_NW = 8;   // waves per workgroup assumed by layer<>
 
 struct LayerArgs {
-    const float *W; int ldw, ntiles;
+    const float *W; int ldw, ntiles;      // W fragment-major (common.h), ldw = its padded K
     int npass, kb, kstep, cstep;          // K passes: weights advance kstep floats, act columns cstep
     const float *bias; int relu;
     const float *act; int lda, acol0;
@@ -25,9 +25,9 @@ __device__ __forceinline__ void layer(const LayerArgs &a) {
             f32x4 acc[1][MTT];
 #pragma unroll
             for (int mt = 0; mt < MTT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float *row = a.W + (size_t)(nt * 16 + i) * a.ldw;
+            const float *row = frag_ptr(a.W, a.ldw, nt, 0, lane);
             for (int ps = 0; ps < a.npass; ++ps) {
-                const float *const wrow[1] = {row + ps * a.kstep};
+                const float *const wrow[1] = {row + ps * a.kstep * 16};
                 int moff[MTT];
 #pragma unroll
                 for (int mt = 0; mt < MTT; ++mt) moff[mt] = a.acol0 + mt * 16 + ps * a.cstep;
@@ -47,9 +47,9 @@ __device__ __forceinline__ void layer(const LayerArgs &a) {
         for (int item = wave; item < a.ntiles * MTT; item += LAYER_NW) {
             const int nt = item / MTT, mt = item - nt * MTT;
             f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-            const float *row = a.W + (size_t)(nt * 16 + i) * a.ldw;
+            const float *row = frag_ptr(a.W, a.ldw, nt, 0, lane);
             for (int ps = 0; ps < a.npass; ++ps) {
-                const float *const wrow[1] = {row + ps * a.kstep};
+                const float *const wrow[1] = {row + ps * a.kstep * 16};
                 const int moff[1] = {a.acol0 + mt * 16 + ps * a.cstep};
                 gemm_rt<1, 1, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
                                              AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);

@@ -33,7 +33,6 @@ namespace silero {
 // Encoder GEMM weights are stored FRAGMENT-MAJOR: [16-row tile][16-k block S][lane = 16q+i][4], i.e. exactly the
 // f32x4 each lane feeds to the four MFMAs of block S (row 16*tile+i, k = 16S+4q+j).  One wave-wide load is then
 // one contiguous 1 KB run (8 full cache lines) instead of 16 half-used lines of a row-major matrix.
-constexpr int FRAG = 256;                          // floats per (tile, block)
 constexpr int OFF_STFT = 0;                        // [8 waves][re16|im16][256]  (bins 0..127), k-permuted per 16
 constexpr int OFF_NYQ = OFF_STFT + 256 * 256;      // [2][256]                   (bin 128 re, im)
 constexpr int C1_KP = 128;                         // input channels 0..127 on MFMA; channel 128 (Nyquist) on VALU
@@ -627,7 +626,7 @@ __global__ void silero_segments_kernel(const float *__restrict__ probs, int B, i
     counts[b] = ns;
 }
 
-// ---- test hook: C = A * W^T through gemm_pass ---------------------------------------------------
+// ---- test hook: C = A * W^T through gemm_pass (W fragment-major, see vadx_frag_major_host) ---------------------------------------------------
 __global__ void test_gemm_kernel(const float *A, const float *W, float *C, int M, int N, int K, int swap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lda = M + 4;                        // M in {16,32,48,64}: (M+4) % 8 == 4
@@ -641,10 +640,10 @@ __global__ void test_gemm_kernel(const float *A, const float *W, float *C, int M
     for (int nt = wave; nt < N / 16; nt += nw) {
         for (int mt = 0; mt < M / 16; ++mt) {
             f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-            const float *const wrow[1] = {W + (size_t)(nt * 16 + i) * K};
+            const float *const wrow[1] = {frag_ptr(W, K, nt, 0, lane)};
             const int moff[1] = {mt * 16};
             for (int kb = 0; kb < K / 16; ++kb) {
-                const float *const wr[1] = {wrow[0] + kb * 16};
+                const float *const wr[1] = {wrow[0] + kb * FRAG};
                 if (swap) gemm_pass<1, 1, 1, true>(acc, lds + kb * 16 * lda, lda, moff, wr, lane);
                 else gemm_pass<1, 1, 1, false>(acc, lds + kb * 16 * lda, lda, moff, wr, lane);
             }
@@ -663,6 +662,7 @@ __global__ void test_gemm_kernel(const float *A, const float *W, float *C, int M
 // C ABI
 // =================================================================================================
 using namespace vadx::silero;
+using vadx::FRAG;
 
 extern "C" size_t vadx_silero_packed_floats(void) { return (size_t)PACKED_FLOATS; }
 

@@ -240,20 +240,20 @@ class DfsmnEngine:
         mw.hidden, mw.fsmn_hidden, mw.layers, mw.lorder = m["hidden"], m["fsmn_hidden"], m["layers"], m["lorder"]
         self._mask_keep = []
 
-        def mdev(a, pad_axes=()):
+        def mdev(a, pad_axes=(), frag=False):
             a = np.asarray(a, dtype=np.float32)
             pads = [(0, (-a.shape[ax]) % 16 if ax in pad_axes else 0) for ax in range(a.ndim)]
-            d_ = dev(np.pad(a, pads))
+            d_ = dev(_lib.frag_major(a) if frag else np.pad(a, pads))       # GEMM operands: fragment-major
             self._mask_keep.append(d_)
             return d_.data_ptr()
         shift = w["mask.shift"] + np.float32(np.log(np.float32(32768.0 ** 2)))      # wrapper __init__ :291
         mw.shift, mw.scale = mdev(shift), mdev(w["mask.scale"])
-        mw.linear1_w, mw.linear1_b = mdev(w["mask.linear1.weight"], (0,)), mdev(w["mask.linear1.bias"], (0,))
+        mw.linear1_w, mw.linear1_b = mdev(w["mask.linear1.weight"], frag=True), mdev(w["mask.linear1.bias"], (0,))
         mw.linear3_w, mw.linear3_b = mdev(w["mask.linear3.weight"].reshape(-1)), mdev(w["mask.linear3.bias"])
         for l in range(m["layers"]):
-            mw.fsmn_linear_w[l] = mdev(w[f"mask.deepfsmn.{l}.linear.weight"], (0, 1))
+            mw.fsmn_linear_w[l] = mdev(w[f"mask.deepfsmn.{l}.linear.weight"], frag=True)
             mw.fsmn_linear_b[l] = mdev(w[f"mask.deepfsmn.{l}.linear.bias"], (0,))
-            mw.fsmn_project_w[l] = mdev(w[f"mask.deepfsmn.{l}.project.weight"], (0, 1))
+            mw.fsmn_project_w[l] = mdev(w[f"mask.deepfsmn.{l}.project.weight"], frag=True)
             mw.fsmn_conv_w[l] = mdev(w[f"mask.deepfsmn.{l}.conv1.weight"][:, 0, :, 0])
         self.mask = mw
 

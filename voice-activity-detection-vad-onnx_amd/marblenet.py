@@ -46,12 +46,12 @@ class MarbleNetEngine:
                                           w[p + "_mean"], w[p + "_var"], eps)
                 last = r == rep - 1
                 cfg = _lib.SepConvCfg(cin, filt, k, stride, dil, 1 if sep else 0, block_cin if (residual and last) else 0, 1)
-                st = {"cfg": cfg, "dw": dev(w[p + "_dw"]) if sep else None, "pw": dev(_pad16(pw[:, :, 0], (0, 1))),
+                st = {"cfg": cfg, "dw": dev(w[p + "_dw"]) if sep else None, "pw": dev(_lib.frag_major(pw[:, :, 0])),
                       "pb": dev(_pad16(pb, (0,))), "rw": None, "rb": None, "first": r == 0, "res": residual and last}
                 if residual and last:
                     rw, rb = _weights.fold_bn(np.asarray(w[f"b{bi}res_pw"])[:, :, None], None, w[f"b{bi}res_gamma"],
                                               w[f"b{bi}res_beta"], w[f"b{bi}res_mean"], w[f"b{bi}res_var"], eps)
-                    st["rw"], st["rb"] = dev(_pad16(rw[:, :, 0], (0, 1))), dev(_pad16(rb, (0,)))
+                    st["rw"], st["rb"] = dev(_lib.frag_major(rw[:, :, 0])), dev(_pad16(rb, (0,)))
                 self.stages.append(st)
                 cin = filt
         self.cout = cin
