@@ -41,9 +41,9 @@ MAC_HH = 512 * 128
 FLOP_ENCODE = 2 * (MAC_STFT + MAC_CONV1 + MAC_CONV2 + MAC_CONV3 + MAC_CONV4 + MAC_IH)
 FLOP_RECUR = 2 * MAC_HH
 # What the encoder kernel actually issues per 16-window tile: v_mfma_f32_16x16x4 counts per phase
-# (folded STFT 2048, conv1 2560, conv2 640, conv3 128, conv4 128, W_ih 1024), 2048 flop each.  Lower than the
-# algorithmic count because the DFT's time symmetry halves the STFT contraction (DESIGN.md "Silero path").
-MFMA_PER_TILE = 2048 + 2560 + 640 + 128 + 128 + 1024
+# (folded STFT 1024, conv1 2560, conv2 640, conv3 128, conv4 128, W_ih 1024), 2048 flop each.  Lower than the
+# dense count because the DFT's time and frequency symmetries quarter the STFT contraction (DESIGN.md "Silero path").
+MFMA_PER_TILE = 1024 + 2560 + 640 + 128 + 128 + 1024
 FLOP_ENCODE_ISSUED = MFMA_PER_TILE * 2048 // 16
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = f32 vector rate
 

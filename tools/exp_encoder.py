@@ -1,7 +1,8 @@
 """Encoder what-if timing (development aid, not part of the product or the tests).
 
 build : python tools/exp_encoder.py build 0 1 2 ...   -> voice-activity-detection-vad-onnx_amd/_exp/libvadx_expN.so
-        (silero.hip compiled with -DVADX_EXP=N; the variants skip or alter parts of silero_encode_kernel, so their
+        (silero.hip compiled with -DVADX_EXP=N, N a BIT MASK of switches (bit 1 no global loads, 2 no barriers, 3 no conv2-4,
+        4 no STFT pass, 5 no conv1, 6 no W_ih, 7 no Nyquist bin, 8 no gx stores; LSTM kernel: 9 no gate non-linearities, 10 no per-step barrier, 11 no gx loads, 12 no probs reduce); the variants skip or alter parts of silero_encode_kernel, so their
         RESULTS ARE WRONG on purpose -- only the kernel time is of interest)
 run   : python tools/exp_encoder.py run 0 1 2 ...     (on the GPU box) -> one line per variant with the mean
         silero_encode_kernel time at the bench shape.
@@ -61,14 +62,23 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def enc():
     rc = h.vadx_silero_encode(pk.data_ptr(), audio.data_ptr(), B, N, audio.stride(0), ws.data_ptr(), nws, st)
     assert rc == 0, h.vadx_last_error()
-for _ in range(2): enc()
+h.vadx_silero_recur.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+probs = torch.empty((B, T), dtype=torch.float32, device="cuda")
+def rec():
+    rc = h.vadx_silero_recur(pk.data_ptr(), ws.data_ptr(), nws, B, T, None, probs.data_ptr(), None, st)
+    assert rc == 0, h.vadx_last_error()
+for _ in range(2): enc(); rec()
 torch.cuda.synchronize()
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
 for a, b in ev:
     a.record(); enc(); b.record()
 torch.cuda.synchronize()
 ts = [a.elapsed_time(b) for a, b in ev]
-print("EXP", os.path.basename(os.environ["VADX_LIBRARY"]), "encode ms mean %%.3f min %%.3f" %% (sum(ts) / len(ts), min(ts)))
+for a, b in ev:
+    a.record(); rec(); b.record()
+torch.cuda.synchronize()
+tr = [a.elapsed_time(b) for a, b in ev]
+print("EXP", os.path.basename(os.environ["VADX_LIBRARY"]), "encode ms mean %%.3f min %%.3f | recur ms mean %%.3f min %%.3f" %% (sum(ts) / len(ts), min(ts), sum(tr) / len(tr), min(tr)))
 """
 
 

@@ -19,8 +19,8 @@
 #ifndef VADX_EXP
 #define VADX_EXP 0
 #endif
-#define ENC_SKIP(n) (VADX_EXP == (n))
-#if VADX_EXP == 2
+#define ENC_SKIP(n) ((VADX_EXP >> (n)) & 1)          // VADX_EXP is a bit mask of what-if switches
+#if (VADX_EXP >> 2) & 1
 #define ENC_SYNC() __builtin_amdgcn_wave_barrier()
 #else
 #define ENC_SYNC() __syncthreads()
@@ -50,11 +50,12 @@ constexpr int OFF_BG = OFF_IH + 512 * 128;         // [512] b_ih + b_hh
 constexpr int OFF_HH = OFF_BG + 512;               // [512][128]
 constexpr int OFF_DW = OFF_HH + 512 * 128;         // [128]
 constexpr int OFF_DB = OFF_DW + 128;               // [1] (+3 pad)
-// Folded STFT basis (used when the basis has the DFT's time symmetry, see pack_host): for n = 1..128
-// re rows hold (c[n] + c[256-n]) / 2, im rows (s[n] - s[256-n]) / 2 (n = 128: c[128] / 2 and 0), k-permuted per 16.
-constexpr int OFF_SF = OFF_DB + 4;                 // [8 waves][re|im][8 blocks][FRAG]
-constexpr int OFF_S0 = OFF_SF + 256 * 128;         // [2][128]  the n = 0 column (re, im) of bins 0..127
-constexpr int OFF_FOLD = OFF_S0 + 256;             // [1] (+3 pad)  1.0 = folded pass valid
+// Folded STFT basis (used when the table has the DFT's time and frequency symmetries, see pack_host and
+// stft_fold_class): symmetrised coefficients of bins 0..63 for the even-n / odd-n classes.
+constexpr int OFF_SF = OFF_DB + 4;                 // [4 bin tiles][E|O][re|im][4 blocks][FRAG]
+constexpr int OFF_S0 = OFF_SF + 4 * 2 * 2 * 4 * 256;   // [2][64]   the n = 0 column (re, im) of bins 0..63
+constexpr int OFF_B64 = OFF_S0 + 128;              // [2][128] bin 64, time-folded (re, im), n = 1..128; then [4]: n = 0 (re, im)
+constexpr int OFF_FOLD = OFF_B64 + 256 + 4;        // [1] (+3 pad)  1.0 = folded pass valid
 constexpr int PACKED_FLOATS = OFF_FOLD + 4;
 
 // ---- encoder LDS map (floats): 50 304 B per workgroup => THREE workgroups per CU ------------------
@@ -112,35 +113,40 @@ __device__ __forceinline__ void gemm_pass_mmajor(f32x4 (&acc)[NT][MT], const flo
     }
 }
 
-// Folded STFT pass.  A real DFT basis with a symmetric window obeys c[k][256-n] = c[k][n], s[k][256-n] = -s[k][n],
-// so  re = sum_{n=1..128} cF[n] (x[n] + x[256-n]),  im = sum_{n=1..127} sF[n] (x[n] - x[256-n])  (+ the n = 0 column,
-// preloaded into the accumulators by the caller): half the MFMAs of the dense pass for two extra VALU adds per
-// operand pair.  Contraction slot (block S, sub-step j, quarter q) <-> n = 16S + q + 4j + 1.
-__device__ __forceinline__ void stft_fold_pass(f32x4 (&are)[4], f32x4 (&aim)[4], const float *X, const float *wre,
-                                               const float *wim, int lane) {
-    const int q = lane >> 4, i = lane & 15;
-    const float *af = X + i * X_LDM + q + 1;          // x[n]
-    const float *ar = X + i * X_LDM + 255 - q;        // x[256 - n]
+// Folded STFT pass.  A windowed real-DFT basis (symmetric window) has two symmetries that the dense 258x256
+// conv ignores:
+//   time      c[k][256-n] =  c[k][n],  s[k][256-n] = -s[k][n]        -> contract x[n] +- x[256-n] over n = 1..128
+//   frequency c[128-k][n] = (-1)^n c[k][n],  s[128-k][n] = -(-1)^n s[k][n]
+//                                                                    -> bins k and 128-k share the partial sums over
+//                                                                       even n (E) and odd n (O): X[k] = E + O, X[128-k] = +-(E - O)
+// so bins 0..63 (4 tiles) over two 64-long contractions give all of bins 0..63 and 65..128: a quarter of the dense
+// pass's MFMAs, for two VALU adds per operand pair.  (Bin 64 pairs with itself and goes through the VALU.)
+// X is staged de-interleaved: per clip row an even-sample plane [0..320] and an odd-sample plane [321..641], so the
+// contraction index of either class walks its plane with unit stride (bank = 2*clip + q: conflict free).
+// Class E: n = 2m + 2 (plane index m + 1, mirror 127 - m); class O: n = 2m + 1 (plane index m, mirror 127 - m);
+// contraction slot (block S, sub-step j, quarter q) <-> m = 16S + q + 4j.
+constexpr int X_ODD = 321;            // offset of the odd plane inside a clip row
+__device__ __forceinline__ void stft_fold_class(f32x4 (&are)[2], f32x4 (&aim)[2], const float *fwd, const float *rev,
+                                                const float *wre, const float *wim) {
     f32x4 cre = *reinterpret_cast<const f32x4 *>(wre), cim = *reinterpret_cast<const f32x4 *>(wim);
-#pragma unroll 1
-    for (int S = 0; S < 8; ++S) {
-        const int Sn = (S + 1 < 8) ? S + 1 : S;
+#pragma unroll
+    for (int S = 0; S < 4; ++S) {
+        const int Sn = (S + 1 < 4) ? S + 1 : S;
         const f32x4 nre = *reinterpret_cast<const f32x4 *>(wre + FRAG * Sn);
         const f32x4 nim = *reinterpret_cast<const f32x4 *>(wim + FRAG * Sn);
-        const float *pf = af + 16 * S, *pr = ar - 16 * S;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float e[4], o[4];
+            float e[2], o[2];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const float a = pf[4 * j + 128 * f], b = pr[128 * f - 4 * j];
+            for (int f = 0; f < 2; ++f) {
+                const float a = fwd[16 * S + 4 * j + 64 * f], b = rev[64 * f - 16 * S - 4 * j];
                 e[f] = a + b;
                 o[f] = a - b;
             }
 #pragma unroll
-            for (int f = 0; f < 4; ++f) are[f] = mfma16(e[f], cre[j], are[f]);
+            for (int f = 0; f < 2; ++f) are[f] = mfma16(e[f], cre[j], are[f]);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) aim[f] = mfma16(o[f], cim[j], aim[f]);
+            for (int f = 0; f < 2; ++f) aim[f] = mfma16(o[f], cim[j], aim[f]);
         }
         cre = nre;
         cim = nim;
@@ -216,7 +222,10 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
     const int q = lane >> 4, i = lane & 15;
     const int grp = blockIdx.x % G, t = blockIdx.x / G;
 
+    const bool fold = P[OFF_FOLD] != 0.f;      // uniform: the basis has the DFT symmetries -> folded STFT pass
     // ---------------- phase 0: copy the 16 windows (576 samples each) + right reflect pad of 64
+    // (folded pass: even / odd samples go to separate planes of the clip row)
+    auto xslot = [fold](int pp) { return fold ? (pp & 1) * X_ODD + (pp >> 1) : pp; };
     {
         const long long base = (long long)t * 512 + origin;
         const bool vec_ok = ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(audio) & 15) == 0);
@@ -244,41 +253,84 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int pp = p + jj;
-                    row[pp] = v[jj];
-                    if (pp >= 511 && pp <= 574) row[1150 - pp] = v[jj];       // reflect pad (0,64)
+                    row[xslot(pp)] = v[jj];
+                    if (pp >= 511 && pp <= 574) row[xslot(1150 - pp)] = v[jj];       // reflect pad (0,64)
                 }
             }
         }
     }
     ENC_SYNC();
 
-    // ---------------- phase 1: STFT conv (bins 0..127 on MFMA, bin 128 on VALU) -> magnitude
-    {
-        f32x4 acc[2][4];
-        if (P[OFF_FOLD] != 0.f) {      // uniform: the basis has the DFT time symmetry -> folded pass (half the MFMAs)
-            const float c0 = P[OFF_S0 + wave * 16 + i], s0 = P[OFF_S0 + 128 + wave * 16 + i];
+    // ---------------- phase 1: STFT conv -> magnitude (results stay in registers until every wave is done with X)
+    if (fold) {
+        // wave = (bin tile tl: bins 16 tl .. 16 tl + 15, frame pair fp); it produces bins k and 128 - k
+        const int tl = wave & 3, fp = wave >> 2;
+        f32x4 ere[2], eim[2], ore[2], oim[2];
+        const float c0 = P[OFF_S0 + tl * 16 + i], s0 = P[OFF_S0 + 64 + tl * 16 + i];
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float x0 = X[(4 * q + r) * X_LDM + 128 * f];
-                    acc[0][f][r] = c0 * x0;
-                    acc[1][f][r] = s0 * x0;
-                }
-            if (!ENC_SKIP(4)) stft_fold_pass(acc[0], acc[1], X, P + OFF_SF + (wave * 2 + 0) * 8 * FRAG + lane * 4,
-                                              P + OFF_SF + (wave * 2 + 1) * 8 * FRAG + lane * 4, lane);
-        } else {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int f = 0; f < 4; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float *const wrow[2] = {P + OFF_STFT + (wave * 32 + i) * 256,
-                                          P + OFF_STFT + (wave * 32 + 16 + i) * 256};
-            const int koff[4] = {0, 128, 256, 384};
-            gemm_pass_mmajor<2, 4, 16>(acc, X, X_LDM, koff, wrow, lane);
+            for (int r = 0; r < 4; ++r) {
+                const float x0 = X[(4 * q + r) * X_LDM + 64 * (2 * fp + f)];          // n = 0 belongs to the even class
+                ere[f][r] = c0 * x0;
+                eim[f][r] = s0 * x0;
+                ore[f][r] = 0.f;
+                oim[f][r] = 0.f;
+            }
+        if (!ENC_SKIP(4)) {
+            const float *row = X + i * X_LDM + 128 * fp;                              // frame 2 fp starts 64 fp... x2 planes
+            const float *wt = P + OFF_SF + tl * 16 * FRAG + lane * 4;                 // [E|O][re|im][4 blocks]
+            stft_fold_class(ere, eim, row + 1 + q, row + 127 - q, wt, wt + 4 * FRAG);
+            stft_fold_class(ore, oim, row + X_ODD + q, row + X_ODD + 127 - q, wt + 8 * FRAG, wt + 12 * FRAG);
         }
+        float b64 = 0.f;
+        if (wave < 4 && !ENC_SKIP(7)) {   // bin 64 (its own mirror): frame f = wave, lane = (clip i, quarter q of n = 1..128)
+            const int f = wave;
+            const float *bre = P + OFF_B64 + q * 32, *bim = P + OFF_B64 + 128 + q * 32;
+            const float *xr = X + i * X_LDM + 64 * f;
+            float sre = 0.f, sim = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const int n = q * 32 + k + 1;                                         // 1..128, mirror 256 - n
+                const float a = xr[(n & 1) * X_ODD + (n >> 1)], b = xr[(n & 1) * X_ODD + ((256 - n) >> 1)];
+                sre = fmaf(a + b, bre[k], sre);
+                sim = fmaf(a - b, bim[k], sim);
+            }
+            sre += __shfl_xor(sre, 16); sre += __shfl_xor(sre, 32);
+            sim += __shfl_xor(sim, 16); sim += __shfl_xor(sim, 32);
+            const float x0 = xr[0];
+            sre = fmaf(x0, P[OFF_B64 + 256], sre);
+            sim = fmaf(x0, P[OFF_B64 + 257], sim);
+            b64 = sqrtf(sre * sre + sim * sim);
+        }
+        ENC_SYNC();          // every wave is done reading X: Mg may now overwrite it
+        const int k = tl * 16 + i;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            f32x4 mk, mn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = ere[f][r] + ore[f][r], pi = eim[f][r] + oim[f][r];
+                const float nr = ere[f][r] - ore[f][r], ni = eim[f][r] - oim[f][r];
+                mk[r] = sqrtf(pr * pr + pi * pi);
+                mn[r] = sqrtf(nr * nr + ni * ni);
+            }
+            *reinterpret_cast<f32x4 *>(&Mg[k * MG_LD + (2 * fp + f) * 16 + 4 * q]) = mk;
+            *reinterpret_cast<f32x4 *>(&Mg[(128 - k) * MG_LD + (2 * fp + f) * 16 + 4 * q]) = mn;
+        }
+        if (wave < 4 && q == 0) Mg[64 * MG_LD + wave * 16 + i] = b64;
+    } else {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *const wrow[2] = {P + OFF_STFT + (wave * 32 + i) * 256,
+                                      P + OFF_STFT + (wave * 32 + 16 + i) * 256};
+        const int koff[4] = {0, 128, 256, 384};
+        gemm_pass_mmajor<2, 4, 16>(acc, X, X_LDM, koff, wrow, lane);
         float nyq = 0.f;
-        if (wave < 4 && !ENC_SKIP(7)) {   // Nyquist bin: frame f = wave, lane = (clip i, k-quarter q)
+        if (wave < 4) {   // Nyquist bin: frame f = wave, lane = (clip i, k-quarter q)
             const int f = wave;
             const float *nre = P + OFF_NYQ + q * 64, *nim = P + OFF_NYQ + 256 + q * 64;
             const float *xp = X + i * X_LDM + 128 * f + q * 64;
@@ -413,7 +465,8 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
         }
         float *dst = gx + ((size_t)t * G + grp) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = acc[g][0];
+        for (int g = 0; g < 4; ++g)
+            if (!ENC_SKIP(8) || acc[g][0][0] == 12345.f) *reinterpret_cast<f32x4 *>(dst + g * 256) = acc[g][0];
     }
 }
 
@@ -475,25 +528,41 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void silero_lstm_kernel(
     for (int t = 0; t < T; ++t) {
         const int tn = (t + 1 < T) ? t + 1 : t;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gnxt[g] = *reinterpret_cast<const f32x4 *>(gsrc + tn * gstep + g * 256);
+        for (int g = 0; g < 4; ++g) gnxt[g] = ENC_SKIP(11) ? gcur[g] : *reinterpret_cast<const f32x4 *>(gsrc + tn * gstep + g * 256);
 
-        f32x4 acc[4] = {gcur[0], gcur[1], gcur[2], gcur[3]};
+        // Gate-outer order: a gate's 32 MFMAs finish before the next gate's start, so its non-linearity (VALU +
+        // transcendentals) runs in the shadow of the following gate's MFMAs instead of after all 128 of them; only
+        // sigmoid(o) and the h update stay exposed.  (Within a gate the MFMAs are a dependent chain at a 40-cycle
+        // cadence; the SIMD's other wave fills the gaps.)
         const float *hb = Hs + cur * 16 * HS_LD + n * HS_LD + 4 * q;
+        f32x4 hv[8];
 #pragma unroll
-        for (int S = 0; S < 8; ++S) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(hb + 16 * S);
+        for (int S = 0; S < 8; ++S) hv[S] = *reinterpret_cast<const f32x4 *>(hb + 16 * S);
+        auto gate = [&](int g) {
+            f32x4 acc = gcur[g];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int S = 0; S < 8; ++S)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[g][4 * S + j], b4[j], acc[g]);
-        }
+                for (int j = 0; j < 4; ++j) acc = mfma16(a[g][4 * S + j], hv[S][j], acc);
+            return acc;
+        };
+        const f32x4 ai = gate(0), af = gate(1);
+        f32x4 ig, fg, gg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ig[r] = ENC_SKIP(9) ? ai[r] * 1e-3f : gate_sigmoid(ai[r]);
+        const f32x4 ag = gate(2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fg[r] = ENC_SKIP(9) ? af[r] * 1e-3f : gate_sigmoid(af[r]);
+        const f32x4 ao = gate(3);
         float dpart = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float ig = gate_sigmoid(acc[0][r]), fg = gate_sigmoid(acc[1][r]);
-            const float gg = gate_tanh(acc[2][r]), og = gate_sigmoid(acc[3][r]);
-            c[r] = fg * c[r] + ig * gg;
-            h[r] = og * gate_tanh(c[r]);
+            gg[r] = ENC_SKIP(9) ? ag[r] * 1e-3f : gate_tanh(ag[r]);
+            c[r] = fg[r] * c[r] + ig[r] * gg[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            h[r] = ENC_SKIP(9) ? ao[r] * 1e-3f + c[r] * 1e-3f : gate_sigmoid(ao[r]) * gate_tanh(c[r]);
             dpart = fmaf(dw[r], fmaxf(h[r], 0.f), dpart);
         }
         const int nxt = cur ^ 1;
@@ -501,8 +570,8 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void silero_lstm_kernel(
         dpart += __shfl_xor(dpart, 16);
         dpart += __shfl_xor(dpart, 32);
         if (q == 0) part[(nxt * 8 + wave) * 16 + n] = dpart;
-        __syncthreads();
-        if (wave == 0 && lane < 16 && bvalid) {
+        if (!ENC_SKIP(10)) __syncthreads();
+        if (wave == 0 && lane < 16 && bvalid && !ENC_SKIP(12)) {
             float s = db;
 #pragma unroll
             for (int w = 0; w < 8; ++w) s += part[(nxt * 8 + w) * 16 + lane];
@@ -683,41 +752,65 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
                                 w->stft_basis[(size_t)(part * 129 + wv * 16 + i) * 256 + 16 * S + qq + 4 * j];
     memcpy(p + OFF_NYQ, w->stft_basis + (size_t)128 * 256, 256 * sizeof(float));
     memcpy(p + OFF_NYQ + 256, w->stft_basis + (size_t)257 * 256, 256 * sizeof(float));
-    {   // folded basis: valid when c[k][256-n] == c[k][n] and s[k][256-n] == -s[k][n] (n = 1..127) and s[k][128] == 0
-        // up to f32 rounding of the table (1e-6 of the largest entry), which every windowed real-DFT basis satisfies
+    // fragment-major slot of element (row i of its tile, contraction index k) inside a tile that starts at `base`
+    auto frag = [](size_t base, int i, int k) { return base + ((size_t)(k / 16) * 64 + ((k % 16) / 4) * 16 + i) * 4 + (k % 4); };
+    {   // folded basis: valid when the table has the time symmetry c[k][256-n] == c[k][n], s[k][256-n] == -s[k][n]
+        // (n = 1..127; s[k][128] == 0) AND the frequency symmetry c[128-k][n] == (-1)^n c[k][n],
+        // s[128-k][n] == -(-1)^n s[k][n], both up to f32 rounding of the table (1e-6 of the largest entry) -- which
+        // every windowed real-DFT basis satisfies.  Otherwise the kernel takes the dense pass.
         const float *re = w->stft_basis, *im = w->stft_basis + (size_t)129 * 256;
         float amax = 0.f, dev = 0.f;
         for (size_t e = 0; e < (size_t)258 * 256; ++e) amax = fmaxf(amax, fabsf(w->stft_basis[e]));
-        for (int k = 0; k < 128; ++k) {
+        for (int k = 0; k <= 128; ++k) {
             for (int n = 1; n < 128; ++n) {
                 dev = fmaxf(dev, fabsf(re[k * 256 + n] - re[k * 256 + 256 - n]));
                 dev = fmaxf(dev, fabsf(im[k * 256 + n] + im[k * 256 + 256 - n]));
             }
             dev = fmaxf(dev, fabsf(im[k * 256 + 128]));
         }
+        for (int k = 0; k < 64; ++k)
+            for (int n = 0; n < 256; ++n) {
+                const float sg = (n & 1) ? -1.f : 1.f;
+                dev = fmaxf(dev, fabsf(re[(128 - k) * 256 + n] - sg * re[k * 256 + n]));
+                dev = fmaxf(dev, fabsf(im[(128 - k) * 256 + n] + sg * im[k * 256 + n]));
+            }
         const bool fold = dev <= 1e-6f * amax;
         p[OFF_FOLD] = fold ? 1.f : 0.f;
         if (fold) {
-            for (int wv = 0; wv < 8; ++wv)
-                for (int part = 0; part < 2; ++part)
-                    for (int i = 0; i < 16; ++i) {
-                        const float *row = (part ? im : re) + (size_t)(wv * 16 + i) * 256;
-                        float *dst = p + OFF_SF + (size_t)(wv * 2 + part) * 8 * FRAG;
-                        for (int S = 0; S < 8; ++S)
-                            for (int qq = 0; qq < 4; ++qq)
-                                for (int j = 0; j < 4; ++j) {
-                                    const int n = 16 * S + qq + 4 * j + 1;
-                                    float v;
-                                    if (n == 128) v = part ? 0.f : 0.5f * row[128];        // x[128] is added to itself
-                                    else v = part ? 0.5f * (row[n] - row[256 - n]) : 0.5f * (row[n] + row[256 - n]);
-                                    dst[(S * 64 + qq * 16 + i) * 4 + j] = v;
-                                }
-                        p[OFF_S0 + part * 128 + wv * 16 + i] = row[0];
+            // symmetrised coefficient of bin k (<= 64) at sample n: average of the four table entries that must agree
+            auto C = [&](int k, int n) {
+                const float sg = (n & 1) ? -1.f : 1.f;
+                const int nm = (256 - n) & 255;
+                return 0.25f * (re[k * 256 + n] + re[k * 256 + nm] + sg * (re[(128 - k) * 256 + n] + re[(128 - k) * 256 + nm]));
+            };
+            auto S = [&](int k, int n) {
+                const float sg = (n & 1) ? -1.f : 1.f;
+                const int nm = (256 - n) & 255;
+                return 0.25f * (im[k * 256 + n] - im[k * 256 + nm] - sg * (im[(128 - k) * 256 + n] - im[(128 - k) * 256 + nm]));
+            };
+            for (int k = 0; k < 64; ++k) {
+                const int tl = k / 16, i = k % 16;
+                for (int cls = 0; cls < 2; ++cls)
+                    for (int m = 0; m < 64; ++m) {
+                        const int n = cls ? 2 * m + 1 : 2 * m + 2;
+                        // n = 128 is its own mirror: x[128] gets added to itself, so its coefficient is halved
+                        const float cv = (n == 128) ? 0.5f * C(k, 128) : C(k, n), sv = (n == 128) ? 0.f : S(k, n);
+                        const int slot = 16 * (m / 16) + 4 * (m % 4) + (m % 16) / 4;     // m = 16S + q + 4j -> slot 16S + 4q + j
+                        p[frag(OFF_SF + (size_t)((tl * 2 + cls) * 2 + 0) * 4 * FRAG, i, slot)] = cv;
+                        p[frag(OFF_SF + (size_t)((tl * 2 + cls) * 2 + 1) * 4 * FRAG, i, slot)] = sv;
                     }
+                p[OFF_S0 + k] = 0.5f * (re[k * 256] + re[(128 - k) * 256]);
+                p[OFF_S0 + 64 + k] = 0.5f * (im[k * 256] - im[(128 - k) * 256]);
+            }
+            for (int n = 1; n <= 128; ++n) {          // bin 64, time-folded only
+                const float h = (n == 128) ? 0.5f : 1.f;
+                p[OFF_B64 + n - 1] = h * 0.5f * (re[64 * 256 + n] + re[64 * 256 + ((256 - n) & 255)]);
+                p[OFF_B64 + 128 + n - 1] = (n == 128) ? 0.f : 0.5f * (im[64 * 256 + n] - im[64 * 256 + 256 - n]);
+            }
+            p[OFF_B64 + 256] = re[64 * 256];
+            p[OFF_B64 + 257] = im[64 * 256];
         }
     }
-    // fragment-major slot of element (row i of its tile, contraction index k) inside a tile that starts at `base`
-    auto frag = [](size_t base, int i, int k) { return base + ((size_t)(k / 16) * 64 + ((k % 16) / 4) * 16 + i) * 4 + (k % 4); };
     for (int co = 0; co < 128; ++co)
         for (int kk = 0; kk < 3; ++kk) {
             for (int ci = 0; ci < 128; ++ci)
