@@ -48,6 +48,31 @@ FLOP_ENCODE_ISSUED = MFMA_PER_TILE * 2048 // 16
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = f32 vector rate
 
 
+def profiled_traffic():
+    """HBM bytes per encoder launch from the newest committed rocprofv3 PMC summary (profiles/rNN*/SUMMARY.txt, written by
+    tools/profile_bench.sh from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this very command).  FETCH_SIZE is
+    doubled (gfx950 counts a wide coalesced read at half its bytes, MI355X_MICROARCH.md "HBM"); both are KiB."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "SUMMARY.txt"))):
+        fetch = write = None
+        grid = -1
+        for line in open(path):
+            if "silero_encode_kernel" not in line or "grid=" not in line or "_SIZE" not in line:
+                continue
+            g = int(line.split("grid=")[1].split()[0])
+            name, val = line.split()[-3], float(line.split()[-2])
+            if name in ("FETCH_SIZE", "WRITE_SIZE") and g >= grid:
+                grid = g
+                if name == "FETCH_SIZE":
+                    fetch = val
+                else:
+                    write = val
+        if fetch is not None and write is not None:
+            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT), "grid_threads": grid}
+    return best
+
+
 def synth_batch(torch, device, batch, samples, seed):
     """int16-quantised burst clips generated on the GPU (every clip unique): 0.5-2 s segments
     alternating N(0,3000) / N(0,30), then x 1/32768 as the reference feeds Silero
@@ -244,6 +269,7 @@ def main():
             log("cpu baseline done")
 
     if rank == 0:
+        traffic = profiled_traffic() if (B, T) == (CLIPS_PER_GPU, STEPS_PER_CLIP) else None
         line = {
             "metric": "audio frames/sec/GPU (16 kHz, 512-sample hop); RTF at batch=1",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -260,7 +286,9 @@ def main():
             # the reference's dense arithmetic would count FLOP_ENCODE per frame ("dense_equivalent").
             "roofline": {"bound": "mfma", "kernel": "silero_encode_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None,
+                         "traffic": traffic["bytes"] if traffic else None, "traffic_unit": "B/launch",
+                         "traffic_source": traffic["source"] if traffic else None,
+                         "algorithmic_bytes_per_launch": B * T * (2048 + 2048),
                          "flop_per_frame": FLOP_ENCODE_ISSUED, "frames_per_launch": B * T,
                          "dense_equivalent": {"flop_per_frame": FLOP_ENCODE,
                                               "achieved": achieved * FLOP_ENCODE / FLOP_ENCODE_ISSUED}},
