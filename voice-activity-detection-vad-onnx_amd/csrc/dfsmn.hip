@@ -103,65 +103,129 @@ struct PwArgs {
     View add;                          // MODE 2
     ViewW out0, out1;
     int F, co, act;
+    int fc, nchunk;                    // bins per workgroup chunk, chunks per tile
 };
 
+// The op is HBM-bound (a few hundred flop per 64-B row), so the kernel is built around the memory system: a
+// workgroup owns (tile, chunk of `fc` bins); it stages the chunk's input rows (+1 halo bin each side for the (3,1)
+// conv) into LDS with 16-B coalesced loads -- a channel's bins are contiguous in the FT layout, so every run is
+// fh*64 B -- together with the LayerNorm weight/bias of each (channel, bin); the MFMA loop reads its B operand
+// from LDS (row stride fh*16 floats with fh odd: the four k-quarters land 16 banks apart), results go to an LDS
+// output block and leave as 16-B coalesced stores (+ the residual `add` of MODE 2, read the same way).
 template <int MT, int KS, int KF, int MODE>
 __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
-    const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, i = lane & 15;
+    const int tile = blockIdx.x;
     const int cin = p.a.c + p.b.c;
-    constexpr int K = KS * 4;
-    float wa[MT][KS], wb[MODE == 1 ? MT : 1][MODE == 1 ? KS : 1];
+    constexpr int K = KS * 4, HALO = (KF - 1) / 2;
+    const int fh = p.fc + 2 * HALO, fs = fh | 1;        // rows per channel, and their (odd) LDS pitch
+    float *raw = lds;                                   // [cin][fs][16]
+    float *wb = raw + cin * fs * 16;                    // [cin][fs][2]   LayerNorm (weight, bias); (0, 0) outside [0, F)
+    float *o0 = wb + cin * fs * 2;                      // [co][fc][16]
+    float *o1 = o0 + p.co * p.fc * 16;                  // MODE 1 only
+
+    // weights stay in VGPRs for every chunk of the tile
+    float wa[MT][KS], wg[MODE == 1 ? MT : 1][MODE == 1 ? KS : 1];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             wa[mt][s] = p.W[(size_t)(mt * 16 + i) * K + 4 * s + q];
-            if (MODE == 1) wb[mt][s] = p.W2[(size_t)(mt * 16 + i) * K + 4 * s + q];
+            if (MODE == 1) wg[mt][s] = p.W2[(size_t)(mt * 16 + i) * K + 4 * s + q];
         }
     const float ln_mean = p.ln.stats ? p.ln.stats[((size_t)tile * 16 + i) * 2] : 0.f;          // this lane's frame is fixed
     const float ln_inv = p.ln.stats ? p.ln.stats[((size_t)tile * 16 + i) * 2 + 1] : 1.f;
-    for (int f = wave; f < p.F; f += nw) {
-        f32x4 acc[MT], acc2[MODE == 1 ? MT : 1];
+    int koff[KS];              // this lane's k rows: k = 4s + q -> (tap, channel) -> LDS row (channel*fs + tap)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; if (MODE == 1) acc2[mt] = acc[mt]; }
+    for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + q, tap = (KF == 1) ? 0 : k / cin, c = (KF == 1) ? k : k - tap * cin;
+        koff[s] = c * fs + tap;
+    }
+    float bias_r[MT][4], bias2_r[MODE == 1 ? MT : 1][4];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int k = 4 * s + q;
-            const int tap = (KF == 1) ? 0 : k / cin, c = (KF == 1) ? k : k - tap * cin;
-            const int ff = f + tap - (KF - 1) / 2;
-            float raw = 0.f, lnv = 0.f;
-            if (ff >= 0 && ff < p.F) {
-                raw = c < p.a.c ? p.a.ptr[ft_idx(tile, p.a.c_total, p.a.c_off + c, p.F, ff) + i]
-                                : p.b.ptr[ft_idx(tile, p.b.c_total, p.b.c_off + c - p.a.c, p.F, ff) + i];
-                lnv = p.ln.stats ? ln_apply2(p.ln, ln_mean, ln_inv, c * p.F + ff, raw) : raw;
-            }
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                acc[mt] = mfma16(wa[mt][s], lnv, acc[mt]);
-                if (MODE == 1) acc2[mt] = mfma16(wb[mt][s], raw, acc2[mt]);
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int co = mt * 16 + 4 * q + r;
+            bias_r[mt][r] = co < p.co ? p.bias[co] : 0.f;
+            if (MODE == 1) bias2_r[mt][r] = co < p.co ? p.bias2[co] : 0.f;
         }
+
+    for (int chunk = blockIdx.y; chunk < p.nchunk; chunk += gridDim.y) {
+        const int f0 = chunk * p.fc, fcv = min(p.fc, p.F - f0);
+        // ---- stage the input rows: thread = (row (c, ffl), frame quad)
+        for (int e = tid; e < cin * fh * 4; e += 256) {
+            const int rowi = e >> 2, tq = e & 3, c = rowi / fh, ffl = rowi - c * fh, ff = f0 - HALO + ffl;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ff >= 0 && ff < p.F) {
+                const float *src = c < p.a.c ? p.a.ptr + ft_idx(tile, p.a.c_total, p.a.c_off + c, p.F, ff)
+                                             : p.b.ptr + ft_idx(tile, p.b.c_total, p.b.c_off + c - p.a.c, p.F, ff);
+                v = *reinterpret_cast<const f32x4 *>(src + 4 * tq);
+            }
+            *reinterpret_cast<f32x4 *>(raw + (c * fs + ffl) * 16 + 4 * tq) = v;
+        }
+        if (p.ln.stats)
+            for (int rowi = tid; rowi < cin * fh; rowi += 256) {
+                const int c = rowi / fh, ffl = rowi - c * fh, ff = f0 - HALO + ffl;
+                const bool in = ff >= 0 && ff < p.F;
+                wb[2 * (c * fs + ffl)] = in ? p.ln.w[c * p.F + ff] : 0.f;
+                wb[2 * (c * fs + ffl) + 1] = in ? p.ln.b[c * p.F + ff] : 0.f;
+            }
+        __syncthreads();
+
+        // ---- MFMA: wave walks the chunk's bins
+        for (int fl = wave; fl < fcv; fl += 4) {
+            f32x4 acc[MT], acc2[MODE == 1 ? MT : 1];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; if (MODE == 1) acc2[mt] = acc[mt]; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = mt * 16 + 4 * q + r;
-                if (co < p.co) {
-                    float v = acc[mt][r] + p.bias[co];
-                    const size_t o0 = ft_idx(tile, p.out0.c_total, p.out0.c_off + co, p.F, f) + i;
-                    if (MODE == 0) {
-                        if (p.act == 1) v = sigmoidf_(v);
-                        p.out0.ptr[o0] = v;
-                    } else if (MODE == 1) {
-                        const float g = sigmoidf_(v), xi = acc2[mt][r] + p.bias2[co], gx = g * xi;
-                        p.out0.ptr[o0] = gx;
-                        p.out1.ptr[ft_idx(tile, p.out1.c_total, p.out1.c_off + co, p.F, f) + i] = xi - gx;
-                    } else {
-                        p.out0.ptr[o0] = v + p.add.ptr[ft_idx(tile, p.add.c_total, p.add.c_off + co, p.F, f) + i];
-                    }
+            for (int s = 0; s < KS; ++s) {
+                const int row = koff[s] + fl;
+                const float x = raw[row * 16 + i];
+                float lnv = x;
+                if (p.ln.stats) lnv = (x - ln_mean) * ln_inv * wb[2 * row] + wb[2 * row + 1];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt] = mfma16(wa[mt][s], lnv, acc[mt]);
+                    if (MODE == 1) acc2[mt] = mfma16(wg[mt][s], x, acc2[mt]);
                 }
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = mt * 16 + 4 * q + r;
+                    if (co < p.co) {
+                        const float v = acc[mt][r] + bias_r[mt][r];
+                        const int o = (co * p.fc + fl) * 16 + i;
+                        if (MODE == 0) {
+                            o0[o] = p.act == 1 ? sigmoidf_(v) : v;
+                        } else if (MODE == 1) {
+                            const float g = sigmoidf_(v), xi = acc2[mt][r] + bias2_r[mt][r], gx = g * xi;
+                            o0[o] = gx;
+                            o1[o] = xi - gx;
+                        } else {
+                            o0[o] = v;
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+
+        // ---- coalesced write-out: thread = (row (co, fl), frame quad)
+        for (int e = tid; e < p.co * fcv * 4; e += 256) {
+            const int rowi = e >> 2, tq = e & 3, co = rowi / fcv, fl = rowi - co * fcv;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(o0 + (co * p.fc + fl) * 16 + 4 * tq);
+            if (MODE == 2) v += *reinterpret_cast<const f32x4 *>(p.add.ptr + ft_idx(tile, p.add.c_total, p.add.c_off + co, p.F, f0 + fl) + 4 * tq);
+            *reinterpret_cast<f32x4 *>(p.out0.ptr + ft_idx(tile, p.out0.c_total, p.out0.c_off + co, p.F, f0 + fl) + 4 * tq) = v;
+            if (MODE == 1)
+                *reinterpret_cast<f32x4 *>(p.out1.ptr + ft_idx(tile, p.out1.c_total, p.out1.c_off + co, p.F, f0 + fl) + 4 * tq) =
+                    *reinterpret_cast<const f32x4 *>(o1 + (co * p.fc + fl) * 16 + 4 * tq);
+        }
+        // the next chunk's staging writes raw/wb (last read before the barrier above); o0/o1 are rewritten only after
+        // the next chunk's first barrier, i.e. after every thread has finished this write-out
     }
 }
 
@@ -601,8 +665,26 @@ extern "C" int vadx_dfsmn_frame_stats(const vadx_ft_view *a, const vadx_ft_view 
 }
 
 template <int MT, int KS, int KF, int MODE>
-static int launch_pw(const PwArgs &p, int tiles, void *stream) {
-    hipLaunchKernelGGL((pw_conv_kernel<MT, KS, KF, MODE>), dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+static int launch_pw(PwArgs p, int tiles, void *stream) {
+    // bins per chunk: the largest multiple of 4 (one bin per wave per round) up to 32 that keeps the workgroup's LDS
+    // within 52 KB (three workgroups per CU); a workgroup walks all chunks of its tile (weights stay in VGPRs),
+    // two workgroups per tile when there are few tiles
+    const int cin = p.a.c + p.b.c, halo = (KF - 1) / 2, nout = MODE == 1 ? 2 : 1;
+    auto lds_floats = [&](int fc) { return cin * ((fc + 2 * halo) | 1) * 18 + nout * p.co * fc * 16; };
+    int fc = 32;
+    while (fc > 4 && lds_floats(fc) * 4 > 52 * 1024) fc -= 4;
+    p.fc = fc;
+    p.nchunk = (p.F + fc - 1) / fc;
+    const size_t lds = (size_t)lds_floats(fc) * sizeof(float);
+    static bool done = false;
+    if (!done) {
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_conv_kernel<MT, KS, KF, MODE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        done = true;
+    }
+    const unsigned split = tiles < 4096 ? 2 : 1;
+    hipLaunchKernelGGL((pw_conv_kernel<MT, KS, KF, MODE>), dim3((unsigned)tiles, split), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), p);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }
