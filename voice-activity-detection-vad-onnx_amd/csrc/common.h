@@ -206,4 +206,10 @@ __device__ __forceinline__ void gemm_rt_simple(f32x4 (&acc)[NT][MT], const float
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Gate non-linearities of the recurrent cells on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each):
+// a recurrent step is a serial chain MFMA -> gates -> next step, so libm's branchy expf/tanhf (~140 VALU instructions
+// per unit) sat directly on the critical path.  |error| < 3e-7 per gate, far inside the 1e-4 score bar.
+__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
 }  // namespace vadx

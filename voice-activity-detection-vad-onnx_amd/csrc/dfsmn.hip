@@ -15,6 +15,12 @@
 #include <math.h>
 #include <string.h>
 
+// DFSMN_EXP: development-only what-if switches (bit mask; results are wrong when set): 1 lstm_f without its output
+// stores, 2 without input loads, 4 without gate non-linearities
+#ifndef DFSMN_EXP
+#define DFSMN_EXP 0
+#endif
+
 namespace vadx {
 namespace dfsmn {
 
@@ -201,9 +207,9 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
                         const float v = acc[mt][r] + bias_r[mt][r];
                         const int o = (co * p.fc + fl) * 16 + i;
                         if (MODE == 0) {
-                            o0[o] = p.act == 1 ? sigmoidf_(v) : v;
+                            o0[o] = p.act == 1 ? gate_sigmoid(v) : v;
                         } else if (MODE == 1) {
-                            const float g = sigmoidf_(v), xi = acc2[mt][r] + bias2_r[mt][r], gx = g * xi;
+                            const float g = gate_sigmoid(v), xi = acc2[mt][r] + bias2_r[mt][r], gx = g * xi;
                             o0[o] = gx;
                             o1[o] = xi - gx;
                         } else {
@@ -318,9 +324,16 @@ struct LstmFArgs {
     int F;
 };
 
+// Input path: the recurrence consumes one bin (IN rows of 64 B) per step, far too little to cover HBM latency with
+// per-step loads, so each wave streams CHUNKS of NB = 4 bins: all rows of the next chunk are requested as 16-B
+// coalesced loads (10 per lane for IN = 40) while the current chunk's four steps run, then LayerNorm'd and parked in
+// the wave's private LDS double buffer, from where the MFMA B operand is read ([row][16 frames]: the k-quarters land
+// 16 banks apart).  Waves never share LDS data, so no workgroup barrier is needed.
 template <int IN>
 __global__ __launch_bounds__(128) void lstm_f_kernel(LstmFArgs p) {
-    constexpr int KI = IN / 4, H = 20, MT = 5;
+    constexpr int KI = IN / 4, H = 20, MT = 5, NB = 4;
+    constexpr int CH_FLOATS = NB * IN * 16, NLD = NB * IN / 16;      // floats per chunk; float4 loads per lane per chunk
+    __shared__ __attribute__((aligned(16))) float xs[2][2][CH_FLOATS];      // [direction][buffer]
     const int tile = blockIdx.x, lane = threadIdx.x & 63, dir = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
     const int grow = (i & 3) * H + (i >> 2);          // A-fragment row i <-> gate (i&3), unit-in-quad (i>>2)
     float wi[MT][KI], wh[MT][MT], bias[MT][4];
@@ -337,44 +350,77 @@ __global__ __launch_bounds__(128) void lstm_f_kernel(LstmFArgs p) {
     float h[MT], c[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { h[mt] = 0.f; c[mt] = 0.f; }
-    const float ln_mean = p.ln.stats ? p.ln.stats[((size_t)tile * 16 + i) * 2] : 0.f;
-    const float ln_inv = p.ln.stats ? p.ln.stats[((size_t)tile * 16 + i) * 2 + 1] : 1.f;
-    auto load_x = [&](int f, float (&x)[KI]) {
+    // staging role of this lane: float4 number e = lane + 64 r of the chunk -> row e/4 = (bin b, channel ch), frames 4 (lane&3)..+3
+    const int tq = lane & 3;
+    f32x4 ln_mean = {0.f, 0.f, 0.f, 0.f}, ln_inv = {1.f, 1.f, 1.f, 1.f};
+    if (p.ln.stats)
 #pragma unroll
-        for (int s = 0; s < KI; ++s) {
-            const int ch = 4 * s + q;
-            const float v = p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + ch, p.F, f) + i];
-            x[s] = p.ln.stats ? ln_apply2(p.ln, ln_mean, ln_inv, ch * p.F + f, v) : v;
+        for (int r = 0; r < 4; ++r) {
+            ln_mean[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2];
+            ln_inv[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2 + 1];
+        }
+    const int nchunk = (p.F + NB - 1) / NB;
+    auto bin_of = [&](int ck, int b) { const int st = ck * NB + b; return dir ? p.F - 1 - st : st; };      // may run past the end
+    f32x4 pre[NLD];
+    auto request = [&](int ck) {
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int row = (lane >> 2) + 16 * r, b = row / IN, ch = row - b * IN, f = bin_of(ck, b);
+            pre[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (DFSMN_EXP & 2) continue;
+            if (f >= 0 && f < p.F)
+                pre[r] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + ch, p.F, f) + 4 * tq);
         }
     };
-    float xc[KI], xn[KI];
-    load_x(dir ? p.F - 1 : 0, xc);
-    for (int st = 0; st < p.F; ++st) {
-        const int f = dir ? p.F - 1 - st : st;
-        if (st + 1 < p.F) load_x(dir ? f - 1 : f + 1, xn);
-        f32x4 acc[MT];
+    auto park = [&](int ck, float *dst) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
-#pragma unroll
-        for (int s = 0; s < KI; ++s)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wi[mt][s], xc[s], acc[mt]);
-#pragma unroll
-        for (int s = 0; s < MT; ++s)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wh[mt][s], h[s], acc[mt]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float ig = sigmoidf_(acc[mt][0]), fg = sigmoidf_(acc[mt][1]), gg = tanhf(acc[mt][2]), og = sigmoidf_(acc[mt][3]);
-            c[mt] = fg * c[mt] + ig * gg;
-            h[mt] = og * tanhf(c[mt]);
-            p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + dir * H + 4 * mt + q, p.F, f) + i] = h[mt];
+        for (int r = 0; r < NLD; ++r) {
+            const int row = (lane >> 2) + 16 * r, b = row / IN, ch = row - b * IN, f = bin_of(ck, b);
+            f32x4 v = pre[r];
+            if (p.ln.stats && f >= 0 && f < p.F) v = (v - ln_mean) * ln_inv * p.ln.w[ch * p.F + f] + p.ln.b[ch * p.F + f];
+            *reinterpret_cast<f32x4 *>(dst + row * 16 + 4 * tq) = v;
         }
+    };
+    request(0);
+    park(0, xs[dir][0]);
+    if (nchunk > 1) request(1);
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const float *xb = xs[dir][ck & 1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // this wave's LDS writes precede its reads below
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int b = 0; b < NB; ++b) {
+            const int f = bin_of(ck, b);
+            if (f < 0 || f >= p.F) break;
+            f32x4 acc[MT];
 #pragma unroll
-        for (int s = 0; s < KI; ++s) xc[s] = xn[s];
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
+#pragma unroll
+            for (int s = 0; s < KI; ++s) {
+                const float xv = xb[(b * IN + 4 * s + q) * 16 + i];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wi[mt][s], xv, acc[mt]);
+            }
+#pragma unroll
+            for (int s = 0; s < MT; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wh[mt][s], h[s], acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool lin = DFSMN_EXP & 4;
+                const float ig = lin ? acc[mt][0] : gate_sigmoid(acc[mt][0]), fg = lin ? acc[mt][1] * 0.1f : gate_sigmoid(acc[mt][1]);
+                const float gg = lin ? acc[mt][2] : gate_tanh(acc[mt][2]), og = lin ? acc[mt][3] : gate_sigmoid(acc[mt][3]);
+                c[mt] = fg * c[mt] + ig * gg;
+                h[mt] = lin ? og * c[mt] * 0.01f : og * gate_tanh(c[mt]);
+                if (!(DFSMN_EXP & 1) || h[mt] == 123.f) p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + dir * H + 4 * mt + q, p.F, f) + i] = h[mt];
+            }
+        }
+        if (ck + 1 < nchunk) {
+            park(ck + 1, xs[dir][(ck + 1) & 1]);          // the buffer last read two chunks ago
+            if (ck + 2 < nchunk) request(ck + 2);
+        }
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // alpha_scale (DFSMN_VAD.forward :326-335): x4 = [mix_re, mix_im, |alpha| * far_re, |alpha| * far_im] with
@@ -485,9 +531,9 @@ __global__ __launch_bounds__(64 * LAYERS) void lstm_t_kernel(LstmTArgs p) {
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wh[mt][s], h[s], acc[mt]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const float ig = sigmoidf_(acc[mt][0]), fg = sigmoidf_(acc[mt][1]), gg = tanhf(acc[mt][2]), og = sigmoidf_(acc[mt][3]);
+                const float ig = gate_sigmoid(acc[mt][0]), fg = gate_sigmoid(acc[mt][1]), gg = gate_tanh(acc[mt][2]), og = gate_sigmoid(acc[mt][3]);
                 c[mt] = fg * c[mt] + ig * gg;
-                h[mt] = og * tanhf(c[mt]);
+                h[mt] = og * gate_tanh(c[mt]);
                 if (!last) hs[t & 1][(4 * mt + q) * 16 + i] = h[mt];
             }
             if (last) {

@@ -471,12 +471,6 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
 }
 
 // ---- persistent LSTM --------------------------------------------------------------------------
-// Gate non-linearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): the recurrent step is
-// a serial chain MFMA -> gates -> LDS -> barrier, so libm's branchy expf/tanhf (~140 VALU instructions per unit)
-// sat directly on the critical path of all 313 steps.  |error| < 3e-7 per gate, far inside the 1e-4 score bar.
-__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
-
 constexpr int HS_LD = 136;                       // h [16 clips][128] (+8 pad: conflict-free b128)
 constexpr int LSTM_LDS_FLOATS = 2 * 16 * HS_LD + 2 * 8 * 16;
 constexpr int LSTM_THREADS = 512;
