@@ -252,40 +252,74 @@ struct DftArgs {
     int C;
 };
 
+// Memory path: channel c+1's rows are requested as 16-B coalesced loads before channel c's MFMAs issue and parked in
+// the other half of the LDS double buffer afterwards; results leave through a (double-buffered) LDS output block as
+// 16-B coalesced stores -- an output channel's bins are contiguous in the FT layout.
 template <bool INV>
 __global__ __launch_bounds__(INV ? 320 : 384) void dft_f_kernel(DftArgs p) {
-    constexpr int KS = INV ? 41 : 40, NWAVE = INV ? 5 : 6, KROWS = KS * 4;
-    __shared__ float Bs[2][KROWS * 16];
+    constexpr int KS = INV ? 41 : 40, NWAVE = INV ? 5 : 6, KROWS = KS * 4, NT = NWAVE * 64;
+    constexpr int OROWS = NWAVE * 32;                       // FWD 192 (96 cos | 96 sin), INV 160
+    constexpr int ITEMS = INV ? 81 * 4 : 160 * 4, NR = (ITEMS + NT - 1) / NT;      // staging work items (row, frame quad)
+    __shared__ __attribute__((aligned(16))) float Bs[2][KROWS * 16];
+    __shared__ __attribute__((aligned(16))) float Os[2][OROWS * 16];
     const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
     float ta[2][KS];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int s = 0; s < KS; ++s) ta[h][s] = p.tbl[(size_t)((wave * 2 + h) * 16 + i) * KROWS + 4 * s + q];
-    const float ln_mean = (!INV && p.ln.stats) ? p.ln.stats[((size_t)tile * 16 + (tid & 15)) * 2] : 0.f;
-    const float ln_inv = (!INV && p.ln.stats) ? p.ln.stats[((size_t)tile * 16 + (tid & 15)) * 2 + 1] : 1.f;
-    auto stage = [&](int c, float *dst) {
-        for (int e = tid; e < KROWS * 16; e += NWAVE * 64) {
-            const int k = e >> 4, t = e & 15;
-            float v = 0.f;
+    const int tq = tid & 3;                                 // NT is a multiple of 4: a thread's frame quad is fixed
+    f32x4 ln_mean = {0.f, 0.f, 0.f, 0.f}, ln_inv = {1.f, 1.f, 1.f, 1.f};
+    if (!INV && p.ln.stats)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ln_mean[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2];
+            ln_inv[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2 + 1];
+        }
+    for (int e = tid; e < 2 * KROWS * 16; e += NT) Bs[0][e] = 0.f;          // rows past the data stay zero (table padding)
+    f32x4 pre[NR][INV ? 4 : 1];
+    float lw[NR], lb[NR];
+    auto request = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int e = tid + NT * r, k = e >> 2;
+            if (e >= ITEMS) continue;
             if (!INV) {
-                if (k < 160) v = ln_apply2(p.ln, ln_mean, ln_inv, c * 160 + k, p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + c, 160, k) + t]);
-            } else if (k < 162) {
-                const int kk = k < 81 ? k : k - 81;
-                const float re = p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + c, 81, kk) + t];
-                const float im = p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + p.C + c, 81, kk) + t];
-                const float pr = p.lo.ptr[ft_idx(tile, p.lo.c_total, p.lo.c_off + c, 81, kk) + t];
-                const float pi = p.lo.ptr[ft_idx(tile, p.lo.c_total, p.lo.c_off + p.C + c, 81, kk) + t];
-                v = k < 81 ? pr * re - pi * im : pr * im + pi * re;
+                pre[r][0] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + c, 160, k) + 4 * tq);
+                lw[r] = p.ln.stats ? p.ln.w[c * 160 + k] : 1.f;
+                lb[r] = p.ln.stats ? p.ln.b[c * 160 + k] : 0.f;
+            } else {
+                pre[r][0] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + c, 81, k) + 4 * tq);
+                pre[r][1] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + p.C + c, 81, k) + 4 * tq);
+                pre[r][2] = *reinterpret_cast<const f32x4 *>(p.lo.ptr + ft_idx(tile, p.lo.c_total, p.lo.c_off + c, 81, k) + 4 * tq);
+                pre[r][3] = *reinterpret_cast<const f32x4 *>(p.lo.ptr + ft_idx(tile, p.lo.c_total, p.lo.c_off + p.C + c, 81, k) + 4 * tq);
             }
-            dst[e] = v;
         }
     };
-    stage(0, Bs[0]);
+    auto park = [&](float *dst) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int e = tid + NT * r, k = e >> 2;
+            if (e >= ITEMS) continue;
+            if (!INV) {
+                f32x4 v = pre[r][0];
+                if (p.ln.stats) v = (v - ln_mean) * ln_inv * lw[r] + lb[r];
+                *reinterpret_cast<f32x4 *>(dst + k * 16 + 4 * tq) = v;
+            } else {
+                const f32x4 re = pre[r][0], im = pre[r][1], pr = pre[r][2], pi = pre[r][3];
+                *reinterpret_cast<f32x4 *>(dst + k * 16 + 4 * tq) = pr * re - pi * im;
+                *reinterpret_cast<f32x4 *>(dst + (81 + k) * 16 + 4 * tq) = pr * im + pi * re;
+            }
+        }
+    };
+    request(0);
+    __syncthreads();                 // the zero fill above
+    park(Bs[0]);
     __syncthreads();
     for (int c = 0; c < p.C; ++c) {
         const float *B = Bs[c & 1];
-        if (c + 1 < p.C) stage(c + 1, Bs[(c + 1) & 1]);
+        float *O = Os[c & 1];
+        if (c + 1 < p.C) request(c + 1);
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -296,16 +330,21 @@ __global__ __launch_bounds__(INV ? 320 : 384) void dft_f_kernel(DftArgs p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = (wave * 2 + h) * 16 + 4 * q + r;
-                if (!INV) {          // tiles 0..5 = cos rows, 6..11 = sin rows
-                    const int kk = m < 96 ? m : m - 96;
-                    if (kk < 81) p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + (m < 96 ? c : p.C + c), 81, kk) + i] = acc[h][r];
-                } else {
-                    p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + c, 160, m) + i] = acc[h][r];
-                }
-            }
+            for (int r = 0; r < 4; ++r) O[((wave * 2 + h) * 16 + 4 * q + r) * 16 + i] = acc[h][r];
+        if (c + 1 < p.C) park(Bs[(c + 1) & 1]);
         __syncthreads();
+        // copy-out of channel c (reads O; O is next written two channels later, after the next barrier)
+        if (!INV) {          // rows 0..95 = cos bins (81 valid) -> channel c, rows 96..191 = sin bins -> channel C + c
+            for (int e = tid; e < 2 * 81 * 4; e += NT) {
+                const int half = e >= 81 * 4, rowq = e - half * 81 * 4, kk = rowq >> 2, oq = rowq & 3;
+                *reinterpret_cast<f32x4 *>(p.out.ptr + ft_idx(tile, p.out.c_total, p.out.c_off + (half ? p.C + c : c), 81, kk) + 4 * oq) =
+                    *reinterpret_cast<const f32x4 *>(O + (half * 96 + kk) * 16 + 4 * oq);
+            }
+        } else {
+            for (int e = tid; e < 160 * 4; e += NT)
+                *reinterpret_cast<f32x4 *>(p.out.ptr + ft_idx(tile, p.out.c_total, p.out.c_off + c, 160, e >> 2) + 4 * (e & 3)) =
+                    *reinterpret_cast<const f32x4 *>(O + (e >> 2) * 16 + 4 * (e & 3));
+        }
     }
 }
 
