@@ -37,14 +37,19 @@ __device__ __forceinline__ size_t ft_idx(int tile, int c_total, int c, int F, in
     return (((size_t)tile * c_total + c) * F + f) * 16;
 }
 
+__device__ __forceinline__ float c_first(const View &a, const View &b, int tile, int F, int t) {
+    return a.c > 0 ? a.ptr[ft_idx(tile, a.c_total, a.c_off, F, 0) + t] : b.ptr[ft_idx(tile, b.c_total, b.c_off, F, 0) + t];
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm statistics over (C, F) per frame: stats[tile][16][2] = (mean, 1/(std_unbiased + 1e-6))
-// (LayerNorm.forward, Export_DFSMN_VAD.py:163-167).  Two passes (mean, then centred squares).
+// (LayerNorm.forward, Export_DFSMN_VAD.py:163-167).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void frame_stats_kernel(View a, View b, int F, float *__restrict__ stats) {
-    // thread = (row group tid>>2, frame quad tid&3): 16-B loads, a wave reads 1 KiB contiguous
-    __shared__ f32x4 red[64][4];
-    __shared__ float mean_s[16];
+    // thread = (row group tid>>2, frame quad tid&3): 16-B loads, a wave reads 1 KiB contiguous.  ONE pass over the
+    // tile: sums of d = x - K and d^2 with the shift K = the frame's first element (|K - mean| is of the order of the
+    // standard deviation, so var = (S2 - S1^2/n) / (n-1) has none of the cancellation of the raw-moment formula).
+    __shared__ f32x4 red1[64][4], red2[64][4];
     const int tile = blockIdx.x, tid = threadIdx.x, tq = tid & 3, rg = tid >> 2;
     const int n = (a.c + b.c) * F;
     auto at = [&](int e) -> f32x4 {
@@ -53,28 +58,26 @@ __global__ __launch_bounds__(256) void frame_stats_kernel(View a, View b, int F,
                                    : b.ptr + ft_idx(tile, b.c_total, b.c_off + c - a.c, F, f);
         return *reinterpret_cast<const f32x4 *>(ptr + 4 * tq);
     };
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int e = rg; e < n; e += 64) s += at(e);
-    red[rg][tq] = s;
-    __syncthreads();
-    if (tid < 16) {
-        float m = 0.f;
-        for (int g = 0; g < 64; ++g) m += red[g][tid >> 2][tid & 3];
-        mean_s[tid] = m / (float)n;
+    const f32x4 K = at(0);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    int e = rg;
+    for (; e + 192 < n; e += 256) {          // four independent loads in flight per thread
+        const f32x4 d0 = at(e) - K, d1 = at(e + 64) - K, d2 = at(e + 128) - K, d3 = at(e + 192) - K;
+        s1 += (d0 + d1) + (d2 + d3);
+        s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
-    __syncthreads();
-    const f32x4 mean = {mean_s[4 * tq], mean_s[4 * tq + 1], mean_s[4 * tq + 2], mean_s[4 * tq + 3]};
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int e = rg; e < n; e += 64) { const f32x4 d = at(e) - mean; v += d * d; }
-    __syncthreads();
-    red[rg][tq] = v;
+    for (; e < n; e += 64) { const f32x4 d = at(e) - K; s1 += d; s2 += d * d; }
+    red1[rg][tq] = s1;
+    red2[rg][tq] = s2;
     __syncthreads();
     if (tid < 16) {
-        float var = 0.f;
-        for (int g = 0; g < 64; ++g) var += red[g][tid >> 2][tid & 3];
-        const float sd = sqrtf(var / (float)(n - 1));
-        stats[((size_t)tile * 16 + tid) * 2] = mean_s[tid];
-        stats[((size_t)tile * 16 + tid) * 2 + 1] = 1.0f / (sd + 1e-6f);
+        float S1 = 0.f, S2 = 0.f;
+        for (int g = 0; g < 64; ++g) { S1 += red1[g][tid >> 2][tid & 3]; S2 += red2[g][tid >> 2][tid & 3]; }
+        const float k = (c_first(a, b, tile, F, tid));
+        const float mean = k + S1 / (float)n;
+        const float var = fmaxf(S2 - S1 * S1 / (float)n, 0.f) / (float)(n - 1);
+        stats[((size_t)tile * 16 + tid) * 2] = mean;
+        stats[((size_t)tile * 16 + tid) * 2 + 1] = 1.0f / (sqrtf(var) + 1e-6f);
     }
 }
 
@@ -512,8 +515,11 @@ struct LstmTArgs {
     int F, T, nt, out_ch;
 };
 
+// Direct variant (loads / stores issued per step): kept for the two-layer bottleneck LSTM, whose weight-resident
+// waves already fill the register file (1 wave/SIMD) -- a third, loader wave per workgroup halves the workgroups per
+// CU and measured slower there (16.9 vs 13.5 ms); see the chunked kernel below for the one-layer case.
 template <int IN, int HID, int LAYERS, int OUT_MT, int MODE>
-__global__ __launch_bounds__(64 * LAYERS) void lstm_t_kernel(LstmTArgs p) {
+__global__ __launch_bounds__(64 * LAYERS) void lstm_t_direct_kernel(LstmTArgs p) {
     constexpr int MT = HID / 4, KI0 = IN / 4;
     __shared__ float hs[2][HID * 16];
     const int lane = threadIdx.x & 63, layer = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
@@ -594,6 +600,156 @@ __global__ __launch_bounds__(64 * LAYERS) void lstm_t_kernel(LstmTArgs p) {
             }
         }
         if (LAYERS > 1) __syncthreads();
+    }
+}
+
+// Memory path.  In the FT layout one time step of a 16-bin group is 16 B out of each of IN*16 different 64-B rows, so
+// per-step loads / stores (one cache line per lane, issued when needed) left the recurrence waiting on HBM every
+// step.  A dedicated LOADER wave (the last wave of the workgroup; it holds no weights) streams CHUNKS of TS steps:
+// it requests chunk k+1's rows as 16-B loads while the compute waves run chunk k, applies the LayerNorm, and parks
+// them transposed in LDS as Xs[ch][t][bin] (channel pitch = 16 mod 32 floats: the MFMA B operand reads are conflict
+// free); the last layer's outputs go to Ys[o][t][bin] and the loader writes chunk k-1 back as 16-B stores (times the
+// `mul` tensor in MODE 0).  One workgroup barrier per step orders everything (it already paced the two layers).
+template <int IN, int HID, int LAYERS, int OUT_MT, int MODE, int TS>
+__global__ __launch_bounds__(64 * (LAYERS + 1)) void lstm_t_kernel(LstmTArgs p) {
+    constexpr int MT = HID / 4, KI0 = IN / 4, CS = TS * 16 + 16, NQ = TS / 4;
+    constexpr int NLD = IN * NQ / 4;                         // float4 loads per loader lane per chunk
+    constexpr int OUTC = OUT_MT * 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Xs = lds;                                         // [2][IN][CS]
+    float *Ys = Xs + 2 * IN * CS;                            // [2][OUTC][CS]
+    float *hs = Ys + 2 * OUTC * CS;                          // [2][HID*16]
+    const int lane = threadIdx.x & 63, layer = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    const int groups = p.F / 16, chunk = blockIdx.x / groups, f0 = (blockIdx.x - chunk * groups) * 16;
+    const int NI = p.T + LAYERS - 1, nck = (p.T + TS - 1) / TS;
+
+    if (layer == LAYERS) {
+        // ------------------------------------------------------------------ loader / storer wave
+        const int sub = lane >> 4, quad = sub % NQ, chs = sub / NQ;      // lane -> (bin i, time quad, channel sub-offset)
+        f32x4 pre[NLD];
+        auto request = [&](int ck) {
+            const int t0 = ck * TS, tile = chunk * p.nt + (t0 >> 4), tb = (t0 & 15) + 4 * quad;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int ch = j * (4 / NQ) + chs;
+                pre[j] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + ch, p.F, f0 + i) + tb);
+            }
+        };
+        auto park = [&](int ck) {
+            const int t0 = ck * TS, tile = chunk * p.nt + (t0 >> 4), tb = (t0 & 15) + 4 * quad;
+            f32x4 mean = {0.f, 0.f, 0.f, 0.f}, inv = {1.f, 1.f, 1.f, 1.f};
+            if (p.ln.stats)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mean[r] = p.ln.stats[((size_t)tile * 16 + tb + r) * 2];
+                    inv[r] = p.ln.stats[((size_t)tile * 16 + tb + r) * 2 + 1];
+                }
+            float *dst = Xs + (ck & 1) * IN * CS;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int ch = j * (4 / NQ) + chs;
+                f32x4 v = pre[j];
+                if (p.ln.stats) v = (v - mean) * inv * p.ln.w[ch * p.F + f0 + i] + p.ln.b[ch * p.F + f0 + i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[ch * CS + (4 * quad + r) * 16 + i] = v[r];
+            }
+        };
+        auto flush = [&](int ck) {
+            const int t0 = ck * TS, tile = chunk * p.nt + (t0 >> 4), tb = (t0 & 15) + 4 * quad;
+            const float *src = Ys + (ck & 1) * OUTC * CS;
+            for (int o = chs; o < p.out_ch; o += 4 / NQ) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = src[o * CS + (4 * quad + r) * 16 + i];
+                if (MODE == 0) v *= *reinterpret_cast<const f32x4 *>(p.mul.ptr + ft_idx(tile, p.mul.c_total, p.mul.c_off + o, p.F, f0 + i) + tb);
+                *reinterpret_cast<f32x4 *>(p.out.ptr + ft_idx(tile, p.out.c_total, p.out.c_off + o, p.F, f0 + i) + tb) = v;
+            }
+        };
+        request(0);
+        park(0);
+        int flushed = 0;                                     // chunks [0, flushed) are written back
+        __syncthreads();
+        for (int it = 0; it < NI; ++it) {
+            const int k = it / TS, j = it - k * TS;
+            if (j == 0 && k + 1 < nck) request(k + 1);       // Xs[(k+1)&1] was last read in chunk k-1
+            if (j == 1 && k >= 1) { flush(k - 1); flushed = k; }     // every layer left chunk k-1 before this iteration
+            if (j == TS - 1 && k + 1 < nck) park(k + 1);
+            __syncthreads();
+        }
+        for (int ck = flushed; ck < nck; ++ck) flush(ck);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves (one per layer)
+    const int grow = (i & 3) * HID + (i >> 2);
+    constexpr int KI = (LAYERS == 2) ? (KI0 > MT ? KI0 : MT) : KI0;       // register array bound
+    const int ki = layer == 0 ? KI0 : MT, in_dim = layer == 0 ? IN : HID;
+    float wi[MT][KI], wh[MT][MT], bias[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = grow + 4 * mt;
+#pragma unroll
+        for (int s = 0; s < KI; ++s) wi[mt][s] = s < ki ? p.w_ih[layer][(size_t)row * in_dim + 4 * s + q] : 0.f;
+#pragma unroll
+        for (int s = 0; s < MT; ++s) wh[mt][s] = p.w_hh[layer][(size_t)row * HID + 4 * s + q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[mt][r] = p.b_ih[layer][r * HID + 4 * mt + q] + p.b_hh[layer][r * HID + 4 * mt + q];
+    }
+    float wl[OUT_MT][MT], blr[OUT_MT][4];
+#pragma unroll
+    for (int om = 0; om < OUT_MT; ++om) {
+#pragma unroll
+        for (int s = 0; s < MT; ++s) wl[om][s] = p.wl[(size_t)(om * 16 + i) * HID + 4 * s + q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) blr[om][r] = (om * 16 + 4 * q + r) < p.out_ch ? p.bl[om * 16 + 4 * q + r] : 0.f;
+    }
+    float h[MT], c[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { h[mt] = 0.f; c[mt] = 0.f; }
+    const bool last = layer == LAYERS - 1;
+    __syncthreads();                                         // chunk 0 is parked
+    for (int it = 0; it < NI; ++it) {
+        const int t = it - layer;                            // this wave's time step
+        if (t >= 0 && t < p.T) {
+            const int ck = t / TS, tl = t - ck * TS;
+            const float *xb = Xs + (ck & 1) * IN * CS + tl * 16 + i;
+            float x[KI];
+#pragma unroll
+            for (int s = 0; s < KI; ++s) {
+                x[s] = 0.f;
+                if (s < ki) x[s] = layer == 0 ? xb[(4 * s + q) * CS] : hs[(t & 1) * HID * 16 + (4 * s + q) * 16 + i];
+            }
+            f32x4 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
+#pragma unroll
+            for (int s = 0; s < KI; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wi[mt][s], x[s], acc[mt]);
+#pragma unroll
+            for (int s = 0; s < MT; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wh[mt][s], h[s], acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float ig = gate_sigmoid(acc[mt][0]), fg = gate_sigmoid(acc[mt][1]), gg = gate_tanh(acc[mt][2]), og = gate_sigmoid(acc[mt][3]);
+                c[mt] = fg * c[mt] + ig * gg;
+                h[mt] = og * gate_tanh(c[mt]);
+                if (!last) hs[(t & 1) * HID * 16 + (4 * mt + q) * 16 + i] = h[mt];
+            }
+            if (last) {
+                float *yb = Ys + (ck & 1) * OUTC * CS + tl * 16 + i;
+#pragma unroll
+                for (int om = 0; om < OUT_MT; ++om) {
+                    f32x4 y = {blr[om][0], blr[om][1], blr[om][2], blr[om][3]};
+#pragma unroll
+                    for (int s = 0; s < MT; ++s) y = mfma16(wl[om][s], h[s], y);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) yb[(om * 16 + 4 * q + r) * CS] = y[r];
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -846,14 +1002,21 @@ extern "C" int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_f
     for (int l = 0; l < 2; ++l) { p.w_ih[l] = w_ih[l]; p.w_hh[l] = w_hh[l]; p.b_ih[l] = b_ih[l]; p.b_hh[l] = b_hh[l]; }
     const unsigned grid = (unsigned)(chunks * (F / 16));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    auto lds_bytes = [](int in, int outc, int hid, int ts) { return (size_t)(2 * in * (ts * 16 + 16) + 2 * outc * (ts * 16 + 16) + 2 * hid * 16) * sizeof(float); };
+    static bool done = false;
+    if (!done) {
+        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_t_kernel<40, 20, 1, 3, 1, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        done = true;
+    }
     if (which == 0) {            // bottleneck ch_lstm: in 20, hidden 40, 2 layers, Linear 40->20, multiplied with `mul`
         VADX_REQUIRE(in->c == 20 && mul && mul->ptr, "vadx_dfsmn_lstm_t(0): in must have 20 channels and mul is required");
         p.out_ch = 20;
-        hipLaunchKernelGGL((lstm_t_kernel<20, 40, 2, 2, 0>), dim3(grid), dim3(128), 0, st, p);
+        hipLaunchKernelGGL((lstm_t_direct_kernel<20, 40, 2, 2, 0>), dim3(grid), dim3(128), 0, st, p);
     } else {                     // out_ch_lstm: in 40, hidden 20, 1 layer, Linear 20->40
         VADX_REQUIRE(in->c == 40, "vadx_dfsmn_lstm_t(1): in must have 40 channels");
         p.out_ch = 40;
-        hipLaunchKernelGGL((lstm_t_kernel<40, 20, 1, 3, 1>), dim3(grid), dim3(64), 0, st, p);
+        hipLaunchKernelGGL((lstm_t_kernel<40, 20, 1, 3, 1, 4>), dim3(grid), dim3(128), lds_bytes(40, 48, 20, 4), st, p);
     }
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;

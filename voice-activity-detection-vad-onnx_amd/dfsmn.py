@@ -21,11 +21,14 @@ def ft_tiles(frames):
 class FT:
     """A device tensor in FT layout + helpers to make channel-slice views."""
 
-    def __init__(self, torch, device, n_chunks, frames, channels, bins):
+    def __init__(self, torch, device, n_chunks, frames, channels, bins, zero=True):
+        """zero=False for intermediates that a kernel overwrites completely (all 16 columns of every tile): the MFMA
+        columns (frames) are independent, so whatever the padding frames hold never reaches a valid frame."""
         self.nt = ft_tiles(frames)
         self.tiles = n_chunks * self.nt
         self.C, self.F, self.frames = channels, bins, frames
-        self.data = torch.zeros((self.tiles, channels, bins, 16), dtype=torch.float32, device=device)
+        alloc = torch.zeros if zero else torch.empty
+        self.data = alloc((self.tiles, channels, bins, 16), dtype=torch.float32, device=device)
 
     def view(self, c_off=0, c=None):
         return _lib.FtView(self.data.data_ptr(), self.C, c_off, self.C - c_off if c is None else c)
@@ -130,7 +133,7 @@ class Iccrn:
         sc = scratch if scratch is not None else {}
         def buf(key, ch, bins):
             if key not in sc or sc[key].tiles != tiles:
-                sc[key] = FT(t, dev, n_chunks, frames, ch, bins)
+                sc[key] = FT(t, dev, n_chunks, frames, ch, bins, zero=False)
             return sc[key]
         gx, r, li, hf, lo, ceps = (buf("gx", CH, F_BINS), buf("r", CH, F_BINS), buf("li", 2 * CH, CEPS_F),
                                    buf("hf", 2 * CH, CEPS_F), buf("lo", 2 * CH, CEPS_F), buf("ceps", CH, F_BINS))
@@ -166,7 +169,7 @@ class Iccrn:
         """x4: FT (4 ch: mix re, mix im, scaled far re, scaled far im) -> Y FT (2 ch: re, im of the AEC spectrum)."""
         t, dev = self.torch, self.device
         tiles = n_chunks * ft_tiles(frames)
-        new = lambda ch, bins=F_BINS: FT(t, dev, n_chunks, frames, ch, bins)      # noqa: E731
+        new = lambda ch, bins=F_BINS: FT(t, dev, n_chunks, frames, ch, bins, zero=False)      # noqa: E731
         hf0, e0l = new(2 * CH), new(CH)
         cats = [new(2 * CH) for _ in range(5)]          # [e0|d1], [e1|d2], [e2|d3], [e3|d4], [e4|d5]
         e5, p5, d0, y = new(CH), new(CH), new(2 * CH), new(2)
