@@ -14,6 +14,14 @@
 #include <math.h>
 #include <string.h>
 
+// FR_EXP: development-only what-if switches (bit mask; results are wrong when set): 1 no FIR memory, 2 no barriers
+// inside the point-wise pairs, 4 no second (H->P) layer, 8 no first (P->H) layer, 16 no dnn / output section,
+// 32 no log-mel staging / zero fills
+#ifndef FR_EXP
+#define FR_EXP 0
+#endif
+#define FR_SYNC() do { if (!(FR_EXP & 2)) __syncthreads(); } while (0)
+
 namespace vadx {
 namespace firered {
 
@@ -28,7 +36,7 @@ constexpr int LDS_FLOATS = MEM_F + P_F + H_F;
 struct Dev {
     int R, M, H, P, N1, S1, N2, S2, odim, T, Hp, Pp;
     int off_fc1, off_fc1b, off_fc2, off_fc2b;
-    int off_lb[MAX_R], off_la[MAX_R], off_bfc1[MAX_R], off_bfc1b[MAX_R], off_bfc2[MAX_R];
+    int off_lb[MAX_R], off_la[MAX_R], off_win[MAX_R], off_bfc1[MAX_R], off_bfc1b[MAX_R], off_bfc2[MAX_R];
     int off_dnn[MAX_M], off_dnnb[MAX_M], off_out, off_outb, total;
 };
 
@@ -50,10 +58,11 @@ static int derive(const vadx_firered_cfg *c, Dev *d) {
     for (int r = 0; r < d->R; ++r) {
         d->off_lb[r] = take(d->Pp * d->N1);
         d->off_la[r] = take(d->Pp * (d->N2 > 0 ? d->N2 : 1));
+        d->off_win[r] = take(d->Pp * 40);          // merged 40-tap window c[-19..20] per channel (fast FIR path)
         if (r > 0) { d->off_bfc1[r] = take(d->Hp * d->Pp); d->off_bfc1b[r] = take(d->Hp); d->off_bfc2[r] = take(d->Pp * d->Hp); }
     }
     for (int m = 0; m < d->M; ++m) { d->off_dnn[m] = take(d->Hp * (m == 0 ? d->Pp : d->Hp)); d->off_dnnb[m] = take(d->Hp); }
-    d->off_out = take(d->odim * d->Hp); d->off_outb = take(4);
+    d->off_out = take(16 * d->Hp); d->off_outb = take(16);      // output head padded to one 16-row MFMA tile
     d->total = o;
     return 0;
 }
@@ -66,40 +75,49 @@ constexpr int MAXTAP = 32;
 // Fast path for undilated filters with <= 20 taps each (the shipped FireRedVAD/AED configs): the
 // look-back and look-ahead filters merge into one 40-tap window c[-19..20] around t; each thread slides
 // it over 28 frames held in registers -- no guards, no address math in the inner loop.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ void fsmn_memory_fast(const Dev &d, const float *__restrict__ Pk, int r, bool skip,
                                                  const float *p, float *mem) {
-    constexpr int LB = 19, LA = 20, SEG = 28, WIN = SEG + LB + LA;
-    const int ch = threadIdx.x >> 2, part = threadIdx.x & 3;
+    // thread = (channel PAIR, eighth of the window): both channels ride in the two halves of v_pk_fma_f32 operands
+    // (twice the f32 FMA rate of the scalar form; the per-channel summation order is unchanged).
+    constexpr int LB = 19, LA = 20, SEG = 14, WIN = SEG + LB + LA;
+    const int cp = threadIdx.x >> 3, part = threadIdx.x & 7, ch = 2 * cp;
     if (ch >= d.Pp) return;
-    float c[LB + 1 + LA];                       // c[j + LB], j = -19..20 ; c[LB] (j = 0) unused
+    f32x2 c[LB + 1 + LA];                       // c[j + LB], j = -19..20 ; c[LB] (j = 0) unused (zero)
+    {   const f32x4 *w0 = reinterpret_cast<const f32x4 *>(Pk + d.off_win[r] + ch * 40), *w1 = w0 + 10;      // merged at pack time
 #pragma unroll
-    for (int j = -LB; j <= LA; ++j) {
-        float v = 0.f;
-        if (j <= 0) { const int k = j + d.N1 - 1; if (k >= 0 && k < d.N1) v = Pk[d.off_lb[r] + ch * d.N1 + k]; }
-        else if (d.N2 > 0 && d.T > 1) { const int k = j - 1; if (k < d.N2) v = Pk[d.off_la[r] + ch * d.N2 + k]; }
-        c[j + LB] = v;
+        for (int g = 0; g < 10; ++g) {
+            const f32x4 a4 = w0[g], b4 = w1[g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[4 * g + e] = f32x2{a4[e], b4[e]};
+        }
     }
-    const float *row = p + ch * M_LD;
+    const float *row0 = p + ch * M_LD, *row1 = row0 + M_LD;
     const int t0 = part * SEG;
-    float win[WIN];
+    f32x2 win[WIN];
 #pragma unroll
     for (int u = 0; u < WIN; ++u) {
         const int t = t0 - LB + u;
-        win[u] = (t >= 0 && t < d.T) ? row[t] : 0.f;
+        const bool in = t >= 0 && t < d.T;
+        const int tc = t < 0 ? 0 : (t > MAX_T - 1 ? MAX_T - 1 : t);      // unconditional loads (clamped) + select:
+        const float v0 = row0[tc], v1 = row1[tc];                          // a guarded load costs a branch and a wait each
+        win[u] = f32x2{in ? v0 : 0.f, in ? v1 : 0.f};
     }
 #pragma unroll
     for (int u = 0; u < SEG; ++u) {
         const int t = t0 + u;
-        float lb = 0.f, la = 0.f;
+        f32x2 lb = {0.f, 0.f}, la = {0.f, 0.f};
 #pragma unroll
-        for (int j = -LB; j <= 0; ++j) lb = fmaf(c[j + LB], win[u + LB + j], lb);      // same order as the generic path
+        for (int j = -LB; j <= 0; ++j) lb = __builtin_elementwise_fma(c[j + LB], win[u + LB + j], lb);      // same order as the generic path
 #pragma unroll
-        for (int j = 1; j <= LA; ++j) la = fmaf(c[j + LB], win[u + LB + j], la);
-        if (t < d.T) {
-            float s2 = (win[u + LB] + lb) + la;
-            if (skip) s2 += mem[ch * M_LD + t];
-            mem[ch * M_LD + t] = s2;
-        }
+        for (int j = 1; j <= LA; ++j) la = __builtin_elementwise_fma(c[j + LB], win[u + LB + j], la);
+        // frames t >= T (< MAX_T) are inside the row: computing / storing them unconditionally is harmless (the next
+        // layer's columns are independent and p is zero there) and keeps the loop branch-free
+        f32x2 s2 = (win[u + LB] + lb) + la;
+        if (skip) s2 += f32x2{mem[ch * M_LD + t], mem[(ch + 1) * M_LD + t]};
+        mem[ch * M_LD + t] = s2[0];
+        mem[(ch + 1) * M_LD + t] = s2[1];
     }
 }
 
@@ -138,7 +156,8 @@ __device__ __forceinline__ void fsmn_memory_generic(const Dev &d, const float *_
 }
 
 __device__ __forceinline__ void fsmn_memory(const Dev &d, const float *__restrict__ Pk, int r, bool skip, const float *p, float *mem) {
-    if (d.S1 == 1 && d.N1 <= 20 && (d.N2 == 0 || d.S2 == 1) && d.N2 <= 20 && d.T <= 112) fsmn_memory_fast(d, Pk, r, skip, p, mem);
+    if (FR_EXP & 1) return;
+    if (d.S1 == 1 && d.N1 <= 20 && (d.N2 == 0 || d.S2 == 1) && d.N2 <= 20 && d.T > 1 && d.T <= 112 && d.Pp <= 128) fsmn_memory_fast(d, Pk, r, skip, p, mem);
     else fsmn_memory_generic(d, Pk, r, skip, p, mem);
 }
 
@@ -148,12 +167,12 @@ __device__ __forceinline__ void pointwise_pair(const Dev &d, const float *W1, co
     for (int f0 = 0; f0 < d.T; f0 += 32) {
         const bool half = (d.T - f0) <= 16;
         LayerArgs a{W1, k1b * 16, d.Hp / 16, 1, k1b, 0, 0, b1, 1, src, M_LD, f0, h, H_LD, 0, nullptr, nullptr};
-        if (half) layer<1, false>(a); else layer<2, false>(a);
-        __syncthreads();
-        if (W2) {
+        if (!(FR_EXP & 8)) { if (half) layer<1, false>(a); else layer<2, false>(a); }
+        FR_SYNC();
+        if (W2 && !(FR_EXP & 4)) {
             LayerArgs c{W2, d.Hp, d.Pp / 16, 1, d.Hp / 16, 0, 0, b2, relu2, h, H_LD, 0, dst, M_LD, f0, nullptr, nullptr};
             if (half) layer<1, false>(c); else layer<2, false>(c);
-            __syncthreads();
+            FR_SYNC();
         }
     }
 }
@@ -163,28 +182,35 @@ __global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *mem = lds, *p = lds + MEM_F, *h = p + P_F;
     const int tid = threadIdx.x;
+    long long tk0 = clock64(), tk_fir = 0, tk_pw = 0, tk_x;      // FR_EXP & 64: cycle accounting (development)
     const float *lm = logmel + (size_t)blockIdx.x * d.T * NMEL;
     // stage log-mel channel-first into `mem` rows 0..79; frames >= T are zero (finite operands)
-    for (int e = tid; e < MAX_T * NMEL; e += THREADS) {
+    for (int e = tid; e < ((FR_EXP & 32) ? 0 : MAX_T * NMEL); e += THREADS) {
         const int t = e / NMEL, mel = e - t * NMEL;
         mem[mel * M_LD + t] = t < d.T ? lm[(size_t)t * NMEL + mel] : 0.f;
     }
-    for (int e = tid; e < MAXP * M_LD; e += THREADS) p[e] = 0.f;
+    for (int e = tid; e < ((FR_EXP & 32) ? 0 : MAXP * M_LD); e += THREADS) p[e] = 0.f;
     __syncthreads();
     // dfsmn.fc1 (80->H, ReLU) ; dfsmn.fc2 (H->P, bias, ReLU) ; fsmn1
     pointwise_pair(d, Pk + d.off_fc1, Pk + d.off_fc1b, NMEL / 16, mem, Pk + d.off_fc2, Pk + d.off_fc2b, 1, p, h);
-    for (int e = tid; e < MAXP * M_LD; e += THREADS) mem[e] = 0.f;        // log-mel rows are dead now
+    for (int e = tid; e < ((FR_EXP & 32) ? 0 : MAXP * M_LD); e += THREADS) mem[e] = 0.f;        // log-mel rows are dead now
     __syncthreads();
+    tk_x = clock64();
     fsmn_memory(d, Pk, 0, false, p, mem);
     __syncthreads();
+    tk_fir += clock64() - tk_x;
     for (int r = 1; r < d.R; ++r) {      // DFSMNBlock: fc1 (P->H, ReLU) ; fc2 (H->P, no bias) ; fsmn + skip
+        tk_x = clock64();
         pointwise_pair(d, Pk + d.off_bfc1[r], Pk + d.off_bfc1b[r], d.Pp / 16, mem, Pk + d.off_bfc2[r], nullptr, 0, p, h);
+        tk_pw += clock64() - tk_x;
+        tk_x = clock64();
         fsmn_memory(d, Pk, r, true, p, mem);
         __syncthreads();
+        tk_fir += clock64() - tk_x;
     }
     // dnns (P->H ReLU, then M-1 x H->H ReLU) and the 1x1 output conv + sigmoid, tile by tile
     float *h2 = p;                        // p is dead: second H-tile buffer for M > 1
-    for (int f0 = 0; f0 < d.T; f0 += 32) {
+    for (int f0 = 0; f0 < ((FR_EXP & 16) ? 0 : d.T); f0 += 32) {
         const bool half = (d.T - f0) <= 16;
         LayerArgs a{Pk + d.off_dnn[0], d.Pp, d.Hp / 16, 1, d.Pp / 16, 0, 0, Pk + d.off_dnnb[0], 1, mem, M_LD, f0, h, H_LD, 0, nullptr, nullptr};
         if (half) layer<1, false>(a); else layer<2, false>(a);
@@ -196,17 +222,20 @@ __global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float 
             __syncthreads();
             float *tmp = cur; cur = nxt; nxt = tmp;
         }
+        // output head (odim <= 4 rows, zero padded to one MFMA tile) -> logits in `lg`, then sigmoid
+        float *lg = p + MAXH * H_LD;            // behind h2
+        {   LayerArgs o{Pk + d.off_out, d.Hp, 1, 1, d.Hp / 16, 0, 0, Pk + d.off_outb, 0, cur, H_LD, 0, lg, H_LD, 0, nullptr, nullptr};
+            if (half) layer<1, false>(o); else layer<2, false>(o); }
+        __syncthreads();
         if (tid < 32 * d.odim) {
             const int t = tid & 31, o = tid >> 5;
-            if (f0 + t < d.T) {
-                const float *wo = Pk + d.off_out + o * d.Hp;
-                float s = 0.f;
-                for (int c2 = 0; c2 < d.H; ++c2) s = fmaf(wo[c2], cur[c2 * H_LD + t], s);
-                s += Pk[d.off_outb + o];
-                probs[((size_t)blockIdx.x * d.odim + o) * d.T + f0 + t] = sigmoidf_(s);
-            }
+            if (f0 + t < d.T) probs[((size_t)blockIdx.x * d.odim + o) * d.T + f0 + t] = sigmoidf_(lg[o * H_LD + t]);
         }
         __syncthreads();
+    }
+    if ((FR_EXP & 64) && tid == 0) {
+        float *dbg = probs + (size_t)blockIdx.x * d.odim * d.T;
+        dbg[0] = (float)tk_fir; dbg[1] = (float)tk_pw; dbg[2] = (float)(clock64() - tk0);
     }
 }
 
@@ -274,15 +303,13 @@ __global__ __launch_bounds__(THREADS, 2) void firered_stream_kernel(Dev d, const
             __syncthreads();
             float *tmp = cur; cur = nxt; nxt = tmp;
         }
+        float *lg = p + MAXH * H_LD;            // behind h2
+        {   LayerArgs o{Pk + d.off_out, d.Hp, 1, 1, d.Hp / 16, 0, 0, Pk + d.off_outb, 0, cur, H_LD, 0, lg, H_LD, 0, nullptr, nullptr};
+            if (half) layer<1, false>(o); else layer<2, false>(o); }
+        __syncthreads();
         if (tid < 32 * d.odim) {
             const int t = tid & 31, o = tid >> 5;
-            if (f0 + t < d.T) {
-                const float *wo = Pk + d.off_out + o * d.Hp;
-                float s2 = 0.f;
-                for (int c2 = 0; c2 < d.H; ++c2) s2 = fmaf(wo[c2], cur[c2 * H_LD + t], s2);
-                s2 += Pk[d.off_outb + o];
-                probs[((size_t)b * d.odim + o) * d.T + f0 + t] = sigmoidf_(s2);
-            }
+            if (f0 + t < d.T) probs[((size_t)b * d.odim + o) * d.T + f0 + t] = sigmoidf_(lg[o * H_LD + t]);
         }
         __syncthreads();
     }
@@ -415,6 +442,11 @@ extern "C" int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_fi
         VADX_REQUIRE(w->fsmn_lb[r] && (d.N2 == 0 || w->fsmn_la[r]), "vadx_firered_pack_host: NULL FSMN filter %d", r);
         memcpy(p + d.off_lb[r], w->fsmn_lb[r], (size_t)d.P * d.N1 * sizeof(float));
         if (d.N2 > 0) memcpy(p + d.off_la[r], w->fsmn_la[r], (size_t)d.P * d.N2 * sizeof(float));
+        if (d.N1 <= 20 && d.N2 <= 20)          // look-back taps end at j = 0 (slot 19), look-ahead taps start at j = 1 (slot 20)
+            for (int ch = 0; ch < d.P; ++ch) {
+                for (int k = 0; k < d.N1; ++k) p[d.off_win[r] + ch * 40 + 19 - (d.N1 - 1) + k] = w->fsmn_lb[r][(size_t)ch * d.N1 + k];
+                for (int k = 0; k < d.N2; ++k) p[d.off_win[r] + ch * 40 + 20 + k] = w->fsmn_la[r][(size_t)ch * d.N2 + k];
+            }
         if (r > 0) {
             VADX_REQUIRE(w->blk_fc1_w[r] && w->blk_fc1_b[r] && w->blk_fc2_w[r], "vadx_firered_pack_host: NULL block %d weight", r);
             mat(d.off_bfc1[r], w->blk_fc1_w[r], d.H, d.P, d.Pp); memcpy(p + d.off_bfc1b[r], w->blk_fc1_b[r], d.H * sizeof(float));
@@ -427,7 +459,8 @@ extern "C" int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_fi
         memcpy(p + d.off_dnnb[m], w->dnn_b[m], d.H * sizeof(float));
     }
     mat(d.off_out, w->out_w, d.odim, d.H, d.Hp); memcpy(p + d.off_outb, w->out_b, d.odim * sizeof(float));
-    // GEMM operands go fragment-major (common.h); the FIR taps and the tiny output head stay row-major (VALU)
+    // GEMM operands go fragment-major (common.h); the FIR taps stay row-major (VALU)
+    vadx::frag_major_inplace(p + d.off_out, 16, d.Hp);
     vadx::frag_major_inplace(p + d.off_fc1, d.Hp, NMEL);
     vadx::frag_major_inplace(p + d.off_fc2, d.Pp, d.Hp);
     for (int r = 1; r < d.R; ++r) {

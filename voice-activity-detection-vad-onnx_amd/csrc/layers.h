@@ -4,7 +4,7 @@
 
 namespace vadx {
 
-constexpr int LAYER_NW = 8;   // waves per workgroup assumed by layer<>
+// layer<> spreads its work items over all waves of the workgroup (blockDim.x / 64)
 
 struct LayerArgs {
     const float *W; int ldw, ntiles;      // W fragment-major (common.h), ldw = its padded K
@@ -20,6 +20,7 @@ struct LayerArgs {
 template <int MTT, bool AFFINE>
 __device__ __forceinline__ void layer(const LayerArgs &a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    const int LAYER_NW = blockDim.x >> 6;
     if (a.ntiles % LAYER_NW == 0) {
         for (int nt = wave; nt < a.ntiles; nt += LAYER_NW) {
             f32x4 acc[1][MTT];
