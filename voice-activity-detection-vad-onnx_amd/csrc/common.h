@@ -126,21 +126,21 @@ __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, 
     const float *ap = act + (4 * q) * lda + i;
     f32x4 w0[NT], w1[NT];
     float a0[4][MT], a1[4][MT];
-    auto fetch = [&](int S, f32x4 (&w)[NT], float (&a)[4][MT]) {
+    f32x4 ad0 = {0.f, 0.f, 0.f, 0.f}, ml0 = {1.f, 1.f, 1.f, 1.f}, ad1 = ad0, ml1 = ml0;      // AFFINE terms ride the same pipeline
+    auto fetch = [&](int S, f32x4 (&w)[NT], float (&a)[4][MT], f32x4 &ad, f32x4 &ml) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + FRAG * S);
+        if (AFFINE) {
+            ad = *reinterpret_cast<const f32x4 *>(add + 16 * S + 4 * q);
+            ml = *reinterpret_cast<const f32x4 *>(mul + 16 * S + 4 * q);
+        }
         const float *aps = ap + 16 * S * lda;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[j][mt] = aps[j * lda + moff[mt]];
     };
-    auto compute = [&](int S, const f32x4 (&w)[NT], const float (&a)[4][MT]) {
-        f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, m4 = {1.f, 1.f, 1.f, 1.f};
-        if (AFFINE) {
-            a4 = *reinterpret_cast<const f32x4 *>(add + 16 * S + 4 * q);
-            m4 = *reinterpret_cast<const f32x4 *>(mul + 16 * S + 4 * q);
-        }
+    auto compute = [&](const f32x4 (&w)[NT], const float (&a)[4][MT], const f32x4 &a4, const f32x4 &m4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float av[MT];
@@ -158,15 +158,15 @@ __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, 
             }
         }
     };
-    fetch(0, w0, a0);
+    fetch(0, w0, a0, ad0, ml0);
     for (int S = 0; S < kb; S += 2) {
-        fetch(S + 1 < kb ? S + 1 : S, w1, a1);
+        fetch(S + 1 < kb ? S + 1 : S, w1, a1, ad1, ml1);
         __builtin_amdgcn_sched_barrier(0);      // next block's operands stay ahead of this block's MFMAs
-        compute(S, w0, a0);
+        compute(w0, a0, ad0, ml0);
         if (S + 1 < kb) {
-            fetch(S + 2 < kb ? S + 2 : S + 1, w0, a0);
+            fetch(S + 2 < kb ? S + 2 : S + 1, w0, a0, ad0, ml0);
             __builtin_amdgcn_sched_barrier(0);
-            compute(S + 1, w1, a1);
+            compute(w1, a1, ad1, ml1);
         }
     }
 }

@@ -17,6 +17,24 @@
 #include <math.h>
 #include <string.h>
 
+// FS_EXP: development-only cycle accounting (tools/exp_fsmn.py): per-section clock64 sums of thread 0, all workgroups
+#ifndef FS_EXP
+#define FS_EXP 0
+#endif
+#if FS_EXP
+__device__ unsigned long long fsmn_dbg[16];
+#define FS_T0() long long fs_t_ = clock64()
+#define FS_ACC(slot) do { if (threadIdx.x == 0) { const long long n_ = clock64(); atomicAdd(&fsmn_dbg[slot], (unsigned long long)(n_ - fs_t_)); fs_t_ = n_; } } while (0)
+extern "C" int vadx_fsmn_debug_cycles(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fsmn_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(fsmn_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define FS_T0() do {} while (0)
+#define FS_ACC(slot) do {} while (0)
+#endif
+
 namespace vadx {
 namespace fsmn {
 
@@ -72,6 +90,7 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
     const int tid = threadIdx.x;
     constexpr int NF = MTT * 16;
 
+    FS_T0();
     // ---- stage log-mel with LFR edge replication: bufB[mel][c] = lm[clamp(f0 + c - 2, 0, T-1)][mel]
     for (int e = tid; e < (NF + 4) * NMEL; e += THREADS) {
         const int c = e / NMEL, mel = e - c * NMEL;
@@ -80,6 +99,7 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
         bufB[mel * A_LD + c] = lm[(size_t)fr * NMEL + mel];
     }
     __syncthreads();
+    FS_ACC(0);
 
     LayerArgs a;
     // in_linear1: K = 5 passes x 80 (LFR concat: frame offset j -> column offset j), CMVN on the operand
@@ -87,11 +107,13 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
                   bufB, A_LD, 0, bufP, A_LD, 0, Pk + d.off_mean, Pk + d.off_var};
     layer<MTT, true>(a);
     __syncthreads();
+    FS_ACC(1);
     // in_linear2 + ReLU
     a = LayerArgs{Pk + d.off_in2, d.Ap, d.Lp / 16, 1, d.Ap / 16, 0, 0, Pk + d.off_b2, 1,
                   bufP, A_LD, 0, bufA, A_LD, 0, nullptr, nullptr};
     layer<MTT, false>(a);
     __syncthreads();
+    FS_ACC(2);
 
     for (int l = 0; l < NLAYER; ++l) {
         // history columns 1..19 of bufP <- cache (previous tile / previous chunk)
@@ -99,10 +121,12 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
             const int ch = e / HIST, h = e - ch * HIST;
             bufP[ch * P_LD + 1 + h] = cin[l][e];
         }
+        FS_ACC(3);
         a = LayerArgs{Pk + d.off_lin[l], d.Lp, PROJ / 16, 1, d.Lp / 16, 0, 0, nullptr, 0,
                       bufA, A_LD, 0, bufP, P_LD, P_CUR, nullptr, nullptr};
         layer<MTT, false>(a);
         __syncthreads();
+        FS_ACC(4);
         {   // FIR + skip: thread = (channel, quarter of the tile's frames)
             const int ch = tid >> 2, fq = tid & 3;
             constexpr int FPT = NF / 4;
@@ -128,10 +152,12 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
             }
         }
         __syncthreads();
+        FS_ACC(5);
         a = LayerArgs{Pk + d.off_aff[l], PROJ, d.Lp / 16, 1, PROJ / 16, 0, 0, Pk + d.off_baff[l], 1,
                       bufB, A_LD, 0, bufA, A_LD, 0, nullptr, nullptr};
         layer<MTT, false>(a);
         __syncthreads();
+        FS_ACC(6);
     }
     a = LayerArgs{Pk + d.off_out1, d.Lp, d.A2p / 16, 1, d.Lp / 16, 0, 0, Pk + d.off_bo1, 0,
                   bufA, A_LD, 0, bufB, A_LD, 0, nullptr, nullptr};
@@ -142,6 +168,7 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
     layer<MTT, false>(a);
     __syncthreads();
 
+    FS_ACC(7);
     // ---- softmax over the O logits of each frame, keep class 0: thread = (part 0..7, frame 0..63)
     {
         const int m = tid & 63, part = tid >> 6;
@@ -165,6 +192,7 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
         }
         __syncthreads();
     }
+    FS_ACC(8);
 }
 
 // score gate of one chunk (FSMN/Export_FSMN_VAD.py:87-101): returns noisy_dB (NaN if no frame is "noise")

@@ -15,52 +15,52 @@ struct LayerArgs {
     const float *add, *mul;               // CMVN (AFFINE only)
 };
 
-// dst[n][m] = act[k][m] x W[n][k] (+bias, ReLU).  Work items: whole n-tiles (all m-tiles of the tile)
-// when the n-tile count fills the 8 waves evenly, otherwise (n-tile, m-tile) pairs.
+// dst[n][m] = act[k][m] x W[n][k] (+bias, ReLU).  Work items: whole n-tiles (all MTT m-tiles of the tile share each
+// weight fragment) for as many rounds as fill every wave; the remaining n-tiles are split into (n-tile, m-tile) pairs.
+// (A layer with 9 n-tiles on 8 waves used to run entirely as 36 single-tile items: one dependent MFMA chain per
+// weight load, i.e. latency-bound -- FSMN's in_linear1 took 20 % of the kernel for 13 % of its MFMAs.)
 template <int MTT, bool AFFINE>
 __device__ __forceinline__ void layer(const LayerArgs &a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
-    const int LAYER_NW = blockDim.x >> 6;
-    if (a.ntiles % LAYER_NW == 0) {
-        for (int nt = wave; nt < a.ntiles; nt += LAYER_NW) {
-            f32x4 acc[1][MTT];
+    const int NW = blockDim.x >> 6;
+    const int full = (a.ntiles / NW) * NW;
+    for (int nt = wave; nt < full; nt += NW) {
+        f32x4 acc[1][MTT];
 #pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float *row = frag_ptr(a.W, a.ldw, nt, 0, lane);
-            for (int ps = 0; ps < a.npass; ++ps) {
-                const float *const wrow[1] = {row + ps * a.kstep * 16};
-                int moff[MTT];
+        for (int mt = 0; mt < MTT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *row = frag_ptr(a.W, a.ldw, nt, 0, lane);
+        for (int ps = 0; ps < a.npass; ++ps) {
+            const float *const wrow[1] = {row + ps * a.kstep * 16};
+            int moff[MTT];
 #pragma unroll
-                for (int mt = 0; mt < MTT; ++mt) moff[mt] = a.acol0 + mt * 16 + ps * a.cstep;
-                gemm_rt<1, MTT, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
-                                               AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
-            }
-            const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) {
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = acc[0][mt][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
-                *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i) * a.ldd + a.dcol0 + mt * 16 + 4 * q) = v;
-            }
+            for (int mt = 0; mt < MTT; ++mt) moff[mt] = a.acol0 + mt * 16 + ps * a.cstep;
+            gemm_rt<1, MTT, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
+                                           AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
         }
-    } else {
-        for (int item = wave; item < a.ntiles * MTT; item += LAYER_NW) {
-            const int nt = item / MTT, mt = item - nt * MTT;
-            f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-            const float *row = frag_ptr(a.W, a.ldw, nt, 0, lane);
-            for (int ps = 0; ps < a.npass; ++ps) {
-                const float *const wrow[1] = {row + ps * a.kstep * 16};
-                const int moff[1] = {a.acol0 + mt * 16 + ps * a.cstep};
-                gemm_rt<1, 1, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
-                                             AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
-            }
-            const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
+        const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
             f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = acc[0][0][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
+            for (int r = 0; r < 4; ++r) { v[r] = acc[0][mt][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
             *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i) * a.ldd + a.dcol0 + mt * 16 + 4 * q) = v;
         }
+    }
+    for (int item = wave; item < (a.ntiles - full) * MTT; item += NW) {
+        const int nt = full + item / MTT, mt = item - (item / MTT) * MTT;
+        f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+        const float *row = frag_ptr(a.W, a.ldw, nt, 0, lane);
+        for (int ps = 0; ps < a.npass; ++ps) {
+            const float *const wrow[1] = {row + ps * a.kstep * 16};
+            const int moff[1] = {a.acol0 + mt * 16 + ps * a.cstep};
+            gemm_rt<1, 1, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
+                                         AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
+        }
+        const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[0][0][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
+        *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i) * a.ldd + a.dcol0 + mt * 16 + 4 * q) = v;
     }
 }
 
