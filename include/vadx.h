@@ -339,6 +339,16 @@ int vadx_dfsmn_vote(const float *vad, int batch, int windows, int frames, int lo
 /* ---------------------------------------------------------------------------------------------
  * Test hooks (used by tests/ only)
  * ------------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------
+ * Audio ingest: the reference drivers' pydub chain set_channels(1).set_frame_rate(r)
+ * (FSMN/Inference_FSMN_VAD_ONNX.py:68 and the other four drivers) = audioop.tomono(0.5, 0.5) + audioop.ratecv,
+ * bit-exact on 16-bit PCM.  src: batch rows of frames_in interleaved frames (1 or 2 channels), row stride in
+ * int16 elements; dst: batch rows of vadx_ingest_out_frames(frames_in, in_rate, out_rate) mono samples.
+ * ------------------------------------------------------------------------------------------- */
+int64_t vadx_ingest_out_frames(int64_t frames_in, int in_rate, int out_rate);
+int vadx_ingest_pcm16(const int16_t *src, int64_t src_stride, int channels, int64_t frames_in, int in_rate,
+                      int out_rate, int16_t *dst, int64_t dst_stride, int batch, void *stream);
+
 /* Weight layout of every GEMM operand the kernels stream from L2 ("fragment-major"): a row-major
  * [rows][cols] matrix, zero-padded to multiples of 16 both ways, stored as
  * [rows/16 tiles][cols/16 blocks][64 lanes][4]: the float4 of (tile, block S, lane 16q+i) holds

@@ -92,3 +92,26 @@ def test_firered_stream_on_vad_sample():
     smooth = (csum[k] - csum[np.maximum(k - 5, 0)]) / np.minimum(k, 5)
     if np.min(np.abs(smooth - 0.3)) > 1e-3:
         assert got == want
+
+
+@pytest.mark.parametrize("ch,in_rate,out_rate,n", [(2, 48000, 16000, 100001), (1, 44100, 16000, 50000), (1, 8000, 16000, 7777),
+                                                   (2, 22050, 16000, 30001), (1, 16000, 16000, 1000)])
+def test_device_ingest_matches_audioop(ch, in_rate, out_rate, n):
+    """Stereo down-mix + resampling on the GPU, bit-exact against the stdlib audioop (= pydub's arithmetic), batched."""
+    import audioop
+    x = np.random.default_rng(n).integers(-32768, 32768, (3, n * ch)).astype(np.int16)
+    got = audio_io.ingest_device(x, ch, in_rate, out_rate).cpu().numpy()
+    for b in range(3):
+        data = x[b].tobytes()
+        if ch == 2:
+            data = audioop.tomono(data, 2, 0.5, 0.5)
+        if in_rate != out_rate:
+            data, _ = audioop.ratecv(data, 2, 1, in_rate, out_rate, None)
+        assert np.array_equal(got[b], np.frombuffer(data, dtype=np.int16)), b
+
+
+def test_device_ingest_on_vad_sample():
+    raw, nch, rate = audio_io.read_wav_raw(WAV)
+    assert (nch, rate) == (2, 48000)
+    got = audio_io.ingest_device(raw, nch, rate)[0].cpu().numpy()
+    assert np.array_equal(got, audio_io.load_wav(WAV)) and got.shape == (89431,)

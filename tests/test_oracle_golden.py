@@ -285,3 +285,19 @@ def test_dfsmn_hostloop(golden):
         flags, silence = od.tail_flags(scores[-1], 51 - 15, 51, silence)
         saved += flags
         assert np.array_equal(np.array(saved, bool), g[f"saved_{c}"]), c
+
+
+# ------------------------------------------------------------------ f3: audio ingest (pydub = audioop tomono + ratecv)
+@pytest.mark.parametrize("ch,in_rate,out_rate,n", [(2, 48000, 16000, 10001), (1, 44100, 16000, 5000), (1, 8000, 16000, 777),
+                                                   (2, 22050, 16000, 3001), (1, 16000, 16000, 100), (1, 48000, 16000, 1)])
+def test_ingest_oracle_matches_audioop(ch, in_rate, out_rate, n):
+    """The restatement is pinned against the stdlib audioop itself (what pydub calls in every reference driver)."""
+    import audioop
+    from oracle import ingest as oing
+    x = np.random.default_rng(n).integers(-32768, 32768, n * ch).astype(np.int16)
+    data = x.tobytes()
+    if ch == 2:
+        data = audioop.tomono(data, 2, 0.5, 0.5)
+    if in_rate != out_rate:
+        data, _ = audioop.ratecv(data, 2, 1, in_rate, out_rate, None)
+    assert np.array_equal(oing.ingest(x, ch, in_rate, out_rate), np.frombuffer(data, dtype=np.int16))

@@ -117,6 +117,8 @@ SIGNATURES = {
     "vadx_firered_packed_floats": (_Z, [C.POINTER(FireRedCfg)]),
     "vadx_firered_pack_host": (_I, [C.POINTER(FireRedCfg), C.POINTER(FireRedWeightsHost), _P]),
     "vadx_firered_run": (_I, [C.POINTER(FireRedCfg), _P, _P, _I, _P, _P]),
+    "vadx_ingest_out_frames": (C.c_int64, [C.c_int64, _I, _I]),
+    "vadx_ingest_pcm16": (_I, [_P, C.c_int64, _I, C.c_int64, _I, _I, _P, C.c_int64, _I, _P]),
     "vadx_frag_major_floats": (C.c_size_t, [_I, _I]),
     "vadx_frag_major_host": (_I, [_P, _I, _I, _P]),
     "vadx_firered_stream_run": (_I, [C.POINTER(FireRedCfg), _P, _P, _I, _P, _P, _P, _P]),
