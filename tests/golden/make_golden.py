@@ -488,6 +488,53 @@ def gen_firered_stream():
     save("firered_stream", **out)
 
 
+def gen_firered_ckpt():
+    print("FireRed checkpoint path: load_cmvn + DetectModel.from_pretrained (CMVN fused into fc1)")
+    import tempfile
+    ns = {"torch": torch, "math": __import__("math"), "np": np}
+    R.select_nodes("FireRedVAD/Export_FireRedVAD.py", {"FSMN", "DFSMNBlock", "DFSMN", "DetectModel", "load_cmvn"}, ns)
+    cfg = dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=1, N2=4, S2=1, odim=3)
+    w = weights.firered_synthetic(21, cfg)
+    rng = np.random.default_rng(21)
+    dim, count = cfg["idim"], 123456.0
+    mean = rng.normal(12.0, 3.0, dim)
+    var = rng.uniform(0.5, 9.0, dim)
+    stats = np.zeros((2, dim + 1), dtype=np.float64)
+    stats[0, :dim], stats[0, dim] = mean * count, count
+    stats[1, :dim] = (var + mean * mean) * count
+    # kaldiio is not installed: the reference only uses it to fetch the statistics matrix
+    sys.modules["kaldiio"].load_mat = lambda _path: stats.copy()
+    means, inv_std = ns["load_cmvn"]("unused")
+    state = checkpoint_state(w, cfg)
+    d = tempfile.mkdtemp()
+    torch.save({"args": types.SimpleNamespace(**cfg), "model_state_dict": state}, os.path.join(d, "model.pth.tar"))
+    model = ns["DetectModel"].from_pretrained(d, means, inv_std)
+    sd = model.state_dict()
+    save("firered_ckpt", stats=stats, means=means.numpy(), inv_std=inv_std.numpy(),
+         fc1_w=sd["dfsmn.fc1.0.weight"][:, :, 0].numpy(), fc1_b=sd["dfsmn.fc1.0.bias"].numpy(),
+         blk1_fc2_w=sd["dfsmn.fsmns.0.fc2.weight"][:, :, 0].numpy(), fsmn2_la=sd["dfsmn.fsmns.1.fsmn.lookahead_filter.weight"][:, 0, :].numpy(),
+         dnn1_w=sd["dfsmn.dnns.2.weight"][:, :, 0].numpy(), out_w=sd["out.weight"][:, :, 0].numpy())
+
+
+def checkpoint_state(w, cfg):
+    """A FireRed `model_state_dict` as the training code saves it (Linear weights 2-D, FIR filters [P,1,N])."""
+    sd = {"dfsmn.fc1.0.weight": w["fc1_w"], "dfsmn.fc1.0.bias": w["fc1_b"], "dfsmn.fc2.0.weight": w["fc2_w"],
+          "dfsmn.fc2.0.bias": w["fc2_b"], "dfsmn.fsmn1.lookback_filter.weight": w["fsmn0_lb"][:, None, :],
+          "out.weight": w["out_w"], "out.bias": w["out_b"]}
+    if cfg["N2"] > 0:
+        sd["dfsmn.fsmn1.lookahead_filter.weight"] = w["fsmn0_la"][:, None, :]
+    for r in range(1, cfg["R"]):
+        p = f"dfsmn.fsmns.{r - 1}."
+        sd[p + "fc1.0.weight"], sd[p + "fc1.0.bias"] = w[f"blk{r}_fc1_w"], w[f"blk{r}_fc1_b"]
+        sd[p + "fc2.weight"] = w[f"blk{r}_fc2_w"]
+        sd[p + "fsmn.lookback_filter.weight"] = w[f"fsmn{r}_lb"][:, None, :]
+        if cfg["N2"] > 0:
+            sd[p + "fsmn.lookahead_filter.weight"] = w[f"fsmn{r}_la"][:, None, :]
+    for m in range(cfg["M"]):
+        sd[f"dfsmn.dnns.{2 * m}.weight"], sd[f"dfsmn.dnns.{2 * m}.bias"] = w[f"dnn{m}_w"], w[f"dnn{m}_b"]
+    return {k: T(v) for k, v in sd.items()}
+
+
 # ------------------------------------------------------------------------------------ DFSMN near+far
 def gen_dfsmn():
     print("DFSMN_VAD wrapper + ICCRN + UniDeepFsmn (near+far)")
@@ -614,7 +661,7 @@ def gen_marblenet_fold():
 if __name__ == "__main__":
     which = set(sys.argv[1:])
     gens = dict(stft=gen_stft, host=gen_host, vadpost=gen_vadpost, silero_host=gen_silero_host,
-                fsmn=gen_fsmn, firered=gen_firered, firered_stream=gen_firered_stream, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn)
+                fsmn=gen_fsmn, firered=gen_firered, firered_stream=gen_firered_stream, firered_ckpt=gen_firered_ckpt, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn)
     for name, fn in gens.items():
         if not which or name in which:
             fn()

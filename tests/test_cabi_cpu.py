@@ -110,3 +110,40 @@ def test_wav_ingest_matches_reference_sample_length():
     a = audio_io.load_wav(os.path.join(ROOT, "tests", "golden", "vad_sample.wav"))
     assert a.dtype == np.int16 and a.shape == (89431,)
     assert int(np.abs(a).max()) == 4220
+
+
+def test_firered_checkpoint_loader_matches_reference(golden, tmp_path):
+    """model.pth.tar + cmvn.ark -> engine weight dict, against what the reference's load_cmvn + DetectModel.from_pretrained
+    produce from the same files (tests/golden/make_golden.py: gen_firered_ckpt).  Pure host code."""
+    import types
+
+    import torch
+
+    from vadx import checkpoints as ck
+    g = golden("firered_ckpt")
+    cfg = dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=1, N2=4, S2=1, odim=3)
+    w = weights.firered_synthetic(21, cfg)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))      # noqa: E731
+    sd = {"dfsmn.fc1.0.weight": w["fc1_w"], "dfsmn.fc1.0.bias": w["fc1_b"], "dfsmn.fc2.0.weight": w["fc2_w"],
+          "dfsmn.fc2.0.bias": w["fc2_b"], "dfsmn.fsmn1.lookback_filter.weight": w["fsmn0_lb"][:, None, :],
+          "dfsmn.fsmn1.lookahead_filter.weight": w["fsmn0_la"][:, None, :], "out.weight": w["out_w"], "out.bias": w["out_b"]}
+    for r in range(1, cfg["R"]):
+        p = f"dfsmn.fsmns.{r - 1}."
+        sd[p + "fc1.0.weight"], sd[p + "fc1.0.bias"], sd[p + "fc2.weight"] = w[f"blk{r}_fc1_w"], w[f"blk{r}_fc1_b"], w[f"blk{r}_fc2_w"]
+        sd[p + "fsmn.lookback_filter.weight"] = w[f"fsmn{r}_lb"][:, None, :]
+        sd[p + "fsmn.lookahead_filter.weight"] = w[f"fsmn{r}_la"][:, None, :]
+    for m in range(cfg["M"]):
+        sd[f"dfsmn.dnns.{2 * m}.weight"], sd[f"dfsmn.dnns.{2 * m}.bias"] = w[f"dnn{m}_w"], w[f"dnn{m}_b"]
+    torch.save({"args": types.SimpleNamespace(**cfg), "model_state_dict": {k: T(v) for k, v in sd.items()}}, tmp_path / "model.pth.tar")
+    for binary in (True, False):
+        ck.write_kaldi_matrix(str(tmp_path / "cmvn.ark"), g["stats"], binary=binary)
+        means, inv_std = ck.load_cmvn(str(tmp_path / "cmvn.ark"))
+        assert np.array_equal(means, g["means"]) and np.array_equal(inv_std, g["inv_std"])
+        got = ck.load_firered(str(tmp_path))
+        assert got["cfg"] == cfg
+        for k in ("fc1_w", "fc1_b", "blk1_fc2_w", "fsmn2_la", "dnn1_w", "out_w"):
+            assert np.array_equal(got[k], g[k]), k
+    # a streaming checkpoint (no look-ahead filters) yields N2 = 0
+    sd_s = {k: T(v) for k, v in sd.items() if "lookahead" not in k}
+    got = ck.firered_from_state(types.SimpleNamespace(**cfg), sd_s)
+    assert got["cfg"]["N2"] == 0 and "fsmn0_la" not in got and np.array_equal(got["fc1_w"], w["fc1_w"])
