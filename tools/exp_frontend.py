@@ -1,0 +1,39 @@
+"""Front-end cycle accounting (development aid): library built with -DFE_EXP=1 sums thread-0 clock64 deltas per phase.
+   python tools/exp_frontend.py build ;  (GPU box) python tools/exp_frontend.py run"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "voice-activity-detection-vad-onnx_amd")
+LIB = os.path.join(PKG, "_exp", "libvadx_fe1.so")
+SRC = ["capi.hip", "silero.hip", "frontend.hip", "fsmn.hip", "firered.hip", "marblenet.hip", "dfsmn.hip", "ingest.hip"]
+NAMES = ["staging: barrier wait", "DFT GEMM + power", "last bin + zero pad rows", "mel GEMM + log + store", "staging: own work (wave 0)"]
+
+if sys.argv[1] == "build":
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DFE_EXP=1"]
+                          + [os.path.join(PKG, "csrc", s) for s in SRC] + ["-o", LIB])
+    print("built", LIB)
+else:
+    os.environ["VADX_LIBRARY"] = LIB
+    sys.path.insert(0, ROOT)
+    import torch
+    import vadx  # noqa: F401
+    from vadx import _lib, frontend, weights
+    h = _lib.lib()
+    h.vadx_frontend_debug_cycles.argtypes = [C.c_void_p, C.c_int]
+    for preset, n in (("marblenet", 89431), ("fsmn", 16000), ("firered", 16000)):
+        fe = frontend.Frontend(preset, n)
+        clips = torch.from_numpy(weights.burst_clips(64, n, seed=5)).cuda().repeat(32 if n > 20000 else 256, 1)
+        fe.logmel(clips); torch.cuda.synchronize()
+        buf = (C.c_ulonglong * 8)()
+        h.vadx_frontend_debug_cycles(buf, 1)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fe.logmel(clips); b.record(); torch.cuda.synchronize()
+        h.vadx_frontend_debug_cycles(buf, 0)
+        tot = sum(buf[:5])
+        print("%s: %d clips x %d samples, %.2f ms" % (preset, clips.shape[0], n, a.elapsed_time(b)))
+        for nm, v in zip(NAMES, buf[:5]):
+            print("   %-30s %6.2f %%" % (nm, 100.0 * v / tot))

@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "voice-activity-detection-vad-onnx_amd")
 LIB = os.path.join(PKG, "_exp", "libvadx_fs1.so")
-SRC = ["capi.hip", "silero.hip", "frontend.hip", "fsmn.hip", "firered.hip", "marblenet.hip", "dfsmn.hip"]
+SRC = ["capi.hip", "silero.hip", "frontend.hip", "fsmn.hip", "firered.hip", "marblenet.hip", "dfsmn.hip", "ingest.hip"]
 NAMES = ["stage", "in_linear1", "in_linear2", "cache load (x4)", "linear (x4)", "FIR + cache store (x4)", "affine (x4)", "out1 + out2", "softmax"]
 
 if sys.argv[1] == "build":

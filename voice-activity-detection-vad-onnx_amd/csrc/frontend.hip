@@ -17,6 +17,26 @@
 
 #include <string.h>
 
+#include <type_traits>
+
+// FE_EXP: development-only cycle accounting (tools/exp_frontend.py)
+#ifndef FE_EXP
+#define FE_EXP 0
+#endif
+#if FE_EXP
+__device__ unsigned long long fe_dbg[8];
+#define FE_T0() long long fe_t_ = clock64()
+#define FE_ACC(slot) do { if (threadIdx.x == 0) { const long long n_ = clock64(); atomicAdd(&fe_dbg[slot], (unsigned long long)(n_ - fe_t_)); fe_t_ = n_; } } while (0)
+extern "C" int vadx_frontend_debug_cycles(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fe_dbg), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(fe_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define FE_T0() do {} while (0)
+#define FE_ACC(slot) do {} while (0)
+#endif
+
 namespace vadx {
 namespace frontend {
 
@@ -50,7 +70,7 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     d->prep = c->prep; d->center_pad = c->center_pad; d->tap0 = c->tap0; d->taps = c->taps; d->hop = c->hop;
     d->n_bins = c->n_bins; d->n_mels = c->n_mels; d->log_mode = c->log_mode; d->frames = c->frames;
     d->window_len = c->window_len; d->k0 = c->k0; d->k1 = c->k1; d->log_floor = c->log_floor;
-    if (c->hop <= 0 || c->hop % 16 || c->taps <= 0 || c->n_bins <= 0 || c->n_mels <= 0 || c->n_mels % 16 ||
+    if (c->hop <= 0 || c->hop > 320 || c->hop % 16 || c->taps <= 0 || c->n_bins <= 0 || c->n_mels <= 0 || c->n_mels % 16 ||
         c->frames <= 0 || c->window_len <= 0)
         return -1;
     d->passes = (c->taps + c->hop - 1) / c->hop;
@@ -89,39 +109,69 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
     constexpr int NF = MT * 16;
     const int cols = NF + d.passes - 1;
 
+    FE_T0();
     // ---- phase 0: prep + polyphase staging  X2[r][g] = s'[(f0+g)*hop + r]
-    for (int e = tid; e < cols * d.hop; e += THREADS) {
-        const int g = e / d.hop, r = e - g * d.hop;
-        const int n = (f0 + g) * d.hop + r + d.tap0 - d.center_pad;      // index into the window
-        float v = 0.f;
-        if (n >= 0 && n < d.window_len) {
-            const float x = win ? (float)win[n] : 0.f;
-            const float xm = (win && n > 0) ? (float)win[n - 1] : 0.f;
-            if (d.prep == 0) {            // FSMN: (x-mean) - 0.97*(x[-1]-mean), first sample kept
-                const float a = __fsub_rn(x, mean);
-                v = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn(xm, mean))) : a;
-            } else if (d.prep == 1) {     // two-tap conv with zero history
-                v = __fadd_rn(__fmul_rn(xm, d.k0), __fmul_rn(x, d.k1));
-            } else if (d.prep == 2) {     // scale, then remove the window mean (mean is of the scaled signal)
-                v = __fsub_rn(__fmul_rn(x, d.k1), mean);
-            } else {                      // DFSMN feature streams (Export_DFSMN_VAD.py:338-341)
-                float npe = 0.f, ape = 0.f;
-                if (d.prep != 4) {        // near: a = k1*x - mean, pre-emphasis keeping a[0]
-                    const float a = __fsub_rn(__fmul_rn(x, d.k1), mean);
-                    npe = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn(__fmul_rn(xm, d.k1), mean))) : a;
+    // wave = column g, lane = row r (+64 j): consecutive lanes read consecutive samples, no divisions.  All loads of a
+    // column are issued first and UNCONDITIONALLY (indices clamped, values selected afterwards; which sources exist is
+    // decided once, outside the loop): a load under any condition -- even a uniform one -- compiles to a branch plus a
+    // full wait, which serialised ~100 memory round trips per tile (29 % of the kernel).
+    auto stage = [&](auto prep_c) {
+        constexpr int PREP = decltype(prep_c)::value;          // compile-time prep: the per-sample code is ~15 instructions
+        constexpr bool HW = PREP != 4, HF = PREP >= 4;
+        for (int g = wave; g < cols; g += THREADS / 64) {
+            const int nb = (f0 + g) * d.hop + d.tap0 - d.center_pad;      // window index of row 0
+            float xs[5], xms[5], as_[5], ams[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {                                  // hop <= 320
+                const int n = nb + lane + 64 * j;
+                const int nc = n < 0 ? 0 : (n >= d.window_len ? d.window_len - 1 : n), nm = nc > 0 ? nc - 1 : 0;
+                xs[j] = HW ? (float)win[nc] : 0.f;
+                xms[j] = HW ? (float)win[nm] : 0.f;
+                as_[j] = HF ? fwin[nc] : 0.f;
+                ams[j] = HF ? fwin[nm] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int r = lane + 64 * j, n = nb + r;
+                const bool in = n >= 0 && n < d.window_len;
+                const float x = xs[j], xm = n > 0 ? xms[j] : 0.f;
+                float v;
+                if (PREP == 0) {              // FSMN: (x-mean) - 0.97*(x[-1]-mean), first sample kept
+                    const float a = __fsub_rn(x, mean);
+                    v = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn(xm, mean))) : a;
+                } else if (PREP == 1) {       // two-tap conv with zero history
+                    v = __fadd_rn(__fmul_rn(xm, d.k0), __fmul_rn(x, d.k1));
+                } else if (PREP == 2) {       // scale, then remove the window mean (mean is of the scaled signal)
+                    v = __fsub_rn(__fmul_rn(x, d.k1), mean);
+                } else {                      // DFSMN feature streams (Export_DFSMN_VAD.py:338-341)
+                    float npe = 0.f, ape = 0.f;
+                    if (PREP != 4) {          // near: a = k1*x - mean, pre-emphasis keeping a[0]
+                        const float a = __fsub_rn(__fmul_rn(x, d.k1), mean);
+                        npe = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn(__fmul_rn(xm, d.k1), mean))) : a;
+                    }
+                    if (PREP != 3) {          // AEC output (float source), same pre-emphasis
+                        const float a = as_[j];
+                        ape = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, ams[j])) : a;
+                    }
+                    v = PREP == 3 ? npe : (PREP == 4 ? ape : __fsub_rn(npe, __fmul_rn(d.k0, ape)));   // 5: echo = near - k0*aec
                 }
-                if (d.prep != 3) {        // AEC output (float source), same pre-emphasis
-                    const float a = fwin[n];
-                    ape = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, fwin[n - 1])) : a;
-                }
-                v = d.prep == 3 ? npe : (d.prep == 4 ? ape : __fsub_rn(npe, __fmul_rn(d.k0, ape)));   // 5: echo = near - k0*aec
+                if (r < d.hop) X2[r * X_LD + g] = in ? v : 0.f;
             }
         }
-        X2[r * X_LD + g] = v;
+    };
+    switch (d.prep) {       // uniform
+        case 0: stage(std::integral_constant<int, 0>{}); break;
+        case 1: stage(std::integral_constant<int, 1>{}); break;
+        case 2: stage(std::integral_constant<int, 2>{}); break;
+        case 3: stage(std::integral_constant<int, 3>{}); break;
+        case 4: stage(std::integral_constant<int, 4>{}); break;
+        default: stage(std::integral_constant<int, 5>{}); break;
     }
     // rows hop..round16 of a partial last pass never exist in X2; the table is zero there but the
     // activations must be finite: they alias rows of the NEXT column block, which are finite.
+    FE_ACC(4);
     __syncthreads();
+    FE_ACC(0);
 
     // ---- phase 1: DFT GEMM, |.|^2 -> PW[bin][frame]
     for (int bt = wave; bt < d.nbt; bt += THREADS / 64) {
@@ -158,23 +208,27 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
         }
     }
     if (COMPLEX) return;
+    FE_ACC(1);
     if (d.nyq) {            // last bin (n_bins % 16 == 1): frames x taps dot products on the VALU
+        // thread = (frame tid >> 4, tap residue tid & 15): all 512 threads share the dot products and the 16 partial sums
+        // of a frame meet through four shuffles (this used to run on 128 threads over 4 residues: a third of the kernel)
         const float *nre = P + d.off_nyq, *nim = nre + d.Kp;
-        for (int e = tid; e < NF * 4; e += THREADS) {       // (frame, k-quarter)
-            const int f = e >> 2, kq = e & 3;
-            float sre = 0.f, sim = 0.f;
+        const int f = tid >> 4, part = tid & 15;
+        float sre = 0.f, sim = 0.f;
+        if (f < NF)
             for (int a = 0; a < d.passes; ++a) {
                 const int rows = d.pass_kb[a] * 16;
-                for (int r = kq; r < rows; r += 4) {
-                    const float x = X2[r * X_LD + f + a];
-                    sre = fmaf(x, nre[d.pass_koff[a] + r], sre);
-                    sim = fmaf(x, nim[d.pass_koff[a] + r], sim);
+                const float *xr = X2 + f + a, *tr = nre + d.pass_koff[a], *ti = nim + d.pass_koff[a];
+#pragma unroll 5
+                for (int r = part; r < rows; r += 16) {
+                    const float x = xr[r * X_LD];
+                    sre = fmaf(x, tr[r], sre);
+                    sim = fmaf(x, ti[r], sim);
                 }
             }
-            sre += __shfl_xor(sre, 1); sre += __shfl_xor(sre, 2);
-            sim += __shfl_xor(sim, 1); sim += __shfl_xor(sim, 2);
-            if (kq == 0) PW[(d.n_bins - 1) * P_LD + f] = __fadd_rn(__fmul_rn(sre, sre), __fmul_rn(sim, sim));
-        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { sre += __shfl_xor(sre, o); sim += __shfl_xor(sim, o); }
+        if (part == 0 && f < NF) PW[(d.n_bins - 1) * P_LD + f] = __fadd_rn(__fmul_rn(sre, sre), __fmul_rn(sim, sim));
     }
     // zero the padded power rows (bins n_bins..Fp-1) so the mel GEMM multiplies 0 x 0
     for (int e = tid; e < (d.Fp - d.n_bins) * NF; e += THREADS) {
@@ -182,6 +236,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
         PW[(d.n_bins + r) * P_LD + c] = 0.f;
     }
     __syncthreads();
+    FE_ACC(2);
 
     // ---- phase 2: banded mel GEMM + log, D rows = mel (SWAP) so each lane stores 4 consecutive mels
     for (int mtile = wave; mtile < d.nmt; mtile += THREADS / 64) {
@@ -208,6 +263,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
             }
         }
     }
+    FE_ACC(3);
 }
 
 __global__ __launch_bounds__(THREADS, 4) void frontend_logmel_kernel(
