@@ -27,6 +27,12 @@ struct Cfg {
     int cin, cout, k, stride, dil, pad, has_dw, cres, relu, cinp, coutp, cresp;
 };
 
+// KT / DT / ST: compile-time kernel size, dilation and stride of the depthwise stage (0 = take them from `c` at run
+// time: the generic fallback).  With constants the FIR is a register-window filter -- a thread owns 8 consecutive
+// outputs of one channel, reads its (8-1)*stride + (k-1)*dil + 1 inputs and its k taps ONCE, and everything after
+// is FMAs on registers -- and every staging load is unconditional (index clamped, value selected): a guarded load
+// compiles to a branch plus a full wait, which used to serialise ~20 memory round trips per thread.
+template <int KT, int DT, int ST>
 __global__ __launch_bounds__(THREADS, 2) void sepconv_block_kernel(
     Cfg c, const float *__restrict__ dw_w, const float *__restrict__ pw_w, const float *__restrict__ pw_b,
     const float *__restrict__ res_w, const float *__restrict__ res_b, const float *__restrict__ x,
@@ -34,42 +40,102 @@ __global__ __launch_bounds__(THREADS, 2) void sepconv_block_kernel(
     float *__restrict__ y, int T_out, int tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *IN = lds, *D = lds + IN_F, *OUT = D + T_F, *RIN = OUT + T_F, *ROUT = RIN + T_F;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TILE;
-    const int width = (TILE - 1) * c.stride + (c.k - 1) * c.dil + 1;
+    const int K = KT ? KT : c.k, DIL = KT ? DT : c.dil, STR = KT ? ST : c.stride;
+    const int width = (TILE - 1) * STR + (K - 1) * DIL + 1;
     const float *xb = x + (long long)b * xs_b;
-    const int tin0 = t0 * c.stride - c.pad;
-    if (xs_c == 1) {            // time-major source (front-end output): channel fastest
-        for (int e = tid; e < width * c.cinp; e += THREADS) {
-            const int j = e / c.cinp, ch = e - j * c.cinp, ti = tin0 + j;
-            IN[ch * IN_LD + j] = (ch < c.cin && ti >= 0 && ti < T_in) ? xb[(long long)ti * xs_t + ch] : 0.f;
+    const int tin0 = t0 * STR - c.pad;
+    if (xs_c == 1) {            // time-major source (front-end output): channel fastest -> lane = channel, wave = time
+        for (int j0 = 0; j0 < width; j0 += 4 * (THREADS / 64)) {
+            float v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = j0 + u * (THREADS / 64) + wave, ch = lane + 64 * h, ti = tin0 + j;
+                    const int tc = ti < 0 ? 0 : (ti >= T_in ? T_in - 1 : ti), cc = ch < c.cin ? ch : c.cin - 1;
+                    v[u][h] = xb[(long long)tc * xs_t + cc];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = j0 + u * (THREADS / 64) + wave, ch = lane + 64 * h, ti = tin0 + j;
+                    if (j < width && ch < c.cinp) IN[ch * IN_LD + j] = (ch < c.cin && ti >= 0 && ti < T_in) ? v[u][h] : 0.f;
+                }
         }
-    } else {                    // channel-first source: time fastest
-        for (int e = tid; e < width * c.cinp; e += THREADS) {
-            const int ch = e / width, j = e - ch * width, ti = tin0 + j;
-            IN[ch * IN_LD + j] = (ch < c.cin && ti >= 0 && ti < T_in) ? xb[(long long)ch * xs_c + (long long)ti * xs_t] : 0.f;
+    } else {                    // channel-first source: time fastest -> lane = time, wave = channel
+        for (int ch0 = 0; ch0 < c.cinp; ch0 += 4 * (THREADS / 64)) {
+            float v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ch = ch0 + u * (THREADS / 64) + wave, j = lane + 64 * h, ti = tin0 + j;
+                    const int tc = ti < 0 ? 0 : (ti >= T_in ? T_in - 1 : ti), cc = ch < c.cin ? ch : c.cin - 1;
+                    v[u][h] = xb[(long long)cc * xs_c + (long long)tc * xs_t];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ch = ch0 + u * (THREADS / 64) + wave, j = lane + 64 * h, ti = tin0 + j;
+                    if (j < width && ch < c.cinp) IN[ch * IN_LD + j] = (ch < c.cin && ti >= 0 && ti < T_in) ? v[u][h] : 0.f;
+                }
         }
     }
-    if (c.cres) {
+    if (c.cres) {               // residual input tile [cres][32]: lane&31 = frame, 16 rows per pass
         const float *rb = xres + (long long)b * c.cres * T_out;
-        for (int e = tid; e < c.cresp * TILE; e += THREADS) {
-            const int ch = e / TILE, m = e - ch * TILE;
-            RIN[ch * A_LD + m] = (ch < c.cres && t0 + m < T_out) ? rb[(long long)ch * T_out + t0 + m] : 0.f;
+        const int m = tid & 31, tm = (t0 + m < T_out) ? t0 + m : T_out - 1;
+        for (int ch0 = 0; ch0 < c.cresp; ch0 += 4 * (THREADS / 32)) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ch = ch0 + u * (THREADS / 32) + (tid >> 5), cc = ch < c.cres ? ch : c.cres - 1;
+                v[u] = rb[(long long)cc * T_out + tm];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ch = ch0 + u * (THREADS / 32) + (tid >> 5);
+                if (ch < c.cresp) RIN[ch * A_LD + m] = (ch < c.cres && t0 + m < T_out) ? v[u] : 0.f;
+            }
         }
     }
     __syncthreads();
     const float *act = IN;
     int lda = IN_LD;
     if (c.has_dw) {
-        for (int e = tid; e < c.cinp * TILE; e += THREADS) {
-            const int ch = e / TILE, m = e - ch * TILE;
-            float s = 0.f;
-            if (ch < c.cin) {
-                const float *row = IN + ch * IN_LD + m * c.stride;
-                const float *wk = dw_w + ch * c.k;
-                for (int kk = 0; kk < c.k; ++kk) s = fmaf(wk[kk], row[kk * c.dil], s);
+        if (KT) {               // register-window FIR: thread = (channel tid >> 2, 8 outputs starting at 8 * (tid & 3))
+            constexpr int KK = KT ? KT : 1, WIN = 7 * (ST ? ST : 1) + (KK - 1) * (DT ? DT : 1) + 1;
+            const int ch = tid >> 2, m0 = 8 * (tid & 3);
+            if (ch < c.cinp) {
+                const int cc = ch < c.cin ? ch : c.cin - 1;
+                float wk[KK], win[WIN];
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) wk[kk] = dw_w[cc * KK + kk];
+                const float *row = IN + ch * IN_LD + m0 * (ST ? ST : 1);
+#pragma unroll
+                for (int u = 0; u < WIN; ++u) win[u] = row[u];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    float s2 = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) s2 = fmaf(wk[kk], win[o * (ST ? ST : 1) + kk * (DT ? DT : 1)], s2);
+                    D[ch * A_LD + m0 + o] = ch < c.cin ? s2 : 0.f;
+                }
             }
-            D[ch * A_LD + m] = s;
+        } else {
+            for (int e = tid; e < c.cinp * TILE; e += THREADS) {
+                const int ch = e / TILE, m = e - ch * TILE;
+                float s2 = 0.f;
+                if (ch < c.cin) {
+                    const float *row = IN + ch * IN_LD + m * c.stride;
+                    const float *wk = dw_w + ch * c.k;
+                    for (int kk = 0; kk < c.k; ++kk) s2 = fmaf(wk[kk], row[kk * c.dil], s2);
+                }
+                D[ch * A_LD + m] = s2;
+            }
         }
         __syncthreads();
         act = D;
@@ -137,17 +203,28 @@ extern "C" int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w
     VADX_REQUIRE(!c.cres || (res_w && res_b && xres), "vadx_sepconv_block: residual branch needs res_w/res_b/xres");
     VADX_REQUIRE(batch > 0 && t_in > 0 && t_out > 0 && t_out == (t_in + 2 * c.pad - c.dil * (c.k - 1) - 1) / c.stride + 1,
                  "vadx_sepconv_block: t_out=%d inconsistent with t_in=%d", t_out, t_in);
-    static bool done = false;
-    if (!done) {
-        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sepconv_block_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));
-        done = true;
-    }
     const int tiles = (t_out + TILE - 1) / TILE;
     VADX_REQUIRE((long long)batch * tiles < (1LL << 31), "vadx_sepconv_block: too many tiles");
-    hipLaunchKernelGGL(sepconv_block_kernel, dim3((unsigned)(batch * tiles)), dim3(THREADS), LDS_FLOATS * sizeof(float),
-                       static_cast<hipStream_t>(stream), c, dw_w, pw_w, pw_b, res_w, res_b, x, (long long)xs_b,
-                       (long long)xs_c, (long long)xs_t, t_in, xres, y, t_out, tiles);
+#define SEPCONV_LAUNCH(KT, DT, ST)                                                                                              \
+    do {                                                                                                                        \
+        static bool done_ = false;                                                                                              \
+        if (!done_) {                                                                                                           \
+            VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sepconv_block_kernel<KT, DT, ST>),                  \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));          \
+            done_ = true;                                                                                                       \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((sepconv_block_kernel<KT, DT, ST>), dim3((unsigned)(batch * tiles)), dim3(THREADS),                  \
+                           LDS_FLOATS * sizeof(float), static_cast<hipStream_t>(stream), c, dw_w, pw_w, pw_b, res_w, res_b, x,  \
+                           (long long)xs_b, (long long)xs_c, (long long)xs_t, t_in, xres, y, t_out, tiles);                      \
+    } while (0)
+    // the depthwise shapes of the published MarbleNet 3x2x64 get compile-time FIRs; anything else runs the generic kernel
+    if (c.has_dw && c.k == 11 && c.dil == 1 && c.stride == 2) SEPCONV_LAUNCH(11, 1, 2);
+    else if (c.has_dw && c.k == 13 && c.dil == 1 && c.stride == 1) SEPCONV_LAUNCH(13, 1, 1);
+    else if (c.has_dw && c.k == 15 && c.dil == 1 && c.stride == 1) SEPCONV_LAUNCH(15, 1, 1);
+    else if (c.has_dw && c.k == 17 && c.dil == 1 && c.stride == 1) SEPCONV_LAUNCH(17, 1, 1);
+    else if (c.has_dw && c.k == 29 && c.dil == 2 && c.stride == 1) SEPCONV_LAUNCH(29, 2, 1);
+    else SEPCONV_LAUNCH(0, 0, 0);
+#undef SEPCONV_LAUNCH
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }
