@@ -167,12 +167,12 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
         // ---- stage the input rows: thread = (row (c, ffl), frame quad)
         for (int e = tid; e < cin * fh * 4; e += 256) {
             const int rowi = e >> 2, tq = e & 3, c = rowi / fh, ffl = rowi - c * fh, ff = f0 - HALO + ffl;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ff >= 0 && ff < p.F) {
-                const float *src = c < p.a.c ? p.a.ptr + ft_idx(tile, p.a.c_total, p.a.c_off + c, p.F, ff)
-                                             : p.b.ptr + ft_idx(tile, p.b.c_total, p.b.c_off + c - p.a.c, p.F, ff);
-                v = *reinterpret_cast<const f32x4 *>(src + 4 * tq);
-            }
+            // unconditional (clamped) load, then select: a guarded load is a branch plus a full wait per iteration
+            const int fc2 = ff < 0 ? 0 : (ff >= p.F ? p.F - 1 : ff);
+            const float *src = c < p.a.c ? p.a.ptr + ft_idx(tile, p.a.c_total, p.a.c_off + c, p.F, fc2)
+                                         : p.b.ptr + ft_idx(tile, p.b.c_total, p.b.c_off + c - p.a.c, p.F, fc2);
+            f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * tq);
+            if (ff < 0 || ff >= p.F) v = f32x4{0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4 *>(raw + (c * fs + ffl) * 16 + 4 * tq) = v;
         }
         if (p.ln.stats)
@@ -410,8 +410,8 @@ __global__ __launch_bounds__(128) void lstm_f_kernel(LstmFArgs p) {
             const int row = (lane >> 2) + 16 * r, b = row / IN, ch = row - b * IN, f = bin_of(ck, b);
             pre[r] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (DFSMN_EXP & 2) continue;
-            if (f >= 0 && f < p.F)
-                pre[r] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + ch, p.F, f) + 4 * tq);
+            const int fcl = f < 0 ? 0 : (f >= p.F ? p.F - 1 : f);        // unconditional (clamped) load; park() ignores the excess bins
+            pre[r] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + ch, p.F, fcl) + 4 * tq);
         }
     };
     auto park = [&](int ck, float *dst) {

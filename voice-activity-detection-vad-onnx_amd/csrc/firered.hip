@@ -187,7 +187,8 @@ __global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float 
     // stage log-mel channel-first into `mem` rows 0..79; frames >= T are zero (finite operands)
     for (int e = tid; e < ((FR_EXP & 32) ? 0 : MAX_T * NMEL); e += THREADS) {
         const int t = e / NMEL, mel = e - t * NMEL;
-        mem[mel * M_LD + t] = t < d.T ? lm[(size_t)t * NMEL + mel] : 0.f;
+        const float v = lm[(size_t)(t < d.T ? t : d.T - 1) * NMEL + mel];      // unconditional (clamped) load, then select
+        mem[mel * M_LD + t] = t < d.T ? v : 0.f;
     }
     for (int e = tid; e < ((FR_EXP & 32) ? 0 : MAXP * M_LD); e += THREADS) p[e] = 0.f;
     __syncthreads();
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(THREADS, 2) void firered_stream_kernel(Dev d, const
     const float *lm = logmel + (size_t)b * d.T * NMEL;
     for (int e = tid; e < MAX_T * NMEL; e += THREADS) {
         const int t = e / NMEL, mel = e - t * NMEL;
-        mem[mel * M_LD + t] = t < d.T ? lm[(size_t)t * NMEL + mel] : 0.f;
+        const float v = lm[(size_t)(t < d.T ? t : d.T - 1) * NMEL + mel];      // unconditional (clamped) load, then select
+        mem[mel * M_LD + t] = t < d.T ? v : 0.f;
     }
     for (int e = tid; e < MAXP * M_LD; e += THREADS) p[e] = 0.f;
     __syncthreads();
