@@ -228,7 +228,22 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
     auto xslot = [fold](int pp) { return fold ? (pp & 1) * X_ODD + (pp >> 1) : pp; };
     {
         const long long base = (long long)t * 512 + origin;
-        const bool vec_ok = ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(audio) & 15) == 0);
+        const bool vec_ok = ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(audio) & 15) == 0) && n_samples >= 4 && !ENC_SKIP(1);
+        // Work item e = (clip c, float4 p/4) of the 16 x 576-sample tile.  In the normal case every lane loads its
+        // float4 UNCONDITIONALLY from a clamped address, all five loads back to back (a load under a condition -- even a
+        // uniform one -- compiles to a branch plus a full wait: five serialised HBM round trips per tile); the rare edge
+        // lanes (first / last windows, clips past B) patch their values afterwards in a branch that is normally skipped.
+        f32x4 x4[5];
+        if (vec_ok) {
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int e = min(tid + ENC_THREADS * it, 16 * 144 - 1), c = e / 144, p = 4 * (e - c * 144);
+                const long long b = (long long)grp * 16 + c, idx = base + p;
+                const float *src = audio + (b < B ? b : 0) * row_stride;
+                const long long idc = idx < 0 ? 0 : (idx + 3 < n_samples ? idx : ((n_samples - 4) & ~3LL));
+                x4[it] = *reinterpret_cast<const f32x4 *>(src + idc);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
             const int e = tid + ENC_THREADS * it;            // 16 clips x 144 float4
@@ -239,11 +254,10 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                 const float *src = audio + (bvalid ? b : 0) * row_stride;
                 const long long idx = base + p;
                 float v[4];
-                if (ENC_SKIP(1)) {
+                if (vec_ok && bvalid && idx >= 0 && idx + 3 < n_samples) {
+                    v[0] = x4[it][0]; v[1] = x4[it][1]; v[2] = x4[it][2]; v[3] = x4[it][3];
+                } else if (ENC_SKIP(1)) {
                     v[0] = v[1] = v[2] = v[3] = 1e-3f * (float)(p & 63);
-                } else if (bvalid && vec_ok && idx >= 0 && idx + 3 < n_samples) {
-                    const f32x4 x4 = *reinterpret_cast<const f32x4 *>(src + idx);
-                    v[0] = x4[0]; v[1] = x4[1]; v[2] = x4[2]; v[3] = x4[3];
                 } else {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
