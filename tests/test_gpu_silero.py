@@ -215,3 +215,13 @@ def test_full_size_batch_invariance():
     om = osil.OnnxWrapperOracle(w)
     ref = np.array(osil.speech_probs(T(base[7]), om), dtype=np.float32)
     np.testing.assert_allclose(probs[7].cpu().numpy(), ref, rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("n", [0, 1, 100, 511, 512, 513])
+def test_tiny_clips_match_oracle(oracle_w, n):
+    """Empty and sub-window clips: the reference zero-pads the last (only) window; empty audio yields no segments."""
+    model = silero.load_silero_vad(onnx=True, path="synthetic:1234")
+    a = (weights.burst_clips(1, max(n, 1), seed=n + 1, quiet=3000.0)[0][:n].astype(np.float32) / 32768.0)
+    got = silero.get_speech_timestamps(T(a), model, min_speech_duration_ms=0, return_seconds=False)
+    want = osil.get_speech_timestamps(T(a), osil.OnnxWrapperOracle(oracle_w), min_speech_duration_ms=0, return_seconds=False)
+    assert got == want

@@ -302,6 +302,9 @@ def get_speech_timestamps_batch(audio, model, lengths=None, threshold: float = 0
         raise ValueError("Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates"
                          if sampling_rate != 8000 else "this build supports 16000 Hz (or a multiple) only")
     B, N = audio.shape
+    if N == 0:           # empty audio: the reference's chunk loop never runs and it returns [] (utils_vad.py:330-344)
+        res = [[] for _ in range(B)]
+        return (res, t.empty((B, 0), dtype=t.float32, device=engine.device)) if return_probs else res
     if lengths is None:
         lens = np.full((B,), N, dtype=np.int64)
     else:
