@@ -547,22 +547,61 @@ __global__ __launch_bounds__(64 * LAYERS) void lstm_t_direct_kernel(LstmTArgs p)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { h[mt] = 0.f; c[mt] = 0.f; }
     const bool last = layer == LAYERS - 1;
+    // Every per-step global value (layer 0: the KI0 inputs + the frame's LayerNorm statistics; last layer: the `mul`
+    // operands) is requested ONE STEP AHEAD, unconditionally (time index clamped), so the HBM round trip runs under the
+    // previous step's MFMAs instead of at the head of every step; the (channel, bin) LayerNorm weights are loaded once.
+    float lnw[KI0], lnb[KI0], xn[KI0], mean_n = 0.f, inv_n = 1.f, muln[OUT_MT][4];
+#pragma unroll
+    for (int s = 0; s < KI0; ++s) {
+        lnw[s] = p.ln.stats ? p.ln.w[(4 * s + q) * p.F + f0 + i] : 1.f;
+        lnb[s] = p.ln.stats ? p.ln.b[(4 * s + q) * p.F + f0 + i] : 0.f;
+        xn[s] = 0.f;
+    }
+#pragma unroll
+    for (int om = 0; om < OUT_MT; ++om)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) muln[om][r] = 1.f;
+    float blr[OUT_MT][4];
+#pragma unroll
+    for (int om = 0; om < OUT_MT; ++om)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) blr[om][r] = (om * 16 + 4 * q + r) < p.out_ch ? p.bl[om * 16 + 4 * q + r] : 0.f;
+    auto prefetch = [&](int t) {                 // values of time step t (clamped) for this wave's role
+        const int tc = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t), tile = chunk * p.nt + (tc >> 4), t16 = tc & 15;
+        if (layer == 0) {
+#pragma unroll
+            for (int s = 0; s < KI0; ++s) xn[s] = p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + 4 * s + q, p.F, f0 + i) + t16];
+            if (p.ln.stats) { mean_n = p.ln.stats[((size_t)tile * 16 + t16) * 2]; inv_n = p.ln.stats[((size_t)tile * 16 + t16) * 2 + 1]; }
+        }
+        if (last && MODE == 0) {
+#pragma unroll
+            for (int om = 0; om < OUT_MT; ++om)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = om * 16 + 4 * q + r, oc = o < p.out_ch ? o : p.out_ch - 1;
+                    muln[om][r] = p.mul.ptr[ft_idx(tile, p.mul.c_total, p.mul.c_off + oc, p.F, f0 + i) + t16];
+                }
+        }
+    };
+    prefetch(0);
     for (int it = 0; it < p.T + LAYERS - 1; ++it) {
         const int t = it - layer;                            // this wave's time step
         if (t >= 0 && t < p.T) {
             const int tile = chunk * p.nt + (t >> 4), t16 = t & 15;
-            float x[KI];
+            float x[KI], mulc[OUT_MT][4];
 #pragma unroll
             for (int s = 0; s < KI; ++s) {
                 x[s] = 0.f;
                 if (s < ki) {
-                    if (layer == 0) {
-                        const float v = p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + 4 * s + q, p.F, f0 + i) + t16];
-                        x[s] = p.ln.stats ? ln_apply(p.ln, tile, t16, (4 * s + q) * p.F + f0 + i, v) : v;
-                    }
+                    if (layer == 0) { if (s < KI0) x[s] = p.ln.stats ? (xn[s] - mean_n) * inv_n * lnw[s] + lnb[s] : xn[s]; }
                     else x[s] = hs[t & 1][(4 * s + q) * 16 + i];
                 }
             }
+#pragma unroll
+            for (int om = 0; om < OUT_MT; ++om)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mulc[om][r] = muln[om][r];
+            prefetch(t + 1);
             f32x4 acc[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
@@ -591,8 +630,8 @@ __global__ __launch_bounds__(64 * LAYERS) void lstm_t_direct_kernel(LstmTArgs p)
                     for (int r = 0; r < 4; ++r) {
                         const int o = om * 16 + 4 * q + r;
                         if (o < p.out_ch) {
-                            float v = y[r] + p.bl[o];
-                            if (MODE == 0) v *= p.mul.ptr[ft_idx(tile, p.mul.c_total, p.mul.c_off + o, p.F, f0 + i) + t16];
+                            float v = y[r] + blr[om][r];
+                            if (MODE == 0) v *= mulc[om][r];
                             p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + o, p.F, f0 + i) + t16] = v;
                         }
                     }
