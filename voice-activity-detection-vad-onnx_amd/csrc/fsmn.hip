@@ -92,11 +92,23 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
 
     FS_T0();
     // ---- stage log-mel with LFR edge replication: bufB[mel][c] = lm[clamp(f0 + c - 2, 0, T-1)][mel]
-    for (int e = tid; e < (NF + 4) * NMEL; e += THREADS) {
-        const int c = e / NMEL, mel = e - c * NMEL;
-        int fr = f0 + c - 2;
-        fr = fr < 0 ? 0 : (fr > d.T - 1 ? d.T - 1 : fr);
-        bufB[mel * A_LD + c] = lm[(size_t)fr * NMEL + mel];
+    {   // batches of four loads per thread in flight (the index is always clamped into the chunk)
+        constexpr int NE = (NF + 4) * NMEL, NIT = (NE + THREADS - 1) / THREADS;
+        for (int u0 = 0; u0 < NIT; u0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(tid + THREADS * (u0 + u), NE - 1), c = e / NMEL, mel = e - c * NMEL;
+                int fr = f0 + c - 2;
+                fr = fr < 0 ? 0 : (fr > d.T - 1 ? d.T - 1 : fr);
+                v[u] = lm[(size_t)fr * NMEL + mel];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + THREADS * (u0 + u), c = e / NMEL, mel = e - c * NMEL;
+                if (e < NE) bufB[mel * A_LD + c] = v[u];
+            }
+        }
     }
     __syncthreads();
     FS_ACC(0);
@@ -117,9 +129,16 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
 
     for (int l = 0; l < NLAYER; ++l) {
         // history columns 1..19 of bufP <- cache (previous tile / previous chunk)
-        for (int e = tid; e < PROJ * HIST; e += THREADS) {
-            const int ch = e / HIST, h = e - ch * HIST;
-            bufP[ch * P_LD + 1 + h] = cin[l][e];
+        {   // all five loads of a thread are issued back to back (clamped index), then stored
+            constexpr int NH = (PROJ * HIST + THREADS - 1) / THREADS;
+            float hv[NH];
+#pragma unroll
+            for (int u = 0; u < NH; ++u) { const int e = tid + THREADS * u; hv[u] = cin[l][e < PROJ * HIST ? e : PROJ * HIST - 1]; }
+#pragma unroll
+            for (int u = 0; u < NH; ++u) {
+                const int e = tid + THREADS * u, ch = e / HIST, h = e - ch * HIST;
+                if (e < PROJ * HIST) bufP[ch * P_LD + 1 + h] = hv[u];
+            }
         }
         FS_ACC(3);
         a = LayerArgs{Pk + d.off_lin[l], d.Lp, PROJ / 16, 1, d.Lp / 16, 0, 0, nullptr, 0,
