@@ -115,3 +115,23 @@ def test_device_ingest_on_vad_sample():
     assert (nch, rate) == (2, 48000)
     got = audio_io.ingest_device(raw, nch, rate)[0].cpu().numpy()
     assert np.array_equal(got, audio_io.load_wav(WAV)) and got.shape == (89431,)
+
+
+def test_dfsmn_on_reference_example_pair(tmp_path):
+    """The reference's own near-end / far-end example recordings (DFSMN/near_and_far_end_audio/examples) through the
+    script-level drop-in, against the oracle's restatement of the same driver."""
+    from vadx import dfsmn
+    from oracle import dfsmn as od
+    gold = os.path.join(os.path.dirname(WAV))
+    near_p, far_p = os.path.join(gold, "dfsmn_nearend_mic.wav"), os.path.join(gold, "dfsmn_farend_speech.wav")
+    wts = weights.dfsmn_synthetic(1234)
+    nz1, nz2 = np.random.default_rng(8).standard_normal((1, 20000)), np.random.default_rng(9).standard_normal((1, 20000))
+    sec, idx = str(tmp_path / "s.txt"), str(tmp_path / "i.txt")
+    got = drivers.inference_dfsmn(near_p, far_p, dfsmn.DfsmnEngine(wts), sec, idx, pad_noise_near=nz1, pad_noise_far=nz2, echo=lambda *_: None)
+    w = {k: T(v) for k, v in wts.items()}
+    w["mask.shift"] = w["mask.shift"] + torch.log(torch.tensor(32768 ** 2, dtype=torch.float32))
+    a, f = audio_io.load_wav(near_p).astype(np.float32), audio_io.load_wav(far_p).astype(np.float32)
+    assert a.shape == (159999,) and f.shape == (159999,)
+    want, _ = od.run_clip(od.Frontend(), w, a, f, nz1[0], nz2[0], weights.DFSMN_MASK["layers"])
+    assert got == want
+    assert open(idx).read() == "".join(opp.timestamp_lines(want, 16000)[1])

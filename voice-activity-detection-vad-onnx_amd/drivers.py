@@ -175,3 +175,26 @@ def inference_marblenet(test_vad_audio="./vad_sample.wav", engine=None, save_tim
         all_ts += engine.detect(c[None, :], window_len=INPUT_AUDIO_LENGTH, pad_noise=None if nz is None else nz[None, :], post=post)
     elapsed = time.time() - t0
     return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_vad_audio, (list, tuple)), elapsed, echo)
+
+
+def inference_dfsmn(test_near_end_audio="./examples/nearend_mic.wav", test_far_end_audio="./examples/farend_speech.wav", engine=None,
+                    save_timestamps_second="./timestamps_second.txt", save_timestamps_indices="./timestamps_indices.txt",
+                    SPEAKING_SCORE=0.5, SILENCE_SCORE=0.5, FUSION_THRESHOLD=0.3, MIN_SPEECH_DURATION=0.2,
+                    pad_noise_near=None, pad_noise_far=None, echo=print):
+    """DFSMN/near_and_far_end_audio/Inference_DFSMN_VAD_ONNX.py:121-300: near-end mic + far-end reference -> AEC ->
+    mask-net VAD -> look-ahead vote -> timestamps (both text files).  Lists of paths run as a batch of clip pairs."""
+    from . import dfsmn
+    nears, fars = _as_list(test_near_end_audio), _as_list(test_far_end_audio)
+    engine = dfsmn.DfsmnEngine() if engine is None else engine
+    echo(f"\nTest Input Near_End Audio: {test_near_end_audio}\nTest Input Far_End Audio: {test_far_end_audio}")
+    all_ts = []
+    t0 = time.time()
+    for k, (pn, pf) in enumerate(zip(nears, fars)):
+        a, f = audio_io.load_wav(pn, 16000).astype(np.float32), audio_io.load_wav(pf, 16000).astype(np.float32)
+        nzn = None if pad_noise_near is None else np.asarray(pad_noise_near)[k][None, :]
+        nzf = None if pad_noise_far is None else np.asarray(pad_noise_far)[k][None, :]
+        n = min(len(a), len(f))
+        all_ts += engine.detect(a[None, :n], f[None, :n], nzn, nzf, fusion_threshold=FUSION_THRESHOLD,
+                                min_speech_duration=MIN_SPEECH_DURATION, speaking_score=SPEAKING_SCORE, silence_score=SILENCE_SCORE)
+    elapsed = time.time() - t0
+    return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_near_end_audio, (list, tuple)), elapsed, echo)
