@@ -135,3 +135,36 @@ def test_dfsmn_on_reference_example_pair(tmp_path):
     want, _ = od.run_clip(od.Frontend(), w, a, f, nz1[0], nz2[0], weights.DFSMN_MASK["layers"])
     assert got == want
     assert open(idx).read() == "".join(opp.timestamp_lines(want, 16000)[1])
+
+
+def test_firered_and_marblenet_on_vad_sample(tmp_path):
+    """The remaining two script-level drop-ins on the reference's sample file: probabilities within 1e-4 of the oracle
+    drivers, identical segments whenever no frame sits within tolerance of a decision threshold, files written."""
+    from vadx import firered, marblenet
+    from oracle import firered as ofr
+    from oracle import marblenet as omb
+    a = audio_io.load_wav(WAV)
+    # FireRed VAD
+    wfr = weights.firered_synthetic(1234)
+    noise = np.random.default_rng(11).standard_normal((1, 20000))
+    sec, idx = str(tmp_path / "fs.txt"), str(tmp_path / "fi.txt")
+    efr = firered.FireRedEngine(wfr)
+    got = drivers.inference_firered(WAV, efr, sec, idx, pad_noise=noise, echo=lambda *_: None)
+    wt = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in wfr.items()}
+    want, oprobs, odec = ofr.run_clip(ofr.Frontend(), wt, a, noise[0])
+    _, track, dec = efr.detect(a[None, :], pad_noise=noise, return_probs=True)
+    np.testing.assert_allclose(track[0].cpu().numpy(), oprobs, rtol=0, atol=1e-4)
+    if np.array_equal(np.asarray(dec[0].cpu().numpy()), np.asarray(odec)):
+        assert got == want and open(idx).read() == "".join(opp.timestamp_lines(want, 16000)[1])
+    assert os.path.exists(sec)
+    # MarbleNet (dynamic axis: the whole clip is one window)
+    wm = weights.marblenet_synthetic(1234)
+    em = marblenet.MarbleNetEngine(wm)
+    sec2, idx2 = str(tmp_path / "ms.txt"), str(tmp_path / "mi.txt")
+    got_m = drivers.inference_marblenet(WAV, em, sec2, idx2, echo=lambda *_: None)
+    ow = {k: T(v) for k, v in wm.items()}
+    want_m, p_m, dec_m = omb.run_clip(omb.Frontend(), ow, a)
+    _, track_m, dec_g = em.detect(a[None, :], return_probs=True)
+    np.testing.assert_allclose(track_m[0].cpu().numpy(), p_m, rtol=0, atol=1e-4)
+    if np.array_equal(dec_g[0].cpu().numpy(), dec_m):
+        assert got_m == want_m and open(idx2).read() == "".join(opp.timestamp_lines(want_m, 16000)[1])
