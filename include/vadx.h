@@ -306,9 +306,12 @@ int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float 
                       const float *const w_hh[2], const float *const b_ih[2], const float *const b_hh[2],
                       const vadx_ft_view *out, int F, int tiles, void *stream);
 
-/* x4 = [mix_re, mix_im, |alpha| far_re, |alpha| far_im] (FT, 4 ch x 160), DFSMN_VAD.forward :326-335. */
+/* x4 = [mix_re, mix_im, |alpha| far_re, |alpha| far_im] (FT, 4 ch x 160), DFSMN_VAD.forward :326-335.
+ * pow_far NULL: far power from channels 2, 3 (near + far model).  pow_far = [160][frames][10] floats: the near-end-only
+ * model's baked far-end power (DFSMN/only_near_end_audio/Export_DFSMN_VAD.py:309, :327); channels 2, 3 of `in` then
+ * hold its constant far spectrum. */
 int vadx_dfsmn_alpha_scale(const float *in, float *out, int chunks, int nt, const float *w1, const float *b1,
-                           const float *w2, const float *b2, void *stream);
+                           const float *w2, const float *b2, const float *pow_far, int frames, void *stream);
 /* LSTM along time, 16 bins per workgroup.  which = 0: NET.ch_lstm (in 20, hidden 40, 2 layers, Linear 40->20,
  * output multiplied element-wise with `mul` = e5);  which = 1: NET.out_ch_lstm (in 40, hidden 20, Linear 20->40).
  * wl rows zero-padded to a multiple of 16. */

@@ -168,25 +168,31 @@ class Frontend:
         self.frame_starts = torch.arange(max_frames).unsqueeze(1) + torch.arange(ALPHA_K).unsqueeze(0)
 
 
-def forward(fe, w, near_i16, far_i16, n_fsmn):
+def forward(fe, w, near_i16, far_i16, n_fsmn, near_only=None):
     """session.run equivalent: two int16 [1,1,L] -> vad_results f32 [T_A].
-    ref: DFSMN_VAD.forward, Export_DFSMN_VAD.py:317-354.  Returns (vad, aec waveform) for staged tests."""
+    ref: DFSMN_VAD.forward, DFSMN/near_and_far_end_audio/Export_DFSMN_VAD.py:317-354.  far_i16 None = the near-end-only
+    model (DFSMN/only_near_end_audio/Export_DFSMN_VAD.py:318-350): near_only = (pow_far [160,T',10], far_comp [2,160,T'])
+    are its baked white-noise tensors.  Returns (vad, aec waveform) for staged tests."""
     inv = float(1.0 / 32768.0)
     near = near_i16.float() * inv
-    far = far_i16.float() * inv
     near = near - torch.mean(near)
-    far = far - torch.mean(far)
     nre, nim = ostft.stft(near, fe.cos_b, fe.sin_b, HOP_B, True)
-    fre, fim = ostft.stft(far, fe.cos_b, fe.sin_b, HOP_B, True)
     mix = torch.cat([nre, nim], dim=0).unsqueeze(0)                      # [1,2,160,T]
-    farc = torch.cat([fre, fim], dim=0).unsqueeze(0)
     T = mix.shape[-1]
     pad = torch.zeros((1, 2, F_BINS, ALPHA_K - 1))
     idx = fe.frame_starts[:T]
     mu = torch.cat([pad, mix], dim=-1)[..., idx]                         # [1,2,160,T,10]
-    fu = torch.cat([pad, farc], dim=-1)[..., idx]
     pow_mix = (mu * mu).sum(dim=1, keepdim=True)
-    pow_far = (fu * fu).sum(dim=1, keepdim=True)
+    if far_i16 is None:
+        pow_far = near_only[0][:, :T, :].float().reshape(1, 1, F_BINS, T, ALPHA_K)
+        farc = near_only[1][:, :, :T].float().reshape(1, 1, 2, F_BINS, T)[0]          # [1,2,160,T]
+    else:
+        far = far_i16.float() * inv
+        far = far - torch.mean(far)
+        fre, fim = ostft.stft(far, fe.cos_b, fe.sin_b, HOP_B, True)
+        farc = torch.cat([fre, fim], dim=0).unsqueeze(0)
+        fu = torch.cat([pad, farc], dim=-1)[..., idx]
+        pow_far = (fu * fu).sum(dim=1, keepdim=True)
     ci = torch.stack([pow_far, pow_mix], dim=-1).unsqueeze(dim=1)
     alpha = F.linear(torch.sum(ci, dim=2, keepdim=True), w["alpha.linear1.weight"], w["alpha.linear1.bias"]).squeeze(dim=-1)
     alpha = F.linear(alpha, w["alpha.linear2.weight"], w["alpha.linear2.bias"]).squeeze(dim=-1)
@@ -223,21 +229,24 @@ def tail_flags(score, start, stop, silence, hi=0.5, lo=0.5):
     return flags, silence
 
 
-def run_clip(fe, w, near_1d, far_1d, pad_noise_near, pad_noise_far, n_fsmn, L=16001, look_backward_s=0.3):
-    """Whole-clip driver. ref: Inference_DFSMN_VAD_ONNX.py:124-163 (prep), :221-278 (loop)."""
-    n = min(len(near_1d), len(far_1d))
+def run_clip(fe, w, near_1d, far_1d, pad_noise_near, pad_noise_far, n_fsmn, L=16001, look_backward_s=0.3, near_only=None):
+    """Whole-clip driver. ref: Inference_DFSMN_VAD_ONNX.py:124-163 (prep), :221-278 (loop); far_1d None = the
+    near-end-only driver (DFSMN/only_near_end_audio/Inference_DFSMN_VAD_ONNX.py:120-145, same loop)."""
+    n = len(near_1d) if far_1d is None else min(len(near_1d), len(far_1d))
     near = postproc.normalize_to_int16(np.asarray(near_1d[:n], dtype=np.float32))
-    far = postproc.normalize_to_int16(np.asarray(far_1d[:n], dtype=np.float32))
     frame = 320
     lb = int(look_backward_s * 16000 // frame)
     stride = L - (lb + 1) * frame
     near, _ = postproc.pad_to_window_grid(near, L, stride, pad_noise_near)
-    far, _ = postproc.pad_to_window_grid(far, L, stride, pad_noise_far)
+    far = None
+    if far_1d is not None:
+        far = postproc.normalize_to_int16(np.asarray(far_1d[:n], dtype=np.float32))
+        far, _ = postproc.pad_to_window_grid(far, L, stride, pad_noise_far)
     silence, saved, s, vad = True, [], 0, None
     while s + L <= near.shape[0]:
         a = torch.from_numpy(near[s:s + L].copy()).reshape(1, 1, -1)
-        b = torch.from_numpy(far[s:s + L].copy()).reshape(1, 1, -1)
-        vad = forward(fe, w, a, b, n_fsmn)[0].numpy()
+        b = None if far is None else torch.from_numpy(far[s:s + L].copy()).reshape(1, 1, -1)
+        vad = forward(fe, w, a, b, n_fsmn, near_only)[0].numpy()
         flags, silence = postproc.lookahead_vote(vad, len(vad) - lb, lb, 0.5, 0.5, silence, thresholds=(0.5, 0.5))
         saved += flags
         s += stride

@@ -631,6 +631,68 @@ def gen_dfsmn():
     save("dfsmn_hostloop", **hl)
 
 
+def gen_dfsmn_near_only():
+    print("DFSMN_VAD wrapper, near-end-only variant (baked white-noise far end)")
+    import types as _t
+    import torchaudio
+    D = "DFSMN/only_near_end_audio/"
+    stft_mod = R.load_module(D + "STFT_Process.py", "ref_stft_v1c")
+    pkg = _t.ModuleType("aecpkg2")
+    pkg.__path__ = []
+    sys.modules["aecpkg2"] = pkg
+    lb = _t.ModuleType("aecpkg2.layer_base")
+
+    class LayerBase(torch.nn.Module):
+        pass
+    lb.LayerBase = LayerBase
+    lb.expect_token_number = lb.expect_kaldi_matrix = lb.to_kaldi_matrix = lambda *a, **k: None
+    sys.modules["aecpkg2.layer_base"] = lb
+    spec = __import__("importlib.util").util.spec_from_file_location(
+        "aecpkg2.uni_deep_fsmn", os.path.join(R.REF, D + "modeling_modified/uni_deep_fsmn.py"))
+    udf = __import__("importlib.util").util.module_from_spec(spec)
+    sys.modules["aecpkg2.uni_deep_fsmn"] = udf
+    spec.loader.exec_module(udf)
+    ns = {"torch": torch, "torchaudio": torchaudio, "np": np}
+    R.select_nodes(D + "Export_DFSMN_VAD.py",
+                   {"AlphaPredictor", "CFB", "CepsUnit", "LayerNorm", "NET", "CH_LSTM_T", "CH_LSTM_F", "DFSMN_VAD"}, ns,
+                   consts={"NFFT_B", "WINDOW_LENGTH_B", "HOP_LENGTH_B", "ALPHA_K"})
+    seed = 1234
+    w = weights.dfsmn_synthetic(seed)
+    m = weights.DFSMN_MASK
+    torch.manual_seed(0)
+    net = ns["NET"](max_frames=200)
+    net.load_state_dict({k[len("iccrn."):]: T(v) for k, v in w.items() if k.startswith("iccrn.")}, strict=False)
+    net = net.float().eval()
+    alpha = ns["AlphaPredictor"](10)
+    alpha.load_state_dict({k[len("alpha."):]: T(v) for k, v in w.items() if k.startswith("alpha.")}, strict=True)
+    alpha = alpha.float().eval()
+
+    class Mask(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.linear1 = torch.nn.Linear(240, m["hidden"])
+            self.relu = torch.nn.ReLU()
+            self.deepfsmn = torch.nn.Sequential(*[udf.UniDeepFsmn(m["hidden"], m["hidden"], m["lorder"], m["fsmn_hidden"])
+                                                   for _ in range(m["layers"])])
+            self.linear3 = torch.nn.Linear(m["hidden"], 1)
+    mask = Mask()
+    mask.load_state_dict({k[len("mask."):]: T(v) for k, v in w.items() if k.startswith("mask.") and k not in ("mask.shift", "mask.scale")}, strict=True)
+    holder = _t.SimpleNamespace(model=mask.eval(), preprocessor=_t.SimpleNamespace(
+        feature=_t.SimpleNamespace(shift=T(w["mask.shift"]), scale=T(w["mask.scale"]))))
+    mk = lambda n, h, wl: stft_mod.STFT_Process(model_type="stft_B", n_fft=n, hop_len=h, win_length=wl, max_frames=0, window_type="hamming").eval()   # noqa: E731
+    torch.manual_seed(4321)              # the export draws its white-noise constants here (Export_DFSMN_VAD.py:309-310)
+    model = ns["DFSMN_VAD"](holder, net, alpha, mk(1024, 320, 640), mk(640, 320, 640), mk(319, 160, 319),
+                            1024, 319, 10, 200, 0.97, 16000, 80)
+    near = weights.burst_clips(1, 16001, seed=seed + 1)[0].reshape(1, 1, -1)
+    with torch.no_grad():
+        # the wrapper calls .unsqueeze on a shape entry: it only runs under tracing (as in torch.onnx.export), where
+        # sizes are tensors -- so the module is traced on the input and the traced graph evaluated
+        traced = torch.jit.trace(model, (T(near),), check_trace=False)
+        vad = traced(T(near))
+    save("dfsmn_near_only", near=near, vad=vad.numpy(),
+         pow_far=model.pow_far_white_noise[0, 0, :, :101].numpy(), far_comp=model.far_comp_white_noise[0, 0, :, :, :101].numpy())
+
+
 # ------------------------------------------------------------------------------------ MarbleNet BN fold
 def gen_marblenet_fold():
     print("MarbleNet fold_bn_into_conv1d")
@@ -661,7 +723,7 @@ def gen_marblenet_fold():
 if __name__ == "__main__":
     which = set(sys.argv[1:])
     gens = dict(stft=gen_stft, host=gen_host, vadpost=gen_vadpost, silero_host=gen_silero_host,
-                fsmn=gen_fsmn, firered=gen_firered, firered_stream=gen_firered_stream, firered_ckpt=gen_firered_ckpt, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn)
+                fsmn=gen_fsmn, firered=gen_firered, firered_stream=gen_firered_stream, firered_ckpt=gen_firered_ckpt, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn, dfsmn_near_only=gen_dfsmn_near_only)
     for name, fn in gens.items():
         if not which or name in which:
             fn()

@@ -68,3 +68,21 @@ def test_whole_clip_pair_segments():
     for b in range(B):
         want, _ = od.run_clip(fe, w, near[b], far[b], nz1[b], nz2[b], weights.DFSMN_MASK["layers"])
         assert got[b] == want
+
+
+def test_near_only_session_matches_reference_fixture(golden):
+    """DFSMN/only_near_end_audio: one stream in, the far end replaced by the export's baked white-noise tensors
+    (carried by the fixture), against what the reference wrapper produced."""
+    g = golden("dfsmn_near_only")
+    consts = (g["pow_far"].astype(np.float32), g["far_comp"].astype(np.float32))
+    sess = dfsmn.DfsmnSession(weights.dfsmn_synthetic(1234), near_only=consts)
+    assert [m.name for m in sess.get_inputs()] == ["audio"]
+    out = sess.run(None, {"audio": g["near"]})[0]
+    assert out.shape == (51,)
+    np.testing.assert_allclose(out, g["vad"], rtol=0, atol=1e-4)
+    # batched windows give the same answer, and the two-stream path of the same engine is untouched
+    three = np.repeat(g["near"].reshape(1, -1), 3, axis=0)
+    v3 = sess.engine.run(three, None).cpu().numpy()
+    assert np.array_equal(v3[0], v3[2]) and np.array_equal(v3[0], out)
+    with pytest.raises(ValueError):
+        dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234)).run(three, None)

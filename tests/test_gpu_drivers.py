@@ -168,3 +168,21 @@ def test_firered_and_marblenet_on_vad_sample(tmp_path):
     np.testing.assert_allclose(track_m[0].cpu().numpy(), p_m, rtol=0, atol=1e-4)
     if np.array_equal(dec_g[0].cpu().numpy(), dec_m):
         assert got_m == want_m and open(idx2).read() == "".join(opp.timestamp_lines(want_m, 16000)[1])
+
+
+def test_dfsmn_near_only_on_vad_sample(tmp_path):
+    from vadx import dfsmn
+    from oracle import dfsmn as od
+    wts = weights.dfsmn_synthetic(1234)
+    pf, fc = weights.dfsmn_near_only_constants(1234)
+    eng = dfsmn.DfsmnEngine(wts)
+    eng.set_near_only_constants(pf, fc)
+    nz = np.random.default_rng(12).standard_normal((1, 20000))
+    sec, idx = str(tmp_path / "s.txt"), str(tmp_path / "i.txt")
+    got = drivers.inference_dfsmn_near_only(WAV, eng, sec, idx, pad_noise=nz, echo=lambda *_: None)
+    w = {k: T(v) for k, v in wts.items()}
+    w["mask.shift"] = w["mask.shift"] + torch.log(torch.tensor(32768 ** 2, dtype=torch.float32))
+    a = audio_io.load_wav(WAV).astype(np.float32)
+    want, _ = od.run_clip(od.Frontend(), w, a, None, nz[0], None, weights.DFSMN_MASK["layers"], near_only=(T(pf), T(fc)))
+    assert got == want
+    assert open(idx).read() == "".join(opp.timestamp_lines(want, 16000)[1])

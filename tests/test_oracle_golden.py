@@ -273,6 +273,18 @@ def test_dfsmn_forward(golden, seed):
     np.testing.assert_allclose(vad.numpy(), g[f"s{seed}_vad"], rtol=0, atol=2e-5)
 
 
+def test_dfsmn_near_only_forward(golden):
+    """The near-end-only export (DFSMN/only_near_end_audio): same graph with the far end replaced by two baked
+    white-noise tensors, which the fixture carries as that model's constants."""
+    from oracle import dfsmn as od
+    g = golden("dfsmn_near_only")
+    w = {k: T(v) for k, v in weights.dfsmn_synthetic(1234).items()}
+    w["mask.shift"] = w["mask.shift"] + torch.log(torch.tensor(32768 ** 2, dtype=torch.float32))
+    consts = (T(g["pow_far"].astype(np.float32)), T(g["far_comp"].astype(np.float32)))
+    vad, _ = od.forward(od.Frontend(), w, T(g["near"]), None, weights.DFSMN_MASK["layers"], consts)
+    np.testing.assert_allclose(vad.numpy(), g["vad"], rtol=0, atol=2e-5)
+
+
 def test_dfsmn_hostloop(golden):
     from oracle import dfsmn as od
     g = golden("dfsmn_hostloop")

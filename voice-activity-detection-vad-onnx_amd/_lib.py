@@ -132,7 +132,7 @@ SIGNATURES = {
     "vadx_dfsmn_dft_f": (_I, [_I, C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtLn), _P, C.POINTER(FtView), _I, _I, _P]),
     "vadx_dfsmn_lstm_f": (_I, [C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
                                C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), C.POINTER(FtView), _I, _I, _P]),
-    "vadx_dfsmn_alpha_scale": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "vadx_dfsmn_alpha_scale": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "vadx_dfsmn_lstm_t": (_I, [_I, C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
                                C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), _P, _P, C.POINTER(FtView),
                                C.POINTER(FtView), _I, _I, _I, _P]),

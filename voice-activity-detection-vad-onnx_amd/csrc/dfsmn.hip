@@ -469,9 +469,12 @@ __global__ __launch_bounds__(128) void lstm_f_kernel(LstmFArgs p) {
 //   alpha[f][t] = linear2_j( linear1( [pow_far, pow_mix][t-9+j] ) ),  pow = re^2 + im^2, zero history.
 // in: FT [4 ch] (mix re, mix im, far re, far im) of NT tiles per chunk; one thread per (tile, f, t16).
 // ---------------------------------------------------------------------------------------------
+// pow_far != nullptr: the near-end-only model (DFSMN/only_near_end_audio/Export_DFSMN_VAD.py:309-331), whose far-end
+// power is a constant [160][frames][10] baked at export (channels 2, 3 of `in` then hold the constant far spectrum).
 __global__ void alpha_scale_kernel(const float *__restrict__ in, float *__restrict__ out, int nt, long long total,
                                    const float *__restrict__ w1, const float *__restrict__ b1,
-                                   const float *__restrict__ w2, const float *__restrict__ b2) {
+                                   const float *__restrict__ w2, const float *__restrict__ b2,
+                                   const float *__restrict__ pow_far, int frames) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     const int t16 = (int)(e & 15), f = (int)((e >> 4) % 160);
@@ -487,6 +490,7 @@ __global__ void alpha_scale_kernel(const float *__restrict__ in, float *__restri
             pm = mr * mr + mi * mi;
             pf = fr * fr + fi * fi;
         }
+        if (pow_far) pf = pow_far[((size_t)f * frames + (t < frames ? t : frames - 1)) * 10 + j];
         const float a1 = w1[0] * pf + w1[1] * pm + b1[0];
         alpha = fmaf(w2[j], a1, alpha);
     }
@@ -1021,11 +1025,12 @@ extern "C" int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, c
 
 
 extern "C" int vadx_dfsmn_alpha_scale(const float *in, float *out, int chunks, int nt, const float *w1, const float *b1,
-                                      const float *w2, const float *b2, void *stream) {
+                                      const float *w2, const float *b2, const float *pow_far, int frames, void *stream) {
     VADX_REQUIRE(in && out && w1 && b1 && w2 && b2 && chunks > 0 && nt > 0, "vadx_dfsmn_alpha_scale: bad argument");
+    VADX_REQUIRE(!pow_far || (frames > 0 && frames <= nt * 16), "vadx_dfsmn_alpha_scale: frames out of range for the constant far power");
     const long long total = (long long)chunks * nt * 160 * 16;
     hipLaunchKernelGGL(alpha_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       in, out, nt, total, w1, b1, w2, b2);
+                       in, out, nt, total, w1, b1, w2, b2, pow_far, frames);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }

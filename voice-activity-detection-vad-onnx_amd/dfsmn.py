@@ -260,11 +260,28 @@ class DfsmnEngine:
             mw.fsmn_conv_w[l] = mdev(w[f"mask.deepfsmn.{l}.conv1.weight"][:, 0, :, 0])
         self.mask = mw
 
-    def run(self, near_i16, far_i16, windows_per_clip=1, win_stride=None, return_aec=False):
-        """near/far int16 [B, N] on the window grid -> vad f32 [B*W, 51] (each window stateless, as the reference)."""
+    def set_near_only_constants(self, pow_far, far_comp):
+        """The near-end-only model (DFSMN/only_near_end_audio/Export_DFSMN_VAD.py:309-310, :327-331) replaces the far-end
+        spectrum by two tensors of white noise drawn ONCE at export and baked into the graph: pow_far [160, T>=T_B, 10]
+        and far_comp [2, 160, T>=T_B] (float16 values).  They are part of that model's weights: pass the ones of the
+        export being replaced, or `weights.dfsmn_near_only_constants(seed)` for a stand-in."""
+        t = self.torch
+        pf = np.asarray(pow_far, dtype=np.float32)[:, :self.T_B, :]
+        fc = np.asarray(far_comp, dtype=np.float32)[:, :, :self.T_B]
+        if pf.shape != (F_BINS, self.T_B, 10) or fc.shape != (2, F_BINS, self.T_B):
+            raise ValueError(f"near-only constants must cover [160, {self.T_B}, 10] and [2, 160, {self.T_B}]")
+        self.pow_far = t.from_numpy(np.ascontiguousarray(pf)).to(self.device)
+        self.far_ft = to_ft(t, t.from_numpy(np.ascontiguousarray(fc)).unsqueeze(0), self.device).data      # [nt, 2, 160, 16]
+
+    def run(self, near_i16, far_i16=None, windows_per_clip=1, win_stride=None, return_aec=False):
+        """near/far int16 [B, N] on the window grid -> vad f32 [B*W, 51] (each window stateless, as the reference).
+        far_i16 None = the near-end-only model (needs set_near_only_constants)."""
         t = self.torch
         to_dev = lambda a: (a if t.is_tensor(a) else t.from_numpy(np.ascontiguousarray(a, dtype=np.int16))).to(self.device).contiguous()   # noqa: E731
-        near, far = to_dev(near_i16), to_dev(far_i16)
+        if far_i16 is None and getattr(self, "pow_far", None) is None:
+            raise ValueError("near-only run: call set_near_only_constants(pow_far, far_comp) first")
+        near = to_dev(near_i16)
+        far = None if far_i16 is None else to_dev(far_i16)
         B, W = near.shape[0], int(windows_per_clip)
         ws = self.L if win_stride is None else int(win_stride)
         n_chunks = B * W
@@ -273,7 +290,7 @@ class DfsmnEngine:
         per = max(1, self.sub_batch // W)                  # clips per sub-batch (activations are ~30 MB per window)
         for b0 in range(0, B, per):
             nb = min(per, B - b0)
-            v, a = self._run_sub(near[b0:b0 + nb], far[b0:b0 + nb], W, ws)
+            v, a = self._run_sub(near[b0:b0 + nb], None if far is None else far[b0:b0 + nb], W, ws)
             vad[b0 * W:(b0 + nb) * W] = v
             if return_aec:
                 aec_all[b0 * W:(b0 + nb) * W] = a
@@ -291,9 +308,13 @@ class DfsmnEngine:
         st = _lib.stream_ptr()
         with t.cuda.device(self.device):
             for src, means, coff in ((near, mean_near, 0), (far, mean_far, 2)):
+                if src is None:          # near-only: channels 2, 3 = the baked far spectrum, the same for every window
+                    xraw.data.view(n, nt, 4, F_BINS, 16)[:, :, 2:4] = self.far_ft.unsqueeze(0)
+                    continue
                 _lib.check(lib.vadx_frontend_stft_ft(C.byref(self.fe_b.cfg), self.fe_b.packed.data_ptr(), src.data_ptr(),
                                                      _lib.row_stride(src), ws, B, W, means.data_ptr(), xraw.data.data_ptr(), 4, coff, st))
-            _lib.check(lib.vadx_dfsmn_alpha_scale(xraw.data.data_ptr(), x4.data.data_ptr(), n, nt, *[a.data_ptr() for a in self.alpha], st))
+            _lib.check(lib.vadx_dfsmn_alpha_scale(xraw.data.data_ptr(), x4.data.data_ptr(), n, nt, *[a.data_ptr() for a in self.alpha],
+                                                  None if far is not None else self.pow_far.data_ptr(), self.T_B, st))
             y = self.iccrn.forward(x4, n, self.T_B)
             z = t.empty((n, self.T_B, 320), dtype=t.float32, device=self.device)
             aec = t.empty((n, self.L), dtype=t.float32, device=self.device)
@@ -321,17 +342,19 @@ class DfsmnEngine:
         from . import timestamps as ts
         from .fsmn import pad_to_window_grid
         t = self.torch
-        near_clips, far_clips = np.asarray(near_clips), np.asarray(far_clips)
+        near_clips = np.asarray(near_clips)
+        far_clips = None if far_clips is None else np.asarray(far_clips)      # None: the near-end-only model
         B = near_clips.shape[0]
-        n = min(near_clips.shape[1], far_clips.shape[1])
+        n = near_clips.shape[1] if far_clips is None else min(near_clips.shape[1], far_clips.shape[1])
         lb, stride = self.grid()
         rows_n, rows_f = [], []
         for b in range(B):
             a = ts.normalize_to_int16(near_clips[b, :n].astype(np.float32))
-            f = ts.normalize_to_int16(far_clips[b, :n].astype(np.float32))
             rows_n.append(pad_to_window_grid(a, self.L, stride, None if pad_noise_near is None else pad_noise_near[b]))
-            rows_f.append(pad_to_window_grid(f, self.L, stride, None if pad_noise_far is None else pad_noise_far[b]))
-        near, far = np.stack(rows_n), np.stack(rows_f)
+            if far_clips is not None:
+                f = ts.normalize_to_int16(far_clips[b, :n].astype(np.float32))
+                rows_f.append(pad_to_window_grid(f, self.L, stride, None if pad_noise_far is None else pad_noise_far[b]))
+        near, far = np.stack(rows_n), (np.stack(rows_f) if far_clips is not None else None)
         W = (near.shape[1] - self.L) // stride + 1
         vad = self.run(near, far, W, stride)
         flags = t.empty((B, W * (self.T_A - lb) + lb), dtype=t.uint8, device=self.device)
@@ -345,12 +368,18 @@ class DfsmnEngine:
 
 class DfsmnSession:
     """{'near_end_audio','far_end_audio': int16 [1,1,16001]} -> [vad_results f32 [51]]
-    (DFSMN/near_and_far_end_audio/Export_DFSMN_VAD.py:377-393)."""
+    (DFSMN/near_and_far_end_audio/Export_DFSMN_VAD.py:377-393).  near_only = (pow_far, far_comp): the near-end-only export
+    instead -- {'audio': int16 [1,1,16001]} (DFSMN/only_near_end_audio/Export_DFSMN_VAD.py:373-392)."""
 
-    def __init__(self, weights=None, device="cuda:0"):
+    def __init__(self, weights=None, device="cuda:0", near_only=None):
         from .fsmn import _Meta
         self.engine = DfsmnEngine(weights, device)
-        self._inputs_meta = [_Meta("near_end_audio", [1, 1, 16001], "tensor(int16)"), _Meta("far_end_audio", [1, 1, 16001], "tensor(int16)")]
+        self.near_only = near_only is not None
+        if self.near_only:
+            self.engine.set_near_only_constants(*near_only)
+            self._inputs_meta = [_Meta("audio", [1, 1, 16001], "tensor(int16)")]
+        else:
+            self._inputs_meta = [_Meta("near_end_audio", [1, 1, 16001], "tensor(int16)"), _Meta("far_end_audio", [1, 1, 16001], "tensor(int16)")]
         self._outputs_meta = [_Meta("vad_results", [51], "tensor(float)")]
 
     def get_inputs(self):
@@ -363,10 +392,13 @@ class DfsmnSession:
         return ["VadxMI355XExecutionProvider"]
 
     def run(self, output_names, feeds):
-        near, far = np.asarray(feeds["near_end_audio"]), np.asarray(feeds["far_end_audio"])
-        if near.dtype != np.int16 or far.dtype != np.int16:
-            raise ValueError("Unexpected input data type, expected: (tensor(int16))")
-        if near.shape[-1] != 16001 or far.shape[-1] != 16001:
-            raise ValueError("Got invalid dimensions for input: expected last dim 16001")
-        vad = self.engine.run(near.reshape(-1, 16001), far.reshape(-1, 16001)).cpu().numpy()
+        arrs = [np.asarray(feeds[m.name]) for m in self._inputs_meta]
+        for a in arrs:
+            if a.dtype != np.int16:
+                raise ValueError("Unexpected input data type, expected: (tensor(int16))")
+            if a.shape[-1] != 16001:
+                raise ValueError("Got invalid dimensions for input: expected last dim 16001")
+        near = arrs[0].reshape(-1, 16001)
+        far = None if self.near_only else arrs[1].reshape(-1, 16001)
+        vad = self.engine.run(near, far).cpu().numpy()
         return [vad.reshape(-1) if vad.shape[0] == 1 else vad]

@@ -198,3 +198,25 @@ def inference_dfsmn(test_near_end_audio="./examples/nearend_mic.wav", test_far_e
                                 min_speech_duration=MIN_SPEECH_DURATION, speaking_score=SPEAKING_SCORE, silence_score=SILENCE_SCORE)
     elapsed = time.time() - t0
     return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_near_end_audio, (list, tuple)), elapsed, echo)
+
+
+def inference_dfsmn_near_only(test_vad_audio="./vad_sample.wav", engine=None, save_timestamps_second="./timestamps_second.txt",
+                              save_timestamps_indices="./timestamps_indices.txt", SPEAKING_SCORE=0.5, SILENCE_SCORE=0.5,
+                              FUSION_THRESHOLD=0.3, MIN_SPEECH_DURATION=0.2, pad_noise=None, echo=print):
+    """DFSMN/only_near_end_audio/Inference_DFSMN_VAD_ONNX.py: one microphone file in, timestamps out.  `engine` must
+    carry the export's baked white-noise constants (DfsmnEngine.set_near_only_constants)."""
+    from . import dfsmn, weights
+    files = _as_list(test_vad_audio)
+    if engine is None:
+        engine = dfsmn.DfsmnEngine()
+        engine.set_near_only_constants(*weights.dfsmn_near_only_constants(1234))
+    echo(f"\nTest Input Audio: {test_vad_audio}")
+    all_ts = []
+    t0 = time.time()
+    for k, pth in enumerate(files):
+        a = audio_io.load_wav(pth, 16000).astype(np.float32)
+        nz = None if pad_noise is None else np.asarray(pad_noise)[k][None, :]
+        all_ts += engine.detect(a[None, :], None, nz, None, fusion_threshold=FUSION_THRESHOLD, min_speech_duration=MIN_SPEECH_DURATION,
+                                speaking_score=SPEAKING_SCORE, silence_score=SILENCE_SCORE)
+    elapsed = time.time() - t0
+    return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_vad_audio, (list, tuple)), elapsed, echo)

@@ -299,3 +299,13 @@ def dfsmn_synthetic(seed=1234, mask=None):
 
 
 _DFSMN_OUT_CALIB = {}
+
+
+def dfsmn_near_only_constants(seed=1234, frames=200, k=10, n_bins=160):
+    """Stand-in for the two white-noise tensors the near-end-only DFSMN export bakes into its graph
+    (DFSMN/only_near_end_audio/Export_DFSMN_VAD.py:309-310): float16 randn, squared for the power term.
+    -> (pow_far [n_bins, frames, k], far_comp [2, n_bins, frames]) as float32 arrays holding float16 values."""
+    rng = _rng(seed, "dfsmn_near_only")
+    pow_far = np.square(rng.standard_normal((n_bins, frames, k)).astype(np.float16)).astype(np.float16)
+    far_comp = rng.standard_normal((2, n_bins, frames)).astype(np.float16)
+    return pow_far.astype(np.float32), far_comp.astype(np.float32)
