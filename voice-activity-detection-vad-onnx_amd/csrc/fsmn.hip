@@ -116,7 +116,7 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
     LayerArgs a;
     // in_linear1: K = 5 passes x 80 (LFR concat: frame offset j -> column offset j), CMVN on the operand
     a = LayerArgs{Pk + d.off_in1, 400, d.Ap / 16, LFR_M, NMEL / 16, NMEL, 1, Pk + d.off_b1, 0,
-                  bufB, A_LD, 0, bufP, A_LD, 0, Pk + d.off_mean, Pk + d.off_var};
+                  bufB, A_LD, 0, bufP, A_LD, 0, Pk + d.off_mean, Pk + d.off_var, bufA};      // bufA is idle: K-split scratch
     layer<MTT, true>(a);
     __syncthreads();
     FS_ACC(1);
@@ -179,7 +179,7 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
         FS_ACC(6);
     }
     a = LayerArgs{Pk + d.off_out1, d.Lp, d.A2p / 16, 1, d.Lp / 16, 0, 0, Pk + d.off_bo1, 0,
-                  bufA, A_LD, 0, bufB, A_LD, 0, nullptr, nullptr};
+                  bufA, A_LD, 0, bufB, A_LD, 0, nullptr, nullptr, bufP};                      // bufP is idle: K-split scratch
     layer<MTT, false>(a);
     __syncthreads();
     a = LayerArgs{Pk + d.off_out2, d.A2p, d.Op / 16, 1, d.A2p / 16, 0, 0, Pk + d.off_bo2, 0,

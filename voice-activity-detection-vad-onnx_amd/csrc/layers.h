@@ -13,6 +13,8 @@ struct LayerArgs {
     const float *act; int lda, acol0;
     float *dst; int ldd, dcol0;
     const float *add, *mul;               // CMVN (AFFINE only)
+    float *scratch = nullptr;             // optional LDS scratch (>= NW*256*MTT floats, not act/dst): leftover n-tiles are
+                                          // then K-split over all waves instead of running as single-tile chains
 };
 
 // dst[n][m] = act[k][m] x W[n][k] (+bias, ReLU).  Work items: whole n-tiles (all MTT m-tiles of the tile share each
@@ -45,6 +47,49 @@ __device__ __forceinline__ void layer(const LayerArgs &a) {
             for (int r = 0; r < 4; ++r) { v[r] = acc[0][mt][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
             *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i) * a.ldd + a.dcol0 + mt * 16 + 4 * q) = v;
         }
+    }
+    if (a.scratch && a.ntiles - full == 1) {
+        // One leftover n-tile (e.g. 9 tiles on 8 waves): every wave contracts a slice of its K blocks for all MTT m-tiles
+        // (full weight reuse, no dependent single-tile chain), the partial tiles meet in LDS and are summed in wave
+        // order -- a fixed order, so the result is reproducible.
+        const int nt = full, nblk = a.npass * a.kb;
+        f32x4 acc[MTT];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *row = frag_ptr(a.W, a.ldw, nt, 0, lane);
+        const float *ap = a.act + (4 * q) * a.lda + i + a.acol0;
+        for (int b = wave; b < nblk; b += NW) {
+            const int ps = b / a.kb, S = b - ps * a.kb;
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(row + ps * a.kstep * 16 + S * FRAG);
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, m4 = {1.f, 1.f, 1.f, 1.f};
+            if (AFFINE) {
+                a4 = *reinterpret_cast<const f32x4 *>(a.add + ps * a.kstep + 16 * S + 4 * q);
+                m4 = *reinterpret_cast<const f32x4 *>(a.mul + ps * a.kstep + 16 * S + 4 * q);
+            }
+            const float *aps = ap + 16 * S * a.lda + ps * a.cstep;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MTT; ++mt) {
+                    float av = aps[j * a.lda + mt * 16];
+                    if (AFFINE) av = __fmul_rn(__fadd_rn(av, a4[j]), m4[j]);
+                    acc[mt] = mfma16(av, w4[j], acc[mt]);
+                }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt)
+            *reinterpret_cast<f32x4 *>(a.scratch + ((wave * 16 + i) * MTT + mt) * 16 + 4 * q) = acc[mt];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 16 * MTT * 4; e += blockDim.x) {      // (row i2, m-tile, frame quad)
+            const int i2 = e / (MTT * 4), rem = e - i2 * MTT * 4;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(a.scratch + (i2 * MTT) * 16 + rem * 4);
+            for (int w2 = 1; w2 < NW; ++w2) v += *reinterpret_cast<const f32x4 *>(a.scratch + ((w2 * 16 + i2) * MTT) * 16 + rem * 4);
+            const float b = a.bias ? a.bias[nt * 16 + i2] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] += b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
+            *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i2) * a.ldd + a.dcol0 + rem * 4) = v;
+        }
+        return;
     }
     for (int item = wave; item < (a.ntiles - full) * MTT; item += NW) {
         const int nt = full + item / MTT, mt = item - (item / MTT) * MTT;
