@@ -164,16 +164,29 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
 
     for (int chunk = blockIdx.y; chunk < p.nchunk; chunk += gridDim.y) {
         const int f0 = chunk * p.fc, fcv = min(p.fc, p.F - f0);
-        // ---- stage the input rows: thread = (row (c, ffl), frame quad)
-        for (int e = tid; e < cin * fh * 4; e += 256) {
-            const int rowi = e >> 2, tq = e & 3, c = rowi / fh, ffl = rowi - c * fh, ff = f0 - HALO + ffl;
-            // unconditional (clamped) load, then select: a guarded load is a branch plus a full wait per iteration
-            const int fc2 = ff < 0 ? 0 : (ff >= p.F ? p.F - 1 : ff);
-            const float *src = c < p.a.c ? p.a.ptr + ft_idx(tile, p.a.c_total, p.a.c_off + c, p.F, fc2)
-                                         : p.b.ptr + ft_idx(tile, p.b.c_total, p.b.c_off + c - p.a.c, p.F, fc2);
-            f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * tq);
-            if (ff < 0 || ff >= p.F) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(raw + (c * fs + ffl) * 16 + 4 * tq) = v;
+        // ---- stage the input rows: thread = (row (c, ffl), frame quad); four unconditional (clamped) loads in flight
+        // per thread, then the stores -- a load-store pair per iteration is one serialised round trip each
+        {
+            const int nitem = cin * fh * 4;
+            auto src_of = [&](int e) -> const float * {
+                const int rowi = e >> 2, tq = e & 3, c = rowi / fh, ffl = rowi - c * fh;
+                const int ff = f0 - HALO + ffl, fc2 = ff < 0 ? 0 : (ff >= p.F ? p.F - 1 : ff);
+                return (c < p.a.c ? p.a.ptr + ft_idx(tile, p.a.c_total, p.a.c_off + c, p.F, fc2)
+                                  : p.b.ptr + ft_idx(tile, p.b.c_total, p.b.c_off + c - p.a.c, p.F, fc2)) + 4 * tq;
+            };
+            auto put = [&](int e, f32x4 v) {
+                const int rowi = e >> 2, tq = e & 3, c = rowi / fh, ffl = rowi - c * fh, ff = f0 - HALO + ffl;
+                *reinterpret_cast<f32x4 *>(raw + (c * fs + ffl) * 16 + 4 * tq) = (ff < 0 || ff >= p.F) ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+            };
+            int e0 = tid;
+            for (; e0 + 3 * 256 < nitem; e0 += 4 * 256) {       // full batches: four loads in flight, then four stores
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src_of(e0 + 256 * u));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) put(e0 + 256 * u, v[u]);
+            }
+            for (; e0 < nitem; e0 += 256) put(e0, *reinterpret_cast<const f32x4 *>(src_of(e0)));
         }
         if (p.ln.stats)
             for (int rowi = tid; rowi < cin * fh; rowi += 256) {
@@ -223,15 +236,33 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
         }
         __syncthreads();
 
-        // ---- coalesced write-out: thread = (row (co, fl), frame quad)
-        for (int e = tid; e < p.co * fcv * 4; e += 256) {
-            const int rowi = e >> 2, tq = e & 3, co = rowi / fcv, fl = rowi - co * fcv;
-            f32x4 v = *reinterpret_cast<const f32x4 *>(o0 + (co * p.fc + fl) * 16 + 4 * tq);
-            if (MODE == 2) v += *reinterpret_cast<const f32x4 *>(p.add.ptr + ft_idx(tile, p.add.c_total, p.add.c_off + co, p.F, f0 + fl) + 4 * tq);
-            *reinterpret_cast<f32x4 *>(p.out0.ptr + ft_idx(tile, p.out0.c_total, p.out0.c_off + co, p.F, f0 + fl) + 4 * tq) = v;
-            if (MODE == 1)
-                *reinterpret_cast<f32x4 *>(p.out1.ptr + ft_idx(tile, p.out1.c_total, p.out1.c_off + co, p.F, f0 + fl) + 4 * tq) =
-                    *reinterpret_cast<const f32x4 *>(o1 + (co * p.fc + fl) * 16 + 4 * tq);
+        // ---- coalesced write-out: thread = (row (co, fl), frame quad); the residual `add` rows of a batch are requested
+        // together before the stores
+        {
+            const int nitem = p.co * fcv * 4;
+            for (int e0 = tid; e0 < nitem; e0 += 4 * 256) {
+                f32x4 av[4];
+                if (MODE == 2) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = min(e0 + 256 * u, nitem - 1), rowi = e >> 2, tq = e & 3, co = rowi / fcv, fl = rowi - co * fcv;
+                        av[u] = *reinterpret_cast<const f32x4 *>(p.add.ptr + ft_idx(tile, p.add.c_total, p.add.c_off + co, p.F, f0 + fl) + 4 * tq);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + 256 * u;
+                    if (e < nitem) {
+                        const int rowi = e >> 2, tq = e & 3, co = rowi / fcv, fl = rowi - co * fcv;
+                        f32x4 v = *reinterpret_cast<const f32x4 *>(o0 + (co * p.fc + fl) * 16 + 4 * tq);
+                        if (MODE == 2) v += av[u];
+                        *reinterpret_cast<f32x4 *>(p.out0.ptr + ft_idx(tile, p.out0.c_total, p.out0.c_off + co, p.F, f0 + fl) + 4 * tq) = v;
+                        if (MODE == 1)
+                            *reinterpret_cast<f32x4 *>(p.out1.ptr + ft_idx(tile, p.out1.c_total, p.out1.c_off + co, p.F, f0 + fl) + 4 * tq) =
+                                *reinterpret_cast<const f32x4 *>(o1 + (co * p.fc + fl) * 16 + 4 * tq);
+                    }
+                }
+            }
         }
         // the next chunk's staging writes raw/wb (last read before the barrier above); o0/o1 are rewritten only after
         // the next chunk's first barrier, i.e. after every thread has finished this write-out
