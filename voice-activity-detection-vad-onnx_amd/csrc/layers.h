@@ -26,7 +26,38 @@ __device__ __forceinline__ void layer(const LayerArgs &a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
     const int NW = blockDim.x >> 6;
     const int full = (a.ntiles / NW) * NW;
-    for (int nt = wave; nt < full; nt += NW) {
+    // rounds are taken two at a time (n-tiles nt and nt + NW side by side: 2*MTT accumulators, one pipeline fill and
+    // drain instead of two -- all waves fill at the same moment after a barrier, so that time is not hidden by anyone)
+    int nt0 = wave;
+    for (; nt0 + NW < full; nt0 += 2 * NW) {
+        f32x4 acc[2][MTT];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) acc[h][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *row0 = frag_ptr(a.W, a.ldw, nt0, 0, lane), *row1 = frag_ptr(a.W, a.ldw, nt0 + NW, 0, lane);
+        for (int ps = 0; ps < a.npass; ++ps) {
+            const float *const wrow[2] = {row0 + ps * a.kstep * 16, row1 + ps * a.kstep * 16};
+            int moff[MTT];
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) moff[mt] = a.acol0 + mt * 16 + ps * a.cstep;
+            gemm_rt<2, MTT, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
+                                           AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int nt = nt0 + h * NW;
+            const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = acc[h][mt][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
+                *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i) * a.ldd + a.dcol0 + mt * 16 + 4 * q) = v;
+            }
+        }
+    }
+    for (int nt = nt0; nt < full; nt += NW) {
         f32x4 acc[1][MTT];
 #pragma unroll
         for (int mt = 0; mt < MTT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
