@@ -18,13 +18,17 @@ namespace marblenet {
 
 constexpr int THREADS = 512;
 constexpr int TILE = 32, A_LD = 36;     // frames per tile, k-major row stride
-constexpr int IN_LD = 100;              // halo tile row stride (>= 31*stride + (k-1)*dil + 1, % 8 == 4)
+constexpr int IN_LD_MAX = 100;          // largest halo tile row stride (>= 31*stride + (k-1)*dil + 1, % 8 == 4)
 constexpr int MAXC = 128;
-constexpr int IN_F = MAXC * IN_LD, T_F = MAXC * A_LD;
-constexpr int LDS_FLOATS = IN_F + 4 * T_F;
+// LDS is carved per launch from the block's real shape (Cfg::in_ld, channel counts): a 64-channel k=13 block needs
+// 47 KB instead of the 125 KB worst case, i.e. three workgroups per CU instead of one -- a tile is a short serial chain
+// (stage -> FIR -> GEMM -> store), so with one workgroup per CU the launch was pure latency (72 rounds x ~6 us).
+static size_t lds_floats(int cinp, int coutp, int cresp, int in_ld, bool has_dw) {
+    return (size_t)cinp * in_ld + (has_dw ? (size_t)cinp * A_LD : 0) + (size_t)coutp * A_LD + (cresp ? (size_t)(cresp + coutp) * A_LD : 0);
+}
 
 struct Cfg {
-    int cin, cout, k, stride, dil, pad, has_dw, cres, relu, cinp, coutp, cresp;
+    int cin, cout, k, stride, dil, pad, has_dw, cres, relu, cinp, coutp, cresp, in_ld;
 };
 
 // KT / DT / ST: compile-time kernel size, dilation and stride of the depthwise stage (0 = take them from `c` at run
@@ -39,7 +43,8 @@ __global__ __launch_bounds__(THREADS, 2) void sepconv_block_kernel(
     long long xs_b, long long xs_c, long long xs_t, int T_in, const float *__restrict__ xres,
     float *__restrict__ y, int T_out, int tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *IN = lds, *D = lds + IN_F, *OUT = D + T_F, *RIN = OUT + T_F, *ROUT = RIN + T_F;
+    const int IN_LD = c.in_ld;
+    float *IN = lds, *D = IN + c.cinp * IN_LD, *OUT = D + (c.has_dw ? c.cinp * A_LD : 0), *RIN = OUT + c.coutp * A_LD, *ROUT = RIN + c.cresp * A_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TILE;
     const int K = KT ? KT : c.k, DIL = KT ? DT : c.dil, STR = KT ? ST : c.stride;
@@ -197,8 +202,11 @@ extern "C" int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w
     c.cinp = (c.cin + 15) & ~15; c.coutp = (c.cout + 15) & ~15; c.cresp = (c.cres + 15) & ~15;
     VADX_REQUIRE(c.cin > 0 && c.cin <= MAXC && c.cout > 0 && c.cout <= MAXC && c.cres >= 0 && c.cres <= MAXC,
                  "vadx_sepconv_block: channels must be in [1,128]");
-    VADX_REQUIRE(c.k >= 1 && c.stride >= 1 && c.dil >= 1 && (TILE - 1) * c.stride + (c.k - 1) * c.dil + 1 <= IN_LD,
-                 "vadx_sepconv_block: receptive field of a 32-frame tile exceeds %d samples", IN_LD);
+    VADX_REQUIRE(c.k >= 1 && c.stride >= 1 && c.dil >= 1 && (TILE - 1) * c.stride + (c.k - 1) * c.dil + 1 <= IN_LD_MAX,
+                 "vadx_sepconv_block: receptive field of a 32-frame tile exceeds %d samples", IN_LD_MAX);
+    {   const int width = (TILE - 1) * c.stride + (c.k - 1) * c.dil + 1;
+        c.in_ld = c.has_dw ? (((width + 7) & ~7) + 4) : A_LD; }      // % 8 == 4; a plain 1x1 block feeds IN straight to the GEMM
+    const size_t lds_bytes = lds_floats(c.cinp, c.coutp, c.cresp, c.in_ld, c.has_dw) * sizeof(float);
     VADX_REQUIRE(c.has_dw ? dw_w != nullptr : (c.k == 1 && c.stride == 1), "vadx_sepconv_block: plain conv must be k=1, stride 1");
     VADX_REQUIRE(!c.cres || (res_w && res_b && xres), "vadx_sepconv_block: residual branch needs res_w/res_b/xres");
     VADX_REQUIRE(batch > 0 && t_in > 0 && t_out > 0 && t_out == (t_in + 2 * c.pad - c.dil * (c.k - 1) - 1) / c.stride + 1,
@@ -210,11 +218,11 @@ extern "C" int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w
         static bool done_ = false;                                                                                              \
         if (!done_) {                                                                                                           \
             VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sepconv_block_kernel<KT, DT, ST>),                  \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));          \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                          \
             done_ = true;                                                                                                       \
         }                                                                                                                       \
         hipLaunchKernelGGL((sepconv_block_kernel<KT, DT, ST>), dim3((unsigned)(batch * tiles)), dim3(THREADS),                  \
-                           LDS_FLOATS * sizeof(float), static_cast<hipStream_t>(stream), c, dw_w, pw_w, pw_b, res_w, res_b, x,  \
+                           lds_bytes, static_cast<hipStream_t>(stream), c, dw_w, pw_w, pw_b, res_w, res_b, x,                   \
                            (long long)xs_b, (long long)xs_c, (long long)xs_t, t_in, xres, y, t_out, tiles);                      \
     } while (0)
     // the depthwise shapes of the published MarbleNet 3x2x64 get compile-time FIRs; anything else runs the generic kernel
