@@ -292,6 +292,10 @@ def main():
                          "flop_per_frame": FLOP_ENCODE_ISSUED, "frames_per_launch": B * T,
                          "dense_equivalent": {"flop_per_frame": FLOP_ENCODE,
                                               "achieved": achieved * FLOP_ENCODE / FLOP_ENCODE_ISSUED}},
+            # the recurrent kernel is matrix-pipe work too (W_hh x h, 16 clips = one MFMA tile wide): its own fraction
+            "roofline_recurrent": {"bound": "mfma", "kernel": "silero_lstm_kernel", "flop_per_frame": FLOP_RECUR,
+                                   "achieved": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
             "hbm": {"algorithmic_bytes_per_frame": 2048 + 4,
                     "achieved_GBps_whole_step": B * T * 2052 / (elapsed / args.steps) / 1e9, "peak_GBps": 8000.0},
             "cpu_baseline": cpu,

@@ -81,6 +81,21 @@ int vadx_silero_encode(const float *packed, const float *audio, int batch, int64
 int vadx_silero_recur(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
                       int steps, const float *state0, float *probs, float *state_n, void *stream);
 
+/* The same two launches over a SPAN of windows [first_step, first_step + n_steps) of the clips, for recordings whose
+ * whole-clip workspace (32 KB per 16-clip group and window) is too large: the caller walks the spans in order on one
+ * stream with one span-sized workspace (vadx_silero_workspace_bytes(batch, n_steps)), as
+ * vadx.silero.SileroEngine.clips_spanned does.  encode_span reads the clip rows with the usual zero context before
+ * sample 0 and zero padding after n_samples.  recur_span: `probs` points at column first_step of the [B][probs_stride]
+ * table, state0 (NULL = zeros) / state_n (may alias state0) carry [2,B,128] between spans.  Results are identical to
+ * the single launches (same kernels, same arithmetic order).  (Running span k's recurrence on a second stream under
+ * span k+1's encoder was measured and gains nothing: both kernels are matrix-pipe-bound) */
+int vadx_silero_encode_span(const float *packed, const float *audio, int batch, int64_t n_samples,
+                            int64_t row_stride, int first_step, int n_steps, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int vadx_silero_recur_span(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
+                           int n_steps, const float *state0, float *probs, int64_t probs_stride,
+                           float *state_n, void *stream);
+
 /* Parameters of the segmenter; defaults of get_speech_timestamps (utils_vad.py:248-263). */
 typedef struct vadx_silero_seg_params {
     double threshold;                 /* 0.5 */

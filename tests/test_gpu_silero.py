@@ -225,3 +225,44 @@ def test_tiny_clips_match_oracle(oracle_w, n):
     got = silero.get_speech_timestamps(T(a), model, min_speech_duration_ms=0, return_seconds=False)
     want = osil.get_speech_timestamps(T(a), osil.OnnxWrapperOracle(oracle_w), min_speech_duration_ms=0, return_seconds=False)
     assert got == want
+
+
+# ------------------------------------------------------------------ span-by-span schedule == single launches
+@pytest.mark.parametrize("batch,n,span", [(37, 20000, 16), (37, 20000, 1), (16, 5000, 3), (300, 160000, 100)])
+def test_spanned_schedule_is_bitwise_identical(engine, batch, n, span):
+    """clips_spanned (bounded workspace, LSTM state carried between spans) must give exactly the single-launch result:
+    scores and final state, for ragged lengths and partial clip groups."""
+    a = torch.from_numpy(weights.burst_clips(batch, n, seed=batch + n).astype(np.float32) * np.float32(0.000030517578)).cuda()
+    L = _lib.lib()
+    steps = (n + 511) // 512
+    ws = engine._workspace(batch, steps)
+    want = torch.empty((batch, steps), dtype=torch.float32, device="cuda")
+    st_want = torch.empty((2, batch, 128), dtype=torch.float32, device="cuda")
+    _lib.check(L.vadx_silero_clips(engine.packed.data_ptr(), a.data_ptr(), batch, n, _lib.row_stride(a), want.data_ptr(),
+                                   st_want.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    got = torch.full((batch, steps), -1.0, dtype=torch.float32, device="cuda")
+    st = engine.clips_spanned(a, n, got, span=span)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(st, st_want)
+
+
+def test_clips_switches_to_spans_above_the_workspace_cap(engine, monkeypatch):
+    a = torch.from_numpy(weights.burst_clips(20, 30000, seed=3).astype(np.float32) * np.float32(0.000030517578)).cuda()
+    want, st_want = engine.clips(a, return_state=True)
+    monkeypatch.setattr(silero, "WORKSPACE_CAP_BYTES", 5 * _lib.lib().vadx_silero_workspace_bytes(20, 1))
+    got, st = engine.clips(a, return_state=True)
+    assert torch.equal(got, want) and torch.equal(st, st_want)
+
+
+def test_span_entries_reject_bad_spans(engine):
+    a = torch.zeros((16, 2048), dtype=torch.float32, device="cuda")
+    ws = engine._workspace(16, 4)
+    L = _lib.lib()
+    assert L.vadx_silero_encode_span(engine.packed.data_ptr(), a.data_ptr(), 16, 2048, 2048, 3, 2, ws.data_ptr(), ws.numel(),
+                                     _lib.stream_ptr()) != 0     # windows 3..4 of a 4-window clip
+    assert L.vadx_silero_encode_span(engine.packed.data_ptr(), a.data_ptr(), 16, 2048, 2048, -1, 2, ws.data_ptr(), ws.numel(),
+                                     _lib.stream_ptr()) != 0
+    p = torch.zeros((16, 4), dtype=torch.float32, device="cuda")
+    assert L.vadx_silero_recur_span(engine.packed.data_ptr(), ws.data_ptr(), ws.numel(), 16, 4, None, p.data_ptr(), 3, None,
+                                    _lib.stream_ptr()) != 0      # probs_stride < n_steps

@@ -928,6 +928,25 @@ extern "C" int vadx_silero_recur(const float *packed, const void *workspace, siz
     return silero_recur_launch(packed, workspace, workspace_bytes, batch, steps, state0, probs, steps, state_n, stream);
 }
 
+extern "C" int vadx_silero_encode_span(const float *packed, const float *audio, int batch, int64_t n_samples,
+                                       int64_t row_stride, int first_step, int n_steps, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
+    VADX_REQUIRE(n_samples > 0 && row_stride >= n_samples, "vadx_silero_encode_span: n_samples=%lld row_stride=%lld",
+                 (long long)n_samples, (long long)row_stride);
+    const long long steps = (n_samples + 511) / 512;
+    VADX_REQUIRE(first_step >= 0 && n_steps > 0 && (long long)first_step + n_steps <= steps,
+                 "vadx_silero_encode_span: span [%d, %d + %d) outside the clip's %lld windows", first_step, first_step, n_steps, steps);
+    return silero_encode_launch(packed, audio, n_samples, row_stride, (long long)first_step * 512 - 64, batch, n_steps,
+                                workspace, workspace_bytes, stream);
+}
+
+extern "C" int vadx_silero_recur_span(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
+                                      int n_steps, const float *state0, float *probs, int64_t probs_stride,
+                                      float *state_n, void *stream) {
+    VADX_REQUIRE(probs_stride >= n_steps, "vadx_silero_recur_span: probs_stride=%lld < n_steps=%d", (long long)probs_stride, n_steps);
+    return silero_recur_launch(packed, workspace, workspace_bytes, batch, n_steps, state0, probs, probs_stride, state_n, stream);
+}
+
 extern "C" int vadx_silero_step(const float *packed, const float *input, const float *state, int64_t sr,
                                 int batch, float *out, float *state_n, void *workspace,
                                 size_t workspace_bytes, void *stream) {

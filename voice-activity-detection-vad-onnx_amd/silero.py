@@ -40,6 +40,9 @@ def _as_weight_dict(path_or_weights):
     return w
 
 
+WORKSPACE_CAP_BYTES = 8 << 30     # clips(): above this the gate-preactivation workspace is reused span by span
+
+
 class SileroEngine:
     """Device-resident packed weights + workspace; thin wrappers over the C ABI."""
 
@@ -115,12 +118,41 @@ class SileroEngine:
         steps = (n + NUM_SAMPLES - 1) // NUM_SAMPLES
         probs = t.empty((B, steps), dtype=t.float32, device=self.device)
         state_n = t.empty((2, B, HIDDEN), dtype=t.float32, device=self.device) if return_state else None
+        if _lib.lib().vadx_silero_workspace_bytes(B, steps) > WORKSPACE_CAP_BYTES:
+            state_n = self.clips_spanned(audio, n, probs, state_n)
+            return (probs, state_n) if return_state else probs
         ws = self._workspace(B, steps)
         with t.cuda.device(self.device):
             _lib.check(_lib.lib().vadx_silero_clips(self.packed.data_ptr(), audio.data_ptr(), B, n, _lib.row_stride(audio),
                                                     probs.data_ptr(), None if state_n is None else state_n.data_ptr(),
                                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
         return (probs, state_n) if return_state else probs
+
+    def clips_spanned(self, audio, n, probs, state=None, span=None):
+        """`clips` for recordings whose whole-clip workspace (32 KB per 16-clip group and window) would not fit: the
+        encoder and the recurrent kernel run span by span over windows [first, first + span) on the caller's stream,
+        reusing one span-sized workspace, the LSTM state carried in `state` [2,B,128].  Same kernels and arithmetic
+        order as `clips`: identical results.  audio f32 [B,N] on the device; probs [B,steps] is filled."""
+        t = self.torch
+        L = _lib.lib()
+        B = int(audio.shape[0])
+        steps = (int(n) + NUM_SAMPLES - 1) // NUM_SAMPLES
+        tile_bytes = L.vadx_silero_workspace_bytes(B, 1)
+        if span is None:
+            span = max(1, min(steps, WORKSPACE_CAP_BYTES // tile_bytes))
+        if state is None:
+            state = t.empty((2, B, HIDDEN), dtype=t.float32, device=self.device)
+        ws = self._workspace(B, min(span, steps))
+        with t.cuda.device(self.device):
+            st = _lib.stream_ptr()
+            for first in range(0, steps, span):
+                ns = min(span, steps - first)
+                _lib.check(L.vadx_silero_encode_span(self.packed.data_ptr(), audio.data_ptr(), B, int(n), _lib.row_stride(audio),
+                                                     first, ns, ws.data_ptr(), ns * tile_bytes, st))
+                _lib.check(L.vadx_silero_recur_span(self.packed.data_ptr(), ws.data_ptr(), ns * tile_bytes, B, ns,
+                                                    None if first == 0 else state.data_ptr(), probs.data_ptr() + 4 * first,
+                                                    steps, state.data_ptr(), st))
+        return state
 
     def encode(self, audio, n_samples=None):
         """First half of `clips` as its own launch (fills the workspace); returns (batch, steps)."""
