@@ -147,3 +147,23 @@ def test_firered_checkpoint_loader_matches_reference(golden, tmp_path):
     sd_s = {k: T(v) for k, v in sd.items() if "lookahead" not in k}
     got = ck.firered_from_state(types.SimpleNamespace(**cfg), sd_s)
     assert got["cfg"]["N2"] == 0 and "fsmn0_la" not in got and np.array_equal(got["fc1_w"], w["fc1_w"])
+
+
+def build_c_client(out_dir):
+    """gcc (C99, no hipcc) builds tests/c/cabi_silero.c against include/vadx.h and libvadx.so; returns the executable."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(out_dir), "cabi_silero")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c", "cabi_silero.c"), "-o", exe,
+                           "-L" + libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/vadx.h must compile as C99 and every symbol the C client uses must resolve in libvadx.so (the run itself
+    needs a GPU: tests/test_gpu_cabi_c.py)."""
+    assert os.path.exists(build_c_client(tmp_path))
+

@@ -180,7 +180,10 @@ class SileroEngine:
         t = self.torch
         probs = self._dev_f32(probs)
         B, T = probs.shape
-        lens = t.as_tensor(np.broadcast_to(np.asarray(n_samples, dtype=np.int64), (B,)).copy(), device=self.device)
+        if t.is_tensor(n_samples):             # clip lengths may already live on the device
+            lens = n_samples.to(device=self.device, dtype=t.int64).reshape(-1).expand(B).contiguous()
+        else:
+            lens = t.as_tensor(np.broadcast_to(np.asarray(n_samples, dtype=np.int64), (B,)).copy(), device=self.device)
         prm = seg_params(**kw)
         while True:
             segs = t.empty((B, cap, 2), dtype=t.int64, device=self.device)
