@@ -313,7 +313,7 @@ int vadx_dfsmn_pw_conv(int mode, const vadx_ft_view *a, const vadx_ft_view *b, c
                        int F, int co, int kf, int act, int tiles, void *stream);
 /* CepsUnit's length-160 real DFT along F (inverse=0: in C ch x 160 -> out 2C ch x 81, LayerNorm on the
  * input) and its pinv-based inverse fused with the complex product (inverse=1: in = spectrum, lo = LSTM
- * output, both 2C ch x 81 -> out C ch x 160).  tbl = [192][160] (cos|sin rows, padded) / [160][164]. */
+ * output, both 2C ch x 81 -> out C ch x 160).  tbl = [192][160] (cos|sin rows, padded) / [192][164] (rows 160.. zero). */
 int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_ft_view *lo, const vadx_ft_ln *ln,
                      const float *tbl, const vadx_ft_view *out, int C, int tiles, void *stream);
 /* bi-LSTM (hidden 20) along F with the tile's 16 frames as the batch; in->c = 4 or 40; out 40 ch. */

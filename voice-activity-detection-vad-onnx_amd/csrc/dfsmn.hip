@@ -16,7 +16,8 @@
 #include <string.h>
 
 // DFSMN_EXP: development-only what-if switches (bit mask; results are wrong when set): 1 lstm_f without its output
-// stores, 2 without input loads, 4 without gate non-linearities
+// stores, 2 without input loads, 4 without gate non-linearities; dft_f: 8 one k-step instead of all, 16 no copy-out,
+// 32 no input request / park, 64 no per-channel barrier
 #ifndef DFSMN_EXP
 #define DFSMN_EXP 0
 #endif
@@ -130,8 +131,11 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
     const int cin = p.a.c + p.b.c;
     constexpr int K = KS * 4, HALO = (KF - 1) / 2;
     const int fh = p.fc + 2 * HALO, fs = fh | 1;        // rows per channel, and their (odd) LDS pitch
+    // LayerNorm: MODE 0 has none; MODE 2 consumes only LN(in), applied while staging; MODE 1 needs the raw rows too
+    // (input conv) and normalises on the fly with the per-row (weight, bias) pairs staged next to them
+    constexpr bool LN_STAGE = MODE == 2, LN_FLY = MODE == 1;
     float *raw = lds;                                   // [cin][fs][16]
-    float *wb = raw + cin * fs * 16;                    // [cin][fs][2]   LayerNorm (weight, bias); (0, 0) outside [0, F)
+    float *wb = raw + cin * fs * 16;                    // [cin][fs][2]   MODE 1: LayerNorm (weight, bias); (0, 0) outside [0, F)
     float *o0 = wb + cin * fs * 2;                      // [co][fc][16]
     float *o1 = o0 + p.co * p.fc * 16;                  // MODE 1 only
 
@@ -144,8 +148,15 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
             wa[mt][s] = p.W[(size_t)(mt * 16 + i) * K + 4 * s + q];
             if (MODE == 1) wg[mt][s] = p.W2[(size_t)(mt * 16 + i) * K + 4 * s + q];
         }
-    const float ln_mean = p.ln.stats ? p.ln.stats[((size_t)tile * 16 + i) * 2] : 0.f;          // this lane's frame is fixed
-    const float ln_inv = p.ln.stats ? p.ln.stats[((size_t)tile * 16 + i) * 2 + 1] : 1.f;
+    float ln_mean = 0.f, ln_inv = 1.f;                  // MODE 1: this lane's frame (column i) is fixed
+    f32x4 st_mean = {0.f, 0.f, 0.f, 0.f}, st_inv = {1.f, 1.f, 1.f, 1.f};      // MODE 2: the staging thread's frame quad
+    if (LN_FLY) { ln_mean = p.ln.stats[((size_t)tile * 16 + i) * 2]; ln_inv = p.ln.stats[((size_t)tile * 16 + i) * 2 + 1]; }
+    if (LN_STAGE)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st_mean[r] = p.ln.stats[((size_t)tile * 16 + 4 * (tid & 3) + r) * 2];
+            st_inv[r] = p.ln.stats[((size_t)tile * 16 + 4 * (tid & 3) + r) * 2 + 1];
+        }
     int koff[KS];              // this lane's k rows: k = 4s + q -> (tap, channel) -> LDS row (channel*fs + tap)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -164,6 +175,11 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
 
     for (int chunk = blockIdx.y; chunk < p.nchunk; chunk += gridDim.y) {
         const int f0 = chunk * p.fc, fcv = min(p.fc, p.F - f0);
+        auto lnidx = [&](int e) {                               // (channel, clamped bin) of item e in the LayerNorm tables
+            const int rowi = e >> 2, c = rowi / fh, ffl = rowi - c * fh;
+            const int ff = f0 - HALO + ffl, fc2 = ff < 0 ? 0 : (ff >= p.F ? p.F - 1 : ff);
+            return c * p.F + fc2;
+        };
         // ---- stage the input rows: thread = (row (c, ffl), frame quad); four unconditional (clamped) loads in flight
         // per thread, then the stores -- a load-store pair per iteration is one serialised round trip each
         {
@@ -174,45 +190,87 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
                 return (c < p.a.c ? p.a.ptr + ft_idx(tile, p.a.c_total, p.a.c_off + c, p.F, fc2)
                                   : p.b.ptr + ft_idx(tile, p.b.c_total, p.b.c_off + c - p.a.c, p.F, fc2)) + 4 * tq;
             };
-            auto put = [&](int e, f32x4 v) {
+            auto put = [&](int e, f32x4 v, float w, float b) {
                 const int rowi = e >> 2, tq = e & 3, c = rowi / fh, ffl = rowi - c * fh, ff = f0 - HALO + ffl;
+                if (LN_STAGE) v = (v - st_mean) * st_inv * w + b;
                 *reinterpret_cast<f32x4 *>(raw + (c * fs + ffl) * 16 + 4 * tq) = (ff < 0 || ff >= p.F) ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
             };
             int e0 = tid;
             for (; e0 + 3 * 256 < nitem; e0 += 4 * 256) {       // full batches: four loads in flight, then four stores
                 f32x4 v[4];
+                float w[4] = {1.f, 1.f, 1.f, 1.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src_of(e0 + 256 * u));
+                for (int u = 0; u < 4; ++u) {
+                    v[u] = *reinterpret_cast<const f32x4 *>(src_of(e0 + 256 * u));
+                    if (LN_STAGE) { w[u] = p.ln.w[lnidx(e0 + 256 * u)]; b[u] = p.ln.b[lnidx(e0 + 256 * u)]; }
+                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) put(e0 + 256 * u, v[u]);
+                for (int u = 0; u < 4; ++u) put(e0 + 256 * u, v[u], w[u], b[u]);
             }
-            for (; e0 < nitem; e0 += 256) put(e0, *reinterpret_cast<const f32x4 *>(src_of(e0)));
+            for (; e0 < nitem; e0 += 256)
+                put(e0, *reinterpret_cast<const f32x4 *>(src_of(e0)), LN_STAGE ? p.ln.w[lnidx(e0)] : 1.f, LN_STAGE ? p.ln.b[lnidx(e0)] : 0.f);
         }
-        if (p.ln.stats)
-            for (int rowi = tid; rowi < cin * fh; rowi += 256) {
-                const int c = rowi / fh, ffl = rowi - c * fh, ff = f0 - HALO + ffl;
-                const bool in = ff >= 0 && ff < p.F;
-                wb[2 * (c * fs + ffl)] = in ? p.ln.w[c * p.F + ff] : 0.f;
-                wb[2 * (c * fs + ffl) + 1] = in ? p.ln.b[c * p.F + ff] : 0.f;
+        if (LN_FLY) {                                           // (weight, bias) per staged row: unconditional clamped loads
+            const int nrow = cin * fh;
+            for (int r0 = tid; r0 < nrow; r0 += 2 * 256) {
+                float w[2], b[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int rowi = min(r0 + 256 * u, nrow - 1);
+                    w[u] = p.ln.w[lnidx(rowi << 2)];
+                    b[u] = p.ln.b[lnidx(rowi << 2)];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int rowi = r0 + 256 * u;
+                    if (rowi < nrow) {
+                        const int c = rowi / fh, ffl = rowi - c * fh, ff = f0 - HALO + ffl;
+                        const bool in = ff >= 0 && ff < p.F;
+                        *reinterpret_cast<float2 *>(wb + 2 * (c * fs + ffl)) = in ? float2{w[u], b[u]} : float2{0.f, 0.f};
+                    }
+                }
             }
+        }
         __syncthreads();
 
         // ---- MFMA: wave walks the chunk's bins
+        // The operands of a bin are fetched as one batch of independent LDS reads (left alone the compiler emits
+        // read -> wait -> LayerNorm -> wait -> 2 MFMAs per k-step: two exposed LDS round trips each); MODE 0 / 2 also
+        // request the next bin's batch before this bin's MFMAs issue.
+        float xc[KS], xn[LN_FLY ? 1 : KS];
+        float2 wbc[LN_FLY ? KS : 1];
+        auto fetch = [&](int fl, float (&x)[KS]) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) x[s] = raw[(koff[s] + fl) * 16 + i];
+        };
+        if constexpr (!LN_FLY) fetch(min(wave, fcv - 1), xc);
         for (int fl = wave; fl < fcv; fl += 4) {
+            if constexpr (LN_FLY) {
+                fetch(fl, xc);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) wbc[s] = *reinterpret_cast<const float2 *>(wb + 2 * (koff[s] + fl));
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) xn[s] = raw[(koff[s] + min(fl + 4, fcv - 1)) * 16 + i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 acc[MT], acc2[MODE == 1 ? MT : 1];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; if (MODE == 1) acc2[mt] = acc[mt]; }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const int row = koff[s] + fl;
-                const float x = raw[row * 16 + i];
+                const float x = xc[s];
                 float lnv = x;
-                if (p.ln.stats) lnv = (x - ln_mean) * ln_inv * wb[2 * row] + wb[2 * row + 1];
+                if constexpr (LN_FLY) lnv = (x - ln_mean) * ln_inv * wbc[s].x + wbc[s].y;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     acc[mt] = mfma16(wa[mt][s], lnv, acc[mt]);
                     if (MODE == 1) acc2[mt] = mfma16(wg[mt][s], x, acc2[mt]);
                 }
+            }
+            if constexpr (!LN_FLY) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) xc[s] = xn[s];
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -275,7 +333,9 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
 //        12 tiles of 16; out channel c <- cos rows, C + c <- sin rows, Fout = 81.
 //   INV (:141-153): k = (re k'<81 | im k'<81) (164 padded); B_c = complex product of the LSTM output
 //        (pr, pi) = lo[c], lo[C+c] with the raw spectrum (re, im) = li[c], li[C+c]; rows m = f (160).
-// Table rows live in VGPRs (2 m-tiles per wave); the channel's B matrix is staged through LDS.
+// Table rows live in VGPRs: 12 row tiles (FWD 96 cos | 96 sin rows, INV 160 rows + 2 zero tiles) on FOUR waves of
+// three tiles each -- one wave per SIMD, so every SIMD carries the same MFMA load (with 6 / 5 waves of two tiles two
+// SIMDs carried double and the workgroup's channel time was theirs).  The channel's B matrix is staged through LDS.
 // ---------------------------------------------------------------------------------------------
 struct DftArgs {
     View in;             // FWD: r (C ch, F=160).  INV: li (2C ch, F=81)
@@ -290,21 +350,21 @@ struct DftArgs {
 // the other half of the LDS double buffer afterwards; results leave through a (double-buffered) LDS output block as
 // 16-B coalesced stores -- an output channel's bins are contiguous in the FT layout.
 template <bool INV>
-__global__ __launch_bounds__(INV ? 320 : 384) void dft_f_kernel(DftArgs p) {
-    constexpr int KS = INV ? 41 : 40, NWAVE = INV ? 5 : 6, KROWS = KS * 4, NT = NWAVE * 64;
-    constexpr int OROWS = NWAVE * 32;                       // FWD 192 (96 cos | 96 sin), INV 160
+__global__ __launch_bounds__(256, 2) void dft_f_kernel(DftArgs p) {
+    constexpr int KS = INV ? 41 : 40, NWAVE = 4, RT = 3, KROWS = KS * 4, NT = NWAVE * 64;
+    constexpr int OROWS = NWAVE * RT * 16;                  // 192: FWD 96 cos | 96 sin, INV 160 + 32 zero rows
     constexpr int ITEMS = INV ? 81 * 4 : 160 * 4, NR = (ITEMS + NT - 1) / NT;      // staging work items (row, frame quad)
     __shared__ __attribute__((aligned(16))) float Bs[2][KROWS * 16];
     __shared__ __attribute__((aligned(16))) float Os[2][OROWS * 16];
     const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
-    float ta[2][KS];
+    float ta[RT][KS];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < RT; ++h)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) ta[h][s] = p.tbl[(size_t)((wave * 2 + h) * 16 + i) * KROWS + 4 * s + q];
+        for (int s = 0; s < KS; ++s) ta[h][s] = p.tbl[(size_t)((wave * RT + h) * 16 + i) * KROWS + 4 * s + q];
     const int tq = tid & 3;                                 // NT is a multiple of 4: a thread's frame quad is fixed
     f32x4 ln_mean = {0.f, 0.f, 0.f, 0.f}, ln_inv = {1.f, 1.f, 1.f, 1.f};
-    if (!INV && p.ln.stats)
+    if (!INV)                        // the forward direction always normalises (LN2; the launcher requires it)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ln_mean[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2];
@@ -313,15 +373,16 @@ __global__ __launch_bounds__(INV ? 320 : 384) void dft_f_kernel(DftArgs p) {
     for (int e = tid; e < 2 * KROWS * 16; e += NT) Bs[0][e] = 0.f;          // rows past the data stay zero (table padding)
     f32x4 pre[NR][INV ? 4 : 1];
     float lw[NR], lb[NR];
+    // every load is unconditional (the item index is clamped; surplus lanes re-read the last row): a load under a
+    // condition costs a branch and a full wait, i.e. one serialised memory round trip per item
     auto request = [&](int c) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int e = tid + NT * r, k = e >> 2;
-            if (e >= ITEMS) continue;
+            const int e = min(tid + NT * r, ITEMS - 1), k = e >> 2;
             if (!INV) {
                 pre[r][0] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + c, 160, k) + 4 * tq);
-                lw[r] = p.ln.stats ? p.ln.w[c * 160 + k] : 1.f;
-                lb[r] = p.ln.stats ? p.ln.b[c * 160 + k] : 0.f;
+                lw[r] = p.ln.w[c * 160 + k];
+                lb[r] = p.ln.b[c * 160 + k];
             } else {
                 pre[r][0] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + c, 81, k) + 4 * tq);
                 pre[r][1] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + p.C + c, 81, k) + 4 * tq);
@@ -336,9 +397,7 @@ __global__ __launch_bounds__(INV ? 320 : 384) void dft_f_kernel(DftArgs p) {
             const int e = tid + NT * r, k = e >> 2;
             if (e >= ITEMS) continue;
             if (!INV) {
-                f32x4 v = pre[r][0];
-                if (p.ln.stats) v = (v - ln_mean) * ln_inv * lw[r] + lb[r];
-                *reinterpret_cast<f32x4 *>(dst + k * 16 + 4 * tq) = v;
+                *reinterpret_cast<f32x4 *>(dst + k * 16 + 4 * tq) = (pre[r][0] - ln_mean) * ln_inv * lw[r] + lb[r];
             } else {
                 const f32x4 re = pre[r][0], im = pre[r][1], pr = pre[r][2], pi = pre[r][3];
                 *reinterpret_cast<f32x4 *>(dst + k * 16 + 4 * tq) = pr * re - pi * im;
@@ -353,20 +412,37 @@ __global__ __launch_bounds__(INV ? 320 : 384) void dft_f_kernel(DftArgs p) {
     for (int c = 0; c < p.C; ++c) {
         const float *B = Bs[c & 1];
         float *O = Os[c & 1];
-        if (c + 1 < p.C) request(c + 1);
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (c + 1 < p.C && !(DFSMN_EXP & 32)) request(c + 1);
+        f32x4 acc[RT];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float bv = B[(4 * s + q) * 16 + i];
-            acc[0] = mfma16(ta[0][s], bv, acc[0]);
-            acc[1] = mfma16(ta[1][s], bv, acc[1]);
+        for (int h = 0; h < RT; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the B column is read KB k-steps at a time, the next batch requested before this batch's MFMAs issue (left to
+        // itself the compiler emits read -> wait -> 2 MFMAs: one exposed LDS round trip per k-step)
+        constexpr int KB = 8, KSX = (DFSMN_EXP & 8) ? 1 : KS;
+        float bcur[KB], bnxt[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) bcur[u] = B[(4 * u + q) * 16 + i];
+#pragma unroll
+        for (int s0 = 0; s0 < KSX; s0 += KB) {
+#pragma unroll
+            for (int u = 0; u < KB; ++u) bnxt[u] = B[(4 * min(s0 + KB + u, KS - 1) + q) * 16 + i];
+            __builtin_amdgcn_sched_barrier(0);           // keep the reads above the MFMAs (the scheduler sinks them back)
+#pragma unroll
+            for (int u = 0; u < KB; ++u)
+                if (s0 + u < KSX) {
+#pragma unroll
+                    for (int h = 0; h < RT; ++h) acc[h] = mfma16(ta[h][s0 + u], bcur[u], acc[h]);
+                }
+#pragma unroll
+            for (int u = 0; u < KB; ++u) bcur[u] = bnxt[u];
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < RT; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) O[((wave * 2 + h) * 16 + 4 * q + r) * 16 + i] = acc[h][r];
-        if (c + 1 < p.C) park(Bs[(c + 1) & 1]);
-        __syncthreads();
+            for (int r = 0; r < 4; ++r) O[((wave * RT + h) * 16 + 4 * q + r) * 16 + i] = acc[h][r];
+        if (c + 1 < p.C && !(DFSMN_EXP & 32)) park(Bs[(c + 1) & 1]);
+        if (!(DFSMN_EXP & 64)) __syncthreads();
+        if ((DFSMN_EXP & 16) && acc[0][0] != 123.f) continue;
         // copy-out of channel c (reads O; O is next written two channels later, after the next barrier)
         if (!INV) {          // rows 0..95 = cos bins (81 valid) -> channel c, rows 96..191 = sin bins -> channel C + c
             for (int e = tid; e < 2 * 81 * 4; e += NT) {
@@ -1012,6 +1088,8 @@ extern "C" int vadx_dfsmn_pw_conv(int mode, const vadx_ft_view *a, const vadx_ft
     PwArgs p;
     p.a = mkview(a); p.b = mkview(b); p.ln = mkln(ln); p.W = w; p.bias = bias; p.W2 = w2; p.bias2 = bias2;
     p.add = mkview(add); p.out0 = mkvieww(out0); p.out1 = mkvieww(out1); p.F = F; p.co = co; p.act = act;
+    VADX_REQUIRE(mode == 0 ? !(ln && ln->stats) : (ln && ln->stats && ln->w && ln->b),
+                 "vadx_dfsmn_pw_conv: mode %d %s a LayerNorm", mode, mode == 0 ? "takes no" : "needs");
     const int cin = p.a.c + p.b.c, K = kf * cin, MT = (co + 15) / 16;
     VADX_REQUIRE(K % 4 == 0, "vadx_dfsmn_pw_conv: kf*cin must be a multiple of 4");
     const int KS = K / 4;
@@ -1034,8 +1112,8 @@ extern "C" int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_
     VADX_REQUIRE(inverse ? (lo && lo->ptr) : (ln && ln->stats), "vadx_dfsmn_dft_f: missing lo / ln");
     DftArgs p;
     p.in = mkview(in); p.lo = mkview(lo); p.ln = mkln(ln); p.tbl = tbl; p.out = mkvieww(out); p.C = C;
-    if (inverse) hipLaunchKernelGGL(dft_f_kernel<true>, dim3(tiles), dim3(320), 0, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL(dft_f_kernel<false>, dim3(tiles), dim3(384), 0, static_cast<hipStream_t>(stream), p);
+    if (inverse) hipLaunchKernelGGL(dft_f_kernel<true>, dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(dft_f_kernel<false>, dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }

@@ -93,8 +93,8 @@ class Iccrn:
         fb = t.fft.fft(t.eye(n, dtype=t.float32))
         basis = t.vstack([t.real(fb[:half + 1]), t.imag(fb[:half + 1])]).float()
         inv_basis = t.linalg.pinv(basis).T                                            # [162,160]
-        inv = t.zeros((160, 164), dtype=t.float32)
-        inv[:, :162] = inv_basis.t()
+        inv = t.zeros((192, 164), dtype=t.float32)                                    # 12 row tiles like fwd (rows 160.. zero)
+        inv[:160, :162] = inv_basis.t()
         self.tbl_fwd, self.tbl_inv = fwd.to(self.device), inv.to(self.device)
 
     # ---- small helpers around the C ABI -------------------------------------------------------
