@@ -474,13 +474,15 @@ struct LstmFArgs {
 };
 
 // Input path: the recurrence consumes one bin (IN rows of 64 B) per step, far too little to cover HBM latency with
-// per-step loads, so each wave streams CHUNKS of NB = 4 bins: all rows of the next chunk are requested as 16-B
-// coalesced loads (10 per lane for IN = 40) while the current chunk's four steps run, then LayerNorm'd and parked in
-// the wave's private LDS double buffer, from where the MFMA B operand is read ([row][16 frames]: the k-quarters land
-// 16 banks apart).  Waves never share LDS data, so no workgroup barrier is needed.
+// per-step loads, so each wave streams CHUNKS of NB bins: all rows of a chunk are requested as 16-B coalesced loads
+// (5 per lane for IN = 40, together with their LayerNorm weight / bias) two chunks ahead, then LayerNorm'd and parked
+// in the wave's private LDS double buffer, from where the MFMA B operand is read ([row][16 frames]: the k-quarters
+// land 16 banks apart).  Waves never share LDS data, so no workgroup barrier is needed.  NB = 2 for IN = 40: 20 KB per
+// workgroup, so the four workgroups (two waves per SIMD) that the registers allow also fit the LDS -- with NB = 4 the
+// 40 KB x 4 = 160 KB did not, and a third of the wave slots stayed empty.
 template <int IN>
-__global__ __launch_bounds__(128) void lstm_f_kernel(LstmFArgs p) {
-    constexpr int KI = IN / 4, H = 20, MT = 5, NB = 4;
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void lstm_f_kernel(LstmFArgs p) {
+    constexpr int KI = IN / 4, H = 20, MT = 5, NB = IN == 40 ? 2 : 4;
     constexpr int CH_FLOATS = NB * IN * 16, NLD = NB * IN / 16;      // floats per chunk; float4 loads per lane per chunk
     __shared__ __attribute__((aligned(16))) float xs[2][2][CH_FLOATS];      // [direction][buffer]
     const int tile = blockIdx.x, lane = threadIdx.x & 63, dir = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(128) void lstm_f_kernel(LstmFArgs p) {
     // staging role of this lane: float4 number e = lane + 64 r of the chunk -> row e/4 = (bin b, channel ch), frames 4 (lane&3)..+3
     const int tq = lane & 3;
     f32x4 ln_mean = {0.f, 0.f, 0.f, 0.f}, ln_inv = {1.f, 1.f, 1.f, 1.f};
-    if (p.ln.stats)
+    if (IN == 40)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ln_mean[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2];
@@ -510,50 +512,72 @@ __global__ __launch_bounds__(128) void lstm_f_kernel(LstmFArgs p) {
         }
     const int nchunk = (p.F + NB - 1) / NB;
     auto bin_of = [&](int ck, int b) { const int st = ck * NB + b; return dir ? p.F - 1 - st : st; };      // may run past the end
+    constexpr bool HAS_LN = IN == 40;                 // CepsUnit normalises its LSTM input, in_ch_lstm does not (launcher checks)
     f32x4 pre[NLD];
+    float lw[HAS_LN ? NLD : 1], lb[HAS_LN ? NLD : 1];   // LayerNorm (weight, bias) of the requested rows
     auto request = [&](int ck) {
 #pragma unroll
         for (int r = 0; r < NLD; ++r) {
             const int row = (lane >> 2) + 16 * r, b = row / IN, ch = row - b * IN, f = bin_of(ck, b);
             pre[r] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (DFSMN_EXP & 2) continue;
-            const int fcl = f < 0 ? 0 : (f >= p.F ? p.F - 1 : f);        // unconditional (clamped) load; park() ignores the excess bins
+            const int fcl = f < 0 ? 0 : (f >= p.F ? p.F - 1 : f);        // unconditional (clamped) loads; bins past the end are never used
             pre[r] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + ch, p.F, fcl) + 4 * tq);
+            if constexpr (HAS_LN) { lw[r] = p.ln.w[ch * p.F + fcl]; lb[r] = p.ln.b[ch * p.F + fcl]; }
         }
     };
-    auto park = [&](int ck, float *dst) {
+    auto park = [&](float *dst) {
 #pragma unroll
         for (int r = 0; r < NLD; ++r) {
-            const int row = (lane >> 2) + 16 * r, b = row / IN, ch = row - b * IN, f = bin_of(ck, b);
             f32x4 v = pre[r];
-            if (p.ln.stats && f >= 0 && f < p.F) v = (v - ln_mean) * ln_inv * p.ln.w[ch * p.F + f] + p.ln.b[ch * p.F + f];
-            *reinterpret_cast<f32x4 *>(dst + row * 16 + 4 * tq) = v;
+            if constexpr (HAS_LN) v = (v - ln_mean) * ln_inv * lw[r] + lb[r];
+            *reinterpret_cast<f32x4 *>(dst + ((lane >> 2) + 16 * r) * 16 + 4 * tq) = v;
+        }
+    };
+    // The step is software-pipelined inside the wave: the input half of step t+1 (W_ih x, 10 k-steps, independent of the
+    // recurrence) is issued right after the recurrent half of step t (W_hh h, 5 k-steps), so the matrix pipe works on it
+    // while the VALU runs step t's gate non-linearities -- in program order (input half, recurrent half, gates) the
+    // pipe idled through the gates and the wave through the MFMAs.  For that the NEXT chunk must already be parked when
+    // a chunk's last step runs: chunk ck+1 is parked at the start of chunk ck (its loads were requested a chunk ago).
+    auto input_half = [&](const float *xrow, f32x4 (&a)[MT]) {        // a = bias + W_ih x, x = 16 frames of one bin
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
+#pragma unroll
+        for (int s = 0; s < KI; ++s) {
+            const float xv = xrow[(4 * s + q) * 16 + i];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = mfma16(wi[mt][s], xv, a[mt]);
         }
     };
     request(0);
-    park(0, xs[dir][0]);
+    park(xs[dir][0]);
     if (nchunk > 1) request(1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // this wave's LDS writes precede its reads below
+    __builtin_amdgcn_wave_barrier();
+    f32x4 accn[MT];
+    input_half(xs[dir][0], accn);
     for (int ck = 0; ck < nchunk; ++ck) {
-        const float *xb = xs[dir][ck & 1];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // this wave's LDS writes precede its reads below
-        __builtin_amdgcn_wave_barrier();
+        const float *xb = xs[dir][ck & 1], *xnext = xs[dir][(ck + 1) & 1];
+        if (ck + 1 < nchunk) {
+            park(xs[dir][(ck + 1) & 1]);                  // the buffer last read by chunk ck - 1
+            if (ck + 2 < nchunk) request(ck + 2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll 1
         for (int b = 0; b < NB; ++b) {
             const int f = bin_of(ck, b);
             if (f < 0 || f >= p.F) break;
             f32x4 acc[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
-#pragma unroll
-            for (int s = 0; s < KI; ++s) {
-                const float xv = xb[(b * IN + 4 * s + q) * 16 + i];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wi[mt][s], xv, acc[mt]);
-            }
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = accn[mt];
 #pragma unroll
             for (int s = 0; s < MT; ++s)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wh[mt][s], h[s], acc[mt]);
+            // next step's input half: the next bin of this chunk, or bin 0 of the parked next chunk (after the very last
+            // step this reads stale rows of the other buffer; the result is never used)
+            input_half(b + 1 < NB ? xb + (b + 1) * IN * 16 : xnext, accn);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bool lin = DFSMN_EXP & 4;
@@ -563,10 +587,6 @@ __global__ __launch_bounds__(128) void lstm_f_kernel(LstmFArgs p) {
                 h[mt] = lin ? og * c[mt] * 0.01f : og * gate_tanh(c[mt]);
                 if (!(DFSMN_EXP & 1) || h[mt] == 123.f) p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + dir * H + 4 * mt + q, p.F, f) + i] = h[mt];
             }
-        }
-        if (ck + 1 < nchunk) {
-            park(ck + 1, xs[dir][(ck + 1) & 1]);          // the buffer last read two chunks ago
-            if (ck + 2 < nchunk) request(ck + 2);
         }
     }
 }
@@ -1122,6 +1142,8 @@ extern "C" int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, c
                                  const float *const w_hh[2], const float *const b_ih[2], const float *const b_hh[2],
                                  const vadx_ft_view *out, int F, int tiles, void *stream) {
     VADX_REQUIRE(in && in->ptr && out && out->ptr && w_ih && w_hh && b_ih && b_hh && F > 0 && tiles > 0, "vadx_dfsmn_lstm_f: bad argument");
+    VADX_REQUIRE(in->c == 40 ? (ln && ln->stats && ln->w && ln->b) : !(ln && ln->stats),
+                 "vadx_dfsmn_lstm_f: the 40-channel (CepsUnit) LSTM takes a LayerNorm, the 4-channel one does not");
     LstmFArgs p;
     p.in = mkview(in); p.ln = mkln(ln); p.out = mkvieww(out); p.F = F;
     for (int d = 0; d < 2; ++d) { p.w_ih[d] = w_ih[d]; p.w_hh[d] = w_hh[d]; p.b_ih[d] = b_ih[d]; p.b_hh[d] = b_hh[d]; }
