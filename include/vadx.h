@@ -304,18 +304,26 @@ typedef struct vadx_ft_ln { const float *stats, *w, *b; } vadx_ft_ln;           
 
 /* stats[tile][16][2] = (mean, 1/(unbiased std + 1e-6)) over (C,F) of cat(a, b) per frame. */
 int vadx_dfsmn_frame_stats(const vadx_ft_view *a, const vadx_ft_view *b, int F, int tiles, float *stats, void *stream);
+/* Fused alternative: pw_conv and the forward dft_f can emit, per frame, the (count, mean, sum of squared deviations) of
+ * what each workgroup wrote -- "partial statistics", float [tiles][VADX_DFSMN_STAT_PARTS][16][4], caller-owned --
+ * and this merges the partials of one tensor (part_b NULL) or of the channel concatenation of two into the same
+ * stats[tile][16][2] that frame_stats produces, without re-reading the tensors. */
+#define VADX_DFSMN_STAT_PARTS 2
+int vadx_dfsmn_stats_merge(const float *part_a, const float *part_b, int tiles, float *stats, void *stream);
 /* mode 0: out0 = act(conv(cat(a,b)) + bias)        (kf taps along F, weights [ceil16(co)][kf*cin])
  * mode 1: CFB front: g = sigmoid(convG(LN(x)) + bias); xi = convI(x) + bias2; out0 = g*xi; out1 = xi - g*xi
- * mode 2: CFB back : out0 = conv31(LN(x)) + bias + add */
+ * mode 2: CFB back : out0 = conv31(LN(x)) + bias + add
+ * part0 / part1 (optional, may be NULL): partial statistics of out0 / out1 (mode 1) for vadx_dfsmn_stats_merge. */
 int vadx_dfsmn_pw_conv(int mode, const vadx_ft_view *a, const vadx_ft_view *b, const vadx_ft_ln *ln,
                        const float *w, const float *bias, const float *w2, const float *bias2,
                        const vadx_ft_view *add, const vadx_ft_view *out0, const vadx_ft_view *out1,
-                       int F, int co, int kf, int act, int tiles, void *stream);
+                       int F, int co, int kf, int act, int tiles, float *part0, float *part1, void *stream);
 /* CepsUnit's length-160 real DFT along F (inverse=0: in C ch x 160 -> out 2C ch x 81, LayerNorm on the
  * input) and its pinv-based inverse fused with the complex product (inverse=1: in = spectrum, lo = LSTM
- * output, both 2C ch x 81 -> out C ch x 160).  tbl = [192][160] (cos|sin rows, padded) / [192][164] (rows 160.. zero). */
+ * output, both 2C ch x 81 -> out C ch x 160).  tbl = [192][160] (cos|sin rows, padded) / [192][164] (rows 160.. zero).
+ * part (optional, forward only): partial statistics of out. */
 int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_ft_view *lo, const vadx_ft_ln *ln,
-                     const float *tbl, const vadx_ft_view *out, int C, int tiles, void *stream);
+                     const float *tbl, const vadx_ft_view *out, int C, int tiles, float *part, void *stream);
 /* bi-LSTM (hidden 20) along F with the tile's 16 frames as the batch; in->c = 4 or 40; out 40 ch. */
 int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2],
                       const float *const w_hh[2], const float *const b_ih[2], const float *const b_hh[2],

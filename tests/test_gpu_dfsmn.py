@@ -41,6 +41,31 @@ def test_cfb_block(wts, name, cin, frames, chunks):
     assert err < 2e-4 * max(1.0, want.abs().max().item()), err
 
 
+@pytest.mark.parametrize("chunks,frames", [(3, 101), (4200, 16)])       # 21 tiles: two workgroups per tile; 4200: one
+def test_fused_layernorm_statistics_match_the_separate_pass(wts, chunks, frames):
+    """The partial statistics pw_conv emits while writing a tensor, merged (one tensor and a channel concatenation of
+    two), equal what frame_stats computes by re-reading it -- also with a large mean (cancellation) -- and torch's."""
+    w, _ = wts
+    net = dfsmn.Iccrn(w)
+    tiles = chunks * dfsmn.ft_tiles(frames)
+    torch.manual_seed(chunks)
+    xin = dfsmn.FT(torch, net.device, chunks, frames, 24, 160)
+    xin.data.normal_(25.0, 0.7)                                                        # mean >> std
+    y = dfsmn.FT(torch, net.device, chunks, frames, 40, 160)
+    p0, p1 = net.new_part(tiles), net.new_part(tiles)
+    for half, part in ((0, p0), (20, p1)):
+        net.pw(0, xin.view(0, 20) if half == 0 else xin.view(4, 20), xin.view(20, 4) if half == 0 else xin.view(0, 4), None,
+               "in_conv.weight", "in_conv.bias", y.view(half, 20), 160, 20, tiles=tiles, part0=part)
+    for got, ref in ((net.merged_stats(p0, None, tiles), net.stats(y.view(0, 20), None, 160, tiles)),
+                     (net.merged_stats(p0, p1, tiles), net.stats(y.view(0, 20), y.view(20, 20), 160, tiles))):
+        torch.testing.assert_close(got, ref, rtol=2e-5, atol=1e-6)
+    yt = dfsmn.from_ft(y, chunks)[:2].cpu().double()                                   # [2, 40, 160, frames]
+    mean = yt.mean(dim=(1, 2)); inv = 1.0 / (yt.std(dim=(1, 2), unbiased=True) + 1e-6)
+    got = net.merged_stats(p0, p1, tiles).cpu().double().view(chunks, -1, 2)[:2, :frames]
+    torch.testing.assert_close(got[..., 0], mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got[..., 1], inv, rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("seed", [1234, 7])
 def test_session_matches_reference_fixture(golden, seed):
     """Whole graph, two streams in -> vad_results, against what the REFERENCE classes produced."""

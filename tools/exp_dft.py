@@ -28,10 +28,10 @@ name = "cfb_e1"
 L = _lib.lib()
 def fwd():
     _lib.check(L.vadx_dfsmn_dft_f(0, C.byref(r.view()), None, C.byref(net._ln(s2, name + ".LN2")), net.tbl_fwd.data_ptr(),
-                                  C.byref(li.view()), 20, tiles, _lib.stream_ptr()))
+                                  C.byref(li.view()), 20, tiles, None, _lib.stream_ptr()))
 def inv():
     _lib.check(L.vadx_dfsmn_dft_f(1, C.byref(li.view()), C.byref(lo.view()), None, net.tbl_inv.data_ptr(),
-                                  C.byref(ceps.view()), 20, tiles, _lib.stream_ptr()))
+                                  C.byref(ceps.view()), 20, tiles, None, _lib.stream_ptr()))
 out = []
 for f in (fwd, inv):
     f(); t.cuda.synchronize()

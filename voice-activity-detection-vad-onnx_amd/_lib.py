@@ -129,9 +129,10 @@ SIGNATURES = {
     "vadx_sepconv_block": (_I, [C.POINTER(SepConvCfg), _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _I, _I, _P]),
     "vadx_frame_classifier": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vadx_dfsmn_frame_stats": (_I, [C.POINTER(FtView), C.POINTER(FtView), _I, _I, _P, _P]),
+    "vadx_dfsmn_stats_merge": (_I, [_P, _P, _I, _P, _P]),
     "vadx_dfsmn_pw_conv": (_I, [_I, C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtLn), _P, _P, _P, _P,
-                                C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtView), _I, _I, _I, _I, _I, _P]),
-    "vadx_dfsmn_dft_f": (_I, [_I, C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtLn), _P, C.POINTER(FtView), _I, _I, _P]),
+                                C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtView), _I, _I, _I, _I, _I, _P, _P, _P]),
+    "vadx_dfsmn_dft_f": (_I, [_I, C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtLn), _P, C.POINTER(FtView), _I, _I, _P, _P]),
     "vadx_dfsmn_lstm_f": (_I, [C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
                                C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), C.POINTER(FtView), _I, _I, _P]),
     "vadx_dfsmn_alpha_scale": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),

@@ -82,6 +82,109 @@ __global__ __launch_bounds__(256) void frame_stats_kernel(View a, View b, int F,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused LayerNorm statistics.  The kernels that PRODUCE a tensor (pw_conv, the forward dft_f) also emit, per frame, the
+// (count, mean, M2 = sum (x - mean)^2) of what the workgroup wrote -- "partial statistics" [tile][PARTS][16][4] -- so
+// that the consumer's (mean, 1/(std + eps)) come from a tiny merge kernel instead of another pass over the tensor
+// (frame_stats re-read 1.4 GB per LayerNorm, 41 times per forward).  Accumulation: every thread owns one frame quad of
+// the coalesced write-out, sums d = x - K and d^2 against its own first value K (no cancellation), and the partials
+// are merged pairwise with Chan's update in a fixed order (reproducible).
+// ---------------------------------------------------------------------------------------------
+constexpr int STAT_PARTS = 2;            // partial slots per tile (pw_conv runs one or two workgroups per tile)
+
+struct StatAcc {                         // short-lived: one write-out pass of one thread
+    f32x4 K, s1, s2;
+    float n;
+    __device__ __forceinline__ void init() { K = s1 = s2 = f32x4{0.f, 0.f, 0.f, 0.f}; n = 0.f; }
+    __device__ __forceinline__ void add(f32x4 v) {
+        if (n == 0.f) K = v;
+        const f32x4 d = v - K;
+        s1 += d; s2 += d * d; n += 1.f;
+    }
+};
+
+__device__ __forceinline__ void chan_merge(float &na, float &ma, float &Ma, float nb, float mb, float Mb) {
+    const float n = na + nb, f = n > 0.f ? nb / n : 0.f, d = mb - ma;      // nb == 0 or both empty: nothing moves
+    ma += d * f;
+    Ma += Mb + d * d * (na * f);
+    na = n;
+}
+
+struct StatRun {                         // a thread's running (count, mean, M2) of its frame quad: 9 registers
+    f32x4 mean, M2;
+    float n;
+    __device__ __forceinline__ void init() { mean = M2 = f32x4{0.f, 0.f, 0.f, 0.f}; n = 0.f; }
+    __device__ __forceinline__ void merge(float nb, f32x4 mb, f32x4 Mb) {
+        float nn = n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = mean[r], M = M2[r];
+            nn = n;
+            chan_merge(nn, m, M, nb, mb[r], Mb[r]);
+            mean[r] = m; M2[r] = M;
+        }
+        n = nn;
+    }
+    __device__ __forceinline__ void merge(const StatAcc &a) {
+        if (a.n == 0.f) return;
+        const float inv = 1.0f / a.n;
+        f32x4 m, M;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { m[r] = a.K[r] + a.s1[r] * inv; M[r] = fmaxf(a.s2[r] - a.s1[r] * a.s1[r] * inv, 0.f); }
+        merge(a.n, m, M);
+    }
+};
+
+// All 256 threads call this (tid & 3 is the thread's frame quad); `red` = 144 floats of LDS nobody else is using any
+// more.  Lanes with the same frame quad are merged with wave shuffles (4 steps), the four waves through LDS.  Writes
+// slot `part` of the tile; `zero_other` also clears the other slot (single-workgroup tiles).
+__device__ __forceinline__ void stat_reduce_store(StatRun a, float *red, float *__restrict__ dst, int tile, int part, bool zero_other) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) {
+        f32x4 mb, Mb;
+        const float nb = __shfl_xor(a.n, off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mb[r] = __shfl_xor(a.mean[r], off); Mb[r] = __shfl_xor(a.M2[r], off); }
+        a.merge(nb, mb, Mb);
+    }
+    if (lane < 4) {
+        float *o = red + (wave * 4 + lane) * 9;
+        o[0] = a.n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[1 + r] = a.mean[r]; o[5 + r] = a.M2[r]; }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int tq = tid >> 2, r = tid & 3;
+        float n = 0.f, m = 0.f, M = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) chan_merge(n, m, M, red[(w * 4 + tq) * 9], red[(w * 4 + tq) * 9 + 1 + r], red[(w * 4 + tq) * 9 + 5 + r]);
+        float *o = dst + (((size_t)tile * STAT_PARTS + part) * 16 + tid) * 4;
+        o[0] = n; o[1] = m; o[2] = M; o[3] = 0.f;
+        if (zero_other) { float *z = dst + (((size_t)tile * STAT_PARTS + (part ^ 1)) * 16 + tid) * 4; z[0] = z[1] = z[2] = z[3] = 0.f; }
+    }
+    __syncthreads();
+}
+
+// stats[tile][16][2] = (mean, 1/(unbiased std + 1e-6)) of the concatenation of the tensors whose partials are given
+__global__ void stats_merge_kernel(const float *__restrict__ pa, const float *__restrict__ pb, int tiles, float *__restrict__ stats) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= tiles * 16) return;
+    const int tile = idx >> 4, fr = idx & 15;
+    float n = 0.f, m = 0.f, M = 0.f;
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const float *src = s2 ? pb : pa;
+        if (!src) continue;
+        for (int part = 0; part < STAT_PARTS; ++part) {
+            const float *o = src + (((size_t)tile * STAT_PARTS + part) * 16 + fr) * 4;
+            chan_merge(n, m, M, o[0], o[1], o[2]);
+        }
+    }
+    stats[(size_t)idx * 2] = m;
+    stats[(size_t)idx * 2 + 1] = 1.0f / (sqrtf(M / (n - 1.f)) + 1e-6f);
+}
+
 struct LN {              // LayerNorm applied on the fly to an input view: (x - mean) * inv * w[c][f] + b[c][f]
     const float *stats, *w, *b;        // stats NULL = identity
 };
@@ -112,6 +215,7 @@ struct PwArgs {
     const float *W2, *bias2;           // MODE 1: input-conv weights / bias
     View add;                          // MODE 2
     ViewW out0, out1;
+    float *part0, *part1;              // optional partial statistics of out0 / out1 (see StatAcc)
     int F, co, act;
     int fc, nchunk;                    // bins per workgroup chunk, chunks per tile
 };
@@ -173,6 +277,8 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
             if (MODE == 1) bias2_r[mt][r] = co < p.co ? p.bias2[co] : 0.f;
         }
 
+    StatRun run0, run1;
+    run0.init(); run1.init();
     for (int chunk = blockIdx.y; chunk < p.nchunk; chunk += gridDim.y) {
         const int f0 = chunk * p.fc, fcv = min(p.fc, p.F - f0);
         auto lnidx = [&](int e) {                               // (channel, clamped bin) of item e in the LayerNorm tables
@@ -297,6 +403,8 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
         // ---- coalesced write-out: thread = (row (co, fl), frame quad); the residual `add` rows of a batch are requested
         // together before the stores
         {
+            StatAcc st0, st1;
+            st0.init(); st1.init();
             const int nitem = p.co * fcv * 4;
             for (int e0 = tid; e0 < nitem; e0 += 4 * 256) {
                 f32x4 av[4];
@@ -315,15 +423,25 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
                         f32x4 v = *reinterpret_cast<const f32x4 *>(o0 + (co * p.fc + fl) * 16 + 4 * tq);
                         if (MODE == 2) v += av[u];
                         *reinterpret_cast<f32x4 *>(p.out0.ptr + ft_idx(tile, p.out0.c_total, p.out0.c_off + co, p.F, f0 + fl) + 4 * tq) = v;
-                        if (MODE == 1)
-                            *reinterpret_cast<f32x4 *>(p.out1.ptr + ft_idx(tile, p.out1.c_total, p.out1.c_off + co, p.F, f0 + fl) + 4 * tq) =
-                                *reinterpret_cast<const f32x4 *>(o1 + (co * p.fc + fl) * 16 + 4 * tq);
+                        if (p.part0) st0.add(v);
+                        if (MODE == 1) {
+                            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(o1 + (co * p.fc + fl) * 16 + 4 * tq);
+                            *reinterpret_cast<f32x4 *>(p.out1.ptr + ft_idx(tile, p.out1.c_total, p.out1.c_off + co, p.F, f0 + fl) + 4 * tq) = v1;
+                            if (p.part1) st1.add(v1);
+                        }
                     }
                 }
             }
+            if (p.part0) run0.merge(st0);
+            if (MODE == 1 && p.part1) run1.merge(st1);
         }
         // the next chunk's staging writes raw/wb (last read before the barrier above); o0/o1 are rewritten only after
         // the next chunk's first barrier, i.e. after every thread has finished this write-out
+    }
+    if (p.part0 || p.part1) {
+        __syncthreads();                                   // the last write-out is done with the LDS
+        if (p.part0) stat_reduce_store(run0, lds, p.part0, tile, blockIdx.y, gridDim.y == 1);
+        if (MODE == 1 && p.part1) stat_reduce_store(run1, lds, p.part1, tile, blockIdx.y, gridDim.y == 1);
     }
 }
 
@@ -343,6 +461,7 @@ struct DftArgs {
     LN ln;               // FWD only
     const float *tbl;    // [MTILES*16][KS*4] row-major, zero padded
     ViewW out;           // FWD: li (2C ch, 81).  INV: ceps_out (C ch, 160)
+    float *part;         // FWD, optional: partial statistics of out (slot 0; slot 1 cleared)
     int C;
 };
 
@@ -405,6 +524,8 @@ __global__ __launch_bounds__(256, 2) void dft_f_kernel(DftArgs p) {
             }
         }
     };
+    StatRun run;
+    run.init();
     request(0);
     __syncthreads();                 // the zero fill above
     park(Bs[0]);
@@ -445,16 +566,24 @@ __global__ __launch_bounds__(256, 2) void dft_f_kernel(DftArgs p) {
         if ((DFSMN_EXP & 16) && acc[0][0] != 123.f) continue;
         // copy-out of channel c (reads O; O is next written two channels later, after the next barrier)
         if (!INV) {          // rows 0..95 = cos bins (81 valid) -> channel c, rows 96..191 = sin bins -> channel C + c
+            StatAcc st;
+            st.init();
             for (int e = tid; e < 2 * 81 * 4; e += NT) {
-                const int half = e >= 81 * 4, rowq = e - half * 81 * 4, kk = rowq >> 2, oq = rowq & 3;
-                *reinterpret_cast<f32x4 *>(p.out.ptr + ft_idx(tile, p.out.c_total, p.out.c_off + (half ? p.C + c : c), 81, kk) + 4 * oq) =
-                    *reinterpret_cast<const f32x4 *>(O + (half * 96 + kk) * 16 + 4 * oq);
+                const int half = e >= 81 * 4, rowq = e - half * 81 * 4, kk = rowq >> 2, oq = rowq & 3;      // oq == tid & 3
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(O + (half * 96 + kk) * 16 + 4 * oq);
+                *reinterpret_cast<f32x4 *>(p.out.ptr + ft_idx(tile, p.out.c_total, p.out.c_off + (half ? p.C + c : c), 81, kk) + 4 * oq) = v;
+                if (p.part) st.add(v);
             }
+            if (p.part) run.merge(st);
         } else {
             for (int e = tid; e < 160 * 4; e += NT)
                 *reinterpret_cast<f32x4 *>(p.out.ptr + ft_idx(tile, p.out.c_total, p.out.c_off + c, 160, e >> 2) + 4 * (e & 3)) =
                     *reinterpret_cast<const f32x4 *>(O + (e >> 2) * 16 + 4 * (e & 3));
         }
+    }
+    if (!INV && p.part) {
+        __syncthreads();                                   // the last copy-out is done with Os
+        stat_reduce_store(run, &Os[0][0], p.part, tile, 0, true);
     }
 }
 
@@ -1075,6 +1204,14 @@ extern "C" int vadx_dfsmn_frame_stats(const vadx_ft_view *a, const vadx_ft_view 
     return VADX_OK;
 }
 
+extern "C" int vadx_dfsmn_stats_merge(const float *part_a, const float *part_b, int tiles, float *stats, void *stream) {
+    VADX_REQUIRE(part_a && stats && tiles > 0, "vadx_dfsmn_stats_merge: bad argument");
+    hipLaunchKernelGGL(stats_merge_kernel, dim3((unsigned)((tiles * 16 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       part_a, part_b, tiles, stats);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
 template <int MT, int KS, int KF, int MODE>
 static int launch_pw(PwArgs p, int tiles, void *stream) {
     // bins per chunk: the largest multiple of 4 (one bin per wave per round) up to 32 that keeps the workgroup's LDS
@@ -1087,6 +1224,7 @@ static int launch_pw(PwArgs p, int tiles, void *stream) {
     p.fc = fc;
     p.nchunk = (p.F + fc - 1) / fc;
     const size_t lds = (size_t)lds_floats(fc) * sizeof(float);
+    VADX_REQUIRE(!(p.part0 || p.part1) || lds_floats(fc) >= 144, "vadx_dfsmn_pw_conv: shape too small for fused statistics");
     static bool done = false;
     if (!done) {
         VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_conv_kernel<MT, KS, KF, MODE>),
@@ -1103,11 +1241,12 @@ static int launch_pw(PwArgs p, int tiles, void *stream) {
 extern "C" int vadx_dfsmn_pw_conv(int mode, const vadx_ft_view *a, const vadx_ft_view *b, const vadx_ft_ln *ln,
                                   const float *w, const float *bias, const float *w2, const float *bias2,
                                   const vadx_ft_view *add, const vadx_ft_view *out0, const vadx_ft_view *out1,
-                                  int F, int co, int kf, int act, int tiles, void *stream) {
+                                  int F, int co, int kf, int act, int tiles, float *part0, float *part1, void *stream) {
     VADX_REQUIRE(a && a->ptr && w && bias && out0 && out0->ptr && F > 0 && tiles > 0 && co > 0, "vadx_dfsmn_pw_conv: bad argument");
     PwArgs p;
     p.a = mkview(a); p.b = mkview(b); p.ln = mkln(ln); p.W = w; p.bias = bias; p.W2 = w2; p.bias2 = bias2;
     p.add = mkview(add); p.out0 = mkvieww(out0); p.out1 = mkvieww(out1); p.F = F; p.co = co; p.act = act;
+    p.part0 = part0; p.part1 = mode == 1 ? part1 : nullptr;
     VADX_REQUIRE(mode == 0 ? !(ln && ln->stats) : (ln && ln->stats && ln->w && ln->b),
                  "vadx_dfsmn_pw_conv: mode %d %s a LayerNorm", mode, mode == 0 ? "takes no" : "needs");
     const int cin = p.a.c + p.b.c, K = kf * cin, MT = (co + 15) / 16;
@@ -1127,11 +1266,11 @@ extern "C" int vadx_dfsmn_pw_conv(int mode, const vadx_ft_view *a, const vadx_ft
 }
 
 extern "C" int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_ft_view *lo, const vadx_ft_ln *ln,
-                                const float *tbl, const vadx_ft_view *out, int C, int tiles, void *stream) {
+                                const float *tbl, const vadx_ft_view *out, int C, int tiles, float *part, void *stream) {
     VADX_REQUIRE(in && in->ptr && tbl && out && out->ptr && C > 0 && tiles > 0, "vadx_dfsmn_dft_f: bad argument");
     VADX_REQUIRE(inverse ? (lo && lo->ptr) : (ln && ln->stats), "vadx_dfsmn_dft_f: missing lo / ln");
     DftArgs p;
-    p.in = mkview(in); p.lo = mkview(lo); p.ln = mkln(ln); p.tbl = tbl; p.out = mkvieww(out); p.C = C;
+    p.in = mkview(in); p.lo = mkview(lo); p.ln = mkln(ln); p.tbl = tbl; p.out = mkvieww(out); p.C = C; p.part = inverse ? nullptr : part;
     if (inverse) hipLaunchKernelGGL(dft_f_kernel<true>, dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     else hipLaunchKernelGGL(dft_f_kernel<false>, dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     VADX_HIP_TRY(hipGetLastError());

@@ -18,6 +18,9 @@ def ft_tiles(frames):
     return (frames + 15) // 16
 
 
+STAT_PARTS = 2             # VADX_DFSMN_STAT_PARTS (include/vadx.h)
+
+
 class FT:
     """A device tensor in FT layout + helpers to make channel-slice views."""
 
@@ -111,13 +114,28 @@ class Iccrn:
                                                    _lib.stream_ptr()))
         return s
 
-    def pw(self, mode, a, b, ln, w, bias, out0, F, co, kf=1, act=0, w2=None, bias2=None, add=None, out1=None, tiles=None):
+    def new_part(self, tiles):
+        """Buffer for the partial LayerNorm statistics a producing kernel emits (include/vadx.h, stats_merge)."""
+        t = self.torch
+        return t.empty((tiles, STAT_PARTS, 16, 4), dtype=t.float32, device=self.device)
+
+    def merged_stats(self, part_a, part_b, tiles):
+        """(mean, 1/(std + eps)) per frame of a tensor (or of cat(a, b)) from the partials its producers emitted."""
+        t = self.torch
+        s = t.empty((tiles, 16, 2), dtype=t.float32, device=self.device)
+        _lib.check(self.lib.vadx_dfsmn_stats_merge(part_a.data_ptr(), None if part_b is None else part_b.data_ptr(), tiles,
+                                                   s.data_ptr(), _lib.stream_ptr()))
+        return s
+
+    def pw(self, mode, a, b, ln, w, bias, out0, F, co, kf=1, act=0, w2=None, bias2=None, add=None, out1=None, tiles=None,
+           part0=None, part1=None):
         _lib.check(self.lib.vadx_dfsmn_pw_conv(mode, C.byref(a), None if b is None else C.byref(b),
                                                None if ln is None else C.byref(ln), self._p(w), self._p(bias),
                                                None if w2 is None else self._p(w2), None if bias2 is None else self._p(bias2),
                                                None if add is None else C.byref(add), C.byref(out0),
                                                None if out1 is None else C.byref(out1), F, co, kf, act, tiles,
-                                               _lib.stream_ptr()))
+                                               None if part0 is None else part0.data_ptr(),
+                                               None if part1 is None else part1.data_ptr(), _lib.stream_ptr()))
 
     def lstm_f(self, prefix, inp, ln, out, F, tiles):
         arr = lambda n: (C.c_void_p * 2)(self._p(f"{prefix}.lstm2.{n}_l0"), self._p(f"{prefix}.lstm2.{n}_l0_reverse"))   # noqa: E731
@@ -126,8 +144,10 @@ class Iccrn:
                                               C.byref(bi), C.byref(bh), C.byref(out), F, tiles, _lib.stream_ptr()))
 
     # ---- CFB (:76-93) ---------------------------------------------------------------------------
-    def cfb(self, name, a, b, out, n_chunks, frames, scratch=None):
-        """y = CFB(cat(a, b)) written into the view `out` (20 channels)."""
+    def cfb(self, name, a, b, out, n_chunks, frames, scratch=None, a_part=None, b_part=None):
+        """y = CFB(cat(a, b)) written into the view `out` (20 channels).  a_part / b_part: the partial statistics the
+        producers of a / b emitted (None: a separate frame_stats pass over the tensor); returns (scratch, partials of y).
+        Every LayerNorm inside the block takes its statistics from the kernel that wrote its input."""
         t, dev = self.torch, self.device
         tiles = n_chunks * ft_tiles(frames)
         sc = scratch if scratch is not None else {}
@@ -137,22 +157,31 @@ class Iccrn:
             return sc[key]
         gx, r, li, hf, lo, ceps = (buf("gx", CH, F_BINS), buf("r", CH, F_BINS), buf("li", 2 * CH, CEPS_F),
                                    buf("hf", 2 * CH, CEPS_F), buf("lo", 2 * CH, CEPS_F), buf("ceps", CH, F_BINS))
-        s0 = self.stats(a, b, F_BINS, tiles)
+        def pbuf(key):
+            if key not in sc or sc[key].shape[0] != tiles:
+                sc[key] = self.new_part(tiles)
+            return sc[key]
+        gx_part, r_part, li_part = pbuf("gx_part"), pbuf("r_part"), pbuf("li_part")
+        out_part = self.new_part(tiles)                 # outlives the block (encoder outputs are normalised again by the decoder)
+        have = a_part is not None and (b is None or b_part is not None)
+        s0 = self.merged_stats(a_part, b_part if b is not None else None, tiles) if have else self.stats(a, b, F_BINS, tiles)
         self.pw(1, a, b, self._ln(s0, name + ".LN0"), name + ".conv_gate.weight", name + ".conv_gate.bias", gx.view(), F_BINS, CH,
-                w2=name + ".conv_input.weight", bias2=name + ".conv_input.bias", out1=r.view(), tiles=tiles)
-        s2 = self.stats(r.view(), None, F_BINS, tiles)
+                w2=name + ".conv_input.weight", bias2=name + ".conv_input.bias", out1=r.view(), tiles=tiles,
+                part0=gx_part, part1=r_part)
+        s2 = self.merged_stats(r_part, None, tiles)
         _lib.check(self.lib.vadx_dfsmn_dft_f(0, C.byref(r.view()), None, C.byref(self._ln(s2, name + ".LN2")),
-                                             self.tbl_fwd.data_ptr(), C.byref(li.view()), CH, tiles, _lib.stream_ptr()))
-        sl = self.stats(li.view(), None, CEPS_F, tiles)
+                                             self.tbl_fwd.data_ptr(), C.byref(li.view()), CH, tiles, li_part.data_ptr(),
+                                             _lib.stream_ptr()))
+        sl = self.merged_stats(li_part, None, tiles)
         self.lstm_f(name + ".ceps_unit.ch_lstm_f", li.view(), self._ln(sl, name + ".ceps_unit.LN"), hf.view(), CEPS_F, tiles)
         self.pw(0, hf.view(), None, None, name + ".ceps_unit.ch_lstm_f.linear.weight", name + ".ceps_unit.ch_lstm_f.linear.bias",
                 lo.view(), CEPS_F, 2 * CH, tiles=tiles)
         _lib.check(self.lib.vadx_dfsmn_dft_f(1, C.byref(li.view()), C.byref(lo.view()), None, self.tbl_inv.data_ptr(),
-                                             C.byref(ceps.view()), CH, tiles, _lib.stream_ptr()))
-        s1 = self.stats(gx.view(), None, F_BINS, tiles)
+                                             C.byref(ceps.view()), CH, tiles, None, _lib.stream_ptr()))
+        s1 = self.merged_stats(gx_part, None, tiles)
         self.pw(2, gx.view(), None, self._ln(s1, name + ".LN1"), name + ".conv.weight", name + ".conv.bias", out, F_BINS, CH, kf=3,
-                add=ceps.view(), tiles=tiles)
-        return sc
+                add=ceps.view(), tiles=tiles, part0=out_part)
+        return sc, out_part
 
     # ---- LSTMs along time (:252-267) ------------------------------------------------------------
     def lstm_t(self, which, prefix, inp, ln, mul, out, frames, n_chunks):
@@ -175,16 +204,21 @@ class Iccrn:
         e5, p5, d0, y = new(CH), new(CH), new(2 * CH), new(2)
         self.lstm_f("in_ch_lstm", x4.view(), None, hf0.view(), F_BINS, tiles)
         self.pw(0, hf0.view(), None, None, "in_ch_lstm.linear.weight", "in_ch_lstm.linear.bias", e0l.view(), F_BINS, CH, tiles=tiles)
-        self.pw(0, e0l.view(), x4.view(), None, "in_conv.weight", "in_conv.bias", cats[0].view(0, CH), F_BINS, CH, tiles=tiles)
+        e_part = [self.new_part(tiles)]                 # partial statistics of e0..e4 (each is normalised twice: by the next
+        self.pw(0, e0l.view(), x4.view(), None, "in_conv.weight", "in_conv.bias", cats[0].view(0, CH), F_BINS, CH, tiles=tiles,
+                part0=e_part[0])                        # encoder block and, concatenated with d_{k+1}, by decoder block k)
         sc = {}
         for k in range(1, 5):                           # e1..e4
-            self.cfb(f"cfb_e{k}", cats[k - 1].view(0, CH), None, cats[k].view(0, CH), n_chunks, frames, sc)
-        self.cfb("cfb_e5", cats[4].view(0, CH), None, e5.view(), n_chunks, frames, sc)
-        s5 = self.stats(e5.view(), None, F_BINS, tiles)
+            sc, pk = self.cfb(f"cfb_e{k}", cats[k - 1].view(0, CH), None, cats[k].view(0, CH), n_chunks, frames, sc,
+                              a_part=e_part[k - 1])
+            e_part.append(pk)
+        sc, e5_part = self.cfb("cfb_e5", cats[4].view(0, CH), None, e5.view(), n_chunks, frames, sc, a_part=e_part[4])
+        s5 = self.merged_stats(e5_part, None, tiles)
         self.lstm_t(0, "ch_lstm", e5.view(), self._ln(s5, "ln"), e5.view(), p5.view(), frames, n_chunks)
-        self.cfb("cfb_d5", p5.view(), None, cats[4].view(CH, CH), n_chunks, frames, sc)
+        sc, d_part = self.cfb("cfb_d5", p5.view(), None, cats[4].view(CH, CH), n_chunks, frames, sc)     # p5: frame_stats pass
         for k in range(4, 0, -1):                       # d4..d1: cfb_dk(cat[e_k, d_{k+1}]) -> second half of cats[k-1]
-            self.cfb(f"cfb_d{k}", cats[k].view(0, CH), cats[k].view(CH, CH), cats[k - 1].view(CH, CH), n_chunks, frames, sc)
+            sc, d_part = self.cfb(f"cfb_d{k}", cats[k].view(0, CH), cats[k].view(CH, CH), cats[k - 1].view(CH, CH), n_chunks, frames,
+                                  sc, a_part=e_part[k], b_part=d_part)
         self.lstm_t(1, "out_ch_lstm", cats[0].view(), None, None, d0.view(), frames, n_chunks)
         self.pw(0, d0.view(), cats[0].view(CH, CH), None, "out_conv.weight", "out_conv.bias", y.view(), F_BINS, 2, tiles=tiles)
         return y
