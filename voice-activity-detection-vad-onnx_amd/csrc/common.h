@@ -67,6 +67,15 @@ inline size_t frag_index(int ldw, int r, int k) {
     return (size_t)(r / 16) * 16 * ldw + (size_t)(k / 16) * FRAG + (size_t)(((k % 16) / 4) * 16 + (r % 16)) * 4 + (k % 4);
 }
 
+// Weight / table loads name the global address space explicitly.  Inside a non-inlined device function a plain
+// `const float *` is a generic pointer and the load compiles to flat_load, which counts on BOTH vmcnt and lgkmcnt: the
+// LDS waits of the GEMM loops then also wait for the weight prefetch they were meant to overlap.
+typedef const __attribute__((address_space(1))) f32x4 *global_f32x4_ptr;
+typedef const __attribute__((address_space(1))) float *global_f32_ptr;
+__device__ __forceinline__ f32x4 ldg4(const float *p) { return *(global_f32x4_ptr)(p); }
+__device__ __forceinline__ float ldg1(const float *p) { return *(global_f32_ptr)(p); }
+__device__ __forceinline__ void stg1(float *p, float v) { *(__attribute__((address_space(1))) float *)(p) = v; }
+
 // host: convert a row-major [rows][ldw] block (rows, ldw multiples of 16) to fragment-major in place
 inline void frag_major_inplace(float *w, int rows, int ldw) {
     float *tmp = new float[(size_t)rows * ldw];
@@ -84,13 +93,13 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NT][MT], const float *act
     const float *ap = act + (4 * q) * lda + i;
     f32x4 wcur[NT], wnxt[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt]);
+    for (int nt = 0; nt < NT; ++nt) wcur[nt] = ldg4(wrow[nt]);
 #pragma unroll 2
     for (int S = 0; S < KB; ++S) {
         const int Sn = (S + 1 < KB) ? S + 1 : S;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + FRAG * Sn);
+            wnxt[nt] = ldg4(wrow[nt] + FRAG * Sn);
         __builtin_amdgcn_sched_barrier(0);      // keep the next block's weight loads ahead of this block's MFMAs
         const float *aps = ap + 16 * S * lda;
 #pragma unroll
@@ -129,10 +138,10 @@ __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, 
     f32x4 ad0 = {0.f, 0.f, 0.f, 0.f}, ml0 = {1.f, 1.f, 1.f, 1.f}, ad1 = ad0, ml1 = ml0;      // AFFINE terms ride the same pipeline
     auto fetch = [&](int S, f32x4 (&w)[NT], float (&a)[4][MT], f32x4 &ad, f32x4 &ml) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + FRAG * S);
+        for (int nt = 0; nt < NT; ++nt) w[nt] = ldg4(wrow[nt] + FRAG * S);
         if (AFFINE) {
-            ad = *reinterpret_cast<const f32x4 *>(add + 16 * S + 4 * q);
-            ml = *reinterpret_cast<const f32x4 *>(mul + 16 * S + 4 * q);
+            ad = ldg4(add + 16 * S + 4 * q);
+            ml = ldg4(mul + 16 * S + 4 * q);
         }
         const float *aps = ap + 16 * S * lda;
 #pragma unroll
@@ -180,11 +189,11 @@ __device__ __forceinline__ void gemm_rt_simple(f32x4 (&acc)[NT][MT], const float
     const float *ap = act + (4 * q) * lda + i;
     f32x4 wcur[NT], wnxt[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt]);
+    for (int nt = 0; nt < NT; ++nt) wcur[nt] = ldg4(wrow[nt]);
     for (int S = 0; S < kb; ++S) {
         const int Sn = (S + 1 < kb) ? S + 1 : S;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + FRAG * Sn);
+        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = ldg4(wrow[nt] + FRAG * Sn);
         const float *aps = ap + 16 * S * lda;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

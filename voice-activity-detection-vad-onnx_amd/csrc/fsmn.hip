@@ -101,7 +101,7 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
                 const int e = min(tid + THREADS * (u0 + u), NE - 1), c = e / NMEL, mel = e - c * NMEL;
                 int fr = f0 + c - 2;
                 fr = fr < 0 ? 0 : (fr > d.T - 1 ? d.T - 1 : fr);
-                v[u] = lm[(size_t)fr * NMEL + mel];
+                v[u] = ldg1(lm + (size_t)fr * NMEL + mel);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -133,7 +133,7 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
             constexpr int NH = (PROJ * HIST + THREADS - 1) / THREADS;
             float hv[NH];
 #pragma unroll
-            for (int u = 0; u < NH; ++u) { const int e = tid + THREADS * u; hv[u] = cin[l][e < PROJ * HIST ? e : PROJ * HIST - 1]; }
+            for (int u = 0; u < NH; ++u) { const int e = tid + THREADS * u; hv[u] = ldg1(cin[l] + (e < PROJ * HIST ? e : PROJ * HIST - 1)); }
 #pragma unroll
             for (int u = 0; u < NH; ++u) {
                 const int e = tid + THREADS * u, ch = e / HIST, h = e - ch * HIST;
@@ -152,7 +152,7 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
             const float *wf = Pk + d.off_fir[l] + ch * LORDER;
             float w[LORDER];
 #pragma unroll
-            for (int k = 0; k < LORDER; ++k) w[k] = wf[k];
+            for (int k = 0; k < LORDER; ++k) w[k] = ldg1(wf + k);
             const float *seq = bufP + ch * P_LD + 1 + fq * FPT;       // seq[s], s = t + k
             float win[FPT + HIST];
 #pragma unroll
@@ -167,7 +167,7 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
             // new cache = last 19 entries of (history ++ valid frames)
             for (int e = tid; e < PROJ * HIST; e += THREADS) {
                 const int c2 = e / HIST, h = e - c2 * HIST;
-                cout[l][e] = bufP[c2 * P_LD + 1 + nvalid + h];
+                stg1(cout[l] + e, bufP[c2 * P_LD + 1 + nvalid + h]);
             }
         }
         __syncthreads();

@@ -47,7 +47,7 @@ __device__ __forceinline__ void layer(const LayerArgs &a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int nt = nt0 + h * NW;
-            const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
+            const float b = a.bias ? ldg1(a.bias + nt * 16 + i) : 0.f;
 #pragma unroll
             for (int mt = 0; mt < MTT; ++mt) {
                 f32x4 v;
@@ -70,7 +70,7 @@ __device__ __forceinline__ void layer(const LayerArgs &a) {
             gemm_rt<1, MTT, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
                                            AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
         }
-        const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
+        const float b = a.bias ? ldg1(a.bias + nt * 16 + i) : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MTT; ++mt) {
             f32x4 v;
@@ -91,11 +91,11 @@ __device__ __forceinline__ void layer(const LayerArgs &a) {
         const float *ap = a.act + (4 * q) * a.lda + i + a.acol0;
         for (int b = wave; b < nblk; b += NW) {
             const int ps = b / a.kb, S = b - ps * a.kb;
-            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(row + ps * a.kstep * 16 + S * FRAG);
+            const f32x4 w4 = ldg4(row + ps * a.kstep * 16 + S * FRAG);
             f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, m4 = {1.f, 1.f, 1.f, 1.f};
             if (AFFINE) {
-                a4 = *reinterpret_cast<const f32x4 *>(a.add + ps * a.kstep + 16 * S + 4 * q);
-                m4 = *reinterpret_cast<const f32x4 *>(a.mul + ps * a.kstep + 16 * S + 4 * q);
+                a4 = ldg4(a.add + ps * a.kstep + 16 * S + 4 * q);
+                m4 = ldg4(a.mul + ps * a.kstep + 16 * S + 4 * q);
             }
             const float *aps = ap + 16 * S * a.lda + ps * a.cstep;
 #pragma unroll
@@ -115,7 +115,7 @@ __device__ __forceinline__ void layer(const LayerArgs &a) {
             const int i2 = e / (MTT * 4), rem = e - i2 * MTT * 4;
             f32x4 v = *reinterpret_cast<const f32x4 *>(a.scratch + (i2 * MTT) * 16 + rem * 4);
             for (int w2 = 1; w2 < NW; ++w2) v += *reinterpret_cast<const f32x4 *>(a.scratch + ((w2 * 16 + i2) * MTT) * 16 + rem * 4);
-            const float b = a.bias ? a.bias[nt * 16 + i2] : 0.f;
+            const float b = a.bias ? ldg1(a.bias + nt * 16 + i2) : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] += b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
             *reinterpret_cast<f32x4 *>(a.dst + (nt * 16 + i2) * a.ldd + a.dcol0 + rem * 4) = v;
@@ -132,7 +132,7 @@ __device__ __forceinline__ void layer(const LayerArgs &a) {
             gemm_rt<1, 1, false, AFFINE>(acc, a.act, a.lda, moff, wrow, a.kb, lane,
                                          AFFINE ? a.add + ps * a.kstep : nullptr, AFFINE ? a.mul + ps * a.kstep : nullptr);
         }
-        const float b = a.bias ? a.bias[nt * 16 + i] : 0.f;
+        const float b = a.bias ? ldg1(a.bias + nt * 16 + i) : 0.f;
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] = acc[0][0][r] + b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
