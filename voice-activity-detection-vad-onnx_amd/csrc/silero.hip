@@ -613,6 +613,7 @@ __global__ void silero_segments_kernel(const float *__restrict__ probs, int B, i
     const double min_sil_at_max = sr * prm.min_silence_at_max_speech / 1000.0;
     const long long L = n_samples[b];
     const int nwin = (int)((L + W - 1) / W) < T ? (int)((L + W - 1) / W) : T;
+
     long long *out = segs + (size_t)b * cap * 2;
     int ns = 0;
     auto push = [&](long long s, long long e) {
@@ -620,29 +621,40 @@ __global__ void silero_segments_kernel(const float *__restrict__ probs, int B, i
         ++ns;
     };
 
+    // The state machine runs in WINDOW units on 32-bit integers: every position it handles is a multiple of W, and the
+    // reference's float comparisons of such positions against second-derived thresholds are equivalent to integer
+    // comparisons against the thresholds' floor / ceiling in windows (d*W > X <=> d > floor(X/W); d*W < X <=> d < ceil(X/W);
+    // W is a power of two, so X/W is exact); a float32 probability compares against a double threshold like against the
+    // smallest float32 not below it.  (The 64-bit / double version spent ~1200 cycles per step on conversions.)
+    auto win_floor = [&](double x) { const double q = floor(x / (double)W); return q >= 2147483647.0 ? 2147483647 : (q <= -2147483648.0 ? (int)-2147483647 - 1 : (int)q); };
+    auto win_ceil = [&](double x) { const double q = ceil(x / (double)W); return q >= 2147483647.0 ? 2147483647 : (q <= -2147483648.0 ? (int)-2147483647 - 1 : (int)q); };
+    auto f32_not_below = [](double x) { float f = (float)x; if ((double)f < x) f = nextafterf(f, INFINITY); return f; };
+    const float thr_f = f32_not_below(thr), neg_f = f32_not_below(neg);
+    const int d_sil_at_max = win_floor(min_sil_at_max), d_max_speech = win_floor(max_speech), d_min_sil = win_ceil(min_sil),
+              d_min_speech = win_floor(min_speech);
+    auto pushw = [&](int s_, int e_) { push((long long)s_ * W, (long long)e_ * W); };
+
     bool triggered = false, have_cur = false, have_possible = false;
-    long long cur_start = 0, temp_end = 0, prev_end = 0, next_start = 0;
-    long long best_end = 0, best_dur = 0;
-    const float *pr = probs + (size_t)b * T;
-    auto step = [&](int k, double p) {          // one probability through the state machine (`continue` -> return)
-        const long long pos = W * k;
-        if (p >= thr && temp_end) {
-            const long long gap = pos - temp_end;
-            if ((double)gap > min_sil_at_max) {
+    int cur_start = 0, temp_end = 0, prev_end = 0, next_start = 0;      // window indices (0 doubles as "unset", like the reference)
+    int best_end = 0, best_dur = 0;
+    auto step = [&](int pos, float p) {          // one probability through the state machine (`continue` -> return)
+        if (p >= thr_f && temp_end) {
+            const int gap = pos - temp_end;
+            if (gap > d_sil_at_max) {
                 if (!have_possible || gap > best_dur) { best_end = temp_end; best_dur = gap; }
                 have_possible = true;
             }
             temp_end = 0;
             if (next_start < prev_end) next_start = pos;
         }
-        if (p >= thr && !triggered) {
+        if (p >= thr_f && !triggered) {
             triggered = true; cur_start = pos; have_cur = true;
             return;
         }
-        if (triggered && (double)(pos - cur_start) > max_speech) {
+        if (triggered && (pos - cur_start) > d_max_speech) {
             if (prm.use_max_poss_sil_at_max_speech && have_possible) {
                 prev_end = best_end;
-                push(cur_start, prev_end);
+                pushw(cur_start, prev_end);
                 have_cur = false;
                 next_start = prev_end + best_dur;
                 if (next_start < prev_end + pos) { cur_start = next_start; have_cur = true; }
@@ -650,14 +662,14 @@ __global__ void silero_segments_kernel(const float *__restrict__ probs, int B, i
                 prev_end = next_start = temp_end = 0;
                 have_possible = false;
             } else if (prev_end) {
-                push(cur_start, prev_end);
+                pushw(cur_start, prev_end);
                 have_cur = false;
                 if (next_start < prev_end) triggered = false;
                 else { cur_start = next_start; have_cur = true; }
                 prev_end = next_start = temp_end = 0;
                 have_possible = false;
             } else {
-                push(cur_start, pos);
+                pushw(cur_start, pos);
                 have_cur = false;
                 prev_end = next_start = temp_end = 0;
                 triggered = false;
@@ -665,12 +677,12 @@ __global__ void silero_segments_kernel(const float *__restrict__ probs, int B, i
                 return;
             }
         }
-        if (p < neg && triggered) {
+        if (p < neg_f && triggered) {
             if (!temp_end) temp_end = pos;
-            const long long sil_now = pos - temp_end;
-            if (!prm.use_max_poss_sil_at_max_speech && (double)sil_now > min_sil_at_max) prev_end = temp_end;
-            if ((double)sil_now < min_sil) return;
-            if ((double)(temp_end - cur_start) > min_speech) push(cur_start, temp_end);
+            const int sil_now = pos - temp_end;
+            if (!prm.use_max_poss_sil_at_max_speech && sil_now > d_sil_at_max) prev_end = temp_end;
+            if (sil_now < d_min_sil) return;
+            if ((temp_end - cur_start) > d_min_speech) pushw(cur_start, temp_end);
             have_cur = false;
             prev_end = next_start = temp_end = 0;
             triggered = false;
@@ -679,16 +691,19 @@ __global__ void silero_segments_kernel(const float *__restrict__ probs, int B, i
         }
         };
     // probabilities are fetched eight at a time, unconditionally (clamped index): a per-step load sat on the serial path
-    // of all T steps (0.23 ms per batch for what is a few microseconds of arithmetic)
+    // of all T steps (0.23 ms per batch for what is a few microseconds of arithmetic).  (Staging them through LDS with
+    // coalesced row reads was tried: no further gain -- what remains is the divergent state machine itself, ~1000
+    // cycles per step for one wave per 64 clips.)
+    const float *pr = probs + (size_t)b * T;
     for (int k0 = 0; k0 < nwin; k0 += 8) {
         float buf[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) buf[j] = pr[k0 + j < T ? k0 + j : T - 1];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (k0 + j < nwin) step(k0 + j, (double)buf[j]);
+            if (k0 + j < nwin) step(k0 + j, buf[j]);
     }
-    if (have_cur && (double)(L - cur_start) > min_speech) push(cur_start, L);
+    if (have_cur && (double)(L - (long long)cur_start * W) > min_speech) push((long long)cur_start * W, L);
 
     // +-speech_pad with midpoint split of short gaps (utils_vad.py:464-476)
     const int m = ns < cap ? ns : cap;
