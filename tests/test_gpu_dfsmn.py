@@ -95,6 +95,27 @@ def test_whole_clip_pair_segments():
         assert got[b] == want
 
 
+def test_sub_batching_and_batch_position_do_not_change_scores():
+    """A clip pair's window scores must not depend on its neighbours, its position in the batch or how the engine cuts
+    the batch into sub-batches (the only batch-size dependence is the summation order of the fused LayerNorm statistics:
+    two workgroups per tile below 4096 tiles -- last-bit differences, bounded here)."""
+    w = weights.dfsmn_synthetic(1234)
+    big, small = dfsmn.DfsmnEngine(w, sub_batch=960), dfsmn.DfsmnEngine(w, sub_batch=7)
+    lb, stride = big.grid()
+    W = 3
+    n = (W - 1) * stride + big.L
+    near = torch.from_numpy(weights.burst_clips(5, n, seed=21)).cuda()
+    far = torch.from_numpy(weights.burst_clips(5, n, seed=22)).cuda()
+    ref = big.run(near, far, W, stride)                                   # [15, 51] in one sub-batch
+    cut = small.run(near, far, W, stride)                                 # 2 clips (6 windows) per sub-batch
+    assert torch.equal(ref.view(5, W, -1)[:4], cut.view(5, W, -1)[:4])    # equal tile counts per launch shape -> bitwise
+    torch.testing.assert_close(cut, ref, rtol=0, atol=2e-6)
+    alone = big.run(near[3:4], far[3:4], W, stride)
+    torch.testing.assert_close(alone, ref.view(5, W, -1)[3], rtol=0, atol=2e-6)
+    rep = big.run(near.repeat(2, 1), far.repeat(2, 1), W, stride).view(2, 5, W, -1)
+    assert torch.equal(rep[0], rep[1])                                    # position in the batch: bitwise
+
+
 def test_near_only_session_matches_reference_fixture(golden):
     """DFSMN/only_near_end_audio: one stream in, the far end replaced by the export's baked white-noise tensors
     (carried by the fixture), against what the reference wrapper produced."""
