@@ -180,6 +180,94 @@ __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, 
     }
 }
 
+// gemm_rt with the first TWO weight blocks already in registers (r0, r1; kb >= 4, even).  A layer that runs again and
+// again on new activations (FireRed's point-wise pair walks the window tile by tile with the same two matrices) keeps
+// those fragments resident, so a phase starts multiplying as soon as its LDS operands arrive and streams from block 2
+// on -- instead of every wave opening every phase with an L2 round trip nobody else on the CU can cover (one workgroup
+// per CU, all waves at the same barrier).
+template <int NT, int MT>
+__device__ __forceinline__ void gemm_rt_resident(f32x4 (&acc)[NT][MT], const float *act, int lda, const int (&moff)[MT],
+                                                 const float *const (&wrow)[NT], int kb, int lane,
+                                                 const f32x4 (&r0)[NT], const f32x4 (&r1)[NT]) {
+    const int q = lane >> 4, i = lane & 15;
+    const float *ap = act + (4 * q) * lda + i;
+    f32x4 w0[NT], w1[NT];
+    float a0[4][MT], a1[4][MT];
+    auto fetch_w = [&](int S, f32x4 (&w)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) w[nt] = ldg4(wrow[nt] + FRAG * S);
+    };
+    auto fetch_a = [&](int S, float (&a)[4][MT]) {
+        const float *aps = ap + 16 * S * lda;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[j][mt] = aps[j * lda + moff[mt]];
+    };
+    auto compute = [&](const f32x4 (&w)[NT], const float (&a)[4][MT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(a[j][mt], w[nt][j], acc[nt][mt]);
+    };
+    fetch_w(2, w0);
+    fetch_w(3, w1);
+    fetch_a(0, a0);
+    fetch_a(1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(r0, a0);
+    fetch_a(2, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(r1, a1);
+    for (int S = 2; S < kb; S += 2) {          // w0 = block S, w1 = block S+1, a0 = operands of block S
+        fetch_a(S + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(w0, a0);
+        if (S + 2 < kb) { fetch_w(S + 2, w0); fetch_a(S + 2, a0); }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(w1, a1);
+        if (S + 3 < kb) fetch_w(S + 3, w1);
+    }
+}
+
+// All KB weight blocks of the wave's n-tiles resident in registers (w[S][nt]): no global traffic at all, the LDS operands
+// of block S+1 are requested before block S's MFMAs issue.
+template <int NT, int MT, int KB>
+__device__ __forceinline__ void gemm_resident(f32x4 (&acc)[NT][MT], const float *act, int lda, const int (&moff)[MT], int lane,
+                                              const f32x4 (&w)[KB][NT]) {
+    const int q = lane >> 4, i = lane & 15;
+    const float *ap = act + (4 * q) * lda + i;
+    float a0[4][MT], a1[4][MT];
+    auto fetch_a = [&](int S, float (&a)[4][MT]) {
+        const float *aps = ap + 16 * S * lda;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[j][mt] = aps[j * lda + moff[mt]];
+    };
+    auto compute = [&](const f32x4 (&wb)[NT], const float (&a)[4][MT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(a[j][mt], wb[nt][j], acc[nt][mt]);
+    };
+    static_assert(KB % 2 == 0, "gemm_resident: even block count");
+    fetch_a(0, a0);
+#pragma unroll
+    for (int S = 0; S < KB; S += 2) {
+        fetch_a(S + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(w[S], a0);
+        if (S + 2 < KB) fetch_a(S + 2, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(w[S + 1], a1);
+    }
+}
+
 // Plain one-block look-ahead variant (weights only): measured faster than the operand-pipelined gemm_rt
 // for the front-end's NT=2 x MT=2 DFT tiles, where a block already carries 16 MFMAs per 8 ds_reads.
 template <int NT, int MT, bool SWAP>

@@ -162,8 +162,75 @@ __device__ __forceinline__ void fsmn_memory(const Dev &d, const float *__restric
 }
 
 // pointwise pair on every 32-frame tile of the window: h = relu(W1 x src + b1); dst = W2 x h (+b2, relu)
+// The DFSMN block's P -> H -> P pair at the published widths (H = 256: one pair of n-tiles per wave; P = 128: one
+// n-tile per wave; 8 waves).  A wave's slice of BOTH matrices -- 8 blocks x 2 tiles of W1, 16 blocks x 1 tile of W2,
+// 128 VGPRs -- is loaded once per block and stays in registers while the window's tiles stream through: no weight
+// traffic inside the pair (it was re-streamed from L2 for every 32-frame tile, and every phase opened with an L2 round
+// trip that nobody else on the CU could cover: one workgroup per CU, all waves at the same barrier).  Bias / ReLU /
+// LDS store as in layer<>.  MT = 2 for a full 32-frame tile, 1 for a last tile of <= 16 frames.
+struct PairResident {
+    f32x4 w1[8][2], w2[16][1];
+    float bias1[2];
+};
+
+template <int MT>
+__device__ __forceinline__ void pair_tile_resident(const PairResident &R, const float *src, float *dst, float *h, int f0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    int moff[MT], hoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { moff[mt] = f0 + 16 * mt; hoff[mt] = 16 * mt; }
+    {   f32x4 acc[2][MT];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_resident<2, MT, 8>(acc, src, M_LD, moff, lane, R.w1);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[nt][mt][r] + R.bias1[nt], 0.f);
+                *reinterpret_cast<f32x4 *>(h + ((wave + 8 * nt) * 16 + i) * H_LD + mt * 16 + 4 * q) = v;
+            }
+    }
+    __syncthreads();
+    {   f32x4 acc[1][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_resident<1, MT, 16>(acc, h, H_LD, hoff, lane, R.w2);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<f32x4 *>(dst + (wave * 16 + i) * M_LD + f0 + mt * 16 + 4 * q) = acc[0][mt];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void pointwise_pair_resident(const Dev &d, const float *W1, const float *b1, const float *src,
+                                                        const float *W2, float *dst, float *h) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15;
+    PairResident R;
+    const float *row10 = frag_ptr(W1, 128, wave, 0, lane), *row11 = frag_ptr(W1, 128, wave + 8, 0, lane);
+    const float *row2 = frag_ptr(W2, 256, wave, 0, lane);
+#pragma unroll
+    for (int S = 0; S < 8; ++S) { R.w1[S][0] = ldg4(row10 + FRAG * S); R.w1[S][1] = ldg4(row11 + FRAG * S); }
+#pragma unroll
+    for (int S = 0; S < 16; ++S) R.w2[S][0] = ldg4(row2 + FRAG * S);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) R.bias1[nt] = ldg1(b1 + (wave + 8 * nt) * 16 + i);
+    for (int f0 = 0; f0 < d.T; f0 += 32) {
+        if (d.T - f0 <= 16) pair_tile_resident<1>(R, src, dst, h, f0);
+        else pair_tile_resident<2>(R, src, dst, h, f0);
+    }
+}
+
 __device__ __forceinline__ void pointwise_pair(const Dev &d, const float *W1, const float *b1, int k1b, const float *src,
                                                const float *W2, const float *b2, int relu2, float *dst, float *h) {
+    if (!FR_EXP && W2 && !b2 && !relu2 && k1b == d.Pp / 16 && d.Hp == 256 && d.Pp == 128 && blockDim.x == 512) {
+        pointwise_pair_resident(d, W1, b1, src, W2, dst, h);
+        return;
+    }
     for (int f0 = 0; f0 < d.T; f0 += 32) {
         const bool half = (d.T - f0) <= 16;
         LayerArgs a{W1, k1b * 16, d.Hp / 16, 1, k1b, 0, 0, b1, 1, src, M_LD, f0, h, H_LD, 0, nullptr, nullptr};
