@@ -255,16 +255,15 @@ __device__ __forceinline__ void gemm_resident(f32x4 (&acc)[NT][MT], const float 
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(a[j][mt], wb[nt][j], acc[nt][mt]);
     };
-    static_assert(KB % 2 == 0, "gemm_resident: even block count");
     fetch_a(0, a0);
 #pragma unroll
     for (int S = 0; S < KB; S += 2) {
-        fetch_a(S + 1, a1);
+        if (S + 1 < KB) fetch_a(S + 1, a1);
         __builtin_amdgcn_sched_barrier(0);
         compute(w[S], a0);
         if (S + 2 < KB) fetch_a(S + 2, a0);
         __builtin_amdgcn_sched_barrier(0);
-        compute(w[S + 1], a1);
+        if (S + 1 < KB) compute(w[S + 1 < KB ? S + 1 : S], a1);
     }
 }
 

@@ -168,13 +168,15 @@ __device__ __forceinline__ void fsmn_memory(const Dev &d, const float *__restric
 // traffic inside the pair (it was re-streamed from L2 for every 32-frame tile, and every phase opened with an L2 round
 // trip that nobody else on the CU could cover: one workgroup per CU, all waves at the same barrier).  Bias / ReLU /
 // LDS store as in layer<>.  MT = 2 for a full 32-frame tile, 1 for a last tile of <= 16 frames.
+template <int KB1>
 struct PairResident {
-    f32x4 w1[8][2], w2[16][1];
-    float bias1[2];
+    f32x4 w1[KB1][2], w2[16][1];
+    float bias1[2], bias2;
 };
 
-template <int MT>
-__device__ __forceinline__ void pair_tile_resident(const PairResident &R, const float *src, float *dst, float *h, int f0) {
+// HAS2: the second (H -> P) layer exists; otherwise the H tile in `h` is the result (dnn layer before the output head)
+template <int MT, int KB1, bool HAS2>
+__device__ __forceinline__ void pair_tile_resident(const PairResident<KB1> &R, const float *src, float *dst, float *h, int f0, bool relu2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
     int moff[MT], hoff[MT];
 #pragma unroll
@@ -184,7 +186,7 @@ __device__ __forceinline__ void pair_tile_resident(const PairResident &R, const 
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_resident<2, MT, 8>(acc, src, M_LD, moff, lane, R.w1);
+        gemm_resident<2, MT, KB1>(acc, src, M_LD, moff, lane, R.w1);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -196,40 +198,54 @@ __device__ __forceinline__ void pair_tile_resident(const PairResident &R, const 
             }
     }
     __syncthreads();
-    {   f32x4 acc[1][MT];
+    if (HAS2) {
+        f32x4 acc[1][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         gemm_resident<1, MT, 16>(acc, h, H_LD, hoff, lane, R.w2);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            *reinterpret_cast<f32x4 *>(dst + (wave * 16 + i) * M_LD + f0 + mt * 16 + 4 * q) = acc[0][mt];
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[0][mt][r] + R.bias2; if (relu2) v[r] = fmaxf(v[r], 0.f); }
+            *reinterpret_cast<f32x4 *>(dst + (wave * 16 + i) * M_LD + f0 + mt * 16 + 4 * q) = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 }
 
-__device__ __forceinline__ void pointwise_pair_resident(const Dev &d, const float *W1, const float *b1, const float *src,
-                                                        const float *W2, float *dst, float *h) {
+template <int KB1, bool HAS2>
+__device__ __forceinline__ void load_pair_resident(PairResident<KB1> &R, const float *W1, const float *b1, const float *W2, const float *b2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15;
-    PairResident R;
-    const float *row10 = frag_ptr(W1, 128, wave, 0, lane), *row11 = frag_ptr(W1, 128, wave + 8, 0, lane);
-    const float *row2 = frag_ptr(W2, 256, wave, 0, lane);
+    const float *row10 = frag_ptr(W1, KB1 * 16, wave, 0, lane), *row11 = frag_ptr(W1, KB1 * 16, wave + 8, 0, lane);
 #pragma unroll
-    for (int S = 0; S < 8; ++S) { R.w1[S][0] = ldg4(row10 + FRAG * S); R.w1[S][1] = ldg4(row11 + FRAG * S); }
+    for (int S = 0; S < KB1; ++S) { R.w1[S][0] = ldg4(row10 + FRAG * S); R.w1[S][1] = ldg4(row11 + FRAG * S); }
+    if (HAS2) {
+        const float *row2 = frag_ptr(W2, 256, wave, 0, lane);
 #pragma unroll
-    for (int S = 0; S < 16; ++S) R.w2[S][0] = ldg4(row2 + FRAG * S);
+        for (int S = 0; S < 16; ++S) R.w2[S][0] = ldg4(row2 + FRAG * S);
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) R.bias1[nt] = ldg1(b1 + (wave + 8 * nt) * 16 + i);
+    R.bias2 = (HAS2 && b2) ? ldg1(b2 + wave * 16 + i) : 0.f;
+}
+
+template <int KB1>
+__device__ __forceinline__ void pointwise_pair_resident(const Dev &d, const float *W1, const float *b1, const float *src,
+                                                        const float *W2, const float *b2, bool relu2, float *dst, float *h) {
+    PairResident<KB1> R;
+    load_pair_resident<KB1, true>(R, W1, b1, W2, b2);
     for (int f0 = 0; f0 < d.T; f0 += 32) {
-        if (d.T - f0 <= 16) pair_tile_resident<1>(R, src, dst, h, f0);
-        else pair_tile_resident<2>(R, src, dst, h, f0);
+        if (d.T - f0 <= 16) pair_tile_resident<1, KB1, true>(R, src, dst, h, f0, relu2);
+        else pair_tile_resident<2, KB1, true>(R, src, dst, h, f0, relu2);
     }
 }
 
 __device__ __forceinline__ void pointwise_pair(const Dev &d, const float *W1, const float *b1, int k1b, const float *src,
                                                const float *W2, const float *b2, int relu2, float *dst, float *h) {
-    if (!FR_EXP && W2 && !b2 && !relu2 && k1b == d.Pp / 16 && d.Hp == 256 && d.Pp == 128 && blockDim.x == 512) {
-        pointwise_pair_resident(d, W1, b1, src, W2, dst, h);
-        return;
+    if (!FR_EXP && W2 && d.Hp == 256 && d.Pp == 128 && blockDim.x == 512) {
+        if (k1b == 8) { pointwise_pair_resident<8>(d, W1, b1, src, W2, b2, relu2 != 0, dst, h); return; }      // DFSMN block
+        if (k1b == 5) { pointwise_pair_resident<5>(d, W1, b1, src, W2, b2, relu2 != 0, dst, h); return; }      // fc1 (80 mels) / fc2
     }
     for (int f0 = 0; f0 < d.T; f0 += 32) {
         const bool half = (d.T - f0) <= 16;
@@ -278,11 +294,19 @@ __global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float 
     }
     // dnns (P->H ReLU, then M-1 x H->H ReLU) and the 1x1 output conv + sigmoid, tile by tile
     float *h2 = p;                        // p is dead: second H-tile buffer for M > 1
+    const bool dnn_resident = !FR_EXP && d.Hp == 256 && d.Pp == 128 && blockDim.x == 512;
+    PairResident<8> RD;                   // dnn[0] (P -> H) stays in registers across the window's tiles, like the pairs
+    if (dnn_resident) load_pair_resident<8, false>(RD, Pk + d.off_dnn[0], Pk + d.off_dnnb[0], nullptr, nullptr);
     for (int f0 = 0; f0 < ((FR_EXP & 16) ? 0 : d.T); f0 += 32) {
         const bool half = (d.T - f0) <= 16;
-        LayerArgs a{Pk + d.off_dnn[0], d.Pp, d.Hp / 16, 1, d.Pp / 16, 0, 0, Pk + d.off_dnnb[0], 1, mem, M_LD, f0, h, H_LD, 0, nullptr, nullptr};
-        if (half) layer<1, false>(a); else layer<2, false>(a);
-        __syncthreads();
+        if (dnn_resident) {
+            if (half) pair_tile_resident<1, 8, false>(RD, mem, nullptr, h, f0, false);
+            else pair_tile_resident<2, 8, false>(RD, mem, nullptr, h, f0, false);
+        } else {
+            LayerArgs a{Pk + d.off_dnn[0], d.Pp, d.Hp / 16, 1, d.Pp / 16, 0, 0, Pk + d.off_dnnb[0], 1, mem, M_LD, f0, h, H_LD, 0, nullptr, nullptr};
+            if (half) layer<1, false>(a); else layer<2, false>(a);
+            __syncthreads();
+        }
         float *cur = h, *nxt = h2;
         for (int m = 1; m < d.M; ++m) {
             LayerArgs c{Pk + d.off_dnn[m], d.Hp, d.Hp / 16, 1, d.Hp / 16, 0, 0, Pk + d.off_dnnb[m], 1, cur, H_LD, 0, nxt, H_LD, 0, nullptr, nullptr};
