@@ -231,7 +231,6 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, i = lane & 15;
-    const int tile = blockIdx.x;
     const int cin = p.a.c + p.b.c;
     constexpr int K = KS * 4, HALO = (KF - 1) / 2;
     const int fh = p.fc + 2 * HALO, fs = fh | 1;        // rows per channel, and their (odd) LDS pitch
@@ -252,6 +251,9 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
             wa[mt][s] = p.W[(size_t)(mt * 16 + i) * K + 4 * s + q];
             if (MODE == 1) wg[mt][s] = p.W2[(size_t)(mt * 16 + i) * K + 4 * s + q];
         }
+    // (a persistent variant -- one resident wave of workgroups walking the tiles with their weights kept -- was slower
+    // here, 1.30 -> 1.54 ms: the per-workgroup set-up is small and the hoisted per-tile state costs occupancy)
+    const int tile = blockIdx.x;
     float ln_mean = 0.f, ln_inv = 1.f;                  // MODE 1: this lane's frame (column i) is fixed
     f32x4 st_mean = {0.f, 0.f, 0.f, 0.f}, st_inv = {1.f, 1.f, 1.f, 1.f};      // MODE 2: the staging thread's frame quad
     if (LN_FLY) { ln_mean = p.ln.stats[((size_t)tile * 16 + i) * 2]; ln_inv = p.ln.stats[((size_t)tile * 16 + i) * 2 + 1]; }
@@ -462,7 +464,7 @@ struct DftArgs {
     const float *tbl;    // [MTILES*16][KS*4] row-major, zero padded
     ViewW out;           // FWD: li (2C ch, 81).  INV: ceps_out (C ch, 160)
     float *part;         // FWD, optional: partial statistics of out (slot 0; slot 1 cleared)
-    int C;
+    int C, tiles;
 };
 
 // Memory path: channel c+1's rows are requested as 16-B coalesced loads before channel c's MFMAs issue and parked in
@@ -475,13 +477,15 @@ __global__ __launch_bounds__(256, 2) void dft_f_kernel(DftArgs p) {
     constexpr int ITEMS = INV ? 81 * 4 : 160 * 4, NR = (ITEMS + NT - 1) / NT;      // staging work items (row, frame quad)
     __shared__ __attribute__((aligned(16))) float Bs[2][KROWS * 16];
     __shared__ __attribute__((aligned(16))) float Os[2][OROWS * 16];
-    const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
-    float ta[RT][KS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
+    float ta[RT][KS];                                       // loaded once: the workgroup walks tiles blockIdx.x, + gridDim.x, ...
 #pragma unroll
     for (int h = 0; h < RT; ++h)
 #pragma unroll
         for (int s = 0; s < KS; ++s) ta[h][s] = p.tbl[(size_t)((wave * RT + h) * 16 + i) * KROWS + 4 * s + q];
     const int tq = tid & 3;                                 // NT is a multiple of 4: a thread's frame quad is fixed
+    for (int e = tid; e < 2 * KROWS * 16; e += NT) Bs[0][e] = 0.f;          // rows past the data stay zero (table padding)
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
     f32x4 ln_mean = {0.f, 0.f, 0.f, 0.f}, ln_inv = {1.f, 1.f, 1.f, 1.f};
     if (!INV)                        // the forward direction always normalises (LN2; the launcher requires it)
 #pragma unroll
@@ -489,7 +493,6 @@ __global__ __launch_bounds__(256, 2) void dft_f_kernel(DftArgs p) {
             ln_mean[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2];
             ln_inv[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2 + 1];
         }
-    for (int e = tid; e < 2 * KROWS * 16; e += NT) Bs[0][e] = 0.f;          // rows past the data stay zero (table padding)
     f32x4 pre[NR][INV ? 4 : 1];
     float lw[NR], lb[NR];
     // every load is unconditional (the item index is clamped; surplus lanes re-read the last row): a load under a
@@ -584,6 +587,8 @@ __global__ __launch_bounds__(256, 2) void dft_f_kernel(DftArgs p) {
     if (!INV && p.part) {
         __syncthreads();                                   // the last copy-out is done with Os
         stat_reduce_store(run, &Os[0][0], p.part, tile, 0, true);
+    }
+    __syncthreads();                                        // Bs / Os are free for the next tile
     }
 }
 
@@ -1270,9 +1275,10 @@ extern "C" int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_
     VADX_REQUIRE(in && in->ptr && tbl && out && out->ptr && C > 0 && tiles > 0, "vadx_dfsmn_dft_f: bad argument");
     VADX_REQUIRE(inverse ? (lo && lo->ptr) : (ln && ln->stats), "vadx_dfsmn_dft_f: missing lo / ln");
     DftArgs p;
-    p.in = mkview(in); p.lo = mkview(lo); p.ln = mkln(ln); p.tbl = tbl; p.out = mkvieww(out); p.C = C; p.part = inverse ? nullptr : part;
-    if (inverse) hipLaunchKernelGGL(dft_f_kernel<true>, dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL(dft_f_kernel<false>, dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    p.in = mkview(in); p.lo = mkview(lo); p.ln = mkln(ln); p.tbl = tbl; p.out = mkvieww(out); p.C = C; p.part = inverse ? nullptr : part; p.tiles = tiles;
+    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);      // two persistent workgroups per CU, table in VGPRs
+    if (inverse) hipLaunchKernelGGL(dft_f_kernel<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(dft_f_kernel<false>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }
