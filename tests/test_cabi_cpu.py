@@ -167,3 +167,33 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     needs a GPU: tests/test_gpu_cabi_c.py)."""
     assert os.path.exists(build_c_client(tmp_path))
 
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: the product package, the shim, bench_models.py and the tools that ship with it
+    must not import it; bench.py may, inside cpu_baseline() only; __graft_entry__ in build() / smoke() only."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.dirname(_lib.LIB_PATH)
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for fn in ast.walk(tree):
+            scope = fn.name if isinstance(fn, (ast.FunctionDef, ast.AsyncFunctionDef)) else None
+            if scope is None and not isinstance(fn, ast.Module):
+                continue
+            for node in (fn.body if scope else [n for n in tree.body if not isinstance(n, (ast.FunctionDef, ast.ClassDef))]):
+                for sub in ast.walk(node):
+                    names = ([a.name for a in sub.names] if isinstance(sub, ast.Import) else
+                             [sub.module or ""] if isinstance(sub, ast.ImportFrom) else [])
+                    if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                        hits.append(scope or "<module>")
+        return set(hits)
+
+    product = [os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py")] + [os.path.join(root, "vadx.py"),
+                                                                                       os.path.join(root, "bench_models.py")]
+    for path in product:
+        assert not oracle_imports(path), path
+    assert oracle_imports(os.path.join(root, "bench.py")) <= {"cpu_baseline"}
+    assert oracle_imports(os.path.join(root, "__graft_entry__.py")) <= {"build", "smoke"}
