@@ -3,12 +3,21 @@
 Silero-VAD f32, batch = 4096 synthetic 10 s @ 16 kHz clips per MI355X (weak scaling: every rank owns
 its own 4096 clips, no data-path collective), raw audio resident in HBM -> speech-segment tables.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One "step" = one pass of the hot path over the resident batch: encoder kernel (STFT conv + conv stack
-+ W_ih, f32 MFMA) -> persistent LSTM kernel -> device segmenter.  Rank 0 prints ONE JSON line.
+N > 1 without a launcher: this process starts N ranks itself (`python -m torch.distributed.run`, rendezvous on
+127.0.0.1) BEFORE anything touches a GPU and relays rank 0's line; under an external launcher (WORLD_SIZE set, the way
+the driver runs it) it is one of the ranks.  One "step" = one pass of the hot path over the resident batch: encoder
+kernel (STFT conv + conv stack + W_ih, f32 MFMA) -> persistent LSTM kernel -> device segmenter.  Rank 0 prints ONE JSON
+line.  Besides the contract keys it carries
+  * `roofline` / `roofline_recurrent`: the two matrix-pipe kernels against the f32 MFMA peak, with SURVEY 8(d) byte accounting
+    (`algorithmic_bytes_per_launch` = 2052 B / window, `traffic` from the committed PMC passes, `traffic_ratio`);
+  * `hbm`: the north star's HBM fraction of the whole step;
+  * `feed`: the same batch timed INCLUDING the int16 upload from pinned host memory, double-buffered against compute;
+  * `secondary`: BASELINE configs 3, 4, 5 measured in the same process (bench_models.py), N = 1 only;
+  * `cpu_baseline`: the oracle driven like the reference drives ORT, on this host's cores (N = 1, rank 0).
+`--dry-run` replaces the device work by a sleep and RCCL by gloo so the launch / barrier / collect path can be tested
+on a CPU-only box; its line says so (`data`: "dry-run") and carries no measurement.
 """
 from __future__ import annotations
 
@@ -16,6 +25,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,53 +57,51 @@ FLOP_RECUR = 2 * MAC_HH
 MFMA_PER_TILE = 1024 + 2560 + 640 + 128 + 128 + 1024
 FLOP_ENCODE_ISSUED = MFMA_PER_TILE * 2048 // 16
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = f32 vector rate
+PEAK_HBM_GBPS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak
+# algorithmic HBM bytes per 512-sample window on the Silero path = 2048 B of float32 PCM in (as the reference
+# feeds it) + one 4-byte score out.  The encoder -> LSTM intermediate `gx` (2048 B written + 2048 B read per window) is
+# DESIGN traffic, not algorithmic: it is what `traffic_ratio` exposes.
+ALGO_BYTES_PER_WINDOW = 2048 + 4
+FEED_CHUNK_CLIPS = 512                # feed-inclusive mode: upload granularity (164 MB of int16 per chunk)
 
 
-def profiled_traffic():
-    """HBM bytes per encoder launch from the newest committed rocprofv3 PMC summary (profiles/rNN*/SUMMARY.txt, written by
+def _kernel_counter(path, kernel, counter):
+    """mean per-dispatch value of one PMC counter for the LARGEST grid of `kernel` in a profiles/*/SUMMARY.txt"""
+    best, grid = None, -1
+    for line in open(path):
+        if kernel not in line or "grid=" not in line or f" {counter} " not in line:
+            continue
+        g = int(line.split("grid=")[1].split()[0])
+        if g >= grid:
+            grid, best = g, float(line.split()[-2])
+    return best, grid
+
+
+def profiled_traffic(kernel="silero_encode_kernel"):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/rNN*/SUMMARY.txt, written by
     tools/profile_bench.sh from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this very command).  FETCH_SIZE is
     doubled (gfx950 counts a wide coalesced read at half its bytes, MI355X_MICROARCH.md "HBM"); both are KiB."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "SUMMARY.txt"))):
-        fetch = write = None
-        grid = -1
-        for line in open(path):
-            if "silero_encode_kernel" not in line or "grid=" not in line or "_SIZE" not in line:
-                continue
-            g = int(line.split("grid=")[1].split()[0])
-            name, val = line.split()[-3], float(line.split()[-2])
-            if name in ("FETCH_SIZE", "WRITE_SIZE") and g >= grid:
-                grid = g
-                if name == "FETCH_SIZE":
-                    fetch = val
-                else:
-                    write = val
-        if fetch is not None and write is not None:
-            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT), "grid_threads": grid}
+        fetch, g1 = _kernel_counter(path, kernel, "FETCH_SIZE")
+        write, g2 = _kernel_counter(path, kernel, "WRITE_SIZE")
+        if fetch is not None and write is not None and g1 == g2:
+            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT), "grid_threads": g1}
     return best
 
 
-def synth_batch(torch, device, batch, samples, seed):
+def synth_batch(torch, device, batch, samples, seed, pcm16=False):
     """int16-quantised burst clips generated on the GPU (every clip unique): 0.5-2 s segments
     alternating N(0,3000) / N(0,30), then x 1/32768 as the reference feeds Silero
-    (Silero/Inference_Silero_VAD_ONNX.py:83)."""
-    g = torch.Generator(device=device).manual_seed(seed)
+    (Silero/Inference_Silero_VAD_ONNX.py:83).  pcm16=True returns the int16 samples themselves."""
+    import bench_models
+    pcm = bench_models.synth_pcm16(torch, device, batch, samples, seed)
+    if pcm16:
+        return pcm
     out = torch.empty((batch, samples), dtype=torch.float32, device=device)
-    chunk = 512
-    for b0 in range(0, batch, chunk):
-        nb = min(chunk, batch - b0)
-        dur = (torch.rand((nb, 24), generator=g, device=device) * 1.5 + 0.5) * 16000.0
-        edges = torch.cumsum(dur, dim=1)
-        pos = torch.arange(samples, device=device, dtype=torch.float32).unsqueeze(0).expand(nb, -1).contiguous()
-        seg = torch.searchsorted(edges, pos)
-        first = torch.randint(0, 2, (nb, 1), generator=g, device=device)
-        loud = ((seg + first) % 2) == 0
-        sigma = torch.where(loud, torch.tensor(3000.0, device=device), torch.tensor(30.0, device=device))
-        x = torch.randn((nb, samples), generator=g, device=device) * sigma
-        x = torch.clamp(torch.round(x), -32768, 32767)
-        out[b0:b0 + nb] = x * 0.000030517578
-        del dur, edges, pos, seg, loud, sigma, x
+    for b0 in range(0, batch, 512):
+        out[b0:b0 + 512] = pcm[b0:b0 + 512].to(torch.float32) * 0.000030517578
     return out
 
 
@@ -103,6 +112,7 @@ def cpu_baseline(budget_s=10.0):
     best intra-op thread count (the reference uses ORT's auto setting / physical cores)."""
     import torch
     from oracle import silero as osil
+    import bench_models
     import vadx  # noqa: F401
     from vadx import weights
     w = {k: torch.from_numpy(v) for k, v in weights.silero_synthetic(1234).items()}
@@ -153,7 +163,7 @@ def cpu_baseline(budget_s=10.0):
             m2.audio_forward(xb, 16000)
             reps += 1
         batched = reps * bb * 16 / (time.perf_counter() - t0)
-    return {"value": rate, "unit": "frames/s", "cores": best_thr, "kind": "port",
+    return {"value": rate, "unit": "frames/s", "cores": best_thr, "kind": "port", "cpu": bench_models.cpu_model(),
             "sample": f"{n} windows of synthetic 10 s clips, batch 1, one call per 512-sample window, state carried "
                       f"(torch-CPU oracle stand-in for ORT-CPU; best of 1/2/4/8/16 intra-op threads on a "
                       f"{ncpu}-CPU host), {el:.1f} s",
@@ -167,22 +177,126 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (default = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 3-5 (bench_models.py)")
+    ap.add_argument("--no-feed", action="store_true", help="skip the PCIe-inclusive (pinned, double-buffered upload) measurement")
+    ap.add_argument("--secondary-reps", type=int, default=3)
+    ap.add_argument("--dry-run", action="store_true", help="CPU-only: gloo + sleep instead of RCCL + kernels (launch-path test)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """`bench.py --gpus N` started plainly: become the launcher.  No torch import, no HIP call has happened in this
+    process -- the ranks are fresh children of torch.distributed.run -- and this process only relays their output."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("self-launch: " + " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """The N-rank launch / barrier / max-over-ranks / rank-0-prints path without a GPU (gloo): tests/test_bench_contract.py."""
+    import vadx  # noqa: F401
+    from vadx import shard
+    rank, _local, world = shard.env_rank()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = shard.init("gloo")
+    for _ in range(args.warmup):
+        time.sleep(0.002)
+    shard.fence(dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.005)
+    shard.fence(dist)
+    elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0)
+    lo, hi = shard.shard_bounds(world * args.clips, rank, world)
+    owned = shard.gather_ragged(dist, [(rank, lo, hi)])
+    if rank == 0:
+        print(json.dumps({"metric": "audio frames/sec/GPU (16 kHz, 512-sample hop); RTF at batch=1", "value": None,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "dry-run (no GPU work: launch / barrier / collect path only)",
+                          "config": {"workload": "dry-run", "clips_per_gpu": args.clips, "shards": owned}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class FeedPipeline:
+    """The headline batch timed from PINNED HOST int16 PCM: chunks of FEED_CHUNK_CLIPS clips cross PCIe on a copy stream into
+    one of two device buffers while the encoder of the previous chunk runs on the compute stream; the
+    recurrent kernel and the segmenter run once over the whole batch.  int16 is what a host has (wav files); the encoder
+    applies the reference's x 0.000030517578 itself, bit-identically."""
+
+    def __init__(self, torch, eng, L, host_pcm, probs, segs, counts, lens, prm, cap):
+        self.t, self.eng, self.L = torch, eng, L
+        self.host = host_pcm
+        B, N = host_pcm.shape
+        self.B, self.N, self.T = B, N, (N + WINDOW - 1) // WINDOW
+        self.chunk = min(FEED_CHUNK_CLIPS, B)
+        dev = eng.device
+        self.buf = [torch.empty((self.chunk, N), dtype=torch.int16, device=dev) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.free = [torch.cuda.Event() for _ in range(2)]
+        self.in_use = [False, False]
+        self.ws = eng._workspace(B, self.T)
+        self.out = (probs, segs, counts, lens, prm, cap)
+
+    def step(self):
+        t, L, eng = self.t, self.L, self.eng
+        probs, segs, counts, lens, prm, cap = self.out
+        comp = t.cuda.current_stream()
+        st = C.c_void_p(comp.cuda_stream)
+        from vadx import _lib
+        for i, b0 in enumerate(range(0, self.B, self.chunk)):
+            nb = min(self.chunk, self.B - b0)
+            k = i & 1
+            with t.cuda.stream(self.copy_stream):
+                if self.in_use[k]:                      # the encoder launch that last read this buffer (also across steps)
+                    self.copy_stream.wait_event(self.free[k])
+                self.buf[k][:nb].copy_(self.host[b0:b0 + nb], non_blocking=True)
+                self.ready[k].record(self.copy_stream)
+            comp.wait_event(self.ready[k])
+            _lib.check(L.vadx_silero_encode_pcm16_part(eng.packed.data_ptr(), self.buf[k].data_ptr(), eng.PCM16_SCALE, nb, self.N,
+                                                       self.N, b0, self.B, self.ws.data_ptr(), self.ws.numel(), st))
+            self.free[k].record(comp)
+            self.in_use[k] = True
+        _lib.check(L.vadx_silero_recur(eng.packed.data_ptr(), self.ws.data_ptr(), self.ws.numel(), self.B, self.T, None,
+                                       probs.data_ptr(), None, st))
+        _lib.check(L.vadx_silero_segments(probs.data_ptr(), self.B, self.T, lens.data_ptr(), C.byref(prm), segs.data_ptr(),
+                                          counts.data_ptr(), cap, st))
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
+    import bench_models
     import vadx  # noqa: F401
     from vadx import _lib, shard, silero, weights
 
     rank, local_rank, world = shard.env_rank()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run `bench.py --gpus N` "
+                         "without a launcher and let it start the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the vadx product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -192,7 +306,10 @@ def main():
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(device)}; torch imported")
     B = args.clips
     eng = silero.SileroEngine(weights.silero_synthetic(1234), device=device)
-    audio = synth_batch(torch, device, B, SAMPLES, seed=1234 + rank)          # resident in HBM
+    pcm = synth_batch(torch, device, B, SAMPLES, seed=1234 + rank, pcm16=True)
+    audio = torch.empty((B, SAMPLES), dtype=torch.float32, device=device)          # resident in HBM, as the reference feeds it
+    for b0 in range(0, B, 512):
+        audio[b0:b0 + 512] = pcm[b0:b0 + 512].to(torch.float32) * 0.000030517578
     torch.cuda.synchronize()
     log(f"{B} x {SAMPLES} synthetic clips resident ({audio.numel() * 4 / 2**30:.2f} GiB)")
     L = _lib.lib()
@@ -247,15 +364,55 @@ def main():
     assert int(counts.max().item()) <= cap, "segment table overflow"
     assert bool(torch.isfinite(probs).all())
     n_seg = int(counts.sum().item())
+    probs_resident = probs.clone()
 
     frames_per_step = world * B * T
     value = frames_per_step * args.steps / elapsed
     achieved = (B * T * FLOP_ENCODE_ISSUED) / (enc_ms * 1e-3) / 1e12
 
+    # ---- the same batch from pinned host int16, upload overlapped with compute (every rank feeds its own GPU at once)
+    feed = None
+    if not args.no_feed:
+        try:
+            host = torch.empty((B, SAMPLES), dtype=torch.int16, pin_memory=True)
+            host.copy_(pcm)
+            torch.cuda.synchronize()
+            del audio
+            torch.cuda.empty_cache()
+            pipe = FeedPipeline(torch, eng, L, host, probs, segs, counts, lens, prm, cap)
+            for _ in range(max(1, args.warmup)):
+                pipe.step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pipe.step()
+            fence()
+            feed_el = shard.max_over_ranks(dist, time.perf_counter() - t1, device)
+            same = bool(torch.equal(probs, probs_resident))          # int16 in-kernel scaling == host-side float32 product, bit for bit
+            up_bytes = B * SAMPLES * 2
+            # upload alone (same pinned buffer, same chunking, nothing overlapped): what PCIe gives this process
+            t2 = time.perf_counter()
+            for b0 in range(0, B, FEED_CHUNK_CLIPS):
+                pipe.buf[0][:min(FEED_CHUNK_CLIPS, B - b0)].copy_(host[b0:b0 + FEED_CHUNK_CLIPS], non_blocking=True)
+            torch.cuda.synchronize()
+            up_s = time.perf_counter() - t2
+            feed = {"value": world * B * T * args.steps / feed_el, "unit": "frames/s", "ms_per_step": feed_el / args.steps * 1e3,
+                    "upload": "int16 PCM from pinned host memory, chunks of %d clips double-buffered against the encoder" % FEED_CHUNK_CLIPS,
+                    "upload_bytes_per_step_per_gpu": up_bytes, "upload_alone_ms": up_s * 1e3,
+                    "upload_alone_GBps": up_bytes / up_s / 1e9, "pcie_peak_GBps": 63.0,
+                    "scores_bit_identical_to_resident_f32_path": same}
+            log(f"feed-inclusive: {feed['ms_per_step']:.2f} ms/step, upload alone {up_s * 1e3:.1f} ms ({feed['upload_alone_GBps']:.1f} GB/s)")
+            del pipe, host
+        except Exception as e:                                       # noqa: BLE001  (pinned allocation can be refused)
+            feed = {"error": f"{type(e).__name__}: {e}"}
+            log(f"feed-inclusive mode failed: {feed['error']}")
+    del pcm
+
     rtf_b1 = None
     cpu = None
+    secondary = None
     if rank == 0:
-        one = audio[:1].contiguous()
+        one = synth_batch(torch, device, 1, SAMPLES, seed=99)
         eng.clips(one)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -264,16 +421,25 @@ def main():
         torch.cuda.synchronize()
         rtf_b1 = (time.perf_counter() - t1) / 5 / (SAMPLES / 16000.0)
         log(f"rtf_batch1 = {rtf_b1:.5f}")
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline()
-            log("cpu baseline done")
+    if world == 1 and not args.no_secondary:
+        torch.cuda.empty_cache()
+        eng._ws = None
+        secondary = bench_models.run_all(torch, device, args.secondary_reps, 0 if args.no_cpu_baseline else 3.0, log=log)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+        log("cpu baseline done")
 
     if rank == 0:
-        traffic = profiled_traffic() if (B, T) == (CLIPS_PER_GPU, STEPS_PER_CLIP) else None
+        full = (B, T) == (CLIPS_PER_GPU, STEPS_PER_CLIP)
+        tr_enc = profiled_traffic("silero_encode_kernel") if full else None
+        tr_rec = profiled_traffic("silero_lstm_kernel") if full else None
+        algo_launch = B * T * ALGO_BYTES_PER_WINDOW
+        step_traffic = (tr_enc["bytes"] + tr_rec["bytes"]) if (tr_enc and tr_rec) else None
+        step_s = elapsed / args.steps
         line = {
             "metric": "audio frames/sec/GPU (16 kHz, 512-sample hop); RTF at batch=1",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Silero-VAD f32, batch=4096 synthetic 10 s @16 kHz clips per GPU "
                                    "(STFT conv + conv1d stack + LSTM cell HIP, seeded synthetic weights)",
@@ -284,20 +450,32 @@ def main():
             "segments_found": n_seg,
             # achieved = the flops the kernel's algorithm needs (MFMA-issued: folded DFT, no padding taps) / its time;
             # the reference's dense arithmetic would count FLOP_ENCODE per frame ("dense_equivalent").
+            # Bytes follow SURVEY 8(d): algorithmic = 2048 B f32 PCM in + 4 B score out per window; `traffic` = the encoder
+            # launch's counted HBM bytes (it also writes the 2048 B/window gx intermediate the LSTM kernel re-reads).
             "roofline": {"bound": "mfma", "kernel": "silero_encode_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic["bytes"] if traffic else None, "traffic_unit": "B/launch",
-                         "traffic_source": traffic["source"] if traffic else None,
-                         "algorithmic_bytes_per_launch": B * T * (2048 + 2048),
+                         "traffic": tr_enc["bytes"] if tr_enc else None, "traffic_unit": "B/launch",
+                         "traffic_source": tr_enc["source"] if tr_enc else None,
+                         "algorithmic_bytes_per_launch": algo_launch,
+                         "traffic_ratio": (tr_enc["bytes"] / algo_launch) if tr_enc else None,
                          "flop_per_frame": FLOP_ENCODE_ISSUED, "frames_per_launch": B * T,
                          "dense_equivalent": {"flop_per_frame": FLOP_ENCODE,
                                               "achieved": achieved * FLOP_ENCODE / FLOP_ENCODE_ISSUED}},
             # the recurrent kernel is matrix-pipe work too (W_hh x h, 16 clips = one MFMA tile wide): its own fraction
             "roofline_recurrent": {"bound": "mfma", "kernel": "silero_lstm_kernel", "flop_per_frame": FLOP_RECUR,
                                    "achieved": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
-            "hbm": {"algorithmic_bytes_per_frame": 2048 + 4,
-                    "achieved_GBps_whole_step": B * T * 2052 / (elapsed / args.steps) / 1e9, "peak_GBps": 8000.0},
+                                   "unit": "TFLOP/s", "frac": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   "traffic": tr_rec["bytes"] if tr_rec else None},
+            # the north star's HBM view of the whole step: SURVEY 8(d) algorithmic bytes / step time against 8 TB/s, and what
+            # the step really moves (encoder + LSTM launches, PMC) over the algorithmic bytes
+            "hbm": {"algorithmic_bytes_per_frame": ALGO_BYTES_PER_WINDOW, "algorithmic_bytes_per_step": algo_launch,
+                    "achieved_GBps": algo_launch / step_s / 1e9, "peak_GBps": PEAK_HBM_GBPS,
+                    "frac": algo_launch / step_s / 1e9 / PEAK_HBM_GBPS,
+                    "traffic_bytes_per_step": step_traffic,
+                    "traffic_ratio": (step_traffic / algo_launch) if step_traffic else None,
+                    "traffic_GBps": (step_traffic / step_s / 1e9) if step_traffic else None},
+            "feed": feed,
+            "secondary": secondary,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -1,20 +1,161 @@
 #!/usr/bin/env python
-"""Secondary measurements (NOT the driver's bench contract -- that is bench.py): device time of the
-other BASELINE configs on one MI355X, inputs resident in HBM, seeded synthetic weights.
-    python bench_models.py [--reps 5] > profiles/rNN_models.json"""
+"""The other BASELINE configs (C3 FSMN, C4 MarbleNet, C5 FireRed + DFSMN near+far), measured in the same process as
+bench.py's headline and reported in its `secondary` object (bench.py imports this module; run it directly for the
+secondary numbers alone:  python bench_models.py [--reps 3] [--only fsmn,marblenet,firered,dfsmn]).
+
+Every workload: full BASELINE size, synthetic int16 burst clips generated on the GPU (resident in HBM before the timed
+region), seeded synthetic weights of the reference architectures, device ms = median of `reps` passes bracketed by HIP
+events on the launch stream; one extra traced pass (`vadx._lib.trace`) splits the time by C-ABI entry point; the
+dominant entry gets a `roofline` (algorithmic flops of that stage as the reference computes them / its device time /
+the f32-MFMA peak) and the whole pass gets `hbm` = SURVEY 8(d) algorithmic bytes / time / 8 TB/s.  `cpu_baseline` =
+the torch-CPU oracle driven like the reference drives ORT (batch 1, one call per window), bounded to a few seconds.
+"""
 from __future__ import annotations
 
-import argparse
+import glob
 import json
 import os
 import sys
+import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = the f32 vector rate
+PEAK_HBM_GBPS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak
+SR = 16000
 
 
-def timed(torch, fn, reps):
+# ------------------------------------------------------------------------------------------------ algorithmic flops
+def flop_frontend_frame(n_bins, taps, n_mels=80):
+    """One STFT frame as the reference computes it on non-zero window taps: cos + sin tables x taps MACs, the power
+    spectrum, a dense mel projection (the kernel's banded mel issues fewer; the reference's conv1d multiplies the zero
+    padding of the window too -- neither is counted)."""
+    return 2 * (2 * n_bins * taps) + 3 * n_bins + 2 * n_mels * n_bins
+
+
+def flop_fsmn_frame(d=None):
+    from vadx import weights
+    d = dict(weights.FSMN_DIMS if d is None else d)
+    D, A, L, P, K, A2, O, n = (d["input_dim"], d["input_affine_dim"], d["linear_dim"], d["proj_dim"], d["lorder"],
+                               d["output_affine_dim"], d["output_dim"], d["fsmn_layers"])
+    return 2 * (D * A + A * L + n * (L * P + P * K + P * L) + L * A2 + A2 * O)
+
+
+def flop_firered_frame(c=None):
+    from vadx import weights
+    c = dict(weights.FIRERED_CFG if c is None else c)
+    D, R, M, H, P = c["idim"], c["R"], c["M"], c["H"], c["P"]
+    mac = D * H + H * P + R * P * (c["N1"] + c["N2"]) + (R - 1) * (P * H + H * P) + P * H + (M - 1) * H * H + H * c["odim"]
+    return 2 * mac
+
+
+def flop_marblenet_out_frame():
+    """per 20 ms output frame (after the stride-2 first block): depthwise + pointwise + residual 1x1 + decoder"""
+    from vadx import weights
+    mac, cin = 0, 80
+    for filt, rep, k, _s, _d, residual, sep in weights.MARBLENET_BLOCKS:
+        block_cin = cin
+        for _ in range(rep):
+            mac += (cin * k if sep else 0) + cin * filt
+            cin = filt
+        if residual:
+            mac += block_cin * filt
+    return 2 * (mac + 2 * cin)
+
+
+def flop_dfsmn_window(T=101, TA=51, F=160, ch=20):
+    """One 16001-sample near+far window (Export_DFSMN_VAD.py:317-354), by stage."""
+    def lstm(i, h, bi=False, layers=1):
+        m, d = 0, i
+        for _ in range(layers):
+            m += 4 * h * (d + h) * (2 if bi else 1)
+            d = h * (2 if bi else 1)
+        return m
+    out = {}
+    out["lstm_f"] = 2 * T * (F * (lstm(4, ch, True) + 2 * ch * ch) + 10 * 81 * (lstm(2 * ch, ch, True) + 2 * ch * 2 * ch))
+    out["dft_f"] = 2 * T * 10 * ch * (2 * 81 * F + 162 * F)                              # forward (cos, sin) + pinv inverse
+    pw = F * ((4 + ch) * ch + 3 * ch * 2)                                                # in_conv, out_conv
+    for cin in (ch,) * 6 + (2 * ch,) * 4:
+        pw += F * (2 * cin * ch + 3 * ch * ch)                                           # gate, input, (3,1) conv
+    pw += F * (2 * ch * ch + ch * 2 * ch)                                                # the two time-LSTM output linears
+    out["pw_conv"] = 2 * T * pw
+    out["lstm_t"] = 2 * T * F * (lstm(ch, 2 * ch, False, 2) + lstm(2 * ch, ch))
+    out["istft"] = 2 * T * 320 * 319
+    out["frontend"] = 2 * (2 * T * 2 * F * 319) + 3 * TA * (flop_frontend_frame(513, 640))
+    from vadx import weights
+    m = weights.DFSMN_MASK
+    H, H2 = m["hidden"], m["fsmn_hidden"]
+    out["mask_net"] = 2 * TA * (240 * H + m["layers"] * (H * H2 + H2 * H + H * m["lorder"]) + H)
+    out["total"] = sum(out.values())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def synth_pcm16(torch, device, batch, samples, seed, loud=3000.0, quiet=30.0):
+    """int16 burst clips generated on the GPU (every clip unique): 0.5-2 s segments alternating N(0,loud) / N(0,quiet)
+    (SURVEY 8(d) recipe; the host-side twin is vadx.weights.burst_clips)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = torch.empty((batch, samples), dtype=torch.int16, device=device)
+    chunk = 512
+    nseg = int(samples / (0.5 * SR)) + 2
+    for b0 in range(0, batch, chunk):
+        nb = min(chunk, batch - b0)
+        dur = (torch.rand((nb, nseg), generator=g, device=device) * 1.5 + 0.5) * float(SR)
+        edges = torch.cumsum(dur, dim=1)
+        pos = torch.arange(samples, device=device, dtype=torch.float32).unsqueeze(0).expand(nb, -1).contiguous()
+        seg = torch.searchsorted(edges, pos)
+        first = torch.randint(0, 2, (nb, 1), generator=g, device=device)
+        isloud = ((seg + first) % 2) == 0
+        sigma = torch.where(isloud, torch.tensor(loud, device=device), torch.tensor(quiet, device=device))
+        x = torch.randn((nb, samples), generator=g, device=device) * sigma
+        out[b0:b0 + nb] = torch.clamp(torch.round(x), -32768, 32767).to(torch.int16)
+        del dur, edges, pos, seg, isloud, sigma, x
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def timed_cpu(fn, units_per_call, budget_s, threads=(1, 4, 16)):
+    """units/s of `fn` (one batch-1 call of the oracle) on the host: a short calibration picks the intra-op thread count,
+    then calls are repeated for ~budget_s (checked after every call)."""
+    import torch
+    ncpu = os.cpu_count() or 1
+    best_thr, best = 1, 0.0
+    with torch.no_grad():
+        for thr in threads:
+            if thr > ncpu:
+                continue
+            torch.set_num_threads(thr)
+            fn()
+            t0, n = time.perf_counter(), 0
+            while n < 1 or time.perf_counter() - t0 < 0.25:
+                fn()
+                n += 1
+            r = n / (time.perf_counter() - t0)
+            if r > best:
+                best_thr, best = thr, r
+        torch.set_num_threads(best_thr)
+        t0, n = time.perf_counter(), 0
+        while n < 1 or time.perf_counter() - t0 < budget_s:
+            fn()
+            n += 1
+        el = time.perf_counter() - t0
+    return n * units_per_call / el, best_thr, n, el
+
+
+def device_ms(torch, fn, reps):
     fn()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -26,61 +167,239 @@ def timed(torch, fn, reps):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
+def profiled_kernel_traffic(tag, kernel_substr):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary profiles/r*_{tag}/SUMMARY.txt
+    (separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH doubled per MI355X_MICROARCH.md 'HBM'; values are KiB).
+    Lines look like `<kernel> grid=<n> FETCH_SIZE <mean per dispatch> n=<k>`; the largest grid wins."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*{tag}*", "SUMMARY.txt"))):
+        fetch = write = None
+        grid = -1
+        for line in open(path):
+            if kernel_substr not in line or "grid=" not in line or "_SIZE" not in line:
+                continue
+            g = int(line.split("grid=")[1].split()[0])
+            name, val = line.split()[-3], float(line.split()[-2])
+            if name in ("FETCH_SIZE", "WRITE_SIZE") and g >= grid:
+                if g > grid:
+                    fetch = write = None
+                grid = g
+                if name == "FETCH_SIZE":
+                    fetch = val
+                else:
+                    write = val
+        if fetch is not None and write is not None:
+            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT), "grid_threads": grid}
+    return best
+
+
+def _roof(kernel, flop, ms, tag=None, kernel_substr=None, note=None):
+    ach = flop / (ms * 1e-3) / 1e12
+    tr = profiled_kernel_traffic(tag, kernel_substr) if tag else None
+    r = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+         "frac": ach / PEAK_F32_MFMA_TFLOPS, "flop_per_launch": flop, "ms": ms,
+         "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None}
+    if note:
+        r["note"] = note
+    return r
+
+
+def _hbm(bytes_algorithmic, ms):
+    g = bytes_algorithmic / (ms * 1e-3) / 1e9
+    return {"algorithmic_bytes": bytes_algorithmic, "achieved_GBps": g, "peak_GBps": PEAK_HBM_GBPS, "frac": g / PEAK_HBM_GBPS}
+
+
+def _trace(fn):
+    from vadx import _lib
+    import torch
+    torch.cuda.synchronize()
+    with _lib.trace() as tr:
+        fn()
+    return {k: round(v, 4) for k, v in sorted(tr.ms.items(), key=lambda kv: -kv[1])}, tr.calls
+
+
+# ------------------------------------------------------------------------------------------------ the workloads
+def fsmn_c3(torch, device, reps, cpu, clips=4096, log=lambda m: None):
+    from vadx import fsmn, weights
+    eng = fsmn.FsmnEngine(weights.fsmn_synthetic(1234), device=device)
+    lb, stride = eng.grid()
+    n = 160000
+    W = -(-(n - eng.L) // stride) + 1                       # Inference_FSMN_VAD_ONNX.py:88-92 window grid: 15
+    padded = (W - 1) * stride + eng.L
+    audio = synth_pcm16(torch, device, clips, padded, seed=1303)
+    log(f"fsmn: {clips} x {padded} int16 resident, {W} windows/clip")
+    run = lambda: eng.flags(audio, W)                       # noqa: E731
+    ms = device_ms(torch, run, reps)
+    split, _ = _trace(run)
+    frames10 = clips * W * eng.T
+    net_ms = split.get("vadx_fsmn_clips", ms)
+    out = {"workload": f"FSMN-VAD f32, batch={clips} synthetic 10 s clips -> silence flags (window grid {W} x 1 s at stride "
+                       f"{stride}, noise-floor feedback and look-ahead vote on device)",
+           "clips": clips, "samples_per_clip": n, "windows_per_clip": W, "ms": ms,
+           "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split,
+           "roofline": _roof("fsmn_clips_kernel", frames10 * flop_fsmn_frame(), net_ms, "fsmn", "fsmn_clips_kernel"),
+           "roofline_frontend": _roof("frontend_logmel_kernel", frames10 * flop_frontend_frame(257, 400),
+                                      split.get("vadx_frontend_logmel", ms), "fsmn", "frontend_logmel_kernel"),
+           "hbm": _hbm(clips * (padded * 2 + (W * (eng.T - lb) + lb)), ms), "cpu_baseline": None}
+    del audio
+    if cpu:
+        from oracle import fsmn as ofs
+        w = {k: torch.from_numpy(v) for k, v in weights.fsmn_synthetic(1234).items()}
+        fe = ofs.Frontend(16000)
+        a = torch.from_numpy(weights.burst_clips(1, 16000, seed=3)).reshape(1, 1, -1)
+        caches = [torch.zeros(1, 128, 19, 1) for _ in range(4)]
+        thr, nz = torch.tensor([1.0]), torch.tensor([4.0])
+        rate, thr_n, calls, el = timed_cpu(lambda: ofs.forward(fe, w, a, caches, thr, nz), stride / 512.0, cpu)
+        out["cpu_baseline"] = {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(),
+                               "sample": f"{calls} one-second windows, batch 1, one oracle call per window at stride {stride} "
+                                         f"(torch-CPU stand-in for ORT-CPU), {el:.1f} s"}
+    return out
+
+
+def marblenet_c4(torch, device, reps, cpu, clips=8192, log=lambda m: None, tag="marblenet"):
+    from vadx import marblenet, weights
+    eng = marblenet.MarbleNetEngine(weights.marblenet_synthetic(1234), device=device)
+    n = 89431
+    audio = synth_pcm16(torch, device, clips, n, seed=1404)
+    log(f"marblenet: {clips} x {n} int16 resident")
+    run = lambda: eng.run(audio)                            # noqa: E731
+    ms = device_ms(torch, run, reps)
+    split, calls = _trace(run)
+    T = n // 160 + 1
+    Tout = (T + 2 * 5 - 10 - 1) // 2 + 1
+    fe_ms = split.get("vadx_frontend_logmel", ms)
+    net_ms = sum(v for k, v in split.items() if k in ("vadx_sepconv_block", "vadx_marblenet_net", "vadx_frame_classifier"))
+    out = {"workload": f"NVIDIA Frame-VAD MarbleNet v2.0 f32, batch={clips} clips of {n} samples (one dynamic-axis window each) "
+                       "-> per-20-ms speech probabilities",
+           "clips": clips, "samples_per_clip": n, "ms": ms, "frames_per_s": clips * n / 512 / (ms * 1e-3),
+           "kernel_ms": split, "kernel_calls": calls,
+           "roofline": _roof("frontend_logmel_kernel", clips * T * flop_frontend_frame(257, 400), fe_ms, tag, "frontend_logmel_kernel"),
+           "roofline_net": _roof("marblenet encoder+decoder launches", clips * Tout * flop_marblenet_out_frame(), net_ms,
+                                 note="sum of the encoder / classifier launches"),
+           "hbm": _hbm(clips * (n * 2 + 2 * Tout * 4), ms), "cpu_baseline": None}
+    del audio
+    if cpu:
+        from oracle import marblenet as omb
+        w = {k: torch.from_numpy(v) for k, v in weights.marblenet_synthetic(1234).items()}
+        fe = omb.Frontend()
+        a = torch.from_numpy(weights.burst_clips(1, n, seed=4)).reshape(1, 1, -1)
+        rate, thr_n, ncall, el = timed_cpu(lambda: omb.forward(fe, w, a), n / 512.0, cpu)
+        out["cpu_baseline"] = {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(),
+                               "sample": f"{ncall} clips of {n} samples, batch 1, one oracle call per clip (torch-CPU stand-in "
+                                         f"for ORT-CPU), {el:.1f} s"}
+    return out
+
+
+def firered_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None):
+    from vadx import firered, weights
+    eng = firered.FireRedEngine(weights.firered_synthetic(1234), device=device)
+    n, W = 160000, 10
+    audio = synth_pcm16(torch, device, clips, n, seed=1505)
+    log(f"firered: {clips} x {n} int16 resident")
+    run = lambda: eng.run(audio, W)                         # noqa: E731
+    ms = device_ms(torch, run, reps)
+    split, _ = _trace(run)
+    frames10 = clips * W * 98
+    out = {"workload": f"FireRedVAD f32, batch={clips} synthetic 10 s clips ({W} x 1 s windows, 98 frames each) -> per-10-ms "
+                       "speech probabilities",
+           "clips": clips, "samples_per_clip": n, "ms": ms, "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split,
+           "roofline": _roof("firered_kernel", frames10 * flop_firered_frame(), split.get("vadx_firered_run", ms), "firered",
+                             "firered_kernel"),
+           "roofline_frontend": _roof("frontend_logmel_kernel", frames10 * flop_frontend_frame(201, 400),
+                                      split.get("vadx_frontend_logmel", ms), "firered", "frontend_logmel_kernel"),
+           "hbm": _hbm(clips * (n * 2 + W * 98 * 4), ms), "cpu_baseline": None}
+    del audio
+    if cpu:
+        from oracle import firered as ofr
+        w = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in weights.firered_synthetic(1234).items()}
+        fe = ofr.Frontend()
+        a = torch.from_numpy(weights.burst_clips(1, 16000, seed=5)).reshape(1, 1, -1)
+        rate, thr_n, ncall, el = timed_cpu(lambda: ofr.forward(fe, w, a), 16000 / 512.0, cpu)
+        out["cpu_baseline"] = {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(),
+                               "sample": f"{ncall} one-second windows, batch 1, one oracle call per window (torch-CPU stand-in "
+                                         f"for ORT-CPU), {el:.1f} s"}
+    return out
+
+
+def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch=960):
+    from vadx import dfsmn, weights
+    eng = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234), device=device, sub_batch=sub_batch)
+    lb, stride = eng.grid()
+    n = 160000
+    W = -(-(n - eng.L) // stride) + 1                       # 15 windows of 16001 samples at stride 10881
+    padded = (W - 1) * stride + eng.L
+    near = synth_pcm16(torch, device, clips, padded, seed=1606)
+    far = synth_pcm16(torch, device, clips, padded, seed=1607)
+    log(f"dfsmn: 2 x {clips} x {padded} int16 resident, {W} windows/clip")
+    run = lambda: eng.run(near, far, W, stride)             # noqa: E731
+    ms = device_ms(torch, run, max(1, reps - 1))
+    split, calls = _trace(run)
+    fl = flop_dfsmn_window()
+    nwin = clips * W
+    groups = {"lstm_f": split.get("vadx_dfsmn_lstm_f", 0.0), "dft_f": split.get("vadx_dfsmn_dft_f", 0.0),
+              "pw_conv": split.get("vadx_dfsmn_pw_conv", 0.0), "lstm_t": split.get("vadx_dfsmn_lstm_t", 0.0)}
+    dom = max(groups, key=groups.get)
+    out = {"workload": f"DFSMN near+far f32 (SDAEC ICCRN echo canceller + mask-net VAD), batch={clips} clip pairs of 10 s = "
+                       f"{nwin} windows of 16001 samples, measured at full size in sub-batches of {sub_batch} windows",
+           "clip_pairs": clips, "samples_per_clip": n, "windows": nwin, "ms": ms,
+           "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split, "kernel_calls": calls,
+           "flop_per_window": fl,
+           "roofline": _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fl[dom], groups[dom], "dfsmn", dom,
+                             note="all launches of the entry point that takes the most time"),
+           "roofline_whole_pass": _roof("all DFSMN launches", nwin * fl["total"], ms),
+           "hbm": _hbm(clips * (2 * padded * 2 + W * eng.T_A * 4), ms), "cpu_baseline": None}
+    del near, far
+    if cpu:
+        from oracle import dfsmn as od
+        w = {k: torch.from_numpy(v) for k, v in weights.dfsmn_synthetic(1234).items()}
+        w["mask.shift"] = w["mask.shift"] + torch.log(torch.tensor(32768.0 ** 2))
+        fe = od.Frontend()
+        a = torch.from_numpy(weights.burst_clips(1, 16001, seed=6)).reshape(1, 1, -1)
+        b = torch.from_numpy(weights.burst_clips(1, 16001, seed=7)).reshape(1, 1, -1)
+        nf = weights.DFSMN_MASK["layers"]
+        rate, thr_n, ncall, el = timed_cpu(lambda: od.forward(fe, w, a, b, nf), stride / 512.0, cpu, threads=(4,))
+        out["cpu_baseline"] = {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(),
+                               "sample": f"{ncall} windows of 16001 samples, batch 1, one oracle call per window at stride {stride} "
+                                         f"(torch-CPU stand-in for ORT-CPU; the reference pins 4 ORT threads for this model), {el:.1f} s"}
+    return out
+
+
+WORKLOADS = {"fsmn_c3": fsmn_c3, "marblenet_c4": marblenet_c4, "firered_c5": firered_c5, "dfsmn_c5": dfsmn_c5}
+
+
+def run_all(torch, device, reps=3, cpu_budget_s=3.0, only=None, log=lambda m: None):
+    """-> {'fsmn_c3': {...}, 'marblenet_c4': {...}, 'marblenet_c4_one_gpu_share': {...}, 'firered_c5': {...},
+    'dfsmn_c5': {...}}; a workload that fails is reported as {'error': ...} instead of taking the headline line down."""
+    out = {}
+    for name, fn in WORKLOADS.items():
+        if only and name.split("_")[0] not in only:
+            continue
+        try:
+            out[name] = fn(torch, device, reps, cpu_budget_s, log=log)
+            if name == "marblenet_c4":
+                share = marblenet_c4(torch, device, reps, 0, clips=1024, log=log)
+                share["workload"] += " -- one GPU's share of the 8-GPU config"
+                out["marblenet_c4_one_gpu_share"] = share
+        except Exception as e:                               # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+        log(f"{name} done")
+    return out
+
+
 def main():
+    import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     import torch
     import vadx  # noqa: F401
-    from vadx import firered, fsmn, marblenet, weights
-    from vadx import timestamps as ts
-    out = {}
-    # ---- config 3: FSMN, 4096 x 10 s
-    eng = fsmn.FsmnEngine(weights.fsmn_synthetic(1234))
-    lb, stride = eng.grid()
-    base = weights.burst_clips(64, 160000, seed=123)
-    noise = np.random.default_rng(1).standard_normal((64, 20000))
-    rows = np.stack([fsmn.pad_to_window_grid(ts.normalize_to_int16(base[b].astype(np.float32)), 16000, stride, noise[b]) for b in range(64)])
-    W = (rows.shape[1] - 16000) // stride + 1
-    big = torch.from_numpy(rows).cuda().repeat(64, 1)
-    ms_feat = timed(torch, lambda: eng.features(big, W, stride), args.reps)
-    ms_all = timed(torch, lambda: eng.flags(big, W), args.reps)
-    out["fsmn_config3"] = {"clips": 4096, "seconds_per_clip": 10, "windows_per_clip": W, "ms_frontend_energy": ms_feat,
-                           "ms_total": ms_all, "hop512_frames_per_s": 4096 * 313 / (ms_all * 1e-3),
-                           "net_frames_10ms": 4096 * W * 101, "net_TFLOPs": 4096 * W * 101 * 0.854e6 / ((ms_all - ms_feat) * 1e-3) / 1e12}
-    del big
-    # ---- config 4 (one GPU's view): MarbleNet, 8192 x 89,431 samples
-    mb = marblenet.MarbleNetEngine(weights.marblenet_synthetic(1234))
-    base = weights.burst_clips(64, 89431, seed=55)
-    big = torch.from_numpy(base).cuda().repeat(128, 1)
-    fe = mb.frontend(89431)
-    ms_fe = timed(torch, lambda: fe.logmel(big, 1, 89431), args.reps)
-    ms_all = timed(torch, lambda: mb.run(big), args.reps)
-    out["marblenet_config4_1gpu"] = {"clips": 8192, "samples_per_clip": 89431, "ms_frontend": ms_fe, "ms_total": ms_all,
-                                     "hop512_frames_per_s": 8192 * 89431 / 512 / (ms_all * 1e-3),
-                                     "frontend_TFLOPs": 8192 * 559 * (2 * 2 * 257 * 400) / (ms_fe * 1e-3) / 1e12}
-    del big
-    # ---- config 5 (FireRed half): 2048 x 10 s
-    fr = firered.FireRedEngine(weights.firered_synthetic(1234))
-    base = weights.burst_clips(32, 160000, seed=321)
-    big = torch.from_numpy(base).cuda().repeat(64, 1)
-    ms_fe = timed(torch, lambda: fr.fe.logmel(big, 10, 16000), args.reps)
-    ms_all = timed(torch, lambda: fr.run(big, 10), args.reps)
-    out["firered_config5"] = {"clips": 2048, "seconds_per_clip": 10, "ms_frontend": ms_fe, "ms_total": ms_all,
-                              "hop512_frames_per_s": 2048 * 313 / (ms_all * 1e-3),
-                              "net_TFLOPs": 2048 * 980 * 1.09e6 / ((ms_all - ms_fe) * 1e-3) / 1e12}
-    # ---- config 5 (DFSMN near+far half): measured on 128 clip pairs x 10 s (1920 windows), scaled to 2048
-    from vadx import dfsmn
-    de = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234), sub_batch=960)
-    lb, stride = de.grid()
-    W = 15
-    n = (W - 1) * stride + de.L
-    near = torch.from_numpy(weights.burst_clips(16, n, seed=11)).cuda().repeat(8, 1)
-    far = torch.from_numpy(weights.burst_clips(16, n, seed=12)).cuda().repeat(8, 1)
-    ms = timed(torch, lambda: de.run(near, far, W, stride), max(2, args.reps // 2))
-    out["dfsmn_config5"] = {"clip_pairs_measured": 128, "windows": 128 * W, "ms_measured": ms,
-                            "ms_scaled_to_2048_pairs": ms * 16, "hop512_frames_per_s": 128 * 313 / (ms * 1e-3),
-                            "approx_TFLOPs": 128 * W * 4.8e9 / (ms * 1e-3) / 1e12}
+    t0 = time.perf_counter()
+    out = run_all(torch, torch.device("cuda", 0), args.reps, 0 if args.no_cpu_baseline else 3.0,
+                  [s for s in args.only.split(",") if s] or None,
+                  log=lambda m: print(f"[bench_models +{time.perf_counter() - t0:6.1f}s] {m}", file=sys.stderr, flush=True))
     print(json.dumps(out, indent=1))
 
 

@@ -78,6 +78,18 @@ int vadx_silero_clips(const float *packed, const float *audio, int batch, int64_
  * kernel) and the recurrent kernel separately.  `steps` = ceil(n_samples/512). */
 int vadx_silero_encode(const float *packed, const float *audio, int batch, int64_t n_samples,
                        int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream);
+/* The same encoder fed int16 PCM: sample = (float)pcm * scale in one f32 rounding -- with scale = 0.000030517578f exactly the
+ * float32 array the reference script builds on the host (Silero/Inference_Silero_VAD_ONNX.py:83), so results are
+ * bit-identical to vadx_silero_encode on that array while the upload and the HBM read are half the bytes. */
+int vadx_silero_encode_pcm16(const float *packed, const int16_t *audio, float scale, int batch, int64_t n_samples,
+                             int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream);
+/* A slice of the batch: clips [first_clip, first_clip + batch) of a workspace laid out for total_batch clips (first_clip a
+ * multiple of 16).  Lets the encoder of one uploaded chunk run while the next chunk is still crossing PCIe (bench.py's
+ * feed-inclusive mode, SURVEY 8e "pinned-host staging double-buffered per GPU"); one vadx_silero_recur over total_batch
+ * follows.  Results are identical to a single vadx_silero_encode_pcm16 over the whole batch. */
+int vadx_silero_encode_pcm16_part(const float *packed, const int16_t *audio, float scale, int batch, int64_t n_samples,
+                                  int64_t row_stride, int first_clip, int total_batch, void *workspace,
+                                  size_t workspace_bytes, void *stream);
 int vadx_silero_recur(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
                       int steps, const float *state0, float *probs, float *state_n, void *stream);
 
@@ -380,14 +392,10 @@ int vadx_ingest_pcm16(const int16_t *src, int64_t src_stride, int channels, int6
  * [rows/16 tiles][cols/16 blocks][64 lanes][4]: the float4 of (tile, block S, lane 16q+i) holds
  * W[16*tile + i][16*S + 4*q + 0..3], so one wave-wide load is one contiguous 1 KB run.  The *_pack_host
  * functions produce it themselves; entry points that take bare weight pointers (vadx_sepconv_block's
- * pw_w / res_w, vadx_dfsmn_mask_weights' linear1_w / fsmn_linear_w / fsmn_project_w, vadx_test_gemm's w)
+ * pw_w / res_w, vadx_dfsmn_mask_weights' linear1_w / fsmn_linear_w / fsmn_project_w)
  * expect buffers converted with this helper.  dst holds vadx_frag_major_floats(rows, cols) floats. */
 size_t vadx_frag_major_floats(int rows, int cols);
 int vadx_frag_major_host(const float *src, int rows, int cols, float *dst);
-
-/* C[M][N] = A[M][K] * W[N][K]^T through the same LDS/MFMA tile helper the nets use.
- * M multiple of 16 (<=64), N multiple of 16, K multiple of 16; w fragment-major. */
-int vadx_test_gemm(const float *a, const float *w, float *c, int m, int n, int k, int swap, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,5 @@
-"""bench.py's output contract (the driver parses ONE JSON line): keys, units and internal consistency."""
+"""bench.py's output contract (the driver parses ONE JSON line): keys, units and internal consistency; the N-rank launch
+path (self-launch before any GPU call, barrier, max over ranks, rank 0 prints) in a CPU dry run."""
 import json
 import os
 import subprocess
@@ -11,22 +12,63 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
 
 
-def test_flop_accounting_and_committed_profile():
+def test_flop_and_byte_accounting_and_committed_profile():
     sys.path.insert(0, ROOT)
     import bench
     # issued MFMA flops per window: 5504 v_mfma_f32_16x16x4 per 16-window tile, 2048 flop each
     assert bench.FLOP_ENCODE_ISSUED == 5504 * 2048 // 16 == 704512
     assert bench.FLOP_ENCODE == 1186816 and bench.FLOP_RECUR == 131072
+    # 2048 B of float32 PCM in + one 4-byte score out per 512-sample window; the gx intermediate is NOT algorithmic
+    assert bench.ALGO_BYTES_PER_WINDOW == 2052
     tr = bench.profiled_traffic()                      # newest profiles/r*/SUMMARY.txt, FETCH doubled per the gfx950 note
     assert tr is not None and tr["source"].startswith("profiles/r")
-    algorithmic = bench.CLIPS_PER_GPU * bench.STEPS_PER_CLIP * 4096
-    assert 0.95 * algorithmic < tr["bytes"] < 1.10 * algorithmic      # no wasted re-reads
+    windows = bench.CLIPS_PER_GPU * bench.STEPS_PER_CLIP
+    # the encoder launch moves the PCM in and the gx intermediate out: ~2x the algorithmic bytes, and nothing beyond that
+    assert 0.95 * windows * 4096 < tr["bytes"] < 1.10 * windows * 4096
+    rec = bench.profiled_traffic("silero_lstm_kernel")
+    assert rec is not None and 0.95 * windows * 2048 < rec["bytes"] < 1.10 * windows * 2052
+    ratio = (tr["bytes"] + rec["bytes"]) / (windows * bench.ALGO_BYTES_PER_WINDOW)
+    assert 2.8 < ratio < 3.3                           # the gx round trip: design traffic, reported as hbm.traffic_ratio
+
+
+def test_secondary_flop_formulas():
+    sys.path.insert(0, ROOT)
+    import vadx  # noqa: F401
+    import bench_models as bm
+    assert bm.flop_fsmn_frame() == 2 * 426960                        # 400-140-250-(128 x4, 20-tap FIR)-140-248
+    assert bm.flop_marblenet_out_frame() == 2 * 89456                # published 3x2x64 layout, per 20 ms output frame
+    assert bm.flop_firered_frame() == 2 * 585984                     # placeholder dims of SURVEY appendix B
+    d = bm.flop_dfsmn_window()
+    assert d["total"] == sum(v for k, v in d.items() if k != "total")
+    assert 5.5e9 < d["total"] < 6.5e9 and d["lstm_f"] > d["lstm_t"] > d["istft"]
+
+
+def test_self_launch_two_ranks_dry_run():
+    """`bench.py --gpus 2` with no launcher starts two ranks itself (torch.distributed.run on 127.0.0.1) and rank 0 prints
+    one line with n_gpus == 2; --dry-run swaps RCCL + kernels for gloo + sleep so this runs on a CPU-only box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1",
+                        "--clips", "10"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] is None and d["data"].startswith("dry-run")
+    assert d["config"]["shards"] == [[0, 0, 10], [1, 10, 20]]       # contiguous clip shards in rank order
+    assert d["ms_per_step"] >= 5.0
+
+
+def test_gpus_flag_must_match_world_size():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
 
 
 @pytest.mark.gpu
 def test_bench_prints_one_contract_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--clips", "64", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -38,3 +80,22 @@ def test_bench_prints_one_contract_line():
     ro = d["roofline"]
     assert ro["bound"] == "mfma" and ro["unit"] == "TFLOP/s" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
     assert 0 < ro["frac"] < 1 and "workload" in d["config"]
+    assert ro["algorithmic_bytes_per_launch"] == 64 * 313 * 2052
+    assert d["hbm"]["algorithmic_bytes_per_frame"] == 2052 and 0 < d["hbm"]["frac"] < 1
+    # the PCIe-inclusive mode ran, and feeding int16 through the in-kernel scaling gave the very same scores
+    assert d["feed"]["scores_bit_identical_to_resident_f32_path"] is True and d["feed"]["value"] < d["value"] * 1.05
+
+
+@pytest.mark.gpu
+def test_secondary_workloads_small():
+    """The bench_models workloads at toy sizes: every config produces a roofline / hbm entry and a per-entry split."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import vadx  # noqa: F401
+    import bench_models as bm
+    dev = torch.device("cuda", 0)
+    for fn, kw in ((bm.fsmn_c3, dict(clips=32)), (bm.marblenet_c4, dict(clips=32)), (bm.firered_c5, dict(clips=32)),
+                   (bm.dfsmn_c5, dict(clips=4, sub_batch=60))):
+        out = fn(torch, dev, 1, 0, **kw)
+        assert out["ms"] > 0 and out["frames_per_s"] > 0 and 0 < out["roofline"]["frac"] < 1, out
+        assert 0 < out["hbm"]["frac"] < 1 and sum(out["kernel_ms"].values()) <= out["ms"] * 1.5

@@ -40,7 +40,12 @@ def test_mfma_tile_helper(m, n, k, swap):
     w = rng.standard_normal((n, k)).astype(np.float32)
     da, dw = T(a).cuda(), T(_lib.frag_major(w)).cuda()        # weights in the kernels' fragment-major layout
     dc = torch.zeros((m, n), dtype=torch.float32, device="cuda")
-    _lib.check(_lib.lib().vadx_test_gemm(da.data_ptr(), dw.data_ptr(), dc.data_ptr(), m, n, k, swap, _lib.stream_ptr()))
+    import ctypes as C
+    from vadx import build as vbuild
+    hooks = C.CDLL(vbuild.build_test_hooks(verbose=False))         # tests/hip/test_gemm.hip: test-only, not in the product ABI
+    hooks.vadx_test_gemm.restype = C.c_int
+    hooks.vadx_test_gemm.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+    assert hooks.vadx_test_gemm(da.data_ptr(), dw.data_ptr(), dc.data_ptr(), m, n, k, swap, _lib.stream_ptr()) == 0
     torch.cuda.synchronize()
     ref = a.astype(np.float64) @ w.astype(np.float64).T
     np.testing.assert_allclose(dc.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.sqrt(k))
@@ -199,15 +204,16 @@ def test_ragged_lengths_and_tail_padding(oracle_w):
 
 # ------------------------------------------------------------------ full-size property checks (BASELINE config 2 shape)
 def test_full_size_batch_invariance():
-    """B=1024 x 10 s: every clip's scores are independent of its batch neighbours and position
-    (bitwise), and agree with the oracle on a sample of clips."""
+    """BASELINE config 2 at full size, B=4096 x 10 s: every clip's scores are independent of its batch neighbours and
+    position (bitwise), and agree with the oracle on a sample of clips."""
     eng = silero.SileroEngine(weights.silero_synthetic(1234))
     base = weights.burst_clips(32, 160000, seed=99).astype(np.float32) * np.float32(0.000030517578)
-    big = torch.from_numpy(base).cuda().repeat(32, 1)           # [1024,160000], clip i == clip i % 32
+    big = torch.from_numpy(base).cuda().repeat(128, 1)          # [4096,160000], clip i == clip i % 32
     probs = eng.clips(big)
-    assert probs.shape == (1024, 313)
-    p = probs.view(32, 32, 313)
-    assert torch.equal(p[0], p[17]) and torch.equal(p[0], p[31])
+    assert probs.shape == (4096, 313)
+    p = probs.view(128, 32, 313)
+    assert torch.equal(p[0], p[17]) and torch.equal(p[0], p[31]) and torch.equal(p[0], p[127])
+    del big
     small = eng.clips(torch.from_numpy(base[5:8]).cuda())       # different tile composition
     assert torch.equal(small, probs[5:8])
     assert bool(torch.isfinite(probs).all()) and float(probs.min()) >= 0 and float(probs.max()) <= 1
@@ -266,3 +272,41 @@ def test_span_entries_reject_bad_spans(engine):
     p = torch.zeros((16, 4), dtype=torch.float32, device="cuda")
     assert L.vadx_silero_recur_span(engine.packed.data_ptr(), ws.data_ptr(), ws.numel(), 16, 4, None, p.data_ptr(), 3, None,
                                     _lib.stream_ptr()) != 0      # probs_stride < n_steps
+
+
+# ------------------------------------------------------------------ int16 PCM straight into the encoder
+@pytest.mark.parametrize("batch,n", [(5, 16000), (37, 20001), (16, 513), (3, 3)])
+def test_pcm16_encoder_is_bitwise_the_f32_path(engine, batch, n):
+    """vadx_silero_encode_pcm16 applies the reference's int16 * 0.000030517578 while staging: same bits as feeding the
+    float32 product the reference script builds on the host (Silero/Inference_Silero_VAD_ONNX.py:83)."""
+    pcm = weights.burst_clips(batch, n, seed=batch * 7 + n)
+    if n >= 8:
+        pcm[0, :4] = [-32768, 32767, -1, 1]
+    f32 = pcm.astype(np.float32) * np.float32(0.000030517578)
+    want = engine.clips(torch.from_numpy(f32).cuda())
+    got = engine.clips_pcm16(torch.from_numpy(pcm).cuda())
+    assert torch.equal(got, want)
+    ref = np.array(osil.speech_probs(T(f32[0]), osil.OnnxWrapperOracle({k: T(v) for k, v in weights.silero_synthetic(1234).items()})),
+                   dtype=np.float32)
+    np.testing.assert_allclose(got[0].cpu().numpy(), ref, rtol=0, atol=ATOL)
+
+
+def test_pcm16_part_encodes_fill_one_workspace(engine):
+    """Slices of the batch encoded separately (as bench.py's upload pipeline does) + one recurrent launch == one whole-batch
+    pass; slices must start on a 16-clip boundary and stay inside the workspace."""
+    B, n = 80, 12000
+    pcm = torch.from_numpy(weights.burst_clips(B, n, seed=17)).cuda()
+    want = engine.clips_pcm16(pcm)
+    L = _lib.lib()
+    steps = (n + 511) // 512
+    ws = engine._workspace(B, steps)
+    ws.zero_()
+    for b0, nb in ((48, 32), (0, 16), (16, 32)):
+        part = pcm[b0:b0 + nb].contiguous()
+        _lib.check(L.vadx_silero_encode_pcm16_part(engine.packed.data_ptr(), part.data_ptr(), engine.PCM16_SCALE, nb, n, n, b0, B,
+                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    got = engine.recur(B, steps, torch.empty((B, steps), dtype=torch.float32, device="cuda"))
+    assert torch.equal(got, want)
+    bad = lambda b0, nb: L.vadx_silero_encode_pcm16_part(engine.packed.data_ptr(), pcm.data_ptr(), engine.PCM16_SCALE, nb, n, n,   # noqa: E731
+                                                         b0, B, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    assert bad(8, 16) != 0 and bad(64, 32) != 0 and bad(-16, 16) != 0

@@ -103,6 +103,8 @@ SIGNATURES = {
     "vadx_silero_step": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _Z, _P]),
     "vadx_silero_clips": (_I, [_P, _P, _I, _L, _L, _P, _P, _P, _Z, _P]),
     "vadx_silero_encode": (_I, [_P, _P, _I, _L, _L, _P, _Z, _P]),
+    "vadx_silero_encode_pcm16": (_I, [_P, _P, C.c_float, _I, _L, _L, _P, _Z, _P]),
+    "vadx_silero_encode_pcm16_part": (_I, [_P, _P, C.c_float, _I, _L, _L, _I, _I, _P, _Z, _P]),
     "vadx_silero_recur": (_I, [_P, _P, _Z, _I, _I, _P, _P, _P, _P]),
     "vadx_silero_encode_span": (_I, [_P, _P, _I, _L, _L, _I, _I, _P, _Z, _P]),
     "vadx_silero_recur_span": (_I, [_P, _P, _Z, _I, _I, _P, _P, _L, _P, _P]),
@@ -144,14 +146,13 @@ SIGNATURES = {
     "vadx_frontend_logmel_ex": (_I, [C.POINTER(FrontendCfg), _P, _P, _P, _L, _L, _I, _I, _P, _P, _I, _I, _P, _P]),
     "vadx_frontend_stft_ft": (_I, [C.POINTER(FrontendCfg), _P, _P, _L, _L, _I, _I, _P, _P, _I, _I, _P]),
     "vadx_dfsmn_mask_net": (_I, [C.POINTER(DfsmnMaskWeights), _P, _I, _I, _P, _P]),
-    "vadx_test_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
 }
 
 _lib = None
+_trace = None          # list of (entry name, start event, stop event) while a `trace()` block is open
 
 
-def lib():
-    """Load libvadx.so (built in-tree by `python -m vadx.build` / __graft_entry__.build())."""
+def _load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -163,6 +164,56 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib
+
+
+class _TracingLib:
+    """Same attributes as the CDLL handle; every stream-ordered entry point is bracketed by HIP events on the
+    stream it is launched on (torch's current stream = the stream handed to the C ABI)."""
+
+    def __getattr__(self, name):
+        fn = getattr(_load(), name)
+        if name.endswith(("_host", "_floats", "_bytes", "_version", "_error", "_frames")):
+            return fn
+        import torch
+
+        def timed(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            if _trace is not None:
+                _trace.append((name, e0, e1))
+            return rc
+        return timed
+
+
+_tracing = _TracingLib()
+
+
+def lib():
+    """Load libvadx.so (built in-tree by `python -m vadx.build` / __graft_entry__.build())."""
+    return _tracing if _trace is not None else _load()
+
+
+class trace:
+    """`with _lib.trace() as tr: engine.run(...)` -> tr.ms = {entry point: total device ms}, tr.calls = {entry: n}
+    (HIP events around each C-ABI launch; bench.py's per-kernel roofline numbers come from here)."""
+
+    def __enter__(self):
+        global _trace
+        _trace = []
+        self.ms, self.calls = {}, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _trace
+        rec, _trace = _trace, None
+        import torch
+        torch.cuda.synchronize()
+        for name, e0, e1 in rec:
+            self.ms[name] = self.ms.get(name, 0.0) + e0.elapsed_time(e1)
+            self.calls[name] = self.calls.get(name, 0) + 1
+        return False
 
 
 def check(rc, exc=VadxError):

@@ -1,35 +1,84 @@
-"""Build libvadx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libvadx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+One object per source, compiled in parallel (objects are cached under csrc/.obj and rebuilt only when the source or a
+header is newer), then one link.  `build_test_hooks()` builds tests/hip/*.hip into tests/hip/libvadx_testhooks.so --
+test-only entry points that are deliberately NOT part of the product ABI."""
 from __future__ import annotations
 
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(HERE, "libvadx.so")
+TEST_HOOKS_SRC = os.path.join(ROOT, "tests", "hip")
+TEST_HOOKS_LIB = os.path.join(TEST_HOOKS_SRC, "libvadx_testhooks.so")
 SOURCES = ["capi.hip", "silero.hip", "frontend.hip", "fsmn.hip", "firered.hip", "marblenet.hip", "dfsmn.hip", "ingest.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "vadx.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "vadx.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + _headers())
+
+
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _compile(src, obj, verbose):
+    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return obj
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append((src, obj))
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(lambda j: _compile(j[0], j[1], verbose), jobs))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + \
+          [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 
 
+def build_test_hooks(force=False, verbose=True):
+    srcs = sorted(os.path.join(TEST_HOOKS_SRC, f) for f in os.listdir(TEST_HOOKS_SRC) if f.endswith(".hip"))
+    if not force and not _stale(TEST_HOOKS_LIB, srcs + _headers()):
+        return TEST_HOOKS_LIB
+    cmd = [_hipcc()] + FLAGS + ["-shared"] + srcs + ["-o", TEST_HOOKS_LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TEST_HOOKS_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_test_hooks(force="--force" in sys.argv)

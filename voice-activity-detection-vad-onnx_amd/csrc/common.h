@@ -1,6 +1,7 @@
 // common.h -- shared device helpers for libvadx (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -28,6 +29,21 @@ void set_error(const char *fmt, ...);
             vadx::set_error(__VA_ARGS__);  \
             return VADX_EINVAL;            \
         }                                  \
+    } while (0)
+
+// Raise a kernel's dynamic-LDS limit once PER DEVICE (the attribute is per device; engines accept device="cuda:N", so a
+// process-wide flag would leave the kernel at the 64 KB default on the second GPU) and thread-safely.
+#define VADX_DYN_LDS(kernel_expr, bytes)                                                                              \
+    do {                                                                                                              \
+        static std::atomic<unsigned long long> done_{0};                                                              \
+        int dev_ = 0;                                                                                                 \
+        VADX_HIP_TRY(hipGetDevice(&dev_));                                                                            \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                          \
+        if (!(done_.load(std::memory_order_acquire) & bit_)) {                                                        \
+            VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel_expr),                             \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));              \
+            done_.fetch_or(bit_, std::memory_order_release);                                                          \
+        }                                                                                                             \
     } while (0)
 
 // v_mfma_f32_16x16x4_f32: exact f32 FMA chain (A: lane l holds A[l&15][l>>4], B: B[l>>4][l&15],

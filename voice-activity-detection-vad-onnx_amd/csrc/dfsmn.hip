@@ -1230,12 +1230,7 @@ static int launch_pw(PwArgs p, int tiles, void *stream) {
     p.nchunk = (p.F + fc - 1) / fc;
     const size_t lds = (size_t)lds_floats(fc) * sizeof(float);
     VADX_REQUIRE(!(p.part0 || p.part1) || lds_floats(fc) >= 144, "vadx_dfsmn_pw_conv: shape too small for fused statistics");
-    static bool done = false;
-    if (!done) {
-        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_conv_kernel<MT, KS, KF, MODE>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        done = true;
-    }
+    VADX_DYN_LDS((pw_conv_kernel<MT, KS, KF, MODE>), 64 * 1024);
     const unsigned split = tiles < 4096 ? 2 : 1;
     hipLaunchKernelGGL((pw_conv_kernel<MT, KS, KF, MODE>), dim3((unsigned)tiles, split), dim3(256), lds,
                        static_cast<hipStream_t>(stream), p);
@@ -1323,12 +1318,7 @@ extern "C" int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_f
     const unsigned grid = (unsigned)(chunks * (F / 16));
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto lds_bytes = [](int in, int outc, int hid, int ts) { return (size_t)(2 * in * (ts * 16 + 16) + 2 * outc * (ts * 16 + 16) + 2 * hid * 16) * sizeof(float); };
-    static bool done = false;
-    if (!done) {
-        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_t_kernel<40, 20, 1, 3, 1, 4>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        done = true;
-    }
+    VADX_DYN_LDS((lstm_t_kernel<40, 20, 1, 3, 1, 4>), 64 * 1024);
     if (which == 0) {            // bottleneck ch_lstm: in 20, hidden 40, 2 layers, Linear 40->20, multiplied with `mul`
         VADX_REQUIRE(in->c == 20 && mul && mul->ptr, "vadx_dfsmn_lstm_t(0): in must have 20 channels and mul is required");
         p.out_ch = 20;
@@ -1376,12 +1366,7 @@ extern "C" int vadx_dfsmn_mask_net(const vadx_dfsmn_mask_weights *w, const float
     p.vad = vad; p.T = frames; p.H = w->hidden; p.Hp = (w->hidden + 15) & ~15; p.H2p = (w->fsmn_hidden + 15) & ~15;
     p.layers = w->layers; p.lorder = w->lorder;
     for (int l = 0; l < w->layers; ++l) { p.wl[l] = w->fsmn_linear_w[l]; p.bl[l] = w->fsmn_linear_b[l]; p.wp[l] = w->fsmn_project_w[l]; p.wc[l] = w->fsmn_conv_w[l]; }
-    static bool done = false;
-    if (!done) {
-        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mask_net_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         MK_LDS_FLOATS * sizeof(float)));
-        done = true;
-    }
+    VADX_DYN_LDS(mask_net_kernel, MK_LDS_FLOATS * sizeof(float));
     hipLaunchKernelGGL(mask_net_kernel, dim3(chunks), dim3(512), MK_LDS_FLOATS * sizeof(float), static_cast<hipStream_t>(stream), p);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;

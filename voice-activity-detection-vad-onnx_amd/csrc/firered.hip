@@ -570,12 +570,7 @@ extern "C" int vadx_firered_run(const vadx_firered_cfg *cfg, const float *packed
     VADX_REQUIRE(cfg && packed && logmel && probs, "vadx_firered_run: NULL argument");
     VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_firered_run: unsupported config");
     VADX_REQUIRE(windows > 0, "vadx_firered_run: windows must be positive");
-    static bool done = false;
-    if (!done) {
-        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(firered_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));
-        done = true;
-    }
+    VADX_DYN_LDS(firered_kernel, LDS_FLOATS * sizeof(float));
     hipLaunchKernelGGL(firered_kernel, dim3(windows), dim3(THREADS), LDS_FLOATS * sizeof(float),
                        static_cast<hipStream_t>(stream), d, packed, logmel, probs);
     VADX_HIP_TRY(hipGetLastError());
@@ -617,12 +612,7 @@ extern "C" int vadx_firered_stream_run(const vadx_firered_cfg *cfg, const float 
     VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_firered_stream_run: unsupported config");
     VADX_REQUIRE(cfg->N2 == 0, "vadx_firered_stream_run: the streaming model has no look-ahead filter (N2 must be 0)");
     VADX_REQUIRE(streams > 0 && caches_in != caches_out, "vadx_firered_stream_run: streams must be positive, caches must not alias");
-    static bool done = false;
-    if (!done) {
-        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(firered_stream_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));
-        done = true;
-    }
+    VADX_DYN_LDS(firered_stream_kernel, LDS_FLOATS * sizeof(float));
     hipLaunchKernelGGL(firered_stream_kernel, dim3(streams), dim3(THREADS), LDS_FLOATS * sizeof(float),
                        static_cast<hipStream_t>(stream), d, packed, logmel, caches_in, caches_out, streams, probs);
     VADX_HIP_TRY(hipGetLastError());

@@ -415,14 +415,8 @@ extern "C" int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_w
 }
 
 static int set_lds_attr() {
-    static bool done = false;
-    if (!done) {
-        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fsmn_run_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));
-        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fsmn_clips_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * sizeof(float)));
-        done = true;
-    }
+    VADX_DYN_LDS(fsmn_run_kernel, LDS_FLOATS * sizeof(float));
+    VADX_DYN_LDS(fsmn_clips_kernel, LDS_FLOATS * sizeof(float));
     return VADX_OK;
 }
 

@@ -215,12 +215,7 @@ extern "C" int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w
     VADX_REQUIRE((long long)batch * tiles < (1LL << 31), "vadx_sepconv_block: too many tiles");
 #define SEPCONV_LAUNCH(KT, DT, ST)                                                                                              \
     do {                                                                                                                        \
-        static bool done_ = false;                                                                                              \
-        if (!done_) {                                                                                                           \
-            VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sepconv_block_kernel<KT, DT, ST>),                  \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                          \
-            done_ = true;                                                                                                       \
-        }                                                                                                                       \
+        VADX_DYN_LDS((sepconv_block_kernel<KT, DT, ST>), 128 * 1024);                                                           \
         hipLaunchKernelGGL((sepconv_block_kernel<KT, DT, ST>), dim3((unsigned)(batch * tiles)), dim3(THREADS),                  \
                            lds_bytes, static_cast<hipStream_t>(stream), c, dw_w, pw_w, pw_b, res_w, res_b, x,                   \
                            (long long)xs_b, (long long)xs_c, (long long)xs_t, t_in, xres, y, t_out, tiles);                      \

@@ -210,9 +210,29 @@ __device__ __forceinline__ f32x4 gemm_chain(const float *act, int lda, const flo
     return acc0 + acc1;
 }
 
+// Sample fetch of phase 0: the reference feeds Silero float32 = int16 * 0.000030517578 (Silero/Inference_Silero_VAD_ONNX.py:83);
+// the PCM16 instantiation reads the int16 samples themselves (half the HBM read, no f32 copy of the batch) and applies
+// that very multiplication -- one f32 rounding, bit-identical to the host-side product.
+template <typename SampleT> struct SampleIO;
+template <> struct SampleIO<float> {
+    static constexpr int VEC_ALIGN = 16;
+    static __device__ __forceinline__ f32x4 load4(const float *p, float) { return *reinterpret_cast<const f32x4 *>(p); }
+    static __device__ __forceinline__ float load1(const float *p, float) { return *p; }
+};
+template <> struct SampleIO<int16_t> {
+    static constexpr int VEC_ALIGN = 8;
+    static __device__ __forceinline__ f32x4 load4(const int16_t *p, float scale) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const s16x4 v = *reinterpret_cast<const s16x4 *>(p);
+        return f32x4{(float)v[0] * scale, (float)v[1] * scale, (float)v[2] * scale, (float)v[3] * scale};
+    }
+    static __device__ __forceinline__ float load1(const int16_t *p, float scale) { return (float)*p * scale; }
+};
+
+template <typename SampleT>
 __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
-    const float *__restrict__ P, const float *__restrict__ audio, long long n_samples,
-    long long row_stride, long long origin, int B, int G, int T, float *__restrict__ gx) {
+    const float *__restrict__ P, const SampleT *__restrict__ audio, float in_scale, long long n_samples,
+    long long row_stride, long long origin, int B, int G, int T, int Gws, int g0, float *__restrict__ gx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *X = lds, *Mg = lds, *A1 = lds;          // main region, one tenant per phase
     float *A3 = lds + A3_OFF, *A4 = lds + A4_OFF;
@@ -228,7 +248,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
     auto xslot = [fold](int pp) { return fold ? (pp & 1) * X_ODD + (pp >> 1) : pp; };
     {
         const long long base = (long long)t * 512 + origin;
-        const bool vec_ok = ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(audio) & 15) == 0) && n_samples >= 4 && !ENC_SKIP(1);
+        const bool vec_ok = ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(audio) & (SampleIO<SampleT>::VEC_ALIGN - 1)) == 0) && n_samples >= 4 && !ENC_SKIP(1);
         // Work item e = (clip c, float4 p/4) of the 16 x 576-sample tile.  In the normal case every lane loads its
         // float4 UNCONDITIONALLY from a clamped address, all five loads back to back (a load under a condition -- even a
         // uniform one -- compiles to a branch plus a full wait: five serialised HBM round trips per tile); the rare edge
@@ -239,9 +259,9 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             for (int it = 0; it < 5; ++it) {
                 const int e = min(tid + ENC_THREADS * it, 16 * 144 - 1), c = e / 144, p = 4 * (e - c * 144);
                 const long long b = (long long)grp * 16 + c, idx = base + p;
-                const float *src = audio + (b < B ? b : 0) * row_stride;
+                const SampleT *src = audio + (b < B ? b : 0) * row_stride;
                 const long long idc = idx < 0 ? 0 : (idx + 3 < n_samples ? idx : ((n_samples - 4) & ~3LL));
-                x4[it] = *reinterpret_cast<const f32x4 *>(src + idc);
+                x4[it] = SampleIO<SampleT>::load4(src + idc, in_scale);
             }
         }
 #pragma unroll
@@ -251,7 +271,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                 const int c = e / 144, p = 4 * (e - c * 144);
                 const long long b = (long long)grp * 16 + c;
                 const bool bvalid = b < B;
-                const float *src = audio + (bvalid ? b : 0) * row_stride;
+                const SampleT *src = audio + (bvalid ? b : 0) * row_stride;
                 const long long idx = base + p;
                 float v[4];
                 if (vec_ok && bvalid && idx >= 0 && idx + 3 < n_samples) {
@@ -261,7 +281,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                 } else {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
-                        v[jj] = (bvalid && idx + jj >= 0 && idx + jj < n_samples) ? src[idx + jj] : 0.f;
+                        v[jj] = (bvalid && idx + jj >= 0 && idx + jj < n_samples) ? SampleIO<SampleT>::load1(src + idx + jj, in_scale) : 0.f;
                 }
                 float *row = X + c * X_LDM;
 #pragma unroll
@@ -477,7 +497,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                 for (int g = 0; g < 4; ++g) wcur[g] = wnxt[g];
             }
         }
-        float *dst = gx + ((size_t)t * G + grp) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
+        float *dst = gx + ((size_t)t * Gws + g0 + grp) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             if (!ENC_SKIP(8) || acc[g][0][0] == 12345.f) *reinterpret_cast<f32x4 *>(dst + g * 256) = acc[g][0];
@@ -727,34 +747,6 @@ __global__ void silero_segments_kernel(const float *__restrict__ probs, int B, i
     counts[b] = ns;
 }
 
-// ---- test hook: C = A * W^T through gemm_pass (W fragment-major, see vadx_frag_major_host) ---------------------------------------------------
-__global__ void test_gemm_kernel(const float *A, const float *W, float *C, int M, int N, int K, int swap) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lda = M + 4;                        // M in {16,32,48,64}: (M+4) % 8 == 4
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    for (int e = tid; e < M * K; e += blockDim.x) {
-        const int m = e / K, k = e % K;
-        lds[k * lda + m] = A[e];
-    }
-    __syncthreads();
-    const int q = lane >> 4, i = lane & 15;
-    for (int nt = wave; nt < N / 16; nt += nw) {
-        for (int mt = 0; mt < M / 16; ++mt) {
-            f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-            const float *const wrow[1] = {frag_ptr(W, K, nt, 0, lane)};
-            const int moff[1] = {mt * 16};
-            for (int kb = 0; kb < K / 16; ++kb) {
-                const float *const wr[1] = {wrow[0] + kb * FRAG};
-                if (swap) gemm_pass<1, 1, 1, true>(acc, lds + kb * 16 * lda, lda, moff, wr, lane);
-                else gemm_pass<1, 1, 1, false>(acc, lds + kb * 16 * lda, lda, moff, wr, lane);
-            }
-            for (int r = 0; r < 4; ++r) {
-                if (swap) C[(size_t)(mt * 16 + i) * N + nt * 16 + 4 * q + r] = acc[0][0][r];
-                else C[(size_t)(mt * 16 + 4 * q + r) * N + nt * 16 + i] = acc[0][0][r];
-            }
-        }
-    }
-}
 
 }  // namespace silero
 }  // namespace vadx
@@ -879,28 +871,29 @@ extern "C" size_t vadx_silero_workspace_bytes(int batch, int steps) {
     return G * (size_t)steps * GX_TILE_FLOATS * sizeof(float);
 }
 
-static int silero_encode_launch(const float *packed, const float *src, long long n_valid, long long row_stride,
-                                long long origin, int batch, int steps, void *ws, size_t ws_bytes, void *stream) {
+template <typename S>
+static int silero_encode_launch(const float *packed, const S *src, float in_scale, long long n_valid, long long row_stride,
+                                long long origin, int batch, int steps, void *ws, size_t ws_bytes, void *stream,
+                                int first_group = 0, int total_batch = 0) {
     VADX_REQUIRE(packed && src && ws, "silero: NULL pointer argument");
     VADX_REQUIRE(batch > 0 && steps > 0, "silero: batch=%d steps=%d must be positive", batch, steps);
     VADX_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
                  "silero: packed weights and workspace must be 16-byte aligned");
-    if (ws_bytes < vadx_silero_workspace_bytes(batch, steps)) {
-        vadx::set_error("silero: workspace %zu B < required %zu B", ws_bytes, vadx_silero_workspace_bytes(batch, steps));
+    if (total_batch <= 0) total_batch = batch;          // the workspace is laid out for total_batch clips; this launch fills
+    const int Gws = (total_batch + 15) / 16;            // groups [first_group, first_group + G) of it
+    const int G = (batch + 15) / 16;
+    VADX_REQUIRE(first_group >= 0 && first_group + G <= Gws, "silero: clip groups [%d, %d) outside the workspace's %d", first_group,
+                 first_group + G, Gws);
+    if (ws_bytes < vadx_silero_workspace_bytes(total_batch, steps)) {
+        vadx::set_error("silero: workspace %zu B < required %zu B", ws_bytes, vadx_silero_workspace_bytes(total_batch, steps));
         return VADX_ENOSPACE;
     }
-    const int G = (batch + 15) / 16;
-    static bool attr_done = false;
-    if (!attr_done) {
-        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(silero_encode_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_FLOATS * sizeof(float)));
-        attr_done = true;
-    }
+    VADX_DYN_LDS(silero_encode_kernel<S>, ENC_LDS_FLOATS * sizeof(float));
     const long long nblk = (long long)G * steps;
     VADX_REQUIRE(nblk < (1LL << 31), "silero: too many tiles (%lld)", nblk);
-    hipLaunchKernelGGL(silero_encode_kernel, dim3((unsigned)nblk), dim3(ENC_THREADS), ENC_LDS_FLOATS * sizeof(float),
-                       static_cast<hipStream_t>(stream), packed, src, n_valid, row_stride, origin, batch, G, steps,
-                       static_cast<float *>(ws));
+    hipLaunchKernelGGL(silero_encode_kernel<S>, dim3((unsigned)nblk), dim3(ENC_THREADS), ENC_LDS_FLOATS * sizeof(float),
+                       static_cast<hipStream_t>(stream), packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps,
+                       Gws, first_group, static_cast<float *>(ws));
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }
@@ -924,7 +917,7 @@ static int silero_recur_launch(const float *packed, const void *ws, size_t ws_by
 static int silero_run(const float *packed, const float *src, long long n_valid, long long row_stride,
                       long long origin, int batch, int steps, const float *state0, float *probs,
                       long long probs_stride, float *state_n, void *ws, size_t ws_bytes, void *stream) {
-    int rc = silero_encode_launch(packed, src, n_valid, row_stride, origin, batch, steps, ws, ws_bytes, stream);
+    int rc = silero_encode_launch(packed, src, 1.0f, n_valid, row_stride, origin, batch, steps, ws, ws_bytes, stream);
     if (rc != VADX_OK) return rc;
     return silero_recur_launch(packed, ws, ws_bytes, batch, steps, state0, probs, probs_stride, state_n, stream);
 }
@@ -935,7 +928,30 @@ extern "C" int vadx_silero_encode(const float *packed, const float *audio, int b
                  (long long)n_samples, (long long)row_stride);
     const long long steps = (n_samples + 511) / 512;
     VADX_REQUIRE(steps < (1LL << 30), "vadx_silero_encode: clip too long");
-    return silero_encode_launch(packed, audio, n_samples, row_stride, -64, batch, (int)steps, workspace, workspace_bytes, stream);
+    return silero_encode_launch(packed, audio, 1.0f, n_samples, row_stride, -64, batch, (int)steps, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vadx_silero_encode_pcm16(const float *packed, const int16_t *audio, float scale, int batch, int64_t n_samples,
+                                        int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream) {
+    VADX_REQUIRE(n_samples > 0 && row_stride >= n_samples, "vadx_silero_encode_pcm16: n_samples=%lld row_stride=%lld",
+                 (long long)n_samples, (long long)row_stride);
+    const long long steps = (n_samples + 511) / 512;
+    VADX_REQUIRE(steps < (1LL << 30), "vadx_silero_encode_pcm16: clip too long");
+    return silero_encode_launch(packed, audio, scale, n_samples, row_stride, -64, batch, (int)steps, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vadx_silero_encode_pcm16_part(const float *packed, const int16_t *audio, float scale, int batch, int64_t n_samples,
+                                             int64_t row_stride, int first_clip, int total_batch, void *workspace,
+                                             size_t workspace_bytes, void *stream) {
+    VADX_REQUIRE(n_samples > 0 && row_stride >= n_samples, "vadx_silero_encode_pcm16_part: n_samples=%lld row_stride=%lld",
+                 (long long)n_samples, (long long)row_stride);
+    VADX_REQUIRE(first_clip >= 0 && first_clip % 16 == 0 && first_clip + batch <= total_batch,
+                 "vadx_silero_encode_pcm16_part: first_clip=%d must be a multiple of 16 and first_clip + batch <= total_batch=%d",
+                 first_clip, total_batch);
+    const long long steps = (n_samples + 511) / 512;
+    VADX_REQUIRE(steps < (1LL << 30), "vadx_silero_encode_pcm16_part: clip too long");
+    return silero_encode_launch(packed, audio, scale, n_samples, row_stride, -64, batch, (int)steps, workspace, workspace_bytes, stream,
+                                first_clip / 16, total_batch);
 }
 
 extern "C" int vadx_silero_recur(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
@@ -951,7 +967,7 @@ extern "C" int vadx_silero_encode_span(const float *packed, const float *audio, 
     const long long steps = (n_samples + 511) / 512;
     VADX_REQUIRE(first_step >= 0 && n_steps > 0 && (long long)first_step + n_steps <= steps,
                  "vadx_silero_encode_span: span [%d, %d + %d) outside the clip's %lld windows", first_step, first_step, n_steps, steps);
-    return silero_encode_launch(packed, audio, n_samples, row_stride, (long long)first_step * 512 - 64, batch, n_steps,
+    return silero_encode_launch(packed, audio, 1.0f, n_samples, row_stride, (long long)first_step * 512 - 64, batch, n_steps,
                                 workspace, workspace_bytes, stream);
 }
 
@@ -995,18 +1011,3 @@ extern "C" int vadx_silero_segments(const float *probs, int batch, int steps, co
     return VADX_OK;
 }
 
-extern "C" int vadx_test_gemm(const float *a, const float *w, float *c, int m, int n, int k, int swap, void *stream) {
-    VADX_REQUIRE(a && w && c, "vadx_test_gemm: NULL pointer");
-    VADX_REQUIRE(m > 0 && m <= 64 && m % 16 == 0 && n > 0 && n % 16 == 0 && k > 0 && k % 16 == 0 && (size_t)(m + 4) * k * 4 <= 160 * 1024,
-                 "vadx_test_gemm: unsupported shape %dx%dx%d", m, n, k);
-    const size_t lds = (size_t)(m + 4) * k * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(test_gemm_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(test_gemm_kernel, dim3(1), dim3(256), lds, static_cast<hipStream_t>(stream), a, w, c, m, n, k, swap);
-    VADX_HIP_TRY(hipGetLastError());
-    return VADX_OK;
-}

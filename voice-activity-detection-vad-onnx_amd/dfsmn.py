@@ -59,11 +59,12 @@ def _pad_rows16(a):
 
 class Iccrn:
     """Device-side SDAEC ICCRN (`NET`): weights repacked for the pw_conv / dft_f / lstm kernels."""
+    lib = property(lambda self: _lib.lib())
 
     def __init__(self, weights, device="cuda:0"):
         self.torch = t = _lib.require_gpu()
         self.device = t.device(device)
-        self.lib = _lib.lib()
+        _lib.lib()                 # load / symbol check now; `self.lib` resolves per call (so _lib.trace() sees the launches)
         w = {k[len("iccrn."):]: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in weights.items()
              if k.startswith("iccrn.")}
         self.w = w
@@ -226,6 +227,7 @@ class Iccrn:
 
 class DfsmnEngine:
     """Batched DFSMN near+far VAD: two int16 streams in, vad_results [51] per 16001-sample window out."""
+    lib = property(lambda self: _lib.lib())
 
     L, T_B, T_A, LOOK_BACKWARD, FRAME = 16001, 101, 51, 0.3, 320
 
@@ -233,7 +235,7 @@ class DfsmnEngine:
         from . import tables, weights as _w, frontend as _fe
         self.torch = t = _lib.require_gpu()
         self.device = t.device(device)
-        self.lib = _lib.lib()
+        _lib.lib()                 # load / symbol check now; `self.lib` resolves per call (so _lib.trace() sees the launches)
         w = _w.dfsmn_synthetic(1234) if weights is None else weights
         w = {k: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in w.items()}
         self.sub_batch = int(sub_batch)

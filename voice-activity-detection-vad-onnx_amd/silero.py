@@ -166,6 +166,28 @@ class SileroEngine:
                                                      ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
         return B, steps
 
+    PCM16_SCALE = 0.000030517578       # Silero/Inference_Silero_VAD_ONNX.py:83: float32 = int16 * this
+
+    def encode_pcm16(self, pcm, n_samples=None, scale=PCM16_SCALE):
+        """`encode` fed the int16 samples themselves (device tensor [B,N]): the kernel applies the reference's
+        int16 -> float32 scaling while staging, bit-identical to encoding `pcm.float() * float32(scale)`."""
+        t = self.torch
+        if pcm.dtype != t.int16 or pcm.dim() != 2 or not pcm.is_cuda:
+            raise ValueError("encode_pcm16 expects a device int16 tensor [B,N]")
+        B, N = pcm.shape
+        n = int(N if n_samples is None else n_samples)
+        steps = (n + NUM_SAMPLES - 1) // NUM_SAMPLES
+        ws = self._workspace(B, steps)
+        with t.cuda.device(self.device):
+            _lib.check(_lib.lib().vadx_silero_encode_pcm16(self.packed.data_ptr(), pcm.data_ptr(), float(scale), B, n,
+                                                           _lib.row_stride(pcm), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        return B, steps
+
+    def clips_pcm16(self, pcm, n_samples=None, scale=PCM16_SCALE):
+        """int16 PCM [B,N] on the device -> probs [B, ceil(n/512)] (encode_pcm16 + recur)."""
+        B, steps = self.encode_pcm16(pcm, n_samples, scale)
+        return self.recur(B, steps, self.torch.empty((B, steps), dtype=self.torch.float32, device=self.device))
+
     def recur(self, batch, steps, probs):
         """Second half of `clips`: workspace -> probs [B,steps] (zero initial state)."""
         t = self.torch
