@@ -219,7 +219,8 @@ int vadx_fsmn_run(const vadx_fsmn_dims *dims, const float *packed, const float *
                   void *stream);
 
 typedef struct vadx_fsmn_loop_params {   /* FSMN/Inference_FSMN_VAD_ONNX.py:16-23,79-81,159-171 */
-    int    look_backward;                 /* frames: int(LOOK_BACKWARD*16000 // 160) = 30 */
+    int    look_backward;                 /* frames: int(LOOK_BACKWARD*16000 // 160) = 30; 0 is allowed and means what it
+                                           * means in the reference: slide_range = T, one-frame vote, empty tail */
     float  one_minus_speech_threshold;    /* 1.0 */
     float  noise_db_init;                 /* (BACKGROUND_NOISE_dB_INIT + SNR_THRESHOLD) * 0.1 */
     float  snr_threshold;                 /* SNR_THRESHOLD * 0.1 */

@@ -98,14 +98,23 @@ def forward(fe, w, audio_i16):
     return score[..., :1], score[..., 1:], length - 1
 
 
-def run_clip(fe, w, audio_i16_1d, post=(3, 0.5, 10, 1000, 10, 3, 0), frame_shift_s=0.02):
-    """Dynamic-axis driver: one window = whole clip (<= 3600 s).
-    ref: Inference_NVIDIA_MarbleNet_VAD_ONNX.py:130-135, 374-402."""
+def run_clip(fe, w, audio_i16_1d, post=(3, 0.5, 10, 1000, 10, 3, 0), frame_shift_s=0.02, window=None, pad_noise=None):
+    """Whole-clip driver.  window None = the dynamic-axis mode (one window = whole clip, <= 3600 s); an integer = a
+    static-shape export: non-overlapping windows on a noise-padded grid, each window's first min(signal_len, T) frames
+    concatenated.  ref: Inference_NVIDIA_MarbleNet_VAD_ONNX.py:130-147 (grid), :369-388 (loop), :391-402 (post).
+    `pad_noise` replaces the reference's unseeded np.random.normal."""
     a = np.asarray(audio_i16_1d)
     n = a.shape[0]
-    sil, act, slen = forward(fe, w, torch.from_numpy(a.copy()).reshape(1, 1, -1))
-    valid = min(int(slen), act.shape[1])
-    probs = act[0, :valid, 0].numpy()
+    L = min(16000 * 3600, n) if window is None else int(window)
+    padded, _ = postproc.pad_to_window_grid(a, L, L, pad_noise)
+    chunks = []
+    s = 0
+    while s + L <= padded.shape[0]:
+        sil, act, slen = forward(fe, w, torch.from_numpy(padded[s:s + L].copy()).reshape(1, 1, -1))
+        valid = min(int(slen), act.shape[1])
+        chunks.append(act[0, :valid, 0].numpy())
+        s += L
+    probs = np.concatenate(chunks, axis=0) if chunks else np.zeros((0,), dtype=np.float32)
     pp = postproc.VadPostprocessor(*post, frame_shift_s=frame_shift_s, frame_length_s=None)
     dec = pp.process(probs)
     return pp.decision_to_segment(dec, n / 16000), probs, dec

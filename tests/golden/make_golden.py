@@ -720,10 +720,181 @@ def gen_marblenet_fold():
     save("marblenet_fold", **out)
 
 
+
+# ------------------------------------------------------------------------------------ round-2 additions
+def _fsmn_reference_model(seed, ratio):
+    enc = R.load_module("FSMN/modeling_modified/encoder.py", "ref_fsmn_encoder")
+    stft_mod = R.load_module("FSMN/STFT_Process.py", "ref_stft_v1")
+    import torchaudio
+    ns = {"torch": torch, "torchaudio": torchaudio, "math": __import__("math"), "np": np}
+    R.select_nodes("FSMN/Export_FSMN_VAD.py", {"FSMN_VAD"}, ns)
+    d = weights.FSMN_DIMS
+    w = weights.fsmn_synthetic(seed)
+    net = enc.FSMN(d["input_dim"], d["input_affine_dim"], d["fsmn_layers"], d["linear_dim"], d["proj_dim"],
+                   d["lorder"], 0, 1, 0, d["output_affine_dim"], d["output_dim"]).eval()
+    sd = {"in_linear1.linear.weight": w["in1_w"], "in_linear1.linear.bias": w["in1_b"],
+          "in_linear2.linear.weight": w["in2_w"], "in_linear2.linear.bias": w["in2_b"],
+          "out_linear1.linear.weight": w["out1_w"], "out_linear1.linear.bias": w["out1_b"],
+          "out_linear2.linear.weight": w["out2_w"], "out_linear2.linear.bias": w["out2_b"]}
+    for l in range(4):
+        sd[f"fsmn.{l}.linear.linear.weight"] = w[f"l{l}_lin_w"]
+        sd[f"fsmn.{l}.fsmn_block.conv_left.weight"] = w[f"l{l}_fir_w"].reshape(128, 1, 20, 1)
+        sd[f"fsmn.{l}.affine.linear.weight"] = w[f"l{l}_aff_w"]
+        sd[f"fsmn.{l}.affine.linear.bias"] = w[f"l{l}_aff_b"]
+    net.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    stft = stft_mod.STFT_Process(model_type="stft_B", n_fft=512, hop_len=160, win_length=400, max_frames=0, window_type="hamming").eval()
+    L = 16000
+    return ns["FSMN_VAD"](net, stft, 512, L // 160 + 1, 80, 16000, 0.97, 5, 1, (L // 160 + 1), ratio, L, 160,
+                          T(w["cmvn_means"]).reshape(1, 1, -1), T(w["cmvn_vars"]).reshape(1, 1, -1))
+
+
+def gen_fsmn_extra():
+    """SPEECH_2_NOISE_RATIO != 1 branches of the FSMN graph (Export_FSMN_VAD.py:87-92) and the LOOK_BACKWARD = 0 edge of
+    the host loop (Inference_FSMN_VAD_ONNX.py:79-86: slide_range is taken before look_backward is bumped to 1)."""
+    print("FSMN extras: speech_2_noise_ratio 0.5 / 2.0, look_backward 0")
+    out = {}
+    clip = weights.burst_clips(1, 16000 + 11040, seed=1357)[0]
+    clip = (clip.astype(np.float32) * float(32767.0 / np.max(np.abs(clip.astype(np.float32))))).astype(np.int16)
+    out["clip"] = clip
+    for tag, ratio, thrs in (("r05", 0.5, (1.5, 1.45)), ("r20", 2.0, (1.0, 0.7))):
+        model = _fsmn_reference_model(1234, ratio)
+        caches = [torch.zeros(1, 128, 19, 1) for _ in range(4)]
+        with torch.no_grad():
+            for k in range(2):
+                a = T(clip[k * 11040:k * 11040 + 16000].copy()).reshape(1, 1, -1)
+                score, c0, c1, c2, c3, noisy = model(a, *caches, torch.tensor([thrs[k]]), torch.tensor([4.0]))
+                out[f"{tag}_score_{k}"] = score.numpy()
+                out[f"{tag}_noisy_{k}"] = np.array(noisy.numpy())
+                out[f"{tag}_thr_{k}"] = np.array(thrs[k], np.float32)
+                caches = [c0, c1, c2, c3]
+        out[f"{tag}_ratio"] = np.array(ratio)
+    # host loop with LOOK_BACKWARD = 0.0: look_backward 0 -> stride = L - 160, slide_range = score_len, vote length 1, empty tail
+    rng = np.random.default_rng(4321)
+    for case in range(3):
+        n_chunks = [1, 3, 6][case]
+        scores = []
+        for k in range(n_chunks):
+            s = np.zeros(101, np.uint8)
+            st = int(rng.integers(0, 2))
+            for i in range(101):
+                if rng.uniform() < 0.2:
+                    st = 1 - st
+                s[i] = st
+            scores.append(s)
+        noisy_seq = [float(v) for v in rng.uniform(-0.5, 2.0, n_chunks)]
+
+        class FakeSess:
+            def __init__(self):
+                self.k = 0
+
+            def run(self, names, feeds):
+                k = self.k
+                self.k += 1
+                z = np.zeros((1, 128, 19, 1), np.float32)
+                return scores[k], z, z, z, z, np.float32(noisy_seq[k])
+
+        stride = 16000 - 160
+        aligned = (n_chunks - 1) * stride + 16000
+        # the reference's own derivation (:79-86) with LOOK_BACKWARD = 0.0
+        env = dict(np=np, LOOK_BACKWARD=0.0, SAMPLE_RATE=16000, OUTPUT_FRAME_LENGTH=160, INPUT_AUDIO_LENGTH=16000, score_len=101)
+        R.select_lines("FSMN/Inference_FSMN_VAD_ONNX.py", 79, 86, env)
+        assert (env["look_backward"], env["stride_step"], env["slide_range"]) == (1, stride, 101)
+        env.update(time=__import__("time"), ort_session_A=FakeSess(), model_type="tensor(float)",
+                   BACKGROUND_NOISE_dB_INIT=30.0, SNR_THRESHOLD=10.0, ONE_MINUS_SPEECH_THRESHOLD=1.0,
+                   aligned_len=aligned, audio=np.zeros((1, 1, aligned), np.int16), SPEAKING_SCORE=0.5,
+                   SILENCE_SCORE=0.5, inv_audio_len=0.0, print=lambda *a, **k: None)
+        for i in range(7):
+            env[f"in_name_A{i}"] = f"i{i}"
+        for i in range(6):
+            env[f"out_name_A{i}"] = f"o{i}"
+        R.select_lines("FSMN/Inference_FSMN_VAD_ONNX.py", 156, 234, env)
+        out[f"lb0_scores_{case}"] = np.stack(scores)
+        out[f"lb0_noisy_{case}"] = np.array(noisy_seq, np.float32)
+        out[f"lb0_saved_{case}"] = np.array(env["saved"], dtype=bool)
+    out["lb0_n_cases"] = np.array(3)
+    out["lb0_stride"] = np.array(16000 - 160)
+    save("fsmn_extra", **out)
+
+
+def gen_host_extra():
+    """normalise_audio (RMS -> 8192 with clipping, Inference_NVIDIA_MarbleNet_VAD_ONNX.py:110-118; FireRed carries the same
+    function) -- the optional NORMALIZE_AUDIO path of the MarbleNet / FireRed drivers."""
+    print("host extras: normalise_audio")
+    ns = {"np": np}
+    R.select_nodes("NVIDIA_Frame_VAD_Multilingual_MarbleNet/Inference_NVIDIA_MarbleNet_VAD_ONNX.py", {"normalise_audio"}, ns)
+    ns2 = {"np": np}
+    R.select_nodes("FireRedVAD/Inference_FireRed_ONNX.py", {"normalise_audio"}, ns2)
+    rng = np.random.default_rng(99)
+    out = {}
+    cases = [(rng.standard_normal(5000) * 300).astype(np.int16),            # quiet -> scaled up, no clipping
+             (rng.standard_normal(5000) * 9000).astype(np.int16),           # loud -> scaled down
+             np.concatenate([(rng.standard_normal(3000) * 20).astype(np.int16), np.array([32767, -32768, 30000] * 5, np.int16)]),  # clips
+             np.zeros(100, np.int16),                                       # rms == 0 -> returned unchanged
+             np.array([7], np.int16)]
+    for i, a in enumerate(cases):
+        got = ns["normalise_audio"](a.copy())
+        got2 = ns2["normalise_audio"](a.copy())
+        assert np.array_equal(got, got2) and got.dtype == got2.dtype
+        out[f"in_{i}"] = a
+        out[f"out_{i}"] = got
+    out["target_4096_in"] = cases[0]
+    out["target_4096_out"] = ns["normalise_audio"](cases[0].copy(), 4096.0)
+    out["n_cases"] = np.array(len(cases))
+    save("host_extra", **out)
+
+
+def gen_marblenet_hostloop():
+    """The MarbleNet driver's window grid + loop (Inference_NVIDIA_MarbleNet_VAD_ONNX.py:130-147, 369-388) in STATIC-window mode
+    (integer in the input shape), run on a fake session whose `run` is the oracle network, np.random.normal replayed."""
+    print("MarbleNet host loop (static window)")
+    from oracle import marblenet as omb
+    w = {k: T(v) for k, v in weights.marblenet_synthetic(1234).items()}
+    fe = omb.Frontend()
+    out = {}
+    for case, (n, L) in enumerate([(40000, 16000), (16000, 16000), (9000, 16000), (50001, 24000)]):
+        clip = weights.burst_clips(1, n, seed=200 + case)[0]
+        noise = np.random.default_rng(300 + case).standard_normal(40000)
+        calls = []
+
+        class FakeSess:
+            class _M:
+                shape = [1, 1, L]
+            _inputs_meta = [_M()]
+
+            def run(self, names, feeds):
+                a = feeds["audio"]
+                calls.append(a.shape[-1])
+                sil, act, slen = omb.forward(fe, w, T(np.ascontiguousarray(a)))
+                return sil.numpy(), act.numpy(), np.array([int(slen)], np.int32)
+
+        class FakeRandom:
+            @staticmethod
+            def normal(loc=0.0, scale=1.0, size=None):
+                k = int(np.prod(size))
+                return noise[:k].reshape(size)
+
+        fake_np = types.SimpleNamespace(**{k: getattr(np, k) for k in ("ceil", "sqrt", "mean", "concatenate", "float32", "zeros")})
+        fake_np.random = FakeRandom
+        env = dict(np=fake_np, ort_session_A=FakeSess(), IN_SAMPLE_RATE=16000, audio=clip.reshape(1, 1, -1).copy(), audio_len=n,
+                   time=__import__("time"), in_name_A0="audio", out_name_A0="score_silence", out_name_A1="score_active",
+                   out_name_A2="signal_len", print=lambda *a, **k: None)
+        R.select_lines("NVIDIA_Frame_VAD_Multilingual_MarbleNet/Inference_NVIDIA_MarbleNet_VAD_ONNX.py", 130, 147, env)
+        R.select_lines("NVIDIA_Frame_VAD_Multilingual_MarbleNet/Inference_NVIDIA_MarbleNet_VAD_ONNX.py", 369, 388, env)
+        out[f"clip_{case}"] = clip
+        out[f"noise_seed_{case}"] = np.array(300 + case)         # noise = default_rng(seed).standard_normal(40000)
+        out[f"window_{case}"] = np.array(L)
+        out[f"aligned_{case}"] = env["audio"][0, 0]
+        out[f"probs_{case}"] = np.asarray(env["all_vad_probs"], np.float32)
+        out[f"calls_{case}"] = np.array(calls)
+    out["n_cases"] = np.array(4)
+    save("marblenet_hostloop", **out)
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:])
     gens = dict(stft=gen_stft, host=gen_host, vadpost=gen_vadpost, silero_host=gen_silero_host,
-                fsmn=gen_fsmn, firered=gen_firered, firered_stream=gen_firered_stream, firered_ckpt=gen_firered_ckpt, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn, dfsmn_near_only=gen_dfsmn_near_only)
+                fsmn=gen_fsmn, firered=gen_firered, firered_stream=gen_firered_stream, firered_ckpt=gen_firered_ckpt, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn, dfsmn_near_only=gen_dfsmn_near_only,
+                fsmn_extra=gen_fsmn_extra, host_extra=gen_host_extra, marblenet_hostloop=gen_marblenet_hostloop)
     for name, fn in gens.items():
         if not which or name in which:
             fn()

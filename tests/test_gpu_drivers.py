@@ -154,9 +154,15 @@ def test_firered_and_marblenet_on_vad_sample(tmp_path):
     want, oprobs, odec = ofr.run_clip(ofr.Frontend(), wt, a, noise[0])
     _, track, dec = efr.detect(a[None, :], pad_noise=noise, return_probs=True)
     np.testing.assert_allclose(track[0].cpu().numpy(), oprobs, rtol=0, atol=1e-4)
-    if np.array_equal(np.asarray(dec[0].cpu().numpy()), np.asarray(odec)):
-        assert got == want and open(idx).read() == "".join(opp.timestamp_lines(want, 16000)[1])
-    assert os.path.exists(sec)
+    # unconditional: device decisions == oracle post-processor on the device scores; files == oracle segments of those
+    opost = opp.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0)
+    d2 = opost.process(track[0].cpu().numpy())
+    assert np.array_equal(dec[0].cpu().numpy(), d2)
+    seg2 = opost.decision_to_segment(d2, len(a) / 16000)
+    assert got == seg2 and open(idx).read() == "".join(opp.timestamp_lines(seg2, 16000)[1])
+    assert open(sec).read() == "".join(opp.timestamp_lines(seg2, 16000)[0])
+    if np.array_equal(d2, np.asarray(odec)):
+        assert got == want
     # MarbleNet (dynamic axis: the whole clip is one window)
     wm = weights.marblenet_synthetic(1234)
     em = marblenet.MarbleNetEngine(wm)
@@ -166,8 +172,13 @@ def test_firered_and_marblenet_on_vad_sample(tmp_path):
     want_m, p_m, dec_m = omb.run_clip(omb.Frontend(), ow, a)
     _, track_m, dec_g = em.detect(a[None, :], return_probs=True)
     np.testing.assert_allclose(track_m[0].cpu().numpy(), p_m, rtol=0, atol=1e-4)
-    if np.array_equal(dec_g[0].cpu().numpy(), dec_m):
-        assert got_m == want_m and open(idx2).read() == "".join(opp.timestamp_lines(want_m, 16000)[1])
+    opost = opp.VadPostprocessor(3, 0.5, 10, 1000, 10, 3, 0, frame_shift_s=0.02, frame_length_s=None)
+    d2 = opost.process(track_m[0].cpu().numpy())
+    assert np.array_equal(dec_g[0].cpu().numpy(), d2)
+    seg2 = opost.decision_to_segment(d2, len(a) / 16000)
+    assert got_m == seg2 and open(idx2).read() == "".join(opp.timestamp_lines(seg2, 16000)[1])
+    if np.array_equal(d2, dec_m):
+        assert got_m == want_m
 
 
 def test_dfsmn_near_only_on_vad_sample(tmp_path):

@@ -81,6 +81,7 @@ def test_whole_clip_segments(n):
             # decisions bit-exact when the device scores are post-processed by the oracle too
             d2 = opp.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0).process(track[b].cpu().numpy())
             assert np.array_equal(dec[b].cpu().numpy(), d2)
+            assert got[b] == opp.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0).decision_to_segment(d2, n / 16000)
             if np.array_equal(d2, want_dec):
                 assert got[b] == want_seg
                 assert [(int(s * 16000), int(e * 16000)) for s, e in got[b]] == [(int(s * 16000), int(e * 16000)) for s, e in want_seg]

@@ -145,3 +145,48 @@ def test_full_size_config3_properties():
         _, want = ofs.run_clip(fe, ow, a, noise[b])
         assert np.array_equal(flags[b].cpu().numpy().astype(bool), np.array(want, bool))
     print(f"FSMN config-3 pass: {dt * 1e3:.1f} ms for 4096 x 10 s ({4096 * 313 / dt / 1e6:.1f} M 512-hop frames/s)")
+
+
+@pytest.mark.parametrize("tag", ["r05", "r20"])
+def test_speech_2_noise_ratio_branches(golden, tag):
+    """SPEECH_2_NOISE_RATIO != 1 (FSMN/Export_FSMN_VAD.py:87-92) against the reference wrapper's own outputs: two chained
+    windows, thresholds chosen so the score term decides frames."""
+    g = golden("fsmn_extra")
+    ratio = float(g[f"{tag}_ratio"])
+    eng = fsmn.FsmnEngine(weights.fsmn_synthetic(1234), speech_2_noise_ratio=ratio)
+    caches = [torch.zeros(1, 128, 19) for _ in range(4)]
+    for k in range(2):
+        a = T(g["clip"][k * 11040:k * 11040 + 16000].copy()).reshape(1, -1)
+        thr = float(g[f"{tag}_thr_{k}"])
+        score, caches, noisy, psil = eng.run(a, caches, np.array([thr], np.float32), np.array([4.0], np.float32), return_psil=True)
+        p = psil.cpu().numpy()[0].astype(np.float64)
+        raw = p + 1.0 if ratio < 1.0 else p + p ** ratio
+        got, want = score.cpu().numpy()[0], g[f"{tag}_score_{k}"]
+        bad = np.flatnonzero(got != want)
+        assert len(bad) <= 1
+        for i in bad:                  # only a frame whose score sits on the threshold may differ
+            assert abs(raw[i] - thr) < 2 * ATOL, (k, i, raw[i])
+        if len(bad) == 0:
+            np.testing.assert_allclose(noisy.cpu().numpy()[0], g[f"{tag}_noisy_{k}"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("n", [50000, 16000])
+def test_look_backward_zero(golden, n):
+    """LOOK_BACKWARD = 0 (Inference_FSMN_VAD_ONNX.py:79-86): stride L - 160, W*T flags, empty tail -- the reference loop on
+    replayed scores (fixture) pins the oracle; the device loop must equal the oracle on whole clips."""
+    eng = fsmn.FsmnEngine(weights.fsmn_synthetic(1234))
+    assert eng.grid(0.0) == (0, 16000 - 160)
+    fe = ofs.Frontend()
+    ow = {k: T(v) for k, v in weights.fsmn_synthetic(1234).items()}
+    clips = weights.burst_clips(2, n, seed=n + 5)
+    noise = np.random.default_rng(10).standard_normal((2, 20000))
+    got = eng.detect(clips, pad_noise=noise, look_backward_s=0.0)
+    for b in range(2):
+        a = opp.normalize_to_int16(clips[b].astype(np.float32))
+        want_ts, want_flags = ofs.run_clip(fe, ow, a, noise[b], look_backward_s=0.0)
+        padded = fsmn.pad_to_window_grid(a, 16000, 16000 - 160, noise[b])
+        W = (padded.shape[0] - 16000) // (16000 - 160) + 1
+        flags = eng.flags(torch.from_numpy(padded[None]), W, look_backward_s=0.0).cpu().numpy()[0].astype(bool)
+        assert flags.shape[0] == W * 101 == len(want_flags)
+        assert np.array_equal(flags, np.array(want_flags, bool))
+        assert got[b] == want_ts

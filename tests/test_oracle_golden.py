@@ -313,3 +313,95 @@ def test_ingest_oracle_matches_audioop(ch, in_rate, out_rate, n):
     if in_rate != out_rate:
         data, _ = audioop.ratecv(data, 2, 1, in_rate, out_rate, None)
     assert np.array_equal(oing.ingest(x, ch, in_rate, out_rate), np.frombuffer(data, dtype=np.int16))
+
+
+# ------------------------------------------------------------------ round-2 fixtures
+@pytest.mark.parametrize("tag", ["r05", "r20"])
+def test_fsmn_speech_2_noise_ratio_branches(golden, tag):
+    """SPEECH_2_NOISE_RATIO < 1 (score + 1) and > 1 (score + score ** ratio): FSMN/Export_FSMN_VAD.py:87-92."""
+    g = golden("fsmn_extra")
+    fe = ofs.Frontend()
+    w = {k: T(v) for k, v in weights.fsmn_synthetic(1234).items()}
+    ratio = float(g[f"{tag}_ratio"])
+    caches = [torch.zeros(1, 128, 19, 1) for _ in range(4)]
+    for k in range(2):
+        a = T(g["clip"][k * 11040:k * 11040 + 16000].copy()).reshape(1, 1, -1)
+        thr = np.array([g[f"{tag}_thr_{k}"]], np.float32)
+        score, caches, noisy, raw, db = ofs.forward(fe, w, a, caches, thr, np.array([4.0], np.float32), ratio, return_raw=True)
+        want = g[f"{tag}_score_{k}"]
+        diff = np.flatnonzero(score[0].numpy() != want)
+        for i in diff:
+            assert abs(float(raw[0, i]) - float(thr[0])) < 1e-4 or abs(float(db[0, i]) - 4.0) < 1e-4
+        assert len(diff) <= 1
+        if len(diff) == 0:
+            np.testing.assert_allclose(noisy.numpy()[0], g[f"{tag}_noisy_{k}"], rtol=0, atol=1e-4)
+        assert 0 < int(want.sum()) < 101              # the gate really toggles inside the window
+
+
+def test_fsmn_hostloop_look_backward_zero(golden):
+    """LOOK_BACKWARD = 0: slide_range = score_len (taken BEFORE look_backward is bumped to 1), stride = L - 160, so every
+    window contributes all 101 flags and the tail loop is empty (Inference_FSMN_VAD_ONNX.py:79-86, 188-234)."""
+    g = golden("fsmn_extra")
+    for c in range(int(g["lb0_n_cases"])):
+        scores = g[f"lb0_scores_{c}"]
+        silence, saved = True, []
+        for k in range(scores.shape[0]):
+            flags, silence = opp.lookahead_vote(scores[k], 101, 1, 0.5, 0.5, silence)
+            saved += flags
+        flags, silence = opp.tail_flags_fsmn(scores[-1], 101, 101, silence)
+        saved += flags
+        assert np.array_equal(np.array(saved, bool), g[f"lb0_saved_{c}"]), c
+        assert len(saved) == 101 * scores.shape[0]
+
+
+def test_normalise_audio(golden):
+    """Oracle AND product copy of normalise_audio (host code, no GPU) against the reference function."""
+    from vadx import timestamps as ts
+    g = golden("host_extra")
+    for i in range(int(g["n_cases"])):
+        for fn in (opp.normalise_audio, ts.normalise_audio):
+            got = fn(g[f"in_{i}"].copy())
+            assert got.dtype == g[f"out_{i}"].dtype and np.array_equal(got, g[f"out_{i}"]), (i, fn.__module__)
+    for fn in (opp.normalise_audio, ts.normalise_audio):
+        assert np.array_equal(fn(g["target_4096_in"].copy(), 4096.0), g["target_4096_out"])
+
+
+def test_marblenet_static_window_hostloop(golden):
+    """Static-shape MarbleNet export: window grid, noise padding, per-window valid frames, concatenation -- the reference's
+    module-level loop (Inference_NVIDIA_MarbleNet_VAD_ONNX.py:130-147, 369-388) run on the oracle network."""
+    from oracle import marblenet as omb
+    g = golden("marblenet_hostloop")
+    w = {k: T(v) for k, v in weights.marblenet_synthetic(1234).items()}
+    fe = omb.Frontend()
+    for c in range(int(g["n_cases"])):
+        noise = np.random.default_rng(int(g[f"noise_seed_{c}"])).standard_normal(40000)
+        L = int(g[f"window_{c}"])
+        padded, _ = opp.pad_to_window_grid(g[f"clip_{c}"], L, L, noise)
+        assert np.array_equal(padded, g[f"aligned_{c}"])
+        assert list(g[f"calls_{c}"]) == [L] * (len(padded) // L)
+        _, probs, _ = omb.run_clip(fe, w, g[f"clip_{c}"], window=L, pad_noise=noise)
+        assert probs.shape == g[f"probs_{c}"].shape
+        np.testing.assert_allclose(probs, g[f"probs_{c}"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,n_fft,win,wtype,variant", [
+    ("fsmn", 512, 400, "hamming", "v1"), ("dfsmn_b", 319, 319, "hamming", "v1b"), ("dfsmn_a", 1024, 640, "hamming", "v1b"),
+    ("marble", 512, 400, "hann_sym", "v2"), ("firered", 400, 400, "povey", "v2")])
+def test_product_dft_tables_are_the_reference_tables(golden, tag, n_fft, win, wtype, variant):
+    """The PRODUCT's host-side table builder (vadx.tables, fed to csrc/frontend.hip as data) hashes to the reference's
+    STFT_Process buffers -- the GPU front-end tolerance (2e-4 on log-mel) could not tell a reduced-angle table from the
+    reference's unreduced-float32-angle one, this can."""
+    from vadx import tables
+    g = golden("stft")
+    cos_t, sin_t = tables.windowed_dft(n_fft, tables.analysis_window(wtype, win, n_fft, variant), variant)
+    if variant == "v2":
+        assert _sha(torch.cat([cos_t, sin_t], 0)) == str(g[f"{tag}_kernel_sha256"])
+    else:
+        assert _sha(cos_t) == str(g[f"{tag}_cos_sha256"]) and _sha(sin_t) == str(g[f"{tag}_sin_sha256"])
+
+
+def test_product_kaldi_mel_bank_is_the_reference_bank(golden):
+    from vadx import tables
+    g = golden("firered_forward")
+    fb = tables.as_np(tables.mel_filters_kaldi(400, 80, 16000, 20.0, 0.0))
+    assert fb.shape == g["kaldi_fbank"].shape and np.array_equal(fb, g["kaldi_fbank"])

@@ -463,12 +463,15 @@ extern "C" int vadx_fsmn_clips(const vadx_fsmn_dims *dims, const float *packed, 
     VADX_REQUIRE(dims && packed && logmel && db && lp && cache_ws && flags, "vadx_fsmn_clips: NULL argument");
     VADX_REQUIRE(derive(dims, &d) == 0, "vadx_fsmn_clips: unsupported dims");
     VADX_REQUIRE(batch > 0 && windows_per_clip > 0, "vadx_fsmn_clips: batch/windows must be positive");
-    VADX_REQUIRE(lp->look_backward >= 1 && lp->look_backward < d.T && d.T - lp->look_backward <= 128 && d.T <= 112,
+    VADX_REQUIRE(lp->look_backward >= 0 && lp->look_backward < d.T && d.T - lp->look_backward <= 128 && d.T <= 112,
                  "vadx_fsmn_clips: look_backward=%d frames=%d unsupported", lp->look_backward, d.T);
     int rc = set_lds_attr();
     if (rc) return rc;
     ClipArgs c;
-    c.logmel = logmel; c.db = db; c.cache = cache_ws; c.W = windows_per_clip; c.lb = lp->look_backward;
+    c.logmel = logmel; c.db = db; c.cache = cache_ws; c.W = windows_per_clip;
+    // the reference takes slide_range = score_len - look_backward BEFORE it bumps a zero look_backward to 1
+    // (Inference_FSMN_VAD_ONNX.py:79-86): LOOK_BACKWARD = 0 means slide_range = T, a vote over one frame, an empty tail
+    c.lb = lp->look_backward > 0 ? lp->look_backward : 1;
     c.slide = d.T - lp->look_backward; c.thr = lp->one_minus_speech_threshold; c.noise0 = lp->noise_db_init;
     c.snr = lp->snr_threshold; c.speaking = lp->speaking_score; c.silence_score = lp->silence_score;
     c.flags = flags; c.noise_trace = noise_trace;

@@ -113,9 +113,7 @@ class FsmnEngine:
               snr_threshold=10.0, noise_init_dB=30.0, one_minus_speech_threshold=1.0, return_noise=False):
         """padded_i16 [B, (W-1)*stride + L] int16 on the window grid -> silence flags u8 [B, W*(T-lb)+lb]."""
         t = self.torch
-        lb, stride = self.grid(look_backward_s)
-        if lb == 0:
-            lb = 1
+        lb, stride = self.grid(look_backward_s)        # lb may be 0: W*T flags, no tail (Inference_FSMN_VAD_ONNX.py:79-86)
         a = padded_i16.to(self.device).contiguous()
         B, W = a.shape[0], int(windows_per_clip)
         logmel, db = self.features(a, W, stride)
