@@ -218,6 +218,66 @@ def _trace(fn):
     return {k: round(v, 4) for k, v in sorted(tr.ms.items(), key=lambda kv: -kv[1])}, tr.calls
 
 
+# ------------------------------------------------------------------------------------------------ CPU baselines
+# (the ONLY functions of this file that touch oracle/: the torch-CPU restatement timed on the host, batch 1, one call per window,
+#  exactly how the reference drives its ORT session -- a reported, non-target baseline)
+def _cpu_entry(rate, thr_n, sample):
+    return {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(), "sample": sample}
+
+
+def cpu_baseline_fsmn(budget_s, stride):
+    import torch
+    from oracle import fsmn as ofs
+    from vadx import weights
+    w = {k: torch.from_numpy(v) for k, v in weights.fsmn_synthetic(1234).items()}
+    fe = ofs.Frontend(16000)
+    a = torch.from_numpy(weights.burst_clips(1, 16000, seed=3)).reshape(1, 1, -1)
+    caches = [torch.zeros(1, 128, 19, 1) for _ in range(4)]
+    thr, nz = torch.tensor([1.0]), torch.tensor([4.0])
+    rate, thr_n, calls, el = timed_cpu(lambda: ofs.forward(fe, w, a, caches, thr, nz), stride / 512.0, budget_s)
+    return _cpu_entry(rate, thr_n, f"{calls} one-second windows, batch 1, one oracle call per window at stride {stride} "
+                                   f"(torch-CPU stand-in for ORT-CPU), {el:.1f} s")
+
+
+def cpu_baseline_marblenet(budget_s, n):
+    import torch
+    from oracle import marblenet as omb
+    from vadx import weights
+    w = {k: torch.from_numpy(v) for k, v in weights.marblenet_synthetic(1234).items()}
+    fe = omb.Frontend()
+    a = torch.from_numpy(weights.burst_clips(1, n, seed=4)).reshape(1, 1, -1)
+    rate, thr_n, ncall, el = timed_cpu(lambda: omb.forward(fe, w, a), n / 512.0, budget_s)
+    return _cpu_entry(rate, thr_n, f"{ncall} clips of {n} samples, batch 1, one oracle call per clip (torch-CPU stand-in for "
+                                   f"ORT-CPU), {el:.1f} s")
+
+
+def cpu_baseline_firered(budget_s):
+    import torch
+    from oracle import firered as ofr
+    from vadx import weights
+    w = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in weights.firered_synthetic(1234).items()}
+    fe = ofr.Frontend()
+    a = torch.from_numpy(weights.burst_clips(1, 16000, seed=5)).reshape(1, 1, -1)
+    rate, thr_n, ncall, el = timed_cpu(lambda: ofr.forward(fe, w, a), 16000 / 512.0, budget_s)
+    return _cpu_entry(rate, thr_n, f"{ncall} one-second windows, batch 1, one oracle call per window (torch-CPU stand-in for "
+                                   f"ORT-CPU), {el:.1f} s")
+
+
+def cpu_baseline_dfsmn(budget_s, stride):
+    import torch
+    from oracle import dfsmn as od
+    from vadx import weights
+    w = {k: torch.from_numpy(v) for k, v in weights.dfsmn_synthetic(1234).items()}
+    w["mask.shift"] = w["mask.shift"] + torch.log(torch.tensor(32768.0 ** 2))
+    fe = od.Frontend()
+    a = torch.from_numpy(weights.burst_clips(1, 16001, seed=6)).reshape(1, 1, -1)
+    b = torch.from_numpy(weights.burst_clips(1, 16001, seed=7)).reshape(1, 1, -1)
+    nf = weights.DFSMN_MASK["layers"]
+    rate, thr_n, ncall, el = timed_cpu(lambda: od.forward(fe, w, a, b, nf), stride / 512.0, budget_s, threads=(4,))
+    return _cpu_entry(rate, thr_n, f"{ncall} windows of 16001 samples, batch 1, one oracle call per window at stride {stride} "
+                                   f"(torch-CPU stand-in for ORT-CPU; the reference pins 4 ORT threads for this model), {el:.1f} s")
+
+
 # ------------------------------------------------------------------------------------------------ the workloads
 def fsmn_c3(torch, device, reps, cpu, clips=4096, log=lambda m: None):
     from vadx import fsmn, weights
@@ -243,16 +303,7 @@ def fsmn_c3(torch, device, reps, cpu, clips=4096, log=lambda m: None):
            "hbm": _hbm(clips * (padded * 2 + (W * (eng.T - lb) + lb)), ms), "cpu_baseline": None}
     del audio
     if cpu:
-        from oracle import fsmn as ofs
-        w = {k: torch.from_numpy(v) for k, v in weights.fsmn_synthetic(1234).items()}
-        fe = ofs.Frontend(16000)
-        a = torch.from_numpy(weights.burst_clips(1, 16000, seed=3)).reshape(1, 1, -1)
-        caches = [torch.zeros(1, 128, 19, 1) for _ in range(4)]
-        thr, nz = torch.tensor([1.0]), torch.tensor([4.0])
-        rate, thr_n, calls, el = timed_cpu(lambda: ofs.forward(fe, w, a, caches, thr, nz), stride / 512.0, cpu)
-        out["cpu_baseline"] = {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(),
-                               "sample": f"{calls} one-second windows, batch 1, one oracle call per window at stride {stride} "
-                                         f"(torch-CPU stand-in for ORT-CPU), {el:.1f} s"}
+        out["cpu_baseline"] = cpu_baseline_fsmn(cpu, stride)
     return out
 
 
@@ -279,14 +330,7 @@ def marblenet_c4(torch, device, reps, cpu, clips=8192, log=lambda m: None, tag="
            "hbm": _hbm(clips * (n * 2 + 2 * Tout * 4), ms), "cpu_baseline": None}
     del audio
     if cpu:
-        from oracle import marblenet as omb
-        w = {k: torch.from_numpy(v) for k, v in weights.marblenet_synthetic(1234).items()}
-        fe = omb.Frontend()
-        a = torch.from_numpy(weights.burst_clips(1, n, seed=4)).reshape(1, 1, -1)
-        rate, thr_n, ncall, el = timed_cpu(lambda: omb.forward(fe, w, a), n / 512.0, cpu)
-        out["cpu_baseline"] = {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(),
-                               "sample": f"{ncall} clips of {n} samples, batch 1, one oracle call per clip (torch-CPU stand-in "
-                                         f"for ORT-CPU), {el:.1f} s"}
+        out["cpu_baseline"] = cpu_baseline_marblenet(cpu, n)
     return out
 
 
@@ -310,14 +354,7 @@ def firered_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None):
            "hbm": _hbm(clips * (n * 2 + W * 98 * 4), ms), "cpu_baseline": None}
     del audio
     if cpu:
-        from oracle import firered as ofr
-        w = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in weights.firered_synthetic(1234).items()}
-        fe = ofr.Frontend()
-        a = torch.from_numpy(weights.burst_clips(1, 16000, seed=5)).reshape(1, 1, -1)
-        rate, thr_n, ncall, el = timed_cpu(lambda: ofr.forward(fe, w, a), 16000 / 512.0, cpu)
-        out["cpu_baseline"] = {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(),
-                               "sample": f"{ncall} one-second windows, batch 1, one oracle call per window (torch-CPU stand-in "
-                                         f"for ORT-CPU), {el:.1f} s"}
+        out["cpu_baseline"] = cpu_baseline_firered(cpu)
     return out
 
 
@@ -350,17 +387,7 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
            "hbm": _hbm(clips * (2 * padded * 2 + W * eng.T_A * 4), ms), "cpu_baseline": None}
     del near, far
     if cpu:
-        from oracle import dfsmn as od
-        w = {k: torch.from_numpy(v) for k, v in weights.dfsmn_synthetic(1234).items()}
-        w["mask.shift"] = w["mask.shift"] + torch.log(torch.tensor(32768.0 ** 2))
-        fe = od.Frontend()
-        a = torch.from_numpy(weights.burst_clips(1, 16001, seed=6)).reshape(1, 1, -1)
-        b = torch.from_numpy(weights.burst_clips(1, 16001, seed=7)).reshape(1, 1, -1)
-        nf = weights.DFSMN_MASK["layers"]
-        rate, thr_n, ncall, el = timed_cpu(lambda: od.forward(fe, w, a, b, nf), stride / 512.0, cpu, threads=(4,))
-        out["cpu_baseline"] = {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(),
-                               "sample": f"{ncall} windows of 16001 samples, batch 1, one oracle call per window at stride {stride} "
-                                         f"(torch-CPU stand-in for ORT-CPU; the reference pins 4 ORT threads for this model), {el:.1f} s"}
+        out["cpu_baseline"] = cpu_baseline_dfsmn(cpu, stride)
     return out
 
 

@@ -236,7 +236,8 @@ class DfsmnEngine:
         self.torch = t = _lib.require_gpu()
         self.device = t.device(device)
         _lib.lib()                 # load / symbol check now; `self.lib` resolves per call (so _lib.trace() sees the launches)
-        w = _w.dfsmn_synthetic(1234) if weights is None else weights
+        from . import checkpoints as _ck
+        w = _ck.resolve("dfsmn", weights)
         w = {k: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in w.items()}
         self.sub_batch = int(sub_batch)
         self.iccrn = Iccrn(w, device)

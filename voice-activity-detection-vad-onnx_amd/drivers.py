@@ -32,7 +32,7 @@ def inference_silero(test_vad_audio="./vad_sample.wav", model=None, save_timesta
     """Silero/Inference_Silero_VAD_ONNX.py:80-120."""
     from . import silero
     files = _as_list(test_vad_audio)
-    model = silero.load_silero_vad(onnx=True, use_cpu=True, path="synthetic:1234") if model is None else model
+    model = silero.load_silero_vad(onnx=True, use_cpu=True, path=model) if (model is None or isinstance(model, (str, dict))) else model
     clips = [audio_io.load_wav(f, SAMPLE_RATE).astype(np.float32) * np.float32(0.000030517578) for f in files]
     echo("\nStart to run the VAD process.")
     t0 = time.time()
@@ -57,7 +57,7 @@ def inference_fsmn(test_vad_audio="./vad_sample.wav", engine=None, save_timestam
     """FSMN/Inference_FSMN_VAD_ONNX.py:66-260."""
     from . import fsmn
     files = _as_list(test_vad_audio)
-    engine = fsmn.FsmnEngine() if engine is None else engine
+    engine = fsmn.FsmnEngine(engine) if (engine is None or isinstance(engine, (str, dict))) else engine
     clips = [audio_io.load_wav(f, 16000) for f in files]
     echo("\nRunning the FSMN_VAD by ONNX Runtime.")
     t0 = time.time()
@@ -79,7 +79,7 @@ def inference_firered(test_vad_audio="./vad_sample.wav", engine=None, save_times
     """FireRedVAD/Inference_FireRed_ONNX.py:523-613 (RUN_VAD)."""
     from . import firered
     files = _as_list(test_vad_audio)
-    engine = firered.FireRedEngine() if engine is None else engine
+    engine = firered.FireRedEngine(engine) if (engine is None or isinstance(engine, (str, dict))) else engine
     clips = [audio_io.load_wav(f, 16000) for f in files]
     if NORMALIZE_AUDIO:
         clips = [timestamps.normalise_audio(c) for c in clips]
@@ -162,7 +162,7 @@ def inference_marblenet(test_vad_audio="./vad_sample.wav", engine=None, save_tim
     """NVIDIA_.../Inference_NVIDIA_MarbleNet_VAD_ONNX.py:120-422 (dynamic axis: one window per clip)."""
     from . import marblenet
     files = _as_list(test_vad_audio)
-    engine = marblenet.MarbleNetEngine() if engine is None else engine
+    engine = marblenet.MarbleNetEngine(engine) if (engine is None or isinstance(engine, (str, dict))) else engine
     clips = [audio_io.load_wav(f, 16000) for f in files]
     if NORMALIZE_AUDIO:
         clips = [timestamps.normalise_audio(c) for c in clips]
@@ -185,7 +185,7 @@ def inference_dfsmn(test_near_end_audio="./examples/nearend_mic.wav", test_far_e
     mask-net VAD -> look-ahead vote -> timestamps (both text files).  Lists of paths run as a batch of clip pairs."""
     from . import dfsmn
     nears, fars = _as_list(test_near_end_audio), _as_list(test_far_end_audio)
-    engine = dfsmn.DfsmnEngine() if engine is None else engine
+    engine = dfsmn.DfsmnEngine(engine) if (engine is None or isinstance(engine, (str, dict))) else engine
     echo(f"\nTest Input Near_End Audio: {test_near_end_audio}\nTest Input Far_End Audio: {test_far_end_audio}")
     all_ts = []
     t0 = time.time()
@@ -207,9 +207,9 @@ def inference_dfsmn_near_only(test_vad_audio="./vad_sample.wav", engine=None, sa
     carry the export's baked white-noise constants (DfsmnEngine.set_near_only_constants)."""
     from . import dfsmn, weights
     files = _as_list(test_vad_audio)
-    if engine is None:
-        engine = dfsmn.DfsmnEngine()
-        engine.set_near_only_constants(*weights.dfsmn_near_only_constants(1234))
+    if engine is None or isinstance(engine, (str, dict)):
+        raise ValueError("inference_dfsmn_near_only needs a DfsmnEngine carrying the export's baked white-noise constants "
+                         "(DfsmnEngine.set_near_only_constants); weights.dfsmn_near_only_constants(seed) gives a stand-in")
     echo(f"\nTest Input Audio: {test_vad_audio}")
     all_ts = []
     t0 = time.time()

@@ -8,6 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from . import checkpoints as _checkpoints
 from . import frontend as _frontend
 from . import vadpost as _vadpost
 from . import weights as _weights
@@ -27,7 +28,7 @@ class FireRedEngine:
         torch = _lib.require_gpu()
         self.torch = torch
         self.device = torch.device(device)
-        w = _weights.firered_synthetic(1234) if weights is None else weights
+        w = _checkpoints.resolve("firered", weights)
         c = dict(w["cfg"])
         w = {k: (np.ascontiguousarray(np.asarray(v), dtype=np.float32) if k != "cfg" else v) for k, v in w.items()}
         self.L = int(input_audio_length)

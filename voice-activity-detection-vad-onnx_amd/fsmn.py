@@ -12,6 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from . import checkpoints as _checkpoints
 from . import frontend as _frontend
 from . import timestamps as _ts
 from . import weights as _weights
@@ -31,7 +32,7 @@ class FsmnEngine:
         torch = _lib.require_gpu()
         self.torch = torch
         self.device = torch.device(device)
-        w = _weights.fsmn_synthetic(1234) if weights is None else weights
+        w = _checkpoints.resolve("fsmn", weights)
         w = {k: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in w.items()}
         self.L = int(input_audio_length)
         self.fe = _frontend.Frontend("fsmn", self.L, device=device)

@@ -11,6 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from . import checkpoints as _checkpoints
 from . import frontend as _frontend
 from . import vadpost as _vadpost
 from . import weights as _weights
@@ -32,7 +33,7 @@ class MarbleNetEngine:
         torch = _lib.require_gpu()
         self.torch = torch
         self.device = torch.device(device)
-        w = _weights.marblenet_synthetic(1234) if weights is None else weights
+        w = _checkpoints.resolve("marblenet", weights)
         blocks = _weights.MARBLENET_BLOCKS if blocks is None else blocks
         eps = _weights.MARBLENET_BN_EPS if bn_eps is None else bn_eps
         self.stages = []          # (cfg, dev tensors..., block_start flag)

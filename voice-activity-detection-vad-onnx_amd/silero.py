@@ -24,17 +24,11 @@ HIDDEN = 128
 
 
 def _as_weight_dict(path_or_weights):
-    if isinstance(path_or_weights, dict):
-        w = path_or_weights
-    elif path_or_weights is None or path_or_weights == "" or str(path_or_weights).startswith("synthetic"):
-        seed = 1234
-        s = str(path_or_weights or "")
-        if ":" in s:
-            seed = int(s.split(":", 1)[1])
-        w = _weights.silero_synthetic(seed)
-    else:
-        with np.load(str(path_or_weights)) as z:      # .npz with the keys of weights.silero_synthetic()
-            w = {k: z[k] for k in z.files}
+    """dict | silero_vad.onnx | .npz with the keys of weights.silero_synthetic() | the explicit opt-in "synthetic:<seed>".
+    None / "" raises: the reference's default (the silero_vad package's bundled model, model.py:9-41) does not exist here
+    and random weights must never be a silent default (checkpoints.resolve)."""
+    from . import checkpoints
+    w = checkpoints.resolve("silero", path_or_weights)
     w = {k: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in w.items()}
     _weights.silero_check(w)
     return w
@@ -310,8 +304,10 @@ class OnnxWrapper:
 
 
 def load_silero_vad(onnx=True, opset_version=16, use_cpu=True, path="", device="cuda:0"):
-    """Constructor of the boundary object (reference signature; `use_cpu` is accepted and ignored:
-    this build runs on the MI355X only)."""
+    """Constructor of the boundary object (reference signature; `use_cpu` is accepted and ignored: this build runs on the
+    MI355X only).  `path` = the silero_vad.onnx the reference would hand to onnxruntime (its initialisers are read by
+    vadx.onnx_reader), a .npz of arrays, or "synthetic:<seed>"; the reference's `path=""` default (the pip package's bundled
+    file) cannot be honoured here and raises."""
     if onnx and opset_version not in (15, 16):
         raise Exception("Available ONNX opset_version: [15, 16]")
     return OnnxWrapper(path or None, force_onnx_cpu=use_cpu, device=device)
