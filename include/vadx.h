@@ -143,7 +143,11 @@ typedef struct vadx_frontend_cfg {
     int   prep;        /* 0: x-mean(window), then y[n]=a[n]-0.97*a[n-1], y[0]=a[0]        (FSMN)
                           1: y[n]=k0*x[n-1]+k1*x[n], x[-1]=0                             (MarbleNet, FireRed)
                           2: y = k1*x - mean(k1*x)                                       (DFSMN STFT-B)
-                          3/4/5: DFSMN feature streams, see vadx_frontend_logmel_ex */
+                          3/4/5: DFSMN feature streams, see vadx_frontend_logmel_ex
+                          6: linear resample (in_window_len -> window_len samples), THEN prep 1   (IN_SAMPLE_RATE > 16000)
+                          7: prep 1 at the input rate, THEN linear resample                    (IN_SAMPLE_RATE < 16000)
+                             = F.interpolate(mode='linear', align_corners=False) of the exports built for another input
+                             rate (Export_NVIDIA_MarbleNet_VAD.py:237-254, FireRedVAD/Export_FireRedVAD.py:431-449) */
     float k0, k1;
     int   center_pad;  /* zeros on each side of the window (n_fft/2, or 0 for snip-edges) */
     int   tap0, taps;  /* non-zero span of the centre-padded analysis window inside n_fft */
@@ -153,7 +157,9 @@ typedef struct vadx_frontend_cfg {
     int   log_mode;    /* 0: log(max(x,floor))   1: log(x+floor) */
     float log_floor;
     int   frames;      /* frames per window */
-    int   window_len;  /* samples per window */
+    int   window_len;  /* samples per window (at 16 kHz, i.e. after the in-graph resample of prep 6 / 7) */
+    int   in_window_len; /* prep 6 / 7: samples per window in the audio buffer (input rate); 0 otherwise */
+    float rs_scale;    /* prep 6 / 7: source samples per output sample, float32(1 / scale_factor) as torch computes it */
 } vadx_frontend_cfg;
 
 size_t vadx_frontend_packed_floats(const vadx_frontend_cfg *cfg);

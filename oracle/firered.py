@@ -24,9 +24,10 @@ class Frontend:
         self.fbank = omel.kaldi_mel_filterbank(NFFT, NMELS, SR, 20.0, 0.0).unsqueeze(0)   # [1,80,201]
 
 
-def log_mel(fe, audio_i16):
-    """int16 [B,1,L] -> [B,80,T], T = (L-400)//160+1. ref: Export_FireRedVAD.py:428-461."""
-    a = ostft.prep_two_tap(audio_i16, 1.0)
+def log_mel(fe, audio_i16, in_sample_rate=16000):
+    """int16 [B,1,L] -> [B,80,T], T = (L'-400)//160+1 with L' the window length after the in-graph resample.
+    ref: Export_FireRedVAD.py:428-461."""
+    a = ostft.prep_two_tap(audio_i16, 1.0, in_sample_rate)
     re, im = ostft.stft(a, fe.cos_k, fe.sin_k, HOP, center_pad=False)
     return omel.log_mel(re, im, fe.fbank, 1e-7, "clamp")
 
@@ -64,9 +65,9 @@ def detect_model(w, feat):
     return torch.sigmoid(pw(x, "out_w", "out_b"))
 
 
-def forward(fe, w, audio_i16):
+def forward(fe, w, audio_i16, in_sample_rate=16000):
     """session.run equivalent: int16 [B,1,16000] -> probs [B,odim,98]. ref: Export_FireRedVAD.py:420-467."""
-    return detect_model(w, log_mel(fe, audio_i16))
+    return detect_model(w, log_mel(fe, audio_i16, in_sample_rate))
 
 
 def valid_frame_count(num_samples):

@@ -53,9 +53,9 @@ class Frontend:
         self.fbank = omel.melscale_fbanks(257, 0, 8000, 80, 16000, "slaney", "slaney").t().unsqueeze(0)
 
 
-def log_mel(fe, audio_i16):
-    """int16 [B,1,L] -> [B,80,T], T = L//160+1. ref: Export_NVIDIA_MarbleNet_VAD.py:236-262."""
-    a = ostft.prep_two_tap(audio_i16, 1.0 / 32768.0)
+def log_mel(fe, audio_i16, in_sample_rate=16000):
+    """int16 [B,1,L] -> [B,80,T], T = L'//160+1 (L' = length after the in-graph resample). ref: Export_NVIDIA_MarbleNet_VAD.py:236-262."""
+    a = ostft.prep_two_tap(audio_i16, 1.0 / 32768.0, in_sample_rate)
     re, im = ostft.stft(a, fe.cos_k, fe.sin_k, 160, True)
     return omel.log_mel(re, im, fe.fbank, 1e-7, "add")
 
@@ -90,9 +90,9 @@ def encoder(w, x):
     return x, length
 
 
-def forward(fe, w, audio_i16):
+def forward(fe, w, audio_i16, in_sample_rate=16000):
     """session.run equivalent: int16 [B,1,L] -> (score_silence, score_active [B,T',1], signal_len-1)."""
-    enc, length = encoder(w, log_mel(fe, audio_i16))
+    enc, length = encoder(w, log_mel(fe, audio_i16, in_sample_rate))
     logits = F.linear(enc.transpose(1, 2), w["dec_w"], w["dec_b"])
     score = torch.softmax(logits, dim=-1)
     return score[..., :1], score[..., 1:], length - 1

@@ -89,9 +89,19 @@ def prep_fsmn(audio_i16):
     return torch.cat([a[:, :, :1], a[:, :, 1:] - 0.97 * a[:, :, :-1]], dim=-1)
 
 
-def prep_two_tap(audio_i16, scale):
-    """left-zero-padded 2-tap conv [-0.97*scale, scale].
-    ref: Export_NVIDIA_MarbleNet_VAD.py:199-204,245-246 (scale = 1/32768);
-         FireRedVAD/Export_FireRedVAD.py:396-400,440 (scale = 1)."""
+def prep_two_tap(audio_i16, scale, in_sample_rate=16000):
+    """left-zero-padded 2-tap conv [-0.97*scale, scale], with the export's in-graph resample to 16 kHz when it was built for
+    another IN_SAMPLE_RATE: F.interpolate(linear, align_corners=False, scale_factor = 1 / (in_rate / 16000)) BEFORE the conv
+    for a higher input rate, AFTER it for a lower one.
+    ref: Export_NVIDIA_MarbleNet_VAD.py:199-204,237-254 (scale = 1/32768);
+         FireRedVAD/Export_FireRedVAD.py:396-400,431-449 (scale = 1)."""
     k = torch.tensor([[[-0.97 * scale, scale]]], dtype=torch.float32)
-    return F.conv1d(F.pad(audio_i16.float(), (1, 0)), k)
+    a = audio_i16.float()
+    rate_scale = in_sample_rate / 16000.0
+    model_rate_scale = 1.0 / rate_scale
+    if rate_scale > 1.0:
+        a = F.interpolate(a, scale_factor=model_rate_scale, mode="linear", align_corners=False)
+    a = F.conv1d(F.pad(a, (1, 0)), k)
+    if rate_scale < 1.0:
+        a = F.interpolate(a, scale_factor=model_rate_scale, mode="linear", align_corners=False)
+    return a

@@ -890,11 +890,86 @@ def gen_marblenet_hostloop():
     save("marblenet_hostloop", **out)
 
 
+
+def gen_resample():
+    """In-graph linear resample of exports built with IN_SAMPLE_RATE != 16000 (F.interpolate before / after the pre-emphasis):
+    the FireRedVAD_ONNX wrapper end to end, and the front half of NVIDIA_VAD_Optimized (audio -> log-mel) captured at the
+    encoder's input (the NeMo encoder itself is not in the reference tree: a pass-through stand-in receives the features)."""
+    print("in-graph resample (FireRed wrapper, MarbleNet front half)")
+    out = {}
+    stft_mod = R.load_module("FireRedVAD/STFT_Process.py", "ref_stft_v2f")
+    ns = {"torch": torch, "math": __import__("math"), "np": np, "STFT_Process": stft_mod.STFT_Process}
+    R.select_nodes("FireRedVAD/Export_FireRedVAD.py",
+                   {"FSMN", "DFSMNBlock", "DFSMN", "DetectModel", "FireRedVAD_ONNX", "build_kaldi_mel_filterbank"}, ns)
+    cfg = dict(weights.FIRERED_CFG, R=3, M=1, H=64, P=32, N1=8, S1=1, N2=4, S2=1)
+    w = weights.firered_synthetic(7, cfg)
+    dm = ns["DetectModel"](types.SimpleNamespace(**cfg)).eval()
+    sd = {"dfsmn.fc1.0.weight": w["fc1_w"][:, :, None], "dfsmn.fc1.0.bias": w["fc1_b"],
+          "dfsmn.fc2.0.weight": w["fc2_w"][:, :, None], "dfsmn.fc2.0.bias": w["fc2_b"],
+          "dfsmn.fsmn1.lookback_filter.weight": w["fsmn0_lb"][:, None, :], "dfsmn.fsmn1.lookahead_filter.weight": w["fsmn0_la"][:, None, :],
+          "out.weight": w["out_w"][:, :, None], "out.bias": w["out_b"]}
+    for r in range(1, cfg["R"]):
+        p = f"dfsmn.fsmns.{r - 1}."
+        sd[p + "fc1.0.weight"], sd[p + "fc1.0.bias"] = w[f"blk{r}_fc1_w"][:, :, None], w[f"blk{r}_fc1_b"]
+        sd[p + "fc2.weight"] = w[f"blk{r}_fc2_w"][:, :, None]
+        sd[p + "fsmn.lookback_filter.weight"] = w[f"fsmn{r}_lb"][:, None, :]
+        sd[p + "fsmn.lookahead_filter.weight"] = w[f"fsmn{r}_la"][:, None, :]
+    sd["dfsmn.dnns.0.weight"], sd["dfsmn.dnns.0.bias"] = w["dnn0_w"][:, :, None], w["dnn0_b"]
+    dm.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    out["firered_cfg"] = np.array([cfg[k] for k in ("idim", "R", "M", "H", "P", "N1", "S1", "N2", "S2", "odim")])
+    for rate, n in ((8000, 8000), (48000, 48000), (44100, 44100), (22050, 12345)):
+        model = ns["FireRedVAD_ONNX"](dm, 400, 160, 400, 80, 16000, 0.97, "povey", rate).eval()
+        a = weights.burst_clips(1, n, seed=rate).reshape(1, 1, -1)
+        with torch.no_grad():
+            out[f"firered_{rate}_probs"] = model(T(a)).numpy()
+        out[f"firered_{rate}_audio"] = a
+
+    # MarbleNet: the reference wrapper with a stand-in `nvidia_vad` whose encoder hands back the log-mel features it is given
+    stft_v2 = R.load_module("NVIDIA_Frame_VAD_Multilingual_MarbleNet/STFT_Process.py", "ref_stft_v2")
+    import torchaudio
+    ns2 = {"torch": torch, "F": torch.nn.functional, "torchaudio": torchaudio, "np": np}
+    R.select_nodes("NVIDIA_Frame_VAD_Multilingual_MarbleNet/Export_NVIDIA_MarbleNet_VAD.py",
+                   {"NVIDIA_VAD_Optimized", "fold_encoder_batchnorms", "fold_bn_into_conv1d"}, ns2)
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = torch.nn.ModuleList()
+            self.seen = None
+
+        def forward(self, packed):
+            feats, length = packed
+            self.seen = feats[0]
+            return feats[0], length
+
+    class Dec(torch.nn.Module):
+        def forward(self, x):
+            return x[..., :2]
+
+    class Stand(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder, self.decoder = Enc(), Dec()
+
+    for rate, n in ((8000, 8000), (48000, 48000), (32000, 20001)):
+        stft = stft_v2.STFT_Process("stft_B", n_fft=512, win_length=400, hop_len=160, max_frames=0, window_type="hann_sym",
+                                    center_pad=True, pad_mode="constant").eval()
+        net = Stand()
+        model = ns2["NVIDIA_VAD_Optimized"](net, stft, 512, 80, 16000, 0.97, rate).eval()
+        a = weights.burst_clips(1, n, seed=rate + 1).reshape(1, 1, -1)
+        with torch.no_grad():
+            model(T(a))
+        out[f"marble_{rate}_audio"] = a
+        out[f"marble_{rate}_logmel"] = net.encoder.seen.numpy()
+    save("resample", **out)
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:])
     gens = dict(stft=gen_stft, host=gen_host, vadpost=gen_vadpost, silero_host=gen_silero_host,
                 fsmn=gen_fsmn, firered=gen_firered, firered_stream=gen_firered_stream, firered_ckpt=gen_firered_ckpt, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn, dfsmn_near_only=gen_dfsmn_near_only,
-                fsmn_extra=gen_fsmn_extra, host_extra=gen_host_extra, marblenet_hostloop=gen_marblenet_hostloop)
+                fsmn_extra=gen_fsmn_extra, host_extra=gen_host_extra, marblenet_hostloop=gen_marblenet_hostloop,
+                resample=gen_resample)
     for name, fn in gens.items():
         if not which or name in which:
             fn()

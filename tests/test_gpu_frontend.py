@@ -80,3 +80,52 @@ def test_logmel_large_batch_invariance():
     out = fe.logmel(big, windows_per_clip=15, win_stride=11040).view(64, 4, 15, 101, 80)
     assert torch.equal(out[0], out[63]) and torch.equal(out[0], out[31])
     assert bool(torch.isfinite(out).all())
+
+
+# ------------------------------------------------------------------ in-graph linear resample (IN_SAMPLE_RATE != 16000)
+@pytest.mark.parametrize("preset,rate,L,W", [
+    ("firered", 8000, 8000, 2), ("firered", 48000, 48000, 1), ("firered", 44100, 44100, 2), ("firered", 22050, 12345, 1),
+    ("marblenet", 8000, 8000, 2), ("marblenet", 48000, 48000, 1), ("marblenet", 32000, 20001, 1), ("marblenet", 11025, 30000, 2),
+])
+def test_resampled_logmel_matches_oracle(preset, rate, L, W):
+    """prep 6 (interpolate, then pre-emphasis: input rate above 16 kHz) and prep 7 (pre-emphasis, then interpolate: below) of
+    the fused kernel vs torch's own F.interpolate in the oracle (Export_NVIDIA_MarbleNet_VAD.py:237-254,
+    FireRedVAD/Export_FireRedVAD.py:431-449)."""
+    from oracle import marblenet as omb
+    B = 2
+    clips = weights.burst_clips(B, W * L, seed=rate + L)
+    fe = frontend.Frontend(preset, L, in_sample_rate=rate)
+    assert fe.cfg.prep == (6 if rate > 16000 else 7) and fe.window_len == int(np.floor(L * (1.0 / (rate / 16000.0))))
+    out = fe.logmel(clips, windows_per_clip=W).cpu().numpy()
+    wins = T(np.stack([clips[b, w * L:(w + 1) * L] for b in range(B) for w in range(W)])).unsqueeze(1)
+    ref = (ofr.log_mel(ofr.Frontend(), wins, rate) if preset == "firered" else omb.log_mel(omb.Frontend(), wins, rate)).transpose(1, 2).numpy()
+    assert out.shape == ref.shape == (B * W, fe.frames, 80)
+    err = np.abs(out - ref)
+    big = ref > np.log(1e-3 if preset == "firered" else 1e-10)
+    assert err[big].max() < FEAT_ATOL, err[big].max()
+    assert err.max() < 5e-3, err.max()
+
+
+@pytest.mark.parametrize("rate", [8000, 48000, 32000])
+def test_resampled_marblenet_frontend_matches_reference_fixture(golden, rate):
+    """... and vs the reference wrapper's own features (tests/golden/resample.npz: NVIDIA_VAD_Optimized front half)."""
+    g = golden("resample")
+    a = g[f"marble_{rate}_audio"]
+    fe = frontend.Frontend("marblenet", a.shape[-1], in_sample_rate=rate)
+    out = fe.logmel(a.reshape(1, -1)).cpu().numpy()[0]
+    want = g[f"marble_{rate}_logmel"][0].T
+    assert out.shape == want.shape
+    assert np.abs(out - want)[want > np.log(1e-10)].max() < FEAT_ATOL and np.abs(out - want).max() < 5e-3
+
+
+@pytest.mark.parametrize("rate", [8000, 48000, 44100, 22050])
+def test_resampled_firered_session_matches_reference_fixture(golden, rate):
+    """FireRedVAD_ONNX(in_sample_rate) end to end: frame scores within 1e-4 of the reference wrapper's."""
+    from vadx import firered
+    g = golden("resample")
+    cfg = dict(zip(("idim", "R", "M", "H", "P", "N1", "S1", "N2", "S2", "odim"), (int(v) for v in g["firered_cfg"])))
+    a = g[f"firered_{rate}_audio"]
+    sess = firered.FireRedSession(weights.firered_synthetic(7, cfg), a.shape[-1], in_sample_rate=rate)
+    probs = sess.run(None, {"audio": a})[0]
+    assert probs.shape == g[f"firered_{rate}_probs"].shape
+    np.testing.assert_allclose(probs, g[f"firered_{rate}_probs"], rtol=0, atol=1e-4)

@@ -190,3 +190,30 @@ def test_look_backward_zero(golden, n):
         assert flags.shape[0] == W * 101 == len(want_flags)
         assert np.array_equal(flags, np.array(want_flags, bool))
         assert got[b] == want_ts
+
+
+def test_fp16_io_session_matches_f32_session():
+    """The fp16-boundary model (FSMN/Optimize_ONNX.py:48-54, driver :157-164): float16 feeds / fetches, float32 arithmetic.
+    Fed float16-representable values, the uint8 score equals the float32 session's and caches / noisy_dB are its outputs
+    rounded once to float16."""
+    w = weights.fsmn_synthetic(1234)
+    s32, s16 = fsmn.FsmnSession(w), fsmn.FsmnSession(w, io_dtype="float16")
+    assert "float16" in s16._inputs_meta[1].type and "float16" in s16._outputs_meta[5].type and s16._inputs_meta[0].type == "tensor(int16)"
+    rng = np.random.default_rng(5)
+    audio = weights.burst_clips(1, 16000 + 11040, seed=21)
+    c16 = [(rng.standard_normal((1, 128, 19, 1)) * 0.3).astype(np.float16) for _ in range(4)]
+    thr16, nz16 = np.array([1.0], np.float16), np.array([(30.0 + 10.0) * 0.1], np.float16)
+    for k in range(2):
+        a = audio[:, k * 11040:k * 11040 + 16000].reshape(1, 1, -1)
+        feeds16 = {"audio": a, "one_minus_speech_threshold": thr16, "noise_average_dB": nz16, **{f"cache_{i}": c16[i] for i in range(4)}}
+        feeds32 = {k2: (v if v.dtype == np.int16 else v.astype(np.float32)) for k2, v in feeds16.items()}
+        o16, o32 = s16.run(None, feeds16), s32.run(None, feeds32)
+        assert o16[0].dtype == np.uint8 and np.array_equal(o16[0], o32[0])
+        for i in range(1, 6):
+            assert o16[i].dtype == np.float16 and o16[i].shape == o32[i].shape
+            assert np.array_equal(o16[i], o32[i].astype(np.float16), equal_nan=True)
+        c16 = o16[1:5]                                     # caches carried in float16, as the reference driver carries them
+    with pytest.raises(ValueError, match="expected: \\(tensor\\(float16\\)\\)"):
+        s16.run(None, feeds32)
+    with pytest.raises(ValueError, match="expected: \\(tensor\\(float\\)\\)"):
+        s32.run(None, feeds16)

@@ -405,3 +405,24 @@ def test_product_kaldi_mel_bank_is_the_reference_bank(golden):
     g = golden("firered_forward")
     fb = tables.as_np(tables.mel_filters_kaldi(400, 80, 16000, 20.0, 0.0))
     assert fb.shape == g["kaldi_fbank"].shape and np.array_equal(fb, g["kaldi_fbank"])
+
+
+@pytest.mark.parametrize("rate", [8000, 48000, 44100, 22050])
+def test_firered_in_graph_resample(golden, rate):
+    """FireRedVAD_ONNX built with IN_SAMPLE_RATE != 16000 (Export_FireRedVAD.py:431-449): interpolate before the pre-emphasis
+    for higher rates, after it for lower ones."""
+    g = golden("resample")
+    cfg = dict(zip(("idim", "R", "M", "H", "P", "N1", "S1", "N2", "S2", "odim"), (int(v) for v in g["firered_cfg"])))
+    w = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in weights.firered_synthetic(7, cfg).items()}
+    probs = ofr.forward(ofr.Frontend(), w, T(g[f"firered_{rate}_audio"]), rate)
+    assert probs.shape == g[f"firered_{rate}_probs"].shape
+    np.testing.assert_allclose(probs.numpy(), g[f"firered_{rate}_probs"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("rate", [8000, 48000, 32000])
+def test_marblenet_in_graph_resample_frontend(golden, rate):
+    from oracle import marblenet as omb
+    g = golden("resample")
+    lm = omb.log_mel(omb.Frontend(), T(g[f"marble_{rate}_audio"]), rate)
+    assert lm.shape == g[f"marble_{rate}_logmel"].shape
+    np.testing.assert_allclose(lm.numpy(), g[f"marble_{rate}_logmel"], rtol=0, atol=2e-5)

@@ -33,7 +33,7 @@ class FrontendCfg(C.Structure):
     _fields_ = [("prep", C.c_int), ("k0", C.c_float), ("k1", C.c_float), ("center_pad", C.c_int),
                 ("tap0", C.c_int), ("taps", C.c_int), ("hop", C.c_int), ("n_bins", C.c_int),
                 ("n_mels", C.c_int), ("log_mode", C.c_int), ("log_floor", C.c_float), ("frames", C.c_int),
-                ("window_len", C.c_int)]
+                ("window_len", C.c_int), ("in_window_len", C.c_int), ("rs_scale", C.c_float)]
 
 
 class FsmnDims(C.Structure):

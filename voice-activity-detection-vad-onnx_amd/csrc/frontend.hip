@@ -50,7 +50,8 @@ constexpr int MAX_MEL_TILES = 8;
 struct Dev {
     // geometry
     int prep, center_pad, tap0, taps, hop, n_bins, n_mels, log_mode, frames, window_len;
-    float k0, k1, log_floor;
+    int in_len;             // samples per window in the SOURCE buffer (= window_len unless the graph resamples, prep 6 / 7)
+    float k0, k1, log_floor, rs_scale;
     // derived
     int passes, pass_kb[MAX_PASSES], pass_koff[MAX_PASSES];   // 16-blocks per pass, k offset in table row
     int Kp;                 // padded taps per table row
@@ -70,6 +71,10 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     d->prep = c->prep; d->center_pad = c->center_pad; d->tap0 = c->tap0; d->taps = c->taps; d->hop = c->hop;
     d->n_bins = c->n_bins; d->n_mels = c->n_mels; d->log_mode = c->log_mode; d->frames = c->frames;
     d->window_len = c->window_len; d->k0 = c->k0; d->k1 = c->k1; d->log_floor = c->log_floor;
+    d->in_len = c->in_window_len > 0 ? c->in_window_len : c->window_len;
+    d->rs_scale = c->rs_scale;
+    if ((c->prep == 6 || c->prep == 7) && !(c->rs_scale > 0.f && c->in_window_len > 0)) return -1;
+    if (c->prep < 0 || c->prep > 7) return -1;
     if (c->hop <= 0 || c->hop > 320 || c->hop % 16 || c->taps <= 0 || c->n_bins <= 0 || c->n_mels <= 0 || c->n_mels % 16 ||
         c->frames <= 0 || c->window_len <= 0)
         return -1;
@@ -159,7 +164,63 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
             }
         }
     };
+    // In-graph linear resampling of exports built with IN_SAMPLE_RATE != 16000 (Export_NVIDIA_MarbleNet_VAD.py:237-254,
+    // FireRedVAD/Export_FireRedVAD.py:431-449): F.interpolate(mode='linear', align_corners=False, scale_factor=16000/in_rate)
+    // BEFORE the two-tap pre-emphasis when the input rate is higher (prep 6), AFTER it when it is lower (prep 7).  The window in
+    // HBM holds in_len samples at the input rate; output sample n reads source position max(0, rs_scale * (n + 0.5) - 0.5)
+    // (float32 arithmetic, as torch's area_pixel_compute_source_index), neighbours clamped to the window like torch clamps them.
+    auto stage_rs = [&](auto prep_c) {
+        constexpr int PREP = decltype(prep_c)::value;
+        auto src = [&](int n, int &i0, int &i1, float &lam) {
+            float s = __fsub_rn(__fmul_rn(d.rs_scale, __fadd_rn((float)n, 0.5f)), 0.5f);
+            s = s < 0.f ? 0.f : s;
+            i0 = (int)s;
+            i0 = i0 > d.in_len - 1 ? d.in_len - 1 : i0;
+            i1 = i0 + (i0 < d.in_len - 1 ? 1 : 0);
+            lam = __fsub_rn(s, (float)i0);
+        };
+        for (int g = wave; g < cols; g += THREADS / 64) {
+            const int nb = (f0 + g) * d.hop + d.tap0 - d.center_pad;
+            float xa[5], xb[5], xc[5], xd[5], la[5], lb[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int n = nb + lane + 64 * j;
+                const int nc = n < 0 ? 0 : (n >= d.window_len ? d.window_len - 1 : n);
+                int i0, i1, j0, j1;
+                src(nc, i0, i1, la[j]);
+                if (PREP == 6) {              // r(n) and r(n-1): four source samples
+                    src(nc > 0 ? nc - 1 : 0, j0, j1, lb[j]);
+                    xa[j] = (float)win[i0]; xb[j] = (float)win[i1]; xc[j] = (float)win[j0]; xd[j] = (float)win[j1];
+                } else {                      // p(i0) and p(i1): x[i-1], x[i] of both neighbours
+                    lb[j] = 0.f;
+                    xa[j] = (float)win[i0]; xb[j] = (float)win[i1];
+                    xc[j] = i0 > 0 ? (float)win[i0 - 1] : 0.f;          // (uniformly rare branch-free select: index clamped below)
+                    xd[j] = i1 > 0 ? (float)win[i1 - 1] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int r = lane + 64 * j, n = nb + r;
+                const bool in = n >= 0 && n < d.window_len;
+                const float l1 = la[j], l0 = __fsub_rn(1.f, l1);
+                float v;
+                if (PREP == 6) {
+                    const float rn = __fadd_rn(__fmul_rn(l0, xa[j]), __fmul_rn(l1, xb[j]));
+                    const float m1 = lb[j], m0 = __fsub_rn(1.f, m1);
+                    const float rm = n > 0 ? __fadd_rn(__fmul_rn(m0, xc[j]), __fmul_rn(m1, xd[j])) : 0.f;
+                    v = __fadd_rn(__fmul_rn(rm, d.k0), __fmul_rn(rn, d.k1));
+                } else {
+                    const float p0 = __fadd_rn(__fmul_rn(xc[j], d.k0), __fmul_rn(xa[j], d.k1));
+                    const float p1 = __fadd_rn(__fmul_rn(xd[j], d.k0), __fmul_rn(xb[j], d.k1));
+                    v = __fadd_rn(__fmul_rn(l0, p0), __fmul_rn(l1, p1));
+                }
+                if (r < d.hop) X2[r * X_LD + g] = in ? v : 0.f;
+            }
+        }
+    };
     switch (d.prep) {       // uniform
+        case 6: stage_rs(std::integral_constant<int, 6>{}); break;
+        case 7: stage_rs(std::integral_constant<int, 7>{}); break;
         case 0: stage(std::integral_constant<int, 0>{}); break;
         case 1: stage(std::integral_constant<int, 1>{}); break;
         case 2: stage(std::integral_constant<int, 2>{}); break;
@@ -390,16 +451,16 @@ extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *p
     VADX_REQUIRE(cfg && packed && mel_kb_host && audio && out, "vadx_frontend_logmel: NULL argument");
     VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_frontend_logmel: unsupported geometry");
     VADX_REQUIRE(batch > 0 && windows_per_clip > 0, "vadx_frontend_logmel: batch/windows must be positive");
-    VADX_REQUIRE((windows_per_clip - 1) * win_stride + cfg->window_len <= row_stride,
+    VADX_REQUIRE((windows_per_clip - 1) * win_stride + d.in_len <= row_stride,
                  "vadx_frontend_logmel: windows run past the clip row (pad the clip to the window grid first)");
-    VADX_REQUIRE(cfg->prep == 1 || means_ws, "vadx_frontend_logmel: this prep mode needs a means workspace of batch*windows floats");
+    VADX_REQUIRE(cfg->prep == 1 || cfg->prep >= 6 || means_ws, "vadx_frontend_logmel: this prep mode needs a means workspace of batch*windows floats");
     VADX_REQUIRE(TF + d.passes - 1 <= X_LD, "vadx_frontend_logmel: too many passes");
     for (int mt = 0; mt < d.nmt; ++mt) { d.mel_kb_lo[mt] = mel_kb_host[2 * mt]; d.mel_kb_hi[mt] = mel_kb_host[2 * mt + 1]; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long nwin = (long long)batch * windows_per_clip;
     VADX_REQUIRE(nwin * (d.tiles32 + d.tiles16) < (1LL << 31), "vadx_frontend_logmel: too many tiles");
     const float *means = nullptr;
-    if (cfg->prep != 1) {
+    if (cfg->prep != 1 && cfg->prep < 6) {
         const float scale = (cfg->prep == 2) ? cfg->k1 : 1.0f;
         hipLaunchKernelGGL(window_mean_kernel, dim3((unsigned)((nwin + 3) / 4)), dim3(256), 0, st, audio, (long long)row_stride,
                            (long long)win_stride, windows_per_clip, (int)nwin, cfg->window_len, scale, means_ws);

@@ -18,13 +18,16 @@ SAMPLE_RATE, WINDOW_LENGTH, HOP_LENGTH = 16000, 400, 160
 STREAM_CHUNK_SAMPLES = 2560          # 160 ms (Export_FireRedVAD.py:52-53)
 
 
-def valid_frame_count(num_samples):
-    """snip_edges frame count (Inference_FireRed_ONNX.py:84-89, IN_SAMPLE_RATE == 16000)."""
-    return 0 if num_samples < WINDOW_LENGTH else 1 + (num_samples - WINDOW_LENGTH) // HOP_LENGTH
+def valid_frame_count(num_samples, in_sample_rate=SAMPLE_RATE):
+    """snip_edges frame count of a clip of `num_samples` input-rate samples (Inference_FireRed_ONNX.py:84-89)."""
+    resampled = int(num_samples * SAMPLE_RATE / in_sample_rate)
+    return 0 if resampled < WINDOW_LENGTH else 1 + (resampled - WINDOW_LENGTH) // HOP_LENGTH
 
 
 class FireRedEngine:
-    def __init__(self, weights=None, input_audio_length=16000, device="cuda:0"):
+    def __init__(self, weights=None, input_audio_length=16000, device="cuda:0", in_sample_rate=16000):
+        """in_sample_rate: the export's IN_SAMPLE_RATE (FireRedVAD/Export_FireRedVAD.py:431-449): windows hold
+        `input_audio_length` samples at that rate and the graph resamples them to 16 kHz itself."""
         torch = _lib.require_gpu()
         self.torch = torch
         self.device = torch.device(device)
@@ -32,7 +35,8 @@ class FireRedEngine:
         c = dict(w["cfg"])
         w = {k: (np.ascontiguousarray(np.asarray(v), dtype=np.float32) if k != "cfg" else v) for k, v in w.items()}
         self.L = int(input_audio_length)
-        self.fe = _frontend.Frontend("firered", self.L, device=device)
+        self.in_sample_rate = int(in_sample_rate)
+        self.fe = _frontend.Frontend("firered", self.L, device=device, in_sample_rate=self.in_sample_rate)
         self._fes = {self.L: self.fe}
         self.T = self.fe.frames
         self.odim = c["odim"]
@@ -80,7 +84,7 @@ class FireRedEngine:
         if fe is None:
             if len(self._fes) >= 8:                      # chunk length + a few tail lengths; keep it bounded
                 self._fes.pop(next(k for k in self._fes if k != self.L))
-            fe = self._fes[length] = _frontend.Frontend("firered", length, device=self.device)
+            fe = self._fes[length] = _frontend.Frontend("firered", length, device=self.device, in_sample_rate=self.in_sample_rate)
         return fe
 
     def new_caches(self, streams=1):
@@ -146,7 +150,7 @@ class FireRedEngine:
         padded = np.stack(rows)
         W = padded.shape[1] // self.L
         probs = self.run(padded, W).view(B, W, self.odim, self.T)
-        nvalid = valid_frame_count(n)
+        nvalid = valid_frame_count(n, self.in_sample_rate)
         track = probs[:, :, 0, :].reshape(B, W * self.T)[:, :nvalid].contiguous()
         pp = _vadpost.VadPostprocessor(*post, device=self.device)
         if nvalid == 0:
@@ -155,7 +159,7 @@ class FireRedEngine:
         dec, segs, counts = pp.process_batch(track)
         segs, counts = segs.cpu().numpy(), counts.cpu().numpy()
         nfr = track.shape[1]     # min(valid frames, W*T): 10 s clips give 980 of the 998 snip-edge frames
-        out = [pp.segments_to_seconds(segs[b, :counts[b]].tolist(), nfr, n / SAMPLE_RATE) for b in range(B)]
+        out = [pp.segments_to_seconds(segs[b, :counts[b]].tolist(), nfr, n / self.in_sample_rate) for b in range(B)]
         return (out, track, dec) if return_probs else out
 
 
@@ -203,8 +207,8 @@ class FireRedSession:
     """onnxruntime.InferenceSession look-alike: {'audio': int16 [1,1,L]} -> [probs f32 [1,odim,T]]
     (FireRedVAD/Export_FireRedVAD.py:785-807); a leading batch of windows is accepted."""
 
-    def __init__(self, weights=None, input_audio_length=16000, device="cuda:0"):
-        self.engine = FireRedEngine(weights, input_audio_length, device)
+    def __init__(self, weights=None, input_audio_length=16000, device="cuda:0", in_sample_rate=16000):
+        self.engine = FireRedEngine(weights, input_audio_length, device, in_sample_rate)
         self._inputs_meta = [_Meta("audio", [1, 1, self.engine.L], "tensor(int16)")]
         self._outputs_meta = [_Meta("probs", [1, self.engine.odim, self.engine.T], "tensor(float)")]
 

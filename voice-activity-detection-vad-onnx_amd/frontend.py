@@ -25,10 +25,24 @@ PRESETS = {
 }
 
 
+def resampled_length(in_len, in_sample_rate):
+    """(samples after the in-graph resample to 16 kHz, float32 source step) as torch derives them from
+    scale_factor = 1 / (in_sample_rate / 16000): out = floor(in * scale_factor) in double, step = float32(1 / scale_factor);
+    (in_len, None) at 16 kHz."""
+    if int(in_sample_rate) == 16000:
+        return int(in_len), None
+    scale_factor = 1.0 / (in_sample_rate / 16000.0)
+    return int(np.floor(float(in_len) * scale_factor)), np.float32(1.0 / scale_factor)
+
+
 class Frontend:
     """Device-resident packed tables for one preset and one window length."""
 
-    def __init__(self, preset, window_len, device="cuda:0", n_mels=80, sample_rate=16000):
+    def __init__(self, preset, window_len, device="cuda:0", n_mels=80, sample_rate=16000, in_sample_rate=16000):
+        """window_len = samples per window IN THE AUDIO BUFFER.  in_sample_rate != 16000 reproduces the exports built with
+        IN_SAMPLE_RATE set (Export_NVIDIA_MarbleNet_VAD.py:237-254, FireRedVAD/Export_FireRedVAD.py:431-449): the graph itself
+        resamples each window to 16 kHz with F.interpolate(linear, align_corners=False), before the pre-emphasis when the
+        input rate is higher, after it when lower (two-tap presets only)."""
         torch = _lib.require_gpu()
         self.torch = torch
         self.device = torch.device(device)
@@ -36,8 +50,16 @@ class Frontend:
         self.p = p
         n_fft, win, hop = p["n_fft"], p["win"], p["hop"]
         half = n_fft // 2
-        self.window_len = int(window_len)
+        self.in_window_len = int(window_len)
+        self.in_sample_rate = int(in_sample_rate)
+        self.window_len, rs_scale = resampled_length(self.in_window_len, self.in_sample_rate)
+        if rs_scale is not None:
+            if p["prep"] != 1:
+                raise ValueError("in-graph resampling exists only in the two-tap (MarbleNet / FireRed) exports")
+            p["prep"] = 6 if self.in_sample_rate > 16000 else 7
         self.frames = (self.window_len // hop + 1) if p["center"] else ((self.window_len - n_fft) // hop + 1)
+        if self.frames <= 0:
+            raise ValueError(f"window of {self.in_window_len} samples at {self.in_sample_rate} Hz is shorter than one analysis frame")
         w = tables.analysis_window(p["window"], win, n_fft, p["variant"])
         cos_t, sin_t = tables.windowed_dft(n_fft, w, p["variant"])
         if p["mel"][0] == "torchaudio":
@@ -55,6 +77,7 @@ class Frontend:
         cfg.hop, cfg.n_bins, cfg.n_mels = hop, half + 1, n_mels
         cfg.log_mode, cfg.log_floor = p["log_mode"], p["log_floor"]
         cfg.frames, cfg.window_len = self.frames, self.window_len
+        cfg.in_window_len, cfg.rs_scale = (self.in_window_len, float(rs_scale)) if rs_scale is not None else (0, 0.0)
         self.cfg = cfg
         self.n_mels = n_mels
         L = _lib.lib()
@@ -83,12 +106,12 @@ class Frontend:
         a = a.contiguous()
         B, N = a.shape
         W = int(windows_per_clip)
-        ws = self.window_len if win_stride is None else int(win_stride)
-        if (W - 1) * ws + self.window_len > N:
+        ws = self.in_window_len if win_stride is None else int(win_stride)
+        if (W - 1) * ws + self.in_window_len > N:
             raise ValueError("windows run past the clip: pad the clip to the window grid first")
         if out is None:
             out = t.empty((B * W, self.frames, self.n_mels), dtype=t.float32, device=self.device)
-        means = t.empty((B * W,), dtype=t.float32, device=self.device) if self.cfg.prep != 1 else None
+        means = t.empty((B * W,), dtype=t.float32, device=self.device) if self.cfg.prep not in (1, 6, 7) else None
         with t.cuda.device(self.device):
             _lib.check(_lib.lib().vadx_frontend_logmel(C.byref(self.cfg), self.packed.data_ptr(), self.mel_kb.ctypes.data,
                                                        a.data_ptr(), _lib.row_stride(a), ws, B, W,

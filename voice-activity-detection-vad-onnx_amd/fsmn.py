@@ -179,17 +179,28 @@ def pad_to_window_grid(audio_i16, window, stride, noise=None):
 
 class FsmnSession:
     """onnxruntime.InferenceSession look-alike for the FSMN graph (names/dtypes/shapes of
-    FSMN/Export_FSMN_VAD.py:115-134); feeds may carry a leading batch of independent streams."""
+    FSMN/Export_FSMN_VAD.py:115-134); feeds may carry a leading batch of independent streams.
 
-    def __init__(self, weights=None, input_audio_length=16000, device="cuda:0"):
-        self.engine = FsmnEngine(weights, input_audio_length, device)
+    io_dtype="float16" is the drop-in for the reference's fp16-optimised model (FSMN/Optimize_ONNX.py:48-54 converts with
+    keep_io_types=False, so caches, thresholds and noisy_dB cross the boundary as float16 and the driver builds float16
+    feeds when `_inputs_meta[1].type` says so, Inference_FSMN_VAD_ONNX.py:40,157-164).  Only the BOUNDARY is half precision
+    here: feeds are widened to float32, every kernel computes in float32 (>= the reference's precision), fetches are
+    rounded to float16 once.  Against the float32 session fed the same (float16-representable) values the uint8 score
+    is identical and caches / noisy_dB differ by that single rounding (<= 2^-11 relative)."""
+
+    def __init__(self, weights=None, input_audio_length=16000, device="cuda:0", io_dtype="float32", speech_2_noise_ratio=1.0):
+        if io_dtype not in ("float32", "float16"):
+            raise ValueError("io_dtype must be 'float32' or 'float16'")
+        self.io_dtype = np.float16 if io_dtype == "float16" else np.float32
+        ftype = "tensor(float16)" if io_dtype == "float16" else "tensor(float)"
+        self.engine = FsmnEngine(weights, input_audio_length, device, speech_2_noise_ratio)
         L, T = self.engine.L, self.engine.T
         cache = [1, PROJ, HIST, 1]
         self._inputs_meta = [_Meta("audio", [1, 1, L], "tensor(int16)")] + \
-            [_Meta(f"cache_{i}", cache, "tensor(float)") for i in range(4)] + \
-            [_Meta("one_minus_speech_threshold", [1], "tensor(float)"), _Meta("noise_average_dB", [1], "tensor(float)")]
+            [_Meta(f"cache_{i}", cache, ftype) for i in range(4)] + \
+            [_Meta("one_minus_speech_threshold", [1], ftype), _Meta("noise_average_dB", [1], ftype)]
         self._outputs_meta = [_Meta("score", [T], "tensor(uint8)")] + \
-            [_Meta(f"cache_{i}", cache, "tensor(float)") for i in range(4)] + [_Meta("noisy_dB", [], "tensor(float)")]
+            [_Meta(f"cache_{i}", cache, ftype) for i in range(4)] + [_Meta("noisy_dB", [], ftype)]
 
     def get_inputs(self):
         return list(self._inputs_meta)
@@ -205,6 +216,11 @@ class FsmnSession:
         audio = np.asarray(feeds["audio"])
         if audio.dtype != np.int16:
             raise ValueError("Unexpected input data type. Actual: (%s) , expected: (tensor(int16))" % audio.dtype)
+        for name in [f"cache_{i}" for i in range(4)] + ["one_minus_speech_threshold", "noise_average_dB"]:
+            got = np.asarray(feeds[name]).dtype
+            if got != self.io_dtype:       # onnxruntime refuses a feed of the wrong element type; so does this session
+                raise ValueError("Unexpected input data type. Actual: (tensor(%s)) , expected: (tensor(%s))"
+                                 % (got, "float16" if self.io_dtype == np.float16 else "float"))
         audio = audio.reshape(-1, audio.shape[-1])
         B = audio.shape[0]
         caches = [t.from_numpy(np.ascontiguousarray(np.asarray(feeds[f"cache_{i}"], dtype=np.float32)).reshape(B, PROJ, HIST))
@@ -212,10 +228,11 @@ class FsmnSession:
         score, cout, noisy = self.engine.run(t.from_numpy(np.ascontiguousarray(audio)), caches,
                                              np.asarray(feeds["one_minus_speech_threshold"], dtype=np.float32),
                                              np.asarray(feeds["noise_average_dB"], dtype=np.float32))
+        io = self.io_dtype
         res = {"score": score.cpu().numpy().reshape(-1) if B == 1 else score.cpu().numpy(),
-               "noisy_dB": noisy.cpu().numpy().reshape(()) if B == 1 else noisy.cpu().numpy()}
+               "noisy_dB": (noisy.cpu().numpy().reshape(()) if B == 1 else noisy.cpu().numpy()).astype(io)}
         for i in range(4):
-            res[f"cache_{i}"] = cout[i].cpu().numpy().reshape(B, PROJ, HIST, 1)
+            res[f"cache_{i}"] = cout[i].cpu().numpy().reshape(B, PROJ, HIST, 1).astype(io)
         # outputs are name-addressed; the reference script's positional names o0..o5 map in graph order
         order = ["score", "cache_0", "cache_1", "cache_2", "cache_3", "noisy_dB"]
         names = order if output_names is None else output_names

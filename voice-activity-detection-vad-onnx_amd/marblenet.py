@@ -29,8 +29,11 @@ def _pad16(a, axes):
 
 
 class MarbleNetEngine:
-    def __init__(self, weights=None, device="cuda:0", blocks=None, bn_eps=None):
+    def __init__(self, weights=None, device="cuda:0", blocks=None, bn_eps=None, in_sample_rate=16000):
+        """in_sample_rate: the export's IN_SAMPLE_RATE (Export_NVIDIA_MarbleNet_VAD.py:237-254): audio arrives at that rate and
+        the graph resamples every window to 16 kHz itself."""
         torch = _lib.require_gpu()
+        self.in_sample_rate = int(in_sample_rate)
         self.torch = torch
         self.device = torch.device(device)
         w = _checkpoints.resolve("marblenet", weights)
@@ -61,7 +64,7 @@ class MarbleNetEngine:
 
     def frontend(self, L):
         if L not in self._fe:
-            self._fe[L] = _frontend.Frontend("marblenet", L, device=self.device)
+            self._fe[L] = _frontend.Frontend("marblenet", L, device=self.device, in_sample_rate=self.in_sample_rate)
         return self._fe[L]
 
     def run(self, audio_i16, windows_per_clip=1, window_len=None):
@@ -106,7 +109,7 @@ class MarbleNetEngine:
         dynamic-axis mode (one window = the whole clip, up to 3600 s, :130-135)."""
         clips = np.asarray(clips_i16)
         B, n = clips.shape
-        L = min(SAMPLE_RATE * 3600, n) if window_len is None else int(window_len)
+        L = min(self.in_sample_rate * 3600, n) if window_len is None else int(window_len)
         rows = [pad_to_window_grid(clips[b], L, L, None if pad_noise is None else pad_noise[b]) for b in range(B)]
         padded = np.stack(rows)
         W = padded.shape[1] // L
@@ -116,7 +119,7 @@ class MarbleNetEngine:
         pp = _vadpost.VadPostprocessor(*post, frame_shift_s=OUTPUT_FRAME_SHIFT_S, frame_length_s=None, device=self.device)
         dec, segs, counts = pp.process_batch(track)
         segs, counts = segs.cpu().numpy(), counts.cpu().numpy()
-        out = [pp.segments_to_seconds(segs[b, :counts[b]].tolist(), track.shape[1], n / SAMPLE_RATE) for b in range(B)]
+        out = [pp.segments_to_seconds(segs[b, :counts[b]].tolist(), track.shape[1], n / self.in_sample_rate) for b in range(B)]
         return (out, track, dec) if return_probs else out
 
 
@@ -124,8 +127,8 @@ class MarbleNetSession:
     """{'audio': int16 [1,1,L]} -> [score_silence [1,T,1], score_active [1,T,1], signal_len int32 [1]]
     (Export_NVIDIA_MarbleNet_VAD.py:436-457; dynamic audio length)."""
 
-    def __init__(self, weights=None, device="cuda:0"):
-        self.engine = MarbleNetEngine(weights, device)
+    def __init__(self, weights=None, device="cuda:0", in_sample_rate=16000):
+        self.engine = MarbleNetEngine(weights, device, in_sample_rate=in_sample_rate)
         self._inputs_meta = [_Meta("audio", [1, 1, "audio_len"], "tensor(int16)")]
         self._outputs_meta = [_Meta("score_silence", [1, "signal_len", 1], "tensor(float)"),
                               _Meta("score_active", [1, "signal_len", 1], "tensor(float)"),
