@@ -52,9 +52,10 @@ MAC_HH = 512 * 128
 FLOP_ENCODE = 2 * (MAC_STFT + MAC_CONV1 + MAC_CONV2 + MAC_CONV3 + MAC_CONV4 + MAC_IH)
 FLOP_RECUR = 2 * MAC_HH
 # What the encoder kernel actually issues per 16-window tile: v_mfma_f32_16x16x4 counts per phase
-# (folded STFT 1024, conv1 2560, conv2 640, conv3 128, conv4 128, W_ih 1024), 2048 flop each.  Lower than the
-# dense count because the DFT's time and frequency symmetries quarter the STFT contraction (DESIGN.md "Silero path").
-MFMA_PER_TILE = 1024 + 2560 + 640 + 128 + 128 + 1024
+# (folded STFT 1024, Winograd F(4,3) conv1 1536, conv2 640, conv3 128, conv4 128, W_ih 1024), 2048 flop each.  Lower than
+# the dense count because the DFT's time and frequency symmetries quarter the STFT contraction and conv1 runs as six
+# Winograd-plane GEMMs instead of ten tap GEMMs (DESIGN.md "Silero path").
+MFMA_PER_TILE = 1024 + 1536 + 640 + 128 + 128 + 1024
 FLOP_ENCODE_ISSUED = MFMA_PER_TILE * 2048 // 16
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = f32 vector rate
 PEAK_HBM_GBPS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak

@@ -15,8 +15,8 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 def test_flop_and_byte_accounting_and_committed_profile():
     sys.path.insert(0, ROOT)
     import bench
-    # issued MFMA flops per window: 5504 v_mfma_f32_16x16x4 per 16-window tile, 2048 flop each
-    assert bench.FLOP_ENCODE_ISSUED == 5504 * 2048 // 16 == 704512
+    # issued MFMA flops per window: 4480 v_mfma_f32_16x16x4 per 16-window tile (Winograd conv1), 2048 flop each
+    assert bench.FLOP_ENCODE_ISSUED == 4480 * 2048 // 16 == 573440
     assert bench.FLOP_ENCODE == 1186816 and bench.FLOP_RECUR == 131072
     # 2048 B of float32 PCM in + one 4-byte score out per 512-sample window; the gx intermediate is NOT algorithmic
     assert bench.ALGO_BYTES_PER_WINDOW == 2052

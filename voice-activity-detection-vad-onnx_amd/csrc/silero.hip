@@ -36,9 +36,10 @@ namespace silero {
 constexpr int OFF_STFT = 0;                        // [8 waves][re16|im16][256]  (bins 0..127), k-permuted per 16
 constexpr int OFF_NYQ = OFF_STFT + 256 * 256;      // [2][256]                   (bin 128 re, im)
 constexpr int C1_KP = 128;                         // input channels 0..127 on MFMA; channel 128 (Nyquist) on VALU
-constexpr int OFF_C1 = OFF_NYQ + 2 * 256;          // [8 oc tiles][3 taps][8 blocks][FRAG]
-constexpr int OFF_C1N = OFF_C1 + 128 * 3 * C1_KP;  // [128][4]  the three taps of input channel 128 (+1 pad)
-constexpr int OFF_B1 = OFF_C1N + 128 * 4;          // [128]
+// conv1 runs in the Winograd F(4,3) domain (see "phase 2"): 6 transformed weight planes U_j = G g instead of 3 taps
+constexpr int OFF_C1 = OFF_NYQ + 2 * 256;          // [8 oc tiles][6 planes][8 blocks][FRAG]
+constexpr int OFF_C1N = OFF_C1 + 128 * 6 * C1_KP;  // [128][8]  the six transformed taps of input channel 128 (+2 pad)
+constexpr int OFF_B1 = OFF_C1N + 128 * 8;          // [128]
 constexpr int OFF_C2 = OFF_B1 + 128;               // [4 oc tiles][3 taps x 8 blocks][FRAG]
 constexpr int OFF_B2 = OFF_C2 + 64 * 3 * 128;      // [64]
 constexpr int OFF_C3 = OFF_B2 + 64;                // [4 oc tiles][2 taps x 4 blocks][FRAG]  taps 1,2 (tap 0 only sees padding)
@@ -58,22 +59,30 @@ constexpr int OFF_B64 = OFF_S0 + 128;              // [2][128] bin 64, time-fold
 constexpr int OFF_FOLD = OFF_B64 + 256 + 4;        // [1] (+3 pad)  1.0 = folded pass valid
 constexpr int PACKED_FLOATS = OFF_FOLD + 4;
 
-// ---- encoder LDS map (floats): 50 304 B per workgroup => THREE workgroups per CU ------------------
-// One main region is reused by every phase; a phase whose output would overwrite its own input keeps the
-// result in registers across a barrier before storing it (STFT -> Mg, conv1 -> A1):
-//   main : X  [16 clips][642]  raw windows in their global layout (row stride 642 = 2 mod 32: with the
-//              STFT's k permutation the half-wave (clip i, q) hits bank 2i+q -> conflict free)
-//          -> Mg [129 ch][4 frames x 16 (+4)]  |STFT|, k-major
-//          -> A1 [128 ch][4 frames x 16 (+4)]  conv1 output
-//          -> A3 [64][16 (+4)], A4 [128][16 (+4)]   (A1 is dead after conv2)
-//   side : A2 [64][2x16 (+4)]                  conv2 output
-// Conv zero padding is never stored: taps that would read frame -1 / 4 are simply not issued.
+// ---- encoder LDS map (floats): 51 856 B per workgroup => THREE workgroups per CU ------------------
+// One region is reused by every phase; a phase whose output would overwrite its own input keeps the
+// result in registers across a barrier before storing it (STFT -> V, conv1 -> A1):
+//   X  [16 clips][642]  raw windows in their global layout (row stride 642 = 2 mod 32: with the
+//       STFT's k permutation the half-wave (clip i, q) hits bank 2i+q -> conflict free)
+//   -> V  [129 ch][6 planes x 16 (+4)]  |STFT| in the Winograd F(4,3) input domain (V_j = sum_f BT[j][f] |X_f|), k-major;
+//         + 64 floats of scratch behind it (bin 64 / Nyquist magnitudes of the four frames, combined by one wave)
+//   -> A1 [128 ch][4 frames x 16 (+4)]  conv1 output, with A2 [64][2x16 (+4)] (conv2 output) right behind it
+//   -> A3 [64][16 (+4)], A4 [128][16 (+4)]   (A1 is dead after conv2)
+// Conv zero padding is never stored: the Winograd input transform is written for zero frames -1 and 4, and the taps of
+// conv2..4 that would read padding are simply not issued.
 constexpr int X_LDM = 642;
-constexpr int MG_LD = 68, A1_LD = 68, A2_LD = 36, A3_LD = 20, A4_LD = 20;
-constexpr int R0_FLOATS = 16 * X_LDM;              // 10272  (Mg: 129*68 = 8772, A1: 128*68 = 8704)
-constexpr int R1_FLOATS = 64 * A2_LD;              //  2304
-constexpr int A3_OFF = 0, A4_OFF = 64 * A3_LD;     // inside main
-constexpr int ENC_LDS_FLOATS = R0_FLOATS + R1_FLOATS;
+constexpr int V_LD = 100, A1_LD = 68, A2_LD = 36, A3_LD = 20, A4_LD = 20;
+constexpr int V_SCR = 129 * V_LD;                  // [4 frames][16 clips]
+constexpr int R0_FLOATS = V_SCR + 64;              // 12964  (X: 16*642 = 10272; A1 + A2: 128*68 + 64*36 = 11008)
+constexpr int A2_OFF = 128 * A1_LD;
+constexpr int A3_OFF = 0, A4_OFF = 64 * A3_LD;
+constexpr int ENC_LDS_FLOATS = R0_FLOATS;
+static_assert(16 * X_LDM <= R0_FLOATS && A2_OFF + 64 * A2_LD <= R0_FLOATS && 3 * ENC_LDS_FLOATS * 4 <= 160 * 1024, "encoder LDS map");
+
+// Winograd F(4,3) over the window's four STFT frames (frames -1 and 4 are the conv's zero padding): rows of B^T restricted
+// to the four real frames, and A^T is applied to the six accumulators in the epilogue of phase 2.
+__device__ constexpr float WINO_BT[6][4] = {{0.f, -5.f, 0.f, 1.f}, {-4.f, -4.f, 1.f, 1.f}, {4.f, -4.f, -1.f, 1.f},
+                                            {-2.f, -1.f, 2.f, 1.f}, {2.f, -1.f, -2.f, 1.f}, {4.f, 0.f, -5.f, 0.f}};
 constexpr int ENC_THREADS = 512;
 
 // gx: per (t, group) 8 waves x 4 gates x 64 lanes x 4 floats
@@ -175,6 +184,37 @@ __device__ __forceinline__ void gemm_pass_sub(f32x4 (&acc)[1][AN], const float *
     }
 }
 
+// Three Winograd planes side by side: acc[p] += V_p x U_p over KB blocks of 16 input channels.  Plane p's activations sit
+// 16 columns further right in the same LDS rows, its weights KB fragments further in this lane's stream; the three
+// accumulators alternate, so consecutive MFMAs are independent.
+template <int KB>
+__device__ __forceinline__ void gemm_planes3(f32x4 &a0, f32x4 &a1, f32x4 &a2, const float *act, int lda, const float *w, int lane) {
+    // (An explicitly software-pipelined form of this loop -- weight fragments and LDS operands of block S + 1 in flight
+    // under the MFMAs of block S, ping-pong registers, counted waits -- was built and measured: 7.5 - 8.0 ms against 7.3 ms
+    // for this plain form.  Six waves per SIMD already interleave at MFMA-pair granularity; the extra live registers only
+    // cost spills at the 80-VGPR budget.)
+    const int q = lane >> 4, i = lane & 15;
+    const float *ap = act + (4 * q) * lda + i;
+    f32x4 wc[3], wn[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wc[p] = *reinterpret_cast<const f32x4 *>(w + p * KB * FRAG);
+#pragma unroll 1
+    for (int S = 0; S < KB; ++S) {
+        const int Sn = ENC_SKIP(13) ? 0 : ((S + 1 < KB) ? S + 1 : S);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wn[p] = *reinterpret_cast<const f32x4 *>(w + (p * KB + Sn) * FRAG);
+        const float *aps = ap + 16 * S * lda;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a0 = mfma16(aps[j * lda], wc[0][j], a0);
+            a1 = mfma16(aps[j * lda + 16], wc[1][j], a1);
+            a2 = mfma16(aps[j * lda + 32], wc[2][j], a2);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wc[p] = wn[p];
+    }
+}
+
 // Single-tile chain (one 16x16 output tile per wave, K = 16*NB): the weights of blocks B0..NB-1 sit contiguously in
 // this lane's row; activations for block b come from column offset coff(b) and k-row 16*(b % KPB).  With one MFMA
 // per ds_read there is nothing to hide an L2 round trip behind, so the weight stream runs DEPTH blocks ahead, and
@@ -234,9 +274,9 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
     const float *__restrict__ P, const SampleT *__restrict__ audio, float in_scale, long long n_samples,
     long long row_stride, long long origin, int B, int G, int T, int Gws, int g0, float *__restrict__ gx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *X = lds, *Mg = lds, *A1 = lds;          // main region, one tenant per phase
+    float *X = lds, *V = lds, *A1 = lds;           // one region, one tenant per phase
     float *A3 = lds + A3_OFF, *A4 = lds + A4_OFF;
-    float *A2 = lds + R0_FLOATS;
+    float *A2 = lds + A2_OFF, *scr = lds + V_SCR;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, i = lane & 15;
@@ -337,22 +377,42 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             sim = fmaf(x0, P[OFF_B64 + 257], sim);
             b64 = sqrtf(sre * sre + sim * sim);
         }
-        ENC_SYNC();          // every wave is done reading X: Mg may now overwrite it
+        ENC_SYNC();          // every wave is done reading X: V may now overwrite it
+        // Winograd input transform across the two waves that hold a bin's four frames: the fp = 0 wave stores its share
+        // c[j][0] |X_0| + c[j][1] |X_1| of every plane, the fp = 1 wave adds c[j][2] |X_2| + c[j][3] |X_3| behind a barrier
+        // (one store, one add: the sum does not depend on timing).
         const int k = tl * 16 + i;
+        f32x4 mk[2], mn[2];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            f32x4 mk, mn;
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pr = ere[f][r] + ore[f][r], pi = eim[f][r] + oim[f][r];
                 const float nr = ere[f][r] - ore[f][r], ni = eim[f][r] - oim[f][r];
-                mk[r] = sqrtf(pr * pr + pi * pi);
-                mn[r] = sqrtf(nr * nr + ni * ni);
+                mk[f][r] = sqrtf(pr * pr + pi * pi);
+                mn[f][r] = sqrtf(nr * nr + ni * ni);
             }
-            *reinterpret_cast<f32x4 *>(&Mg[k * MG_LD + (2 * fp + f) * 16 + 4 * q]) = mk;
-            *reinterpret_cast<f32x4 *>(&Mg[(128 - k) * MG_LD + (2 * fp + f) * 16 + 4 * q]) = mn;
+        float *vk = V + k * V_LD + 4 * q, *vn = V + (128 - k) * V_LD + 4 * q;
+        if (fp == 0) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                *reinterpret_cast<f32x4 *>(vk + j * 16) = WINO_BT[j][0] * mk[0] + WINO_BT[j][1] * mk[1];
+                *reinterpret_cast<f32x4 *>(vn + j * 16) = WINO_BT[j][0] * mn[0] + WINO_BT[j][1] * mn[1];
+            }
+            if (q == 0) scr[wave * 16 + i] = b64;            // waves 0..3 = (tl, fp = 0): bin 64 of frame `wave`
         }
-        if (wave < 4 && q == 0) Mg[64 * MG_LD + wave * 16 + i] = b64;
+        ENC_SYNC();
+        if (fp == 1) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                f32x4 *pk = reinterpret_cast<f32x4 *>(vk + j * 16), *pn = reinterpret_cast<f32x4 *>(vn + j * 16);
+                *pk = *pk + (WINO_BT[j][2] * mk[0] + WINO_BT[j][3] * mk[1]);
+                *pn = *pn + (WINO_BT[j][2] * mn[0] + WINO_BT[j][3] * mn[1]);
+            }
+        } else if (tid < 96) {                                // bin 64 (its own mirror): plane j = tid / 16, clip = tid % 16
+            const int j = tid >> 4, c = tid & 15;
+            V[64 * V_LD + j * 16 + c] = WINO_BT[j][0] * scr[c] + WINO_BT[j][1] * scr[16 + c] + WINO_BT[j][2] * scr[32 + c] + WINO_BT[j][3] * scr[48 + c];
+        }
     } else {
         f32x4 acc[2][4];
 #pragma unroll
@@ -379,50 +439,59 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             sim += __shfl_xor(sim, 16); sim += __shfl_xor(sim, 32);
             nyq = sqrtf(sre * sre + sim * sim);
         }
-        ENC_SYNC();          // every wave is done reading X: Mg may now overwrite it
+        ENC_SYNC();          // every wave is done reading X: V may now overwrite it
+        {   // this wave holds all four frames of its 16 bins: Winograd input transform in registers
+            f32x4 m[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            f32x4 m;
+            for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m[r] = sqrtf(acc[0][f][r] * acc[0][f][r] + acc[1][f][r] * acc[1][f][r]);
-            *reinterpret_cast<f32x4 *>(&Mg[(wave * 16 + i) * MG_LD + f * 16 + 4 * q]) = m;
+                for (int r = 0; r < 4; ++r) m[f][r] = sqrtf(acc[0][f][r] * acc[0][f][r] + acc[1][f][r] * acc[1][f][r]);
+            float *vr = V + (wave * 16 + i) * V_LD + 4 * q;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                *reinterpret_cast<f32x4 *>(vr + j * 16) = WINO_BT[j][0] * m[0] + WINO_BT[j][1] * m[1] + WINO_BT[j][2] * m[2] + WINO_BT[j][3] * m[3];
         }
-        if (wave < 4 && q == 0) Mg[128 * MG_LD + wave * 16 + i] = nyq;
+        if (wave < 4 && q == 0) scr[wave * 16 + i] = nyq;
+        ENC_SYNC();
+        if (tid < 96) {                                       // Nyquist bin: plane j = tid / 16, clip = tid % 16
+            const int j = tid >> 4, c = tid & 15;
+            V[128 * V_LD + j * 16 + c] = WINO_BT[j][0] * scr[c] + WINO_BT[j][1] * scr[16 + c] + WINO_BT[j][2] * scr[32 + c] + WINO_BT[j][3] * scr[48 + c];
+        }
     }
     ENC_SYNC();
 
-    // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU (taps on frame -1 / 4 are skipped)
+    // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU as Winograd F(4,3) over the window's four frames:
+    // six plane GEMMs M_j = U_j V_j (U_j = G g packed on the host in float64) instead of the ten tap GEMMs a direct
+    // conv issues for 4 output frames with zero frames either side (1536 instead of 2560 MFMAs per tile), then
+    // Y = A^T M on the accumulators.  Rounding error stays in the float32 class (measured 3x a direct conv's on |STFT|
+    // data, three orders below the 1e-4 score tolerance).
     {
-        f32x4 acc[1][4];
-        {   // input channel 128 (the Nyquist bin) on VALU: acc[f] = sum_tap w[tap] * Mg[128][f + tap - 1]
-            const f32x4 wn = *reinterpret_cast<const f32x4 *>(P + OFF_C1N + (wave * 16 + i) * 4);
-            f32x4 mg[4];
+        f32x4 acc[6];
+        {   // input channel 128 (the Nyquist bin) on VALU
+            const float *un = P + OFF_C1N + (wave * 16 + i) * 8;
+            const f32x4 ua = *reinterpret_cast<const f32x4 *>(un), ub = *reinterpret_cast<const f32x4 *>(un + 4);
+            const float *vn = V + 128 * V_LD + 4 * q;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) mg[f] = *reinterpret_cast<const f32x4 *>(&Mg[128 * MG_LD + f * 16 + 4 * q]);
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                f32x4 v = mg[f] * wn[1];
-                if (f > 0) v += mg[f - 1] * wn[0];
-                if (f < 3) v += mg[f + 1] * wn[2];
-                acc[0][f] = v;
-            }
+            for (int j = 0; j < 6; ++j) acc[j] = *reinterpret_cast<const f32x4 *>(vn + j * 16) * (j < 4 ? ua[j] : ub[j - 4]);
         }
-        const float *w0 = P + OFF_C1 + wave * 3 * 8 * FRAG + lane * 4;      // [oc tile][tap][8 blocks]
         if (!ENC_SKIP(5)) {
-        {   const int moff[3] = {0, 16, 32};          // tap 0: out frames 1..3 read in frames 0..2
-            gemm_pass_sub<3, 8, 1, 4>(acc, Mg, MG_LD, moff, w0, lane); }
-        {   const int moff[4] = {0, 16, 32, 48};      // tap 1: out frames 0..3 read in frames 0..3
-            gemm_pass_sub<4, 8, 0, 4>(acc, Mg, MG_LD, moff, w0 + 8 * FRAG, lane); }
-        {   const int moff[3] = {16, 32, 48};         // tap 2: out frames 0..2 read in frames 1..3
-            gemm_pass_sub<3, 8, 0, 4>(acc, Mg, MG_LD, moff, w0 + 16 * FRAG, lane); }
+            const float *w0 = P + OFF_C1 + wave * 6 * 8 * FRAG + lane * 4;      // [oc tile][plane][8 blocks]
+            gemm_planes3<8>(acc[0], acc[1], acc[2], V, V_LD, w0, lane);
+            gemm_planes3<8>(acc[3], acc[4], acc[5], V + 48, V_LD, w0 + 3 * 8 * FRAG, lane);
         }
         const float bias = P[OFF_B1 + wave * 16 + i];
-        ENC_SYNC();          // every wave is done reading Mg: A1 may now overwrite it
+        ENC_SYNC();          // every wave is done reading V: A1 may now overwrite it
+        const f32x4 s12 = acc[1] + acc[2], d12 = acc[1] - acc[2], s34 = acc[3] + acc[4], d34 = acc[3] - acc[4];
+        f32x4 y[4];
+        y[0] = acc[0] + s12 + s34;
+        y[1] = d12 + 2.f * d34;
+        y[2] = s12 + 4.f * s34;
+        y[3] = d12 + 8.f * d34 + acc[5];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[0][f][r] + bias, 0.f);
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(y[f][r] + bias, 0.f);
             *reinterpret_cast<f32x4 *>(&A1[(wave * 16 + i) * A1_LD + f * 16 + 4 * q]) = v;
         }
     }
@@ -482,9 +551,9 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             for (int g = 0; g < 4; ++g) wcur[g] = *reinterpret_cast<const f32x4 *>(wl + g * 64 * FRAG);
 #pragma unroll 2
             for (int S = 0; S < 8; ++S) {
-                const int Sn = (S + 1 < 8) ? S + 1 : S;
+                const int Sn = ENC_SKIP(13) ? 0 : ((S + 1 < 8) ? S + 1 : S);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) wnxt[g] = *reinterpret_cast<const f32x4 *>(wl + g * 64 * FRAG + Sn * FRAG);
+                for (int g = 0; g < 4; ++g) wnxt[g] = *reinterpret_cast<const f32x4 *>(wl + (ENC_SKIP(13) ? 0 : g * 64 * FRAG) + Sn * FRAG);
                 __builtin_amdgcn_sched_barrier(0);
                 const float *aps = ap + 16 * S * A4_LD;
 #pragma unroll
@@ -835,12 +904,18 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
             p[OFF_B64 + 257] = im[64 * 256];
         }
     }
-    for (int co = 0; co < 128; ++co)
-        for (int kk = 0; kk < 3; ++kk) {
-            for (int ci = 0; ci < 128; ++ci)
-                p[frag(OFF_C1 + (size_t)((co / 16) * 3 + kk) * 8 * FRAG, co % 16, ci)] = w->enc_w[0][((size_t)co * 129 + ci) * 3 + kk];
-            p[OFF_C1N + co * 4 + kk] = w->enc_w[0][((size_t)co * 129 + 128) * 3 + kk];
-        }
+    {   // conv1 in the Winograd F(4,3) domain: U_j[co][ci] = sum_t G[j][t] g[co][ci][t], evaluated in float64
+        static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                       {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+        for (int co = 0; co < 128; ++co)
+            for (int j = 0; j < 6; ++j)
+                for (int ci = 0; ci < 129; ++ci) {
+                    const float *g = w->enc_w[0] + ((size_t)co * 129 + ci) * 3;
+                    const float u = (float)(G[j][0] * (double)g[0] + G[j][1] * (double)g[1] + G[j][2] * (double)g[2]);
+                    if (ci < 128) p[frag(OFF_C1 + (size_t)((co / 16) * 6 + j) * 8 * FRAG, co % 16, ci)] = u;
+                    else p[OFF_C1N + co * 8 + j] = u;
+                }
+    }
     memcpy(p + OFF_B1, w->enc_b[0], 128 * sizeof(float));
     for (int co = 0; co < 64; ++co)
         for (int kk = 0; kk < 3; ++kk)
