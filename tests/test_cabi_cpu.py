@@ -50,12 +50,26 @@ def test_pack_host_layout(lib):
     assert np.array_equal(stft[3, 1, 5], w["stft_basis"][129 + 3 * 16 + 5][perm])
     nyq = p[65536:65536 + 512].reshape(2, 256)
     assert np.array_equal(nyq[0], w["stft_basis"][128]) and np.array_equal(nyq[1], w["stft_basis"][257])
-    # conv1 (input channels 0..127) is fragment-major: [8 oc tiles][3 taps][8 blocks][64 lanes][4]
-    c1 = p[66048:66048 + 128 * 3 * 128].reshape(8, 3, 8, 4, 16, 4)          # tile, tap, S, q, i, j
-    rows = c1.transpose(0, 4, 1, 2, 3, 5).reshape(128, 3, 128)              # -> [oc][tap][k = 16S + 4q + j]
-    assert np.array_equal(rows[7, 2], w["enc0_w"][7, :128, 2]) and np.array_equal(rows[100, 0], w["enc0_w"][100, :128, 0])
-    c1n = p[66048 + 128 * 3 * 128:66048 + 128 * 3 * 128 + 512].reshape(128, 4)   # Nyquist input channel, 3 taps (+pad)
-    assert np.array_equal(c1n[:, :3], w["enc0_w"][:, 128, :]) and not c1n[:, 3].any()
+    # conv1 lives in the Winograd F(4,3) domain: six planes U_j = G g (float64 on the host), input channels 0..127
+    # fragment-major [8 oc tiles][6 planes][8 blocks][64 lanes][4], input channel 128 as [128 oc][6 (+2 pad)]
+    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]])
+    U = np.einsum("jt,oct->ojc", G, w["enc0_w"].astype(np.float64)).astype(np.float32)      # [oc][plane][ch]
+    c1 = p[66048:66048 + 128 * 6 * 128].reshape(8, 6, 8, 4, 16, 4)          # tile, plane, S, q, i, j
+    rows = c1.transpose(0, 4, 1, 2, 3, 5).reshape(128, 6, 128)              # -> [oc][plane][k = 16S + 4q + j]
+    assert np.array_equal(rows, U[:, :, :128])
+    assert np.array_equal(rows[:, 5], w["enc0_w"][:, :128, 2]) and np.array_equal(rows[:, 0], w["enc0_w"][:, :128, 0] * np.float32(0.25))
+    c1n = p[66048 + 128 * 6 * 128:66048 + 128 * 6 * 128 + 1024].reshape(128, 8)
+    assert np.array_equal(c1n[:, :6], U[:, :, 128]) and not c1n[:, 6:].any()
+    # the Winograd identity itself, in float64: A^T [(G g) . (B^T d)] == direct conv over frames -1..4 with zero frames at the edges
+    BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], float)
+    AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], float)
+    rng = np.random.default_rng(0)
+    d = np.zeros((6, 129))
+    d[1:5] = rng.uniform(0, 3, (4, 129))
+    g = w["enc0_w"].astype(np.float64)
+    direct = np.stack([sum(g[:, :, t] @ d[f + t] for t in range(3)) for f in range(4)])
+    wino = AT @ np.stack([np.einsum("oc,c->o", np.einsum("t,oct->oc", G[j], g), BT[j] @ d) for j in range(6)])
+    np.testing.assert_allclose(wino, direct, rtol=0, atol=1e-12)
     # the generic helper produces the same layout
     a = np.arange(20 * 37, dtype=np.float32).reshape(20, 37)
     fm = _lib.frag_major(a).reshape(2, 3, 4, 16, 4)                         # tile, S, q, i, j  (32 x 48 padded)
