@@ -964,12 +964,90 @@ def gen_resample():
     save("resample", **out)
 
 
+
+def gen_silero_8k():
+    """get_speech_timestamps at sampling_rate = 8000 (256-sample windows, utils_vad.py:345) on replayed probabilities, and the
+    OnnxWrapper's 8 kHz plumbing (256 + 32-sample context, :99,:115): what the session is FED, with a stand-in network."""
+    print("Silero 8 kHz branch (segmenter + wrapper plumbing)")
+    ns = {"torch": torch, "warnings": __import__("warnings"), "Callable": __import__("typing").Callable,
+          "List": __import__("typing").List, "np": np}
+    R.select_nodes("Silero/modeling_modified/utils_vad.py", {"get_speech_timestamps", "OnnxWrapper"}, ns)
+
+    class Replay:
+        def __init__(self, probs):
+            self.probs, self.i = probs, 0
+
+        def reset_states(self):
+            self.i = 0
+
+        def __call__(self, chunk, sr):
+            assert chunk.shape[-1] == 256 and sr == 8000
+            v = self.probs[self.i]
+            self.i += 1
+            return torch.tensor([[v]], dtype=torch.float32)
+
+    rng = np.random.default_rng(808)
+    out, cases = {}, []
+    for case in range(8):
+        n_samples = int([80000, 44715, 256, 100, 300, 200000, 80000, 16000][case])
+        n_win = (n_samples + 255) // 256
+        kind = case % 4
+        if kind == 0:
+            p = rng.uniform(0, 1, n_win)
+        elif kind == 1:
+            p = np.zeros(n_win)
+            pos, hot = 0, bool(case & 4)
+            while pos < n_win:
+                seg = int(rng.integers(3, 90))
+                p[pos:pos + seg] = rng.uniform(0.5, 1.0, min(seg, n_win - pos)) if hot else rng.uniform(0, 0.4, min(seg, n_win - pos))
+                pos += seg
+                hot = not hot
+        elif kind == 2:
+            p = rng.uniform(0.55, 1.0, n_win)
+            for _ in range(max(1, n_win // 60)):
+                a = int(rng.integers(0, n_win))
+                p[a:a + int(rng.integers(2, 7))] = rng.uniform(0.0, 0.3)
+        else:
+            p = np.clip(0.45 + 0.35 * np.sin(np.arange(n_win) / 7.0) + 0.1 * rng.standard_normal(n_win), 0, 1)
+        p = p.astype(np.float32)
+        kw = [dict(threshold=0.5, sampling_rate=8000, max_speech_duration_s=20, min_speech_duration_ms=250, min_silence_duration_ms=250, return_seconds=True),
+              dict(threshold=0.5, sampling_rate=8000, max_speech_duration_s=6, min_speech_duration_ms=250, min_silence_duration_ms=100, return_seconds=False),
+              dict(threshold=0.6, sampling_rate=8000, max_speech_duration_s=4, min_speech_duration_ms=100, min_silence_duration_ms=250, return_seconds=True,
+                   use_max_poss_sil_at_max_speech=False),
+              dict(threshold=0.5, sampling_rate=8000, return_seconds=False)][case % 4]
+        res = ns["get_speech_timestamps"](torch.zeros(n_samples), Replay([float(v) for v in p]), **kw)
+        out[f"probs_{case}"] = p
+        out[f"nsamp_{case}"] = np.array(n_samples)
+        out[f"res_{case}"] = np.array([[d["start"], d["end"]] for d in res], dtype=np.float64).reshape(-1, 2)
+        cases.append(repr(sorted(kw.items())))
+    out["kwargs"] = np.array(cases)
+    out["n_cases"] = np.array(len(cases))
+
+    fed = []
+
+    class FakeSession:
+        def run(self, _names, feeds):
+            assert int(feeds["sr"]) == 8000 and feeds["input"].shape[1] == 256 + 32
+            fed.append(feeds["input"].copy())
+            return [np.full((feeds["input"].shape[0], 1), 0.25, np.float32), feeds["state"] + np.float32(1.0)]
+
+    wrapper = ns["OnnxWrapper"].__new__(ns["OnnxWrapper"])
+    wrapper.session = FakeSession()
+    wrapper.sample_rates = [8000, 16000]
+    wrapper.reset_states()
+    clip = (weights.burst_clips(2, 1000, seed=12).astype(np.float32) * 0.000030517578)
+    probs = wrapper.audio_forward(torch.from_numpy(clip), 8000).numpy()
+    out["wrap_audio"], out["wrap_probs"], out["wrap_inputs"] = clip, probs, np.stack(fed)
+    out["wrap_final_state"], out["wrap_final_context"] = wrapper._state.numpy(), wrapper._context.numpy()
+    save("silero_8k", **out)
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:])
     gens = dict(stft=gen_stft, host=gen_host, vadpost=gen_vadpost, silero_host=gen_silero_host,
                 fsmn=gen_fsmn, firered=gen_firered, firered_stream=gen_firered_stream, firered_ckpt=gen_firered_ckpt, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn, dfsmn_near_only=gen_dfsmn_near_only,
                 fsmn_extra=gen_fsmn_extra, host_extra=gen_host_extra, marblenet_hostloop=gen_marblenet_hostloop,
-                resample=gen_resample)
+                resample=gen_resample, silero_8k=gen_silero_8k)
     for name, fn in gens.items():
         if not which or name in which:
             fn()

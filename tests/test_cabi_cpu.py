@@ -213,3 +213,25 @@ def test_product_never_imports_the_oracle():
     hits = oracle_imports(os.path.join(root, "bench_models.py"))
     assert hits and all(h.startswith("cpu_baseline_") for h in hits), hits
     assert oracle_imports(os.path.join(root, "__graft_entry__.py")) <= {"build", "smoke"}
+
+
+def test_audio_io_numpy_fallback_matches_audioop(tmp_path):
+    """audio_io without the stdlib audioop (removed in Python 3.13): the numpy tomono / ratecv / lin2lin give the same bytes."""
+    import audioop
+    import wave
+    from vadx import audio_io
+    rng = np.random.default_rng(5)
+    for nch, width, rate, n in ((2, 2, 48000, 7001), (1, 2, 44100, 5000), (2, 2, 16000, 999), (1, 2, 8000, 4000), (1, 1, 22050, 3000),
+                                (2, 4, 32000, 2001), (1, 3, 48000, 1500)):
+        pcm = rng.integers(-2 ** (8 * width - 1), 2 ** (8 * width - 1) - 1, n * nch)
+        raw = b"".join(int(v).to_bytes(width, "little", signed=True) for v in pcm)
+        path = str(tmp_path / f"a_{nch}_{width}_{rate}.wav")
+        with wave.open(path, "wb") as w:
+            w.setnchannels(nch); w.setsampwidth(width); w.setframerate(rate); w.writeframes(raw)
+        want = audio_io.load_wav(path, 16000)
+        saved, audio_io._audioop = audio_io._audioop, None
+        try:
+            got = audio_io.load_wav(path, 16000)
+        finally:
+            audio_io._audioop = saved
+        assert saved is audioop and got.dtype == np.int16 and np.array_equal(got, want), (nch, width, rate)

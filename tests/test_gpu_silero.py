@@ -310,3 +310,43 @@ def test_pcm16_part_encodes_fill_one_workspace(engine):
     bad = lambda b0, nb: L.vadx_silero_encode_pcm16_part(engine.packed.data_ptr(), pcm.data_ptr(), engine.PCM16_SCALE, nb, n, n,   # noqa: E731
                                                          b0, B, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     assert bad(8, 16) != 0 and bad(64, 32) != 0 and bad(-16, 16) != 0
+
+
+# ------------------------------------------------------------------ 8 kHz branch: segmenter + wrapper plumbing
+def test_segmenter_8k_matches_reference(golden, engine):
+    """Device segmenter at sampling_rate = 8000 (256-sample windows) vs the reference's get_speech_timestamps on replayed
+    probabilities: integer sample indices / rounded seconds bit-exact."""
+    g = golden("silero_8k")
+    for i in range(int(g["n_cases"])):
+        kw = dict(eval(str(g["kwargs"][i])))
+        res = silero.segments_from_probs(engine, g[f"probs_{i}"][None, :], [int(g[f"nsamp_{i}"])], **kw)[0]
+        got = np.array([[d["start"], d["end"]] for d in res], dtype=np.float64).reshape(-1, 2)
+        assert np.array_equal(got, g[f"res_{i}"]), i
+
+
+def test_wrapper_8k_plumbing_and_refusal(golden, engine):
+    """The wrapper accepts 8000 Hz like the reference (256-sample windows, 32-sample context, state carried): with the
+    fixture's stand-in session it feeds exactly what the reference wrapper fed; with the real session the 8 kHz network,
+    which is not built, is refused loudly instead of being run through the 16 kHz weights."""
+    g = golden("silero_8k")
+    m = silero.OnnxWrapper(engine)
+    assert m.sample_rates == [8000, 16000]
+    fed = []
+
+    class FakeSession:
+        def run(self, _names, feeds):
+            assert int(feeds["sr"]) == 8000
+            fed.append(feeds["input"].cpu().numpy().copy())
+            return [torch.full((feeds["input"].shape[0], 1), 0.25), feeds["state"] + 1.0]
+
+    m.session = FakeSession()
+    probs = m.audio_forward(T(g["wrap_audio"]), 8000).numpy()
+    assert np.array_equal(probs, g["wrap_probs"]) and np.array_equal(np.stack(fed), g["wrap_inputs"])
+    assert np.array_equal(m._state.cpu().numpy(), g["wrap_final_state"]) and np.array_equal(m._context.cpu().numpy(), g["wrap_final_context"])
+    m2 = silero.OnnxWrapper(engine)
+    with pytest.raises(ValueError, match="16 kHz sub-graph"):
+        m2(torch.zeros(1, 256), 8000)
+    with pytest.raises(ValueError, match="Provided number of samples"):
+        m2(torch.zeros(1, 512), 8000)
+    with pytest.raises(ValueError, match="16 kHz sub-graph"):
+        silero.get_speech_timestamps(torch.zeros(4000), m2, sampling_rate=8000)

@@ -426,3 +426,13 @@ def test_marblenet_in_graph_resample_frontend(golden, rate):
     lm = omb.log_mel(omb.Frontend(), T(g[f"marble_{rate}_audio"]), rate)
     assert lm.shape == g[f"marble_{rate}_logmel"].shape
     np.testing.assert_allclose(lm.numpy(), g[f"marble_{rate}_logmel"], rtol=0, atol=2e-5)
+
+
+def test_silero_segmenter_8k(golden):
+    """sampling_rate = 8000: 256-sample windows (utils_vad.py:345) through the same state machine."""
+    g = golden("silero_8k")
+    for i in range(int(g["n_cases"])):
+        kw = dict(eval(str(g["kwargs"][i])))
+        res = opp.silero_segments([float(v) for v in g[f"probs_{i}"]], int(g[f"nsamp_{i}"]), **kw)
+        got = np.array([[d["start"], d["end"]] for d in res], dtype=np.float64).reshape(-1, 2)
+        assert np.array_equal(got, g[f"res_{i}"]), i

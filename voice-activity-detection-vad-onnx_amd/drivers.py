@@ -1,7 +1,9 @@
 """Script-level drop-ins for the reference's `Inference_*_VAD_ONNX.py` programs: raw audio file(s) in,
 `timestamps_second.txt` / `timestamps_indices.txt` out, same constants (as keyword arguments instead
-of module-level globals), same stdout summary.  Each function also accepts a LIST of files and runs
-them as one device batch (equal-length files; ragged lists are grouped by length)."""
+of module-level globals), same stdout summary.  Each function also accepts a LIST of files: equal-length files run as one
+device batch per length group (`_grouped`; the Silero driver pads ragged clips into one batch instead); the printed RTF is
+over the total audio duration.  `engine` / `model` may be an engine object, a weight dict, a checkpoint path, or the explicit
+opt-in "synthetic:<seed>" (vadx.checkpoints.resolve) -- never an implicit default."""
 from __future__ import annotations
 
 import time
@@ -13,6 +15,20 @@ from . import audio_io, timestamps
 
 def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def _grouped(clips, noises, run):
+    """Run `run(stacked_clips [G, n], stacked_noise or None) -> list of G results` once per group of equal-length clips
+    (one device batch each) and hand the results back in input order."""
+    by_len = {}
+    for k, c in enumerate(clips):
+        by_len.setdefault(len(c), []).append(k)
+    out = [None] * len(clips)
+    for idx in by_len.values():
+        nz = None if noises is None else np.stack([np.asarray(noises[k]) for k in idx])
+        for k, r in zip(idx, run(np.stack([clips[k] for k in idx]), nz)):
+            out[k] = r
+    return out
 
 
 def _finish(all_ts, sample_rate, save_second, save_indices, single, elapsed, echo):
@@ -61,13 +77,11 @@ def inference_fsmn(test_vad_audio="./vad_sample.wav", engine=None, save_timestam
     clips = [audio_io.load_wav(f, 16000) for f in files]
     echo("\nRunning the FSMN_VAD by ONNX Runtime.")
     t0 = time.time()
-    all_ts = []
-    for c, nz in zip(clips, pad_noise if pad_noise is not None else [None] * len(clips)):
-        all_ts += engine.detect(c[None, :].astype(np.float32), pad_noise=None if nz is None else nz[None, :],
-                                fusion_threshold=FUSION_THRESHOLD, min_speech_duration=MIN_SPEECH_DURATION,
-                                look_backward_s=LOOK_BACKWARD, speaking_score=SPEAKING_SCORE, silence_score=SILENCE_SCORE,
-                                snr_threshold=SNR_THRESHOLD, noise_init_dB=BACKGROUND_NOISE_dB_INIT,
-                                one_minus_speech_threshold=ONE_MINUS_SPEECH_THRESHOLD)
+    all_ts = _grouped(clips, pad_noise, lambda batch, nz: engine.detect(
+        batch.astype(np.float32), pad_noise=nz, fusion_threshold=FUSION_THRESHOLD, min_speech_duration=MIN_SPEECH_DURATION,
+        look_backward_s=LOOK_BACKWARD, speaking_score=SPEAKING_SCORE, silence_score=SILENCE_SCORE,
+        snr_threshold=SNR_THRESHOLD, noise_init_dB=BACKGROUND_NOISE_dB_INIT,
+        one_minus_speech_threshold=ONE_MINUS_SPEECH_THRESHOLD))
     elapsed = time.time() - t0
     return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_vad_audio, (list, tuple)), elapsed, echo)
 
@@ -87,11 +101,9 @@ def inference_firered(test_vad_audio="./vad_sample.wav", engine=None, save_times
     t0 = time.time()
     post = (SMOOTH_WINDOW_SIZE, SPEAKING_SCORE, MIN_SPEECH_FRAME, MAX_SPEECH_FRAME, MIN_SILENCE_FRAME,
             MERGE_SILENCE_FRAME, EXTEND_SPEECH_FRAME)
-    all_ts = []
-    for c, nz in zip(clips, pad_noise if pad_noise is not None else [None] * len(clips)):
-        all_ts += engine.detect(c[None, :], pad_noise=None if nz is None else nz[None, :], post=post)
+    all_ts = _grouped(clips, pad_noise, lambda batch, nz: engine.detect(batch, pad_noise=nz, post=post))
     elapsed = time.time() - t0
-    echo(f"RTF: {elapsed / (len(clips[0]) / 16000):.4f}")
+    echo(f"RTF: {elapsed / (sum(len(c) for c in clips) / 16000):.4f}")
     return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_vad_audio, (list, tuple)), elapsed, echo)
 
 
@@ -170,9 +182,7 @@ def inference_marblenet(test_vad_audio="./vad_sample.wav", engine=None, save_tim
     t0 = time.time()
     post = (SMOOTH_WINDOW_SIZE, SPEAKING_SCORE, MIN_SPEECH_FRAME, MAX_SPEECH_FRAME, MIN_SILENCE_FRAME,
             MERGE_SILENCE_FRAME, EXTEND_SPEECH_FRAME)
-    all_ts = []
-    for c, nz in zip(clips, pad_noise if pad_noise is not None else [None] * len(clips)):
-        all_ts += engine.detect(c[None, :], window_len=INPUT_AUDIO_LENGTH, pad_noise=None if nz is None else nz[None, :], post=post)
+    all_ts = _grouped(clips, pad_noise, lambda batch, nz: engine.detect(batch, window_len=INPUT_AUDIO_LENGTH, pad_noise=nz, post=post))
     elapsed = time.time() - t0
     return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_vad_audio, (list, tuple)), elapsed, echo)
 
@@ -187,15 +197,26 @@ def inference_dfsmn(test_near_end_audio="./examples/nearend_mic.wav", test_far_e
     nears, fars = _as_list(test_near_end_audio), _as_list(test_far_end_audio)
     engine = dfsmn.DfsmnEngine(engine) if (engine is None or isinstance(engine, (str, dict))) else engine
     echo(f"\nTest Input Near_End Audio: {test_near_end_audio}\nTest Input Far_End Audio: {test_far_end_audio}")
-    all_ts = []
-    t0 = time.time()
-    for k, (pn, pf) in enumerate(zip(nears, fars)):
+    pairs = []
+    for pn, pf in zip(nears, fars):                 # files are read before the clock starts, like the reference script
         a, f = audio_io.load_wav(pn, 16000).astype(np.float32), audio_io.load_wav(pf, 16000).astype(np.float32)
-        nzn = None if pad_noise_near is None else np.asarray(pad_noise_near)[k][None, :]
-        nzf = None if pad_noise_far is None else np.asarray(pad_noise_far)[k][None, :]
         n = min(len(a), len(f))
-        all_ts += engine.detect(a[None, :n], f[None, :n], nzn, nzf, fusion_threshold=FUSION_THRESHOLD,
-                                min_speech_duration=MIN_SPEECH_DURATION, speaking_score=SPEAKING_SCORE, silence_score=SILENCE_SCORE)
+        pairs.append(np.stack([a[:n], f[:n]]))
+    t0 = time.time()
+    noises = None if pad_noise_near is None else [np.stack([np.asarray(pad_noise_near)[k], np.asarray(pad_noise_far)[k]])
+                                                  for k in range(len(pairs))]
+    by_len = {}
+    for k, pr in enumerate(pairs):
+        by_len.setdefault(pr.shape[1], []).append(k)
+    all_ts = [None] * len(pairs)
+    for idx in by_len.values():                     # one device batch per group of equal-length pairs
+        near, far = np.stack([pairs[k][0] for k in idx]), np.stack([pairs[k][1] for k in idx])
+        nzn = None if noises is None else np.stack([noises[k][0] for k in idx])
+        nzf = None if noises is None else np.stack([noises[k][1] for k in idx])
+        res = engine.detect(near, far, nzn, nzf, fusion_threshold=FUSION_THRESHOLD, min_speech_duration=MIN_SPEECH_DURATION,
+                            speaking_score=SPEAKING_SCORE, silence_score=SILENCE_SCORE)
+        for k, r in zip(idx, res):
+            all_ts[k] = r
     elapsed = time.time() - t0
     return _finish(all_ts, 16000, save_timestamps_second, save_timestamps_indices, not isinstance(test_near_end_audio, (list, tuple)), elapsed, echo)
 

@@ -229,17 +229,37 @@ def seg_params(threshold=0.5, sampling_rate=16000, min_speech_duration_ms=250,
     return p
 
 
+class SileroSession:
+    """What the reference's OnnxWrapper holds as `self.session`: run(None, {'input' [B, ctx + n], 'state' [2,B,128], 'sr' int64})
+    -> [out [B,1], stateN [2,B,128]] (utils_vad.py:116-119).  The 16 kHz sub-graph (576-sample input) runs on the HIP engine;
+    the upstream file's 8 kHz sub-graph (288-sample input, 128-point STFT, 65-channel first conv) is a different network
+    whose weights only exist inside the un-vendored silero_vad.onnx -- it is not built, and asking for it fails loudly."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def run(self, output_names, feeds):
+        sr = int(np.asarray(feeds["sr"]))
+        if sr != 16000:
+            raise ValueError(f"sr={sr}: only the 16 kHz sub-graph of the Silero network is built on the HIP path "
+                             "(the wrapper and the segmenter handle 8000 Hz; the 8 kHz network itself is not implemented)")
+        out, state = self.engine.step(feeds["input"], feeds["state"])
+        return [out, state]
+
+
 class OnnxWrapper:
-    """Stateful per-window model object with the reference wrapper's interface; `path` may be a
-    weight dict, an .npz of the same keys, or 'synthetic[:seed]'."""
+    """Drop-in for the reference wrapper (utils_vad.py:10-146): validation, state / context carry, reset rules."""
 
     def __init__(self, path=None, force_onnx_cpu=True, device="cuda:0"):
         self.engine = path if isinstance(path, SileroEngine) else SileroEngine(path, device)
         self.torch = self.engine.torch
+        self.session = SileroSession(self.engine)
         self.reset_states()
         if isinstance(path, str) and "16k" in path:
             warnings.warn("This model support only 16000 sampling rate!")
-        self.sample_rates = [16000]      # the 8 kHz branch of the upstream graph is not built
+            self.sample_rates = [16000]
+        else:
+            self.sample_rates = [8000, 16000]        # utils_vad.py:63-67; an 8000 Hz call reaches SileroSession.run, which refuses it
 
     def _validate_input(self, x, sr: int):
         if x.dim() == 1:
@@ -267,10 +287,12 @@ class OnnxWrapper:
         if not t.is_tensor(x):
             x = t.as_tensor(np.asarray(x, dtype=np.float32))
         x, sr = self._validate_input(x, sr)
-        if x.shape[-1] != NUM_SAMPLES:
+        num_samples = NUM_SAMPLES if sr == 16000 else 256
+        if x.shape[-1] != num_samples:
             raise ValueError(f"Provided number of samples is {x.shape[-1]} "
                              "(Supported values: 256 for 8000 sample rate, 512 for 16000)")
         batch_size = x.shape[0]
+        context_size = CONTEXT_SIZE if sr == 16000 else 32
         if not self._last_batch_size:
             self.reset_states(batch_size)
         if self._last_sr and self._last_sr != sr:
@@ -279,21 +301,28 @@ class OnnxWrapper:
             self.reset_states(batch_size)
         x = x.to(device=self.engine.device, dtype=t.float32)
         if not len(self._context):
-            self._context = t.zeros(batch_size, CONTEXT_SIZE, device=self.engine.device)
+            self._context = t.zeros(batch_size, context_size, device=self.engine.device)
         x = t.cat([self._context, x], dim=1)
-        out, self._state = self.engine.step(x, self._state)
-        self._context = x[..., -CONTEXT_SIZE:]
+        out, state = self.session.run(None, {"input": x, "state": self._state, "sr": np.array(sr, dtype="int64")})
+        self._state = state if t.is_tensor(state) else t.as_tensor(np.asarray(state), device=self.engine.device)
+        self._context = x[..., -context_size:]
         self._last_sr = sr
         self._last_batch_size = batch_size
-        return out.cpu()
+        return out.cpu() if t.is_tensor(out) else t.as_tensor(np.asarray(out))
 
     def audio_forward(self, x, sr: int):
-        """Whole clips in ONE device call (the reference loops window by window)."""
+        """Whole clips in ONE device call at 16 kHz (the reference loops window by window, utils_vad.py:130-146; at 8000 Hz
+        this does too, through `__call__`, so a substituted session sees exactly the reference's feeds)."""
         t = self.torch
         if not t.is_tensor(x):
             x = t.as_tensor(np.asarray(x, dtype=np.float32))
         x, sr = self._validate_input(x, sr)
         self.reset_states()
+        if sr != 16000:
+            num_samples = 256
+            if x.shape[1] % num_samples:
+                x = t.nn.functional.pad(x, (0, num_samples - (x.shape[1] % num_samples)), "constant", value=0.0)
+            return t.cat([self(x[:, i:i + num_samples], sr) for i in range(0, x.shape[1], num_samples)], dim=1).cpu()
         probs, state = self.engine.clips(x, return_state=True)
         # leave the wrapper exactly where the reference's loop would: last state + last 64 samples
         pad = (-x.shape[1]) % NUM_SAMPLES
@@ -301,6 +330,21 @@ class OnnxWrapper:
         self._state, self._context = state, xp[:, -CONTEXT_SIZE:]
         self._last_sr, self._last_batch_size = sr, x.shape[0]
         return probs.cpu()
+
+
+def segments_from_probs(engine, probs, lengths, **kw):
+    """The segmenter half of get_speech_timestamps on given window probabilities (device state machine, utils_vad.py:374-482):
+    probs [B, T] (T windows of 512 samples at 16 kHz / 256 at 8 kHz), lengths [B] in samples -> list of per-clip lists of
+    {'start','end'}.  kw as get_speech_timestamps (threshold, sampling_rate, min_speech_duration_ms, ..., return_seconds)."""
+    engine = engine.engine if isinstance(engine, OnnxWrapper) else engine
+    return_seconds = kw.pop("return_seconds", False)
+    time_resolution = kw.pop("time_resolution", 1)
+    sr = kw.get("sampling_rate", 16000)
+    if sr not in (8000, 16000):
+        raise ValueError("Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates")
+    lens = np.asarray(lengths, dtype=np.int64).reshape(-1)
+    segs, counts = engine.segments(probs, lens, **kw)
+    return _finish(segs, counts, lens, sr, return_seconds, time_resolution, 1)
 
 
 def load_silero_vad(onnx=True, opset_version=16, use_cpu=True, path="", device="cuda:0"):
@@ -351,9 +395,11 @@ def get_speech_timestamps_batch(audio, model, lengths=None, threshold: float = 0
         sampling_rate = 16000
         audio = audio[:, ::step].contiguous()
         warnings.warn("Sampling rate is a multiply of 16000, casting to 16000 manually!")
-    if sampling_rate != 16000:
-        raise ValueError("Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates"
-                         if sampling_rate != 8000 else "this build supports 16000 Hz (or a multiple) only")
+    if sampling_rate not in (8000, 16000):
+        raise ValueError("Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates")
+    if sampling_rate == 8000:
+        raise ValueError("sampling_rate=8000: only the 16 kHz sub-graph of the Silero network is built on the HIP path; "
+                         "window probabilities from elsewhere can be segmented with segments_from_probs(..., sampling_rate=8000)")
     B, N = audio.shape
     if N == 0:           # empty audio: the reference's chunk loop never runs and it returns [] (utils_vad.py:330-344)
         res = [[] for _ in range(B)]
