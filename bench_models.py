@@ -168,28 +168,29 @@ def device_ms(torch, fn, reps):
 
 
 def profiled_kernel_traffic(tag, kernel_substr):
-    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary profiles/r*_{tag}/SUMMARY.txt
-    (separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH doubled per MI355X_MICROARCH.md 'HBM'; values are KiB).
-    Lines look like `<kernel> grid=<n> FETCH_SIZE <mean per dispatch> n=<k>`; the largest grid wins."""
+    """HBM bytes PER PASS of every kernel whose name contains `kernel_substr`, from the newest committed rocprofv3 PMC summary
+    profiles/r*_{tag}/SUMMARY.txt (tools/profile_secondary.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes of the BASELINE-size
+    workload; lines `<kernel> calls_per_pass=<n> FETCH_SIZE sum_per_pass=<KiB>`).  FETCH is doubled per MI355X_MICROARCH.md
+    'HBM' (gfx950 tallies a wide coalesced read at half its bytes); both counters are KiB."""
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*{tag}*", "SUMMARY.txt"))):
-        fetch = write = None
-        grid = -1
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}", "SUMMARY.txt"))):
+        fetch = write = 0.0
+        calls = 0
+        seen = set()
         for line in open(path):
-            if kernel_substr not in line or "grid=" not in line or "_SIZE" not in line:
+            if kernel_substr not in line or "sum_per_pass=" not in line:
                 continue
-            g = int(line.split("grid=")[1].split()[0])
-            name, val = line.split()[-3], float(line.split()[-2])
-            if name in ("FETCH_SIZE", "WRITE_SIZE") and g >= grid:
-                if g > grid:
-                    fetch = write = None
-                grid = g
-                if name == "FETCH_SIZE":
-                    fetch = val
-                else:
-                    write = val
-        if fetch is not None and write is not None:
-            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT), "grid_threads": grid}
+            name = line.split("calls_per_pass=")[0].strip()
+            val = float(line.split("sum_per_pass=")[1])
+            if " FETCH_SIZE " in line:
+                fetch += val
+                if name not in seen:
+                    seen.add(name)
+                    calls += int(line.split("calls_per_pass=")[1].split()[0])
+            elif " WRITE_SIZE " in line:
+                write += val
+        if fetch > 0 or write > 0:
+            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT), "calls_per_pass": calls}
     return best
 
 
@@ -198,7 +199,34 @@ def _roof(kernel, flop, ms, tag=None, kernel_substr=None, note=None):
     tr = profiled_kernel_traffic(tag, kernel_substr) if tag else None
     r = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
          "frac": ach / PEAK_F32_MFMA_TFLOPS, "flop_per_launch": flop, "ms": ms,
-         "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None}
+         "traffic": tr["bytes"] if tr else None, "traffic_unit": "B per pass (all launches of the kernel)",
+         "traffic_source": tr["source"] if tr else None,
+         "traffic_GBps": (tr["bytes"] / (ms * 1e-3) / 1e9) if tr else None}
+    if note:
+        r["note"] = note
+    return r
+
+
+def bytes_dfsmn_pw_window(T=101, F=160, ch=20):
+    """HBM bytes one window's pw_conv launches must move: every launch reads its input tensors and writes its outputs once
+    (FT layout: tiles of 16 frames; U = one 20-channel tensor of a window).  The (3,1) / 1x1 convs have ~100 flop per 64-byte
+    row: these launches are HBM-bound, not matrix-pipe-bound."""
+    U = ((T + 15) // 16) * ch * F * 16 * 4
+    Uc = ((T + 15) // 16) * 2 * ch * 81 * 16 * 4               # a 40-channel x 81-bin CepsUnit tensor
+    n = 3 * U + (1 + 4 / ch + 1) * U                            # in_ch_lstm linear (40 -> 20), in_conv (24 -> 20)
+    for cin in (ch,) * 6 + (2 * ch,) * 4:
+        n += (cin / ch + 2) * U + 2 * Uc + 3 * U                # CFB front (in -> gx, r), ceps linear, CFB back (gx, ceps -> out)
+    n += (3 + 2 / ch) * U                                       # out_conv (60 -> 2)
+    return int(n)
+
+
+def _roof_hbm(kernel, algorithmic_bytes, ms, tag=None, kernel_substr=None, note=None):
+    ach = algorithmic_bytes / (ms * 1e-3) / 1e9
+    tr = profiled_kernel_traffic(tag, kernel_substr) if tag else None
+    r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBPS,
+         "algorithmic_bytes_per_pass": algorithmic_bytes, "ms": ms, "traffic": tr["bytes"] if tr else None,
+         "traffic_unit": "B per pass (all launches of the kernel)", "traffic_source": tr["source"] if tr else None,
+         "traffic_ratio": (tr["bytes"] / algorithmic_bytes) if tr else None}
     if note:
         r["note"] = note
     return r
@@ -381,8 +409,12 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
            "clip_pairs": clips, "samples_per_clip": n, "windows": nwin, "ms": ms,
            "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split, "kernel_calls": calls,
            "flop_per_window": fl,
-           "roofline": _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fl[dom], groups[dom], "dfsmn", dom,
-                             note="all launches of the entry point that takes the most time"),
+           "roofline": (_roof_hbm("pw_conv launches (vadx_dfsmn_pw_conv)", nwin * bytes_dfsmn_pw_window(), groups["pw_conv"], "dfsmn", "pw_conv",
+                                  note="all launches of the entry point that takes the most time; ~100 flop per 64-B row: HBM-bound")
+                        if dom == "pw_conv" else
+                        _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fl[dom], groups[dom], "dfsmn", dom,
+                              note="all launches of the entry point that takes the most time")),
+           "roofline_by_entry": {k: _roof(f"vadx_dfsmn_{k}", nwin * fl[k], v, "dfsmn", k) for k, v in groups.items() if v > 0},
            "roofline_whole_pass": _roof("all DFSMN launches", nwin * fl["total"], ms),
            "hbm": _hbm(clips * (2 * padded * 2 + W * eng.T_A * 4), ms), "cpu_baseline": None}
     del near, far
