@@ -10,8 +10,6 @@
 // LSTM recurrences keep h and c in registers: with gate rows ordered (unit-quad q, gate r) the D
 // fragment of step t is exactly the B fragment of step t+1 -- no LDS, no shuffles.
 #include "common.h"
-
-#include <stdlib.h>
 #include "layers.h"
 
 #include <math.h>
@@ -1229,8 +1227,9 @@ static int launch_pw(PwArgs p, int tiles, void *stream) {
     const int cin = p.a.c + p.b.c, halo = (KF - 1) / 2, nout = MODE == 1 ? 2 : 1;
     auto lds_floats = [&](int fc) { return cin * ((fc + 2 * halo) | 1) * 18 + nout * p.co * fc * 16; };
     int fc = 32;
-    static const int cap_kb = getenv("VADX_PW_LDS_KB") ? atoi(getenv("VADX_PW_LDS_KB")) : 52;     // (tuning aid)
-    while (fc > 4 && lds_floats(fc) * 4 > cap_kb * 1024) fc -= 4;
+    // (smaller chunks for more workgroups per CU were measured -- LDS caps of 40 / 26 / 16 KB: pw_conv 80 -> 94 / 105 / 111 ms
+    // per 1920 windows: shorter contiguous runs per channel and more halo rows cost more than the occupancy buys)
+    while (fc > 4 && lds_floats(fc) * 4 > 52 * 1024) fc -= 4;
     p.fc = fc;
     p.nchunk = (p.F + fc - 1) / fc;
     const size_t lds = (size_t)lds_floats(fc) * sizeof(float);
