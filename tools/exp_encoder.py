@@ -78,6 +78,16 @@ for a, b in ev:
     a.record(); rec(); b.record()
 torch.cuda.synchronize()
 tr = [a.elapsed_time(b) for a, b in ev]
+if hasattr(h, "vadx_silero_debug_cycles"):
+    buf = (C.c_ulonglong * 16)()
+    h.vadx_silero_debug_cycles(buf, 1)
+    enc(); torch.cuda.synchronize()
+    h.vadx_silero_debug_cycles(buf, 0)
+    tot = sum(buf) or 1
+    names = {0: "stage X", 1: "STFT fold + bin 64", 2: "|.| + transform (fp 0)", 3: "dense STFT", 4: "dense transform", 5: "transform (fp 1) / bin 64 row",
+             6: "conv1 planes", 7: "A^T + store A1", 8: "conv2", 9: "conv3", 10: "conv4", 11: "X loads issued", 12: "X loads landed", 13: "X -> LDS", 15: "W_ih + gx store"}
+    print("PHASES (share of wave-0 cycles, sum over workgroups):", ", ".join(f"{names.get(k, k)} {100.0 * v / tot:.1f}%%" for k, v in enumerate(buf) if v),
+          "| cycles per tile: %%.0f" %% (tot / (B // 16 * T)))
 print("EXP", os.path.basename(os.environ["VADX_LIBRARY"]), "encode ms mean %%.3f min %%.3f | recur ms mean %%.3f min %%.3f" %% (sum(ts) / len(ts), min(ts), sum(tr) / len(tr), min(tr)))
 """
 
@@ -87,6 +97,8 @@ def run(ids):
         env = dict(os.environ, VADX_LIBRARY=os.path.join(EXP, f"libvadx_exp{n}.so"))
         r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in r.stdout.splitlines() if l.startswith("EXP")]
+        for ph in [l for l in r.stdout.splitlines() if l.startswith("PHASES")]:
+            print(ph, flush=True)
         print(line[0] if line else f"EXP {n} FAILED rc={r.returncode}\n{r.stderr[-800:]}", flush=True)
 
 

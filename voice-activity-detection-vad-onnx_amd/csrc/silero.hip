@@ -20,6 +20,21 @@
 #define VADX_EXP 0
 #endif
 #define ENC_SKIP(n) ((VADX_EXP >> (n)) & 1)          // VADX_EXP is a bit mask of what-if switches
+// bit 14: per-phase cycle accounting of wave 0 of every workgroup (s_memtime deltas summed into enc_dbg[slot]; read with
+// vadx_silero_debug_cycles, tools/exp_encoder.py) -- slot k = time from the previous mark to mark k
+#if (VADX_EXP >> 14) & 1
+__device__ unsigned long long enc_dbg[16];
+#define ENC_T0() long long enc_t_ = __builtin_readcyclecounter()
+#define ENC_MARK(slot) do { if (threadIdx.x == 0) { const long long n_ = __builtin_readcyclecounter(); atomicAdd(&enc_dbg[slot], (unsigned long long)(n_ - enc_t_)); enc_t_ = n_; } } while (0)
+extern "C" int vadx_silero_debug_cycles(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(enc_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(enc_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define ENC_T0() do {} while (0)
+#define ENC_MARK(slot) do {} while (0)
+#endif
 #if (VADX_EXP >> 2) & 1
 #define ENC_SYNC() __builtin_amdgcn_wave_barrier()
 #else
@@ -59,21 +74,22 @@ constexpr int OFF_B64 = OFF_S0 + 128;              // [2][128] bin 64, time-fold
 constexpr int OFF_FOLD = OFF_B64 + 256 + 4;        // [1] (+3 pad)  1.0 = folded pass valid
 constexpr int PACKED_FLOATS = OFF_FOLD + 4;
 
-// ---- encoder LDS map (floats): 51 856 B per workgroup => THREE workgroups per CU ------------------
+// ---- encoder LDS map (floats): 52 624 B per workgroup => THREE workgroups per CU ------------------
 // One region is reused by every phase; a phase whose output would overwrite its own input keeps the
 // result in registers across a barrier before storing it (STFT -> V, conv1 -> A1):
 //   X  [16 clips][642]  raw windows in their global layout (row stride 642 = 2 mod 32: with the
 //       STFT's k permutation the half-wave (clip i, q) hits bank 2i+q -> conflict free)
 //   -> V  [129 ch][6 planes x 16 (+4)]  |STFT| in the Winograd F(4,3) input domain (V_j = sum_f BT[j][f] |X_f|), k-major;
-//         + 64 floats of scratch behind it (bin 64 / Nyquist magnitudes of the four frames, combined by one wave)
+//         + 256 floats of scratch behind it (bin 64 partial sums [8 waves][re|im][16 clips] / Nyquist magnitudes of the four
+//         frames, combined by the lanes that write that row of V)
 //   -> A1 [128 ch][4 frames x 16 (+4)]  conv1 output, with A2 [64][2x16 (+4)] (conv2 output) right behind it
 //   -> A3 [64][16 (+4)], A4 [128][16 (+4)]   (A1 is dead after conv2)
 // Conv zero padding is never stored: the Winograd input transform is written for zero frames -1 and 4, and the taps of
 // conv2..4 that would read padding are simply not issued.
 constexpr int X_LDM = 642;
 constexpr int V_LD = 100, A1_LD = 68, A2_LD = 36, A3_LD = 20, A4_LD = 20;
-constexpr int V_SCR = 129 * V_LD;                  // [4 frames][16 clips]
-constexpr int R0_FLOATS = V_SCR + 64;              // 12964  (X: 16*642 = 10272; A1 + A2: 128*68 + 64*36 = 11008)
+constexpr int V_SCR = 129 * V_LD;                  // fold: [8 waves][2][16 clips]; dense: [4 frames][16 clips]
+constexpr int R0_FLOATS = V_SCR + 256;             // 13156  (X: 16*642 = 10272; A1 + A2: 128*68 + 64*36 = 11008)
 constexpr int A2_OFF = 128 * A1_LD;
 constexpr int A3_OFF = 0, A4_OFF = 64 * A3_LD;
 constexpr int ENC_LDS_FLOATS = R0_FLOATS;
@@ -134,7 +150,7 @@ __device__ __forceinline__ void gemm_pass_mmajor(f32x4 (&acc)[NT][MT], const flo
 // contraction index of either class walks its plane with unit stride (bank = 2*clip + q: conflict free).
 // Class E: n = 2m + 2 (plane index m + 1, mirror 127 - m); class O: n = 2m + 1 (plane index m, mirror 127 - m);
 // contraction slot (block S, sub-step j, quarter q) <-> m = 16S + q + 4j.
-constexpr int X_ODD = 321;            // offset of the odd plane inside a clip row
+constexpr int X_ODD = 322;            // offset of the odd plane inside a clip row (even: the staging code stores sample pairs 8 B wide)
 __device__ __forceinline__ void stft_fold_class(f32x4 (&are)[2], f32x4 (&aim)[2], const float *fwd, const float *rev,
                                                 const float *wre, const float *wim) {
     f32x4 cre = *reinterpret_cast<const f32x4 *>(wre), cim = *reinterpret_cast<const f32x4 *>(wim);
@@ -283,6 +299,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
     const int grp = blockIdx.x % G, t = blockIdx.x / G;
 
     const bool fold = P[OFF_FOLD] != 0.f;      // uniform: the basis has the DFT symmetries -> folded STFT pass
+    ENC_T0();
     // ---------------- phase 0: copy the 16 windows (576 samples each) + right reflect pad of 64
     // (folded pass: even / odd samples go to separate planes of the clip row)
     auto xslot = [fold](int pp) { return fold ? (pp & 1) * X_ODD + (pp >> 1) : pp; };
@@ -293,6 +310,52 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
         // float4 UNCONDITIONALLY from a clamped address, all five loads back to back (a load under a condition -- even a
         // uniform one -- compiles to a branch plus a full wait: five serialised HBM round trips per tile); the rare edge
         // lanes (first / last windows, clips past B) patch their values afterwards in a branch that is normally skipped.
+        // FAST PATH (every window except a clip's first and last few, and groups that run past the batch): wave w stages clips
+        // 2w and 2w+1, lane l the float4s l, l+64, l+128 (< 144) of each -- the address is a wave-uniform row base plus
+        // 16 * lane bytes (no divisions, no 64-bit per-lane arithmetic, no per-element conditions), six loads back to back,
+        // and a float4 of samples (p .. p+3) leaves as two 8-byte LDS stores: (p, p+2) into the even plane, (p+1, p+3) into
+        // the odd plane.  Only the 17 float4s that hold samples 511..574 also write the mirrored reflect-pad slots.
+        // (Cycle accounting of the general path below: 8 k cycles to issue the five loads, 11 k for the LDS scatter -- a
+        // sixth of the tile's time on index arithmetic -- against 1.8 k waiting for HBM.)
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const bool fast = fold && vec_ok && base >= 0 && base + 576 <= n_samples && (long long)grp * 16 + 16 <= B;
+        if (fast) {
+            f32x4 xv[2][3];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const SampleT *src = audio + ((long long)grp * 16 + 2 * wv + k2) * row_stride + base;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int f = j < 2 ? lane + 64 * j : min(lane + 128, 143);
+                    xv[k2][j] = SampleIO<SampleT>::load4(src + 4 * f, in_scale);
+                }
+            }
+#if (VADX_EXP >> 14) & 1
+            ENC_MARK(11);
+            if (xv[1][2][3] == 123.456f) X[0] = 0.f;
+            ENC_MARK(12);
+#endif
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                float *row = X + (2 * wv + k2) * X_LDM;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int f = lane + 64 * j;
+                    if (j < 2 || lane < 16) {
+                        const f32x4 v = xv[k2][j];
+                        *reinterpret_cast<float2 *>(row + 2 * f) = float2{v[0], v[2]};
+                        *reinterpret_cast<float2 *>(row + X_ODD + 2 * f) = float2{v[1], v[3]};
+                        if (f >= 127) {                                               // samples 508..575: reflect pad (0, 64)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const int pp = 4 * f + jj;
+                                if (pp >= 511 && pp <= 574) row[xslot(1150 - pp)] = v[jj];
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
         f32x4 x4[5];
         if (vec_ok) {
 #pragma unroll
@@ -304,6 +367,11 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                 x4[it] = SampleIO<SampleT>::load4(src + idc, in_scale);
             }
         }
+#if (VADX_EXP >> 14) & 1
+        ENC_MARK(11);                                   // loads issued
+        if (x4[4][3] == 123.456f) X[0] = 0.f;           // (forces the wait here)
+        ENC_MARK(12);                                   // loads landed
+#endif
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
             const int e = tid + ENC_THREADS * it;            // 16 clips x 144 float4
@@ -332,8 +400,13 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                 }
             }
         }
+        }   // general path
     }
+#if (VADX_EXP >> 14) & 1
+    ENC_MARK(13);                                       // LDS writes issued
+#endif
     ENC_SYNC();
+    ENC_MARK(0);
 
     // ---------------- phase 1: STFT conv -> magnitude (results stay in registers until every wave is done with X)
     if (fold) {
@@ -357,27 +430,30 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             stft_fold_class(ere, eim, row + 1 + q, row + 127 - q, wt, wt + 4 * FRAG);
             stft_fold_class(ore, oim, row + X_ODD + q, row + X_ODD + 127 - q, wt + 8 * FRAG, wt + 12 * FRAG);
         }
-        float b64 = 0.f;
-        if (wave < 4 && !ENC_SKIP(7)) {   // bin 64 (its own mirror): frame f = wave, lane = (clip i, quarter q of n = 1..128)
-            const int f = wave;
-            const float *bre = P + OFF_B64 + q * 32, *bim = P + OFF_B64 + 128 + q * 32;
+        // bin 64 (its own mirror) on the VALU, spread over all eight waves: wave = (frame f = wave & 3, half h of n = 1..128),
+        // lane = (clip i, quarter q of the half): 16 taps each, summed over q by shuffles and over h through the scratch
+        float b64re = 0.f, b64im = 0.f;
+        if (!ENC_SKIP(7)) {
+            const int f = wave & 3, h = wave >> 2, n0 = h * 64 + q * 16;
+            const float *bre = P + OFF_B64 + n0, *bim = P + OFF_B64 + 128 + n0;
             const float *xr = X + i * X_LDM + 64 * f;
-            float sre = 0.f, sim = 0.f;
 #pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
-                const int n = q * 32 + k + 1;                                         // 1..128, mirror 256 - n
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const int n = n0 + k2 + 1;                                            // 1..128, mirror 256 - n
                 const float a = xr[(n & 1) * X_ODD + (n >> 1)], b = xr[(n & 1) * X_ODD + ((256 - n) >> 1)];
-                sre = fmaf(a + b, bre[k], sre);
-                sim = fmaf(a - b, bim[k], sim);
+                b64re = fmaf(a + b, bre[k2], b64re);
+                b64im = fmaf(a - b, bim[k2], b64im);
             }
-            sre += __shfl_xor(sre, 16); sre += __shfl_xor(sre, 32);
-            sim += __shfl_xor(sim, 16); sim += __shfl_xor(sim, 32);
-            const float x0 = xr[0];
-            sre = fmaf(x0, P[OFF_B64 + 256], sre);
-            sim = fmaf(x0, P[OFF_B64 + 257], sim);
-            b64 = sqrtf(sre * sre + sim * sim);
+            b64re += __shfl_xor(b64re, 16); b64re += __shfl_xor(b64re, 32);
+            b64im += __shfl_xor(b64im, 16); b64im += __shfl_xor(b64im, 32);
+            if (h == 0) {                                                             // the n = 0 tap
+                const float x0 = xr[0];
+                b64re = fmaf(x0, P[OFF_B64 + 256], b64re);
+                b64im = fmaf(x0, P[OFF_B64 + 257], b64im);
+            }
         }
         ENC_SYNC();          // every wave is done reading X: V may now overwrite it
+        ENC_MARK(1);
         // Winograd input transform across the two waves that hold a bin's four frames: the fp = 0 wave stores its share
         // c[j][0] |X_0| + c[j][1] |X_1| of every plane, the fp = 1 wave adds c[j][2] |X_2| + c[j][3] |X_3| behind a barrier
         // (one store, one add: the sum does not depend on timing).
@@ -399,9 +475,10 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                 *reinterpret_cast<f32x4 *>(vk + j * 16) = WINO_BT[j][0] * mk[0] + WINO_BT[j][1] * mk[1];
                 *reinterpret_cast<f32x4 *>(vn + j * 16) = WINO_BT[j][0] * mn[0] + WINO_BT[j][1] * mn[1];
             }
-            if (q == 0) scr[wave * 16 + i] = b64;            // waves 0..3 = (tl, fp = 0): bin 64 of frame `wave`
         }
+        if (q == 0) { scr[wave * 32 + i] = b64re; scr[wave * 32 + 16 + i] = b64im; }      // partial (re, im) of bin 64, frame wave & 3
         ENC_SYNC();
+        ENC_MARK(2);
         if (fp == 1) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -409,9 +486,15 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
                 *pk = *pk + (WINO_BT[j][2] * mk[0] + WINO_BT[j][3] * mk[1]);
                 *pn = *pn + (WINO_BT[j][2] * mn[0] + WINO_BT[j][3] * mn[1]);
             }
-        } else if (tid < 96) {                                // bin 64 (its own mirror): plane j = tid / 16, clip = tid % 16
+        } else if (tid < 96) {                                // bin 64 row of V: plane j = tid / 16, clip = tid % 16
             const int j = tid >> 4, c = tid & 15;
-            V[64 * V_LD + j * 16 + c] = WINO_BT[j][0] * scr[c] + WINO_BT[j][1] * scr[16 + c] + WINO_BT[j][2] * scr[32 + c] + WINO_BT[j][3] * scr[48 + c];
+            float m[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const float re = scr[f * 32 + c] + scr[(f + 4) * 32 + c], im = scr[f * 32 + 16 + c] + scr[(f + 4) * 32 + 16 + c];
+                m[f] = sqrtf(re * re + im * im);
+            }
+            V[64 * V_LD + j * 16 + c] = WINO_BT[j][0] * m[0] + WINO_BT[j][1] * m[1] + WINO_BT[j][2] * m[2] + WINO_BT[j][3] * m[3];
         }
     } else {
         f32x4 acc[2][4];
@@ -440,6 +523,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             nyq = sqrtf(sre * sre + sim * sim);
         }
         ENC_SYNC();          // every wave is done reading X: V may now overwrite it
+        ENC_MARK(3);
         {   // this wave holds all four frames of its 16 bins: Winograd input transform in registers
             f32x4 m[4];
 #pragma unroll
@@ -453,12 +537,14 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
         }
         if (wave < 4 && q == 0) scr[wave * 16 + i] = nyq;
         ENC_SYNC();
+        ENC_MARK(4);
         if (tid < 96) {                                       // Nyquist bin: plane j = tid / 16, clip = tid % 16
             const int j = tid >> 4, c = tid & 15;
             V[128 * V_LD + j * 16 + c] = WINO_BT[j][0] * scr[c] + WINO_BT[j][1] * scr[16 + c] + WINO_BT[j][2] * scr[32 + c] + WINO_BT[j][3] * scr[48 + c];
         }
     }
     ENC_SYNC();
+    ENC_MARK(5);
 
     // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU as Winograd F(4,3) over the window's four frames:
     // six plane GEMMs M_j = U_j V_j (U_j = G g packed on the host in float64) instead of the ten tap GEMMs a direct
@@ -481,6 +567,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
         }
         const float bias = P[OFF_B1 + wave * 16 + i];
         ENC_SYNC();          // every wave is done reading V: A1 may now overwrite it
+        ENC_MARK(6);
         const f32x4 s12 = acc[1] + acc[2], d12 = acc[1] - acc[2], s34 = acc[3] + acc[4], d34 = acc[3] - acc[4];
         f32x4 y[4];
         y[0] = acc[0] + s12 + s34;
@@ -496,6 +583,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
         }
     }
     ENC_SYNC();
+    ENC_MARK(7);
 
     // ---------------- phase 3: conv2 128->64, k3 s2 p1, ReLU (out frame fp reads in frames 2fp-1..2fp+1)
     {
@@ -512,6 +600,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
         *reinterpret_cast<f32x4 *>(&A2[(nt * 16 + i) * A2_LD + fp * 16 + 4 * q]) = v;
     }
     ENC_SYNC();
+    ENC_MARK(8);
 
     // ---------------- phase 4: conv3 64->64, k3 s2 p1, ReLU (1 out frame; tap 0 reads padding)
     if (wave < 4) {
@@ -525,6 +614,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
         *reinterpret_cast<f32x4 *>(&A3[(wave * 16 + i) * A3_LD + 4 * q]) = v;
     }
     ENC_SYNC();
+    ENC_MARK(9);
 
     // ---------------- phase 5: conv4 64->128, k3 s1 p1, ReLU (1 frame in/out; centre tap only)
     {
@@ -536,6 +626,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
         *reinterpret_cast<f32x4 *>(&A4[(wave * 16 + i) * A4_LD + 4 * q]) = v;
     }
     ENC_SYNC();
+    ENC_MARK(10);
 
     // ---------------- phase 6: LSTM input projection, gate-major (D rows = hidden units)
     {
@@ -571,6 +662,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
         for (int g = 0; g < 4; ++g)
             if (!ENC_SKIP(8) || acc[g][0][0] == 12345.f) *reinterpret_cast<f32x4 *>(dst + g * 256) = acc[g][0];
     }
+    ENC_MARK(15);
 }
 
 // ---- persistent LSTM --------------------------------------------------------------------------
