@@ -56,7 +56,7 @@ struct Dev {
     int passes, pass_kb[MAX_PASSES], pass_koff[MAX_PASSES];   // 16-blocks per pass, k offset in table row
     int Kp;                 // padded taps per table row
     int nbt;                // MFMA bin tiles (16 bins each)
-    int nyq;                // 1 => bin n_bins-1 handled on the VALU (n_bins % 16 == 1)
+    int nyq;                // 1 => bin n_bins-1 (n_bins % 16 == 1) is its own 16-row tile (row 0 = re, row 1 = im), K-split over the waves
     int Fp;                 // padded bins (power rows)
     int nmt, mel_kb_lo[MAX_MEL_TILES], mel_kb_hi[MAX_MEL_TILES];
     int off_dft, off_nyq, off_mel;    // float offsets in the packed blob
@@ -94,7 +94,7 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     d->nmt = c->n_mels / 16;
     d->off_dft = 0;
     d->off_nyq = d->off_dft + d->nbt * 32 * d->Kp;
-    d->off_mel = d->off_nyq + 2 * d->Kp;
+    d->off_mel = d->off_nyq + 16 * d->Kp;
     d->tiles32 = c->frames / TF;
     const int rem = c->frames - d->tiles32 * TF;
     d->tiles16 = (rem + 15) / 16;
@@ -270,31 +270,46 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
     }
     if (COMPLEX) return;
     FE_ACC(1);
-    if (d.nyq) {            // last bin (n_bins % 16 == 1): frames x taps dot products on the VALU
-        // thread = (frame tid >> 4, tap residue tid & 15): all 512 threads share the dot products and the 16 partial sums
-        // of a frame meet through four shuffles (this used to run on 128 threads over 4 residues: a third of the kernel)
-        const float *nre = P + d.off_nyq, *nim = nre + d.Kp;
-        const int f = tid >> 4, part = tid & 15;
-        float sre = 0.f, sim = 0.f;
-        if (f < NF)
-            for (int a = 0; a < d.passes; ++a) {
-                const int rows = d.pass_kb[a] * 16;
-                const float *xr = X2 + f + a, *tr = nre + d.pass_koff[a], *ti = nim + d.pass_koff[a];
-#pragma unroll 5
-                for (int r = part; r < rows; r += 16) {
-                    const float x = xr[r * X_LD];
-                    sre = fmaf(x, tr[r], sre);
-                    sim = fmaf(x, ti[r], sim);
-                }
-            }
+    if (d.nyq) {
+        // Last bin (n_bins % 16 == 1, e.g. the Nyquist bin of a 512-point DFT): a 17th bin tile would hand one wave three
+        // tiles instead of two (+50 % on the phase), and as a VALU dot product over all taps it cost a fifth of the kernel
+        // (cycle accounting: "last bin" 21 % for the FSMN geometry).  It is ONE 16-row MFMA tile instead -- row 0 = the bin's
+        // real table row, row 1 = its imaginary row -- whose K blocks are dealt round-robin to the eight waves (three or four
+        // blocks each: 1/32 more MFMAs, evenly spread); the per-wave partial sums meet in the padding rows of PW.
+        f32x4 nacc[MT];
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { sre += __shfl_xor(sre, o); sim += __shfl_xor(sim, o); }
-        if (part == 0 && f < NF) PW[(d.n_bins - 1) * P_LD + f] = __fadd_rn(__fmul_rn(sre, sre), __fmul_rn(sim, sim));
-    }
-    // zero the padded power rows (bins n_bins..Fp-1) so the mel GEMM multiplies 0 x 0
-    for (int e = tid; e < (d.Fp - d.n_bins) * NF; e += THREADS) {
-        const int r = e / NF, c = e - r * NF;
-        PW[(d.n_bins + r) * P_LD + c] = 0.f;
+        for (int mt = 0; mt < MT; ++mt) nacc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nblk = d.Kp / 16;
+        for (int b = wave; b < nblk; b += THREADS / 64) {
+            int a = 0, b0 = 0;
+            while (a + 1 < d.passes && b >= b0 + d.pass_kb[a]) { b0 += d.pass_kb[a]; ++a; }
+            const f32x4 w = vadx::ldg4(P + d.off_nyq + (size_t)b * vadx::FRAG + lane * 4);
+            const float *aps = X2 + (16 * (b - b0) + 4 * q) * X_LD + i + a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) nacc[mt] = vadx::mfma16(aps[j * X_LD + mt * 16], w[j], nacc[mt]);
+        }
+        float *scr = PW + (d.n_bins) * P_LD;               // rows n_bins .. Fp-1 (15 x P_LD floats >= 8 waves x 2 x NF)
+        if (i < 2)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                *reinterpret_cast<f32x4 *>(scr + (wave * 2 + i) * NF + mt * 16 + 4 * q) = nacc[mt];
+        for (int e = tid + 16 * NF; e < (d.Fp - d.n_bins) * P_LD; e += THREADS) scr[e] = 0.f;    // the rows' tail: finite for the mel GEMM
+        __syncthreads();
+        if (tid < NF) {
+            float re = 0.f, im = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < THREADS / 64; ++w8) { re += scr[(w8 * 2) * NF + tid]; im += scr[(w8 * 2 + 1) * NF + tid]; }
+            PW[(d.n_bins - 1) * P_LD + tid] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+        }
+        // (the padding rows keep the finite partial sums: their mel weights are exactly zero)
+    } else {
+        // zero the padded power rows (bins n_bins..Fp-1) so the mel GEMM multiplies 0 x 0
+        for (int e = tid; e < (d.Fp - d.n_bins) * NF; e += THREADS) {
+            const int r = e / NF, c = e - r * NF;
+            PW[(d.n_bins + r) * P_LD + c] = 0.f;
+        }
     }
     __syncthreads();
     FE_ACC(2);
@@ -420,7 +435,7 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
             put_row(packed_host + d.off_dft + (size_t)(bt * 32 + i) * d.Kp, cos_tab + (size_t)f * n_fft);
             put_row(packed_host + d.off_dft + (size_t)(bt * 32 + 16 + i) * d.Kp, sin_tab + (size_t)f * n_fft);
         }
-    if (d.nyq) {
+    if (d.nyq) {            // its own 16-row tile: row 0 = real table row, row 1 = imaginary, rows 2..15 zero
         put_row(packed_host + d.off_nyq, cos_tab + (size_t)(d.n_bins - 1) * n_fft);
         put_row(packed_host + d.off_nyq + d.Kp, sin_tab + (size_t)(d.n_bins - 1) * n_fft);
     }
@@ -438,8 +453,9 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
         mel_kb[2 * mt] = lo;
         mel_kb[2 * mt + 1] = hi;
     }
-    // GEMM operands go fragment-major (common.h); the Nyquist rows stay row-major (VALU)
+    // GEMM operands go fragment-major (common.h)
     vadx::frag_major_inplace(packed_host + d.off_dft, d.nbt * 32, d.Kp);
+    if (d.nyq) vadx::frag_major_inplace(packed_host + d.off_nyq, 16, d.Kp);
     vadx::frag_major_inplace(packed_host + d.off_mel, d.n_mels, d.Fp);
     return VADX_OK;
 }
