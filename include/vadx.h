@@ -308,6 +308,18 @@ typedef struct vadx_sepconv_cfg {
 int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w, const float *pw_w, const float *pw_b,
                        const float *res_w, const float *res_b, const float *x, int64_t xs_b, int64_t xs_c,
                        int64_t xs_t, int t_in, const float *xres, float *y, int batch, int t_out, void *stream);
+/* Fused forms for the published MarbleNet 3x2x64 layout (what MarbleNetEngine launches; the per-sub-block entry above stays
+ * for other Jasper stacks).  block2: one residual Jasper block = two separable sub-blocks (depthwise `kernel`, stride 1,
+ * 64 filters each) + the residual 1x1 branch of the block input, x [B][cin][T] -> y [B][64][T]; weights as for
+ * vadx_sepconv_block (dw [c][kernel]; pw / res fragment-major, BatchNorm folded; biases padded to 16).
+ * tail: block 5 (depthwise k 29, dilation 2, 64 -> 128) -> block 6 (plain 1x1, 128 -> 128) -> Linear(128 -> 2) -> softmax,
+ * x [B][64][T] -> score0 / score1 [B][T] (dec_w [2][128], dec_b [2]); the 128-channel tensors never reach HBM. */
+int vadx_marblenet_block2(int cin, int kernel, const float *dw0, const float *pw0, const float *b0, const float *dw1,
+                          const float *pw1, const float *b1, const float *res_w, const float *res_b, const float *x,
+                          float *y, int batch, int frames, void *stream);
+int vadx_marblenet_tail(const float *dw, const float *pw, const float *pb, const float *w6, const float *b6,
+                        const float *dec_w, const float *dec_b, const float *x, float *score0, float *score1,
+                        int batch, int frames, void *stream);
 /* enc [B][C][T] -> softmax(Linear(C->2)) split into score0 / score1 [B][T]. */
 int vadx_frame_classifier(const float *enc, const float *dec_w, const float *dec_b, int batch, int channels,
                           int frames, float *score0, float *score1, void *stream);

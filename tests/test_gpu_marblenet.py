@@ -82,3 +82,20 @@ def test_full_size_config4_properties():
     _, oact, _ = omb.forward(omb.Frontend(), ow, T(base[9]).reshape(1, 1, -1))
     np.testing.assert_allclose(s1[9].cpu().numpy(), oact[0, :, 0].numpy(), rtol=0, atol=ATOL)
     print(f"MarbleNet config-4 pass: {dt * 1e3:.1f} ms for 8192 x 5.59 s ({8192 * 89431 / 512 / dt / 1e6:.1f} M 512-hop frames/s)")
+
+
+def test_fused_blocks_equal_the_per_sub_block_launches():
+    """The fused residual-block / tail kernels against the ten per-sub-block launches they replace (same FIR and GEMM
+    order per element: scores agree to float32 round-off), including a clip shorter than one tile and a ragged last tile."""
+    w = weights.marblenet_synthetic(7)
+    eng = marblenet.MarbleNetEngine(w)
+    assert eng.fused
+    for n in (89431, 16000, 3000, 800):
+        clips = T(weights.burst_clips(3, n, seed=n)).cuda()
+        s0, s1, slen = eng.run(clips)
+        eng.fused = False
+        r0, r1, rlen = eng.run(clips)
+        eng.fused = True
+        assert slen == rlen and s1.shape == r1.shape
+        np.testing.assert_allclose(s1.cpu().numpy(), r1.cpu().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(s0.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=2e-6)

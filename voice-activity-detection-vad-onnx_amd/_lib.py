@@ -129,6 +129,8 @@ SIGNATURES = {
     "vadx_vadpost_workspace_bytes": (_Z, [_I, _I]),
     "vadx_vadpost": (_I, [C.POINTER(VadPostParams), _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "vadx_sepconv_block": (_I, [C.POINTER(SepConvCfg), _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _I, _I, _P]),
+    "vadx_marblenet_block2": (_I, [_I, _I] + [_P] * 10 + [_I, _I, _P]),
+    "vadx_marblenet_tail": (_I, [_P] * 10 + [_I, _I, _P]),
     "vadx_frame_classifier": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vadx_dfsmn_frame_stats": (_I, [C.POINTER(FtView), C.POINTER(FtView), _I, _I, _P, _P]),
     "vadx_dfsmn_stats_merge": (_I, [_P, _P, _I, _P, _P]),

@@ -167,6 +167,205 @@ __global__ __launch_bounds__(THREADS, 2) void sepconv_block_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused Jasper block (the three residual blocks of MarbleNet 3x2x64: two separable sub-blocks + the residual 1x1 branch of
+// the block input): ONE launch per block instead of two, and the 64-channel tensor between the sub-blocks never leaves LDS.
+// Tile = 1 clip x 32 output frames; sub-block 0 is evaluated on the 32 + (K - 1) frames sub-block 1's depthwise filter needs
+// (48 columns = 3 m-tiles: <= 1.5 x recompute of a layer that is a quarter of the block's work), masked to zero outside
+// [0, T) -- the zero padding sub-block 1 sees in the reference.
+//   IN  [cin][48 + K - 1]   block input, frames t0 - (K-1) .. (also the residual branch's operand, column offset K - 1)
+//   D0  [cin][48]           depthwise 0            -> later D1 [c1][32]
+//   H1  [c1][48]            relu(pw0 D0 + b0)      -> later OUT [c2][32]
+//   ROUT[c2][32]            residual 1x1
+// ---------------------------------------------------------------------------------------------
+struct Blk2 {
+    int cin, cinp, c1, c2, in_ld, T;      // c1 = c2 = 64 here; cinp = cin padded to 16
+};
+constexpr int W1 = 48, H_LD = 52;
+
+template <int K>
+__global__ __launch_bounds__(THREADS, (K == 13 ? 4 : 6)) void jasper_block2_kernel(      // K 13: cin 128, 80 KB of LDS -> two workgroups per CU; else three
+    Blk2 c, const float *__restrict__ dw0, const float *__restrict__ pw0, const float *__restrict__ b0,
+    const float *__restrict__ dw1, const float *__restrict__ pw1, const float *__restrict__ b1,
+    const float *__restrict__ rw, const float *__restrict__ rb, const float *__restrict__ x, float *__restrict__ y, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PAD = (K - 1) / 2, WIN0 = W1 + K - 1;
+    const int IN_LD = c.in_ld;
+    float *IN = lds, *D0 = IN + c.cinp * IN_LD, *H1 = D0 + c.cinp * H_LD, *ROUT = H1 + c.c1 * H_LD;
+    float *D1 = D0, *OUT = H1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TILE;
+    const float *xb = x + (long long)b * c.cin * c.T;
+    const int tin0 = t0 - 2 * PAD;
+    // ---- stage the block input (channel-first source: lane = time, wave = channel), unconditional clamped loads
+    for (int ch0 = 0; ch0 < c.cinp; ch0 += 8 * (THREADS / 64)) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ch = ch0 + u * (THREADS / 64) + wave, ti = tin0 + lane;
+            const int tc = ti < 0 ? 0 : (ti >= c.T ? c.T - 1 : ti), cc = ch < c.cin ? ch : c.cin - 1;
+            v[u] = xb[(long long)cc * c.T + tc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ch = ch0 + u * (THREADS / 64) + wave, ti = tin0 + lane;
+            if (lane < WIN0 && ch < c.cinp) IN[ch * IN_LD + lane] = (ch < c.cin && ti >= 0 && ti < c.T) ? v[u] : 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- depthwise 0: register-window FIR, item = (channel, 8 outputs)
+    for (int it = tid; it < c.cinp * (W1 / 8); it += THREADS) {
+        const int ch = it / (W1 / 8), m0 = 8 * (it - ch * (W1 / 8)), cc = ch < c.cin ? ch : c.cin - 1;
+        float wk[K], win[7 + K];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) wk[kk] = dw0[cc * K + kk];
+        const float *row = IN + ch * IN_LD + m0;
+#pragma unroll
+        for (int u = 0; u < 7 + K; ++u) win[u] = row[u];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) s2 = fmaf(wk[kk], win[o + kk], s2);
+            D0[ch * H_LD + m0 + o] = ch < c.cin ? s2 : 0.f;
+        }
+    }
+    __syncthreads();
+    {   // pointwise 0 + folded BN + ReLU on 48 columns
+        LayerArgs a{pw0, c.cinp, c.c1 / 16, 1, c.cinp / 16, 0, 0, b0, 1, D0, H_LD, 0, H1, H_LD, 0, nullptr, nullptr};
+        layer<3, false>(a);
+    }
+    __syncthreads();
+    // ---- depthwise 1 on H1 (column j = frame t0 - PAD + j; frames outside the clip are the conv's zero padding)
+    for (int it = tid; it < c.c1 * (TILE / 8); it += THREADS) {
+        const int ch = it / (TILE / 8), m0 = 8 * (it - ch * (TILE / 8));
+        float wk[K], win[7 + K];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) wk[kk] = dw1[ch * K + kk];
+        const float *row = H1 + ch * H_LD + m0;
+#pragma unroll
+        for (int u = 0; u < 7 + K; ++u) {
+            const int fr = t0 - PAD + m0 + u;
+            win[u] = (fr >= 0 && fr < c.T) ? row[u] : 0.f;
+        }
+        float o8[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) s2 = fmaf(wk[kk], win[o + kk], s2);
+            o8[o] = s2;
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) D1[ch * A_LD + m0 + o] = o8[o];     // D1 aliases D0 (dead since the barrier above)
+    }
+    __syncthreads();                // every H1 read is done: OUT may overwrite it
+    {
+        LayerArgs a{pw1, c.c1, c.c2 / 16, 1, c.c1 / 16, 0, 0, b1, 0, D1, A_LD, 0, OUT, A_LD, 0, nullptr, nullptr};
+        layer<2, false>(a);
+        LayerArgs r{rw, c.cinp, c.c2 / 16, 1, c.cinp / 16, 0, 0, rb, 0, IN, IN_LD, 2 * PAD, ROUT, A_LD, 0, nullptr, nullptr};
+        layer<2, false>(r);
+    }
+    __syncthreads();
+    float *yb = y + (long long)b * c.c2 * c.T;
+    for (int e = tid; e < c.c2 * TILE; e += THREADS) {
+        const int ch = e / TILE, m = e - ch * TILE;
+        if (t0 + m < c.T) yb[(long long)ch * c.T + t0 + m] = fmaxf(OUT[ch * A_LD + m] + ROUT[ch * A_LD + m], 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tail of the encoder + decoder in one launch: block 5 (depthwise k = 29, dilation 2, 64 -> 128, ReLU), block 6 (plain 1x1,
+// 128 -> 128, ReLU), Linear(128 -> 2), softmax: the two 128-channel tensors and the encoder output never reach HBM -- only
+// the two scores per frame leave the kernel (wrapper :265-274).
+//   IN [64][32 + 56] -> D [64][32] -> H [128][32] -> OUT [128][32] (in IN's place) -> scores
+// ---------------------------------------------------------------------------------------------
+struct Tail { int cin, cmid, k, dil, in_ld, T; };
+
+__global__ __launch_bounds__(THREADS, 6) void marblenet_tail_kernel(
+    Tail c, const float *__restrict__ dw, const float *__restrict__ pw, const float *__restrict__ pb,
+    const float *__restrict__ w6, const float *__restrict__ b6, const float *__restrict__ dec_w, const float *__restrict__ dec_b,
+    const float *__restrict__ x, float *__restrict__ s0, float *__restrict__ s1, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int K = 29, DIL = 2, PAD = 28, WIN0 = TILE + 2 * PAD;
+    const int IN_LD = c.in_ld;
+    float *IN = lds, *D = IN + c.cin * IN_LD, *H = D + c.cin * A_LD, *OUT = IN;
+    float *red = D;                                 // [16 parts][32 frames][2] once D is dead
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TILE;
+    const float *xb = x + (long long)b * c.cin * c.T;
+    const int tin0 = t0 - PAD;
+    for (int ch0 = 0; ch0 < c.cin; ch0 += 4 * (THREADS / 64)) {
+        float v[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ch = ch0 + u * (THREADS / 64) + wave, ti = tin0 + lane + 64 * h;
+                const int tc = ti < 0 ? 0 : (ti >= c.T ? c.T - 1 : ti), cc = ch < c.cin ? ch : c.cin - 1;
+                v[u][h] = xb[(long long)cc * c.T + tc];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ch = ch0 + u * (THREADS / 64) + wave, j = lane + 64 * h, ti = tin0 + j;
+                if (j < WIN0 && ch < c.cin) IN[ch * IN_LD + j] = (ti >= 0 && ti < c.T) ? v[u][h] : 0.f;
+            }
+    }
+    __syncthreads();
+    for (int it = tid; it < c.cin * (TILE / 8); it += THREADS) {       // register-window FIR, dilation 2
+        const int ch = it / (TILE / 8), m0 = 8 * (it - ch * (TILE / 8));
+        float wk[K], win[7 + (K - 1) * DIL + 1];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) wk[kk] = dw[ch * K + kk];
+        const float *row = IN + ch * IN_LD + m0;
+#pragma unroll
+        for (int u = 0; u < 7 + (K - 1) * DIL + 1; ++u) win[u] = row[u];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) s2 = fmaf(wk[kk], win[o + kk * DIL], s2);
+            D[ch * A_LD + m0 + o] = s2;
+        }
+    }
+    __syncthreads();
+    {
+        LayerArgs a{pw, c.cin, c.cmid / 16, 1, c.cin / 16, 0, 0, pb, 1, D, A_LD, 0, H, A_LD, 0, nullptr, nullptr};
+        layer<2, false>(a);
+    }
+    __syncthreads();                // IN and D are dead
+    {
+        LayerArgs a{w6, c.cmid, c.cmid / 16, 1, c.cmid / 16, 0, 0, b6, 1, H, A_LD, 0, OUT, A_LD, 0, nullptr, nullptr};
+        layer<2, false>(a);
+    }
+    __syncthreads();
+    {   // decoder: thread = (part of 8 channels, frame); partial logits meet in LDS and are summed in part order
+        const int m = tid & 31, part = tid >> 5;
+        float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ch = part * 8 + u;
+            const float v = OUT[ch * A_LD + m];
+            z0 = fmaf(dec_w[ch], v, z0);
+            z1 = fmaf(dec_w[c.cmid + ch], v, z1);
+        }
+        red[(part * TILE + m) * 2] = z0;
+        red[(part * TILE + m) * 2 + 1] = z1;
+    }
+    __syncthreads();
+    if (tid < TILE && t0 + tid < c.T) {
+        float z0 = dec_b[0], z1 = dec_b[1];
+#pragma unroll
+        for (int part = 0; part < THREADS / 32; ++part) { z0 += red[(part * TILE + tid) * 2]; z1 += red[(part * TILE + tid) * 2 + 1]; }
+        const float mx = fmaxf(z0, z1), e0 = expf(z0 - mx), e1 = expf(z1 - mx), inv = 1.0f / (e0 + e1);
+        s0[(long long)b * c.T + t0 + tid] = e0 * inv;
+        s1[(long long)b * c.T + t0 + tid] = e1 * inv;
+    }
+}
+
 // decoder Linear(C -> 2) + softmax (wrapper :270-274): one thread per (clip, frame)
 __global__ void frame_classifier_kernel(const float *__restrict__ enc, const float *__restrict__ w, const float *__restrict__ bias,
                                         int B, int C, int T, float *__restrict__ s0, float *__restrict__ s1) {
@@ -228,6 +427,52 @@ extern "C" int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w
     else if (c.has_dw && c.k == 29 && c.dil == 2 && c.stride == 1) SEPCONV_LAUNCH(29, 2, 1);
     else SEPCONV_LAUNCH(0, 0, 0);
 #undef SEPCONV_LAUNCH
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+
+extern "C" int vadx_marblenet_block2(int cin, int kernel, const float *dw0, const float *pw0, const float *b0, const float *dw1,
+                                     const float *pw1, const float *b1, const float *res_w, const float *res_b, const float *x,
+                                     float *y, int batch, int frames, void *stream) {
+    VADX_REQUIRE(dw0 && pw0 && b0 && dw1 && pw1 && b1 && res_w && res_b && x && y, "vadx_marblenet_block2: NULL argument");
+    VADX_REQUIRE((cin == 64 || cin == 128) && (kernel == 13 || kernel == 15 || kernel == 17) && batch > 0 && frames > 0,
+                 "vadx_marblenet_block2: built for the published MarbleNet 3x2x64 residual blocks (cin 64/128, 64 filters, kernel 13/15/17)");
+    Blk2 c;
+    c.cin = cin; c.cinp = (cin + 15) & ~15; c.c1 = 64; c.c2 = 64; c.T = frames;
+    const int width = W1 + kernel - 1;
+    c.in_ld = ((width + 7) & ~7) + 4;
+    const int tiles = (frames + TILE - 1) / TILE;
+    VADX_REQUIRE((long long)batch * tiles < (1LL << 31), "vadx_marblenet_block2: too many tiles");
+    const size_t lds = ((size_t)c.cinp * c.in_ld + (size_t)c.cinp * H_LD + (size_t)c.c1 * H_LD + (size_t)c.c2 * A_LD) * sizeof(float);
+#define BLK2_LAUNCH(KK)                                                                                                        \
+    do {                                                                                                                       \
+        VADX_DYN_LDS(jasper_block2_kernel<KK>, 128 * 1024);                                                                    \
+        hipLaunchKernelGGL(jasper_block2_kernel<KK>, dim3((unsigned)(batch * tiles)), dim3(THREADS), lds,                      \
+                           static_cast<hipStream_t>(stream), c, dw0, pw0, b0, dw1, pw1, b1, res_w, res_b, x, y, tiles);         \
+    } while (0)
+    if (kernel == 13) BLK2_LAUNCH(13);
+    else if (kernel == 15) BLK2_LAUNCH(15);
+    else BLK2_LAUNCH(17);
+#undef BLK2_LAUNCH
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+extern "C" int vadx_marblenet_tail(const float *dw, const float *pw, const float *pb, const float *w6, const float *b6,
+                                   const float *dec_w, const float *dec_b, const float *x, float *score0, float *score1,
+                                   int batch, int frames, void *stream) {
+    VADX_REQUIRE(dw && pw && pb && w6 && b6 && dec_w && dec_b && x && score0 && score1, "vadx_marblenet_tail: NULL argument");
+    VADX_REQUIRE(batch > 0 && frames > 0, "vadx_marblenet_tail: bad shape");
+    Tail c;
+    c.cin = 64; c.cmid = 128; c.k = 29; c.dil = 2; c.T = frames;
+    c.in_ld = ((TILE + 56 + 7) & ~7) + 4;
+    const int tiles = (frames + TILE - 1) / TILE;
+    VADX_REQUIRE((long long)batch * tiles < (1LL << 31), "vadx_marblenet_tail: too many tiles");
+    const size_t lds = ((size_t)c.cin * c.in_ld + (size_t)c.cin * A_LD + (size_t)c.cmid * A_LD) * sizeof(float);
+    VADX_DYN_LDS(marblenet_tail_kernel, 128 * 1024);
+    hipLaunchKernelGGL(marblenet_tail_kernel, dim3((unsigned)(batch * tiles)), dim3(THREADS), lds, static_cast<hipStream_t>(stream),
+                       c, dw, pw, pb, w6, b6, dec_w, dec_b, x, score0, score1, tiles);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }

@@ -61,6 +61,8 @@ class MarbleNetEngine:
         self.cout = cin
         self.dec_w, self.dec_b = dev(w["dec_w"]), dev(w["dec_b"])
         self._fe = {}
+        # the published 3x2x64 layout runs on the fused kernels: one launch per residual block, one for blocks 5 + 6 + decoder
+        self.fused = tuple(tuple(b) for b in blocks) == tuple(tuple(b) for b in _weights.MARBLENET_BLOCKS)
 
     def frontend(self, L):
         if L not in self._fe:
@@ -81,6 +83,8 @@ class MarbleNetEngine:
         cur, cur_T = x, T
         block_in = None
         lib = _lib.lib()
+        if self.fused:
+            return self._run_fused(x, N, T)
         with t.cuda.device(self.device):
             for st in self.stages:
                 cfg = st["cfg"]
@@ -103,6 +107,34 @@ class MarbleNetEngine:
             _lib.check(lib.vadx_frame_classifier(cur.data_ptr(), self.dec_w.data_ptr(), self.dec_b.data_ptr(), N, self.cout,
                                                  cur_T, s0.data_ptr(), s1.data_ptr(), _lib.stream_ptr()))
         return s0, s1, cur_T - 1
+
+    def _run_fused(self, x, N, T):
+        """Published layout: block 1 (stride 2, time-major log-mel in) through the per-sub-block entry, blocks 2-4 as one
+        fused launch each (the tensor between a block's two sub-blocks stays in LDS), blocks 5 + 6 + Linear + softmax as one
+        launch (nothing but the two scores per frame is written)."""
+        t, lib, st = self.torch, _lib.lib(), self.stages
+        p = lambda a: None if a is None else a.data_ptr()        # noqa: E731
+        with t.cuda.device(self.device):
+            s0 = st[0]
+            cfg = s0["cfg"]
+            pad = (cfg.dilation * (cfg.kernel - 1)) // 2
+            T1 = (T + 2 * pad - cfg.dilation * (cfg.kernel - 1) - 1) // cfg.stride + 1
+            cur = t.empty((N, cfg.cout, T1), dtype=t.float32, device=self.device)
+            _lib.check(lib.vadx_sepconv_block(C.byref(cfg), p(s0["dw"]), p(s0["pw"]), p(s0["pb"]), None, None, x.data_ptr(),
+                                              T * 80, 1, 80, T, None, cur.data_ptr(), N, T1, _lib.stream_ptr()))
+            for k in (1, 3, 5):
+                a, b = st[k], st[k + 1]
+                y = t.empty((N, 64, T1), dtype=t.float32, device=self.device)
+                _lib.check(lib.vadx_marblenet_block2(a["cfg"].cin, a["cfg"].kernel, p(a["dw"]), p(a["pw"]), p(a["pb"]), p(b["dw"]),
+                                                     p(b["pw"]), p(b["pb"]), p(b["rw"]), p(b["rb"]), cur.data_ptr(), y.data_ptr(), N, T1,
+                                                     _lib.stream_ptr()))
+                cur = y
+            s0o = t.empty((N, T1), dtype=t.float32, device=self.device)
+            s1o = t.empty((N, T1), dtype=t.float32, device=self.device)
+            _lib.check(lib.vadx_marblenet_tail(p(st[7]["dw"]), p(st[7]["pw"]), p(st[7]["pb"]), p(st[8]["pw"]), p(st[8]["pb"]),
+                                               self.dec_w.data_ptr(), self.dec_b.data_ptr(), cur.data_ptr(), s0o.data_ptr(),
+                                               s1o.data_ptr(), N, T1, _lib.stream_ptr()))
+        return s0o, s1o, T1 - 1
 
     def detect(self, clips_i16, window_len=None, pad_noise=None, post=(3, 0.5, 10, 1000, 10, 3, 0), return_probs=False):
         """Equal-length clips int16 [B,N] (host) -> per clip [(start_s, end_s)].  window_len None = the
