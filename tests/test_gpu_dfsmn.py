@@ -132,3 +132,37 @@ def test_near_only_session_matches_reference_fixture(golden):
     assert np.array_equal(v3[0], v3[2]) and np.array_equal(v3[0], out)
     with pytest.raises(ValueError):
         dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234)).run(three, None)
+
+
+def test_full_size_config5_properties():
+    """BASELINE config 5 (DFSMN half) at FULL size: 2048 clip pairs x 10 s = 30 720 windows of 16 001 samples in one call
+    (32 sub-batches of 960 windows).  Bitwise batch-position invariance, finite scores in [0, 1], and agreement with the
+    oracle on the windows of one clip pair."""
+    import time
+    from oracle import dfsmn as od
+    w = weights.dfsmn_synthetic(1234)
+    eng = dfsmn.DfsmnEngine(w, sub_batch=960)
+    lb, stride = eng.grid()
+    W = 15
+    n = (W - 1) * stride + eng.L
+    base_n, base_f = weights.burst_clips(16, n, seed=61), weights.burst_clips(16, n, seed=62)
+    near = torch.from_numpy(base_n).cuda().repeat(128, 1)            # 2048 pairs, pair i == pair i % 16
+    far = torch.from_numpy(base_f).cuda().repeat(128, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vad = eng.run(near, far, W, stride)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert vad.shape == (2048 * W, 51) and bool(torch.isfinite(vad).all())
+    assert float(vad.min()) >= 0.0 and float(vad.max()) <= 1.0
+    v = vad.view(128, 16, W, 51)
+    assert torch.equal(v[0], v[1]) and torch.equal(v[0], v[77]) and torch.equal(v[0], v[127])
+    ow = {k: torch.from_numpy(np.ascontiguousarray(x)) for k, x in w.items()}
+    ow["mask.shift"] = ow["mask.shift"] + torch.log(torch.tensor(32768.0 ** 2))
+    fe = od.Frontend()
+    for k in (0, 7, 14):
+        a = torch.from_numpy(base_n[5, k * stride:k * stride + eng.L].copy()).reshape(1, 1, -1)
+        f = torch.from_numpy(base_f[5, k * stride:k * stride + eng.L].copy()).reshape(1, 1, -1)
+        want, _ = od.forward(fe, ow, a, f, weights.DFSMN_MASK["layers"])
+        np.testing.assert_allclose(v[3, 5, k].cpu().numpy(), want.numpy(), rtol=0, atol=1e-4)
+    print(f"DFSMN config-5 pass: {dt:.2f} s for 2048 x 10 s pairs ({2048 * 313 / dt / 1e3:.0f} k 512-hop frames/s)")
