@@ -151,6 +151,30 @@ def cpu_baseline(budget_s=10.0):
             best_thr, best_rate = thr, rate
     torch.set_num_threads(best_thr)
     rate, n, el = run(budget_s)
+    # BASELINE.md section 3 protocol beside it: all host threads, one 10 s clip, 3 warm-up + 10 timed repetitions, median;
+    # model calls only (the reference's convention) and end to end with the segmenter
+    from oracle import postproc as opp
+    torch.set_num_threads(ncpu)
+    clip = torch.from_numpy(clips[0])
+
+    def one_clip(with_post):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            pr = osil.speech_probs(clip, model, 16000)
+        t1 = time.perf_counter()
+        if with_post:
+            opp.silero_segments([float(v) for v in pr], SAMPLES, threshold=0.5, max_speech_duration_s=20, min_speech_duration_ms=250,
+                                min_silence_duration_ms=250, return_seconds=True)
+            t1 = time.perf_counter()
+        return t1 - t0
+
+    for _ in range(3):
+        one_clip(False)
+    med_model = float(np.median([one_clip(False) for _ in range(10)]))
+    med_e2e = float(np.median([one_clip(True) for _ in range(10)]))
+    protocol = {"threads": ncpu, "repetitions": "3 warm-up + 10 timed, median", "clip": "one synthetic 10 s clip, batch 1",
+                "model_calls_only": {"value": STEPS_PER_CLIP / med_model, "rtf": med_model / (SAMPLES / 16000.0)},
+                "end_to_end": {"value": STEPS_PER_CLIP / med_e2e, "rtf": med_e2e / (SAMPLES / 16000.0)}}
     # the same oracle batched over clips on all cores (NOT how the reference runs; shown for scale)
     torch.set_num_threads(min(ncpu, 64))
     bb = 64
@@ -168,6 +192,7 @@ def cpu_baseline(budget_s=10.0):
             "sample": f"{n} windows of synthetic 10 s clips, batch 1, one call per 512-sample window, state carried "
                       f"(torch-CPU oracle stand-in for ORT-CPU; best of 1/2/4/8/16 intra-op threads on a "
                       f"{ncpu}-CPU host), {el:.1f} s",
+            "baseline_md_protocol": protocol,
             "batched_value": batched, "batched_note": f"same oracle, batch {bb}, {min(ncpu, 64)} threads (not the reference's mode)"}
 
 
