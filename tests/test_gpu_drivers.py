@@ -197,3 +197,32 @@ def test_dfsmn_near_only_on_vad_sample(tmp_path):
     want, _ = od.run_clip(od.Frontend(), w, a, None, nz[0], None, weights.DFSMN_MASK["layers"], near_only=(T(pf), T(fc)))
     assert got == want
     assert open(idx).read() == "".join(opp.timestamp_lines(want, 16000)[1])
+
+
+def test_file_lists_run_as_length_groups_and_match_single_runs(tmp_path):
+    """A LIST of files: equal-length files share one device batch (drivers._grouped), results come back in input order and
+    equal the one-file-at-a-time runs; weights given as the explicit "synthetic:<seed>" string resolve through checkpoints."""
+    import wave
+    from vadx import firered, fsmn, marblenet
+    rng = np.random.default_rng(77)
+    paths, lens = [], [40000, 25000, 40000, 16000]
+    for k, n in enumerate(lens):
+        pcm = weights.burst_clips(1, n, seed=500 + k)[0]
+        pth = str(tmp_path / f"c{k}.wav")
+        with wave.open(pth, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+        paths.append(pth)
+    noise = rng.standard_normal((len(paths), 20000))
+    quiet = lambda *_: None                                                     # noqa: E731
+    for run, eng in ((drivers.inference_fsmn, fsmn.FsmnEngine("synthetic:1234")),
+                     (drivers.inference_firered, firered.FireRedEngine("synthetic:1234")),
+                     (drivers.inference_marblenet, marblenet.MarbleNetEngine("synthetic:1234"))):
+        kw = {} if run is drivers.inference_marblenet else {"pad_noise": noise}
+        many = run(paths, eng, str(tmp_path / "s.txt"), str(tmp_path / "i.txt"), echo=quiet, **kw)
+        assert len(many) == len(paths)
+        for k, pth in enumerate(paths):
+            kw1 = {} if run is drivers.inference_marblenet else {"pad_noise": noise[k:k + 1]}
+            one = run(pth, eng, str(tmp_path / "s1.txt"), str(tmp_path / "i1.txt"), echo=quiet, **kw1)
+            assert many[k] == one, (run.__name__, k)
+    with pytest.raises(ValueError, match="no weights given"):
+        drivers.inference_fsmn(paths[0], None, echo=quiet)
