@@ -347,14 +347,14 @@ def marblenet_c4(torch, device, reps, cpu, clips=8192, log=lambda m: None, tag="
     T = n // 160 + 1
     Tout = (T + 2 * 5 - 10 - 1) // 2 + 1
     fe_ms = split.get("vadx_frontend_logmel", ms)
-    net_ms = sum(v for k, v in split.items() if k in ("vadx_sepconv_block", "vadx_marblenet_net", "vadx_frame_classifier"))
+    net_ms = sum(v for k, v in split.items() if k != "vadx_frontend_logmel")   # every launch after the front end
     out = {"workload": f"NVIDIA Frame-VAD MarbleNet v2.0 f32, batch={clips} clips of {n} samples (one dynamic-axis window each) "
                        "-> per-20-ms speech probabilities",
            "clips": clips, "samples_per_clip": n, "ms": ms, "frames_per_s": clips * n / 512 / (ms * 1e-3),
            "kernel_ms": split, "kernel_calls": calls,
            "roofline": _roof("frontend_logmel_kernel", clips * T * flop_frontend_frame(257, 400), fe_ms, tag, "frontend_logmel_kernel"),
            "roofline_net": _roof("marblenet encoder+decoder launches", clips * Tout * flop_marblenet_out_frame(), net_ms,
-                                 note="sum of the encoder / classifier launches"),
+                                 note="sum of the encoder / classifier entries in kernel_ms (fused block pairs, single blocks, tail)"),
            "hbm": _hbm(clips * (n * 2 + 2 * Tout * 4), ms), "cpu_baseline": None}
     del audio
     if cpu:

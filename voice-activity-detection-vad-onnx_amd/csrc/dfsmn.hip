@@ -220,27 +220,44 @@ struct PwArgs {
     int fc, nchunk;                    // bins per workgroup chunk, chunks per tile
 };
 
-// The op is HBM-bound (a few hundred flop per 64-B row), so the kernel is built around the memory system: a
-// workgroup owns (tile, chunk of `fc` bins); it stages the chunk's input rows (+1 halo bin each side for the (3,1)
+// Shape of one pw_conv instantiation.  Everything that indexes memory is a compile-time constant: the kernel was first
+// written against run-time (cin, co, fc) and spent 12.7 VALU instructions per MFMA -- 60 per staged 16-B item, 125 per
+// written item, mostly signed run-time divisions, 64-bit address arithmetic and per-row predication -- i.e. the SIMDs'
+// issue slots, not HBM, were what the 3.2 TB/s it reached was bound by (profiles/r02_dfsmn: SQ_INSTS_VALU 131 G against
+// 10.3 G MFMAs for the (3,1) conv).
+template <int CO, int CIN, int KF, int MODE>
+struct PwShape {
+    static constexpr int MT = (CO + 15) / 16, K = KF * CIN, KS = K / 4, HALO = (KF - 1) / 2, NOUT = MODE == 1 ? 2 : 1;
+    static constexpr int lds_floats(int fc) { return CIN * ((fc + 2 * HALO) | 1) * 18 + NOUT * CO * fc * 16; }
+    // bins per chunk: the largest multiple of 4 (one bin per wave per round) up to 32 that keeps the workgroup's LDS
+    // within 52 KB (three workgroups per CU).  (Smaller chunks for more workgroups per CU were measured -- LDS caps of
+    // 40 / 26 / 16 KB: pw_conv 80 -> 94 / 105 / 111 ms per 1920 windows: shorter contiguous runs per channel and more
+    // halo rows cost more than the occupancy buys.)
+    static constexpr int pick_fc() { int fc = 32; while (fc > 4 && lds_floats(fc) * 4 > 52 * 1024) fc -= 4; return fc; }
+    static constexpr int FC = pick_fc(), FH = FC + 2 * HALO, FS = FH | 1;      // bins, staged rows per channel, their (odd) LDS pitch
+    static constexpr int LDS_FLOATS = lds_floats(FC);
+    static_assert(K % 4 == 0, "kf * cin must be a multiple of 4");
+};
+
+// A workgroup owns (tile, chunk of FC bins); it stages the chunk's input rows (+1 halo bin each side for the (3,1)
 // conv) into LDS with 16-B coalesced loads -- a channel's bins are contiguous in the FT layout, so every run is
-// fh*64 B -- together with the LayerNorm weight/bias of each (channel, bin); the MFMA loop reads its B operand
-// from LDS (row stride fh*16 floats with fh odd: the four k-quarters land 16 banks apart), results go to an LDS
+// FH*64 B -- together with the LayerNorm weight/bias of each (channel, bin); the MFMA loop reads its B operand
+// from LDS (row stride FS*16 floats with FS odd: the four k-quarters land 16 banks apart), results go to an LDS
 // output block and leave as 16-B coalesced stores (+ the residual `add` of MODE 2, read the same way).
-template <int MT, int KS, int KF, int MODE>
-__global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
+template <int CO, int CIN, int KF, int MODE>
+__global__ __launch_bounds__(256, 3) void pw_conv_kernel(PwArgs p) {
+    using S = PwShape<CO, CIN, KF, MODE>;
+    constexpr int MT = S::MT, KS = S::KS, K = S::K, HALO = S::HALO, FC = S::FC, FH = S::FH, FS = S::FS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, i = lane & 15;
-    const int cin = p.a.c + p.b.c;
-    constexpr int K = KS * 4, HALO = (KF - 1) / 2;
-    const int fh = p.fc + 2 * HALO, fs = fh | 1;        // rows per channel, and their (odd) LDS pitch
+    const int q = lane >> 4, i = lane & 15, tq = tid & 3, rg = tid >> 2;
     // LayerNorm: MODE 0 has none; MODE 2 consumes only LN(in), applied while staging; MODE 1 needs the raw rows too
     // (input conv) and normalises on the fly with the per-row (weight, bias) pairs staged next to them
     constexpr bool LN_STAGE = MODE == 2, LN_FLY = MODE == 1;
-    float *raw = lds;                                   // [cin][fs][16]
-    float *wb = raw + cin * fs * 16;                    // [cin][fs][2]   MODE 1: LayerNorm (weight, bias); (0, 0) outside [0, F)
-    float *o0 = wb + cin * fs * 2;                      // [co][fc][16]
-    float *o1 = o0 + p.co * p.fc * 16;                  // MODE 1 only
+    float *raw = lds;                                   // [CIN][FS][16]
+    float *wb = raw + CIN * FS * 16;                    // [CIN][FS][2]   MODE 1: LayerNorm (weight, bias); (0, 0) outside [0, F)
+    float *o0 = wb + CIN * FS * 2;                      // [CO][FC][16]
+    float *o1 = o0 + CO * FC * 16;                      // MODE 1 only
 
     // weights stay in VGPRs for every chunk of the tile
     float wa[MT][KS], wg[MODE == 1 ? MT : 1][MODE == 1 ? KS : 1];
@@ -248,193 +265,211 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(PwArgs p) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            wa[mt][s] = p.W[(size_t)(mt * 16 + i) * K + 4 * s + q];
-            if (MODE == 1) wg[mt][s] = p.W2[(size_t)(mt * 16 + i) * K + 4 * s + q];
+            wa[mt][s] = p.W[(mt * 16 + i) * K + 4 * s + q];
+            if (MODE == 1) wg[mt][s] = p.W2[(mt * 16 + i) * K + 4 * s + q];
         }
     // (a persistent variant -- one resident wave of workgroups walking the tiles with their weights kept -- was slower
     // here, 1.30 -> 1.54 ms: the per-workgroup set-up is small and the hoisted per-tile state costs occupancy)
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x, F = p.F;
     float ln_mean = 0.f, ln_inv = 1.f;                  // MODE 1: this lane's frame (column i) is fixed
     f32x4 st_mean = {0.f, 0.f, 0.f, 0.f}, st_inv = {1.f, 1.f, 1.f, 1.f};      // MODE 2: the staging thread's frame quad
-    if (LN_FLY) { ln_mean = p.ln.stats[((size_t)tile * 16 + i) * 2]; ln_inv = p.ln.stats[((size_t)tile * 16 + i) * 2 + 1]; }
+    if (LN_FLY) { ln_mean = p.ln.stats[(tile * 16 + i) * 2]; ln_inv = p.ln.stats[(tile * 16 + i) * 2 + 1]; }
     if (LN_STAGE)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            st_mean[r] = p.ln.stats[((size_t)tile * 16 + 4 * (tid & 3) + r) * 2];
-            st_inv[r] = p.ln.stats[((size_t)tile * 16 + 4 * (tid & 3) + r) * 2 + 1];
+            st_mean[r] = p.ln.stats[(tile * 16 + 4 * tq + r) * 2];
+            st_inv[r] = p.ln.stats[(tile * 16 + 4 * tq + r) * 2 + 1];
         }
-    int koff[KS];              // this lane's k rows: k = 4s + q -> (tap, channel) -> LDS row (channel*fs + tap)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int k = 4 * s + q, tap = (KF == 1) ? 0 : k / cin, c = (KF == 1) ? k : k - tap * cin;
-        koff[s] = c * fs + tap;
-    }
+    // this lane's k rows: k = 4s + q -> (tap, channel) = (s / (CIN/4), 4 (s % (CIN/4)) + q) as CIN % 4 == 0 -> LDS row
+    // (channel*FS + tap): ONE address register (k-step 0, bin `wave` of round 0); k-steps, rounds are compile-time offsets
+    static_assert(CIN % 4 == 0, "a k-step of four channels must not straddle two taps");
+    const int kaddr0 = (q * FS + wave) * 16 + i;
+    auto koffs = [](int s) constexpr { return (4 * (s % (CIN / 4)) * FS + s / (CIN / 4)) * 16; };
     float bias_r[MT][4], bias2_r[MODE == 1 ? MT : 1][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = mt * 16 + 4 * q + r;
-            bias_r[mt][r] = co < p.co ? p.bias[co] : 0.f;
-            if (MODE == 1) bias2_r[mt][r] = co < p.co ? p.bias2[co] : 0.f;
+            const int co = min(mt * 16 + 4 * q + r, CO - 1);
+            bias_r[mt][r] = p.bias[co];
+            if (MODE == 1) bias2_r[mt][r] = p.bias2[co];
         }
+    // per-thread global bases of the tile (the in-tile offsets below are 32-bit): view b is addressed with channel c - a.c
+    const int ac = p.a.c;
+    const float *abase = p.a.ptr + ((size_t)tile * p.a.c_total + p.a.c_off) * F * 16 + 4 * tq;
+    const float *bbase = reinterpret_cast<const float *>(reinterpret_cast<uintptr_t>(p.b.ptr) +
+                             (((size_t)tile * p.b.c_total + p.b.c_off) * F * 16 + 4 * tq) * sizeof(float) - (size_t)ac * F * 16 * sizeof(float));
+    float *obase0 = p.out0.ptr + ((size_t)tile * p.out0.c_total + p.out0.c_off) * F * 16 + 4 * tq;
+    float *obase1 = MODE == 1 ? p.out1.ptr + ((size_t)tile * p.out1.c_total + p.out1.c_off) * F * 16 + 4 * tq : nullptr;
+    const float *addbase = MODE == 2 ? p.add.ptr + ((size_t)tile * p.add.c_total + p.add.c_off) * F * 16 + 4 * tq : nullptr;
 
     StatRun run0, run1;
     run0.init(); run1.init();
     for (int chunk = blockIdx.y; chunk < p.nchunk; chunk += gridDim.y) {
-        const int f0 = chunk * p.fc, fcv = min(p.fc, p.F - f0);
-        auto lnidx = [&](int e) {                               // (channel, clamped bin) of item e in the LayerNorm tables
-            const int rowi = e >> 2, c = rowi / fh, ffl = rowi - c * fh;
-            const int ff = f0 - HALO + ffl, fc2 = ff < 0 ? 0 : (ff >= p.F ? p.F - 1 : ff);
-            return c * p.F + fc2;
-        };
-        // ---- stage the input rows: thread = (row (c, ffl), frame quad); four unconditional (clamped) loads in flight
-        // per thread, then the stores -- a load-store pair per iteration is one serialised round trip each
+        const int f0 = chunk * FC, fcv = min(FC, F - f0);
+        // the row -> (channel, bin) maps below do not depend on the chunk; left visible, the compiler hoists all of them
+        // out of this loop and spills (the kernel has 168 VGPRs at three workgroups per CU)
+        int rgc = rg;
+        asm volatile("" : "+v"(rgc));
+        // ---- stage the input rows: thread = (row (c, ffl), frame quad), rows rg + 64 j; four unconditional (clamped) loads
+        // in flight per thread, then the stores -- a load-store pair per iteration is one serialised round trip each.
+        // (One batch of six loads per thread -- the whole chunk in a single round trip -- was measured: pw_conv 80 -> 90 ms per
+        // 1920 windows; the extra live registers cost the third workgroup per CU.)
         {
-            const int nitem = cin * fh * 4;
-            auto src_of = [&](int e) -> const float * {
-                const int rowi = e >> 2, tq = e & 3, c = rowi / fh, ffl = rowi - c * fh;
-                const int ff = f0 - HALO + ffl, fc2 = ff < 0 ? 0 : (ff >= p.F ? p.F - 1 : ff);
-                return (c < p.a.c ? p.a.ptr + ft_idx(tile, p.a.c_total, p.a.c_off + c, p.F, fc2)
-                                  : p.b.ptr + ft_idx(tile, p.b.c_total, p.b.c_off + c - p.a.c, p.F, fc2)) + 4 * tq;
-            };
-            auto put = [&](int e, f32x4 v, float w, float b) {
-                const int rowi = e >> 2, tq = e & 3, c = rowi / fh, ffl = rowi - c * fh, ff = f0 - HALO + ffl;
-                if (LN_STAGE) v = (v - st_mean) * st_inv * w + b;
-                *reinterpret_cast<f32x4 *>(raw + (c * fs + ffl) * 16 + 4 * tq) = (ff < 0 || ff >= p.F) ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
-            };
-            // (one batch of six loads per thread -- the whole chunk in a single round trip -- was measured: pw_conv 80 -> 90 ms per
-            // 1920 windows; the extra live registers cost the third workgroup per CU, and occupancy is what this kernel runs on)
-            int e0 = tid;
-            for (; e0 + 3 * 256 < nitem; e0 += 4 * 256) {       // full batches: four loads in flight, then four stores
+            constexpr int NROW = CIN * FH, NIT = (NROW + 63) / 64;
+#pragma unroll
+            for (int j0 = 0; j0 < NIT; j0 += 4) {
                 f32x4 v[4];
                 float w[4] = {1.f, 1.f, 1.f, 1.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    v[u] = *reinterpret_cast<const f32x4 *>(src_of(e0 + 256 * u));
-                    if (LN_STAGE) { w[u] = p.ln.w[lnidx(e0 + 256 * u)]; b[u] = p.ln.b[lnidx(e0 + 256 * u)]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) put(e0 + 256 * u, v[u], w[u], b[u]);
-            }
-            for (; e0 < nitem; e0 += 256)
-                put(e0, *reinterpret_cast<const f32x4 *>(src_of(e0)), LN_STAGE ? p.ln.w[lnidx(e0)] : 1.f, LN_STAGE ? p.ln.b[lnidx(e0)] : 0.f);
-        }
-        if (LN_FLY) {                                           // (weight, bias) per staged row: unconditional clamped loads
-            const int nrow = cin * fh;
-            for (int r0 = tid; r0 < nrow; r0 += 2 * 256) {
-                float w[2], b[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int rowi = min(r0 + 256 * u, nrow - 1);
-                    w[u] = p.ln.w[lnidx(rowi << 2)];
-                    b[u] = p.ln.b[lnidx(rowi << 2)];
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int rowi = r0 + 256 * u;
-                    if (rowi < nrow) {
-                        const int c = rowi / fh, ffl = rowi - c * fh, ff = f0 - HALO + ffl;
-                        const bool in = ff >= 0 && ff < p.F;
-                        *reinterpret_cast<float2 *>(wb + 2 * (c * fs + ffl)) = in ? float2{w[u], b[u]} : float2{0.f, 0.f};
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < NIT) {
+                        const int rowi = (j0 + u + 1) * 64 <= NROW ? rgc + 64 * (j0 + u) : min(rgc + 64 * (j0 + u), NROW - 1);
+                        const int c = rowi / FH, ffl = rowi - c * FH, ff = f0 - HALO + ffl;
+                        const int cf = c * F + max(0, min(ff, F - 1));
+                        v[u] = *reinterpret_cast<const f32x4 *>((c < ac ? abase : bbase) + cf * 16);
+                        if (LN_STAGE) { w[u] = p.ln.w[cf]; b[u] = p.ln.b[cf]; }
                     }
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- MFMA: wave walks the chunk's bins
-        // The operands of a bin are fetched as one batch of independent LDS reads (left alone the compiler emits
-        // read -> wait -> LayerNorm -> wait -> 2 MFMAs per k-step: two exposed LDS round trips each); MODE 0 / 2 also
-        // request the next bin's batch before this bin's MFMAs issue.
-        float xc[KS], xn[LN_FLY ? 1 : KS];
-        float2 wbc[LN_FLY ? KS : 1];
-        auto fetch = [&](int fl, float (&x)[KS]) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) x[s] = raw[(koff[s] + fl) * 16 + i];
-        };
-        if constexpr (!LN_FLY) fetch(min(wave, fcv - 1), xc);
-        for (int fl = wave; fl < fcv; fl += 4) {
-            if constexpr (LN_FLY) {
-                fetch(fl, xc);
-#pragma unroll
-                for (int s = 0; s < KS; ++s) wbc[s] = *reinterpret_cast<const float2 *>(wb + 2 * (koff[s] + fl));
-            } else {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) xn[s] = raw[(koff[s] + min(fl + 4, fcv - 1)) * 16 + i];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc[MT], acc2[MODE == 1 ? MT : 1];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; if (MODE == 1) acc2[mt] = acc[mt]; }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const float x = xc[s];
-                float lnv = x;
-                if constexpr (LN_FLY) lnv = (x - ln_mean) * ln_inv * wbc[s].x + wbc[s].y;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    acc[mt] = mfma16(wa[mt][s], lnv, acc[mt]);
-                    if (MODE == 1) acc2[mt] = mfma16(wg[mt][s], x, acc2[mt]);
-                }
-            }
-            if constexpr (!LN_FLY) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) xc[s] = xn[s];
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = mt * 16 + 4 * q + r;
-                    if (co < p.co) {
-                        const float v = acc[mt][r] + bias_r[mt][r];
-                        const int o = (co * p.fc + fl) * 16 + i;
-                        if (MODE == 0) {
-                            o0[o] = p.act == 1 ? gate_sigmoid(v) : v;
-                        } else if (MODE == 1) {
-                            const float g = gate_sigmoid(v), xi = acc2[mt][r] + bias2_r[mt][r], gx = g * xi;
-                            o0[o] = gx;
-                            o1[o] = xi - gx;
-                        } else {
-                            o0[o] = v;
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < NIT) {
+                        const int rowi = rgc + 64 * (j0 + u);
+                        if ((j0 + u + 1) * 64 <= NROW || rowi < NROW) {
+                            const int c = rowi / FH, ffl = rowi - c * FH, ff = f0 - HALO + ffl;
+                            f32x4 x = v[u];
+                            if (LN_STAGE) x = (x - st_mean) * st_inv * w[u] + b[u];
+                            if (HALO && (ff < 0 || ff >= F)) x = f32x4{0.f, 0.f, 0.f, 0.f};
+                            *reinterpret_cast<f32x4 *>(raw + (c * FS + ffl) * 16 + 4 * tq) = x;
                         }
                     }
+            }
+        }
+        if (LN_FLY) {                                           // (weight, bias) per staged row: unconditional clamped loads
+            constexpr int NROW = CIN * FH, NIT = (NROW + 255) / 256;
+            float w[NIT], b[NIT];
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int rowi = min(tid + 256 * u, NROW - 1), c = rowi / FH, ffl = rowi - c * FH;
+                const int cf = c * F + min(f0 + ffl, F - 1);
+                w[u] = p.ln.w[cf]; b[u] = p.ln.b[cf];
+            }
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int rowi = tid + 256 * u;
+                if (rowi < NROW) {
+                    const int c = rowi / FH, ffl = rowi - c * FH;
+                    *reinterpret_cast<float2 *>(wb + 2 * (c * FS + ffl)) = f0 + ffl < F ? float2{w[u], b[u]} : float2{0.f, 0.f};
                 }
+            }
         }
         __syncthreads();
 
-        // ---- coalesced write-out: thread = (row (co, fl), frame quad); the residual `add` rows of a batch are requested
-        // together before the stores
+        // ---- MFMA: wave walks the chunk's bins (bin = wave + 4 * round; the loop is unrolled so that every LDS address is
+        // one operand / output base register plus a compile-time offset).  The operands of a bin are fetched as one batch of
+        // independent LDS reads (left alone the compiler emits read -> wait -> LayerNorm -> wait -> 2 MFMAs per k-step: two
+        // exposed LDS round trips each); MODE 0 / 2 also request the next bin's batch before this bin's MFMAs issue.
+        {
+            float xc[KS], xn[LN_FLY ? 1 : KS];
+            float2 wbc[LN_FLY ? KS : 1];
+            const int wbaddr0 = 2 * (q * FS + wave);          // MODE 1 (KF = 1): row 4s + q, bin `wave`
+            const int obase = ((4 * q) * FC + wave) * 16 + i;   // row 4q (+ 16 mt + r), bin `wave` (+ 4 round)
+            if constexpr (!LN_FLY) {
+                if (wave < fcv) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) xc[s] = raw[kaddr0 + koffs(s)];
+                }
+            }
+#pragma unroll
+            for (int rd = 0; rd < FC / 4; ++rd) {
+                const int fl = wave + 4 * rd;
+                if (fl < fcv) {
+                    if constexpr (LN_FLY) {
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) { xc[s] = raw[kaddr0 + koffs(s) + rd * 64]; wbc[s] = *reinterpret_cast<const float2 *>(wb + wbaddr0 + 8 * s * FS + rd * 8); }
+                    } else if (rd + 1 < FC / 4) {
+                        if (fl + 4 < fcv) {
+#pragma unroll
+                            for (int s = 0; s < KS; ++s) xn[s] = raw[kaddr0 + koffs(s) + (rd + 1) * 64];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 acc[MT], acc2[MODE == 1 ? MT : 1];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; if (MODE == 1) acc2[mt] = acc[mt]; }
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const float x = xc[s];
+                        float lnv = x;
+                        if constexpr (LN_FLY) lnv = (x - ln_mean) * ln_inv * wbc[s].x + wbc[s].y;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            acc[mt] = mfma16(wa[mt][s], lnv, acc[mt]);
+                            if (MODE == 1) acc2[mt] = mfma16(wg[mt][s], x, acc2[mt]);
+                        }
+                    }
+                    if constexpr (!LN_FLY) {
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) xc[s] = xn[s];
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        if ((mt + 1) * 16 <= CO || mt * 16 + 4 * q < CO) {          // a lane's four rows are valid together (CO % 4 == 0) ...
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (CO % 4 == 0 || (mt + 1) * 16 <= CO || mt * 16 + 4 * q + r < CO) {      // ... or checked one by one
+                                    const float v = acc[mt][r] + bias_r[mt][r];
+                                    const int o = obase + ((mt * 16 + r) * FC + 4 * rd) * 16;
+                                    if (MODE == 0) {
+                                        o0[o] = p.act == 1 ? gate_sigmoid(v) : v;
+                                    } else if (MODE == 1) {
+                                        const float g = gate_sigmoid(v), xi = acc2[mt][r] + bias2_r[mt][r], gx = g * xi;
+                                        o0[o] = gx;
+                                        o1[o] = xi - gx;
+                                    } else {
+                                        o0[o] = v;
+                                    }
+                                }
+                        }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- coalesced write-out: thread = (row (co, fl), frame quad), rows rg + 64 j over the [CO][FC] block (bins past a
+        // short last chunk are skipped); the residual `add` rows of a batch are requested together before the stores
         {
             StatAcc st0, st1;
             st0.init(); st1.init();
-            const int nitem = p.co * fcv * 4;
-            for (int e0 = tid; e0 < nitem; e0 += 4 * 256) {
+            constexpr int NROW = CO * FC, NIT = (NROW + 63) / 64;
+            const int f016 = f0 * 16;
+#pragma unroll
+            for (int j0 = 0; j0 < NIT; j0 += 4) {
                 f32x4 av[4];
                 if (MODE == 2) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = min(e0 + 256 * u, nitem - 1), rowi = e >> 2, tq = e & 3, co = rowi / fcv, fl = rowi - co * fcv;
-                        av[u] = *reinterpret_cast<const f32x4 *>(p.add.ptr + ft_idx(tile, p.add.c_total, p.add.c_off + co, p.F, f0 + fl) + 4 * tq);
-                    }
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + u < NIT) {
+                            const int rowi = (j0 + u + 1) * 64 <= NROW ? rgc + 64 * (j0 + u) : min(rgc + 64 * (j0 + u), NROW - 1);
+                            const int co = rowi / FC, fl = min(rowi - co * FC, fcv - 1);
+                            av[u] = *reinterpret_cast<const f32x4 *>(addbase + f016 + (co * F + fl) * 16);
+                        }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = e0 + 256 * u;
-                    if (e < nitem) {
-                        const int rowi = e >> 2, tq = e & 3, co = rowi / fcv, fl = rowi - co * fcv;
-                        f32x4 v = *reinterpret_cast<const f32x4 *>(o0 + (co * p.fc + fl) * 16 + 4 * tq);
-                        if (MODE == 2) v += av[u];
-                        *reinterpret_cast<f32x4 *>(p.out0.ptr + ft_idx(tile, p.out0.c_total, p.out0.c_off + co, p.F, f0 + fl) + 4 * tq) = v;
-                        if (p.part0) st0.add(v);
-                        if (MODE == 1) {
-                            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(o1 + (co * p.fc + fl) * 16 + 4 * tq);
-                            *reinterpret_cast<f32x4 *>(p.out1.ptr + ft_idx(tile, p.out1.c_total, p.out1.c_off + co, p.F, f0 + fl) + 4 * tq) = v1;
-                            if (p.part1) st1.add(v1);
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < NIT) {
+                        const int rowi = rgc + 64 * (j0 + u), co = rowi / FC, fl = rowi - co * FC;
+                        if (((j0 + u + 1) * 64 <= NROW || rowi < NROW) && fl < fcv) {
+                            f32x4 v = *reinterpret_cast<const f32x4 *>(o0 + rowi * 16 + 4 * tq);
+                            if (MODE == 2) v += av[u];
+                            *reinterpret_cast<f32x4 *>(obase0 + f016 + (co * F + fl) * 16) = v;
+                            if (p.part0) st0.add(v);
+                            if (MODE == 1) {
+                                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(o1 + rowi * 16 + 4 * tq);
+                                *reinterpret_cast<f32x4 *>(obase1 + f016 + (co * F + fl) * 16) = v1;
+                                if (p.part1) st1.add(v1);
+                            }
                         }
                     }
-                }
             }
             if (p.part0) run0.merge(st0);
             if (MODE == 1 && p.part1) run1.merge(st1);
@@ -1219,24 +1254,17 @@ extern "C" int vadx_dfsmn_stats_merge(const float *part_a, const float *part_b, 
     return VADX_OK;
 }
 
-template <int MT, int KS, int KF, int MODE>
+template <int CO, int CIN, int KF, int MODE>
 static int launch_pw(PwArgs p, int tiles, void *stream) {
-    // bins per chunk: the largest multiple of 4 (one bin per wave per round) up to 32 that keeps the workgroup's LDS
-    // within 52 KB (three workgroups per CU); a workgroup walks all chunks of its tile (weights stay in VGPRs),
-    // two workgroups per tile when there are few tiles
-    const int cin = p.a.c + p.b.c, halo = (KF - 1) / 2, nout = MODE == 1 ? 2 : 1;
-    auto lds_floats = [&](int fc) { return cin * ((fc + 2 * halo) | 1) * 18 + nout * p.co * fc * 16; };
-    int fc = 32;
-    // (smaller chunks for more workgroups per CU were measured -- LDS caps of 40 / 26 / 16 KB: pw_conv 80 -> 94 / 105 / 111 ms
-    // per 1920 windows: shorter contiguous runs per channel and more halo rows cost more than the occupancy buys)
-    while (fc > 4 && lds_floats(fc) * 4 > 52 * 1024) fc -= 4;
-    p.fc = fc;
-    p.nchunk = (p.F + fc - 1) / fc;
-    const size_t lds = (size_t)lds_floats(fc) * sizeof(float);
-    VADX_REQUIRE(!(p.part0 || p.part1) || lds_floats(fc) >= 144, "vadx_dfsmn_pw_conv: shape too small for fused statistics");
-    VADX_DYN_LDS((pw_conv_kernel<MT, KS, KF, MODE>), 64 * 1024);
+    // a workgroup walks all chunks of its tile (weights stay in VGPRs), two workgroups per tile when there are few tiles
+    using S = PwShape<CO, CIN, KF, MODE>;
+    p.fc = S::FC;
+    p.nchunk = (p.F + S::FC - 1) / S::FC;
+    constexpr size_t lds = (size_t)S::LDS_FLOATS * sizeof(float);
+    static_assert(S::LDS_FLOATS >= 144, "shape too small for the fused statistics' reduction scratch");
+    VADX_DYN_LDS((pw_conv_kernel<CO, CIN, KF, MODE>), 64 * 1024);
     const unsigned split = tiles < 4096 ? 2 : 1;
-    hipLaunchKernelGGL((pw_conv_kernel<MT, KS, KF, MODE>), dim3((unsigned)tiles, split), dim3(256), lds,
+    hipLaunchKernelGGL((pw_conv_kernel<CO, CIN, KF, MODE>), dim3((unsigned)tiles, split), dim3(256), lds,
                        static_cast<hipStream_t>(stream), p);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
@@ -1253,17 +1281,17 @@ extern "C" int vadx_dfsmn_pw_conv(int mode, const vadx_ft_view *a, const vadx_ft
     p.part0 = part0; p.part1 = mode == 1 ? part1 : nullptr;
     VADX_REQUIRE(mode == 0 ? !(ln && ln->stats) : (ln && ln->stats && ln->w && ln->b),
                  "vadx_dfsmn_pw_conv: mode %d %s a LayerNorm", mode, mode == 0 ? "takes no" : "needs");
-    const int cin = p.a.c + p.b.c, K = kf * cin, MT = (co + 15) / 16;
-    VADX_REQUIRE(K % 4 == 0, "vadx_dfsmn_pw_conv: kf*cin must be a multiple of 4");
-    const int KS = K / 4;
-#define PW_CASE(mt, ks, kfv, md) if (MT == mt && KS == ks && kf == kfv && mode == md) return launch_pw<mt, ks, kfv, md>(p, tiles, stream)
-    PW_CASE(2, 5, 1, 1);       // CFB front, 20 -> 20
-    PW_CASE(2, 10, 1, 1);      // CFB front, 40 -> 20
-    PW_CASE(2, 15, 3, 2);      // CFB back: conv (3,1) 20 -> 20 + ceps
-    PW_CASE(2, 6, 1, 0);       // in_conv 24 -> 20
-    PW_CASE(2, 10, 1, 0);      // in_ch_lstm linear 40 -> 20
-    PW_CASE(3, 10, 1, 0);      // ceps linear 40 -> 40
-    PW_CASE(1, 15, 1, 0);      // out_conv 60 -> 2
+    const int cin = p.a.c + p.b.c;
+    VADX_REQUIRE((int64_t)tiles * 16 * 2 < INT32_MAX && (int64_t)(p.a.c_total + p.b.c_total + co) * F * 16 < INT32_MAX,
+                 "vadx_dfsmn_pw_conv: tensor too large for the kernel's 32-bit in-tile offsets");
+#define PW_CASE(cov, cinv, kfv, md) if (co == cov && cin == cinv && kf == kfv && mode == md) return launch_pw<cov, cinv, kfv, md>(p, tiles, stream)
+    PW_CASE(20, 20, 1, 1);     // CFB front, 20 -> 20
+    PW_CASE(20, 40, 1, 1);     // CFB front, 40 -> 20
+    PW_CASE(20, 20, 3, 2);     // CFB back: conv (3,1) 20 -> 20 + ceps
+    PW_CASE(20, 24, 1, 0);     // in_conv 24 -> 20
+    PW_CASE(20, 40, 1, 0);     // in_ch_lstm linear 40 -> 20
+    PW_CASE(40, 40, 1, 0);     // ceps linear 40 -> 40
+    PW_CASE(2, 60, 1, 0);      // out_conv 60 -> 2
 #undef PW_CASE
     vadx::set_error("vadx_dfsmn_pw_conv: unsupported shape (co=%d cin=%d kf=%d mode=%d)", co, cin, kf, mode);
     return VADX_EINVAL;
