@@ -386,7 +386,7 @@ def firered_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None):
     return out
 
 
-def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch=960):
+def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch=3072):
     from vadx import dfsmn, weights
     eng = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234), device=device, sub_batch=sub_batch)
     lb, stride = eng.grid()

@@ -30,7 +30,7 @@ elif which == "firered":
     audio = bm.synth_pcm16(torch, dev, 2048, 160000, seed=1505)
     fn = lambda: eng.run(audio, 10)                        # noqa: E731
 else:
-    eng = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234), device=dev, sub_batch=960)
+    eng = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234), device=dev, sub_batch=3072)
     lb, stride = eng.grid()
     W = -(-(160000 - eng.L) // stride) + 1
     n = (W - 1) * stride + eng.L

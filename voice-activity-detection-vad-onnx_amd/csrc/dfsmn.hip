@@ -17,7 +17,7 @@
 
 // DFSMN_EXP: development-only what-if switches (bit mask; results are wrong when set): 1 lstm_f without its output
 // stores, 2 without input loads, 4 without gate non-linearities; dft_f: 8 one k-step instead of all, 16 no copy-out,
-// 32 no input request / park, 64 no per-channel barrier
+// 32 no input request / park, 64 no per-channel barrier; lstm_f: 128 no input-half MFMAs, 256 no recurrent MFMAs
 #ifndef DFSMN_EXP
 #define DFSMN_EXP 0
 #endif
@@ -739,24 +739,57 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void l
         for (int b = 0; b < NB; ++b) {
             const int f = bin_of(ck, b);
             if (f < 0 || f >= p.F) break;
+            // next step's input operands: the next bin of this chunk, or bin 0 of the parked next chunk (after the very last
+            // step this reads stale rows of the other buffer; the result is never used)
+            const float *xrow = b + 1 < NB ? xb + (b + 1) * IN * 16 : xnext;
+            float xv[KI];
+#pragma unroll
+            for (int s = 0; s < KI; ++s) xv[s] = xrow[(4 * s + q) * 16 + i];
             f32x4 acc[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = accn[mt];
 #pragma unroll
             for (int s = 0; s < MT; ++s)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wh[mt][s], h[s], acc[mt]);
-            // next step's input half: the next bin of this chunk, or bin 0 of the parked next chunk (after the very last
-            // step this reads stale rows of the other buffer; the result is never used)
-            input_half(b + 1 < NB ? xb + (b + 1) * IN * 16 : xnext, accn);
+                for (int mt = 0; mt < MT; ++mt) if (!(DFSMN_EXP & 256)) acc[mt] = mfma16(wh[mt][s], h[s], acc[mt]);
+            __builtin_amdgcn_sched_barrier(0);
+            // The matrix pipe takes 32 cycles per MFMA, during which the wave can issue three to four other instructions.  Left
+            // to itself the scheduler emits the next input half as two runs of MFMAs and the gate arithmetic as ~50-instruction
+            // stretches with the pipe idle, so the order is pinned here: PIECES slices per hidden-unit quad, each = a few
+            // input-half MFMAs of step t+1 + one slice of step t's gate arithmetic, fenced by sched_barriers.
+            constexpr int NIN = MT * KI, PIECES = 5, PER = (NIN + MT * PIECES - 1) / (MT * PIECES);
+            auto in_mfma = [&](int n) {                         // n-th MFMA of a = bias + W_ih x  (k-step n / MT, row tile n % MT)
+                if (n >= NIN || (DFSMN_EXP & 128)) return;
+                const int s2 = n / MT, m2 = n % MT;
+                if (s2 == 0) accn[m2] = f32x4{bias[m2][0], bias[m2][1], bias[m2][2], bias[m2][3]};
+                accn[m2] = mfma16(wi[m2][s2], xv[s2], accn[m2]);
+            };
+            const bool lin = DFSMN_EXP & 4;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const bool lin = DFSMN_EXP & 4;
-                const float ig = lin ? acc[mt][0] : gate_sigmoid(acc[mt][0]), fg = lin ? acc[mt][1] * 0.1f : gate_sigmoid(acc[mt][1]);
-                const float gg = lin ? acc[mt][2] : gate_tanh(acc[mt][2]), og = lin ? acc[mt][3] : gate_sigmoid(acc[mt][3]);
+                int n = mt * PIECES * PER;
+#pragma unroll
+                for (int u = 0; u < PER; ++u) in_mfma(n++);
+                const float ig = lin ? acc[mt][0] : gate_sigmoid(acc[mt][0]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PER; ++u) in_mfma(n++);
+                const float fg = lin ? acc[mt][1] * 0.1f : gate_sigmoid(acc[mt][1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PER; ++u) in_mfma(n++);
+                const float gg = lin ? acc[mt][2] : gate_tanh(acc[mt][2]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PER; ++u) in_mfma(n++);
+                const float og = lin ? acc[mt][3] : gate_sigmoid(acc[mt][3]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PER; ++u) in_mfma(n++);
                 c[mt] = fg * c[mt] + ig * gg;
                 h[mt] = lin ? og * c[mt] * 0.01f : og * gate_tanh(c[mt]);
                 if (!(DFSMN_EXP & 1) || h[mt] == 123.f) p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + dir * H + 4 * mt + q, p.F, f) + i] = h[mt];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

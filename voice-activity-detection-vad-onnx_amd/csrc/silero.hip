@@ -203,6 +203,11 @@ __device__ __forceinline__ void gemm_pass_sub(f32x4 (&acc)[1][AN], const float *
 // Three Winograd planes side by side: acc[p] += V_p x U_p over KB blocks of 16 input channels.  Plane p's activations sit
 // 16 columns further right in the same LDS rows, its weights KB fragments further in this lane's stream; the three
 // accumulators alternate, so consecutive MFMAs are independent.
+// |STFT| magnitude: the bare v_sqrt_f32 (1 ulp).  sqrtf() is the correctly rounded, denormal-safe library routine -- about fifteen
+// VALU instructions per value -- and on gfx950 VALU work does not hide under v_mfma_f32_16x16x4_f32: the two ADD UP on a SIMD
+// (tools/mfma_valu_overlap.sh: 15.2 ns per MFMA alone, +1.8 ns per v_fma_f32 placed beside it, one or two waves per SIMD alike).
+__device__ __forceinline__ float mag_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 template <int KB>
 __device__ __forceinline__ void gemm_planes3(f32x4 &a0, f32x4 &a1, f32x4 &a2, const float *act, int lda, const float *w, int lane) {
     // (An explicitly software-pipelined form of this loop -- weight fragments and LDS operands of block S + 1 in flight
@@ -465,8 +470,8 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             for (int r = 0; r < 4; ++r) {
                 const float pr = ere[f][r] + ore[f][r], pi = eim[f][r] + oim[f][r];
                 const float nr = ere[f][r] - ore[f][r], ni = eim[f][r] - oim[f][r];
-                mk[f][r] = sqrtf(pr * pr + pi * pi);
-                mn[f][r] = sqrtf(nr * nr + ni * ni);
+                mk[f][r] = mag_sqrt(pr * pr + pi * pi);
+                mn[f][r] = mag_sqrt(nr * nr + ni * ni);
             }
         float *vk = V + k * V_LD + 4 * q, *vn = V + (128 - k) * V_LD + 4 * q;
         if (fp == 0) {
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const float re = scr[f * 32 + c] + scr[(f + 4) * 32 + c], im = scr[f * 32 + 16 + c] + scr[(f + 4) * 32 + 16 + c];
-                m[f] = sqrtf(re * re + im * im);
+                m[f] = mag_sqrt(re * re + im * im);
             }
             V[64 * V_LD + j * 16 + c] = WINO_BT[j][0] * m[0] + WINO_BT[j][1] * m[1] + WINO_BT[j][2] * m[2] + WINO_BT[j][3] * m[3];
         }
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             }
             sre += __shfl_xor(sre, 16); sre += __shfl_xor(sre, 32);
             sim += __shfl_xor(sim, 16); sim += __shfl_xor(sim, 32);
-            nyq = sqrtf(sre * sre + sim * sim);
+            nyq = mag_sqrt(sre * sre + sim * sim);
         }
         ENC_SYNC();          // every wave is done reading X: V may now overwrite it
         ENC_MARK(3);
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) m[f][r] = sqrtf(acc[0][f][r] * acc[0][f][r] + acc[1][f][r] * acc[1][f][r]);
+                for (int r = 0; r < 4; ++r) m[f][r] = mag_sqrt(acc[0][f][r] * acc[0][f][r] + acc[1][f][r] * acc[1][f][r]);
             float *vr = V + (wave * 16 + i) * V_LD + 4 * q;
 #pragma unroll
             for (int j = 0; j < 6; ++j)
