@@ -1,11 +1,22 @@
-import sys, json, torch
-sys.path.insert(0, "/root/repo")
-import vadx, bench_models as bm
+"""DFSMN config-5 pass against the sub-batch size (development aid, GPU box): python tools/sweep_dfsmn_subbatch.py 960 3072 ..."""
+import sys
+import torch
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import vadx  # noqa: F401
+import bench_models as bm
+from vadx import dfsmn, weights
+
 dev = torch.device("cuda", 0)
-for sb in (3072,):
+for sb in [int(a) for a in sys.argv[1:]] or [3072]:
     try:
-        r = bm.dfsmn_c5(torch, dev, 2, 0, sub_batch=sb)
-        print("SUB", sb, round(r["ms"], 1), {k: round(v, 1) for k, v in r["kernel_ms"].items() if v > 50}, flush=True)
+        eng = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234), device=dev, sub_batch=sb)
+        lb, stride = eng.grid()
+        W = 15
+        n = (W - 1) * stride + eng.L
+        near, far = bm.synth_pcm16(torch, dev, 2048, n, seed=1606), bm.synth_pcm16(torch, dev, 2048, n, seed=1607)
+        ms = bm.device_ms(torch, lambda: eng.run(near, far, W, stride), 2)
+        print("SUB", sb, round(ms, 1), "ms", flush=True)
+        del eng, near, far
     except Exception as e:
-        print("SUB", sb, "ERR", repr(e)[:200], flush=True)
+        print("SUB", sb, "ERR", repr(e)[:300], flush=True)
     torch.cuda.empty_cache()

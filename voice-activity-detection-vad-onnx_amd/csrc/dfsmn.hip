@@ -486,42 +486,43 @@ __global__ __launch_bounds__(256, 3) void pw_conv_kernel(PwArgs p) {
 
 // ---------------------------------------------------------------------------------------------
 // dft_f: GEMM along the frequency axis, per channel:  out[c][m][t] = sum_k Tbl[m][k] * B_c[k][t]
-//   FWD (CepsUnit :134-138): B_c = LN2(in)[c][f] (k = f, 160);  rows m = (cos k'<81 | sin k'<81) in
-//        12 tiles of 16; out channel c <- cos rows, C + c <- sin rows, Fout = 81.
-//   INV (:141-153): k = (re k'<81 | im k'<81) (164 padded); B_c = complex product of the LSTM output
-//        (pr, pi) = lo[c], lo[C+c] with the raw spectrum (re, im) = li[c], li[C+c]; rows m = f (160).
-// Table rows live in VGPRs: 12 row tiles (FWD 96 cos | 96 sin rows, INV 160 rows + 2 zero tiles) on FOUR waves of
-// three tiles each -- one wave per SIMD, so every SIMD carries the same MFMA load (with 6 / 5 waves of two tiles two
-// SIMDs carried double and the workgroup's channel time was theirs).  The channel's B matrix is staged through LDS.
+//   FWD (CepsUnit :134-138): B_c = LN2(in)[c][f] (k = f, 160);  rows m = (cos k' = 0..80 | sin k' = 1..79): the sine rows of
+//        bins 0 and 80 are identically zero, so the 162 outputs are 160 table rows = TEN tiles of 16 (they were padded to
+//        96 + 96 = twelve); out channel c <- cos rows, C + c <- sin rows (bins 0 and 80 written as zeros), Fout = 81.
+//   INV (:141-153): k = (re k' = 0..80 | im k' = 1..79) (160: the pseudo-inverse has zero columns for the two vanishing imaginary
+//        parts; the host checks that); B_c = complex product of the LSTM output (pr, pi) = lo[c], lo[C+c] with the raw
+//        spectrum (re, im) = li[c], li[C+c]; rows m = f (160).
+// Table rows live in VGPRs.  Four waves (one per SIMD) own 3 + 3 + 2 + 2 row tiles; two workgroups share a CU and the dispatcher
+// rotates their starting SIMD, so a SIMD carries at most six and typically five tiles per channel pair where the padded layout
+// cost six always.  The channel's B matrix is staged through LDS.
 // ---------------------------------------------------------------------------------------------
 struct DftArgs {
     View in;             // FWD: r (C ch, F=160).  INV: li (2C ch, F=81)
     View lo;             // INV only: LSTM+linear output (2C ch, F=81)
     LN ln;               // FWD only
-    const float *tbl;    // [MTILES*16][KS*4] row-major, zero padded
+    const float *tbl;    // [160][160] row-major
     ViewW out;           // FWD: li (2C ch, 81).  INV: ceps_out (C ch, 160)
     float *part;         // FWD, optional: partial statistics of out (slot 0; slot 1 cleared)
     int C, tiles;
 };
 
+constexpr int DFT_K = 160, DFT_KS = DFT_K / 4, DFT_ROWS = 160, DFT_NT = 256;
+
 // Memory path: channel c+1's rows are requested as 16-B coalesced loads before channel c's MFMAs issue and parked in
 // the other half of the LDS double buffer afterwards; results leave through a (double-buffered) LDS output block as
 // 16-B coalesced stores -- an output channel's bins are contiguous in the FT layout.
-template <bool INV>
-__global__ __launch_bounds__(256, 2) void dft_f_kernel(DftArgs p) {
-    constexpr int KS = INV ? 41 : 40, NWAVE = 4, RT = 3, KROWS = KS * 4, NT = NWAVE * 64;
-    constexpr int OROWS = NWAVE * RT * 16;                  // 192: FWD 96 cos | 96 sin, INV 160 + 32 zero rows
+// RT = this wave's number of row tiles, rt0 = its first one (the two instantiations meet at the same barriers).
+template <bool INV, int RT>
+__device__ __forceinline__ void dft_f_body(const DftArgs &p, const int rt0, float (*Bs)[DFT_K * 16], float (*Os)[DFT_ROWS * 16]) {
+    constexpr int KS = DFT_KS, NT = DFT_NT;
     constexpr int ITEMS = INV ? 81 * 4 : 160 * 4, NR = (ITEMS + NT - 1) / NT;      // staging work items (row, frame quad)
-    __shared__ __attribute__((aligned(16))) float Bs[2][KROWS * 16];
-    __shared__ __attribute__((aligned(16))) float Os[2][OROWS * 16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, i = lane & 15;
     float ta[RT][KS];                                       // loaded once: the workgroup walks tiles blockIdx.x, + gridDim.x, ...
 #pragma unroll
     for (int h = 0; h < RT; ++h)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) ta[h][s] = p.tbl[(size_t)((wave * RT + h) * 16 + i) * KROWS + 4 * s + q];
+        for (int s = 0; s < KS; ++s) ta[h][s] = p.tbl[((rt0 + h) * 16 + i) * DFT_K + 4 * s + q];
     const int tq = tid & 3;                                 // NT is a multiple of 4: a thread's frame quad is fixed
-    for (int e = tid; e < 2 * KROWS * 16; e += NT) Bs[0][e] = 0.f;          // rows past the data stay zero (table padding)
     for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
     f32x4 ln_mean = {0.f, 0.f, 0.f, 0.f}, ln_inv = {1.f, 1.f, 1.f, 1.f};
     if (!INV)                        // the forward direction always normalises (LN2; the launcher requires it)
@@ -560,14 +561,13 @@ __global__ __launch_bounds__(256, 2) void dft_f_kernel(DftArgs p) {
             } else {
                 const f32x4 re = pre[r][0], im = pre[r][1], pr = pre[r][2], pi = pre[r][3];
                 *reinterpret_cast<f32x4 *>(dst + k * 16 + 4 * tq) = pr * re - pi * im;
-                *reinterpret_cast<f32x4 *>(dst + (81 + k) * 16 + 4 * tq) = pr * im + pi * re;
+                if (k >= 1 && k <= 79) *reinterpret_cast<f32x4 *>(dst + (80 + k) * 16 + 4 * tq) = pr * im + pi * re;
             }
         }
     };
     StatRun run;
     run.init();
     request(0);
-    __syncthreads();                 // the zero fill above
     park(Bs[0]);
     __syncthreads();
     for (int c = 0; c < p.C; ++c) {
@@ -600,17 +600,19 @@ __global__ __launch_bounds__(256, 2) void dft_f_kernel(DftArgs p) {
 #pragma unroll
         for (int h = 0; h < RT; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) O[((wave * RT + h) * 16 + 4 * q + r) * 16 + i] = acc[h][r];
+            for (int r = 0; r < 4; ++r) O[((rt0 + h) * 16 + 4 * q + r) * 16 + i] = acc[h][r];
         if (c + 1 < p.C && !(DFSMN_EXP & 32)) park(Bs[(c + 1) & 1]);
         if (!(DFSMN_EXP & 64)) __syncthreads();
         if ((DFSMN_EXP & 16) && acc[0][0] != 123.f) continue;
         // copy-out of channel c (reads O; O is next written two channels later, after the next barrier)
-        if (!INV) {          // rows 0..95 = cos bins (81 valid) -> channel c, rows 96..191 = sin bins -> channel C + c
+        if (!INV) {          // rows 0..80 = cos bins -> channel c; rows 81..159 = sin bins 1..79 -> channel C + c, whose bins 0, 80 are zero
             StatAcc st;
             st.init();
             for (int e = tid; e < 2 * 81 * 4; e += NT) {
                 const int half = e >= 81 * 4, rowq = e - half * 81 * 4, kk = rowq >> 2, oq = rowq & 3;      // oq == tid & 3
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(O + (half * 96 + kk) * 16 + 4 * oq);
+                const bool zero = half && (kk == 0 || kk == 80);
+                f32x4 v = *reinterpret_cast<const f32x4 *>(O + (zero ? 0 : half * 80 + kk) * 16 + 4 * oq);
+                if (zero) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4 *>(p.out.ptr + ft_idx(tile, p.out.c_total, p.out.c_off + (half ? p.C + c : c), 81, kk) + 4 * oq) = v;
                 if (p.part) st.add(v);
             }
@@ -627,6 +629,20 @@ __global__ __launch_bounds__(256, 2) void dft_f_kernel(DftArgs p) {
     }
     __syncthreads();                                        // Bs / Os are free for the next tile
     }
+}
+
+template <bool INV>
+__global__ __launch_bounds__(DFT_NT, 2) void dft_f_kernel(DftArgs p) {
+    __shared__ __attribute__((aligned(16))) float Bs[2][DFT_K * 16];
+    __shared__ __attribute__((aligned(16))) float Os[2][DFT_ROWS * 16];
+    const int wave = threadIdx.x >> 6;
+#ifndef DFT_HEAVY
+#define DFT_HEAVY 0x5            /* bit mask of the two waves that own three row tiles: 0 and 2 measured best (fwd 1.30 ms; {0,1} 1.39, {0,3} 1.40, {1,2} 1.41) */
+#endif
+    const bool heavy = (DFT_HEAVY >> wave) & 1;
+    const int rank = __builtin_popcount((heavy ? DFT_HEAVY : ~DFT_HEAVY & 0xf) & ((1 << wave) - 1));     // 0 or 1 among its kind
+    if (heavy) dft_f_body<INV, 3>(p, 3 * rank, Bs, Os);
+    else dft_f_body<INV, 2>(p, 6 + 2 * rank, Bs, Os);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -92,13 +92,17 @@ class Iccrn:
         ff = t.arange(half + 1, dtype=t.float32).unsqueeze(1)
         omega = 2 * t.pi * ff * tt / n
         cos_k, sin_k = t.cos(omega), -t.sin(omega)                                   # [81,160], window = ones
-        fwd = t.zeros((192, 160), dtype=t.float32)
-        fwd[:81], fwd[96:96 + 81] = cos_k, sin_k
+        # forward: 160 table rows = cos bins 0..80 | sin bins 1..79 (the sine rows of bins 0 and 80 are identically zero: the kernel
+        # writes those two outputs as zeros), ten MFMA row tiles instead of 96 + 96 padded rows
+        fwd = t.cat([cos_k, sin_k[1:half]], dim=0).contiguous()                       # [160, 160]
         fb = t.fft.fft(t.eye(n, dtype=t.float32))
         basis = t.vstack([t.real(fb[:half + 1]), t.imag(fb[:half + 1])]).float()
-        inv_basis = t.linalg.pinv(basis).T                                            # [162,160]
-        inv = t.zeros((192, 164), dtype=t.float32)                                    # 12 row tiles like fwd (rows 160.. zero)
-        inv[:160, :162] = inv_basis.t()
+        inv_basis = t.linalg.pinv(basis).T                                            # [162 (re 0..80 | im 0..80), 160]
+        # inverse: k = re 0..80 | im 1..79 -- the imaginary parts of bins 0 and 80 meet all-zero rows of the pseudo-inverse
+        dead = inv_basis[[half + 1, 2 * half + 1]]
+        if float(dead.abs().max()) > 1e-6:
+            raise ValueError("CepsUnit inverse basis: the rows of im(bin 0) / im(bin 80) are not zero")
+        inv = t.cat([inv_basis[:half + 1], inv_basis[half + 2:2 * half + 1]], dim=0).t().contiguous()      # [160 (f), 160 (k)]
         self.tbl_fwd, self.tbl_inv = fwd.to(self.device), inv.to(self.device)
 
     # ---- small helpers around the C ABI -------------------------------------------------------
@@ -325,6 +329,8 @@ class DfsmnEngine:
         vad = t.empty((n_chunks, self.T_A), dtype=t.float32, device=self.device)
         aec_all = t.empty((n_chunks, self.L), dtype=t.float32, device=self.device) if return_aec else None
         per = max(1, self.sub_batch // W)                  # clips per sub-batch (activations are ~30 MB per window)
+        # (alternating the independent sub-batches over two or three side streams so that one's HBM-bound launches overlap another's
+        # matrix-pipe-bound ones was measured: 2986 / 2985 ms against 2990 -- every launch fills the chip by itself)
         for b0 in range(0, B, per):
             nb = min(per, B - b0)
             v, a = self._run_sub(near[b0:b0 + nb], None if far is None else far[b0:b0 + nb], W, ws)
