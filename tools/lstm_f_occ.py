@@ -20,7 +20,7 @@ def timed(fn, reps=5):
     return min(a.elapsed_time(b) for a, b in ev)
 
 
-for tiles in (256, 1024, 6720):
+for tiles in (1024, 6720):
     li = dfsmn.FT(torch, dev, tiles, frames, 40, 81)
     li.data.normal_()
     hf = dfsmn.FT(torch, dev, tiles, frames, 40, 81, zero=False)

@@ -721,6 +721,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void l
             *reinterpret_cast<f32x4 *>(dst + ((lane >> 2) + 16 * r) * 16 + 4 * tq) = v;
         }
     };
+    // (Requests arranged so that every one covers a whole, aligned 128-B line -- F = 81 is odd, so for every other channel the two
+    // bins of a chunk straddle two lines -- were built and change nothing (2.04 vs 2.05 ms): the rocprofv3 FETCH_SIZE of this
+    // kernel equals the tensor's bytes UNdoubled, i.e. 64-B requests are tallied at 64 B and there never was an over-fetch.)
     // The step is software-pipelined inside the wave: the input half of step t+1 (W_ih x, 10 k-steps, independent of the
     // recurrence) is issued right after the recurrent half of step t (W_hh h, 5 k-steps), so the matrix pipe works on it
     // while the VALU runs step t's gate non-linearities -- in program order (input half, recurrent half, gates) the

@@ -75,7 +75,6 @@ constexpr int MAXTAP = 32;
 // Fast path for undilated filters with <= 20 taps each (the shipped FireRedVAD/AED configs): the
 // look-back and look-ahead filters merge into one 40-tap window c[-19..20] around t; each thread slides
 // it over 28 frames held in registers -- no guards, no address math in the inner loop.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void fsmn_memory_fast(const Dev &d, const float *__restrict__ Pk, int r, bool skip,
                                                  const float *p, float *mem) {

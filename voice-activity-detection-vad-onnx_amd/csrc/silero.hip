@@ -161,6 +161,8 @@ __device__ __forceinline__ void stft_fold_class(f32x4 (&are)[2], f32x4 (&aim)[2]
         const f32x4 nim = *reinterpret_cast<const f32x4 *>(wim + FRAG * Sn);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            // (forming the two frames' operands as f32x2 pairs for v_pk_add_f32 -- half the adds -- costs more in register
+            // shuffles than it saves: 291 instead of 199 VALU instructions in this loop)
             float e[2], o[2];
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
@@ -213,13 +215,14 @@ __device__ __forceinline__ void gemm_planes3(f32x4 &a0, f32x4 &a1, f32x4 &a2, co
     // (An explicitly software-pipelined form of this loop -- weight fragments and LDS operands of block S + 1 in flight
     // under the MFMAs of block S, ping-pong registers, counted waits -- was built and measured: 7.5 - 8.0 ms against 7.3 ms
     // for this plain form.  Six waves per SIMD already interleave at MFMA-pair granularity; the extra live registers only
-    // cost spills at the 80-VGPR budget.)
+    // cost spills at the 80-VGPR budget.)  The loop is unrolled by four all the same: rolled, every block carried a dozen v_mov
+    // (wc = wn) and 64-bit pointer updates -- 37 VALU instructions per 12 MFMAs -- and VALU time adds to f32-MFMA time here.
     const int q = lane >> 4, i = lane & 15;
     const float *ap = act + (4 * q) * lda + i;
     f32x4 wc[3], wn[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) wc[p] = *reinterpret_cast<const f32x4 *>(w + p * KB * FRAG);
-#pragma unroll 1
+#pragma unroll 4
     for (int S = 0; S < KB; ++S) {
         const int Sn = ENC_SKIP(13) ? 0 : ((S + 1 < KB) ? S + 1 : S);
 #pragma unroll
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             f32x4 wcur[4], wnxt[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) wcur[g] = *reinterpret_cast<const f32x4 *>(wl + g * 64 * FRAG);
-#pragma unroll 2
+#pragma unroll
             for (int S = 0; S < 8; ++S) {
                 const int Sn = ENC_SKIP(13) ? 0 : ((S + 1 < 8) ? S + 1 : S);
 #pragma unroll
