@@ -167,12 +167,21 @@ def device_ms(torch, fn, reps):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
+# FETCH_SIZE calibration (MI355X_MICROARCH.md 'HBM': gfx950 tallies a 128-B request at 64 B -- "double it" holds for wide coalesced
+# reads only, other access widths are to be calibrated on a known byte count).  Calibrated here: the DFSMN frequency-axis LSTM
+# reads its input as 64-B rows 5 KB apart, and its raw FETCH_SIZE equals the tensor's bytes (1.302 M KiB counted for 1.361 M KiB
+# read, tools/prof_lstmf_fetch.sh; what-if builds without loads / without stores separate the two directions) -- factor 1.  The
+# time-axis LSTMs read 4-B / 16-B pieces of 64-B rows the same way.
+FETCH_FACTOR_64B = ("lstm_f", "lstm_t")
+
+
 def profiled_kernel_traffic(tag, kernel_substr):
     """HBM bytes PER PASS of every kernel whose name contains `kernel_substr`, from the newest committed rocprofv3 PMC summary
     profiles/r*_{tag}/SUMMARY.txt (tools/profile_secondary.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes of the BASELINE-size
-    workload; lines `<kernel> calls_per_pass=<n> FETCH_SIZE sum_per_pass=<KiB>`).  FETCH is doubled per MI355X_MICROARCH.md
-    'HBM' (gfx950 tallies a wide coalesced read at half its bytes); both counters are KiB."""
+    workload; lines `<kernel> calls_per_pass=<n> FETCH_SIZE sum_per_pass=<KiB>`).  FETCH is doubled for kernels that read wide
+    coalesced runs and taken as counted for the 64-B-row readers (FETCH_FACTOR_64B); both counters are KiB."""
     best = None
+    factor = 1.0 if any(k in kernel_substr for k in FETCH_FACTOR_64B) else 2.0
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}", "SUMMARY.txt"))):
         fetch = write = 0.0
         calls = 0
@@ -190,7 +199,8 @@ def profiled_kernel_traffic(tag, kernel_substr):
             elif " WRITE_SIZE " in line:
                 write += val
         if fetch > 0 or write > 0:
-            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT), "calls_per_pass": calls}
+            best = {"bytes": (factor * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT), "calls_per_pass": calls,
+                    "fetch_factor": factor}
     return best
 
 
