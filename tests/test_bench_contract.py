@@ -43,6 +43,20 @@ def test_secondary_flop_formulas():
     assert 5.5e9 < d["total"] < 6.5e9 and d["lstm_f"] > d["lstm_t"] > d["istft"]
 
 
+def test_cpu_baseline_is_bounded_and_reports_the_protocol():
+    """The CPU leg must stay a bounded sample (it once ran for half an hour on a 256-thread host with torch's intra-op pool on
+    every thread): a 0.5 s budget finishes within two minutes here and carries the BASELINE.md section-3 protocol figures."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    t0 = time.perf_counter()
+    r = bench.cpu_baseline(0.5)
+    assert time.perf_counter() - t0 < 120
+    assert r["kind"] == "port" and r["value"] > 0 and 1 <= r["cores"] <= 16
+    p = r["baseline_md_protocol"]
+    assert p["threads"] == r["cores"] and p["model_calls_only"]["value"] > 0 and p["end_to_end"]["rtf"] > 0
+
+
 def test_self_launch_two_ranks_dry_run():
     """`bench.py --gpus 2` with no launcher starts two ranks itself (torch.distributed.run on 127.0.0.1) and rank 0 prints
     one line with n_gpus == 2; --dry-run swaps RCCL + kernels for gloo + sleep so this runs on a CPU-only box."""
