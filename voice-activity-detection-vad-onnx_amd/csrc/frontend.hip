@@ -103,6 +103,13 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     return 0;
 }
 
+// log of the mel energies: v_log_f32 (1 ulp in log2) times ln 2 instead of the library logf (~25 VALU instructions per value; VALU
+// time adds to f32-MFMA time on gfx950).  |difference| <= 4e-6 over the feature range, two orders inside the feature tolerance.
+#ifndef FE_FAST_LOG
+#define FE_FAST_LOG 1
+#endif
+__device__ __forceinline__ float FE_LOG(float x) { return FE_FAST_LOG ? __builtin_amdgcn_logf(x) * 0.6931471805599453f : logf(x); }
+
 struct FtOut { float *ptr; int tile0, c_total, c_off; };      // COMPLEX: FT destination (re -> c_off, im -> c_off+1)
 
 template <int MT, bool COMPLEX = false>
@@ -120,14 +127,16 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
     // column are issued first and UNCONDITIONALLY (indices clamped, values selected afterwards; which sources exist is
     // decided once, outside the loop): a load under any condition -- even a uniform one -- compiles to a branch plus a
     // full wait, which serialised ~100 memory round trips per tile (29 % of the kernel).
-    auto stage = [&](auto prep_c) {
-        constexpr int PREP = decltype(prep_c)::value;          // compile-time prep: the per-sample code is ~15 instructions
+    // NJ = rows per lane (64 NJ >= hop): three for the 160-sample hops of FSMN / MarbleNet / FireRed, five up to hop 320 (DFSMN) --
+    // with five everywhere, two fifths of the staging instructions of the 160-hop models produced rows that were never stored
+    auto stage = [&](auto prep_c, auto nj_c) {
+        constexpr int PREP = decltype(prep_c)::value, NJ = decltype(nj_c)::value;      // compile-time prep: ~15 instructions per sample
         constexpr bool HW = PREP != 4, HF = PREP >= 4;
         for (int g = wave; g < cols; g += THREADS / 64) {
             const int nb = (f0 + g) * d.hop + d.tap0 - d.center_pad;      // window index of row 0
-            float xs[5], xms[5], as_[5], ams[5];
+            float xs[NJ], xms[NJ], as_[NJ], ams[NJ];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {                                  // hop <= 320
+            for (int j = 0; j < NJ; ++j) {                                 // hop <= 64 NJ
                 const int n = nb + lane + 64 * j;
                 const int nc = n < 0 ? 0 : (n >= d.window_len ? d.window_len - 1 : n), nm = nc > 0 ? nc - 1 : 0;
                 xs[j] = HW ? (float)win[nc] : 0.f;
@@ -136,7 +145,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
                 ams[j] = HF ? fwin[nm] : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int r = lane + 64 * j, n = nb + r;
                 const bool in = n >= 0 && n < d.window_len;
                 const float x = xs[j], xm = n > 0 ? xms[j] : 0.f;
@@ -169,8 +178,8 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
     // BEFORE the two-tap pre-emphasis when the input rate is higher (prep 6), AFTER it when it is lower (prep 7).  The window in
     // HBM holds in_len samples at the input rate; output sample n reads source position max(0, rs_scale * (n + 0.5) - 0.5)
     // (float32 arithmetic, as torch's area_pixel_compute_source_index), neighbours clamped to the window like torch clamps them.
-    auto stage_rs = [&](auto prep_c) {
-        constexpr int PREP = decltype(prep_c)::value;
+    auto stage_rs = [&](auto prep_c, auto nj_c) {
+        constexpr int PREP = decltype(prep_c)::value, NJ = decltype(nj_c)::value;
         auto src = [&](int n, int &i0, int &i1, float &lam) {
             float s = __fsub_rn(__fmul_rn(d.rs_scale, __fadd_rn((float)n, 0.5f)), 0.5f);
             s = s < 0.f ? 0.f : s;
@@ -181,9 +190,9 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
         };
         for (int g = wave; g < cols; g += THREADS / 64) {
             const int nb = (f0 + g) * d.hop + d.tap0 - d.center_pad;
-            float xa[5], xb[5], xc[5], xd[5], la[5], lb[5];
+            float xa[NJ], xb[NJ], xc[NJ], xd[NJ], la[NJ], lb[NJ];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int n = nb + lane + 64 * j;
                 const int nc = n < 0 ? 0 : (n >= d.window_len ? d.window_len - 1 : n);
                 int i0, i1, j0, j1;
@@ -199,7 +208,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int r = lane + 64 * j, n = nb + r;
                 const bool in = n >= 0 && n < d.window_len;
                 const float l1 = la[j], l0 = __fsub_rn(1.f, l1);
@@ -218,16 +227,20 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
             }
         }
     };
-    switch (d.prep) {       // uniform
-        case 6: stage_rs(std::integral_constant<int, 6>{}); break;
-        case 7: stage_rs(std::integral_constant<int, 7>{}); break;
-        case 0: stage(std::integral_constant<int, 0>{}); break;
-        case 1: stage(std::integral_constant<int, 1>{}); break;
-        case 2: stage(std::integral_constant<int, 2>{}); break;
-        case 3: stage(std::integral_constant<int, 3>{}); break;
-        case 4: stage(std::integral_constant<int, 4>{}); break;
-        default: stage(std::integral_constant<int, 5>{}); break;
-    }
+    auto stage_any = [&](auto nj_c) {
+        switch (d.prep) {       // uniform
+            case 6: stage_rs(std::integral_constant<int, 6>{}, nj_c); break;
+            case 7: stage_rs(std::integral_constant<int, 7>{}, nj_c); break;
+            case 0: stage(std::integral_constant<int, 0>{}, nj_c); break;
+            case 1: stage(std::integral_constant<int, 1>{}, nj_c); break;
+            case 2: stage(std::integral_constant<int, 2>{}, nj_c); break;
+            case 3: stage(std::integral_constant<int, 3>{}, nj_c); break;
+            case 4: stage(std::integral_constant<int, 4>{}, nj_c); break;
+            default: stage(std::integral_constant<int, 5>{}, nj_c); break;
+        }
+    };
+    if (d.hop <= 192) stage_any(std::integral_constant<int, 3>{});
+    else stage_any(std::integral_constant<int, 5>{});
     // rows hop..round16 of a partial last pass never exist in X2; the table is zero there but the
     // activations must be finite: they alias rows of the NEXT column block, which are finite.
     FE_ACC(4);
@@ -333,7 +346,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float m = acc[0][mt][r];
-                    v[r] = logf(d.log_mode ? __fadd_rn(m, d.log_floor) : fmaxf(m, d.log_floor));
+                    v[r] = FE_LOG(d.log_mode ? __fadd_rn(m, d.log_floor) : fmaxf(m, d.log_floor));
                 }
                 *reinterpret_cast<f32x4 *>(out_win + (size_t)f * d.out_stride + d.out_off + mtile * 16 + 4 * q) = v;
             }
