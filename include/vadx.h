@@ -341,7 +341,9 @@ int vadx_dfsmn_frame_stats(const vadx_ft_view *a, const vadx_ft_view *b, int F, 
  * stats[tile][16][2] that frame_stats produces, without re-reading the tensors. */
 #define VADX_DFSMN_STAT_PARTS 2
 int vadx_dfsmn_stats_merge(const float *part_a, const float *part_b, int tiles, float *stats, void *stream);
-/* mode 0: out0 = act(conv(cat(a,b)) + bias)        (kf taps along F, weights [ceil16(co)][kf*cin])
+/* Shapes are instantiated at compile time: (co, cin, kf, mode) in {(20,20,1,1), (20,40,1,1), (20,20,3,2), (20,24,1,0), (20,40,1,0),
+ * (40,40,1,0), (2,60,1,0)} -- the ICCRN's seven; anything else returns VADX_EINVAL.
+ * mode 0: out0 = act(conv(cat(a,b)) + bias)        (kf taps along F, weights [ceil16(co)][kf*cin])
  * mode 1: CFB front: g = sigmoid(convG(LN(x)) + bias); xi = convI(x) + bias2; out0 = g*xi; out1 = xi - g*xi
  * mode 2: CFB back : out0 = conv31(LN(x)) + bias + add
  * part0 / part1 (optional, may be NULL): partial statistics of out0 / out1 (mode 1) for vadx_dfsmn_stats_merge. */
@@ -351,7 +353,9 @@ int vadx_dfsmn_pw_conv(int mode, const vadx_ft_view *a, const vadx_ft_view *b, c
                        int F, int co, int kf, int act, int tiles, float *part0, float *part1, void *stream);
 /* CepsUnit's length-160 real DFT along F (inverse=0: in C ch x 160 -> out 2C ch x 81, LayerNorm on the
  * input) and its pinv-based inverse fused with the complex product (inverse=1: in = spectrum, lo = LSTM
- * output, both 2C ch x 81 -> out C ch x 160).  tbl = [192][160] (cos|sin rows, padded) / [192][164] (rows 160.. zero).
+ * output, both 2C ch x 81 -> out C ch x 160).  tbl = float [160][160] row-major:
+ *   forward: rows = cos bins 0..80 | sin bins 1..79 (the sine rows of bins 0 and 80 vanish; those two outputs are written as 0);
+ *   inverse: rows = output bin f, columns k = re 0..80 | im 1..79 of the pseudo-inverse basis (its im(0), im(80) columns are 0).
  * part (optional, forward only): partial statistics of out. */
 int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_ft_view *lo, const vadx_ft_ln *ln,
                      const float *tbl, const vadx_ft_view *out, int C, int tiles, float *part, void *stream);
