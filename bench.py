@@ -271,47 +271,25 @@ def dry_run(args):
 
 
 class FeedPipeline:
-    """The headline batch timed from PINNED HOST int16 PCM: chunks of FEED_CHUNK_CLIPS clips cross PCIe on a copy stream into
-    one of two device buffers while the encoder of the previous chunk runs on the compute stream; the
-    recurrent kernel and the segmenter run once over the whole batch.  int16 is what a host has (wav files); the encoder
-    applies the reference's x 0.000030517578 itself, bit-identically."""
+    """The headline batch timed from PINNED HOST int16 PCM through the product's own feed (vadx.silero.HostFeed: chunks of
+    FEED_CHUNK_CLIPS clips cross PCIe on a copy stream into one of two device buffers while the encoder of the previous chunk
+    runs); the recurrent kernel and the segmenter run once over the whole batch."""
 
     def __init__(self, torch, eng, L, host_pcm, probs, segs, counts, lens, prm, cap):
         self.t, self.eng, self.L = torch, eng, L
         self.host = host_pcm
         B, N = host_pcm.shape
-        self.B, self.N, self.T = B, N, (N + WINDOW - 1) // WINDOW
-        self.chunk = min(FEED_CHUNK_CLIPS, B)
-        dev = eng.device
-        self.buf = [torch.empty((self.chunk, N), dtype=torch.int16, device=dev) for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(device=dev)
-        self.ready = [torch.cuda.Event() for _ in range(2)]
-        self.free = [torch.cuda.Event() for _ in range(2)]
-        self.in_use = [False, False]
-        self.ws = eng._workspace(B, self.T)
+        self.feed = eng.host_feed(B, N, FEED_CHUNK_CLIPS)
+        self.B, self.N, self.T = B, N, self.feed.T
         self.out = (probs, segs, counts, lens, prm, cap)
 
     def step(self):
         t, L, eng = self.t, self.L, self.eng
         probs, segs, counts, lens, prm, cap = self.out
-        comp = t.cuda.current_stream()
-        st = C.c_void_p(comp.cuda_stream)
+        st = C.c_void_p(t.cuda.current_stream().cuda_stream)
         from vadx import _lib
-        for i, b0 in enumerate(range(0, self.B, self.chunk)):
-            nb = min(self.chunk, self.B - b0)
-            k = i & 1
-            with t.cuda.stream(self.copy_stream):
-                if self.in_use[k]:                      # the encoder launch that last read this buffer (also across steps)
-                    self.copy_stream.wait_event(self.free[k])
-                self.buf[k][:nb].copy_(self.host[b0:b0 + nb], non_blocking=True)
-                self.ready[k].record(self.copy_stream)
-            comp.wait_event(self.ready[k])
-            _lib.check(L.vadx_silero_encode_pcm16_part(eng.packed.data_ptr(), self.buf[k].data_ptr(), eng.PCM16_SCALE, nb, self.N,
-                                                       self.N, b0, self.B, self.ws.data_ptr(), self.ws.numel(), st))
-            self.free[k].record(comp)
-            self.in_use[k] = True
-        _lib.check(L.vadx_silero_recur(eng.packed.data_ptr(), self.ws.data_ptr(), self.ws.numel(), self.B, self.T, None,
-                                       probs.data_ptr(), None, st))
+        self.feed.encode(self.host)
+        eng.recur(self.B, self.T, probs)
         _lib.check(L.vadx_silero_segments(probs.data_ptr(), self.B, self.T, lens.data_ptr(), C.byref(prm), segs.data_ptr(),
                                           counts.data_ptr(), cap, st))
 
@@ -429,7 +407,7 @@ def main(argv=None):
             # upload alone (same pinned buffer, same chunking, nothing overlapped): what PCIe gives this process
             t2 = time.perf_counter()
             for b0 in range(0, B, FEED_CHUNK_CLIPS):
-                pipe.buf[0][:min(FEED_CHUNK_CLIPS, B - b0)].copy_(host[b0:b0 + FEED_CHUNK_CLIPS], non_blocking=True)
+                pipe.feed.buf[0][:min(FEED_CHUNK_CLIPS, B - b0)].copy_(host[b0:b0 + FEED_CHUNK_CLIPS], non_blocking=True)
             torch.cuda.synchronize()
             up_s = time.perf_counter() - t2
             feed = {"value": world * B * T * args.steps / feed_el, "unit": "frames/s", "ms_per_step": feed_el / args.steps * 1e3,

@@ -312,6 +312,27 @@ def test_pcm16_part_encodes_fill_one_workspace(engine):
     assert bad(8, 16) != 0 and bad(64, 32) != 0 and bad(-16, 16) != 0
 
 
+@pytest.mark.parametrize("batch,chunk,pinned", [(80, 32, True), (53, 16, False), (7, 512, True)])
+def test_host_feed_is_bitwise_the_resident_path(engine, batch, chunk, pinned):
+    """SURVEY 8e in the product: int16 PCM in (pinned) host memory, uploaded chunk by chunk on a copy stream into two device
+    buffers while the previous chunk is encoded -- same scores as the resident batch, bit for bit, also when the feed object
+    (its device buffers and events) is reused for the next batch."""
+    n = 9000
+    a, b = weights.burst_clips(batch, n, seed=batch), weights.burst_clips(batch, n, seed=batch + 1)
+    feed = engine.host_feed(batch, n, chunk)
+    for pcm in (a, b, a):
+        host = torch.from_numpy(pcm)
+        if pinned:
+            host = host.pin_memory()
+        got = engine.clips_from_host(host, feed=feed)
+        assert torch.equal(got, engine.clips_pcm16(torch.from_numpy(pcm).cuda()))
+    assert torch.equal(engine.clips_from_host(a, chunk_clips=chunk), engine.clips_pcm16(torch.from_numpy(a).cuda()))     # numpy in, one-shot feed
+    with pytest.raises(ValueError):
+        engine.clips_from_host(torch.from_numpy(a[:, :100]), feed=feed)
+    with pytest.raises(ValueError):
+        engine.clips_from_host(torch.from_numpy(a).cuda())
+
+
 # ------------------------------------------------------------------ 8 kHz branch: segmenter + wrapper plumbing
 def test_segmenter_8k_matches_reference(golden, engine):
     """Device segmenter at sampling_rate = 8000 (256-sample windows) vs the reference's get_speech_timestamps on replayed
