@@ -867,44 +867,74 @@ struct LstmTArgs {
     View mul;                                                // MODE 0
     ViewW out;
     int F, T, nt, out_ch;
+    int nunits;                                              // lstm_t2_kernel: chunks * (F / 16) bin groups
 };
 
-// Direct variant (loads / stores issued per step): kept for the two-layer bottleneck LSTM, whose weight-resident
-// waves already fill the register file (1 wave/SIMD) -- a third, loader wave per workgroup halves the workgroups per
-// CU and measured slower there (16.9 vs 13.5 ms); see the chunked kernel below for the one-layer case.
-template <int IN, int HID, int LAYERS, int OUT_MT, int MODE>
-__global__ __launch_bounds__(64 * LAYERS) void lstm_t_direct_kernel(LstmTArgs p) {
-    constexpr int MT = HID / 4, KI0 = IN / 4;
-    __shared__ float hs[2][HID * 16];
-    const int lane = threadIdx.x & 63, layer = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
-    const int groups = p.F / 16, chunk = blockIdx.x / groups, f0 = (blockIdx.x - chunk * groups) * 16;
-    const int grow = (i & 3) * HID + (i >> 2);
-    constexpr int KI = (LAYERS == 2) ? (KI0 > MT ? KI0 : MT) : KI0;       // register array bound
-    const int ki = layer == 0 ? KI0 : MT, in_dim = layer == 0 ? IN : HID;
-    float wi[MT][KI], wh[MT][MT], bias[MT][4];
+// acc[mt] += W(mt, s) * b[s] over KS k-steps with the A fragments in LDS (w = this lane's base: fragment (mt, s) at w[(mt * KS + s) * 64]).
+// One k-step's MT fragments are in flight while the previous step's MFMAs issue; the fences keep the scheduler from hoisting
+// every read of the GEMM to its top (100 registers for a 10 x 10 layer: spills at three waves per SIMD).
+template <int MT, int KS>
+__device__ __forceinline__ void gemm_lds_frag(f32x4 (&acc)[MT], const float *w, const float (&b)[KS]) {
+    float wc[MT], wn[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int row = grow + 4 * mt;
+    for (int mt = 0; mt < MT; ++mt) wc[mt] = w[(mt * KS) * 64];
 #pragma unroll
-        for (int s = 0; s < KI; ++s) wi[mt][s] = s < ki ? p.w_ih[layer][(size_t)row * in_dim + 4 * s + q] : 0.f;
+    for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
 #pragma unroll
-        for (int s = 0; s < MT; ++s) wh[mt][s] = p.w_hh[layer][(size_t)row * HID + 4 * s + q];
+            for (int mt = 0; mt < MT; ++mt) wn[mt] = w[(mt * KS + s + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[mt][r] = p.b_ih[layer][r * HID + 4 * mt + q] + p.b_hh[layer][r * HID + 4 * mt + q];
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wc[mt], b[s], acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) wc[mt] = wn[mt];
+        __builtin_amdgcn_sched_barrier(0);
     }
-    float wl[OUT_MT][MT];
-#pragma unroll
-    for (int om = 0; om < OUT_MT; ++om)
-#pragma unroll
-        for (int s = 0; s < MT; ++s) wl[om][s] = p.wl[(size_t)(om * 16 + i) * HID + 4 * s + q];
+}
+
+template <int IN, int HID, int OUT_MT, int MODE, int NTILE>
+__global__ __launch_bounds__(128 * NTILE) void lstm_t2_kernel(LstmTArgs p) {
+    constexpr int MT = HID / 4, KI0 = IN / 4;
+    constexpr int OFF_WI0 = 0, OFF_WH0 = OFF_WI0 + MT * KI0 * 64, OFF_WI1 = OFF_WH0 + MT * MT * 64, OFF_WH1 = OFF_WI1 + MT * MT * 64,
+                  OFF_WL = OFF_WH1 + MT * MT * 64, OFF_BIAS = OFF_WL + OUT_MT * MT * 64, OFF_HS = OFF_BIAS + 2 * MT * 16,
+                  LDS_FLOATS = OFF_HS + NTILE * 2 * HID * 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = wave >> 1, layer = wave & 1, q = lane >> 4, i = lane & 15;
+    const int groups = p.F / 16;
+    // ---- one copy of the weights per workgroup: fragment (mt, s) of matrix W[4 HID][K], lane (q, i) <- W[grow(i) + 4 mt][4 s + q]
+    auto stage_w = [&](float *dst, const float *W, int K, int nmt, bool gate_rows) {
+        const int ks = K / 4;
+        for (int e = tid; e < nmt * ks * 64; e += blockDim.x) {
+            const int l = e & 63, s2 = (e >> 6) % ks, mt = (e >> 6) / ks, lq = l >> 4, li = l & 15;
+            const int row = gate_rows ? ((li & 3) * HID + (li >> 2) + 4 * mt) : (mt * 16 + li);
+            dst[e] = W[(size_t)row * K + 4 * s2 + lq];
+        }
+    };
+    stage_w(lds + OFF_WI0, p.w_ih[0], IN, MT, true);
+    stage_w(lds + OFF_WH0, p.w_hh[0], HID, MT, true);
+    stage_w(lds + OFF_WI1, p.w_ih[1], HID, MT, true);
+    stage_w(lds + OFF_WH1, p.w_hh[1], HID, MT, true);
+    stage_w(lds + OFF_WL, p.wl, HID, OUT_MT, false);
+    for (int e = tid; e < 2 * MT * 16; e += blockDim.x) {                 // bias rows: [layer][mt][q][gate r]
+        const int l2 = e / (MT * 16), r = e & 3, qq = (e >> 2) & 3, mt = (e >> 4) % MT;
+        lds[OFF_BIAS + e] = p.b_ih[l2][r * HID + 4 * mt + qq] + p.b_hh[l2][r * HID + 4 * mt + qq];
+    }
+    __syncthreads();
+    const int unit = blockIdx.x * NTILE + slot;                           // this wave pair's (chunk, bin group)
+    const int total = p.nunits;
+    const bool live = unit < total;
+    const int uc = live ? unit : total - 1, chunk = uc / groups, f0 = (uc - chunk * groups) * 16;
+    float *hs = lds + OFF_HS + slot * 2 * HID * 16;                       // [2][HID][16]: layer 0's h, double buffered
+    const float *wi = lds + (layer == 0 ? OFF_WI0 : OFF_WI1) + lane, *wh = lds + (layer == 0 ? OFF_WH0 : OFF_WH1) + lane;
+    const float *wl = lds + OFF_WL + lane;
+    const f32x4 *biasq = reinterpret_cast<const f32x4 *>(lds + OFF_BIAS + layer * MT * 16) + q;
     float h[MT], c[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { h[mt] = 0.f; c[mt] = 0.f; }
-    const bool last = layer == LAYERS - 1;
-    // Every per-step global value (layer 0: the KI0 inputs + the frame's LayerNorm statistics; last layer: the `mul`
-    // operands) is requested ONE STEP AHEAD, unconditionally (time index clamped), so the HBM round trip runs under the
-    // previous step's MFMAs instead of at the head of every step; the (channel, bin) LayerNorm weights are loaded once.
-    float lnw[KI0], lnb[KI0], xn[KI0], mean_n = 0.f, inv_n = 1.f, muln[OUT_MT][4];
+    // every per-step global value is requested ONE STEP AHEAD, unconditionally (time index clamped)
+    float lnw[KI0], lnb[KI0], xn[KI0], mean_n = 0.f, inv_n = 1.f, muln[OUT_MT][4], blr[OUT_MT][4];
 #pragma unroll
     for (int s = 0; s < KI0; ++s) {
         lnw[s] = p.ln.stats ? p.ln.w[(4 * s + q) * p.F + f0 + i] : 1.f;
@@ -914,20 +944,14 @@ __global__ __launch_bounds__(64 * LAYERS) void lstm_t_direct_kernel(LstmTArgs p)
 #pragma unroll
     for (int om = 0; om < OUT_MT; ++om)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) muln[om][r] = 1.f;
-    float blr[OUT_MT][4];
-#pragma unroll
-    for (int om = 0; om < OUT_MT; ++om)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) blr[om][r] = (om * 16 + 4 * q + r) < p.out_ch ? p.bl[om * 16 + 4 * q + r] : 0.f;
-    auto prefetch = [&](int t) {                 // values of time step t (clamped) for this wave's role
+        for (int r = 0; r < 4; ++r) { muln[om][r] = 1.f; blr[om][r] = (om * 16 + 4 * q + r) < p.out_ch ? p.bl[om * 16 + 4 * q + r] : 0.f; }
+    auto prefetch = [&](int t) {
         const int tc = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t), tile = chunk * p.nt + (tc >> 4), t16 = tc & 15;
         if (layer == 0) {
 #pragma unroll
             for (int s = 0; s < KI0; ++s) xn[s] = p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + 4 * s + q, p.F, f0 + i) + t16];
             if (p.ln.stats) { mean_n = p.ln.stats[((size_t)tile * 16 + t16) * 2]; inv_n = p.ln.stats[((size_t)tile * 16 + t16) * 2 + 1]; }
-        }
-        if (last && MODE == 0) {
+        } else if (MODE == 0) {
 #pragma unroll
             for (int om = 0; om < OUT_MT; ++om)
 #pragma unroll
@@ -938,61 +962,59 @@ __global__ __launch_bounds__(64 * LAYERS) void lstm_t_direct_kernel(LstmTArgs p)
         }
     };
     prefetch(0);
-    for (int it = 0; it < p.T + LAYERS - 1; ++it) {
+    for (int it = 0; it < p.T + 1; ++it) {
         const int t = it - layer;                            // this wave's time step
         if (t >= 0 && t < p.T) {
             const int tile = chunk * p.nt + (t >> 4), t16 = t & 15;
-            float x[KI], mulc[OUT_MT][4];
-#pragma unroll
-            for (int s = 0; s < KI; ++s) {
-                x[s] = 0.f;
-                if (s < ki) {
-                    if (layer == 0) { if (s < KI0) x[s] = p.ln.stats ? (xn[s] - mean_n) * inv_n * lnw[s] + lnb[s] : xn[s]; }
-                    else x[s] = hs[t & 1][(4 * s + q) * 16 + i];
-                }
-            }
-#pragma unroll
-            for (int om = 0; om < OUT_MT; ++om)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mulc[om][r] = muln[om][r];
-            prefetch(t + 1);
             f32x4 acc[MT];
+            float mulc[OUT_MT][4];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = biasq[mt * 4];
+            if (layer == 0) {
+                float x[KI0];
 #pragma unroll
-            for (int s = 0; s < KI; ++s)
+                for (int s = 0; s < KI0; ++s) x[s] = p.ln.stats ? (xn[s] - mean_n) * inv_n * lnw[s] + lnb[s] : xn[s];
+                prefetch(t + 1);
+                gemm_lds_frag<MT, KI0>(acc, wi, x);
+            } else {
+                float x[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wi[mt][s], x[s], acc[mt]);
+                for (int s = 0; s < MT; ++s) x[s] = hs[(t & 1) * HID * 16 + (4 * s + q) * 16 + i];
 #pragma unroll
-            for (int s = 0; s < MT; ++s)
+                for (int om = 0; om < OUT_MT; ++om)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wh[mt][s], h[s], acc[mt]);
+                    for (int r = 0; r < 4; ++r) mulc[om][r] = muln[om][r];
+                prefetch(t + 1);
+                gemm_lds_frag<MT, MT>(acc, wi, x);
+            }
+            gemm_lds_frag<MT, MT>(acc, wh, h);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const float ig = gate_sigmoid(acc[mt][0]), fg = gate_sigmoid(acc[mt][1]), gg = gate_tanh(acc[mt][2]), og = gate_sigmoid(acc[mt][3]);
                 c[mt] = fg * c[mt] + ig * gg;
                 h[mt] = og * gate_tanh(c[mt]);
-                if (!last) hs[t & 1][(4 * mt + q) * 16 + i] = h[mt];
+                if (layer == 0) hs[(t & 1) * HID * 16 + (4 * mt + q) * 16 + i] = h[mt];
             }
-            if (last) {
+            if (layer == 1) {
+                f32x4 yy[OUT_MT];
+#pragma unroll
+                for (int om = 0; om < OUT_MT; ++om) yy[om] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_lds_frag<OUT_MT, MT>(yy, wl, h);
 #pragma unroll
                 for (int om = 0; om < OUT_MT; ++om) {
-                    f32x4 y = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < MT; ++s) y = mfma16(wl[om][s], h[s], y);
+                    const f32x4 y = yy[om];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int o = om * 16 + 4 * q + r;
-                        if (o < p.out_ch) {
+                        if (o < p.out_ch && live) {
                             float v = y[r] + blr[om][r];
-                            if (MODE == 0) v *= mulc[om][r];
-                            p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + o, p.F, f0 + i) + t16] = v;
+                            p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + o, p.F, f0 + i) + t16] = MODE == 0 ? v * mulc[om][r] : v;
                         }
                     }
                 }
             }
         }
-        if (LAYERS > 1) __syncthreads();
+        __syncthreads();
     }
 }
 
@@ -1406,7 +1428,11 @@ extern "C" int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_f
     if (which == 0) {            // bottleneck ch_lstm: in 20, hidden 40, 2 layers, Linear 40->20, multiplied with `mul`
         VADX_REQUIRE(in->c == 20 && mul && mul->ptr, "vadx_dfsmn_lstm_t(0): in must have 20 channels and mul is required");
         p.out_ch = 20;
-        hipLaunchKernelGGL((lstm_t_direct_kernel<20, 40, 2, 2, 0>), dim3(grid), dim3(128), 0, st, p);
+        constexpr int NTILE = 4;
+        constexpr size_t lds2 = (size_t)(10 * 5 * 64 + 3 * 10 * 10 * 64 + 2 * 10 * 64 + 2 * 10 * 16 + NTILE * 2 * 40 * 16) * sizeof(float);
+        p.nunits = (int)grid;
+        VADX_DYN_LDS((lstm_t2_kernel<20, 40, 2, 0, NTILE>), lds2);
+        hipLaunchKernelGGL((lstm_t2_kernel<20, 40, 2, 0, NTILE>), dim3((grid + NTILE - 1) / NTILE), dim3(128 * NTILE), lds2, st, p);
     } else {                     // out_ch_lstm: in 40, hidden 20, 1 layer, Linear 20->40
         VADX_REQUIRE(in->c == 40, "vadx_dfsmn_lstm_t(1): in must have 40 channels");
         p.out_ch = 40;
