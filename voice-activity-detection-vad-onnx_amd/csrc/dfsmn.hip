@@ -854,8 +854,8 @@ __global__ void alpha_scale_kernel(const float *__restrict__ in, float *__restri
 
 // ---------------------------------------------------------------------------------------------
 // lstm_t: LSTM ALONG TIME (CH_LSTM_T :252-267), one sequence per bin, batch = 16 bins of one chunk.
-//   LAYERS = 2 (hidden 40, the bottleneck `ch_lstm`): wave 0 runs layer 0, wave 1 runs layer 1 one step
-//   behind, h0 handed over through double-buffered LDS (one barrier per step).
+//   Two layers (hidden 40, the bottleneck `ch_lstm`, lstm_t2_kernel): of a wave pair, one runs layer 0 and the other layer 1
+//   one step behind, h0 handed over through double-buffered LDS (one barrier per step).  One layer (out_ch_lstm): lstm_t_kernel.
 //   The output Linear is applied per step from the register-resident h; MODE 0 multiplies it with a
 //   second tensor (d5 input = e5 * lstm_out, NET.forward :236), MODE 1 stores it (out_ch_lstm).
 // ---------------------------------------------------------------------------------------------
@@ -893,6 +893,17 @@ __device__ __forceinline__ void gemm_lds_frag(f32x4 (&acc)[MT], const float *w, 
     }
 }
 
+// Two-layer bottleneck LSTM (loads / stores issued per step, requested one step ahead) with every weight in LDS.  Its predecessor
+// kept a layer's weights in its wave's registers (452 VGPRs + AGPRs): one wave per SIMD, and a lone wave pays 15.1 ns per MFMA,
+// 2.6 ns per VALU instruction and 7 ns per transcendental where co-resident waves pay 13.7 / 0.93 / 6 (tools/mfma_valu_overlap.sh)
+// -- it sat at 0.38 of the pipe, 32.6 ms per 3060 windows; this form takes 26.4 ms (outputs equal to 7e-7).  The weights are the
+// same for every bin group, so ONE copy per CU lives in LDS as per-lane A fragments, [row tile][k-step][lane] (W_ih0 12.8 KB,
+// W_hh0 / W_ih1 / W_hh1 25.6 KB each, the output Linear 5 KB: 95 KB; a lane's fragment is one conflict-free ds_read, and LDS
+// reads cost next to nothing beside MFMAs), and a workgroup runs NTILE bin groups at once: 2 NTILE waves of 228 registers --
+// NTILE = 4: two per SIMD (six waves of <= 168 registers spill) -- sharing the matrix pipe, one barrier per step.
+// (The same scheme for the ONE-layer out_ch_lstm -- 40 input channels gathered 4 B at a time per step, 125 registers, four waves
+// per SIMD -- ran three times slower than lstm_t_kernel's loader wave, 37 vs 12.4 ms per 3060 windows: that LSTM is bound by its
+// memory path, not by the pipe.)
 template <int IN, int HID, int OUT_MT, int MODE, int NTILE>
 __global__ __launch_bounds__(128 * NTILE) void lstm_t2_kernel(LstmTArgs p) {
     constexpr int MT = HID / 4, KI0 = IN / 4;
