@@ -102,6 +102,12 @@ inline void frag_major_inplace(float *w, int rows, int ldw) {
     delete[] tmp;
 }
 
+// VADX_GEMM_EXP: development-only what-if switches of gemm_rt (results are wrong when set): 1 activations not read from LDS,
+// 2 every weight fragment from the same address (L1 instead of L2)
+#ifndef VADX_GEMM_EXP
+#define VADX_GEMM_EXP 0
+#endif
+
 template <int NT, int MT, int KB, bool SWAP>
 __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NT][MT], const float *act, int lda,
                                           const int (&moff)[MT], const float *const (&wrow)[NT],
@@ -155,7 +161,7 @@ __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, 
     f32x4 ad0 = {0.f, 0.f, 0.f, 0.f}, ml0 = {1.f, 1.f, 1.f, 1.f}, ad1 = ad0, ml1 = ml0;      // AFFINE terms ride the same pipeline
     auto fetch = [&](int S, f32x4 (&w)[NT], float (&a)[4][MT], f32x4 &ad, f32x4 &ml) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) w[nt] = ldg4(wrow[nt] + FRAG * S);
+        for (int nt = 0; nt < NT; ++nt) w[nt] = ldg4(wrow[nt] + FRAG * ((VADX_GEMM_EXP & 2) ? 0 : S));
         if (AFFINE) {
             ad = ldg4(add + 16 * S + 4 * q);
             ml = ldg4(mul + 16 * S + 4 * q);
@@ -164,7 +170,7 @@ __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, 
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[j][mt] = aps[j * lda + moff[mt]];
+            for (int mt = 0; mt < MT; ++mt) a[j][mt] = (VADX_GEMM_EXP & 1) ? (float)(S + j + mt) : aps[j * lda + moff[mt]];
     };
     auto compute = [&](const f32x4 (&w)[NT], const float (&a)[4][MT], const f32x4 &a4, const f32x4 &m4) {
 #pragma unroll
