@@ -1,0 +1,7 @@
+"""MarbleNet config-4 pass (8192 clips), per-entry split; VADX_LIBRARY selects the build (A/B)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vadx  # noqa: F401
+import bench_models as bm
+r = bm.marblenet_c4(torch, torch.device("cuda", 0), 3, 0)
+print("MB", os.path.basename(os.environ.get("VADX_LIBRARY", "libvadx.so")), "ms %.2f" % r["ms"], {k: round(v, 2) for k, v in r["kernel_ms"].items()})

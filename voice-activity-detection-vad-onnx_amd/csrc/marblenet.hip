@@ -174,10 +174,11 @@ __global__ __launch_bounds__(THREADS, 2) void sepconv_block_kernel(
 // Tile = 1 clip x 32 output frames; sub-block 0 is evaluated on the 32 + (K - 1) frames sub-block 1's depthwise filter needs
 // (48 columns = 3 m-tiles: <= 1.5 x recompute of a layer that is a quarter of the block's work), masked to zero outside
 // [0, T) -- the zero padding sub-block 1 sees in the reference.
-//   IN  [cin][48 + K - 1]   block input, frames t0 - (K-1) .. (also the residual branch's operand, column offset K - 1)
-//   D0  [cin][48]           depthwise 0            -> later D1 [c1][32]
-//   H1  [c1][48]            relu(pw0 D0 + b0)      -> later OUT [c2][32]
-//   ROUT[c2][32]            residual 1x1
+//   IN  [cin][48 + K - 1]   block input, frames t0 - (K-1) ..; the residual 1x1 (operand: columns K - 1 ..) runs FIRST, into
+//   ROUT[c2][32]; then depthwise 0 overwrites IN in place (every thread reads its windows, barrier, writes) -> D0 [cin][48];
+//   H1  [c1][48]            relu(pw0 D0 + b0);  depthwise 1 -> D1 [c1][32] in IN's place;  pw1 -> OUT [c2][32] in H1's place.
+// Three live regions instead of four: 53 KB for the 128-channel block -- three workgroups per CU like the 64-channel blocks
+// (it ran two at 80 KB; a tile is a short serial chain, so this kernel lives on workgroups per CU).
 // ---------------------------------------------------------------------------------------------
 struct Blk2 {
     int cin, cinp, c1, c2, in_ld, T;      // c1 = c2 = 64 here; cinp = cin padded to 16
@@ -185,15 +186,15 @@ struct Blk2 {
 constexpr int W1 = 48, H_LD = 52;
 
 template <int K>
-__global__ __launch_bounds__(THREADS, (K == 13 ? 4 : 6)) void jasper_block2_kernel(      // K 13: cin 128, 80 KB of LDS -> two workgroups per CU; else three
+__global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     Blk2 c, const float *__restrict__ dw0, const float *__restrict__ pw0, const float *__restrict__ b0,
     const float *__restrict__ dw1, const float *__restrict__ pw1, const float *__restrict__ b1,
     const float *__restrict__ rw, const float *__restrict__ rb, const float *__restrict__ x, float *__restrict__ y, int tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PAD = (K - 1) / 2, WIN0 = W1 + K - 1;
     const int IN_LD = c.in_ld;
-    float *IN = lds, *D0 = IN + c.cinp * IN_LD, *H1 = D0 + c.cinp * H_LD, *ROUT = H1 + c.c1 * H_LD;
-    float *D1 = D0, *OUT = H1;
+    float *IN = lds, *H1 = IN + c.cinp * IN_LD, *ROUT = H1 + c.c1 * H_LD;
+    float *D0 = IN, *D1 = IN, *OUT = H1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TILE;
     const float *xb = x + (long long)b * c.cin * c.T;
@@ -214,26 +215,40 @@ __global__ __launch_bounds__(THREADS, (K == 13 ? 4 : 6)) void jasper_block2_kern
         }
     }
     __syncthreads();
-    // ---- depthwise 0: register-window FIR, item = (channel, 8 outputs)
-    for (int it = tid; it < c.cinp * (W1 / 8); it += THREADS) {
-        const int ch = it / (W1 / 8), m0 = 8 * (it - ch * (W1 / 8)), cc = ch < c.cin ? ch : c.cin - 1;
-        float wk[K], win[7 + K];
+    {   // residual 1x1 of the block input (frames t0 .. t0 + 31 sit at column 2 PAD), before the input is overwritten
+        LayerArgs r{rw, c.cinp, c.c2 / 16, 1, c.cinp / 16, 0, 0, rb, 0, IN, IN_LD, 2 * PAD, ROUT, A_LD, 0, nullptr, nullptr};
+        layer<2, false>(r);
+    }
+    __syncthreads();                // every residual operand is read: depthwise 0 may overwrite IN
+    // ---- depthwise 0 IN PLACE: register-window FIR, item = (channel, 8 outputs).  The six items of a channel are six neighbouring
+    // lanes of ONE wave: a wave's window reads all precede its writes in program order (the FMAs in between depend on them), and
+    // no two waves share a channel, so the overwrite needs no further barrier.
+    for (int ch0 = 0; ch0 < c.cinp; ch0 += 10 * (THREADS / 64)) {
+        const int ch = ch0 + wave * 10 + lane / 6, m0 = 8 * (lane % 6);
+        if (lane < 60 && ch < c.cinp) {
+            const int cc = ch < c.cin ? ch : c.cin - 1;
+            float wk[K], win[7 + K];
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) wk[kk] = dw0[cc * K + kk];
-        const float *row = IN + ch * IN_LD + m0;
+            for (int kk = 0; kk < K; ++kk) wk[kk] = dw0[cc * K + kk];
+            float *row = IN + ch * IN_LD + m0;
 #pragma unroll
-        for (int u = 0; u < 7 + K; ++u) win[u] = row[u];
+            for (int u = 0; u < 7 + K; ++u) win[u] = row[u];
+            float o8[8];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            float s2 = 0.f;
+            for (int o = 0; o < 8; ++o) {
+                float s2 = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk) s2 = fmaf(wk[kk], win[o + kk], s2);
-            D0[ch * H_LD + m0 + o] = ch < c.cin ? s2 : 0.f;
+                for (int kk = 0; kk < K; ++kk) s2 = fmaf(wk[kk], win[o + kk], s2);
+                o8[o] = ch < c.cin ? s2 : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();                // keep every lane's reads above every lane's writes in the schedule
+#pragma unroll
+            for (int o = 0; o < 8; ++o) row[o] = o8[o];
         }
     }
     __syncthreads();
     {   // pointwise 0 + folded BN + ReLU on 48 columns
-        LayerArgs a{pw0, c.cinp, c.c1 / 16, 1, c.cinp / 16, 0, 0, b0, 1, D0, H_LD, 0, H1, H_LD, 0, nullptr, nullptr};
+        LayerArgs a{pw0, c.cinp, c.c1 / 16, 1, c.cinp / 16, 0, 0, b0, 1, D0, IN_LD, 0, H1, H_LD, 0, nullptr, nullptr};
         layer<3, false>(a);
     }
     __syncthreads();
@@ -258,14 +273,12 @@ __global__ __launch_bounds__(THREADS, (K == 13 ? 4 : 6)) void jasper_block2_kern
             o8[o] = s2;
         }
 #pragma unroll
-        for (int o = 0; o < 8; ++o) D1[ch * A_LD + m0 + o] = o8[o];     // D1 aliases D0 (dead since the barrier above)
+        for (int o = 0; o < 8; ++o) D1[ch * A_LD + m0 + o] = o8[o];     // D1 sits in IN's region (D0 is dead since the barrier above)
     }
     __syncthreads();                // every H1 read is done: OUT may overwrite it
     {
         LayerArgs a{pw1, c.c1, c.c2 / 16, 1, c.c1 / 16, 0, 0, b1, 0, D1, A_LD, 0, OUT, A_LD, 0, nullptr, nullptr};
         layer<2, false>(a);
-        LayerArgs r{rw, c.cinp, c.c2 / 16, 1, c.cinp / 16, 0, 0, rb, 0, IN, IN_LD, 2 * PAD, ROUT, A_LD, 0, nullptr, nullptr};
-        layer<2, false>(r);
     }
     __syncthreads();
     float *yb = y + (long long)b * c.c2 * c.T;
@@ -441,10 +454,11 @@ extern "C" int vadx_marblenet_block2(int cin, int kernel, const float *dw0, cons
     Blk2 c;
     c.cin = cin; c.cinp = (cin + 15) & ~15; c.c1 = 64; c.c2 = 64; c.T = frames;
     const int width = W1 + kernel - 1;
-    c.in_ld = ((width + 7) & ~7) + 4;
+    c.in_ld = width + ((4 - width % 8) + 8) % 8;             // smallest row stride >= width with stride % 8 == 4
     const int tiles = (frames + TILE - 1) / TILE;
     VADX_REQUIRE((long long)batch * tiles < (1LL << 31), "vadx_marblenet_block2: too many tiles");
-    const size_t lds = ((size_t)c.cinp * c.in_ld + (size_t)c.cinp * H_LD + (size_t)c.c1 * H_LD + (size_t)c.c2 * A_LD) * sizeof(float);
+    const size_t lds = ((size_t)c.cinp * c.in_ld + (size_t)c.c1 * H_LD + (size_t)c.c2 * A_LD) * sizeof(float);
+    VADX_REQUIRE(c.cinp * c.in_ld >= c.c1 * A_LD, "vadx_marblenet_block2: the depthwise-1 output does not fit the input region");
 #define BLK2_LAUNCH(KK)                                                                                                        \
     do {                                                                                                                       \
         VADX_DYN_LDS(jasper_block2_kernel<KK>, 128 * 1024);                                                                    \
