@@ -160,6 +160,13 @@ def _load():
         if not os.path.exists(LIB_PATH):
             raise VadxError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # torch first: it ships its own libamdhip64.  If libvadx.so were loaded before torch, it would bind the system HIP runtime
+        # and the process would hold two runtimes -- the second one then finds "no ROCm-capable device" (seen when build() and
+        # smoke() ran in one process).  With torch's runtime already mapped, the loader resolves libvadx.so against that same copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the .so does not export it
