@@ -16,7 +16,7 @@ import vadx, bench_models as bm
 dev = torch.device("cuda", 0)
 r = bm.fsmn_c3(torch, dev, 2, 0, clips=1024) if hasattr(bm.fsmn_c3, "__call__") else None
 f = bm.firered_c5(torch, dev, 2, 0, clips=512)
-print("EXP", os.path.basename(os.environ["VADX_LIBRARY"]), "fsmn net %%.2f ms (1024 clips)  firered net %%.2f ms (512 clips)" %% (r["kernel_ms"]["vadx_fsmn_clips"], f["kernel_ms"]["vadx_firered_run"]))
+print("EXP", os.path.basename(os.environ["VADX_LIBRARY"]), "fsmn net %%.2f ms, front-end %%.2f ms (1024 clips)  firered net %%.2f ms, front-end %%.2f ms (512 clips)" %% (r["kernel_ms"]["vadx_fsmn_clips"], r["kernel_ms"]["vadx_frontend_logmel"], f["kernel_ms"]["vadx_firered_run"], f["kernel_ms"]["vadx_frontend_logmel"]))
 """
 if __name__ == "__main__":
     ids = [int(a) for a in sys.argv[2:]]

@@ -303,13 +303,13 @@ __device__ __forceinline__ void gemm_rt_simple(f32x4 (&acc)[NT][MT], const float
     for (int S = 0; S < kb; ++S) {
         const int Sn = (S + 1 < kb) ? S + 1 : S;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = ldg4(wrow[nt] + FRAG * Sn);
+        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = ldg4(wrow[nt] + FRAG * ((VADX_GEMM_EXP & 2) ? 0 : Sn));
         const float *aps = ap + 16 * S * lda;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float av[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = aps[j * lda + moff[mt]];
+            for (int mt = 0; mt < MT; ++mt) av[mt] = (VADX_GEMM_EXP & 1) ? (float)(S + j + mt) : aps[j * lda + moff[mt]];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float wj = wcur[nt][j];
