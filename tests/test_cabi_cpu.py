@@ -81,6 +81,29 @@ def test_pack_host_layout(lib):
     assert b"NULL" in lib.vadx_last_error()
 
 
+def test_dfsmn_entry_points_validate_before_touching_the_device():
+    """Argument checks of the ICCRN building blocks run on the host, before any HIP call: unsupported shapes / missing operands
+    come back as VADX_EINVAL with a message (the pw_conv kernel is instantiated for the ICCRN's seven (co, cin, kf, mode) only)."""
+    import ctypes as C
+    lib = _lib.lib()
+    buf = (C.c_float * 64)()
+    ptr = C.cast(buf, C.c_void_p).value
+    v = lambda ct, c: _lib.FtView(ptr, ct, 0, c)                                    # noqa: E731
+    ln = _lib.FtLn(ptr, ptr, ptr)
+    pw = lambda mode, a, lnp, co, kf: lib.vadx_dfsmn_pw_conv(mode, C.byref(a), None, lnp, ptr, ptr, None, None, None, C.byref(v(20, 20)),   # noqa: E731
+                                                             None, 160, co, kf, 0, 4, None, None, None)
+    assert pw(0, v(20, 20), None, 7, 1) == -1 and b"unsupported shape" in lib.vadx_last_error()
+    assert pw(0, v(20, 20), C.byref(ln), 20, 1) == -1 and b"LayerNorm" in lib.vadx_last_error()          # mode 0 takes none
+    assert pw(2, v(20, 20), None, 20, 3) == -1 and b"LayerNorm" in lib.vadx_last_error()                   # mode 2 needs one
+    assert pw(0, v(22, 22), None, 20, 1) == -1                                                              # kf * cin % 4 (22 channels)
+    assert lib.vadx_dfsmn_dft_f(1, C.byref(v(40, 40)), None, None, ptr, C.byref(v(20, 20)), 20, 4, None, None) == -1
+    assert b"missing lo" in lib.vadx_last_error()
+    two = (C.c_void_p * 2)(ptr, ptr)
+    assert lib.vadx_dfsmn_lstm_t(0, C.byref(v(20, 20)), C.byref(ln), C.byref(two), C.byref(two), C.byref(two), C.byref(two), ptr, ptr,
+                                 C.byref(v(20, 20)), C.byref(v(20, 20)), 150, 101, 1, None) == -1
+    assert b"multiple of 16" in lib.vadx_last_error()
+
+
 def test_weight_validation():
     w = weights.silero_synthetic(1)
     assert weights.silero_check(w)
