@@ -363,7 +363,7 @@ def marblenet_c4(torch, device, reps, cpu, clips=8192, log=lambda m: None, tag="
            "clips": clips, "samples_per_clip": n, "ms": ms, "frames_per_s": clips * n / 512 / (ms * 1e-3),
            "kernel_ms": split, "kernel_calls": calls,
            "roofline": _roof("frontend_logmel_kernel", clips * T * flop_frontend_frame(257, 400), fe_ms, tag, "frontend_logmel_kernel"),
-           "roofline_net": _roof("marblenet encoder+decoder launches", clips * Tout * flop_marblenet_out_frame(), net_ms,
+           "roofline_net": _roof("marblenet encoder+decoder launches", clips * Tout * flop_marblenet_out_frame(), net_ms, tag, "vadx::marblenet::",
                                  note="sum of the encoder / classifier entries in kernel_ms (fused block pairs, single blocks, tail)"),
            "hbm": _hbm(clips * (n * 2 + 2 * Tout * 4), ms), "cpu_baseline": None}
     del audio
