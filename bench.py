@@ -92,6 +92,27 @@ def profiled_traffic(kernel="silero_encode_kernel"):
     return best
 
 
+# Per-SIMD instruction costs beside f32 MFMAs, measured with two or more waves per SIMD (tools/mfma_valu_overlap.sh):
+# on gfx950 the f32-input MFMA shares the vector datapath, so VALU time ADDS to MFMA time instead of hiding under it.
+NS_PER_MFMA, NS_PER_VALU = 13.7, 0.93
+
+
+def instruction_mix(kernel="silero_encode_kernel"):
+    """MFMA / VALU instruction counts per launch of `kernel` (SQ_INSTS_* of the newest committed PMC summary) and the fraction of
+    the f32-MFMA peak that mix could reach if nothing but issue time were spent: MFMA / (MFMA + VALU * 0.93 / 13.7)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "SUMMARY.txt"))):
+        mfma, g1 = _kernel_counter(path, kernel, "SQ_INSTS_MFMA")
+        valu, g2 = _kernel_counter(path, kernel, "SQ_INSTS_VALU")
+        if mfma and valu and g1 == g2:
+            best = {"mfma_insts": mfma, "valu_insts": valu, "valu_per_mfma": valu / mfma,
+                    "ceiling_frac": mfma * NS_PER_MFMA / (mfma * NS_PER_MFMA + valu * NS_PER_VALU),
+                    "model": f"{NS_PER_MFMA} ns per v_mfma_f32_16x16x4_f32 + {NS_PER_VALU} ns per VALU instruction per SIMD, additive "
+                             "(tools/mfma_valu_overlap.sh)", "source": os.path.relpath(path, ROOT)}
+    return best
+
+
 def synth_batch(torch, device, batch, samples, seed, pcm16=False):
     """int16-quantised burst clips generated on the GPU (every clip unique): 0.5-2 s segments
     alternating N(0,3000) / N(0,30), then x 1/32768 as the reference feeds Silero
@@ -447,6 +468,7 @@ def main(argv=None):
         full = (B, T) == (CLIPS_PER_GPU, STEPS_PER_CLIP)
         tr_enc = profiled_traffic("silero_encode_kernel") if full else None
         tr_rec = profiled_traffic("silero_lstm_kernel") if full else None
+        mix_enc = instruction_mix("silero_encode_kernel") if full else None
         algo_launch = B * T * ALGO_BYTES_PER_WINDOW
         step_traffic = (tr_enc["bytes"] + tr_rec["bytes"]) if (tr_enc and tr_rec) else None
         step_s = elapsed / args.steps
@@ -474,12 +496,15 @@ def main(argv=None):
                          "traffic_ratio": (tr_enc["bytes"] / algo_launch) if tr_enc else None,
                          "flop_per_frame": FLOP_ENCODE_ISSUED, "frames_per_launch": B * T,
                          "dense_equivalent": {"flop_per_frame": FLOP_ENCODE,
-                                              "achieved": achieved * FLOP_ENCODE / FLOP_ENCODE_ISSUED}},
+                                              "achieved": achieved * FLOP_ENCODE / FLOP_ENCODE_ISSUED},
+                         # what this kernel's own instruction mix allows of the peak (VALU time adds to f32-MFMA time on gfx950)
+                         "instruction_mix": mix_enc},
             # the recurrent kernel is matrix-pipe work too (W_hh x h, 16 clips = one MFMA tile wide): its own fraction
             "roofline_recurrent": {"bound": "mfma", "kernel": "silero_lstm_kernel", "flop_per_frame": FLOP_RECUR,
                                    "achieved": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                                    "unit": "TFLOP/s", "frac": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                   "traffic": tr_rec["bytes"] if tr_rec else None},
+                                   "traffic": tr_rec["bytes"] if tr_rec else None,
+                                   "instruction_mix": instruction_mix("silero_lstm_kernel") if full else None},
             # the north star's HBM view of the whole step: SURVEY 8(d) algorithmic bytes / step time against 8 TB/s, and what
             # the step really moves (encoder + LSTM launches, PMC) over the algorithmic bytes
             "hbm": {"algorithmic_bytes_per_frame": ALGO_BYTES_PER_WINDOW, "algorithmic_bytes_per_step": algo_launch,
