@@ -103,7 +103,7 @@ inline void frag_major_inplace(float *w, int rows, int ldw) {
 }
 
 // VADX_GEMM_EXP: development-only what-if switches of gemm_rt (results are wrong when set): 1 activations not read from LDS,
-// 2 every weight fragment from the same address (L1 instead of L2)
+// 2 every weight fragment from the same address (L1 instead of L2), 4 gemm_rt issues one VALU FMA in place of each MFMA
 #ifndef VADX_GEMM_EXP
 #define VADX_GEMM_EXP 0
 #endif
@@ -185,8 +185,10 @@ __device__ __forceinline__ void gemm_rt(f32x4 (&acc)[NT][MT], const float *act, 
             for (int nt = 0; nt < NT; ++nt) {
                 const float wj = w[nt][j];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (VADX_GEMM_EXP & 4) { acc[nt][mt][0] += wj * av[mt]; continue; }      // what-if: no MFMA (one VALU FMA keeps the operands live)
                     acc[nt][mt] = SWAP ? mfma16(wj, av[mt], acc[nt][mt]) : mfma16(av[mt], wj, acc[nt][mt]);
+                }
             }
         }
     };
