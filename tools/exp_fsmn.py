@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "voice-activity-detection-vad-onnx_amd")
 LIB = os.path.join(PKG, "_exp", "libvadx_fs1.so")
 SRC = ["capi.hip", "silero.hip", "frontend.hip", "fsmn.hip", "firered.hip", "marblenet.hip", "dfsmn.hip", "ingest.hip"]
-NAMES = ["stage", "in_linear1", "in_linear2", "cache load (x4)", "linear (x4)", "FIR + cache store (x4)", "affine (x4)", "out1 + out2", "softmax"]
+NAMES = ["stage", "in_linear1", "in_linear2", "cache load (x4)", "linear (x4)", "FIR + cache store (x4)", "affine (x4)", "out1 + out2", "softmax",
+         "barrier waits of wave 0 (after every section)"]
 
 if sys.argv[1] == "build":
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -40,7 +41,7 @@ else:
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); eng.flags(clips, W); b.record(); torch.cuda.synchronize()
     h.vadx_fsmn_debug_cycles(buf, 0)
-    tot = sum(buf[:9])
+    tot = sum(buf[:10])
     print("1024 clips x 10 s: %.1f ms" % a.elapsed_time(b))
-    for n, v in zip(NAMES, buf[:9]):
+    for n, v in zip(NAMES, buf[:10]):
         print("%-26s %6.2f %%" % (n, 100.0 * v / tot))

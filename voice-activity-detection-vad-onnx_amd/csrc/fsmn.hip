@@ -110,22 +110,25 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
             }
         }
     }
-    __syncthreads();
     FS_ACC(0);
+    __syncthreads();
+    FS_ACC(9);
 
     LayerArgs a;
     // in_linear1: K = 5 passes x 80 (LFR concat: frame offset j -> column offset j), CMVN on the operand
     a = LayerArgs{Pk + d.off_in1, 400, d.Ap / 16, LFR_M, NMEL / 16, NMEL, 1, Pk + d.off_b1, 0,
                   bufB, A_LD, 0, bufP, A_LD, 0, Pk + d.off_mean, Pk + d.off_var, bufA};      // bufA is idle: K-split scratch
     layer<MTT, true>(a);
-    __syncthreads();
     FS_ACC(1);
+    __syncthreads();
+    FS_ACC(9);
     // in_linear2 + ReLU
     a = LayerArgs{Pk + d.off_in2, d.Ap, d.Lp / 16, 1, d.Ap / 16, 0, 0, Pk + d.off_b2, 1,
                   bufP, A_LD, 0, bufA, A_LD, 0, nullptr, nullptr};
     layer<MTT, false>(a);
-    __syncthreads();
     FS_ACC(2);
+    __syncthreads();
+    FS_ACC(9);
 
     for (int l = 0; l < NLAYER; ++l) {
         // history columns 1..19 of bufP <- cache (previous tile / previous chunk)
@@ -144,8 +147,9 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
         a = LayerArgs{Pk + d.off_lin[l], d.Lp, PROJ / 16, 1, d.Lp / 16, 0, 0, nullptr, 0,
                       bufA, A_LD, 0, bufP, P_LD, P_CUR, nullptr, nullptr};
         layer<MTT, false>(a);
-        __syncthreads();
         FS_ACC(4);
+        __syncthreads();
+        FS_ACC(9);
         {   // FIR + skip: thread = (channel, quarter of the tile's frames)
             const int ch = tid >> 2, fq = tid & 3;
             constexpr int FPT = NF / 4;
@@ -170,13 +174,15 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
                 stg1(cout[l] + e, bufP[c2 * P_LD + 1 + nvalid + h]);
             }
         }
-        __syncthreads();
         FS_ACC(5);
+        __syncthreads();
+        FS_ACC(9);
         a = LayerArgs{Pk + d.off_aff[l], PROJ, d.Lp / 16, 1, PROJ / 16, 0, 0, Pk + d.off_baff[l], 1,
                       bufB, A_LD, 0, bufA, A_LD, 0, nullptr, nullptr};
         layer<MTT, false>(a);
-        __syncthreads();
         FS_ACC(6);
+        __syncthreads();
+        FS_ACC(9);
     }
     a = LayerArgs{Pk + d.off_out1, d.Lp, d.A2p / 16, 1, d.Lp / 16, 0, 0, Pk + d.off_bo1, 0,
                   bufA, A_LD, 0, bufB, A_LD, 0, nullptr, nullptr, bufP};                      // bufP is idle: K-split scratch
@@ -185,9 +191,10 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
     a = LayerArgs{Pk + d.off_out2, d.A2p, d.Op / 16, 1, d.A2p / 16, 0, 0, Pk + d.off_bo2, 0,
                   bufB, A_LD, 0, bufA, A_LD, 0, nullptr, nullptr};
     layer<MTT, false>(a);
+    FS_ACC(7);
     __syncthreads();
 
-    FS_ACC(7);
+    FS_ACC(9);
     // ---- softmax over the O logits of each frame, keep class 0: thread = (part 0..7, frame 0..63)
     {
         const int m = tid & 63, part = tid >> 6;
