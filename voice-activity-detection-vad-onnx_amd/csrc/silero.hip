@@ -420,6 +420,41 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
     if (fold) {
         // wave = (bin tile tl: bins 16 tl .. 16 tl + 15, frame pair fp); it produces bins k and 128 - k
         const int tl = wave & 3, fp = wave >> 2;
+        // bin 64 (its own mirror) on the VALU, spread over all eight waves: wave = (frame f = wave & 3, half h of n = 1..128),
+        // lane = (clip i, quarter q of the half): 16 taps each, summed over q by shuffles and over h through the scratch
+        float b64re = 0.f, b64im = 0.f;
+        if (!ENC_SKIP(7)) {
+            const int f = wave & 3, h = wave >> 2, n0 = h * 64 + q * 16;
+            // the lane's 16 + 16 coefficients as eight 16-byte loads, one group of four taps ahead of its use (they were 32 scalar
+            // loads: 32 VMEM instructions per wave and tile).  This block runs BEFORE the folded MFMA pass: beside that pass's 32
+            // accumulator registers the eight fragments spilled at the 80-VGPR budget
+            static_assert(OFF_B64 % 4 == 0, "bin-64 table must be 16-byte aligned in the packed blob");
+            const float *xr = X + i * X_LDM + 64 * f;
+            f32x4 cre = *reinterpret_cast<const f32x4 *>(P + OFF_B64 + n0), cim = *reinterpret_cast<const f32x4 *>(P + OFF_B64 + 128 + n0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int un = u + 1 < 4 ? u + 1 : u;
+                const f32x4 nre = *reinterpret_cast<const f32x4 *>(P + OFF_B64 + n0 + 4 * un);
+                const f32x4 nim = *reinterpret_cast<const f32x4 *>(P + OFF_B64 + 128 + n0 + 4 * un);
+#pragma unroll
+                for (int k3 = 0; k3 < 4; ++k3) {
+                    const int n = n0 + 4 * u + k3 + 1;                                // 1..128, mirror 256 - n
+                    const float a = xr[(n & 1) * X_ODD + (n >> 1)], b = xr[(n & 1) * X_ODD + ((256 - n) >> 1)];
+                    b64re = fmaf(a + b, cre[k3], b64re);
+                    b64im = fmaf(a - b, cim[k3], b64im);
+                }
+                cre = nre;
+                cim = nim;
+            }
+            b64re += __shfl_xor(b64re, 16); b64re += __shfl_xor(b64re, 32);
+            b64im += __shfl_xor(b64im, 16); b64im += __shfl_xor(b64im, 32);
+            if (h == 0) {                                                             // the n = 0 tap
+                const float x0 = xr[0];
+                b64re = fmaf(x0, P[OFF_B64 + 256], b64re);
+                b64im = fmaf(x0, P[OFF_B64 + 257], b64im);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the bin-64 registers from overlapping the fold's accumulators
         f32x4 ere[2], eim[2], ore[2], oim[2];
         const float c0 = P[OFF_S0 + tl * 16 + i], s0 = P[OFF_S0 + 64 + tl * 16 + i];
 #pragma unroll
@@ -437,28 +472,6 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
             const float *wt = P + OFF_SF + tl * 16 * FRAG + lane * 4;                 // [E|O][re|im][4 blocks]
             stft_fold_class(ere, eim, row + 1 + q, row + 127 - q, wt, wt + 4 * FRAG);
             stft_fold_class(ore, oim, row + X_ODD + q, row + X_ODD + 127 - q, wt + 8 * FRAG, wt + 12 * FRAG);
-        }
-        // bin 64 (its own mirror) on the VALU, spread over all eight waves: wave = (frame f = wave & 3, half h of n = 1..128),
-        // lane = (clip i, quarter q of the half): 16 taps each, summed over q by shuffles and over h through the scratch
-        float b64re = 0.f, b64im = 0.f;
-        if (!ENC_SKIP(7)) {
-            const int f = wave & 3, h = wave >> 2, n0 = h * 64 + q * 16;
-            const float *bre = P + OFF_B64 + n0, *bim = P + OFF_B64 + 128 + n0;
-            const float *xr = X + i * X_LDM + 64 * f;
-#pragma unroll 8
-            for (int k2 = 0; k2 < 16; ++k2) {
-                const int n = n0 + k2 + 1;                                            // 1..128, mirror 256 - n
-                const float a = xr[(n & 1) * X_ODD + (n >> 1)], b = xr[(n & 1) * X_ODD + ((256 - n) >> 1)];
-                b64re = fmaf(a + b, bre[k2], b64re);
-                b64im = fmaf(a - b, bim[k2], b64im);
-            }
-            b64re += __shfl_xor(b64re, 16); b64re += __shfl_xor(b64re, 32);
-            b64im += __shfl_xor(b64im, 16); b64im += __shfl_xor(b64im, 32);
-            if (h == 0) {                                                             // the n = 0 tap
-                const float x0 = xr[0];
-                b64re = fmaf(x0, P[OFF_B64 + 256], b64re);
-                b64im = fmaf(x0, P[OFF_B64 + 257], b64im);
-            }
         }
         ENC_SYNC();          // every wave is done reading X: V may now overwrite it
         ENC_MARK(1);
