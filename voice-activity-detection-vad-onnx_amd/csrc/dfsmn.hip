@@ -1036,11 +1036,11 @@ __global__ __launch_bounds__(128 * NTILE) void lstm_t2_kernel(LstmTArgs p) {
 // them transposed in LDS as Xs[ch][t][bin] (channel pitch = 16 mod 32 floats: the MFMA B operand reads are conflict
 // free); the last layer's outputs go to Ys[o][t][bin] and the loader writes chunk k-1 back as 16-B stores (times the
 // `mul` tensor in MODE 0).  One workgroup barrier per step orders everything (it already paced the two layers).
-template <int IN, int HID, int LAYERS, int OUT_MT, int MODE, int TS>
+template <int IN, int HID, int LAYERS, int OUT_MT, int MODE, int TS, int OUT_CH = OUT_MT * 16>
 __global__ __launch_bounds__(64 * (LAYERS + 1)) void lstm_t_kernel(LstmTArgs p) {
     constexpr int MT = HID / 4, KI0 = IN / 4, CS = TS * 16 + 16, NQ = TS / 4;
     constexpr int NLD = IN * NQ / 4;                         // float4 loads per loader lane per chunk
-    constexpr int OUTC = OUT_MT * 16;
+    constexpr int OUTC = OUT_CH;                             // rows of the output staging block: the real channels (the MFMA tiles' padding rows are not stored)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Xs = lds;                                         // [2][IN][CS]
     float *Ys = Xs + 2 * IN * CS;                            // [2][OUTC][CS]
@@ -1171,7 +1171,8 @@ __global__ __launch_bounds__(64 * (LAYERS + 1)) void lstm_t_kernel(LstmTArgs p) 
 #pragma unroll
                     for (int s = 0; s < MT; ++s) y = mfma16(wl[om][s], h[s], y);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) yb[(om * 16 + 4 * q + r) * CS] = y[r];
+                    for (int r = 0; r < 4; ++r)
+                        if (om * 16 + 4 * q + r < OUTC) yb[(om * 16 + 4 * q + r) * CS] = y[r];
                 }
             }
         }
@@ -1434,8 +1435,9 @@ extern "C" int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_f
     for (int l = 0; l < 2; ++l) { p.w_ih[l] = w_ih[l]; p.w_hh[l] = w_hh[l]; p.b_ih[l] = b_ih[l]; p.b_hh[l] = b_hh[l]; }
     const unsigned grid = (unsigned)(chunks * (F / 16));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    auto lds_bytes = [](int in, int outc, int hid, int ts) { return (size_t)(2 * in * (ts * 16 + 16) + 2 * outc * (ts * 16 + 16) + 2 * hid * 16) * sizeof(float); };
-    VADX_DYN_LDS((lstm_t_kernel<40, 20, 1, 3, 1, 4>), 64 * 1024);
+    // 40 (not 48) staged output rows and no inter-layer buffer for the one-layer net: 51.2 KB, three workgroups per CU instead of two
+    auto lds_bytes = [](int in, int outc, int hid, int ts, int layers) { return (size_t)(2 * in * (ts * 16 + 16) + 2 * outc * (ts * 16 + 16) + (layers > 1 ? 2 * hid * 16 : 0)) * sizeof(float); };
+    VADX_DYN_LDS((lstm_t_kernel<40, 20, 1, 3, 1, 4, 40>), 64 * 1024);
     if (which == 0) {            // bottleneck ch_lstm: in 20, hidden 40, 2 layers, Linear 40->20, multiplied with `mul`
         VADX_REQUIRE(in->c == 20 && mul && mul->ptr, "vadx_dfsmn_lstm_t(0): in must have 20 channels and mul is required");
         p.out_ch = 20;
@@ -1447,7 +1449,7 @@ extern "C" int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_f
     } else {                     // out_ch_lstm: in 40, hidden 20, 1 layer, Linear 20->40
         VADX_REQUIRE(in->c == 40, "vadx_dfsmn_lstm_t(1): in must have 40 channels");
         p.out_ch = 40;
-        hipLaunchKernelGGL((lstm_t_kernel<40, 20, 1, 3, 1, 4>), dim3(grid), dim3(128), lds_bytes(40, 48, 20, 4), st, p);
+        hipLaunchKernelGGL((lstm_t_kernel<40, 20, 1, 3, 1, 4, 40>), dim3(grid), dim3(128), lds_bytes(40, 40, 20, 4, 1), st, p);
     }
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
