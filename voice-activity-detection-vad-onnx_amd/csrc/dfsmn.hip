@@ -1435,7 +1435,10 @@ extern "C" int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_f
     for (int l = 0; l < 2; ++l) { p.w_ih[l] = w_ih[l]; p.w_hh[l] = w_hh[l]; p.b_ih[l] = b_ih[l]; p.b_hh[l] = b_hh[l]; }
     const unsigned grid = (unsigned)(chunks * (F / 16));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // 40 (not 48) staged output rows and no inter-layer buffer for the one-layer net: 51.2 KB, three workgroups per CU instead of two
+    // 40 (not 48) staged output rows and no inter-layer buffer for the one-layer net: 51.2 KB, three workgroups per CU instead of two.
+    // (Dropping the output staging block altogether -- the compute wave storing its 4-B outputs itself, 25.6 KB, four workgroups
+    // per CU -- was measured: lstm_t launches 365 -> 516 ms per pass; forty scattered store instructions per step cost far more
+    // than the fourth workgroup brings.)
     auto lds_bytes = [](int in, int outc, int hid, int ts, int layers) { return (size_t)(2 * in * (ts * 16 + 16) + 2 * outc * (ts * 16 + 16) + (layers > 1 ? 2 * hid * 16 : 0)) * sizeof(float); };
     VADX_DYN_LDS((lstm_t_kernel<40, 20, 1, 3, 1, 4, 40>), 64 * 1024);
     if (which == 0) {            // bottleneck ch_lstm: in 20, hidden 40, 2 layers, Linear 40->20, multiplied with `mul`
