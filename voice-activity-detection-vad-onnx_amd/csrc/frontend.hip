@@ -361,7 +361,7 @@ __global__ __launch_bounds__(THREADS, 4) void frontend_logmel_kernel(
     const float *__restrict__ faux) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *X2 = lds;
-    float *PW = lds + d.hop * X_LD + 16 * X_LD;       // +16 rows: partial last pass reads past hop
+    float *PW = lds + d.hop * X_LD;                   // a pass never reads past row hop - 1: its rows round up to 16 <= hop (hop % 16 == 0)
     const int tiles = d.tiles32 + d.tiles16;
     const int widx = blockIdx.x / tiles, tile = blockIdx.x - widx * tiles;
     const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(THREADS, 4) void stft_complex_kernel(
     int ft_nt, int ft_ctotal, int ft_coff) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *X2 = lds;
-    float *PW = lds + d.hop * X_LD + 16 * X_LD;
+    float *PW = lds + d.hop * X_LD;
     const int tiles = (d.frames + TF - 1) / TF;
     const int widx = blockIdx.x / tiles, tile = blockIdx.x - widx * tiles;
     const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
@@ -496,7 +496,7 @@ extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *p
         VADX_HIP_TRY(hipGetLastError());
         means = means_ws;
     }
-    const size_t lds = ((size_t)(d.hop + 16) * X_LD + (size_t)d.Fp * P_LD) * sizeof(float);
+    const size_t lds = ((size_t)d.hop * X_LD + (size_t)d.Fp * P_LD) * sizeof(float);      // FSMN / FireRed: 52 992 B -- three workgroups per CU (it was 2.3 KB more: two)
     VADX_REQUIRE(lds <= 160 * 1024, "vadx_frontend_logmel: geometry needs %zu B of LDS", lds);
     if (lds > 64 * 1024)
         VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(frontend_logmel_kernel),
@@ -524,7 +524,7 @@ extern "C" int vadx_frontend_logmel_ex(const vadx_frontend_cfg *cfg, const float
     for (int mt = 0; mt < d.nmt; ++mt) { d.mel_kb_lo[mt] = mel_kb_host[2 * mt]; d.mel_kb_hi[mt] = mel_kb_host[2 * mt + 1]; }
     d.out_stride = out_stride; d.out_off = out_off;
     const long long nwin = (long long)batch * windows_per_clip;
-    const size_t lds = ((size_t)(d.hop + 16) * X_LD + (size_t)d.Fp * P_LD) * sizeof(float);
+    const size_t lds = ((size_t)d.hop * X_LD + (size_t)d.Fp * P_LD) * sizeof(float);      // FSMN / FireRed: 52 992 B -- three workgroups per CU (it was 2.3 KB more: two)
     VADX_REQUIRE(lds <= 160 * 1024, "vadx_frontend_logmel_ex: geometry needs %zu B of LDS", lds);
     if (lds > 64 * 1024)
         VADX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(frontend_logmel_kernel),
@@ -552,7 +552,7 @@ extern "C" int vadx_frontend_stft_ft(const vadx_frontend_cfg *cfg, const float *
                        (long long)win_stride, windows_per_clip, (int)nwin, cfg->window_len, cfg->k1, means_ws);
     VADX_HIP_TRY(hipGetLastError());
     const int ft_nt = (d.frames + 15) / 16, tiles = (d.frames + TF - 1) / TF;
-    const size_t lds = ((size_t)(d.hop + 16) * X_LD) * sizeof(float);
+    const size_t lds = ((size_t)d.hop * X_LD) * sizeof(float);
     hipLaunchKernelGGL(stft_complex_kernel, dim3((unsigned)(nwin * tiles)), dim3(THREADS), lds, st, d, packed, audio,
                        (long long)row_stride, (long long)win_stride, windows_per_clip, means_ws, ft_out, ft_nt, c_total, c_off);
     VADX_HIP_TRY(hipGetLastError());
