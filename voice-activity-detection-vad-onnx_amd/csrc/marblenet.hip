@@ -23,12 +23,18 @@ constexpr int MAXC = 128;
 // LDS is carved per launch from the block's real shape (Cfg::in_ld, channel counts): a 64-channel k=13 block needs
 // 47 KB instead of the 125 KB worst case, i.e. three workgroups per CU instead of one -- a tile is a short serial chain
 // (stage -> FIR -> GEMM -> store), so with one workgroup per CU the launch was pure latency (72 rounds x ~6 us).
+// A block without a residual branch whose depthwise stage has consumed the input tile writes its output over that tile
+// (out_alias): the prologue (80 -> 128 channels, k = 11, stride 2) drops from 56.8 to 38.4 KB -- three workgroups per CU, not two.
+static bool out_aliases_in(int cinp, int coutp, int cresp, int in_ld, bool has_dw) {
+    return has_dw && !cresp && (size_t)coutp * A_LD <= (size_t)cinp * in_ld;
+}
 static size_t lds_floats(int cinp, int coutp, int cresp, int in_ld, bool has_dw) {
-    return (size_t)cinp * in_ld + (has_dw ? (size_t)cinp * A_LD : 0) + (size_t)coutp * A_LD + (cresp ? (size_t)(cresp + coutp) * A_LD : 0);
+    return (size_t)cinp * in_ld + (has_dw ? (size_t)cinp * A_LD : 0) + (out_aliases_in(cinp, coutp, cresp, in_ld, has_dw) ? 0 : (size_t)coutp * A_LD) +
+           (cresp ? (size_t)(cresp + coutp) * A_LD : 0);
 }
 
 struct Cfg {
-    int cin, cout, k, stride, dil, pad, has_dw, cres, relu, cinp, coutp, cresp, in_ld;
+    int cin, cout, k, stride, dil, pad, has_dw, cres, relu, cinp, coutp, cresp, in_ld, out_alias;
 };
 
 // KT / DT / ST: compile-time kernel size, dilation and stride of the depthwise stage (0 = take them from `c` at run
@@ -44,7 +50,8 @@ __global__ __launch_bounds__(THREADS, 2) void sepconv_block_kernel(
     float *__restrict__ y, int T_out, int tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int IN_LD = c.in_ld;
-    float *IN = lds, *D = IN + c.cinp * IN_LD, *OUT = D + (c.has_dw ? c.cinp * A_LD : 0), *RIN = OUT + c.coutp * A_LD, *ROUT = RIN + c.cresp * A_LD;
+    float *IN = lds, *D = IN + c.cinp * IN_LD, *OUT = c.out_alias ? IN : D + (c.has_dw ? c.cinp * A_LD : 0), *RIN = OUT + c.coutp * A_LD,
+          *ROUT = RIN + c.cresp * A_LD;           // (out_alias implies no residual branch: RIN / ROUT are unused then)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TILE;
     const int K = KT ? KT : c.k, DIL = KT ? DT : c.dil, STR = KT ? ST : c.stride;
@@ -418,6 +425,7 @@ extern "C" int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w
                  "vadx_sepconv_block: receptive field of a 32-frame tile exceeds %d samples", IN_LD_MAX);
     {   const int width = (TILE - 1) * c.stride + (c.k - 1) * c.dil + 1;
         c.in_ld = c.has_dw ? (((width + 7) & ~7) + 4) : A_LD; }      // % 8 == 4; a plain 1x1 block feeds IN straight to the GEMM
+    c.out_alias = out_aliases_in(c.cinp, c.coutp, c.cresp, c.in_ld, c.has_dw) ? 1 : 0;
     const size_t lds_bytes = lds_floats(c.cinp, c.coutp, c.cresp, c.in_ld, c.has_dw) * sizeof(float);
     VADX_REQUIRE(c.has_dw ? dw_w != nullptr : (c.k == 1 && c.stride == 1), "vadx_sepconv_block: plain conv must be k=1, stride 1");
     VADX_REQUIRE(!c.cres || (res_w && res_b && xres), "vadx_sepconv_block: residual branch needs res_w/res_b/xres");
