@@ -363,13 +363,28 @@ __global__ void fsmn_energy_kernel(const int16_t *__restrict__ audio, long long 
     for (int f = wave; f < T; f += nw) {
         const int ff = f < nfr ? f : nfr - 1;          // last value repeated up to T frames
         float s = 0.f;
-        for (int k = lane; k < n_fft; k += 64) {
-            const int n = ff * hop + k;
-            const float a = __fsub_rn((float)win[n], mean);
-            float y = a;
-            if (n > 0) y = __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn((float)win[n - 1], mean)));
-            y = __fmul_rn(y, inv_ref);
-            s = fmaf(y, y, s);
+        // eight (sample, predecessor) pairs per lane are requested before any is used, unconditionally (clamped index, value selected
+        // afterwards): the guarded predecessor load compiled to a branch plus a full wait -- one serialised round trip per sample.
+        // Accumulation order per lane is unchanged (k ascending): the sums are bit-identical.
+        for (int k0 = lane; k0 < n_fft; k0 += 64 * 8) {
+            float xa[8], xb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = min(k0 + 64 * u, n_fft - 1), n = ff * hop + k;
+                xa[u] = (float)win[n];
+                xb[u] = (float)win[n > 0 ? n - 1 : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 64 * u, n = ff * hop + k;
+                if (k < n_fft) {
+                    const float a = __fsub_rn(xa[u], mean);
+                    float y = a;
+                    if (n > 0) y = __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn(xb[u], mean)));
+                    y = __fmul_rn(y, inv_ref);
+                    s = fmaf(y, y, s);
+                }
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
