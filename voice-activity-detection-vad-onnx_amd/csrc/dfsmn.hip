@@ -831,14 +831,22 @@ __global__ void alpha_scale_kernel(const float *__restrict__ in, float *__restri
     const int tile = (int)(e / (160 * 16)), chunk = tile / nt, tl = tile - chunk * nt;
     const int t = tl * 16 + t16;
     float alpha = b2[0];
+    // the ten history taps' four operands are requested first, unconditionally (time index clamped; taps before the chunk's first
+    // frame are zeroed afterwards): loads under `if (tt >= 0)` were ten serialised round trips
+    float mr[10], mi[10], fr[10], fi[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const int tt = t - 9 + j, tc = tt < 0 ? 0 : tt;
+        const size_t base = ft_idx(chunk * nt + (tc >> 4), 4, 0, 160, f) + (tc & 15);
+        mr[j] = in[base]; mi[j] = in[base + 160 * 16]; fr[j] = in[base + 2 * 160 * 16]; fi[j] = in[base + 3 * 160 * 16];
+    }
+#pragma unroll
     for (int j = 0; j < 10; ++j) {
         const int tt = t - 9 + j;
         float pf = 0.f, pm = 0.f;
         if (tt >= 0) {
-            const size_t base = ft_idx(chunk * nt + (tt >> 4), 4, 0, 160, f) + (tt & 15);
-            const float mr = in[base], mi = in[base + 160 * 16], fr = in[base + 2 * 160 * 16], fi = in[base + 3 * 160 * 16];
-            pm = mr * mr + mi * mi;
-            pf = fr * fr + fi * fi;
+            pm = mr[j] * mr[j] + mi[j] * mi[j];
+            pf = fr[j] * fr[j] + fi[j] * fi[j];
         }
         if (pow_far) pf = pow_far[((size_t)f * frames + (t < frames ? t : frames - 1)) * 10 + j];
         const float a1 = w1[0] * pf + w1[1] * pm + b1[0];
