@@ -140,11 +140,30 @@ def firered_from_state(args, state, cmvn=None):
     return {k: (v if k == "cfg" else np.ascontiguousarray(v.numpy(), dtype=np.float32)) for k, v in w.items()}
 
 
+def _torch_load(src, what):
+    """torch.load restricted to tensors / containers / argparse.Namespace (`weights_only=True`): a downloaded checkpoint is a
+    pickle, and these loaders are reachable from any engine's `weights=<path>` string.  A file that needs more than that is
+    refused unless the caller opts in with VADX_TRUST_CHECKPOINTS=1 (full unpickling executes code from the file: only for
+    files whose origin is trusted)."""
+    import argparse
+    import pickle
+    import torch
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(src, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if os.environ.get("VADX_TRUST_CHECKPOINTS") != "1":
+            raise ValueError(f"{what}: the checkpoint holds objects beyond tensors / containers ({str(e).splitlines()[0]}); "
+                             "set VADX_TRUST_CHECKPOINTS=1 to unpickle it fully if (and only if) you trust the file") from e
+        if hasattr(src, "seek"):
+            src.seek(0)
+        return torch.load(src, map_location="cpu", weights_only=False)
+
+
 def load_firered(model_dir):
     """`<model_dir>/model.pth.tar` + `<model_dir>/cmvn.ark` (the layout of the VAD / AED / Stream-VAD downloads,
     Export_FireRedVAD.py:13-15, :339-341) -> weight dict for FireRedEngine / FireRedStreamSession."""
-    import torch
-    package = torch.load(os.path.join(model_dir, "model.pth.tar"), map_location="cpu", weights_only=False)
+    package = _torch_load(os.path.join(model_dir, "model.pth.tar"), "firered model.pth.tar")
     cmvn_path = os.path.join(model_dir, "cmvn.ark")
     cmvn = load_cmvn(cmvn_path) if os.path.exists(cmvn_path) else None
     return firered_from_state(package["args"], package["model_state_dict"], cmvn)
@@ -238,7 +257,7 @@ def load_fsmn(model_dir):
     that `AutoModel(model=model_path)` reads (FSMN/Export_FSMN_VAD.py:11, :107-113)."""
     import torch
     pt = os.path.join(model_dir, "model.pt") if os.path.isdir(model_dir) else model_dir
-    pkg = torch.load(pt, map_location="cpu", weights_only=False)
+    pkg = _torch_load(pt, "fsmn model.pt")
     for key in ("state_dict", "model", "model_state_dict"):
         if isinstance(pkg, dict) and key in pkg and isinstance(pkg[key], dict):
             pkg = pkg[key]
@@ -345,7 +364,7 @@ def load_marblenet(nemo_path):
                              bool(j.get("residual", False)), bool(j.get("separable", False))) for j in jasper)
                 if got != tuple(_w.MARBLENET_BLOCKS):
                     raise ValueError(f"model_config.yaml describes {got}; the HIP net is built for {_w.MARBLENET_BLOCKS}")
-    state = torch.load(io.BytesIO(blob), map_location="cpu", weights_only=False)
+    state = _torch_load(io.BytesIO(blob), "marblenet model_weights.ckpt")
     if isinstance(state, dict) and "state_dict" in state:
         state = state["state_dict"]
     return marblenet_from_state(state)

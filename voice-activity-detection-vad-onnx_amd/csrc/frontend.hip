@@ -203,8 +203,9 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
                 } else {                      // p(i0) and p(i1): x[i-1], x[i] of both neighbours
                     lb[j] = 0.f;
                     xa[j] = (float)win[i0]; xb[j] = (float)win[i1];
-                    xc[j] = i0 > 0 ? (float)win[i0 - 1] : 0.f;          // (uniformly rare branch-free select: index clamped below)
-                    xd[j] = i1 > 0 ? (float)win[i1 - 1] : 0.f;
+                    const float pc = (float)win[i0 > 0 ? i0 - 1 : 0], pd = (float)win[i1 > 0 ? i1 - 1 : 0];      // unconditional loads from
+                    xc[j] = i0 > 0 ? pc : 0.f;                                                                       // clamped indices, zero
+                    xd[j] = i1 > 0 ? pd : 0.f;                                                                       // selected afterwards
                 }
             }
 #pragma unroll
@@ -241,8 +242,6 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
     };
     if (d.hop <= 192) stage_any(std::integral_constant<int, 3>{});
     else stage_any(std::integral_constant<int, 5>{});
-    // rows hop..round16 of a partial last pass never exist in X2; the table is zero there but the
-    // activations must be finite: they alias rows of the NEXT column block, which are finite.
     FE_ACC(4);
     __syncthreads();
     FE_ACC(0);

@@ -25,10 +25,19 @@ def _grouped(clips, noises, run):
         by_len.setdefault(len(c), []).append(k)
     out = [None] * len(clips)
     for idx in by_len.values():
-        nz = None if noises is None else np.stack([np.asarray(noises[k]) for k in idx])
-        for k, r in zip(idx, run(np.stack([clips[k] for k in idx]), nz)):
+        for k, r in zip(idx, run(np.stack([clips[k] for k in idx]), _stack_noise(noises, idx))):
             out[k] = r
     return out
+
+
+def _stack_noise(noises, idx):
+    """Per-clip pad-noise rows of one length group as a matrix: rows may be ragged (each clip ran alone in the reference), so
+    they are trimmed to the group's shortest row -- the engines take `[B, >= pad]` and use the first `pad` samples."""
+    if noises is None:
+        return None
+    rows = [np.asarray(noises[k]).reshape(-1) for k in idx]
+    n = min(len(r) for r in rows)
+    return np.stack([r[:n] for r in rows])
 
 
 def _finish(all_ts, sample_rate, save_second, save_indices, single, elapsed, echo):
@@ -114,9 +123,7 @@ def inference_firered_aed(test_aed_audio="./vad_sample.wav", engine=None, NORMAL
     """FireRedVAD/Inference_FireRed_ONNX.py:620-742 (RUN_AED): -> (event2timestamps, event2ratio) per file."""
     from . import firered
     files = _as_list(test_aed_audio)
-    if engine is None:
-        from . import weights
-        engine = firered.FireRedEngine(weights.firered_synthetic(1234, dict(weights.FIRERED_CFG, odim=3)))
+    engine = firered.FireRedEngine(engine) if (engine is None or isinstance(engine, (str, dict))) else engine      # None raises (checkpoints.resolve)
     clips = [audio_io.load_wav(f, 16000) for f in files]
     if NORMALIZE_AUDIO:
         clips = [timestamps.normalise_audio(c) for c in clips]
@@ -144,10 +151,7 @@ def inference_firered_stream(test_vad_audio="./vad_sample.wav", engine=None, NOR
     """FireRedVAD/Inference_FireRed_ONNX.py:744-840 (RUN_STREAM_VAD): -> [(start_s, end_s)] per file."""
     from . import firered
     files = _as_list(test_vad_audio)
-    if engine is None:
-        from . import weights
-        engine = firered.FireRedEngine(weights.firered_synthetic(1234, dict(weights.FIRERED_CFG, N2=0, S2=0)),
-                                       STREAM_CHUNK_SAMPLES)
+    engine = firered.FireRedEngine(engine, STREAM_CHUNK_SAMPLES) if (engine is None or isinstance(engine, (str, dict))) else engine
     clips = [audio_io.load_wav(f, 16000) for f in files]
     if NORMALIZE_AUDIO:
         clips = [timestamps.normalise_audio(c) for c in clips]
@@ -203,16 +207,13 @@ def inference_dfsmn(test_near_end_audio="./examples/nearend_mic.wav", test_far_e
         n = min(len(a), len(f))
         pairs.append(np.stack([a[:n], f[:n]]))
     t0 = time.time()
-    noises = None if pad_noise_near is None else [np.stack([np.asarray(pad_noise_near)[k], np.asarray(pad_noise_far)[k]])
-                                                  for k in range(len(pairs))]
     by_len = {}
     for k, pr in enumerate(pairs):
         by_len.setdefault(pr.shape[1], []).append(k)
     all_ts = [None] * len(pairs)
     for idx in by_len.values():                     # one device batch per group of equal-length pairs
         near, far = np.stack([pairs[k][0] for k in idx]), np.stack([pairs[k][1] for k in idx])
-        nzn = None if noises is None else np.stack([noises[k][0] for k in idx])
-        nzf = None if noises is None else np.stack([noises[k][1] for k in idx])
+        nzn, nzf = _stack_noise(pad_noise_near, idx), _stack_noise(pad_noise_far, idx)      # each side independently, either may be None
         res = engine.detect(near, far, nzn, nzf, fusion_threshold=FUSION_THRESHOLD, min_speech_duration=MIN_SPEECH_DURATION,
                             speaking_score=SPEAKING_SCORE, silence_score=SILENCE_SCORE)
         for k, r in zip(idx, res):

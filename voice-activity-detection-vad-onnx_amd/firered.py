@@ -237,8 +237,7 @@ class FireRedStreamSession:
     The weights must have no look-ahead filter (cfg N2 == 0)."""
 
     def __init__(self, weights=None, device="cuda:0"):
-        w = _weights.firered_synthetic(1234, dict(_weights.FIRERED_CFG, N2=0)) if weights is None else weights
-        self.engine = FireRedEngine(w, STREAM_CHUNK_SAMPLES, device)
+        self.engine = FireRedEngine(weights, STREAM_CHUNK_SAMPLES, device)      # None / "" raise in checkpoints.resolve: no silent default
         e = self.engine
         self._inputs_meta = [_Meta("audio", [1, 1, "audio_len"], "tensor(int16)"),
                              _Meta("caches_in", list(e.cache_shape), "tensor(float)")]

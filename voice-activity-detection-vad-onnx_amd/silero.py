@@ -65,6 +65,16 @@ class SileroEngine:
         self.packed = torch.from_numpy(packed).to(self.device)
         self._ws = None
 
+    def _check_workspace_cap(self, batch, steps, who):
+        """The whole-batch gx workspace is 32 KB per 16-clip group and window; `clips` falls back to spans above WORKSPACE_CAP_BYTES,
+        the int16 / host-feed entry points have no spanned variant and say so instead of running the allocator out of memory."""
+        need = _lib.lib().vadx_silero_workspace_bytes(int(batch), int(steps))
+        if need > WORKSPACE_CAP_BYTES:
+            raise ValueError(f"{who}: a batch of {batch} clips x {steps} windows needs a {need / 2**30:.1f} GiB workspace "
+                             f"(cap {WORKSPACE_CAP_BYTES / 2**30:.0f} GiB): split the batch into groups of at most "
+                             f"{max(16, WORKSPACE_CAP_BYTES // _lib.lib().vadx_silero_workspace_bytes(16, int(steps)) * 16)} clips, "
+                             "or use clips() (float32, spanned automatically)")
+
     # -- scratch (gx tiles) grows on demand and is reused
     def _workspace(self, batch, steps):
         need = _lib.lib().vadx_silero_workspace_bytes(int(batch), int(steps))
@@ -171,6 +181,7 @@ class SileroEngine:
         B, N = pcm.shape
         n = int(N if n_samples is None else n_samples)
         steps = (n + NUM_SAMPLES - 1) // NUM_SAMPLES
+        self._check_workspace_cap(B, steps, "encode_pcm16")
         ws = self._workspace(B, steps)
         with t.cuda.device(self.device):
             _lib.check(_lib.lib().vadx_silero_encode_pcm16(self.packed.data_ptr(), pcm.data_ptr(), float(scale), B, n,
@@ -246,6 +257,7 @@ class HostFeed:
         t = engine.torch
         self.eng, self.B, self.N = engine, int(batch), int(n_samples)
         self.T = (self.N + NUM_SAMPLES - 1) // NUM_SAMPLES
+        engine._check_workspace_cap(self.B, self.T, "HostFeed")
         self.chunk = max(16, (int(chunk_clips) + 15) // 16 * 16)       # slices of the workspace start on a 16-clip group boundary
         self.buf = [t.empty((self.chunk, self.N), dtype=t.int16, device=engine.device) for _ in range(2)]
         self.copy_stream = t.cuda.Stream(device=engine.device)
