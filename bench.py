@@ -14,8 +14,13 @@ line.  Besides the contract keys it carries
     (`algorithmic_bytes_per_launch` = 2052 B / window, `traffic` from the committed PMC passes, `traffic_ratio`);
   * `hbm`: the north star's HBM fraction of the whole step;
   * `feed`: the same batch timed INCLUDING the int16 upload from pinned host memory, double-buffered against compute;
-  * `secondary`: BASELINE configs 3, 4, 5 measured in the same process (bench_models.py), N = 1 only;
-  * `cpu_baseline`: the oracle driven like the reference drives ORT, on this host's cores (N = 1, rank 0).
+  * `configs`: BASELINE configs 3, 4, 5 measured in the same process (bench_models.py), a few numbers each (N = 1 only);
+  * `c4_sharded`: BASELINE config 4 as the config states it -- 8192 MarbleNet clips strong-sharded over the N GPUs, resident and
+    from pinned host memory (every N);
+  * `cpu_baseline`: the oracle driven like the reference drives ORT, on this host's cores (N = 1, rank 0), beside the reference's
+    own published README figure.
+The line is kept under 6 KB (the driver records its tail); everything it summarises -- per-entry-point splits, every roofline
+object in full, sample descriptions -- is written by rank 0 to `--detail` (default profiles/r03_bench_detail.json).
 `--dry-run` replaces the device work by a sleep and RCCL by gloo so the launch / barrier / collect path can be tested
 on a CPU-only box; its line says so (`data`: "dry-run") and carries no measurement.
 """
@@ -227,6 +232,51 @@ def cpu_baseline(budget_s=10.0):
             "batched_value": batched, "batched_note": f"same oracle, batch {bb}, {min(ncpu, 64)} threads (not the reference's mode)"}
 
 
+def compact_line(full, detail_path=None):
+    """The driver's record keeps the TAIL of the line, so the line stays short (< 6 KB): the contract keys, the dominant kernel's
+    roofline with its byte accounting, one small object per BASELINE config, the CPU baseline.  `full` (every number) is what
+    `--detail` holds."""
+    import bench_models
+    r4 = lambda v: None if v is None else float(f"{v:.5g}")      # noqa: E731
+    ro, rr, hb, fd, cp = full["roofline"], full["roofline_recurrent"], full["hbm"], full.get("feed"), full.get("cpu_baseline")
+    mix = ro.get("instruction_mix") or {}
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data", "config", "per_gpu_value", "rtf_batch1")}
+    line["kernel_ms"] = {k: r4(v) for k, v in full["kernel_ms"].items()}
+    line["roofline"] = {"bound": ro["bound"], "kernel": ro["kernel"], "achieved": r4(ro["achieved"]), "peak": ro["peak"], "unit": ro["unit"],
+                        "frac": r4(ro["frac"]), "traffic": ro["traffic"], "traffic_unit": ro["traffic_unit"],
+                        "algorithmic_bytes_per_launch": ro["algorithmic_bytes_per_launch"], "traffic_ratio": r4(ro["traffic_ratio"]),
+                        "flop_per_frame": ro["flop_per_frame"], "dense_equivalent_achieved": r4(ro["dense_equivalent"]["achieved"]),
+                        "valu_per_mfma": r4(mix.get("valu_per_mfma")), "ceiling_frac": r4(mix.get("ceiling_frac")),
+                        "traffic_source": ro.get("traffic_source")}
+    line["roofline_recurrent"] = {"kernel": rr["kernel"], "achieved": r4(rr["achieved"]), "frac": r4(rr["frac"])}
+    line["hbm"] = {"algorithmic_bytes_per_frame": hb["algorithmic_bytes_per_frame"], "achieved_GBps": r4(hb["achieved_GBps"]),
+                   "peak_GBps": hb["peak_GBps"], "frac": r4(hb["frac"]), "traffic_ratio": r4(hb["traffic_ratio"])}
+    if fd is not None:
+        line["feed"] = fd if "error" in fd else {"value": r4(fd["value"]), "ms_per_step": r4(fd["ms_per_step"]),
+                                                 "upload_alone_GBps": r4(fd["upload_alone_GBps"]), "pcie_peak_GBps": fd["pcie_peak_GBps"],
+                                                 "scores_bit_identical_to_resident_f32_path": fd["scores_bit_identical_to_resident_f32_path"]}
+    if full.get("secondary"):
+        line["configs"] = {k: bench_models.compact(v) for k, v in full["secondary"].items()}
+    c4 = full.get("c4_sharded")
+    if c4 is not None:
+        line["c4_sharded"] = c4 if "error" in c4 else {
+            "clips": c4["clips"], "n_gpus": c4["n_gpus"], "scaling": "strong", "ms": r4(c4["ms"]), "frames_per_s": r4(c4["frames_per_s"]),
+            "feed_ms": r4((c4.get("feed") or {}).get("ms")), "feed_frames_per_s": r4((c4.get("feed") or {}).get("frames_per_s")),
+            "feed_bit_identical": (c4.get("feed") or {}).get("scores_bit_identical_to_resident")}
+    if cp is not None:
+        pub = cp.get("reference_published") or {}
+        line["cpu_baseline"] = {"value": r4(cp["value"]), "unit": cp["unit"], "cores": cp["cores"], "kind": cp["kind"], "cpu": cp["cpu"],
+                                "sample": f"{cp['sample'].split(',')[0]}, batch 1, one oracle call per 512-sample window (torch-CPU stand-in for ORT-CPU)",
+                                "reference_published": {"frames_per_s": r4(pub.get("frames_per_s")), "rtf": pub.get("rtf"),
+                                                        "hardware": pub.get("hardware"), "source": pub.get("source")}}
+    else:
+        line["cpu_baseline"] = None
+    if detail_path:
+        line["detail"] = os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path
+    return line
+
+
 _T0 = time.perf_counter()
 
 
@@ -244,6 +294,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 3-5 (bench_models.py)")
     ap.add_argument("--no-feed", action="store_true", help="skip the PCIe-inclusive (pinned, double-buffered upload) measurement")
     ap.add_argument("--secondary-reps", type=int, default=3)
+    ap.add_argument("--no-c4-sharded", action="store_true", help="skip BASELINE config 4 strong-sharded over the ranks")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "profiles", "r03_bench_detail.json"),
+                    help="where rank 0 writes the full (long) result object; '' = nowhere")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only: gloo + sleep instead of RCCL + kernels (launch-path test)")
     return ap.parse_args(argv)
 
@@ -280,12 +333,14 @@ def dry_run(args):
     elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0)
     lo, hi = shard.shard_bounds(world * args.clips, rank, world)
     owned = shard.gather_ragged(dist, [(rank, lo, hi)])
+    c4 = shard.gather_ragged(dist, [(rank,) + tuple(shard.shard_bounds(8192, rank, world))])      # BASELINE config 4: strong shards
     if rank == 0:
         print(json.dumps({"metric": "audio frames/sec/GPU (16 kHz, 512-sample hop); RTF at batch=1", "value": None,
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "dry-run (no GPU work: launch / barrier / collect path only)",
-                          "config": {"workload": "dry-run", "clips_per_gpu": args.clips, "shards": owned}}), flush=True)
+                          "config": {"workload": "dry-run", "clips_per_gpu": args.clips, "shards": owned},
+                          "c4_sharded": {"clips": 8192, "scaling": "strong", "shards": c4}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -456,9 +511,17 @@ def main(argv=None):
         torch.cuda.synchronize()
         rtf_b1 = (time.perf_counter() - t1) / 5 / (SAMPLES / 16000.0)
         log(f"rtf_batch1 = {rtf_b1:.5f}")
-    if world == 1 and not args.no_secondary:
+    torch.cuda.empty_cache()
+    eng._ws = None
+    c4s = None
+    if not args.no_c4_sharded:                               # every rank: its shard of the 8192 clips
+        try:
+            c4s = bench_models.marblenet_c4_sharded(torch, device, dist, rank, world, max(2, args.secondary_reps), log=log,
+                                                    feed=not args.no_feed)
+        except Exception as e:                               # noqa: BLE001
+            c4s = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
-        eng._ws = None
+    if world == 1 and not args.no_secondary:
         secondary = bench_models.run_all(torch, device, args.secondary_reps, 0 if args.no_cpu_baseline else 3.0, log=log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -515,9 +578,19 @@ def main(argv=None):
                     "traffic_GBps": (step_traffic / step_s / 1e9) if step_traffic else None},
             "feed": feed,
             "secondary": secondary,
+            "c4_sharded": c4s,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        if cpu is not None:
+            cpu["reference_published"] = bench_models.REFERENCE_PUBLISHED["silero"]
+        if args.detail:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
+                with open(args.detail, "w") as fh:
+                    json.dump(line, fh, indent=1)
+            except OSError as e:
+                log(f"detail file not written: {e}")
+        print(json.dumps(compact_line(line, args.detail)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

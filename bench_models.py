@@ -29,6 +29,18 @@ PEAK_HBM_GBPS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak
 SR = 16000
 
 
+# The reference's own published single-stream CPU figures (/root/reference/README.md:37-44: real-time factors measured with ONNX
+# Runtime's CPU provider on desktop CPUs; frames/s = 31.25 / RTF in this bench's unit).  Printed inside every `cpu_baseline` beside the
+# torch-CPU stand-in timed here: the stand-in is slower than ORT on a desktop part, so the published figure is the fairer yardstick.
+REFERENCE_PUBLISHED = {
+    "silero": {"rtf": 0.0026, "frames_per_s": 31.25 / 0.0026, "hardware": "Intel i3-12300, ONNX Runtime CPU, Ubuntu 24.04", "chunk": "512 samples", "source": "README.md:41"},
+    "fsmn": {"rtf": 0.0047, "frames_per_s": 31.25 / 0.0047, "hardware": "Intel i3-12300, ONNX Runtime CPU, Ubuntu 24.04", "chunk": "512 samples", "source": "README.md:40"},
+    "marblenet": {"rtf": 0.0005, "frames_per_s": 31.25 / 0.0005, "hardware": "Intel i7-1165G7, ONNX Runtime CPU, Ubuntu 24.04", "chunk": "89000 samples", "source": "README.md:42"},
+    "dfsmn": {"rtf": 0.27, "frames_per_s": 31.25 / 0.27, "hardware": "Intel i7-1165G7, ONNX Runtime CPU (4 threads), Ubuntu 24.04", "chunk": "31841 samples", "source": "README.md:43"},
+    "firered": {"rtf": 0.0013, "frames_per_s": 31.25 / 0.0013, "hardware": "Intel i7-1165G7, ONNX Runtime CPU, Ubuntu 24.04", "chunk": "16000 samples", "source": "README.md:44"},
+}
+
+
 # ------------------------------------------------------------------------------------------------ algorithmic flops
 def flop_frontend_frame(n_bins, taps, n_mels=80):
     """One STFT frame as the reference computes it on non-zero window taps: cos + sin tables x taps MACs, the power
@@ -84,6 +96,10 @@ def flop_dfsmn_window(T=101, TA=51, F=160, ch=20):
     pw += F * (2 * ch * ch + ch * 2 * ch)                                                # the two time-LSTM output linears
     out["pw_conv"] = 2 * T * pw
     out["lstm_t"] = 2 * T * F * (lstm(ch, 2 * ch, False, 2) + lstm(2 * ch, ch))
+    # the fused block kernels (csrc/dfsmn_cfb.hip) regroup the same arithmetic: cfb_front = gate / input / (3,1) convs + forward DFT,
+    # cfb_back = CepsUnit Linear + pinv inverse DFT (NOT added to the total: they are pw_conv / dft_f / lstm_f's linear, regrouped)
+    conv_cfb = sum(F * (2 * cin * ch + 3 * ch * ch) for cin in (ch,) * 6 + (2 * ch,) * 4)
+    regroup = {"cfb_front": 2 * T * (conv_cfb + 10 * ch * 2 * 81 * F), "cfb_back": 2 * T * 10 * (81 * 2 * ch * 2 * ch + ch * 162 * F)}
     out["istft"] = 2 * T * 320 * 319
     out["frontend"] = 2 * (2 * T * 2 * F * 319) + 3 * TA * (flop_frontend_frame(513, 640))
     from vadx import weights
@@ -91,6 +107,7 @@ def flop_dfsmn_window(T=101, TA=51, F=160, ch=20):
     H, H2 = m["hidden"], m["fsmn_hidden"]
     out["mask_net"] = 2 * TA * (240 * H + m["layers"] * (H * H2 + H2 * H + H * m["lorder"]) + H)
     out["total"] = sum(out.values())
+    out.update(regroup)
     return out
 
 
@@ -204,6 +221,29 @@ def profiled_kernel_traffic(tag, kernel_substr):
     return best
 
 
+def profiled_pass_traffic(tag):
+    """HBM bytes of ALL launches of one pass of a secondary workload, from the newest profiles/r*_{tag}/SUMMARY.txt: every
+    kernel's FETCH_SIZE (doubled, except the 64-B-row readers of FETCH_FACTOR_64B) + WRITE_SIZE."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}", "SUMMARY.txt"))):
+        total, launches, seen = 0.0, 0, set()
+        for line in open(path):
+            if "sum_per_pass=" not in line or line.startswith("#"):
+                continue
+            name = line.split("calls_per_pass=")[0].strip()
+            val = float(line.split("sum_per_pass=")[1])
+            if " FETCH_SIZE " in line:
+                total += (1.0 if any(k in name for k in FETCH_FACTOR_64B) else 2.0) * val * 1024.0
+                if name not in seen:
+                    seen.add(name)
+                    launches += int(line.split("calls_per_pass=")[1].split()[0])
+            elif " WRITE_SIZE " in line:
+                total += val * 1024.0
+        if total > 0:
+            best = {"bytes": total, "launches_per_pass": launches, "source": os.path.relpath(path, ROOT)}
+    return best
+
+
 def _roof(kernel, flop, ms, tag=None, kernel_substr=None, note=None):
     ach = flop / (ms * 1e-3) / 1e12
     tr = profiled_kernel_traffic(tag, kernel_substr) if tag else None
@@ -242,9 +282,16 @@ def _roof_hbm(kernel, algorithmic_bytes, ms, tag=None, kernel_substr=None, note=
     return r
 
 
-def _hbm(bytes_algorithmic, ms):
+def _hbm(bytes_algorithmic, ms, tag=None):
+    """SURVEY 8(d) view of a whole pass: algorithmic bytes (PCM in + scores out) / time against the HBM peak, and -- when a PMC
+    profile of the full-size pass is committed -- what ALL its launches really moved over those bytes (`traffic_ratio`)."""
     g = bytes_algorithmic / (ms * 1e-3) / 1e9
-    return {"algorithmic_bytes": bytes_algorithmic, "achieved_GBps": g, "peak_GBps": PEAK_HBM_GBPS, "frac": g / PEAK_HBM_GBPS}
+    out = {"algorithmic_bytes": bytes_algorithmic, "achieved_GBps": g, "peak_GBps": PEAK_HBM_GBPS, "frac": g / PEAK_HBM_GBPS}
+    tr = profiled_pass_traffic(tag) if tag else None
+    if tr:
+        out.update({"traffic_bytes_per_pass": tr["bytes"], "traffic_ratio": tr["bytes"] / bytes_algorithmic,
+                    "launches_per_pass": tr["launches_per_pass"], "traffic_source": tr["source"]})
+    return out
 
 
 def _trace(fn):
@@ -259,8 +306,9 @@ def _trace(fn):
 # ------------------------------------------------------------------------------------------------ CPU baselines
 # (the ONLY functions of this file that touch oracle/: the torch-CPU restatement timed on the host, batch 1, one call per window,
 #  exactly how the reference drives its ORT session -- a reported, non-target baseline)
-def _cpu_entry(rate, thr_n, sample):
-    return {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(), "sample": sample}
+def _cpu_entry(rate, thr_n, sample, model):
+    return {"value": rate, "unit": "frames/s", "cores": thr_n, "kind": "port", "cpu": cpu_model(), "sample": sample,
+            "reference_published": REFERENCE_PUBLISHED[model]}
 
 
 def cpu_baseline_fsmn(budget_s, stride):
@@ -274,7 +322,7 @@ def cpu_baseline_fsmn(budget_s, stride):
     thr, nz = torch.tensor([1.0]), torch.tensor([4.0])
     rate, thr_n, calls, el = timed_cpu(lambda: ofs.forward(fe, w, a, caches, thr, nz), stride / 512.0, budget_s)
     return _cpu_entry(rate, thr_n, f"{calls} one-second windows, batch 1, one oracle call per window at stride {stride} "
-                                   f"(torch-CPU stand-in for ORT-CPU), {el:.1f} s")
+                                   f"(torch-CPU stand-in for ORT-CPU), {el:.1f} s", "fsmn")
 
 
 def cpu_baseline_marblenet(budget_s, n):
@@ -286,7 +334,7 @@ def cpu_baseline_marblenet(budget_s, n):
     a = torch.from_numpy(weights.burst_clips(1, n, seed=4)).reshape(1, 1, -1)
     rate, thr_n, ncall, el = timed_cpu(lambda: omb.forward(fe, w, a), n / 512.0, budget_s)
     return _cpu_entry(rate, thr_n, f"{ncall} clips of {n} samples, batch 1, one oracle call per clip (torch-CPU stand-in for "
-                                   f"ORT-CPU), {el:.1f} s")
+                                   f"ORT-CPU), {el:.1f} s", "marblenet")
 
 
 def cpu_baseline_firered(budget_s):
@@ -298,7 +346,7 @@ def cpu_baseline_firered(budget_s):
     a = torch.from_numpy(weights.burst_clips(1, 16000, seed=5)).reshape(1, 1, -1)
     rate, thr_n, ncall, el = timed_cpu(lambda: ofr.forward(fe, w, a), 16000 / 512.0, budget_s)
     return _cpu_entry(rate, thr_n, f"{ncall} one-second windows, batch 1, one oracle call per window (torch-CPU stand-in for "
-                                   f"ORT-CPU), {el:.1f} s")
+                                   f"ORT-CPU), {el:.1f} s", "firered")
 
 
 def cpu_baseline_dfsmn(budget_s, stride):
@@ -313,7 +361,7 @@ def cpu_baseline_dfsmn(budget_s, stride):
     nf = weights.DFSMN_MASK["layers"]
     rate, thr_n, ncall, el = timed_cpu(lambda: od.forward(fe, w, a, b, nf), stride / 512.0, budget_s, threads=(4,))
     return _cpu_entry(rate, thr_n, f"{ncall} windows of 16001 samples, batch 1, one oracle call per window at stride {stride} "
-                                   f"(torch-CPU stand-in for ORT-CPU; the reference pins 4 ORT threads for this model), {el:.1f} s")
+                                   f"(torch-CPU stand-in for ORT-CPU; the reference pins 4 ORT threads for this model), {el:.1f} s", "dfsmn")
 
 
 # ------------------------------------------------------------------------------------------------ the workloads
@@ -338,7 +386,7 @@ def fsmn_c3(torch, device, reps, cpu, clips=4096, log=lambda m: None):
            "roofline": _roof("fsmn_clips_kernel", frames10 * flop_fsmn_frame(), net_ms, "fsmn", "fsmn_clips_kernel"),
            "roofline_frontend": _roof("frontend_logmel_kernel", frames10 * flop_frontend_frame(257, 400),
                                       split.get("vadx_frontend_logmel", ms), "fsmn", "frontend_logmel_kernel"),
-           "hbm": _hbm(clips * (padded * 2 + (W * (eng.T - lb) + lb)), ms), "cpu_baseline": None}
+           "hbm": _hbm(clips * (padded * 2 + (W * (eng.T - lb) + lb)), ms, "fsmn"), "cpu_baseline": None}
     del audio
     if cpu:
         out["cpu_baseline"] = cpu_baseline_fsmn(cpu, stride)
@@ -365,7 +413,7 @@ def marblenet_c4(torch, device, reps, cpu, clips=8192, log=lambda m: None, tag="
            "roofline": _roof("frontend_logmel_kernel", clips * T * flop_frontend_frame(257, 400), fe_ms, tag, "frontend_logmel_kernel"),
            "roofline_net": _roof("marblenet encoder+decoder launches", clips * Tout * flop_marblenet_out_frame(), net_ms, tag, "vadx::marblenet::",
                                  note="sum of the encoder / classifier entries in kernel_ms (fused block pairs, single blocks, tail)"),
-           "hbm": _hbm(clips * (n * 2 + 2 * Tout * 4), ms), "cpu_baseline": None}
+           "hbm": _hbm(clips * (n * 2 + 2 * Tout * 4), ms, tag), "cpu_baseline": None}
     del audio
     if cpu:
         out["cpu_baseline"] = cpu_baseline_marblenet(cpu, n)
@@ -389,7 +437,7 @@ def firered_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None):
                              "firered_kernel"),
            "roofline_frontend": _roof("frontend_logmel_kernel", frames10 * flop_frontend_frame(201, 400),
                                       split.get("vadx_frontend_logmel", ms), "firered", "frontend_logmel_kernel"),
-           "hbm": _hbm(clips * (n * 2 + W * 98 * 4), ms), "cpu_baseline": None}
+           "hbm": _hbm(clips * (n * 2 + W * 98 * 4), ms, "firered"), "cpu_baseline": None}
     del audio
     if cpu:
         out["cpu_baseline"] = cpu_baseline_firered(cpu)
@@ -412,25 +460,83 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
     fl = flop_dfsmn_window()
     nwin = clips * W
     groups = {"lstm_f": split.get("vadx_dfsmn_lstm_f", 0.0), "dft_f": split.get("vadx_dfsmn_dft_f", 0.0),
-              "pw_conv": split.get("vadx_dfsmn_pw_conv", 0.0), "lstm_t": split.get("vadx_dfsmn_lstm_t", 0.0)}
+              "pw_conv": split.get("vadx_dfsmn_pw_conv", 0.0), "lstm_t": split.get("vadx_dfsmn_lstm_t", 0.0),
+              "cfb_front": split.get("vadx_dfsmn_cfb_front", 0.0), "cfb_back": split.get("vadx_dfsmn_cfb_back", 0.0)}
     dom = max(groups, key=groups.get)
+    if dom == "pw_conv":                                     # (only the unfused chain is dominated by the HBM-bound pw_conv launches)
+        dom = max((k for k in groups if k != "pw_conv"), key=groups.get)
     out = {"workload": f"DFSMN near+far f32 (SDAEC ICCRN echo canceller + mask-net VAD), batch={clips} clip pairs of 10 s = "
                        f"{nwin} windows of 16001 samples, measured at full size in sub-batches of {sub_batch} windows",
            "clip_pairs": clips, "samples_per_clip": n, "windows": nwin, "ms": ms,
            "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split, "kernel_calls": calls,
            "flop_per_window": fl,
-           "roofline": (_roof_hbm("pw_conv launches (vadx_dfsmn_pw_conv)", nwin * bytes_dfsmn_pw_window(), groups["pw_conv"], "dfsmn", "pw_conv",
-                                  note="all launches of the entry point that takes the most time; ~100 flop per 64-B row: HBM-bound")
-                        if dom == "pw_conv" else
-                        _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fl[dom], groups[dom], "dfsmn", dom,
-                              note="all launches of the entry point that takes the most time")),
+           "roofline": _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fl[dom], groups[dom], "dfsmn", dom,
+                             note="all launches of the entry point that takes the most time; flops as the reference computes them "
+                                  "(the kernel issues more: 20 output channels pad to 32 MFMA rows)"),
            "roofline_by_entry": {k: _roof(f"vadx_dfsmn_{k}", nwin * fl[k], v, "dfsmn", k) for k, v in groups.items() if v > 0},
            "roofline_whole_pass": _roof("all DFSMN launches", nwin * fl["total"], ms),
-           "hbm": _hbm(clips * (2 * padded * 2 + W * eng.T_A * 4), ms), "cpu_baseline": None}
+           "hbm": _hbm(clips * (2 * padded * 2 + W * eng.T_A * 4), ms, "dfsmn"), "cpu_baseline": None}
     del near, far
     if cpu:
         out["cpu_baseline"] = cpu_baseline_dfsmn(cpu, stride)
     return out
+
+
+def marblenet_c4_sharded(torch, device, dist, rank, world, reps=3, clips=8192, log=lambda m: None, feed=True):
+    """BASELINE config 4 as the config states it: 8192 clips of 89 431 samples STRONG-sharded over the node's GPUs -- rank r owns
+    clips shard_bounds(8192, r, world), no data-path collective; the time is the max over ranks between two barriers, the value
+    the whole job's 512-hop frames / s.  `feed`: the same shard timed from PINNED HOST int16 (vadx.feed.HostPcmFeed) -- what the
+    node sustains from host memory.  Every rank returns the same dict."""
+    from vadx import feed as vfeed, marblenet, shard, weights
+    eng = marblenet.MarbleNetEngine(weights.marblenet_synthetic(1234), device=device)
+    n = 89431
+    lo, hi = shard.shard_bounds(clips, rank, world)
+    audio = synth_pcm16(torch, device, hi - lo, n, seed=1404 + rank)
+    fence = lambda: shard.fence(dist, torch.cuda.synchronize)           # noqa: E731
+
+    def timed(fn):
+        fn()
+        best = None
+        for _ in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            fn()
+            fence()
+            el = shard.max_over_ranks(dist, time.perf_counter() - t0, device)
+            best = el if best is None else min(best, el)
+        return best
+
+    el = timed(lambda: eng.run(audio))
+    out = {"workload": f"MarbleNet v2.0 f32, {clips} clips x {n} samples strong-sharded over {world} GPU(s), no collective",
+           "clips": clips, "n_gpus": world, "shard": [lo, hi], "ms": el * 1e3, "frames_per_s": clips * n / 512 / el, "scaling": "strong"}
+    if feed:
+        try:
+            host = vfeed.pin(audio.cpu())
+            f = vfeed.HostPcmFeed(device, n, 128)
+            ref = eng.run(audio)
+            got = eng.run_from_host(host, feed=f)
+            same = bool(torch.equal(got[1], ref[1]))
+            elf = timed(lambda: eng.run_from_host(host, feed=f))
+            out["feed"] = {"ms": elf * 1e3, "frames_per_s": clips * n / 512 / elf, "upload_bytes_per_gpu": (hi - lo) * n * 2,
+                           "scores_bit_identical_to_resident": same}
+        except Exception as e:                               # noqa: BLE001  (pinned allocation can be refused)
+            out["feed"] = {"error": f"{type(e).__name__}: {e}"}
+    log(f"marblenet_c4 sharded x{world}: {out['ms']:.2f} ms")
+    return out
+
+
+def compact(entry):
+    """The few numbers of one workload that go into bench.py's JSON line (the full entry goes to the detail file)."""
+    if entry is None or "error" in entry:
+        return entry
+    ro = entry.get("roofline") or {}
+    cpu = entry.get("cpu_baseline") or {}
+    hbm = entry.get("hbm") or {}
+    r3 = lambda v: None if v is None else float(f"{v:.4g}")      # noqa: E731
+    out = {"ms": r3(entry.get("ms")), "frames_per_s": r3(entry.get("frames_per_s")), "kernel": ro.get("kernel"), "frac": r3(ro.get("frac")),
+           "bound": ro.get("bound"), "traffic_ratio": r3(hbm.get("traffic_ratio")), "launches": hbm.get("launches_per_pass"),
+           "cpu": r3(cpu.get("value")), "cpu_published": r3((cpu.get("reference_published") or {}).get("frames_per_s"))}
+    return {k: v for k, v in out.items() if v is not None}
 
 
 WORKLOADS = {"fsmn_c3": fsmn_c3, "marblenet_c4": marblenet_c4, "firered_c5": firered_c5, "dfsmn_c5": dfsmn_c5}

@@ -364,6 +364,31 @@ int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float 
                       const float *const w_hh[2], const float *const b_ih[2], const float *const b_hh[2],
                       const vadx_ft_view *out, int F, int tiles, void *stream);
 
+/* One gated conv block (CFB :76-93 with its CepsUnit :96-154) as two streaming launches around vadx_dfsmn_lstm_f
+ * (csrc/dfsmn_cfb.hip): the block's 20-channel intermediates gx, r, lo, ceps never reach memory.
+ *   front: cat(a, b) (20 or 40 ch x 160, LN0 statistics stats0[tile][16][2] as frame_stats / stats_merge give them)
+ *          -> y1 [tiles][20][160][16] = conv31(ln1_w * gx) WITHOUT LayerNorm 1's (mean, inv, bias) and the conv bias,
+ *             stats1 [tile][16][2] = (mean, 1/(std + 1e-6)) of gx,
+ *             li [tiles][40][81][16] = DFT_F(LN2(xi - gx)) (real | imaginary parts) and its statistics stats_li for the LSTM's LayerNorm;
+ *   back:  hf (the LSTM output, [tiles][40][81][16]), li, y1, stats1 -> out (20-channel slice of an FT tensor)
+ *          = conv31(LN1(gx)) + bias + ceps_unit(...), part (optional): its partial statistics for vadx_dfsmn_stats_merge.
+ * All pointers are device pointers; the derived tables are built on the host (vadx/dfsmn.py: Iccrn._cfb_tables):
+ *   gate_w / in_w [32][cin], gate_b / in_b [32] (rows >= 20 zero); conv_w [32][60], column tap * 20 + ci;
+ *   fwd_tbl [10 row tiles][40 k-steps][64 lanes]: lane (q, i) of fragment (m, s) = T[16 m + i][4 s + q], T = the 160 x 160 forward
+ *           table of vadx_dfsmn_dft_f; fwd_fix [20 ch][10][64]: lane quarter q = 0 -> (T ln2_w[c])[16 m + i], q = 1 -> (T ln2_b[c])[..], else 0;
+ *   lin_w [48][40], lin_b [48]: CepsUnit's Linear with rows permuted so that row 16 t + 4 q + r = (r >> 1 ? imaginary : real) output
+ *           of channel 8 t + 2 q + (r & 1) (zero rows for channels >= 20);
+ *   inv_tbl [10][41][64]: k-steps 0..20 = real parts of bins 4 s .. 4 s + 3, 21..40 = imaginary parts of bins 4 (s - 21) .. + 3
+ *           (zero for bin 0 and bins > 80); out_fix [20][10][64]: q = 0 -> conv31(ln1_w)[c][16 m + i], q = 1 -> conv31(ln1_b) + bias. */
+typedef struct vadx_dfsmn_cfb_weights {
+    const float *ln0_w, *ln0_b, *gate_w, *gate_b, *in_w, *in_b, *ln1_w, *conv_w, *ln2_w, *fwd_tbl, *fwd_fix, *lin_w, *lin_b,
+                *inv_tbl, *out_fix;
+} vadx_dfsmn_cfb_weights;
+int vadx_dfsmn_cfb_front(const vadx_dfsmn_cfb_weights *w, const vadx_ft_view *a, const vadx_ft_view *b, const float *stats0,
+                         float *y1, float *stats1, float *li, float *stats_li, int tiles, void *stream);
+int vadx_dfsmn_cfb_back(const vadx_dfsmn_cfb_weights *w, const float *hf, const float *li, const float *y1, const float *stats1,
+                        const vadx_ft_view *out, float *part, int tiles, void *stream);
+
 /* x4 = [mix_re, mix_im, |alpha| far_re, |alpha| far_im] (FT, 4 ch x 160), DFSMN_VAD.forward :326-335.
  * pow_far NULL: far power from channels 2, 3 (near + far model).  pow_far = [160][frames][10] floats: the near-end-only
  * model's baked far-end power (DFSMN/only_near_end_audio/Export_DFSMN_VAD.py:309, :327); channels 2, 3 of `in` then

@@ -39,7 +39,8 @@ def test_secondary_flop_formulas():
     assert bm.flop_marblenet_out_frame() == 2 * 89456                # published 3x2x64 layout, per 20 ms output frame
     assert bm.flop_firered_frame() == 2 * 585984                     # placeholder dims of SURVEY appendix B
     d = bm.flop_dfsmn_window()
-    assert d["total"] == sum(v for k, v in d.items() if k != "total")
+    assert d["total"] == sum(v for k, v in d.items() if k not in ("total", "cfb_front", "cfb_back"))      # the fused kernels regroup pw_conv / dft_f work
+    assert d["cfb_front"] + d["cfb_back"] < d["pw_conv"] + d["dft_f"] + d["lstm_f"]
     assert 5.5e9 < d["total"] < 6.5e9 and d["lstm_f"] > d["lstm_t"] > d["istft"]
 
 
@@ -69,6 +70,7 @@ def test_self_launch_two_ranks_dry_run():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] is None and d["data"].startswith("dry-run")
     assert d["config"]["shards"] == [[0, 0, 10], [1, 10, 20]]       # contiguous clip shards in rank order
+    assert d["c4_sharded"]["shards"] == [[0, 0, 4096], [1, 4096, 8192]] and d["c4_sharded"]["scaling"] == "strong"      # BASELINE config 4
     assert d["ms_per_step"] >= 5.0
 
 
@@ -82,11 +84,15 @@ def test_gpus_flag_must_match_world_size():
 @pytest.mark.gpu
 def test_bench_prints_one_contract_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--clips", "64", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--no-cpu-baseline", "--no-secondary", "--no-c4-sharded", "--detail", os.path.join(ROOT, "gpurun_out", "test_detail.json")],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
+    assert len(lines[0]) < 6144                                       # the driver records the tail of the line
     d = json.loads(lines[0])
+    full = json.load(open(os.path.join(ROOT, "gpurun_out", "test_detail.json")))
+    assert full["value"] == d["value"] and "instruction_mix" in full["roofline"]
     assert REQUIRED <= set(d)
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None

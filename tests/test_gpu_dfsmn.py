@@ -41,6 +41,33 @@ def test_cfb_block(wts, name, cin, frames, chunks):
     assert err < 2e-4 * max(1.0, want.abs().max().item()), err
 
 
+@pytest.mark.parametrize("name,cin,frames,chunks", [("cfb_e2", 20, 101, 3), ("cfb_d2", 40, 53, 2), ("cfb_d5", 20, 16, 300)])
+def test_fused_cfb_equals_the_unfused_chain(wts, name, cin, frames, chunks):
+    """cfb_front -> lstm_f -> cfb_back (LayerNorm 1 / 2 commuted behind the (3,1) conv / the DFT, every intermediate on chip) against
+    the six-launch chain of building-block kernels with every intermediate in HBM: same block, re-associated sums only; the
+    partial statistics cfb_back emits merge to what a separate pass over its output measures; more tiles than workgroups
+    (300 > 256 CUs) exercise the persistent loop."""
+    w, _ = wts
+    net = dfsmn.Iccrn(w)
+    tiles = chunks * dfsmn.ft_tiles(frames)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(chunks, cin, 160, frames, generator=g) * 0.9 + 0.3
+    xin = dfsmn.to_ft(torch, x, net.device)
+    a, b = (xin.view(), None) if cin == 20 else (xin.view(0, 20), xin.view(20, 20))
+    out_f = dfsmn.FT(torch, net.device, chunks, frames, 40, 160)          # written into channel slice [20, 40) of a 40-channel tensor
+    out_u = dfsmn.FT(torch, net.device, chunks, frames, 20, 160)
+    _, part_f = net.cfb(name, a, b, out_f.view(20, 20), chunks, frames)
+    _, part_u = net.cfb_unfused(name, a, b, out_u.view(), chunks, frames)
+    got, want = dfsmn.from_ft(out_f, chunks)[:, 20:].cpu(), dfsmn.from_ft(out_u, chunks).cpu()
+    assert torch.isfinite(got).all()
+    scale = max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() < 2e-5 * scale
+    sf, su = net.merged_stats(part_f, None, tiles), net.stats(out_f.view(20, 20), None, 160, tiles)
+    valid = torch.arange(dfsmn.ft_tiles(frames) * 16, device=sf.device).view(-1, 16) < frames      # padding frames hold zeros / garbage
+    valid = valid.repeat(chunks, 1)
+    torch.testing.assert_close(sf[valid], su[valid], rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("chunks,frames", [(3, 101), (4200, 16)])       # 21 tiles: two workgroups per tile; 4200: one
 def test_fused_layernorm_statistics_match_the_separate_pass(wts, chunks, frames):
     """The partial statistics pw_conv emits while writing a tensor, merged (one tensor and a channel concatenation of

@@ -226,3 +226,35 @@ def test_file_lists_run_as_length_groups_and_match_single_runs(tmp_path):
             assert many[k] == one, (run.__name__, k)
     with pytest.raises(ValueError, match="no weights given"):
         drivers.inference_fsmn(paths[0], None, echo=quiet)
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_host_feed_is_bitwise_the_resident_path(pinned):
+    """SURVEY 8e for the int16 engines: the batch stays in (pinned) HOST memory and crosses PCIe chunk by chunk on a copy stream
+    while the previous chunk's launches run (vadx.feed.HostPcmFeed) -- FSMN flags, MarbleNet / FireRed scores and DFSMN window
+    scores equal the resident batch's bit for bit, also with a ragged last chunk and when the feed object is reused."""
+    from vadx import dfsmn, feed, firered, fsmn, marblenet
+    prep = (lambda a: feed.pin(a)) if pinned else (lambda a: torch.from_numpy(a))
+    # FSMN: 3 windows per clip on the engine's grid, 7 clips in chunks of 3 (3 + 3 + 1)
+    eng = fsmn.FsmnEngine("synthetic:1234")
+    lb, stride = eng.grid()
+    W = 3
+    pcm = weights.burst_clips(7, (W - 1) * stride + eng.L, seed=31)
+    f = feed.HostPcmFeed(eng.device, pcm.shape[1], 3)
+    for _ in range(2):
+        assert torch.equal(eng.flags_from_host(prep(pcm), W, feed=f), eng.flags(torch.from_numpy(pcm).cuda(), W))
+    # MarbleNet: one dynamic-axis window per clip
+    mb = marblenet.MarbleNetEngine("synthetic:1234")
+    pcm = weights.burst_clips(5, 24000, seed=32)
+    got, want = mb.run_from_host(prep(pcm), chunk_clips=2), mb.run(torch.from_numpy(pcm).cuda())
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and got[2] == want[2]
+    # FireRed: two one-second windows per clip
+    fr = firered.FireRedEngine("synthetic:1234")
+    pcm = weights.burst_clips(5, 32000, seed=33)
+    assert torch.equal(fr.run_from_host(prep(pcm), 2, chunk_clips=4), fr.run(torch.from_numpy(pcm).cuda(), 2))
+    # DFSMN near + far: two parallel streams per chunk
+    df = dfsmn.DfsmnEngine("synthetic:1234")
+    near, far = weights.burst_clips(3, 16001, seed=34), weights.burst_clips(3, 16001, seed=35)
+    assert torch.equal(df.run_from_host(prep(near), prep(far), chunk_clips=2), df.run(torch.from_numpy(near).cuda(), torch.from_numpy(far).cuda()))
+    with pytest.raises(ValueError):
+        f.map([torch.from_numpy(pcm).cuda()], lambda a: a)

@@ -84,6 +84,11 @@ class FtLn(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p)]
 
 
+class DfsmnCfbWeights(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("ln0_w", "ln0_b", "gate_w", "gate_b", "in_w", "in_b", "ln1_w", "conv_w", "ln2_w", "fwd_tbl",
+                                          "fwd_fix", "lin_w", "lin_b", "inv_tbl", "out_fix")]
+
+
 class DfsmnMaskWeights(C.Structure):
     _fields_ = [("hidden", C.c_int), ("fsmn_hidden", C.c_int), ("layers", C.c_int), ("lorder", C.c_int),
                 ("shift", C.c_void_p), ("scale", C.c_void_p), ("linear1_w", C.c_void_p), ("linear1_b", C.c_void_p),
@@ -139,6 +144,8 @@ SIGNATURES = {
     "vadx_dfsmn_dft_f": (_I, [_I, C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtLn), _P, C.POINTER(FtView), _I, _I, _P, _P]),
     "vadx_dfsmn_lstm_f": (_I, [C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
                                C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), C.POINTER(FtView), _I, _I, _P]),
+    "vadx_dfsmn_cfb_front": (_I, [C.POINTER(DfsmnCfbWeights), C.POINTER(FtView), C.POINTER(FtView), _P, _P, _P, _P, _P, _I, _P]),
+    "vadx_dfsmn_cfb_back": (_I, [C.POINTER(DfsmnCfbWeights), _P, _P, _P, _P, C.POINTER(FtView), _P, _I, _P]),
     "vadx_dfsmn_alpha_scale": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "vadx_dfsmn_lstm_t": (_I, [_I, C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
                                C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), _P, _P, C.POINTER(FtView),

@@ -141,15 +141,16 @@ def firered_from_state(args, state, cmvn=None):
 
 
 def _torch_load(src, what):
-    """torch.load restricted to tensors / containers / argparse.Namespace (`weights_only=True`): a downloaded checkpoint is a
+    """torch.load restricted to tensors / containers / plain namespaces (`weights_only=True`): a downloaded checkpoint is a
     pickle, and these loaders are reachable from any engine's `weights=<path>` string.  A file that needs more than that is
     refused unless the caller opts in with VADX_TRUST_CHECKPOINTS=1 (full unpickling executes code from the file: only for
     files whose origin is trusted)."""
     import argparse
     import pickle
+    import types
     import torch
     try:
-        with torch.serialization.safe_globals([argparse.Namespace]):
+        with torch.serialization.safe_globals([argparse.Namespace, types.SimpleNamespace]):      # plain attribute holders (`args`)
             return torch.load(src, map_location="cpu", weights_only=True)
     except pickle.UnpicklingError as e:
         if os.environ.get("VADX_TRUST_CHECKPOINTS") != "1":

@@ -69,6 +69,7 @@ class Iccrn:
              if k.startswith("iccrn.")}
         self.w = w
         self.d = {}
+        self._cfb_cache = {}
 
         def dev(name, arr):
             self.d[name] = t.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
@@ -149,10 +150,103 @@ class Iccrn:
                                               C.byref(bi), C.byref(bh), C.byref(out), F, tiles, _lib.stream_ptr()))
 
     # ---- CFB (:76-93) ---------------------------------------------------------------------------
+    def _cfb_tables(self, name):
+        """Device-side `vadx_dfsmn_cfb_weights` of one block (include/vadx.h): the block's own weights plus the tables the two
+        streaming kernels derive from them -- DFT tables in MFMA fragment order, CepsUnit's Linear with (re, im) rows paired per
+        lane, and the LayerNorm corrections TW = T w2, TB = T b2, CW = conv31(w1), CB = conv31(b1) + bias (float64 on the host)."""
+        if name in self._cfb_cache:
+            return self._cfb_cache[name]
+        t, w = self.torch, self.w
+        keep = []
+
+        def dev(a):
+            d = t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+            keep.append(d)
+            return d.data_ptr()
+
+        def frag(tbl, ksteps, col):
+            """[160][*] table -> [10 row tiles][ksteps][64 lanes]: lane (q, i) of (m, s) = tbl[16 m + i][col(s, q)] (col < 0: zero)"""
+            out = np.zeros((10, ksteps, 64), np.float64)
+            for s_ in range(ksteps):
+                for q in range(4):
+                    k = col(s_, q)
+                    if k >= 0:
+                        out[:, s_, 16 * q:16 * q + 16] = tbl[:, k].reshape(10, 16)
+            return out
+
+        def fix(a, b):
+            """two [20][160] tables -> [20][10][64]: lane quarter 0 = a, quarter 1 = b, rest zero"""
+            out = np.zeros((CH, 10, 64), np.float64)
+            out[:, :, 0:16] = a.reshape(CH, 10, 16)
+            out[:, :, 16:32] = b.reshape(CH, 10, 16)
+            return out
+
+        fwd = self.tbl_fwd.cpu().numpy().astype(np.float64)                  # [160 rows][160 f]
+        inv = self.tbl_inv.cpu().numpy().astype(np.float64)                  # [160 f][160 k: re 0..80 | im 1..79]
+        def inv_col(s_, q):
+            if s_ < 21:
+                k = 4 * s_ + q
+                return k if k <= 80 else -1
+            k = 4 * (s_ - 21) + q                                             # imaginary part of bin k
+            return 80 + k if 1 <= k <= 79 else -1
+        ln1_w, ln1_b = w[name + ".LN1.w"].reshape(CH, F_BINS).astype(np.float64), w[name + ".LN1.b"].reshape(CH, F_BINS).astype(np.float64)
+        ln2_w, ln2_b = w[name + ".LN2.w"].reshape(CH, F_BINS).astype(np.float64), w[name + ".LN2.b"].reshape(CH, F_BINS).astype(np.float64)
+        w31 = w[name + ".conv.weight"][:, :, :, 0].astype(np.float64)       # [co][ci][tap]
+        def conv31(x):                                                        # [ci][160] -> [co][160], zero padding
+            xp = np.pad(x, ((0, 0), (1, 1)))
+            return sum(w31[:, :, tap] @ xp[:, tap:tap + F_BINS] for tap in range(3))
+        lin_w, lin_b = w[name + ".ceps_unit.ch_lstm_f.linear.weight"], w[name + ".ceps_unit.ch_lstm_f.linear.bias"]
+        lw, lb = np.zeros((48, 2 * CH), np.float32), np.zeros(48, np.float32)
+        for row in range(48):
+            tile, qq, rr = row // 16, (row % 16) // 4, row % 4
+            c = 8 * tile + 2 * qq + (rr & 1)
+            if c < CH:
+                lw[row], lb[row] = lin_w[(rr >> 1) * CH + c], lin_b[(rr >> 1) * CH + c]
+        cw = _lib.DfsmnCfbWeights()
+        cw.ln0_w, cw.ln0_b = self._p(name + ".LN0.w"), self._p(name + ".LN0.b")
+        cw.gate_w, cw.gate_b = self._p(name + ".conv_gate.weight"), self._p(name + ".conv_gate.bias")
+        cw.in_w, cw.in_b = self._p(name + ".conv_input.weight"), self._p(name + ".conv_input.bias")
+        cw.ln1_w, cw.ln2_w, cw.conv_w = self._p(name + ".LN1.w"), self._p(name + ".LN2.w"), self._p(name + ".conv.weight")
+        cw.fwd_tbl = dev(frag(fwd, 40, lambda s_, q: 4 * s_ + q))
+        cw.fwd_fix = dev(fix(ln2_w @ fwd.T, ln2_b @ fwd.T))
+        cw.lin_w, cw.lin_b = dev(lw), dev(lb)
+        cw.inv_tbl = dev(frag(inv, 41, inv_col))
+        cw.out_fix = dev(fix(conv31(ln1_w), conv31(ln1_b) + w[name + ".conv.bias"].astype(np.float64)[:CH, None]))
+        self._cfb_cache[name] = (cw, keep)
+        return self._cfb_cache[name]
+
     def cfb(self, name, a, b, out, n_chunks, frames, scratch=None, a_part=None, b_part=None):
-        """y = CFB(cat(a, b)) written into the view `out` (20 channels).  a_part / b_part: the partial statistics the
-        producers of a / b emitted (None: a separate frame_stats pass over the tensor); returns (scratch, partials of y).
-        Every LayerNorm inside the block takes its statistics from the kernel that wrote its input."""
+        """y = CFB(cat(a, b)) written into the view `out` (20 channels): cfb_front -> lstm_f -> cfb_back (csrc/dfsmn_cfb.hip).
+        a_part / b_part: the partial statistics the producers of a / b emitted (None: a frame_stats pass over the tensor);
+        returns (scratch, partial statistics of y)."""
+        t, dev = self.torch, self.device
+        tiles = n_chunks * ft_tiles(frames)
+        sc = scratch if scratch is not None else {}
+        def buf(key, ch, bins):
+            if key not in sc or sc[key].tiles != tiles:
+                sc[key] = FT(t, dev, n_chunks, frames, ch, bins, zero=False)
+            return sc[key]
+        y1, li, hf = buf("y1", CH, F_BINS), buf("li", 2 * CH, CEPS_F), buf("hf", 2 * CH, CEPS_F)
+        def sbuf(key):
+            if key not in sc or sc[key].shape[0] != tiles:
+                sc[key] = t.empty((tiles, 16, 2), dtype=t.float32, device=dev)
+            return sc[key]
+        s1, sl = sbuf("stats1"), sbuf("stats_li")
+        out_part = self.new_part(tiles)                 # outlives the block (encoder outputs are normalised again by the decoder)
+        have = a_part is not None and (b is None or b_part is not None)
+        s0 = self.merged_stats(a_part, b_part if b is not None else None, tiles) if have else self.stats(a, b, F_BINS, tiles)
+        cw, _keep = self._cfb_tables(name)
+        st = _lib.stream_ptr()
+        _lib.check(self.lib.vadx_dfsmn_cfb_front(C.byref(cw), C.byref(a), None if b is None else C.byref(b), s0.data_ptr(),
+                                                 y1.data.data_ptr(), s1.data_ptr(), li.data.data_ptr(), sl.data_ptr(), tiles, st))
+        self.lstm_f(name + ".ceps_unit.ch_lstm_f", li.view(), self._ln(sl, name + ".ceps_unit.LN"), hf.view(), CEPS_F, tiles)
+        _lib.check(self.lib.vadx_dfsmn_cfb_back(C.byref(cw), hf.data.data_ptr(), li.data.data_ptr(), y1.data.data_ptr(), s1.data_ptr(),
+                                                C.byref(out), out_part.data_ptr(), tiles, st))
+        return sc, out_part
+
+    def cfb_unfused(self, name, a, b, out, n_chunks, frames, scratch=None, a_part=None, b_part=None):
+        """The same block as six launches of the building-block kernels (pw_conv / dft_f / lstm_f, csrc/dfsmn.hip) with every
+        intermediate in HBM: the A/B reference for `cfb` (tests/test_gpu_dfsmn.py) -- not used by the engine."""
         t, dev = self.torch, self.device
         tiles = n_chunks * ft_tiles(frames)
         sc = scratch if scratch is not None else {}
@@ -338,6 +432,14 @@ class DfsmnEngine:
             if return_aec:
                 aec_all[b0 * W:(b0 + nb) * W] = a
         return (vad, aec_all) if return_aec else vad
+
+    def run_from_host(self, host_near_i16, host_far_i16, windows_per_clip=1, win_stride=None, chunk_clips=64, feed=None):
+        """`run` fed from HOST memory (two int16 [B, N] tensors, ideally pinned: vadx.feed.pin), uploads overlapped with compute
+        (vadx.feed.HostPcmFeed with two streams); bit-identical to `run` of the resident batch when chunk_clips * windows_per_clip
+        is a multiple of the engine's sub-batch cut or below it (the same launches see the same windows)."""
+        from . import feed as _feed
+        f = feed or _feed.HostPcmFeed(self.device, host_near_i16.shape[1], chunk_clips, streams=2)
+        return _feed.cat_results(f.map([host_near_i16, host_far_i16], lambda a, b: self.run(a, b, windows_per_clip, win_stride)))
 
     def _run_sub(self, near, far, W, ws):
         t, lib = self.torch, self.lib

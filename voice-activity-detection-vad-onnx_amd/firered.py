@@ -79,6 +79,13 @@ class FireRedEngine:
                                                    probs.data_ptr(), _lib.stream_ptr()))
         return probs
 
+    def run_from_host(self, host_i16, windows_per_clip=1, chunk_clips=256, feed=None):
+        """`run` fed from HOST memory (int16 [B, W*L], ideally pinned: vadx.feed.pin), uploads overlapped with compute
+        (vadx.feed.HostPcmFeed); bit-identical to `run` of the resident batch."""
+        from . import feed as _feed
+        f = feed or _feed.HostPcmFeed(self.device, host_i16.shape[1], chunk_clips)
+        return _feed.cat_results(f.map([host_i16], lambda a: self.run(a, windows_per_clip)))
+
     def _frontend_for(self, length):
         fe = self._fes.get(length)
         if fe is None:

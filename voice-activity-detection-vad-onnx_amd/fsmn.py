@@ -134,6 +134,13 @@ class FsmnEngine:
                                                   None if trace is None else trace.data_ptr(), _lib.stream_ptr()))
         return (flags, trace) if return_noise else flags
 
+    def flags_from_host(self, host_padded_i16, windows_per_clip, chunk_clips=256, feed=None, **loop_kw):
+        """`flags` fed from HOST memory (int16 [B, (W-1)*stride + L], ideally pinned: vadx.feed.pin): chunks of clips are uploaded on
+        a copy stream while the previous chunk's launches run (vadx.feed.HostPcmFeed); bit-identical to `flags` of the resident batch."""
+        from . import feed as _feed
+        f = feed or _feed.HostPcmFeed(self.device, host_padded_i16.shape[1], chunk_clips)
+        return _feed.cat_results(f.map([host_padded_i16], lambda a: self.flags(a, windows_per_clip, **loop_kw)))
+
     def detect(self, clips_i16, pad_noise=None, fusion_threshold=0.3, min_speech_duration=0.2, normalize=True, **loop_kw):
         """Equal-length clips int16 [B,N] (host numpy) -> per clip [(start_s, end_s)], as the reference
         script would print for each.  pad_noise: standard-normal array [B, >=pad] replacing the

@@ -108,6 +108,13 @@ class MarbleNetEngine:
                                                  cur_T, s0.data_ptr(), s1.data_ptr(), _lib.stream_ptr()))
         return s0, s1, cur_T - 1
 
+    def run_from_host(self, host_i16, windows_per_clip=1, window_len=None, chunk_clips=256, feed=None):
+        """`run` fed from HOST memory (int16 [B, W*L], ideally pinned: vadx.feed.pin), the upload of chunk k + 1 overlapped with the
+        launches of chunk k (vadx.feed.HostPcmFeed); bit-identical to `run` of the resident batch."""
+        from . import feed as _feed
+        f = feed or _feed.HostPcmFeed(self.device, host_i16.shape[1], chunk_clips)
+        return _feed.cat_results(f.map([host_i16], lambda a: self.run(a, windows_per_clip, window_len)))
+
     def _run_fused(self, x, N, T):
         """Published layout: block 1 (stride 2, time-major log-mel in) through the per-sub-block entry, blocks 2-4 as one
         fused launch each (the tensor between a block's two sub-blocks stays in LDS), blocks 5 + 6 + Linear + softmax as one
