@@ -373,7 +373,9 @@ int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float 
  *   back:  hf (the LSTM output, [tiles][40][81][16]), li, y1, stats1 -> out (20-channel slice of an FT tensor)
  *          = conv31(LN1(gx)) + bias + ceps_unit(...), part (optional): its partial statistics for vadx_dfsmn_stats_merge.
  * All pointers are device pointers; the derived tables are built on the host (vadx/dfsmn.py: Iccrn._cfb_tables):
- *   gate_w / in_w [32][cin], gate_b / in_b [32] (rows >= 20 zero); conv_w [32][60], column tap * 20 + ci;
+ *   ln0_w [cin][160]; gate_w / in_w [32][cin], in_b [32] (rows >= 20 zero); conv_w [32][60], column tap * 20 + ci;
+ *   front_tab [160 bins][4][20 channels]: (conv_gate ln0_w, conv_gate ln0_b + gate bias, ln1_w, ln2_w) -- LayerNorm 0 is applied
+ *           BEHIND the gate conv: pre-activation = inv0 * (Wg (ln0_w * x)) + front_tab[1] - mean0 * inv0 * front_tab[0];
  *   fwd_tbl [10 row tiles][40 k-steps][64 lanes]: lane (q, i) of fragment (m, s) = T[16 m + i][4 s + q], T = the 160 x 160 forward
  *           table of vadx_dfsmn_dft_f; fwd_fix [20 ch][10][64]: lane quarter q = 0 -> (T ln2_w[c])[16 m + i], q = 1 -> (T ln2_b[c])[..], else 0;
  *   lin_w [48][40], lin_b [48]: CepsUnit's Linear with rows permuted so that row 16 t + 4 q + r = (r >> 1 ? imaginary : real) output
@@ -381,8 +383,7 @@ int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float 
  *   inv_tbl [10][41][64]: k-steps 0..20 = real parts of bins 4 s .. 4 s + 3, 21..40 = imaginary parts of bins 4 (s - 21) .. + 3
  *           (zero for bin 0 and bins > 80); out_fix [20][10][64]: q = 0 -> conv31(ln1_w)[c][16 m + i], q = 1 -> conv31(ln1_b) + bias. */
 typedef struct vadx_dfsmn_cfb_weights {
-    const float *ln0_w, *ln0_b, *gate_w, *gate_b, *in_w, *in_b, *ln1_w, *conv_w, *ln2_w, *fwd_tbl, *fwd_fix, *lin_w, *lin_b,
-                *inv_tbl, *out_fix;
+    const float *ln0_w, *gate_w, *in_w, *in_b, *front_tab, *conv_w, *fwd_tbl, *fwd_fix, *lin_w, *lin_b, *inv_tbl, *out_fix;
 } vadx_dfsmn_cfb_weights;
 int vadx_dfsmn_cfb_front(const vadx_dfsmn_cfb_weights *w, const vadx_ft_view *a, const vadx_ft_view *b, const float *stats0,
                          float *y1, float *stats1, float *li, float *stats_li, int tiles, void *stream);

@@ -220,16 +220,18 @@ def forward(fe, w, near_i16, far_i16, n_fsmn, near_only=None):
 def tail_flags(score, start, stop, silence, hi=0.5, lo=0.5):
     """Tail rule of the DFSMN loop. ref: DFSMN/.../Inference_DFSMN_VAD_ONNX.py:262-273."""
     flags = []
+    hi, lo = np.float32(hi), np.float32(lo)       # float32 comparisons, as NumPy 2 evaluates `float32_score >= python_float`
     for i in range(start, stop):
         if silence:
-            silence = not (score[i] >= hi)
+            silence = not (np.float32(score[i]) >= hi)
         else:
-            silence = bool(score[i] <= lo)
+            silence = bool(np.float32(score[i]) <= lo)
         flags.append(silence)
     return flags, silence
 
 
-def run_clip(fe, w, near_1d, far_1d, pad_noise_near, pad_noise_far, n_fsmn, L=16001, look_backward_s=0.3, near_only=None):
+def run_clip(fe, w, near_1d, far_1d, pad_noise_near, pad_noise_far, n_fsmn, L=16001, look_backward_s=0.3, near_only=None,
+             speaking=0.5, silence_score=0.5):
     """Whole-clip driver. ref: Inference_DFSMN_VAD_ONNX.py:124-163 (prep), :221-278 (loop); far_1d None = the
     near-end-only driver (DFSMN/only_near_end_audio/Inference_DFSMN_VAD_ONNX.py:120-145, same loop)."""
     n = len(near_1d) if far_1d is None else min(len(near_1d), len(far_1d))
@@ -247,10 +249,10 @@ def run_clip(fe, w, near_1d, far_1d, pad_noise_near, pad_noise_far, n_fsmn, L=16
         a = torch.from_numpy(near[s:s + L].copy()).reshape(1, 1, -1)
         b = None if far is None else torch.from_numpy(far[s:s + L].copy()).reshape(1, 1, -1)
         vad = forward(fe, w, a, b, n_fsmn, near_only)[0].numpy()
-        flags, silence = postproc.lookahead_vote(vad, len(vad) - lb, lb, 0.5, 0.5, silence, thresholds=(0.5, 0.5))
+        flags, silence = postproc.lookahead_vote(vad, len(vad) - lb, lb, speaking, silence_score, silence, thresholds=(speaking, silence_score))
         saved += flags
         s += stride
-    flags, silence = tail_flags(vad, len(vad) - lb, len(vad), silence)
+    flags, silence = tail_flags(vad, len(vad) - lb, len(vad), silence, speaking, silence_score)
     saved += flags
     ts = postproc.vad_to_timestamps(saved, frame / 16000)
     return postproc.process_timestamps(ts, 0.3, 0.2), saved

@@ -129,9 +129,11 @@ def lookahead_vote(score, slide_range, look_backward, speaking_score, silence_sc
         on = lambda v: v != inactive_value      # noqa: E731  "frame looks active"
         off = lambda v: v != active_value       # noqa: E731  "frame looks inactive"
     else:
-        hi, lo = thresholds
-        on = lambda v: v >= hi                  # noqa: E731
-        off = lambda v: v <= lo                 # noqa: E731
+        # float32 score against a Python-float constant: NumPy 2 (NEP 50) compares in float32 -- the fixtures were produced by
+        # the reference's loop under NumPy 2.2, and a score sitting exactly on float32(0.7) counts as >= 0.7 there
+        hi, lo = np.float32(thresholds[0]), np.float32(thresholds[1])
+        on = lambda v: np.float32(v) >= hi      # noqa: E731
+        off = lambda v: np.float32(v) <= lo     # noqa: E731
     for i in range(slide_range):
         if silence:
             if on(score[i]):

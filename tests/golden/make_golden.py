@@ -816,6 +816,79 @@ def gen_fsmn_extra():
     save("fsmn_extra", **out)
 
 
+def gen_hostloop_thresholds():
+    """Round 3: the asymmetric SPEAKING_SCORE / SILENCE_SCORE branches of both look-ahead host loops (every earlier fixture used the
+    defaults 0.5 / 0.5): FSMN/Inference_FSMN_VAD_ONNX.py:21-23,188-215 on replayed uint8 scores and
+    DFSMN/near_and_far_end_audio/Inference_DFSMN_VAD_ONNX.py:22-27,231-258 on replayed float scores, the reference's own
+    module-level loops executed with the constants overridden."""
+    rng = np.random.default_rng(4321)
+    out = {}
+    pairs = [(0.7, 0.3), (0.3, 0.7), (0.9, 0.1), (0.6, 0.6), (0.2, 0.4)]
+    out["pairs"] = np.array(pairs, np.float64)
+    for case, (spk, sil) in enumerate(pairs):
+        # ---- FSMN: 6 chunks of uint8 scores with persistent runs
+        n_chunks = 6
+        scores = []
+        st = int(rng.integers(0, 2))
+        for k in range(n_chunks):
+            s_ = np.zeros(101, np.uint8)
+            for i in range(101):
+                if rng.uniform() < 0.08:
+                    st = 1 - st
+                s_[i] = st if rng.uniform() < 0.75 else int(rng.uniform() < 0.5)
+            scores.append(s_)
+        noisy_seq = [float(v) for v in rng.uniform(-0.5, 2.0, n_chunks)]
+
+        class FakeSess:
+            def __init__(self):
+                self.k = 0
+
+            def run(self, names, feeds):
+                k = self.k
+                self.k += 1
+                z = np.zeros((1, 128, 19, 1), np.float32)
+                return scores[k], z, z, z, z, np.float32(noisy_seq[k])
+
+        aligned = (n_chunks - 1) * 11040 + 16000
+        env = dict(np=np, time=__import__("time"), ort_session_A=FakeSess(), model_type="tensor(float)",
+                   BACKGROUND_NOISE_dB_INIT=30.0, SNR_THRESHOLD=10.0, ONE_MINUS_SPEECH_THRESHOLD=1.0,
+                   INPUT_AUDIO_LENGTH=16000, aligned_len=aligned, audio=np.zeros((1, 1, aligned), np.int16),
+                   slide_range=71, look_backward=30, inv_look_backward=float(1.0 / 30), SPEAKING_SCORE=spk,
+                   SILENCE_SCORE=sil, inv_audio_len=0.0, stride_step=11040, score_len=101,
+                   print=lambda *a, **k: None)
+        for i in range(7):
+            env[f"in_name_A{i}"] = f"i{i}"
+        for i in range(6):
+            env[f"out_name_A{i}"] = f"o{i}"
+        R.select_lines("FSMN/Inference_FSMN_VAD_ONNX.py", 156, 234, env)
+        out[f"fsmn_scores_{case}"] = np.stack(scores)
+        out[f"fsmn_noisy_{case}"] = np.array(noisy_seq, np.float32)
+        out[f"fsmn_saved_{case}"] = np.array(env["saved"], dtype=bool)
+        # ---- DFSMN: 6 chunks of float scores swinging through both thresholds
+        fsc = [np.clip(0.5 + 0.45 * np.sin(np.arange(51) / (1.5 + case) + 0.7 * k) + 0.15 * rng.standard_normal(51), 0, 1).astype(np.float32)
+               for k in range(n_chunks)]
+        fsc[2][10:20] = np.float32(spk)                                  # exactly on the thresholds
+        fsc[3][5:15] = np.float32(sil)
+
+        class FakeSessD:
+            def __init__(self):
+                self.k = 0
+
+            def run(self, names, feeds):
+                self.k += 1
+                return [fsc[self.k - 1]]
+        L, stride = 16001, 16001 - 16 * 320
+        aligned = (n_chunks - 1) * stride + L
+        env = dict(np=np, time=__import__("time"), ort_session_A=FakeSessD(), out_name_A0="o", in_name_A0="a", in_name_A1="b",
+                   near_end_audio=np.zeros((1, 1, aligned), np.int16), far_end_audio=np.zeros((1, 1, aligned), np.int16),
+                   INPUT_AUDIO_LENGTH=L, aligned_len=aligned, look_backward=15, stride_step=stride, SPEAKING_SCORE=spk,
+                   SILENCE_SCORE=sil, inv_audio_len=0.0, print=lambda *a, **k: None)
+        R.select_lines("DFSMN/near_and_far_end_audio/Inference_DFSMN_VAD_ONNX.py", 221, 273, env)
+        out[f"dfsmn_scores_{case}"] = np.stack(fsc)
+        out[f"dfsmn_saved_{case}"] = np.array(env["saved"], dtype=bool)
+    save("hostloop_thresholds", **out)
+
+
 def gen_host_extra():
     """normalise_audio (RMS -> 8192 with clipping, Inference_NVIDIA_MarbleNet_VAD_ONNX.py:110-118; FireRed carries the same
     function) -- the optional NORMALIZE_AUDIO path of the MarbleNet / FireRed drivers."""
@@ -1047,7 +1120,7 @@ if __name__ == "__main__":
     gens = dict(stft=gen_stft, host=gen_host, vadpost=gen_vadpost, silero_host=gen_silero_host,
                 fsmn=gen_fsmn, firered=gen_firered, firered_stream=gen_firered_stream, firered_ckpt=gen_firered_ckpt, marblenet_fold=gen_marblenet_fold, dfsmn=gen_dfsmn, dfsmn_near_only=gen_dfsmn_near_only,
                 fsmn_extra=gen_fsmn_extra, host_extra=gen_host_extra, marblenet_hostloop=gen_marblenet_hostloop,
-                resample=gen_resample, silero_8k=gen_silero_8k)
+                resample=gen_resample, silero_8k=gen_silero_8k, hostloop_thresholds=gen_hostloop_thresholds)
     for name, fn in gens.items():
         if not which or name in which:
             fn()

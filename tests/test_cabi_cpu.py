@@ -157,6 +157,7 @@ def test_firered_checkpoint_loader_matches_reference(golden, tmp_path):
 
     import torch
 
+    import _containers
     from vadx import checkpoints as ck
     g = golden("firered_ckpt")
     cfg = dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=1, N2=4, S2=1, odim=3)
@@ -174,7 +175,7 @@ def test_firered_checkpoint_loader_matches_reference(golden, tmp_path):
         sd[f"dfsmn.dnns.{2 * m}.weight"], sd[f"dfsmn.dnns.{2 * m}.bias"] = w[f"dnn{m}_w"], w[f"dnn{m}_b"]
     torch.save({"args": types.SimpleNamespace(**cfg), "model_state_dict": {k: T(v) for k, v in sd.items()}}, tmp_path / "model.pth.tar")
     for binary in (True, False):
-        ck.write_kaldi_matrix(str(tmp_path / "cmvn.ark"), g["stats"], binary=binary)
+        _containers.write_kaldi_matrix(str(tmp_path / "cmvn.ark"), g["stats"], binary=binary)
         means, inv_std = ck.load_cmvn(str(tmp_path / "cmvn.ark"))
         assert np.array_equal(means, g["means"]) and np.array_equal(inv_std, g["inv_std"])
         got = ck.load_firered(str(tmp_path))

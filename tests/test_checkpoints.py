@@ -12,6 +12,8 @@ import torch
 import vadx  # noqa: F401
 from vadx import checkpoints as ck
 from vadx import onnx_reader as O
+
+import _containers as CW           # test-only writers of the container formats (tests/_containers.py)
 from vadx import weights
 
 
@@ -34,14 +36,14 @@ def test_onnx_reader_roundtrip_encodings_and_scopes(tmp_path):
     a, b = rng.standard_normal((4, 3, 3)).astype(np.float32), rng.standard_normal(4).astype(np.float32)
     h = rng.standard_normal((2, 5)).astype(np.float16)
     i64 = np.array([[1, -2], [3, 1 << 40]], np.int64)
-    inner = O.enc_graph([O.enc_node("Conv", ["x", "w", "b"], ["y"], "/enc/conv", attrs={"kernel_shape": [3], "group": 1}),
-                         O.enc_node("Constant", [], ["/enc/Constant_output_0"], attrs={"value": h})],
+    inner = CW.enc_graph([CW.enc_node("Conv", ["x", "w", "b"], ["y"], "/enc/conv", attrs={"kernel_shape": [3], "group": 1}),
+                         CW.enc_node("Constant", [], ["/enc/Constant_output_0"], attrs={"value": h})],
                         [("w", a, True), ("b", b, False)], "then")                       # raw_data and packed float_data
-    other = O.enc_graph([], [("w", a * 2, True), ("shape", i64, False)], "else")          # packed int64_data
-    top = O.enc_graph([O.enc_node("If", ["cond"], ["out"], "/If.1", attrs={"then_branch": ("graph", inner), "else_branch": ("graph", other)}),
-                       O.enc_node("Relu", ["out"], ["final"], attrs={"alpha": 0.25, "mode": b"x"})],
+    other = CW.enc_graph([], [("w", a * 2, True), ("shape", i64, False)], "else")          # packed int64_data
+    top = CW.enc_graph([CW.enc_node("If", ["cond"], ["out"], "/If.1", attrs={"then_branch": ("graph", inner), "else_branch": ("graph", other)}),
+                       CW.enc_node("Relu", ["out"], ["final"], attrs={"alpha": 0.25, "mode": b"x"})],
                       [("top.scale", np.array([1.5, -2.0], np.float64))])
-    path = O.write_onnx(str(tmp_path / "m.onnx"), top)
+    path = CW.write_onnx(str(tmp_path / "m.onnx"), top)
     g = O.read_onnx(path)
     then, els = (("/If.1", "then_branch"),), (("/If.1", "else_branch"),)
     assert g.scopes() == [then, els, ()]
@@ -64,12 +66,12 @@ def _silero_onnx(tmp_path, w, lstm_node, with_8k=True):
     """A Silero-v5-shaped container: top-level If(sr == 16000) -> 16 kHz sub-graph / 8 kHz sub-graph."""
     def branch(basis, conv0, tag):
         inits = [(f"{tag}.stft.forward_basis_buffer", basis)]
-        nodes = [O.enc_node("Conv", ["x", f"{tag}.stft.forward_basis_buffer"], ["spec"], f"/{tag}/stft/Conv", attrs={"strides": [128]})]
+        nodes = [CW.enc_node("Conv", ["x", f"{tag}.stft.forward_basis_buffer"], ["spec"], f"/{tag}/stft/Conv", attrs={"strides": [128]})]
         prev = "mag"
         for i, cw in enumerate([conv0, w["enc1_w"], w["enc2_w"], w["enc3_w"]]):
             wn, bn = f"{tag}.encoder.{i}.reparam_conv.weight", f"onnx::Conv_{100 + i}_{tag}"     # bias name shares nothing with the weight
             inits += [(wn, cw, bool(i & 1)), (bn, w[f"enc{i}_b"], False)]
-            nodes.append(O.enc_node("Conv", [prev, wn, bn], [f"c{i}"], f"/{tag}/encoder.{i}/Conv"))
+            nodes.append(CW.enc_node("Conv", [prev, wn, bn], [f"c{i}"], f"/{tag}/encoder.{i}/Conv"))
             prev = f"c{i}"
         H = 128
         if lstm_node:
@@ -77,14 +79,14 @@ def _silero_onnx(tmp_path, w, lstm_node, with_8k=True):
             W, R = w["lstm_w_ih"][order][None], w["lstm_w_hh"][order][None]
             B = np.concatenate([w["lstm_b_ih"][order], w["lstm_b_hh"][order]])[None]
             inits += [(f"onnx::LSTM_{tag}_W", W), (f"onnx::LSTM_{tag}_R", R), (f"onnx::LSTM_{tag}_B", B)]
-            nodes.append(O.enc_node("LSTM", [prev, f"onnx::LSTM_{tag}_W", f"onnx::LSTM_{tag}_R", f"onnx::LSTM_{tag}_B", "", "h0", "c0"],
+            nodes.append(CW.enc_node("LSTM", [prev, f"onnx::LSTM_{tag}_W", f"onnx::LSTM_{tag}_R", f"onnx::LSTM_{tag}_B", "", "h0", "c0"],
                                     ["y", "hn", "cn"], f"/{tag}/decoder/rnn/LSTM", attrs={"hidden_size": H}))
         else:
             inits += [(f"{tag}.decoder.rnn.weight_ih", w["lstm_w_ih"]), (f"{tag}.decoder.rnn.weight_hh", w["lstm_w_hh"]),
                       (f"{tag}.decoder.rnn.bias_ih", w["lstm_b_ih"]), (f"{tag}.decoder.rnn.bias_hh", w["lstm_b_hh"])]
         inits += [(f"{tag}.decoder.decoder.2.weight", w["dec_w"].reshape(1, 128, 1)), (f"{tag}.decoder.decoder.2.bias", w["dec_b"])]
-        nodes.append(O.enc_node("Conv", ["relu_h", f"{tag}.decoder.decoder.2.weight", f"{tag}.decoder.decoder.2.bias"], ["logit"], f"/{tag}/decoder/Conv"))
-        return O.enc_graph(nodes, inits, tag)
+        nodes.append(CW.enc_node("Conv", ["relu_h", f"{tag}.decoder.decoder.2.weight", f"{tag}.decoder.decoder.2.bias"], ["logit"], f"/{tag}/decoder/Conv"))
+        return CW.enc_graph(nodes, inits, tag)
 
     rng = np.random.default_rng(8)
     g16 = branch(w["stft_basis"].reshape(258, 1, 256), w["enc0_w"], "m16")
@@ -92,9 +94,9 @@ def _silero_onnx(tmp_path, w, lstm_node, with_8k=True):
     if with_8k:
         attrs["else_branch"] = ("graph", branch(rng.standard_normal((130, 1, 128)).astype(np.float32),
                                                 rng.standard_normal((128, 65, 3)).astype(np.float32), "m8"))
-    top = O.enc_graph([O.enc_node("Equal", ["sr", "c16k"], ["is16"]), O.enc_node("If", ["is16"], ["out", "stateN"], "If_0", attrs=attrs)],
+    top = CW.enc_graph([CW.enc_node("Equal", ["sr", "c16k"], ["is16"]), CW.enc_node("If", ["is16"], ["out", "stateN"], "If_0", attrs=attrs)],
                       [("c16k", np.array(16000, np.int64))])
-    return O.write_onnx(str(tmp_path / f"silero_{int(lstm_node)}.onnx"), top)
+    return CW.write_onnx(str(tmp_path / f"silero_{int(lstm_node)}.onnx"), top)
 
 
 @pytest.mark.parametrize("lstm_node", [True, False])
@@ -108,7 +110,7 @@ def test_silero_onnx_initialisers(tmp_path, lstm_node):
     with pytest.raises(ValueError, match="16 kHz sub-graph only"):
         ck.silero_from_onnx(path, sample_rate=8000)
     # a file without the 16 kHz tensors is refused with a listing, not half-loaded
-    bad = O.write_onnx(str(tmp_path / "bad.onnx"), O.enc_graph([], [("x", np.zeros((3, 3, 3), np.float32))]))
+    bad = CW.write_onnx(str(tmp_path / "bad.onnx"), CW.enc_graph([], [("x", np.zeros((3, 3, 3), np.float32))]))
     with pytest.raises(ValueError, match="weight shapes present"):
         ck.silero_from_onnx(bad)
 
@@ -249,3 +251,42 @@ def test_resolve_never_defaults_to_random_weights(tmp_path):
     jit.write_bytes(b"PK")
     with pytest.raises(ValueError, match="neither a .onnx"):
         ck.resolve("silero", str(jit))
+
+
+def test_readers_decode_hand_assembled_bytes():
+    """Byte strings written out BY HAND from the format specifications (protobuf wire format + onnx.proto field numbers; Kaldi's
+    binary matrix header), not produced by tests/_containers.py: a mistake shared by a reader and the test writers cannot pass."""
+    # ModelProto { ir_version (1) = 8; graph (7) = GraphProto { name (2) = "g"; initializer (5) = TensorProto {
+    #   dims (1) = 2, dims (1) = 2, data_type (2) = 1 (FLOAT), name (8) = "w", raw_data (9) = 4 little-endian floats } } }
+    raw = np.array([1.0, -2.0, 0.5, 3.25], "<f4").tobytes()
+    tensor = bytes([0x08, 2, 0x08, 2, 0x10, 1, 0x42, 1]) + b"w" + bytes([0x4A, 16]) + raw
+    graph = bytes([0x12, 1]) + b"g" + bytes([0x2A, len(tensor)]) + tensor
+    model = bytes([0x08, 8, 0x3A, len(graph)]) + graph
+    g = O.read_onnx(model)
+    assert list(g.tensors) == [((), "w")] and g.tensors[((), "w")].dtype == np.float32
+    assert np.array_equal(g.tensors[((), "w")], np.array([[1.0, -2.0], [0.5, 3.25]], np.float32))
+    # the same tensor with packed float_data (field 4) and int64 dims as multi-byte varints: dims = [1, 300] -> 300 = 0xAC 0x02
+    vals = np.arange(300, dtype="<f4")
+    packed = vals.tobytes()
+    ln = len(packed)                                                    # 1200 = 0xB0 0x09
+    tensor2 = bytes([0x08, 1, 0x08, 0xAC, 0x02, 0x10, 1, 0x22, 0xB0, 0x09]) + packed + bytes([0x42, 1]) + b"v"
+    assert ln == 1200
+    graph2 = bytes([0x2A]) + bytes([len(tensor2) & 0x7F | 0x80, len(tensor2) >> 7]) + tensor2
+    g2 = O.read_onnx(bytes([0x3A, len(graph2) & 0x7F | 0x80, len(graph2) >> 7]) + graph2)
+    assert g2.tensors[((), "v")].shape == (1, 300) and np.array_equal(g2.tensors[((), "v")][0], vals)
+    # Kaldi binary matrix: "<key> " NUL 'B' "DM " then \4 int32 rows \4 int32 cols, then row-major little-endian doubles
+    import struct
+    import tempfile
+    m = np.array([[1.5, -2.0, 3.0], [0.25, 8.0, -1.0]])
+    blob = b"global \0BDM " + b"\x04" + struct.pack("<i", 2) + b"\x04" + struct.pack("<i", 3) + m.astype("<f8").tobytes()
+    with tempfile.NamedTemporaryFile(suffix=".ark", delete=False) as fh:
+        fh.write(blob)
+    try:
+        assert np.array_equal(ck.read_kaldi_matrix(fh.name), m)
+        # float matrix ("FM ") and the text form "key  [\n rows ]"
+        open(fh.name, "wb").write(b"k \0BFM " + b"\x04" + struct.pack("<i", 1) + b"\x04" + struct.pack("<i", 2) + np.array([7.0, -0.5], "<f4").tobytes())
+        assert np.array_equal(ck.read_kaldi_matrix(fh.name), np.array([[7.0, -0.5]], np.float32))
+        open(fh.name, "wb").write(b"global  [\n  1 2.5 3\n  4 5 6e1 ]\n")
+        assert np.array_equal(ck.read_kaldi_matrix(fh.name), np.array([[1, 2.5, 3], [4, 5, 60.0]]))
+    finally:
+        os.unlink(fh.name)

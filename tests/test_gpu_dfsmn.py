@@ -193,3 +193,36 @@ def test_full_size_config5_properties():
         want, _ = od.forward(fe, ow, a, f, weights.DFSMN_MASK["layers"])
         np.testing.assert_allclose(v[3, 5, k].cpu().numpy(), want.numpy(), rtol=0, atol=1e-4)
     print(f"DFSMN config-5 pass: {dt:.2f} s for 2048 x 10 s pairs ({2048 * 313 / dt / 1e3:.0f} k 512-hop frames/s)")
+
+
+def test_vote_kernel_with_asymmetric_thresholds_replays_the_reference_loop(golden):
+    """vadx_dfsmn_vote on the float scores the REFERENCE loop was run on, SPEAKING_SCORE != SILENCE_SCORE (0.7 / 0.3, 0.3 / 0.7, 0.9 / 0.1,
+    0.6 / 0.6, 0.2 / 0.4; scores sitting exactly on float32(threshold) included): the `saved` flags bit for bit
+    (DFSMN/near_and_far_end_audio/Inference_DFSMN_VAD_ONNX.py:231-273)."""
+    import ctypes as C
+    from vadx import _lib
+    g = golden("hostloop_thresholds")
+    for c, (spk, sil) in enumerate(g["pairs"]):
+        scores = torch.from_numpy(g[f"dfsmn_scores_{c}"]).cuda().contiguous()         # [W, 51]
+        W, Tn, lb = scores.shape[0], scores.shape[1], 15
+        rep = scores.unsqueeze(0).repeat(3, 1, 1).contiguous()                          # three identical clips: per-clip independence
+        flags = torch.empty((3, W * (Tn - lb) + lb), dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().vadx_dfsmn_vote(rep.data_ptr(), 3, W, Tn, lb, float(spk), float(sil), flags.data_ptr(), _lib.stream_ptr()))
+        got = flags.cpu().numpy().astype(bool)
+        for b in range(3):
+            assert np.array_equal(got[b], g[f"dfsmn_saved_{c}"]), (c, b)
+
+
+def test_whole_clip_pair_segments_with_asymmetric_thresholds():
+    eng = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234))
+    w = {k: T(v) for k, v in weights.dfsmn_synthetic(1234).items()}
+    w["mask.shift"] = w["mask.shift"] + torch.log(torch.tensor(32768 ** 2, dtype=torch.float32))
+    fe = od.Frontend()
+    near, far = weights.burst_clips(1, 30000, seed=13), weights.burst_clips(1, 30000, seed=14)
+    nz1, nz2 = np.random.default_rng(15).standard_normal((1, 20000)), np.random.default_rng(16).standard_normal((1, 20000))
+    # thresholds placed inside the synthetic net's score range so that both branches fire
+    vad = eng.run(near[:, :16001], far[:, :16001]).cpu().numpy()[0]
+    hi, lo = float(np.quantile(vad, 0.7)), float(np.quantile(vad, 0.3))
+    got = eng.detect(near, far, nz1, nz2, speaking_score=hi, silence_score=lo)
+    want, _ = od.run_clip(fe, w, near[0], far[0], nz1[0], nz2[0], weights.DFSMN_MASK["layers"], speaking=hi, silence_score=lo)
+    assert got[0] == want

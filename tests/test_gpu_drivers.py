@@ -258,3 +258,29 @@ def test_host_feed_is_bitwise_the_resident_path(pinned):
     assert torch.equal(df.run_from_host(prep(near), prep(far), chunk_clips=2), df.run(torch.from_numpy(near).cuda(), torch.from_numpy(far).cuda()))
     with pytest.raises(ValueError):
         f.map([torch.from_numpy(pcm).cuda()], lambda a: a)
+
+
+def test_fp16_io_variants_are_the_f32_results_rounded_once(tmp_path):
+    """I/O-compatible fp16 variants (float32 arithmetic inside): MarbleNet / DFSMN sessions with io_dtype="float16" return the float32
+    session's scores rounded once to float16 with float16 metadata (NVIDIA_.../Optimize_ONNX.py:37-44, DFSMN/.../Optimize_ONNX.py:40-44:
+    keep_io_types=False); the Silero driver with use_fp16 feeds float16-quantised samples (Inference_Silero_VAD_ONNX.py:16, :83)."""
+    from vadx import dfsmn, marblenet
+    a = weights.burst_clips(1, 20000, seed=41).reshape(1, 1, -1)
+    m32, m16 = marblenet.MarbleNetSession("synthetic:1234"), marblenet.MarbleNetSession("synthetic:1234", io_dtype="float16")
+    r32, r16 = m32.run(None, {"audio": a}), m16.run(None, {"audio": a})
+    assert r16[0].dtype == np.float16 and r16[1].dtype == np.float16 and r16[2].dtype == np.int32
+    assert np.array_equal(r16[1], r32[1].astype(np.float16)) and np.array_equal(r16[2], r32[2])
+    assert m16.get_outputs()[0].type == "tensor(float16)" and m32.get_outputs()[0].type == "tensor(float)"
+    near, far = weights.burst_clips(1, 16001, seed=42).reshape(1, 1, -1), weights.burst_clips(1, 16001, seed=43).reshape(1, 1, -1)
+    d32, d16 = dfsmn.DfsmnSession("synthetic:1234"), dfsmn.DfsmnSession("synthetic:1234", io_dtype="float16")
+    v32 = d32.run(None, {"near_end_audio": near, "far_end_audio": far})[0]
+    v16 = d16.run(None, {"near_end_audio": near, "far_end_audio": far})[0]
+    assert v16.dtype == np.float16 and np.array_equal(v16, v32.astype(np.float16)) and d16.get_outputs()[0].type == "tensor(float16)"
+    # Silero: the driver's float16 feed == running the float32 path on the quantised samples
+    model = silero.load_silero_vad(onnx=True, use_cpu=True, path="synthetic:1234")
+    got = drivers.inference_silero(WAV, model, str(tmp_path / "s.txt"), str(tmp_path / "i.txt"), use_fp16=True, echo=lambda *_: None)
+    q = (audio_io.load_wav(WAV).astype(np.float16) * np.float16(0.000030517578)).astype(np.float32)
+    res = silero.get_speech_timestamps_batch(q[None, :], model, threshold=0.5, max_speech_duration_s=20, min_speech_duration_ms=250,
+                                             min_silence_duration_ms=250, return_seconds=True)[0]
+    from vadx import timestamps
+    assert got == timestamps.process_timestamps([(d["start"], d["end"]) for d in res], 0.3, 0.25)

@@ -217,3 +217,24 @@ def test_fp16_io_session_matches_f32_session():
         s16.run(None, feeds32)
     with pytest.raises(ValueError, match="expected: \\(tensor\\(float\\)\\)"):
         s32.run(None, feeds16)
+
+
+@pytest.mark.parametrize("spk,sil", [(0.7, 0.3), (0.3, 0.7), (0.9, 0.1)])
+def test_whole_clip_flags_with_asymmetric_thresholds(spk, sil):
+    """SPEAKING_SCORE != SILENCE_SCORE (FSMN/Inference_FSMN_VAD_ONNX.py:21-23, 188-215): the device loop against the oracle, whose
+    vote is pinned for these constants by the reference loop's own output (tests/golden/hostloop_thresholds.npz)."""
+    eng = fsmn.FsmnEngine(weights.fsmn_synthetic(1234))
+    fe = ofs.Frontend()
+    ow = {k: T(v) for k, v in weights.fsmn_synthetic(1234).items()}
+    clips = weights.burst_clips(2, 60000, seed=77)
+    noise = np.random.default_rng(12).standard_normal((2, 20000))
+    got = eng.detect(clips, pad_noise=noise, speaking_score=spk, silence_score=sil)
+    lb, stride = eng.grid()
+    for b in range(2):
+        a = opp.normalize_to_int16(clips[b].astype(np.float32))
+        want_ts, want_flags = ofs.run_clip(fe, ow, a, noise[b], speaking=spk, silence_score=sil)
+        padded = fsmn.pad_to_window_grid(a, 16000, stride, noise[b])
+        W = (padded.shape[0] - 16000) // stride + 1
+        flags = eng.flags(torch.from_numpy(padded[None]), W, speaking_score=spk, silence_score=sil).cpu().numpy()[0].astype(bool)
+        assert np.array_equal(flags, np.array(want_flags, bool))
+        assert got[b] == want_ts

@@ -63,6 +63,26 @@ def test_whole_clip_segments(n, window):
     assert full_chain >= 1          # not every clip may sit on a threshold
 
 
+def test_ten_minute_clip_in_one_dynamic_window():
+    """The dynamic-axis export takes a whole recording as ONE window, up to 3600 s (Inference_NVIDIA_MarbleNet_VAD_ONNX.py:130-135): a
+    606 s clip (9.7 M samples -> 60 626 STFT frames -> 30 313 scores) through engine.detect against the oracle driver -- scores
+    within 1e-4, decisions (max-speech splits at 1000 frames fire dozens of times) and segments as in test_whole_clip_segments."""
+    n, post = 9_700_000, (3, 0.5, 10, 1000, 10, 3, 0)
+    eng = marblenet.MarbleNetEngine(weights.marblenet_synthetic(1234))
+    ow = {k: T(v) for k, v in weights.marblenet_synthetic(1234).items()}
+    clip = weights.burst_clips(1, n, seed=606)
+    got, track, dec = eng.detect(clip, window_len=None, return_probs=True)
+    want_seg, want_p, want_dec = omb.run_clip(omb.Frontend(), ow, clip[0], window=None, pad_noise=None)
+    assert tuple(track.shape) == (1, want_p.shape[0]) and want_p.shape[0] > 30000
+    np.testing.assert_allclose(track[0].cpu().numpy(), want_p, rtol=0, atol=ATOL)
+    opost = opp.VadPostprocessor(*post, frame_shift_s=0.02, frame_length_s=None)
+    d2 = opost.process(track[0].cpu().numpy())
+    assert np.array_equal(dec[0].cpu().numpy(), d2)
+    assert got[0] == opost.decision_to_segment(d2, n / 16000) and len(got[0]) > 20
+    if np.array_equal(d2, want_dec):
+        assert got[0] == want_seg
+
+
 def test_full_size_config4_properties():
     """BASELINE config 4 shape on one GPU: B=8192 clips of 89,431 samples (one window each)."""
     import time

@@ -436,3 +436,28 @@ def test_silero_segmenter_8k(golden):
         res = opp.silero_segments([float(v) for v in g[f"probs_{i}"]], int(g[f"nsamp_{i}"]), **kw)
         got = np.array([[d["start"], d["end"]] for d in res], dtype=np.float64).reshape(-1, 2)
         assert np.array_equal(got, g[f"res_{i}"]), i
+
+
+def test_hostloops_with_asymmetric_thresholds(golden):
+    """Round 3: SPEAKING_SCORE != SILENCE_SCORE (0.7 / 0.3, 0.3 / 0.7, 0.9 / 0.1, 0.6 / 0.6, 0.2 / 0.4) through both look-ahead loops --
+    the reference's own loops on replayed scores (FSMN/Inference_FSMN_VAD_ONNX.py:188-234, DFSMN/.../Inference_DFSMN_VAD_ONNX.py:231-273)."""
+    from oracle import dfsmn as od
+    g = golden("hostloop_thresholds")
+    for c, (spk, sil) in enumerate(g["pairs"]):
+        spk, sil = float(spk), float(sil)
+        scores = g[f"fsmn_scores_{c}"]
+        silence, saved = True, []
+        for k in range(scores.shape[0]):
+            flags, silence = opp.lookahead_vote(scores[k], 71, 30, spk, sil, silence)
+            saved += flags
+        flags, silence = opp.tail_flags_fsmn(scores[-1], 71, 101, silence)
+        saved += flags
+        assert np.array_equal(np.array(saved, bool), g[f"fsmn_saved_{c}"]), ("fsmn", c)
+        scores = g[f"dfsmn_scores_{c}"]
+        silence, saved = True, []
+        for k in range(scores.shape[0]):
+            flags, silence = opp.lookahead_vote(scores[k], 51 - 15, 15, spk, sil, silence, thresholds=(spk, sil))
+            saved += flags
+        flags, silence = od.tail_flags(scores[-1], 51 - 15, 51, silence, spk, sil)
+        saved += flags
+        assert np.array_equal(np.array(saved, bool), g[f"dfsmn_saved_{c}"]), ("dfsmn", c)

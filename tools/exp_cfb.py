@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 
 CHILD = r"""
 import os, sys, torch, ctypes as C
-sys.path.insert(0, %r)
+sys.path.insert(0, __ROOT__)
 import vadx
 from vadx import dfsmn, weights, _lib
 net = dfsmn.Iccrn(weights.dfsmn_synthetic(1234))
@@ -41,6 +41,18 @@ for name, cin in (("cfb_e2", 20), ("cfb_d2", 40)):
     out[f"front{cin}"] = ms(front)
     if cin == 20: out["back"] = ms(back)
 print("EXP", os.path.basename(os.environ["VADX_LIBRARY"]), f"{tiles} tiles: ms", {k: round(v, 3) for k, v in out.items()})
+h = C.CDLL(os.environ["VADX_LIBRARY"])
+if hasattr(h, "vadx_cfb_debug_cycles"):
+    buf = (C.c_ulonglong * 32)()
+    h.vadx_cfb_debug_cycles(buf, 1)
+    back(); torch.cuda.synchronize()
+    h.vadx_cfb_debug_cycles(buf, 1)
+    names = {8: "back P: wait operands", 9: "back P: Linear + product + LDS", 10: "back P: copies + next loads", 11: "back P: barrier wait",
+             12: "back D: prologue", 13: "back D: LDS reads + MFMAs", 14: "back D: barrier wait", 15: "back D: epilogue"}
+    tot_p, tot_d = sum(buf[k] for k in (8, 9, 10, 11)), sum(buf[k] for k in (12, 13, 14, 15))
+    for k, n in names.items():
+        print("   %-36s %6.2f %% of its wave" % (n, 100.0 * buf[k] / (tot_p if k < 12 else tot_d)))
+    print("   cycles per tile: producer %.0f, DFT wave %.0f" % (tot_p / tiles, tot_d / tiles))
 """
 
 if __name__ == "__main__":
@@ -61,6 +73,6 @@ if __name__ == "__main__":
             os.remove(obj)
             print("built", lib)
         else:
-            r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=dict(os.environ, VADX_LIBRARY=lib), capture_output=True, text=True, timeout=300)
-            line = [l for l in r.stdout.splitlines() if l.startswith("EXP")]
-            print(line[0] if line else f"EXP {n} FAILED rc={r.returncode}\n{r.stderr[-800:]}", flush=True)
+            r = subprocess.run([sys.executable, "-c", CHILD.replace('__ROOT__', repr(ROOT))], env=dict(os.environ, VADX_LIBRARY=lib), capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith(("EXP", "   "))]
+            print("\n".join(line) if line else f"EXP {n} FAILED rc={r.returncode}\n{r.stderr[-800:]}", flush=True)

@@ -85,8 +85,8 @@ class FtLn(C.Structure):
 
 
 class DfsmnCfbWeights(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("ln0_w", "ln0_b", "gate_w", "gate_b", "in_w", "in_b", "ln1_w", "conv_w", "ln2_w", "fwd_tbl",
-                                          "fwd_fix", "lin_w", "lin_b", "inv_tbl", "out_fix")]
+    _fields_ = [(k, C.c_void_p) for k in ("ln0_w", "gate_w", "in_w", "in_b", "front_tab", "conv_w", "fwd_tbl", "fwd_fix", "lin_w", "lin_b",
+                                          "inv_tbl", "out_fix")]
 
 
 class DfsmnMaskWeights(C.Structure):

@@ -65,21 +65,6 @@ def read_kaldi_matrix(path):
     return np.array(rows, dtype=np.float64)
 
 
-def write_kaldi_matrix(path, mat, key="global", binary=True):
-    """Inverse of read_kaldi_matrix (used by the tests and for exporting statistics)."""
-    m = np.ascontiguousarray(mat)
-    with open(path, "wb") as fh:
-        if binary:
-            tok = b"DM " if m.dtype == np.float64 else b"FM "
-            if tok == b"FM ":
-                m = m.astype(np.float32)
-            fh.write(key.encode() + b" \0B" + tok + b"\4" + struct.pack("<i", m.shape[0]) + b"\4" + struct.pack("<i", m.shape[1]))
-            fh.write(m.tobytes())
-        else:
-            body = "\n".join("  " + " ".join(repr(float(v)) for v in row) for row in m)
-            fh.write((key + "  [\n" + body + " ]\n").encode())
-
-
 def load_cmvn(cmvn_file):
     """(means, inverse standard deviations) float32 [dim] from Kaldi CMVN statistics [2, dim+1], with the float32
     arithmetic of the reference (FireRedVAD/Export_FireRedVAD.py:98-119)."""

@@ -1235,6 +1235,9 @@ __global__ void dfsmn_vote_kernel(const float *__restrict__ vad, int B, int W, i
     if (b >= B) return;
     const int slide = Tn - lb, nflags = W * slide + lb;
     const double inv_lb = 1.0 / (double)lb;
+    // A float32 score against the Python-float constant: NumPy 2 (NEP 50) compares in float32, i.e. against the constant rounded to
+    // float32 -- a score of exactly float32(0.7) IS >= 0.7 there (tests/golden/hostloop_thresholds.npz, produced by the
+    // reference loop under NumPy 2.2).  The vote ratio (int * float) against the constant stays a float64 comparison.
     const float hi = (float)speaking, lo = (float)silence_score;
     int silence = 1;
     unsigned char *fl = flags + (size_t)b * nflags;
@@ -1243,25 +1246,24 @@ __global__ void dfsmn_vote_kernel(const float *__restrict__ vad, int B, int W, i
         sc = vad + ((size_t)b * W + k) * Tn;
         for (int i2 = 0; i2 < slide; ++i2) {
             if (silence) {
-                if ((double)sc[i2] >= speaking) {
+                if (sc[i2] >= hi) {
                     int act = 1;
-                    for (int j = 1; j < lb; ++j) act += ((double)sc[i2 + j] >= speaking) ? 1 : 0;
+                    for (int j = 1; j < lb; ++j) act += (sc[i2 + j] >= hi) ? 1 : 0;
                     silence = !((double)act * inv_lb >= speaking);
                 } else silence = 1;
             } else {
-                if ((double)sc[i2] <= silence_score) {
+                if (sc[i2] <= lo) {
                     int act = 1;
-                    for (int j = 1; j < lb; ++j) act += ((double)sc[i2 + j] <= silence_score) ? 1 : 0;
+                    for (int j = 1; j < lb; ++j) act += (sc[i2 + j] <= lo) ? 1 : 0;
                     silence = !((double)act * inv_lb <= silence_score);
                 } else silence = 0;
             }
             fl[k * slide + i2] = (unsigned char)silence;
         }
     }
-    (void)hi; (void)lo;
     for (int i2 = slide; i2 < Tn; ++i2) {
-        if (silence) silence = !((double)sc[i2] >= speaking);
-        else silence = ((double)sc[i2] <= silence_score) ? 1 : 0;
+        if (silence) silence = !(sc[i2] >= hi);
+        else silence = (sc[i2] <= lo) ? 1 : 0;
         fl[W * slide + (i2 - slide)] = (unsigned char)silence;
     }
 }

@@ -26,13 +26,36 @@
 // output equals the unfused chain's to float32 rounding (tests/test_gpu_dfsmn.py).
 #include "common.h"
 
+#include <type_traits>
+
 // CFB_EXP: development-only what-if switches (bit mask; results are wrong when set; tools/exp_cfb.py): 1 no workgroup barriers in the
 // chunk loops, 2 no global loads of the chunk rows, 4 no gate / input conv MFMAs, 8 no (3,1) conv, 16 no DFT accumulation,
-// 32 no gate arithmetic / statistics, 64 no y1 stores, 128 no Linear + complex product (back), 256 no epilogue stores
+// 32 no gate arithmetic / statistics, 64 no y1 stores, 128 no Linear + complex product (back), 256 no epilogue stores,
+// 512 no y1 loads in cfb_back's prologue, 1024 no prologue transposes
 #ifndef CFB_EXP
 #define CFB_EXP 0
 #endif
 #define CFB_SYNC() do { if (!(CFB_EXP & 1)) __syncthreads(); } while (0)
+// bit 2048: cycle accounting (s_memtime deltas of lane 0 of the first producer and the first DFT wave, summed over all workgroups
+// into cfb_dbg[slot]; vadx_cfb_debug_cycles reads / clears them): slot = 8 * kernel (0 front, 1 back) + 4 * role + section
+#if CFB_EXP & 2048
+__device__ unsigned long long cfb_dbg[32];
+#define CFB_T0() long long cfb_t_ = __builtin_readcyclecounter(); unsigned long long cfb_a_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CFB_MARK(slot) do { const long long n_ = __builtin_readcyclecounter(); cfb_a_[(slot) & 7] += (unsigned long long)(n_ - cfb_t_); cfb_t_ = n_; } while (0)
+#define CFB_FLUSH(base) do { if ((threadIdx.x & 255) == 0) for (int k_ = 0; k_ < 8; ++k_) if (cfb_a_[k_]) atomicAdd(&cfb_dbg[(base) + k_], cfb_a_[k_]); } while (0)
+extern "C" int vadx_cfb_debug_cycles(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(cfb_dbg), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cfb_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define CFB_T0() do {} while (0)
+#define CFB_MARK(slot) do {} while (0)
+#define CFB_FLUSH(base) do {} while (0)
+#endif
+#ifndef CFB_PRIO
+#define CFB_PRIO 3
+#endif
 
 namespace vadx {
 namespace dfsmn_cfb {
@@ -46,14 +69,18 @@ struct ViewW {
     int c_total, c_off, c;
 };
 
-constexpr int F = 160, CH = 20, CF = 81, NTH = 512, TPW = 25;       // bins, channels, ceps bins, threads, DFT tiles per wave
+constexpr int F = 160, CH = 20, CF = 81, NTH = 512;                 // bins, channels, ceps bins, threads
 constexpr int KSF = 40, KSI = 41;                                   // k-steps of the forward / inverse table
-constexpr int XP = 80;                                              // LDS pitch per channel of a 4-bin chunk (4 * 16 + 16: the
-                                                                    // four k-quarters of an MFMA B read land 16 banks apart)
-constexpr int GP = 16 * 16 + 16;                                    // pitch per channel of the 16-slot gx ring
 constexpr int RP = 64, OP = 128;
 constexpr int TBLF_FLOATS = 10 * KSF * 64, TBLI_FLOATS = 10 * KSI * 64;
 constexpr int RED_FLOATS = 8 * 16 * 6 + 16 * 8;
+
+// Global access as UNIFORM base + unsigned 32-bit BYTE offset: the form the hardware addresses as (scalar base, 32-bit lane offset).
+// An element offset would have to be scaled by four in 64 bits (it may overflow 32), i.e. one 64-bit address pair per access.
+__device__ __forceinline__ float ldg1o(const float *base, unsigned byte_off) { return *(global_f32_ptr)(reinterpret_cast<const char *>(base) + byte_off); }
+__device__ __forceinline__ f32x4 ldg4o(const float *base, unsigned byte_off) { return *(global_f32x4_ptr)(reinterpret_cast<const char *>(base) + byte_off); }
+__device__ __forceinline__ void stg1o(float *base, unsigned byte_off, float v) { *(__attribute__((address_space(1))) float *)(reinterpret_cast<char *>(base) + byte_off) = v; }
+__device__ __forceinline__ void stg4o(float *base, unsigned byte_off, f32x4 v) { *(__attribute__((address_space(1))) f32x4 *)(reinterpret_cast<char *>(base) + byte_off) = v; }
 
 __device__ __forceinline__ size_t ft_idx(int tile, int c_total, int c, int Fb, int f) {
     return (((size_t)tile * c_total + c) * Fb + f) * 16;
@@ -68,6 +95,7 @@ struct Acc1 {
         const float d = v - K;
         s1 += d; s2 = fmaf(d, d, s2); n += 1.f;
     }
+    __device__ __forceinline__ void addk(float v) { const float d = v - K; s1 += d; s2 = fmaf(d, d, s2); n += 1.f; }      // K set by the caller
     __device__ __forceinline__ void finish(float &cnt, float &mean, float &M2) const {
         cnt = n;
         const float inv = n > 0.f ? 1.0f / n : 0.f;
@@ -98,6 +126,43 @@ __device__ __forceinline__ float sum_q(float v) {
     return v;
 }
 
+// LDS-only workgroup barrier: every wave's LDS writes are complete (lgkmcnt) before it arrives; outstanding GLOBAL loads / stores
+// are NOT waited for (a __syncthreads() is free to, and the chunk loops keep a prefetch and the y1 / S stores in flight across it).
+__device__ __forceinline__ void lds_barrier() {
+    if (CFB_EXP & 1) return;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Wave specialisation.  Waves 0-3 ("producers", one per SIMD) run the block's small convs, the gate arithmetic and the statistics
+// for one bin each per iteration -- short dependent MFMA chains, transcendentals, global loads and stores; waves 4-7 ("DFT waves",
+// one per SIMD: waves w and w + 4 share a SIMD) do nothing but accumulate the length-160 DFT of what the producers wrote an
+// iteration earlier: 50 independent MFMAs per k-step on 200 accumulator registers.  One LDS-only barrier per iteration.  The first
+// version ran both kinds of work in alternating phases on all eight waves and left the matrix pipe idle through every producer
+// phase (117 us per 20-channel tile against 53 us of MFMA issue time); here the SIMD interleaves the two streams itself.
+constexpr int GPR = 12 * 16 + 16;                  // producer ring: 12 bin slots per channel (+16: the k-quarters 16 banks apart)
+constexpr int NPROD = 4;
+constexpr int WSP = 20, WS_TILE = 16 * WSP, WS_FLOATS = 2 * WS_TILE;      // per-wave 16 x 16 transpose scratch (two tiles), pitch 20: D-layout writes of the four lane
+                                                   // quarters land 16 banks apart, rows stay 16-byte aligned for ds_read_b128
+
+// D layout (lane (q, i) holds rows 4 q + r of column i) <-> row layout (lane l holds row l >> 2, columns 4 (l & 3) .. + 3) of one
+// 16 x 16 tile through the wave's own LDS scratch: a tile then leaves / arrives as ONE 16-byte access per lane -- a wave covers the
+// tile's 1 KB contiguously -- instead of four 4-byte ones (a wave's LDS operations execute in order: no barrier)
+// (the empty asm statements are compiler fences: the scalar and the vector accesses go through differently typed pointers, and
+// nothing else orders them for the optimiser).  Two scratch tiles per wave: tile n + 1 is written while tile n's read is in flight.
+#define CFB_FENCE() asm volatile("" ::: "memory")
+__device__ __forceinline__ void put_d(float *ws, int q, int i, f32x4 d) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ws[(4 * q + r) * WSP + i] = d[r];
+}
+__device__ __forceinline__ f32x4 get_d(const float *ws, int q, int i) {
+    f32x4 d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = ws[(4 * q + r) * WSP + i];
+    return d;
+}
+__device__ __forceinline__ void put_rows(float *ws, int lane, f32x4 v) { *reinterpret_cast<f32x4 *>(ws + (lane >> 2) * WSP + 4 * (lane & 3)) = v; }
+__device__ __forceinline__ f32x4 get_rows(const float *ws, int lane) { return *reinterpret_cast<const f32x4 *>(ws + (lane >> 2) * WSP + 4 * (lane & 3)); }
+
 struct FrontArgs {
     View a, b;
     const float *stats0;
@@ -106,162 +171,206 @@ struct FrontArgs {
     int tiles;
 };
 
+// First half of the block, same scheme as cfb_back below: every wave does both kinds of work.  Per iteration j of EIGHT bins, wave w
+//   * runs the gate / input 1x1 convs of bin 8 j + w (both output-channel tiles share the operand, read straight from global memory
+//     one iteration ahead), the gate arithmetic and the LayerNorm statistics          -> R[j & 1] (ln2_w * r), ring (ln1_w * gx),
+//   * runs the (3,1) conv of output bin 8 j - 9 + w on the ring (bins written before the last barrier)      -> y1 (global),
+//   * accumulates DFT k-steps 2 (j - 1), 2 (j - 1) + 1 of all its 25 tiles from R[(j - 1) & 1],
+// the convs' short dependent chains interleaved with the fifty independent DFT MFMAs; ONE LDS-only barrier per iteration.
+constexpr int RP8 = 8 * 16;                        // R pitch per channel: [8 bins][16]
+constexpr int NSLOT = 18;                          // ring: 18 bin slots per channel = exactly the bins live in an iteration (the (3,1) conv reads
+                                                   // 8 j - 10 .. 8 j - 1, the 1x1 convs write 8 j .. 8 j + 7)
+// ring pitch per channel: 304 = 48 mod 64 puts the k-quarters of a B read 16 banks apart; the 40-channel instantiation gives the 1280
+// bytes of padding to conv_input's fragments instead (in registers they spill, and a scratch reload inside the loop waits out the
+// whole in-order prefetch queue: 2.07 -> 1.5x ms) and lives with 2-way conflicts on the (3,1) conv's fifteen reads
+template <int CIN> constexpr int ring_pitch() { return CIN == 20 ? NSLOT * 16 + 16 : NSLOT * 16; }
+constexpr int NIT8 = F / 8;                        // 20 iterations of front work (+ 2 that drain the (3,1) conv and the DFT)
+
 template <int CIN>
 __global__ __launch_bounds__(NTH) void cfb_front_kernel(FrontArgs p) {
-    constexpr int KS = CIN / 4, NIT = (CIN * 16 + NTH - 1) / NTH;
+    constexpr int KS = CIN / 4, GP20 = ring_pitch<CIN>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *TBL = lds;                              // [10 row tiles][40 k-steps][64 lanes]
-    float *X = TBL + TBLF_FLOATS;                  // [CIN][4 bins][16] pitch XP
-    float *WB = X + CIN * XP;                      // [CIN][4 bins] (LN0 weight, bias)
-    float *R = WB + CIN * 8;                       // [20][4 bins][16]: w2 * r of the chunk
-    float *GXW = R + CH * RP;                      // [20][16 slots][16] pitch GP: w1 * gx, ring over bins
-    float *RED = GXW + CH * GP;
+    float *R = TBL + TBLF_FLOATS;                  // [2][20][8 bins][16]: ln2_w * r of a chunk, double buffered
+    float *GXW = R + 2 * CH * RP8;                 // [20][18 slots][16] pitch GP20: ln1_w * gx, ring over bins
+    float *W31 = GXW + CH * GP20;                  // [2 row tiles][15 k-steps][64 lanes]: the (3,1) conv's A fragments
+    float *WG = W31 + 2 * 15 * 64;                 // [2][KS][64]: conv_gate's A fragments; behind them conv_input's
+    constexpr bool WI_LDS = true;
+    float *WS = R;                                 // epilogue only (R and the ring are dead then): [8 waves][2 tiles] transpose scratch
+    float *RED = GXW;                              //   "          : reduction scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, i = lane & 15;
-    const int fbin = wave & 3, mt = wave >> 2;
-    const bool rows_ok = mt == 0 || q == 0;        // this lane's four output channels 16 mt + 4 q + r exist (20 channels)
-
     for (int e = tid; e < TBLF_FLOATS / 4; e += NTH) reinterpret_cast<f32x4 *>(TBL)[e] = ldg4(p.w.fwd_tbl + 4 * e);
-    float wgf[KS], wif[KS], w31f[15], bg[4], bi[4];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        wgf[s] = p.w.gate_w[(mt * 16 + i) * CIN + 4 * s + q];
-        wif[s] = p.w.in_w[(mt * 16 + i) * CIN + 4 * s + q];
+    for (int e = tid; e < 2 * 15 * 64; e += NTH) W31[e] = p.w.conv_w[((e >> 6) / 15 * 16 + (e & 15)) * 60 + 4 * ((e >> 6) % 15) + ((e >> 4) & 3)];
+    for (int e = tid; e < 2 * KS * 64; e += NTH) {
+        const int idx = ((e >> 6) / KS * 16 + (e & 15)) * CIN + 4 * ((e >> 6) % KS) + ((e >> 4) & 3);
+        WG[e] = p.w.gate_w[idx];
+        if (WI_LDS) WG[2 * KS * 64 + e] = p.w.in_w[idx];
     }
+    float wif[WI_LDS ? 1 : 2][WI_LDS ? 1 : KS], bi[2][4];
 #pragma unroll
-    for (int s = 0; s < 15; ++s) w31f[s] = p.w.conv_w[(mt * 16 + i) * 60 + 4 * s + q];
+    for (int m = 0; m < 2; ++m) {
+        if (!WI_LDS) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { bg[r] = p.w.gate_b[mt * 16 + 4 * q + r]; bi[r] = p.w.in_b[mt * 16 + 4 * q + r]; }
-    // DFT tile ownership: wave = (channel group cg of five channels, row-tile group mg of five tiles); tile jj = (cc, mm) = (jj / 5,
-    // jj % 5) -> channel 5 cg + cc, row tile 5 mg + mm: every LDS address below is one base register plus a compile-time offset, and
-    // a k-step needs five table fragments and five data fragments for its 25 MFMAs
-    const int cg = wave >> 1, mg = wave & 1;
+            for (int s = 0; s < KS; ++s) wif[WI_LDS ? 0 : m][WI_LDS ? 0 : s] = p.w.in_w[(m * 16 + i) * CIN + 4 * s + q];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bi[m][r] = p.w.in_b[m * 16 + 4 * q + r];
+    }
+    const float *wg_w = WG + lane, *wi_w = WG + 2 * KS * 64 + lane;
+    const int ac = p.a.c, ks_a = ac >> 2;
+    const bool up_ok = q == 0;                     // rows 16 + 4 q + r of the upper tile exist for q == 0 only (20 channels)
+    const int cg = wave >> 1, mg = wave & 1;       // DFT tiles: channels 5 cg .. + 4, row tiles 5 mg .. + 4; tile jj = (jj / 5, jj % 5)
     const float *tbl_w = TBL + (5 * mg * KSF) * 64 + lane;
-    const float *r_w = R + (5 * cg) * RP + q * 16 + i;
-    const int ac = p.a.c;
-    const int co0 = min(mt * 16 + 4 * q, CH - 4);  // clamped channel base for the per-lane LayerNorm weight loads
+    const float *r_w = R + (5 * cg) * RP8 + q * 16 + i;
+    float *ws = WS + wave * WS_FLOATS;
+    __syncthreads();
 
     for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
-        f32x4 acc[TPW];
+        f32x4 acc[25];
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jj = 0; jj < 25; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float mean0 = p.stats0[((size_t)tile * 16 + i) * 2], inv0 = p.stats0[((size_t)tile * 16 + i) * 2 + 1];
+        const float mi0 = mean0 * inv0;
+        // Every global access below is a UNIFORM base (scalar registers) plus an unsigned 32-bit per-lane offset: with per-lane 64-bit
+        // pointers the address pairs alone overflowed the register file, and a scratch reload inside the loop waits out the whole
+        // in-order prefetch queue.
         const float *abase = p.a.ptr + ((size_t)tile * p.a.c_total + p.a.c_off) * F * 16;
-        const float *bbase = p.b.ptr ? p.b.ptr + ((size_t)tile * p.b.c_total + p.b.c_off) * F * 16 : abase;
-        f32x4 pre[NIT];
-        float pw0 = 1.f, pb0 = 0.f, w1n[4], w2n[4], w1c[4], w2c[4];
-        auto request = [&](int j) {
+        const float *bbase = p.b.ptr ? p.b.ptr + ((size_t)tile * p.b.c_total + p.b.c_off - ac) * F * 16 : abase;
+        const unsigned lq = (unsigned)(q * F * 16 + i);      // channel q of a k-step, frame i
+        float x0[KS], x1[KS];                       // input rows of even / odd iterations (ping-pong: no copies), requested an iteration ahead
+        auto load_x = [&](int j, float (&x)[KS]) {
+            const unsigned f = (unsigned)min(8 * j + wave, F - 1);
+            unsigned lql = lq;                      // laundered: left visible, the compiler forms one 64-bit pointer per k-step outside the
+            asm volatile("" : "+v"(lql));           // loop and spills them; the reloads then wait out the whole prefetch queue
 #pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int e = min(tid + NTH * u, CIN * 16 - 1), row = e >> 2, tq = e & 3, ci = row >> 2, fl = row & 3;
-                const int f = 4 * j + fl;
-                const float *src = ci < ac ? abase + (size_t)(ci * F + f) * 16 : bbase + (size_t)((ci - ac) * F + f) * 16;
-                pre[u] = (CFB_EXP & 2) ? f32x4{0.1f, 0.2f, 0.3f, 0.4f} : ldg4(src + 4 * tq);
-            }
-            const int e = min(tid, CIN * 4 - 1), ci = e >> 2, f = 4 * j + (e & 3);
-            pw0 = ldg1(p.w.ln0_w + ci * F + f);
-            pb0 = ldg1(p.w.ln0_b + ci * F + f);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                w1n[r] = ldg1(p.w.ln1_w + (co0 + r) * F + 4 * j + fbin);
-                w2n[r] = ldg1(p.w.ln2_w + (co0 + r) * F + 4 * j + fbin);
-            }
+            for (int s = 0; s < KS; ++s) x[s] = (CFB_EXP & 2) ? 0.25f : ldg1o(s < ks_a ? abase : bbase, 4u * (lql + (unsigned)(s * 4 * F * 16) + f * 16u));
         };
-        auto park = [&]() {
-#pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int e = tid + NTH * u, row = e >> 2, tq = e & 3, ci = row >> 2, fl = row & 3;
-                if (e < CIN * 16) *reinterpret_cast<f32x4 *>(X + ci * XP + fl * 16 + 4 * tq) = pre[u];
-            }
-            if (tid < CIN * 4) { WB[2 * tid] = pw0; WB[2 * tid + 1] = pb0; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { w1c[r] = w1n[r]; w2c[r] = w2n[r]; }
-        };
-        for (int e = tid; e < CH * 16; e += NTH) GXW[(e >> 4) * GP + 15 * 16 + (e & 15)] = 0.f;      // bin -1 (zero padding of the (3,1) conv)
-        request(0);
-        park();
-        request(1);
+        load_x(0, x0);
+        for (int e = tid; e < CH * 16; e += NTH) GXW[(e >> 4) * GP20 + (NSLOT - 1) * 16 + (e & 15)] = 0.f;      // bin -1: zero padding of the (3,1) conv
         Acc1 sg, sr;
         sg.init(); sr.init();
-        for (int j = 0; j <= KSF; ++j) {
-            CFB_SYNC();                 // chunk j is parked; nobody reads R / the ring slots written below any more
-            if (j < KSF) {
-                // ---- gate / input 1x1 convs of bin 4 j + fbin, output-channel tile mt
-                const int f = 4 * j + fbin;
-                f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ai = {0.f, 0.f, 0.f, 0.f};
-                float xv[KS], lv[KS];
+        float *y1_t = p.y1 + (size_t)tile * (CH * F * 16);
+        // One iteration, straight-line code: C31 = the (3,1) conv of output bin 8 j - 9 + w (its result is stored only if that bin exists),
+        // DFT = k-steps 2 (j - 1), 2 (j - 1) + 1, FRONT = the 1x1 convs + gate arithmetic of bin 8 j + w.  Order: the L2-resident
+        // tables of this bin are requested first, the (3,1) conv and the DFT run, then the 1x1 convs (their operand xc was requested an
+        // iteration ago), the gate arithmetic, the LDS hand-over, and the y1 stores last.
+        auto iter = [&](auto front_c, auto c31_c, auto dft_c, int j, const float (&xc)[KS]) {
+            constexpr bool FRONT = decltype(front_c)::value, C31 = decltype(c31_c)::value, DFT = decltype(dft_c)::value;
+            const int f = 8 * j + wave, fo = 8 * j - 9 + wave;
+            unsigned qv = (unsigned)q, iv = (unsigned)i;      // laundered lane indices for this iteration's global addresses (see load_x)
+            asm volatile("" : "+v"(qv), "+v"(iv));
+            float w0c[KS];
+            if (FRONT) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    xv[s] = X[(4 * s + q) * XP + fbin * 16 + i];
-                    const float2 wb = *reinterpret_cast<const float2 *>(WB + 2 * ((4 * s + q) * 4 + fbin));
-                    const float sc = inv0 * wb.x;
-                    lv[s] = fmaf(xv[s], sc, wb.y - mean0 * sc);
+                for (int s = 0; s < KS; ++s) w0c[s] = ldg1o(p.w.ln0_w, 4u * (qv * (unsigned)F + (unsigned)(4 * s * F + f)));
+            }
+            f32x4 a3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const float *rb_p = r_w + ((j - 1) & 1) * CH * RP8;
+            const int sl0 = (fo + NSLOT - 1) % NSLOT;    // slot of bin fo - 1 (fo >= -1)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float tf[5], rb[5];
+                __builtin_amdgcn_sched_barrier(0);      // one k-step's fragment reads at a time
+                if (DFT && !(CFB_EXP & 16)) {
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) { tf[u] = tbl_w[(u * KSF + 2 * (j - 1) + ks) * 64]; rb[u] = rb_p[u * RP8 + ks * 64]; }
                 }
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    if (CFB_EXP & 4) { ag[0] += lv[s]; ai[0] += xv[s]; continue; }
-                    ag = mfma16(wgf[s], lv[s], ag);
-                    ai = mfma16(wif[s], xv[s], ai);
-                }
-                if ((CFB_EXP & 32) && ag[0] != 123.f) {
-                    if (rows_ok)
+                for (int g = 0; g < 5; ++g) {
+                    if (C31 && !(CFB_EXP & 8)) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { GXW[(mt * 16 + 4 * q + r) * GP + (f & 15) * 16 + i] = ag[r]; R[(mt * 16 + 4 * q + r) * RP + fbin * 16 + i] = ai[r]; }
-                } else
-                if (rows_ok) {
+                        for (int h = 0; h < 2; ++h) {
+                            const int s = (ks * 5 + g) * 2 + h;          // 0..19; the fifteen k-steps run at s < 15
+                            if (s < 15) {
+                                const int slot = sl0 + s / 5 >= NSLOT ? sl0 + s / 5 - NSLOT : sl0 + s / 5;
+                                const float bv = GXW[(4 * (s % 5) + q) * GP20 + slot * 16 + i];
+                                a3[0] = mfma16(W31[s * 64 + lane], bv, a3[0]);
+                                a3[1] = mfma16(W31[(15 + s) * 64 + lane], bv, a3[1]);
+                            }
+                        }
+                    }
+                    if (DFT && !(CFB_EXP & 16)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int co = mt * 16 + 4 * q + r;
-                        const float g = gate_sigmoid(ag[r] + bg[r]), xi = ai[r] + bi[r], gx = g * xi, rr = xi - gx;
-                        sg.add(gx);
-                        sr.add(rr);
-                        GXW[co * GP + (f & 15) * 16 + i] = gx * w1c[r];
-                        R[co * RP + fbin * 16 + i] = rr * w2c[r];
+                        for (int u = 0; u < 5; ++u) acc[g * 5 + u] = mfma16(tf[u], rb[g], acc[g * 5 + u]);
                     }
                 }
-            } else {
-                for (int e = tid; e < CH * 16; e += NTH) GXW[(e >> 4) * GP + (F & 15) * 16 + (e & 15)] = 0.f;      // bin 160 (zero padding)
             }
-            CFB_SYNC();
-            if (j + 1 < KSF) {
-                park();                                   // chunk j + 1 (requested a phase ago) -> X
-                if (j + 2 < KSF) request(j + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- y1 rows of output bin fo (stores: behind every load this iteration still waits for -- a wave's memory counter retires
+            // in order, and a load issued behind a store waits out the store's acknowledgement too)
+            if (FRONT) {
+                // the two output-channel tiles one after the other (together their accumulators and table rows are 48 more live registers
+                // than this kernel has): table rows (GW, GB, ln1_w, ln2_w; L2-resident) requested, the tile's two chains of KS MFMAs
+                // run, then the gate arithmetic of its rows
+                float xw[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) xw[s] = xc[s] * w0c[s];
+                const int slot = f % NSLOT;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    __builtin_amdgcn_sched_barrier(0);      // (keeps the second tile's loads and MFMAs behind the first tile's arithmetic)
+                    f32x4 ta[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        ta[k] = ldg4o(p.w.front_tab, 4u * ((unsigned)((f * 4 + k) * CH) + (m == 0 ? 4u * qv : 16u)));
+                    f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ai = {bi[m][0], bi[m][1], bi[m][2], bi[m][3]};
+                    if (!(CFB_EXP & 4)) {
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            ag = mfma16(wg_w[(m * KS + s) * 64], xw[s], ag);
+                            ai = mfma16(WI_LDS ? wi_w[(m * KS + s) * 64] : wif[WI_LDS ? 0 : m][WI_LDS ? 0 : s], xc[s], ai);
+                        }
+                    }
+                    if (m == 1 && !up_ok) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = m * 16 + 4 * q + r;
+                        // LN0 commuted behind the gate conv: inv0 * (Wg (w0 x)) + (Wg b0 + bias) - mean0 inv0 (Wg w0)
+                        const float pre = fmaf(inv0, ag[r], fmaf(-mi0, ta[0][r], ta[1][r]));
+                        const float g = (CFB_EXP & 32) ? pre : gate_sigmoid(pre), xi = ai[r], gx = g * xi, rr = xi - gx;
+                        if (!C31 && m == 0 && r == 0) { sg.K = gx; sr.K = rr; }      // the tile's first iteration (no (3,1) conv yet): the shifts
+                        if (!(CFB_EXP & 32)) { sg.addk(gx); sr.addk(rr); }
+                        GXW[co * GP20 + slot * 16 + i] = gx * ta[2][r];
+                        R[(j & 1) * CH * RP8 + co * RP8 + wave * 16 + i] = rr * ta[3][r];
+                    }
+                }
+            } else if (j == NIT8 && wave == 0) {
+                for (int e = lane; e < CH * 16; e += 64) GXW[(e >> 4) * GP20 + (F % NSLOT) * 16 + (e & 15)] = 0.f;      // bin 160: zero padding
             }
-            // ---- (3,1) conv of output bin 4 j - 1 + fbin on the ring (bins fo - 1 .. fo + 1), raw: LN1 is applied by cfb_back
-            const int fo = 4 * j - 1 + fbin;
-            if (fo >= 0 && fo < F && !(CFB_EXP & 8)) {
-                f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
-                float bv[15];
+            if (C31 && fo >= 0 && fo < F && !(CFB_EXP & (8 | 64))) {
+                const unsigned o = qv * (unsigned)(4 * F * 16) + iv + (unsigned)(fo * 16);
 #pragma unroll
-                for (int s = 0; s < 15; ++s) bv[s] = GXW[(4 * (s % 5) + q) * GP + ((fo + s / 5 - 1) & 15) * 16 + i];
+                for (int r = 0; r < 4; ++r) stg1o(y1_t, 4u * (o + (unsigned)(r * F * 16)), a3[0][r]);
+                if (up_ok) {
 #pragma unroll
-                for (int s = 0; s < 15; ++s) a3 = mfma16(w31f[s], bv[s], a3);
-                if (rows_ok && (!(CFB_EXP & 64) || a3[0] == 123.f)) {
-                    float *dst = p.y1 + ft_idx(tile, CH, mt * 16 + 4 * q, F, fo) + i;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) stg1(dst + (size_t)r * F * 16, a3[r]);
+                    for (int r = 0; r < 4; ++r) stg1o(y1_t, 4u * (o + (unsigned)((16 + r) * F * 16)), a3[1][r]);
                 }
             }
-            // ---- DFT k-step j: 25 tiles (channel c, row tile m) per wave
-            if (j < KSF && !(CFB_EXP & 16)) {
-                float ta[5], rb[5];
-#pragma unroll
-                for (int u = 0; u < 5; ++u) { ta[u] = tbl_w[(u * KSF + j) * 64]; rb[u] = r_w[u * RP]; }
-#pragma unroll
-                for (int jj = 0; jj < TPW; ++jj) acc[jj] = mfma16(ta[jj % 5], rb[jj / 5], acc[jj]);
-            }
+            lds_barrier();
+        };
+        using T_ = std::true_type; using F_ = std::false_type;
+        load_x(1, x1);
+        iter(T_{}, F_{}, F_{}, 0, x0);
+        for (int j = 1; j < NIT8 - 1; j += 2) {         // (1, 2), (3, 4), ... (17, 18)
+            load_x(j + 1, x0);
+            iter(T_{}, T_{}, T_{}, j, x1);
+            load_x(j + 2, x1);
+            iter(T_{}, T_{}, T_{}, j + 1, x0);
         }
-        // ---- LayerNorm statistics of gx (LN1, handed to cfb_back) and r (LN2, applied here)
+        iter(T_{}, T_{}, T_{}, NIT8 - 1, x1);           // 19
+        iter(F_{}, T_{}, T_{}, NIT8, x0);               // 20: drains the (3,1) conv (bins 151 .. 158) and the DFT's last two k-steps
+        iter(F_{}, T_{}, F_{}, NIT8 + 1, x0);           // 21: bin 159
+        // ---- LayerNorm statistics of gx (LN1, handed to cfb_back) and r (LN2, applied below): every wave saw one bin in eight
         float n1, m1, M1, n2, m2, M2;
         sg.finish(n1, m1, M1);
         sr.finish(n2, m2, M2);
         chan_merge_q(n1, m1, M1);
         chan_merge_q(n2, m2, M2);
-        __syncthreads();
         if (lane < 16) {
             float *o = RED + (wave * 16 + i) * 6;
             o[0] = n1; o[1] = m1; o[2] = M1; o[3] = n2; o[4] = m2; o[5] = M2;
         }
-        __syncthreads();
+        lds_barrier();
         float *RES = RED + 8 * 16 * 6;
         if (tid < 16) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
@@ -274,66 +383,74 @@ __global__ __launch_bounds__(NTH) void cfb_front_kernel(FrontArgs p) {
             const float inv1 = 1.0f / (sqrtf(a2 / (a0 - 1.f)) + 1e-6f), sd2 = sqrtf(b2 / (b0 - 1.f)) + 1e-6f;
             p.stats1[((size_t)tile * 16 + tid) * 2] = a1;
             p.stats1[((size_t)tile * 16 + tid) * 2 + 1] = inv1;
-            RES[tid * 8] = b1; RES[tid * 8 + 1] = sd2; RES[tid * 8 + 2] = 1.0f / sd2;
+            RES[tid * 4] = b1; RES[tid * 4 + 1] = sd2; RES[tid * 4 + 2] = 1.0f / sd2;
         }
-        __syncthreads();
-        const float mean2 = RES[i * 8], sd2 = RES[i * 8 + 1], inv2 = RES[i * 8 + 2];
+        lds_barrier();
+        const float mean2 = RES[i * 4], sd2 = RES[i * 4 + 1], inv2 = RES[i * 4 + 2];
         const float bfix = q == 0 ? -mean2 : (q == 1 ? sd2 : 0.f);
         float ssum = 0.f;
-        int lane_l = lane;
-        asm volatile("" : "+v"(lane_l));
+        int lane_l = lane, ql = q, il = i;
+        asm volatile("" : "+v"(lane_l), "+v"(ql), "+v"(il));
         const float *fix_w = p.w.fwd_fix + ((5 * cg) * 10 + 5 * mg) * 64;
+        const unsigned lane_u = (unsigned)lane_l;
+        {
+            float fx[5];
 #pragma unroll
-        for (int jj = 0; jj < TPW; ++jj) {
-            acc[jj] = mfma16(ldg1(fix_w + ((jj / 5) * 10 + jj % 5) * 64 + lane_l), bfix, acc[jj]);
-            acc[jj] *= inv2;
-            ssum += (acc[jj][0] + acc[jj][1]) + (acc[jj][2] + acc[jj][3]);
+            for (int u = 0; u < 5; ++u) fx[u] = ldg1o(fix_w, 4u * (lane_u + (unsigned)(u * 64)));
+#pragma unroll
+            for (int jj = 0; jj < 25; ++jj) {
+                acc[jj] = mfma16(fx[jj % 5], bfix, acc[jj]);
+                if (jj + 5 < 25) fx[jj % 5] = ldg1o(fix_w, 4u * (lane_u + (unsigned)((((jj + 5) / 5) * 10 + (jj + 5) % 5) * 64)));
+                acc[jj] *= inv2;
+                ssum += (acc[jj][0] + acc[jj][1]) + (acc[jj][2] + acc[jj][3]);
+            }
         }
         // ---- statistics of S over (40 channels, 81 bins): 160 stored values + 2 structural zeros per channel, two passes in registers
+        float *RD = RES + 64;
         ssum = sum_q(ssum);
-        if (lane < 16) RED[wave * 16 + i] = ssum;
-        __syncthreads();
+        if (lane < 16) RD[wave * 16 + i] = ssum;
+        lds_barrier();
         float tot = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) tot += RED[w * 16 + i];
+        for (int w = 0; w < 8; ++w) tot += RD[w * 16 + i];
         const float nS = (float)(2 * CH * CF), meanS = tot / nS;
         float dsum = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < TPW; ++jj)
+        for (int jj = 0; jj < 25; ++jj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float d = acc[jj][r] - meanS; dsum = fmaf(d, d, dsum); }
         dsum = sum_q(dsum);
-        __syncthreads();
-        if (lane < 16) RED[wave * 16 + i] = dsum;
-        __syncthreads();
+        if (lane < 16) RD[128 + wave * 16 + i] = dsum;
+        lds_barrier();
         if (tid < 16) {
             float M = 2.f * CH * meanS * meanS;                  // the imaginary parts of bins 0 and 80
 #pragma unroll
-            for (int w = 0; w < 8; ++w) M += RED[w * 16 + tid];
+            for (int w = 0; w < 8; ++w) M += RD[128 + w * 16 + tid];
             p.stats_li[((size_t)tile * 16 + tid) * 2] = meanS;
             p.stats_li[((size_t)tile * 16 + tid) * 2 + 1] = 1.0f / (sqrtf(M / (nS - 1.f)) + 1e-6f);
         }
-        // ---- S -> li[40][81]: table rows 0..80 = cos bins of channel c, rows 81..159 = sin bins 1..79 of channel 20 + c
-        // (32-bit offsets from the tile's base, formed from laundered lane indices: left visible, the compiler hoists the hundred
-        // loop-invariant store addresses out of the tile loop and spills them)
-        {
-            int ql = q, il = i;
-            asm volatile("" : "+v"(ql), "+v"(il));
+        // ---- S -> li[40][81]: table rows 0..80 = cos bins of channel c, rows 81..159 = sin bins 1..79 of channel 20 + c; one 16-byte
+        // store per lane and tile through the wave's transpose scratch
+        if (!(CFB_EXP & 256)) {
             float *li_t = p.li + (size_t)tile * (2 * CH * CF * 16);
+            CFB_FENCE();
+            put_d(ws, ql, il, acc[0]);
 #pragma unroll
-            for (int jj = 0; jj < TPW; ++jj) {
+            for (int jj = 0; jj < 25; ++jj) {
                 const int c = 5 * cg + jj / 5, m = 5 * mg + jj % 5;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * m + 4 * ql + r;
-                    const int ch = row <= 80 ? c : CH + c, bin = row <= 80 ? row : row - 80;
-                    stg1(li_t + (ch * CF + bin) * 16 + il, acc[jj][r]);
-                }
+                CFB_FENCE();
+                if (jj + 1 < 25) put_d(ws + ((jj + 1) & 1) * WS_TILE, ql, il, acc[jj + 1]);
+                CFB_FENCE();
+                const f32x4 v = get_rows(ws + (jj & 1) * WS_TILE, lane_l);
+                CFB_FENCE();
+                const int row = 16 * m + (lane_l >> 2);
+                const int ch = row <= 80 ? c : CH + c, bin = row <= 80 ? row : row - 80;
+                stg4o(li_t, 4u * (unsigned)((ch * CF + bin) * 16 + 4 * (lane_l & 3)), v);
             }
+            for (int e = tid; e < CH * 2 * 16; e += NTH)
+                li_t[((CH + (e >> 5)) * CF + (((e >> 4) & 1) ? 80 : 0)) * 16 + (e & 15)] = 0.f;
         }
-        for (int e = tid; e < CH * 2 * 16; e += NTH)
-            p.li[ft_idx(tile, 2 * CH, CH + (e >> 5), CF, ((e >> 4) & 1) ? 80 : 0) + (e & 15)] = 0.f;
-        __syncthreads();
+        lds_barrier();                              // the scratch aliases R and the ring
     }
 }
 
@@ -345,154 +462,216 @@ struct BackArgs {
     int tiles;
 };
 
+// Second half of the block.  Every wave does BOTH kinds of work here (the producer / DFT-wave split of cfb_front left each role
+// waiting on the other: cycle accounting showed the producers stalled 42 % on their operand loads and the DFT waves 37 % in a
+// load-bound prologue and at barriers -- memory time and MFMA time added up).  Per iteration of EIGHT ceps bins, wave w
+//   * computes CepsUnit's Linear 40 -> 40 for bin 8 c + w (three row tiles sharing the operand, read straight from global memory
+//     one iteration = ~7 us ahead) and the complex product with the spectrum  -> OB[c & 1],
+//   * accumulates the pinv inverse DFT of the PREVIOUS chunk (two real-part and two imaginary-part k-steps: 100 MFMAs on its 25
+//     accumulator tiles) from OB[(c - 1) & 1],
+// the Linear's three dependent chains interleaved with the independent DFT MFMAs; ONE LDS-only barrier per iteration.
+constexpr int OP8 = 2 * 8 * 16;                    // OB pitch per channel: [re | im][8 bins][16]
+constexpr int NCH8 = 11;                           // chunks of eight ceps bins (81 -> 88)
+
 __global__ __launch_bounds__(NTH) void cfb_back_kernel(BackArgs p) {
-    constexpr int NCH = 21, NIT = 3;               // chunks of four ceps bins (81 -> 84); float4 staging items per thread (1280 / 512)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *TI = lds;                               // [10 row tiles][41 k-steps][64 lanes]: 21 real-part + 20 imaginary-part steps
-    float *HF = TI + TBLI_FLOATS;                  // [40][4 bins][16] pitch XP: LSTM output
-    float *SX = HF + 2 * CH * XP;                  // [40][4 bins][16]: spectrum
-    float *OB = SX + 2 * CH * XP;                  // [20][re | im][4 bins][16]: complex product
-    float *RED = OB + CH * OP;
+    float *OB = TI + TBLI_FLOATS;                  // [2][20][re | im][8 bins][16]: complex product, double buffered
+    float *WL = OB + 2 * CH * OP8;                 // [3 row tiles][10 k-steps][64 lanes]: the Linear's A fragments (30 registers otherwise)
+    float *WS = OB;                                // prologue / epilogue only (OB is dead then): [8 waves][2 tiles] transpose scratch
+    float *RED = OB + 8 * WS_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, i = lane & 15;
     for (int e = tid; e < TBLI_FLOATS / 4; e += NTH) reinterpret_cast<f32x4 *>(TI)[e] = ldg4(p.w.inv_tbl + 4 * e);
     // Linear 40 -> 40 with rows permuted so that a lane's four D rows are (re c, re c+1, im c, im c+1), c = 8 mt + 2 q
-    const int mt0 = wave >> 2, fl0 = wave & 3;
-    float wl0[10], wl2[10], bl0[4], bl2[4];
+    for (int e = tid; e < 3 * 10 * 64; e += NTH) WL[e] = p.w.lin_w[((e >> 6) / 10 * 16 + (e & 15)) * 40 + 4 * ((e >> 6) % 10) + ((e >> 4) & 3)];
+    float bl[3][4];
 #pragma unroll
-    for (int s = 0; s < 10; ++s) {
-        wl0[s] = p.w.lin_w[(mt0 * 16 + i) * 40 + 4 * s + q];
-        wl2[s] = p.w.lin_w[(2 * 16 + i) * 40 + 4 * s + q];
-    }
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { bl0[r] = p.w.lin_b[mt0 * 16 + 4 * q + r]; bl2[r] = p.w.lin_b[2 * 16 + 4 * q + r]; }
-    const int cg = wave >> 1, mg = wave & 1;           // tile ownership as in cfb_front
+        for (int r = 0; r < 4; ++r) bl[m][r] = p.w.lin_b[m * 16 + 4 * q + r];
+    const float *wl_w = WL + lane;
+    const int cg = wave >> 1, mg = wave & 1;           // DFT tiles: channels 5 cg .. + 4, row tiles 5 mg .. + 4; tile jj = (jj / 5, jj % 5)
     const float *tbl_w = TI + (5 * mg * KSI) * 64 + lane;
-    const float *o_w = OB + (5 * cg) * OP + q * 16 + i;
+    const float *o_w = OB + (5 * cg) * OP8 + q * 16 + i;
+    float *ws = WS + wave * WS_FLOATS;
+    __syncthreads();
+    CFB_T0();
 
+    f32x4 acc[25];
+    // this lane's place in a tile's row layout + the wave's first tile (uniform bases + unsigned 32-bit offsets everywhere: see cfb_front)
+    const unsigned rowoff = (unsigned)((lane >> 2) * 16 + 4 * (lane & 3) + ((5 * cg) * F + 16 * (5 * mg)) * 16);
+    auto y1_load = [&](int tile) {                  // the accumulators START as y1 (row layout; transposed below)
+        const float *y1_t = p.y1 + (size_t)tile * (CH * F * 16);
+#pragma unroll
+        for (int jj = 0; jj < 25; ++jj) acc[jj] = (CFB_EXP & 512) ? f32x4{0.f, 0.f, 0.f, 0.f} : ldg4o(y1_t, 4u * (rowoff + (unsigned)(((jj / 5) * F + 16 * (jj % 5)) * 16)));
+    };
+    if ((int)blockIdx.x < p.tiles) y1_load(blockIdx.x);
     for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
-        f32x4 acc[TPW];
+        // ---- operands of this wave's Linear: bin 8 c + w, requested one iteration ahead
+        // (uniform bases + unsigned 32-bit per-lane offsets: see cfb_front)
+        const float *hf_t = p.hf + (size_t)tile * (2 * CH * CF * 16);
+        const float *li_t = p.li + (size_t)tile * (2 * CH * CF * 16);
+        const unsigned lq = (unsigned)(q * CF * 16 + i), li_ = (unsigned)i;
+        float h0[10], h1[10], s0[12], s1[12];       // operand sets of even / odd chunks (ping-pong: no copies, so a set's loads are
+                                                    // waited for only where the next iteration first uses them)
+        auto load = [&](int c, float (&h)[10], float (&sv)[12]) {
+            const int bin = min(8 * c + wave, CF - 1);            // bins past 80 meet zero table rows: any finite value
+            unsigned lql = lq + (unsigned)(bin * 16), lil = li_ + (unsigned)(bin * 16);      // laundered: the 22 offsets are formed at each call,
+            asm volatile("" : "+v"(lql), "+v"(lil));                                            // not hoisted and spilled
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 pre[NIT];
-        auto request = [&](int jb) {
+            for (int s = 0; s < 10; ++s) h[s] = (CFB_EXP & 2) ? 0.25f : ldg1o(hf_t, 4u * (lql + (unsigned)(s * 4 * CF * 16)));
 #pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int e = min(tid + NTH * u, 1279), which = e >= 640, e2 = e - 640 * which, row = e2 >> 2, tq = e2 & 3;
-                const int ch = row >> 2, bin = min(4 * jb + (row & 3), CF - 1);           // bins past 80 meet zero table rows: any finite value
-                pre[u] = (CFB_EXP & 2) ? f32x4{0.1f, 0.2f, 0.3f, 0.4f} : ldg4((which ? p.li : p.hf) + ft_idx(tile, 2 * CH, ch, CF, bin) + 4 * tq);
-            }
-        };
-        auto park = [&]() {
+            for (int m = 0; m < 3; ++m) {
+                const int ca = min(8 * m + 2 * q, CH - 2);
 #pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int e = tid + NTH * u, which = e >= 640, e2 = e - 640 * which, row = e2 >> 2, tq = e2 & 3;
-                if (e < 1280) *reinterpret_cast<f32x4 *>((which ? SX : HF) + (row >> 2) * XP + (row & 3) * 16 + 4 * tq) = pre[u];
-            }
-        };
-        auto lin_item = [&](int fl, int mt, const float (&wl)[10], const float (&bl)[4]) {
-            f32x4 P = {bl[0], bl[1], bl[2], bl[3]};
-            float hv[10];
-#pragma unroll
-            for (int s = 0; s < 10; ++s) hv[s] = HF[(4 * s + q) * XP + fl * 16 + i];
-#pragma unroll
-            for (int s = 0; s < 10; ++s) P = mfma16(wl[s], hv[s], P);
-            const int ca = 8 * mt + 2 * q;
-            if (ca < CH) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int c = ca + h;
-                    const float sre = SX[c * XP + fl * 16 + i], sim = SX[(CH + c) * XP + fl * 16 + i];
-                    const float pr = P[h], pi = P[2 + h];
-                    OB[c * OP + fl * 16 + i] = pr * sre - pi * sim;
-                    OB[c * OP + 64 + fl * 16 + i] = pr * sim + pi * sre;
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    sv[4 * m + h2] = (CFB_EXP & 2) ? 0.5f : ldg1o(li_t, 4u * (lil + (unsigned)((ca + h2) * CF * 16)));
+                    sv[4 * m + 2 + h2] = (CFB_EXP & 2) ? 0.5f : ldg1o(li_t, 4u * (lil + (unsigned)((CH + ca + h2) * CF * 16)));
                 }
             }
         };
-        request(0);
-        park();
-        request(1);
-        for (int jb = 0; jb < NCH; ++jb) {
-            CFB_SYNC();
-            if (!(CFB_EXP & 128)) {
-                lin_item(fl0, mt0, wl0, bl0);
-                if (wave < 4) lin_item(wave, 2, wl2, bl2);
-            }
-            CFB_SYNC();
-            if (jb + 1 < NCH) {
-                park();
-                if (jb + 2 < NCH) request(jb + 2);
-            }
-            if (!(CFB_EXP & 16)) {
-                float ta[5], ob[5];
-#pragma unroll
-                for (int u = 0; u < 5; ++u) { ta[u] = tbl_w[(u * KSI + jb) * 64]; ob[u] = o_w[u * OP]; }
-#pragma unroll
-                for (int jj = 0; jj < TPW; ++jj) acc[jj] = mfma16(ta[jj % 5], ob[jj / 5], acc[jj]);
-            }
-            if (jb < NCH - 1 && !(CFB_EXP & 16)) {
-                float ta[5], ob[5];
-#pragma unroll
-                for (int u = 0; u < 5; ++u) { ta[u] = tbl_w[(u * KSI + NCH + jb) * 64]; ob[u] = o_w[u * OP + 64]; }
-#pragma unroll
-                for (int jj = 0; jj < TPW; ++jj) acc[jj] = mfma16(ta[jj % 5], ob[jj / 5], acc[jj]);
-            }
-        }
-        // ---- out = inv1 * (y1 - mean1 * CW) + CB + ceps: the (CW, CB) term is one more k-step, y1 is read in D layout
+        load(0, h0, s0);
+        // ---- acc = inv1 * (y1 - mean1 * CW) + CB: y1 arrived as one 16-byte load per lane and tile (requested during the previous
+        // tile's epilogue), is turned into the MFMA D layout through the wave's LDS scratch; the (CW, CB) term is one k-step
         const float mean1 = p.stats1[((size_t)tile * 16 + i) * 2], inv1 = p.stats1[((size_t)tile * 16 + i) * 2 + 1];
         const float bfix = q == 0 ? -mean1 * inv1 : (q == 1 ? 1.f : 0.f);
-        float ssum = 0.f;
         int ql = q, il = i, lane_l = lane;
-        asm volatile("" : "+v"(ql), "+v"(il), "+v"(lane_l));      // see cfb_front: keeps the epilogue's addresses out of the tile loop's preheader
-        const float *y1_t = p.y1 + (size_t)tile * (CH * F * 16);
-        float *out_t = p.out.ptr + ((size_t)tile * p.out.c_total + p.out.c_off) * (F * 16);
+        asm volatile("" : "+v"(ql), "+v"(il), "+v"(lane_l));      // keeps the tile addresses out of the tile loop's preheader
         const float *fix_w = p.w.out_fix + ((5 * cg) * 10 + 5 * mg) * 64;
+        const unsigned lane_u = (unsigned)lane_l;
+        {
+            float fx[5];
 #pragma unroll
-        for (int jj = 0; jj < TPW; ++jj) {
-            const int c = 5 * cg + jj / 5, m = 5 * mg + jj % 5;
-            const int off = (c * F + 16 * m + 4 * ql) * 16 + il;
-            const float *ysrc = y1_t + off;
-            float yv[4];
+            for (int u = 0; u < 5; ++u) fx[u] = ldg1o(fix_w, 4u * (lane_u + (unsigned)(u * 64)));
+            CFB_FENCE();
+            put_rows(ws, lane_l, acc[0]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) yv[r] = ldg1(ysrc + r * 16);
-            acc[jj] = mfma16(ldg1(fix_w + ((jj / 5) * 10 + jj % 5) * 64 + lane_l), bfix, acc[jj]);
-            float *dst = out_t + off;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[jj][r] = fmaf(inv1, yv[r], acc[jj][r]);
-                stg1(dst + r * 16, acc[jj][r]);
-                ssum += acc[jj][r];
+            for (int jj = 0; jj < 25; ++jj) {
+                CFB_FENCE();
+                if (jj + 1 < 25) put_rows(ws + ((jj + 1) & 1) * WS_TILE, lane_l, acc[jj + 1]);
+                CFB_FENCE();
+                f32x4 d = get_d(ws + (jj & 1) * WS_TILE, ql, il);
+                CFB_FENCE();
+                d *= inv1;
+                acc[jj] = mfma16(fx[jj % 5], bfix, d);
+                if (jj + 5 < 25) fx[jj % 5] = ldg1o(fix_w, 4u * (lane_u + (unsigned)((((jj + 5) / 5) * 10 + (jj + 5) % 5) * 64)));
             }
         }
-        if (p.part) {            // (count, mean, M2) of the block's output per frame, in the partial-statistics format of dfsmn.hip
-            ssum = sum_q(ssum);
-            __syncthreads();
-            if (lane < 16) RED[wave * 16 + i] = ssum;
-            __syncthreads();
-            float tot = 0.f;
+        CFB_MARK(0);
+        lds_barrier();                              // the scratch aliases OB
+        // One iteration: Linear + complex product of chunk c from (hc, sc) -> OB[c & 1], and NK k-steps of the inverse DFT of chunk
+        // c - 1 from OB[(c - 1) & 1] (NK = 4: real 2 cm, 2 cm + 1, imaginary 2 cm, 2 cm + 1; NK = 1: the last chunk holds bin 80 only).
+        // Straight-line code: the Linear's ten steps (three chains) sit at every other slot between the DFT's groups of five MFMAs.
+        auto iter = [&](auto lin_c, auto nk_c, int c, const float (&hc)[10], const float (&sc)[12]) {
+            constexpr bool LIN = decltype(lin_c)::value;
+            constexpr int NK = decltype(nk_c)::value;
+            f32x4 P[3];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) tot += RED[w * 16 + i];
-            const float nO = (float)(CH * F), meanO = tot / nO;
-            float dsum = 0.f;
+            for (int m = 0; m < 3; ++m) P[m] = f32x4{bl[m][0], bl[m][1], bl[m][2], bl[m][3]};
+            const float *ob_p = o_w + ((c - 1) & 1) * CH * OP8;
+            const int cm = c - 1;
 #pragma unroll
-            for (int jj = 0; jj < TPW; ++jj)
+            for (int ks = 0; ks < 4; ++ks) {
+                const int part = ks >> 1, half = ks & 1;
+                float tf[5], ob[5];
+                __builtin_amdgcn_sched_barrier(0);      // one k-step's ten fragment reads at a time (hoisted together they spill)
+                if (ks < NK && !(CFB_EXP & 16)) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = acc[jj][r] - meanO; dsum = fmaf(d, d, dsum); }
-            dsum = sum_q(dsum);
-            __syncthreads();
-            if (lane < 16) RED[wave * 16 + i] = dsum;
-            __syncthreads();
-            if (tid < 16) {
-                float M = 0.f;
+                    for (int u = 0; u < 5; ++u) { tf[u] = tbl_w[(u * KSI + part * 21 + 2 * cm + half) * 64]; ob[u] = ob_p[u * OP8 + part * 128 + half * 64]; }
+                }
 #pragma unroll
-                for (int w = 0; w < 8; ++w) M += RED[w * 16 + tid];
-                float *o = p.part + (((size_t)tile * VADX_DFSMN_STAT_PARTS) * 16 + tid) * 4;
-                o[0] = nO; o[1] = meanO; o[2] = M; o[3] = 0.f;
-                float *z = o + 16 * 4;
-                z[0] = z[1] = z[2] = z[3] = 0.f;
+                for (int g = 0; g < 5; ++g) {
+                    if (LIN && !(CFB_EXP & 128) && ((ks * 5 + g) & 1) == 0) {
+                        const int s = (ks * 5 + g) >> 1;
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) P[m] = mfma16(wl_w[(m * 10 + s) * 64], hc[s], P[m]);
+                    }
+                    if (ks < NK && !(CFB_EXP & 16)) {
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) acc[g * 5 + u] = mfma16(tf[u], ob[g], acc[g * 5 + u]);
+                    }
+                }
             }
+            if (LIN) {
+                float *ob = OB + (c & 1) * CH * OP8 + wave * 16 + i;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int ca = 8 * m + 2 * q;
+                    if (ca < CH) {
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const float sre = sc[4 * m + h2], sim = sc[4 * m + 2 + h2], pr = P[m][h2], pi = P[m][2 + h2];
+                            ob[(ca + h2) * OP8] = pr * sre - pi * sim;
+                            ob[(ca + h2) * OP8 + 128] = pr * sim + pi * sre;
+                        }
+                    }
+                }
+            }
+            CFB_MARK(1);
+            lds_barrier();
+            CFB_MARK(2);
+        };
+        using T_ = std::true_type; using F_ = std::false_type;
+        load(1, h1, s1);
+        iter(T_{}, std::integral_constant<int, 0>{}, 0, h0, s0);
+        for (int c = 1; c < NCH8 - 1; c += 2) {          // chunks (1, 2), (3, 4), ... (9, 10): all four k-steps of chunks 0 .. 9 are real
+            load(c + 1, h0, s0);
+            iter(T_{}, std::integral_constant<int, 4>{}, c, h1, s1);
+            if (c + 2 < NCH8) load(c + 2, h1, s1);
+            iter(T_{}, std::integral_constant<int, 4>{}, c + 1, h0, s0);
         }
-        __syncthreads();
+        iter(F_{}, std::integral_constant<int, 1>{}, NCH8, h0, s0);        // chunk 10: bin 80, real part only
+        // ---- out: one 16-byte store per lane and tile; as a tile's registers leave, the NEXT tile's y1 is requested into them, so that
+        // its latency passes under this epilogue's reductions; (count, mean, M2) of the output per frame for the next LayerNorm
+        float ssum = 0.f, dsum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 25; ++jj) ssum += (acc[jj][0] + acc[jj][1]) + (acc[jj][2] + acc[jj][3]);
+        ssum = sum_q(ssum);
+        if (lane < 16) RED[wave * 16 + i] = ssum;
+        lds_barrier();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += RED[w * 16 + i];
+        const float nO = (float)(CH * F), meanO = tot / nO;
+#pragma unroll
+        for (int jj = 0; jj < 25; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = acc[jj][r] - meanO; dsum = fmaf(d, d, dsum); }
+        dsum = sum_q(dsum);
+        if (lane < 16) RED[128 + wave * 16 + i] = dsum;
+        float *out_t = p.out.ptr + ((size_t)tile * p.out.c_total + p.out.c_off) * (F * 16);
+        const int next = tile + gridDim.x;
+        const float *y1_n = p.y1 + (size_t)(next < p.tiles ? next : tile) * (CH * F * 16);
+        unsigned ro = rowoff;
+        asm volatile("" : "+v"(ql), "+v"(il), "+v"(lane_l), "+v"(ro));
+        CFB_FENCE();
+        put_d(ws, ql, il, acc[0]);
+#pragma unroll
+        for (int jj = 0; jj < 25; ++jj) {
+            const unsigned off = ro + (unsigned)(((jj / 5) * F + 16 * (jj % 5)) * 16);
+            CFB_FENCE();
+            if (jj + 1 < 25) put_d(ws + ((jj + 1) & 1) * WS_TILE, ql, il, acc[jj + 1]);
+            CFB_FENCE();
+            const f32x4 v = get_rows(ws + (jj & 1) * WS_TILE, lane_l);
+            CFB_FENCE();
+            if (!(CFB_EXP & 256)) stg4o(out_t, 4u * off, v);
+            if (jj >= 1)        // tile jj - 1's registers are free now: the next tile's y1 lands in them during the reductions below
+                acc[jj - 1] = (CFB_EXP & 512) ? f32x4{0.f, 0.f, 0.f, 0.f} : ldg4o(y1_n, 4u * (ro + (unsigned)((((jj - 1) / 5) * F + 16 * ((jj - 1) % 5)) * 16)));
+        }
+        acc[24] = (CFB_EXP & 512) ? f32x4{0.f, 0.f, 0.f, 0.f} : ldg4o(y1_n, 4u * (ro + (unsigned)((4 * F + 16 * 4) * 16)));
+        lds_barrier();
+        if (p.part && tid < 16) {
+            float M = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) M += RED[128 + w * 16 + tid];
+            float *o = p.part + (((size_t)tile * VADX_DFSMN_STAT_PARTS) * 16 + tid) * 4;
+            o[0] = nO; o[1] = meanO; o[2] = M; o[3] = 0.f;
+            float *z = o + 16 * 4;
+            z[0] = z[1] = z[2] = z[3] = 0.f;
+        }
+        CFB_MARK(3);
     }
+    CFB_FLUSH(8);
 }
 
 static int cu_count() {
@@ -507,8 +686,11 @@ static int cu_count() {
 }
 
 template <int CIN>
-constexpr size_t front_lds_bytes() { return (size_t)(TBLF_FLOATS + CIN * XP + CIN * 8 + CH * RP + CH * GP + RED_FLOATS) * sizeof(float); }
-constexpr size_t back_lds_bytes() { return (size_t)(TBLI_FLOATS + 4 * CH * XP + CH * OP + RED_FLOATS) * sizeof(float); }
+constexpr size_t front_lds_bytes() { return (size_t)(TBLF_FLOATS + 2 * CH * RP8 + CH * ring_pitch<CIN>() + 2 * 15 * 64 + 4 * (CIN / 4) * 64) * sizeof(float); }
+static_assert(front_lds_bytes<20>() <= 160 * 1024 && front_lds_bytes<40>() <= 160 * 1024, "LDS budget of cfb_front");
+static_assert(8 * WS_FLOATS <= 2 * CH * RP8 && 8 * 16 * 6 + 64 + 256 <= CH * NSLOT * 16, "the front kernel's epilogue scratch aliases R and the ring");
+constexpr size_t back_lds_bytes() { return (size_t)(TBLI_FLOATS + 2 * CH * OP8 + 3 * 10 * 64) * sizeof(float); }
+static_assert(8 * WS_FLOATS + 256 <= 2 * CH * OP8, "the back kernel's scratch aliases OB");
 
 }  // namespace dfsmn_cfb
 }  // namespace vadx
@@ -516,8 +698,8 @@ constexpr size_t back_lds_bytes() { return (size_t)(TBLI_FLOATS + 4 * CH * XP + 
 using namespace vadx::dfsmn_cfb;
 
 static bool weights_ok(const vadx_dfsmn_cfb_weights *w) {
-    return w && w->ln0_w && w->ln0_b && w->gate_w && w->gate_b && w->in_w && w->in_b && w->ln1_w && w->conv_w && w->ln2_w &&
-           w->fwd_tbl && w->fwd_fix && w->lin_w && w->lin_b && w->inv_tbl && w->out_fix;
+    return w && w->ln0_w && w->gate_w && w->in_w && w->in_b && w->front_tab && w->conv_w && w->fwd_tbl && w->fwd_fix && w->lin_w &&
+           w->lin_b && w->inv_tbl && w->out_fix;
 }
 
 extern "C" int vadx_dfsmn_cfb_front(const vadx_dfsmn_cfb_weights *w, const vadx_ft_view *a, const vadx_ft_view *b, const float *stats0,
@@ -528,6 +710,7 @@ extern "C" int vadx_dfsmn_cfb_front(const vadx_dfsmn_cfb_weights *w, const vadx_
     p.b = b && b->ptr ? View{b->ptr, b->c_total, b->c_off, b->c} : View{nullptr, 0, 0, 0};
     p.stats0 = stats0; p.w = *w; p.y1 = y1; p.stats1 = stats1; p.li = li; p.stats_li = stats_li; p.tiles = tiles;
     const int cin = p.a.c + p.b.c;
+    VADX_REQUIRE(p.a.c % 4 == 0, "vadx_dfsmn_cfb_front: the first view must hold a multiple of 4 channels (a k-step does not straddle the views)");
     const unsigned grid = (unsigned)(tiles < cu_count() ? tiles : cu_count());
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (cin == 20) {

@@ -203,10 +203,15 @@ class Iccrn:
             if c < CH:
                 lw[row], lb[row] = lin_w[(rr >> 1) * CH + c], lin_b[(rr >> 1) * CH + c]
         cw = _lib.DfsmnCfbWeights()
-        cw.ln0_w, cw.ln0_b = self._p(name + ".LN0.w"), self._p(name + ".LN0.b")
-        cw.gate_w, cw.gate_b = self._p(name + ".conv_gate.weight"), self._p(name + ".conv_gate.bias")
-        cw.in_w, cw.in_b = self._p(name + ".conv_input.weight"), self._p(name + ".conv_input.bias")
-        cw.ln1_w, cw.ln2_w, cw.conv_w = self._p(name + ".LN1.w"), self._p(name + ".LN2.w"), self._p(name + ".conv.weight")
+        cw.ln0_w = self._p(name + ".LN0.w")
+        cw.gate_w, cw.in_w, cw.in_b = self._p(name + ".conv_gate.weight"), self._p(name + ".conv_input.weight"), self._p(name + ".conv_input.bias")
+        cw.conv_w = self._p(name + ".conv.weight")
+        # LayerNorm 0 behind the gate conv: Wg (w0 * x) scaled by inv0, plus Wg b0 + bias, minus mean0 inv0 (Wg w0)
+        wg = w[name + ".conv_gate.weight"][:, :, 0, 0].astype(np.float64)                 # [20][cin]
+        cin = wg.shape[1]
+        ln0_w, ln0_b = w[name + ".LN0.w"].reshape(cin, F_BINS).astype(np.float64), w[name + ".LN0.b"].reshape(cin, F_BINS).astype(np.float64)
+        tab = np.stack([wg @ ln0_w, wg @ ln0_b + w[name + ".conv_gate.bias"].astype(np.float64)[:CH, None], ln1_w, ln2_w], 0)      # [4][20][160]
+        cw.front_tab = dev(np.transpose(tab, (2, 0, 1)))                                  # [160][4][20]
         cw.fwd_tbl = dev(frag(fwd, 40, lambda s_, q: 4 * s_ + q))
         cw.fwd_fix = dev(fix(ln2_w @ fwd.T, ln2_b @ fwd.T))
         cw.lin_w, cw.lin_b = dev(lw), dev(lb)
@@ -516,8 +521,13 @@ class DfsmnSession:
     (DFSMN/near_and_far_end_audio/Export_DFSMN_VAD.py:377-393).  near_only = (pow_far, far_comp): the near-end-only export
     instead -- {'audio': int16 [1,1,16001]} (DFSMN/only_near_end_audio/Export_DFSMN_VAD.py:373-392)."""
 
-    def __init__(self, weights=None, device="cuda:0", near_only=None):
+    def __init__(self, weights=None, device="cuda:0", near_only=None, io_dtype="float32"):
+        """io_dtype="float16": I/O-compatible with the reference's fp16 conversion (Optimize_ONNX.py:40-44, keep_io_types=False: vad_results
+        leaves as float16); the arithmetic here stays float32, the scores are rounded once on the way out."""
         from .fsmn import _Meta
+        if io_dtype not in ("float32", "float16"):
+            raise ValueError("io_dtype must be 'float32' or 'float16'")
+        self.io_dtype = np.float16 if io_dtype == "float16" else np.float32
         self.engine = DfsmnEngine(weights, device)
         self.near_only = near_only is not None
         if self.near_only:
@@ -525,7 +535,7 @@ class DfsmnSession:
             self._inputs_meta = [_Meta("audio", [1, 1, 16001], "tensor(int16)")]
         else:
             self._inputs_meta = [_Meta("near_end_audio", [1, 1, 16001], "tensor(int16)"), _Meta("far_end_audio", [1, 1, 16001], "tensor(int16)")]
-        self._outputs_meta = [_Meta("vad_results", [51], "tensor(float)")]
+        self._outputs_meta = [_Meta("vad_results", [51], "tensor(float16)" if io_dtype == "float16" else "tensor(float)")]
 
     def get_inputs(self):
         return list(self._inputs_meta)
@@ -545,5 +555,5 @@ class DfsmnSession:
                 raise ValueError("Got invalid dimensions for input: expected last dim 16001")
         near = arrs[0].reshape(-1, 16001)
         far = None if self.near_only else arrs[1].reshape(-1, 16001)
-        vad = self.engine.run(near, far).cpu().numpy()
+        vad = self.engine.run(near, far).cpu().numpy().astype(self.io_dtype)
         return [vad.reshape(-1) if vad.shape[0] == 1 else vad]

@@ -53,12 +53,16 @@ def _finish(all_ts, sample_rate, save_second, save_indices, single, elapsed, ech
 def inference_silero(test_vad_audio="./vad_sample.wav", model=None, save_timestamps_second="./timestamps_second.txt",
                      save_timestamps_indices="./timestamps_indices.txt", ACTIVATE_THRESHOLD=0.5, FUSION_THRESHOLD=0.3,
                      MIN_SPEECH_DURATION=0.25, MAX_SPEECH_DURATION=20, MIN_SILENCE_DURATION=250, SAMPLE_RATE=16000,
-                     echo=print):
-    """Silero/Inference_Silero_VAD_ONNX.py:80-120."""
+                     use_fp16=False, echo=print):
+    """Silero/Inference_Silero_VAD_ONNX.py:80-120.  use_fp16 (:16, :83): the samples are quantised to float16 and scaled there, as
+    the reference feeds its fp16-optimised model -- I/O-compatible: the network arithmetic here stays float32."""
     from . import silero
     files = _as_list(test_vad_audio)
     model = silero.load_silero_vad(onnx=True, use_cpu=True, path=model) if (model is None or isinstance(model, (str, dict))) else model
-    clips = [audio_io.load_wav(f, SAMPLE_RATE).astype(np.float32) * np.float32(0.000030517578) for f in files]
+    if use_fp16:            # np.array(samples, dtype=float16) * 0.000030517578: NumPy keeps float16 (the constant is 2^-15: exact, subnormals round)
+        clips = [(audio_io.load_wav(f, SAMPLE_RATE).astype(np.float16) * np.float16(0.000030517578)).astype(np.float32) for f in files]
+    else:
+        clips = [audio_io.load_wav(f, SAMPLE_RATE).astype(np.float32) * np.float32(0.000030517578) for f in files]
     echo("\nStart to run the VAD process.")
     t0 = time.time()
     n = max(len(c) for c in clips)

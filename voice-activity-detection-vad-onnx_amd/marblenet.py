@@ -164,13 +164,19 @@ class MarbleNetEngine:
 
 class MarbleNetSession:
     """{'audio': int16 [1,1,L]} -> [score_silence [1,T,1], score_active [1,T,1], signal_len int32 [1]]
-    (Export_NVIDIA_MarbleNet_VAD.py:436-457; dynamic audio length)."""
+    (Export_NVIDIA_MarbleNet_VAD.py:436-457; dynamic audio length).  io_dtype="float16": I/O-compatible with the reference's
+    fp16-optimised model (Optimize_ONNX.py:37-44 converts with keep_io_types=False, so the two scores leave as float16) -- the
+    arithmetic here stays float32 and the scores are rounded once on the way out."""
 
-    def __init__(self, weights=None, device="cuda:0", in_sample_rate=16000):
+    def __init__(self, weights=None, device="cuda:0", in_sample_rate=16000, io_dtype="float32"):
+        if io_dtype not in ("float32", "float16"):
+            raise ValueError("io_dtype must be 'float32' or 'float16'")
+        self.io_dtype = np.float16 if io_dtype == "float16" else np.float32
+        ftype = "tensor(float16)" if io_dtype == "float16" else "tensor(float)"
         self.engine = MarbleNetEngine(weights, device, in_sample_rate=in_sample_rate)
         self._inputs_meta = [_Meta("audio", [1, 1, "audio_len"], "tensor(int16)")]
-        self._outputs_meta = [_Meta("score_silence", [1, "signal_len", 1], "tensor(float)"),
-                              _Meta("score_active", [1, "signal_len", 1], "tensor(float)"),
+        self._outputs_meta = [_Meta("score_silence", [1, "signal_len", 1], ftype),
+                              _Meta("score_active", [1, "signal_len", 1], ftype),
                               _Meta("signal_len", [1], "tensor(int32)")]
 
     def get_inputs(self):
@@ -187,7 +193,7 @@ class MarbleNetSession:
         if audio.dtype != np.int16:
             raise ValueError("Unexpected input data type. Actual: (%s) , expected: (tensor(int16))" % audio.dtype)
         s0, s1, slen = self.engine.run(audio.reshape(-1, audio.shape[-1]))
-        res = {"score_silence": s0.cpu().numpy()[:, :, None], "score_active": s1.cpu().numpy()[:, :, None],
+        res = {"score_silence": s0.cpu().numpy()[:, :, None].astype(self.io_dtype), "score_active": s1.cpu().numpy()[:, :, None].astype(self.io_dtype),
                "signal_len": np.array([slen], dtype=np.int32)}
         names = ["score_silence", "score_active", "signal_len"] if output_names is None else output_names
         return [res[n] for n in names]
