@@ -243,8 +243,8 @@ def compact_line(full, detail_path=None):
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                  "vs_baseline", "dtype", "data", "config", "per_gpu_value", "rtf_batch1")}
     line["kernel_ms"] = {k: r4(v) for k, v in full["kernel_ms"].items()}
-    line["roofline"] = {"bound": ro["bound"], "kernel": ro["kernel"], "achieved": r4(ro["achieved"]), "peak": ro["peak"], "unit": ro["unit"],
-                        "frac": r4(ro["frac"]), "traffic": ro["traffic"], "traffic_unit": ro["traffic_unit"],
+    line["roofline"] = {"bound": ro["bound"], "kernel": ro["kernel"], "achieved": ro["achieved"], "peak": ro["peak"], "unit": ro["unit"],
+                        "frac": ro["frac"], "traffic": ro["traffic"], "traffic_unit": ro["traffic_unit"],
                         "algorithmic_bytes_per_launch": ro["algorithmic_bytes_per_launch"], "traffic_ratio": r4(ro["traffic_ratio"]),
                         "flop_per_frame": ro["flop_per_frame"], "dense_equivalent_achieved": r4(ro["dense_equivalent"]["achieved"]),
                         "valu_per_mfma": r4(mix.get("valu_per_mfma")), "ceiling_frac": r4(mix.get("ceiling_frac")),

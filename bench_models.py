@@ -460,7 +460,7 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
     fl = flop_dfsmn_window()
     nwin = clips * W
     groups = {"lstm_f": split.get("vadx_dfsmn_lstm_f", 0.0), "dft_f": split.get("vadx_dfsmn_dft_f", 0.0),
-              "pw_conv": split.get("vadx_dfsmn_pw_conv", 0.0), "lstm_t": split.get("vadx_dfsmn_lstm_t", 0.0),
+              "pw_conv": split.get("vadx_dfsmn_pw_conv", 0.0), "lstm_t": split.get("vadx_dfsmn_lstm_t", 0.0) + split.get("vadx_dfsmn_lstm_t_ex", 0.0),
               "cfb_front": split.get("vadx_dfsmn_cfb_front", 0.0), "cfb_back": split.get("vadx_dfsmn_cfb_back", 0.0)}
     dom = max(groups, key=groups.get)
     if dom == "pw_conv":                                     # (only the unfused chain is dominated by the HBM-bound pw_conv launches)

@@ -402,6 +402,15 @@ int vadx_dfsmn_alpha_scale(const float *in, float *out, int chunks, int nt, cons
 int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2], const float *const w_hh[2],
                       const float *const b_ih[2], const float *const b_hh[2], const float *wl, const float *bl,
                       const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, void *stream);
+/* The same with an explicit frame stride between chunks (a multiple of 4): chunk c's frame t is column (c * frame_stride + t) % 16 of
+ * tile (c * frame_stride + t) / 16.  vadx_dfsmn_lstm_t is frame_stride = 16 * ceil(frames / 16). */
+int vadx_dfsmn_lstm_t_ex(int which, const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2], const float *const w_hh[2],
+                         const float *const b_ih[2], const float *const b_hh[2], const float *wl, const float *bl,
+                         const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, int frame_stride, void *stream);
+/* Copy an FT tensor [channels][F] of `chunks` windows between frame strides (both multiples of 4, >= frames): e.g. 112 -> 104 packs
+ * 101-frame windows onto 6.5 tiles each (the per-frame kernels then process 7 % fewer tiles), 104 -> 112 unpacks the result.
+ * dst holds ceil(chunks * dst_stride / 16) tiles. */
+int vadx_dfsmn_ft_repack(const float *src, float *dst, int channels, int F, int frames, int chunks, int src_stride, int dst_stride, void *stream);
 /* NET.istft :220-224: y_ft FT [2 ch x 160] -> out f32 [chunks][(frames-1)*160 + 1]; basis_t [320 j][320 ch]
  * (transposed inverse basis, row 319 zero), wsum_inv = the reference's window_sum_inv buffer; z_ws scratch
  * of chunks*frames*320 floats. */

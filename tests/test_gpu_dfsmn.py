@@ -226,3 +226,19 @@ def test_whole_clip_pair_segments_with_asymmetric_thresholds():
     got = eng.detect(near, far, nz1, nz2, speaking_score=hi, silence_score=lo)
     want, _ = od.run_clip(fe, w, near[0], far[0], nz1[0], nz2[0], weights.DFSMN_MASK["layers"], speaking=hi, silence_score=lo)
     assert got[0] == want
+
+
+def test_packed_frame_layout_is_bitwise_the_unpacked_one(wts):
+    """The ICCRN on the packed layout (windows 104 frames apart, 6.5 tiles each: a tile can hold the tail of one window and the head
+    of the next) against windows on 7 tiles of their own: every per-frame kernel is independent per column and the time-axis LSTMs
+    walk a window's frames by (chunk * stride + t), so the two spectra are equal bit for bit -- odd and even window counts
+    (the last tile half empty or not), and more tiles than workgroups."""
+    w, _ = wts
+    net = dfsmn.Iccrn(w)
+    for chunks in (1, 3, 40):
+        g = torch.Generator().manual_seed(chunks)
+        x = torch.randn(chunks, 4, 160, 101, generator=g) * 0.5
+        x4 = dfsmn.to_ft(torch, x, net.device)
+        y_p = dfsmn.from_ft(net.forward(x4, chunks, 101, pack=True), chunks)
+        y_u = dfsmn.from_ft(net.forward(x4, chunks, 101, pack=False), chunks)
+        assert torch.isfinite(y_u).all() and torch.equal(y_p, y_u), chunks

@@ -861,6 +861,29 @@ __global__ void alpha_scale_kernel(const float *__restrict__ in, float *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// ft_repack: move an FT tensor between frame strides.  A 101-frame window on tiles of its own occupies 7 tiles = 112 columns; packed at a
+// stride of 104 frames (windows start on alternate halves of a tile) the per-frame kernels -- everything but the two time-axis LSTMs --
+// process 6.5 tiles per window: 7 % less work.  Only the 4-channel network input and the 2-channel output are repacked (a fiftieth of
+// the traffic of one block); every per-frame op is independent per column, so the padding frames 101..103 of a window never reach a
+// valid frame.  Columns beyond `frames` in the source are copied as they are (zeros where the writer zero-filled).
+// ---------------------------------------------------------------------------------------------
+__global__ void ft_repack_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int F, int frames, int src_stride,
+                                 int dst_stride, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // (chunk, c, f, t) with t < min stride, 4 frames per thread
+    if (e >= total) return;
+    const int cp = min(src_stride, dst_stride) / 4;
+    const int t4 = (int)(e % cp) * 4;
+    long long r = e / cp;
+    const int f = (int)(r % F); r /= F;
+    const int c = (int)(r % C);
+    const int chunk = (int)(r / C);
+    const int gs = chunk * src_stride + t4, gd = chunk * dst_stride + t4;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + ft_idx(gs >> 4, C, c, F, f) + (gs & 15));
+    *reinterpret_cast<f32x4 *>(dst + ft_idx(gd >> 4, C, c, F, f) + (gd & 15)) = v;
+    (void)frames;
+}
+
+// ---------------------------------------------------------------------------------------------
 // lstm_t: LSTM ALONG TIME (CH_LSTM_T :252-267), one sequence per bin, batch = 16 bins of one chunk.
 //   Two layers (hidden 40, the bottleneck `ch_lstm`, lstm_t2_kernel): of a wave pair, one runs layer 0 and the other layer 1
 //   one step behind, h0 handed over through double-buffered LDS (one barrier per step).  One layer (out_ch_lstm): lstm_t_kernel.
@@ -875,6 +898,8 @@ struct LstmTArgs {
     View mul;                                                // MODE 0
     ViewW out;
     int F, T, nt, out_ch;
+    int tp;                                                  // frames between the starts of two chunks in the FT tensor: nt * 16 (each chunk
+                                                             // on its own tiles) or a packed stride (vadx_dfsmn_ft_repack), a multiple of 4
     int nunits;                                              // lstm_t2_kernel: chunks * (F / 16) bin groups
 };
 
@@ -965,7 +990,7 @@ __global__ __launch_bounds__(128 * NTILE) void lstm_t2_kernel(LstmTArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { muln[om][r] = 1.f; blr[om][r] = (om * 16 + 4 * q + r) < p.out_ch ? p.bl[om * 16 + 4 * q + r] : 0.f; }
     auto prefetch = [&](int t) {
-        const int tc = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t), tile = chunk * p.nt + (tc >> 4), t16 = tc & 15;
+        const int tc = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t), gfr = chunk * p.tp + tc, tile = gfr >> 4, t16 = gfr & 15;
         if (layer == 0) {
 #pragma unroll
             for (int s = 0; s < KI0; ++s) xn[s] = p.in.ptr[ft_idx(tile, p.in.c_total, p.in.c_off + 4 * s + q, p.F, f0 + i) + t16];
@@ -984,7 +1009,7 @@ __global__ __launch_bounds__(128 * NTILE) void lstm_t2_kernel(LstmTArgs p) {
     for (int it = 0; it < p.T + 1; ++it) {
         const int t = it - layer;                            // this wave's time step
         if (t >= 0 && t < p.T) {
-            const int tile = chunk * p.nt + (t >> 4), t16 = t & 15;
+            const int gfr = chunk * p.tp + t, tile = gfr >> 4, t16 = gfr & 15;
             f32x4 acc[MT];
             float mulc[OUT_MT][4];
 #pragma unroll
@@ -1062,7 +1087,7 @@ __global__ __launch_bounds__(64 * (LAYERS + 1)) void lstm_t_kernel(LstmTArgs p) 
         const int sub = lane >> 4, quad = sub % NQ, chs = sub / NQ;      // lane -> (bin i, time quad, channel sub-offset)
         f32x4 pre[NLD];
         auto request = [&](int ck) {
-            const int t0 = ck * TS, tile = chunk * p.nt + (t0 >> 4), tb = (t0 & 15) + 4 * quad;
+            const int t0 = chunk * p.tp + ck * TS, tile = t0 >> 4, tb = (t0 & 15) + 4 * quad;
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const int ch = j * (4 / NQ) + chs;
@@ -1070,7 +1095,7 @@ __global__ __launch_bounds__(64 * (LAYERS + 1)) void lstm_t_kernel(LstmTArgs p) 
             }
         };
         auto park = [&](int ck) {
-            const int t0 = ck * TS, tile = chunk * p.nt + (t0 >> 4), tb = (t0 & 15) + 4 * quad;
+            const int t0 = chunk * p.tp + ck * TS, tile = t0 >> 4, tb = (t0 & 15) + 4 * quad;
             f32x4 mean = {0.f, 0.f, 0.f, 0.f}, inv = {1.f, 1.f, 1.f, 1.f};
             if (p.ln.stats)
 #pragma unroll
@@ -1089,7 +1114,7 @@ __global__ __launch_bounds__(64 * (LAYERS + 1)) void lstm_t_kernel(LstmTArgs p) 
             }
         };
         auto flush = [&](int ck) {
-            const int t0 = ck * TS, tile = chunk * p.nt + (t0 >> 4), tb = (t0 & 15) + 4 * quad;
+            const int t0 = chunk * p.tp + ck * TS, tile = t0 >> 4, tb = (t0 & 15) + 4 * quad;
             const float *src = Ys + (ck & 1) * OUTC * CS;
             for (int o = chs; o < p.out_ch; o += 4 / NQ) {
                 f32x4 v;
@@ -1437,9 +1462,17 @@ extern "C" int vadx_dfsmn_alpha_scale(const float *in, float *out, int chunks, i
 extern "C" int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2], const float *const w_hh[2],
                                  const float *const b_ih[2], const float *const b_hh[2], const float *wl, const float *bl,
                                  const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, void *stream) {
+    return vadx_dfsmn_lstm_t_ex(which, in, ln, w_ih, w_hh, b_ih, b_hh, wl, bl, mul, out, F, frames, chunks, ((frames + 15) / 16) * 16, stream);
+}
+
+extern "C" int vadx_dfsmn_lstm_t_ex(int which, const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2], const float *const w_hh[2],
+                                    const float *const b_ih[2], const float *const b_hh[2], const float *wl, const float *bl,
+                                    const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, int frame_stride, void *stream) {
     VADX_REQUIRE(in && in->ptr && out && out->ptr && w_ih && w_hh && b_ih && b_hh && wl && bl, "vadx_dfsmn_lstm_t: bad argument");
     VADX_REQUIRE(F % 16 == 0 && frames > 0 && chunks > 0, "vadx_dfsmn_lstm_t: F must be a multiple of 16");
+    VADX_REQUIRE(frame_stride % 4 == 0 && frame_stride >= ((frames + 3) / 4) * 4, "vadx_dfsmn_lstm_t: frame_stride must be a multiple of 4 covering the frames rounded up to 4");
     LstmTArgs p;
+    p.tp = frame_stride;
     p.in = mkview(in); p.ln = mkln(ln); p.mul = mkview(mul); p.out = mkvieww(out); p.F = F; p.T = frames; p.nt = (frames + 15) / 16;
     p.wl = wl; p.bl = bl;
     for (int l = 0; l < 2; ++l) { p.w_ih[l] = w_ih[l]; p.w_hh[l] = w_hh[l]; p.b_ih[l] = b_ih[l]; p.b_hh[l] = b_hh[l]; }
@@ -1464,6 +1497,19 @@ extern "C" int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_f
         p.out_ch = 40;
         hipLaunchKernelGGL((lstm_t_kernel<40, 20, 1, 3, 1, 4, 40>), dim3(grid), dim3(128), lds_bytes(40, 40, 20, 4, 1), st, p);
     }
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+extern "C" int vadx_dfsmn_ft_repack(const float *src, float *dst, int channels, int F, int frames, int chunks, int src_stride, int dst_stride,
+                                    void *stream) {
+    VADX_REQUIRE(src && dst && channels > 0 && F > 0 && frames > 0 && chunks > 0, "vadx_dfsmn_ft_repack: bad argument");
+    VADX_REQUIRE(src_stride % 4 == 0 && dst_stride % 4 == 0 && src_stride >= frames && dst_stride >= frames,
+                 "vadx_dfsmn_ft_repack: strides must be multiples of 4 that cover the frames");
+    const int cp = (src_stride < dst_stride ? src_stride : dst_stride) / 4;
+    const long long total = (long long)chunks * channels * F * cp;
+    hipLaunchKernelGGL(ft_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, channels, F,
+                       frames, src_stride, dst_stride, total);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }

@@ -101,7 +101,9 @@ __device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, co
                 const int e = min(tid + THREADS * (u0 + u), NE - 1), c = e / NMEL, mel = e - c * NMEL;
                 int fr = f0 + c - 2;
                 fr = fr < 0 ? 0 : (fr > d.T - 1 ? d.T - 1 : fr);
-                v[u] = ldg1(lm + (size_t)fr * NMEL + mel);
+                // read-once stream: non-temporal, so that it does not push the weight set (1.67 MB, re-read by every tile) and the FIR
+                // caches (rewritten by every tile) out of the 4 MB L2 of the XCD
+                v[u] = __builtin_nontemporal_load((vadx::global_f32_ptr)(lm + (size_t)fr * NMEL + mel));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

@@ -21,14 +21,22 @@ def ft_tiles(frames):
 STAT_PARTS = 2             # VADX_DFSMN_STAT_PARTS (include/vadx.h)
 
 
+def packed_stride(frames):
+    """Frame stride of the PACKED FT layout: the frames rounded up to 8, so that a chunk starts on a tile or a half tile (101 ->
+    104: 6.5 tiles per window instead of 7) and the time-axis LSTMs' aligned 4-frame accesses never straddle a tile."""
+    return (frames + 7) // 8 * 8
+
+
 class FT:
     """A device tensor in FT layout + helpers to make channel-slice views."""
 
-    def __init__(self, torch, device, n_chunks, frames, channels, bins, zero=True):
+    def __init__(self, torch, device, n_chunks, frames, channels, bins, zero=True, stride=None):
         """zero=False for intermediates that a kernel overwrites completely (all 16 columns of every tile): the MFMA
-        columns (frames) are independent, so whatever the padding frames hold never reaches a valid frame."""
+        columns (frames) are independent, so whatever the padding frames hold never reaches a valid frame.
+        stride: frames between the starts of two chunks (None: every chunk on tiles of its own, ft_tiles(frames) * 16)."""
         self.nt = ft_tiles(frames)
-        self.tiles = n_chunks * self.nt
+        self.stride = self.nt * 16 if stride is None else int(stride)
+        self.tiles = (n_chunks * self.stride + 15) // 16
         self.C, self.F, self.frames = channels, bins, frames
         alloc = torch.zeros if zero else torch.empty
         self.data = alloc((self.tiles, channels, bins, 16), dtype=torch.float32, device=device)
@@ -70,6 +78,7 @@ class Iccrn:
         self.w = w
         self.d = {}
         self._cfb_cache = {}
+        self.frame_stride = None       # None: every chunk on tiles of its own; forward() packs (packed_stride) for the duration of a pass
 
         def dev(name, arr):
             self.d[name] = t.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
@@ -107,6 +116,9 @@ class Iccrn:
         self.tbl_fwd, self.tbl_inv = fwd.to(self.device), inv.to(self.device)
 
     # ---- small helpers around the C ABI -------------------------------------------------------
+    def _tiles(self, n_chunks, frames):
+        return (n_chunks * (ft_tiles(frames) * 16 if self.frame_stride is None else self.frame_stride) + 15) // 16
+
     def _p(self, name):
         return self.d[name].data_ptr()
 
@@ -225,11 +237,11 @@ class Iccrn:
         a_part / b_part: the partial statistics the producers of a / b emitted (None: a frame_stats pass over the tensor);
         returns (scratch, partial statistics of y)."""
         t, dev = self.torch, self.device
-        tiles = n_chunks * ft_tiles(frames)
+        tiles = self._tiles(n_chunks, frames)
         sc = scratch if scratch is not None else {}
         def buf(key, ch, bins):
             if key not in sc or sc[key].tiles != tiles:
-                sc[key] = FT(t, dev, n_chunks, frames, ch, bins, zero=False)
+                sc[key] = FT(t, dev, n_chunks, frames, ch, bins, zero=False, stride=self.frame_stride)
             return sc[key]
         y1, li, hf = buf("y1", CH, F_BINS), buf("li", 2 * CH, CEPS_F), buf("hf", 2 * CH, CEPS_F)
         def sbuf(key):
@@ -292,17 +304,33 @@ class Iccrn:
         layers = 2 if which == 0 else 1
         arr = lambda n: (C.c_void_p * 2)(*[self._p(f"{prefix}.lstm2.{n}_l{l}") if l < layers else None for l in range(2)])   # noqa: E731
         wi, wh, bi, bh = arr("weight_ih"), arr("weight_hh"), arr("bias_ih"), arr("bias_hh")
-        _lib.check(self.lib.vadx_dfsmn_lstm_t(which, C.byref(inp), None if ln is None else C.byref(ln), C.byref(wi), C.byref(wh),
-                                              C.byref(bi), C.byref(bh), self._p(prefix + ".linear.weight"),
-                                              self._p(prefix + ".linear.bias"), None if mul is None else C.byref(mul),
-                                              C.byref(out), F_BINS, frames, n_chunks, _lib.stream_ptr()))
+        stride = ft_tiles(frames) * 16 if self.frame_stride is None else self.frame_stride
+        _lib.check(self.lib.vadx_dfsmn_lstm_t_ex(which, C.byref(inp), None if ln is None else C.byref(ln), C.byref(wi), C.byref(wh),
+                                                 C.byref(bi), C.byref(bh), self._p(prefix + ".linear.weight"),
+                                                 self._p(prefix + ".linear.bias"), None if mul is None else C.byref(mul),
+                                                 C.byref(out), F_BINS, frames, n_chunks, stride, _lib.stream_ptr()))
 
     # ---- NET.forward (:226-249) without the ISTFT ------------------------------------------------
-    def forward(self, x4, n_chunks, frames):
-        """x4: FT (4 ch: mix re, mix im, scaled far re, scaled far im) -> Y FT (2 ch: re, im of the AEC spectrum)."""
+    def forward(self, x4, n_chunks, frames, pack=True):
+        """x4: FT (4 ch: mix re, mix im, scaled far re, scaled far im) -> Y FT (2 ch: re, im of the AEC spectrum).
+        pack: run the network on the PACKED frame layout (chunks 104 frames apart instead of on 7 tiles = 112 columns each: the
+        per-frame kernels see 7 % fewer tiles); only the 4-channel input and the 2-channel output are repacked."""
+        if pack and packed_stride(frames) < ft_tiles(frames) * 16:
+            t, st = self.torch, _lib.stream_ptr()
+            stride = packed_stride(frames)
+            xp = FT(t, self.device, n_chunks, frames, 4, F_BINS, zero=False, stride=stride)
+            _lib.check(self.lib.vadx_dfsmn_ft_repack(x4.data.data_ptr(), xp.data.data_ptr(), 4, F_BINS, frames, n_chunks, x4.stride, stride, st))
+            self.frame_stride = stride
+            try:
+                yp = self.forward(xp, n_chunks, frames, pack=False)
+            finally:
+                self.frame_stride = None
+            y = FT(t, self.device, n_chunks, frames, 2, F_BINS, zero=False)
+            _lib.check(self.lib.vadx_dfsmn_ft_repack(yp.data.data_ptr(), y.data.data_ptr(), 2, F_BINS, frames, n_chunks, stride, y.stride, st))
+            return y
         t, dev = self.torch, self.device
-        tiles = n_chunks * ft_tiles(frames)
-        new = lambda ch, bins=F_BINS: FT(t, dev, n_chunks, frames, ch, bins, zero=False)      # noqa: E731
+        tiles = self._tiles(n_chunks, frames)
+        new = lambda ch, bins=F_BINS: FT(t, dev, n_chunks, frames, ch, bins, zero=False, stride=self.frame_stride)      # noqa: E731
         hf0, e0l = new(2 * CH), new(CH)
         cats = [new(2 * CH) for _ in range(5)]          # [e0|d1], [e1|d2], [e2|d3], [e3|d4], [e4|d5]
         e5, p5, d0, y = new(CH), new(CH), new(2 * CH), new(2)
