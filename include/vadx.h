@@ -160,7 +160,16 @@ typedef struct vadx_frontend_cfg {
     int   window_len;  /* samples per window (at 16 kHz, i.e. after the in-graph resample of prep 6 / 7) */
     int   in_window_len; /* prep 6 / 7: samples per window in the audio buffer (input rate); 0 otherwise */
     float rs_scale;    /* prep 6 / 7: source samples per output sample, float32(1 / scale_factor) as torch computes it */
+    int   fold;        /* 0: dense DFT product.  1 / 2: folded product of vadx_frontend_logmel (mirror-paired taps about the window
+                          centre + f16 residual; same table bits, half the f32 MFMAs) -- the value vadx_frontend_fold_kind returned
+                          for this table; set it before vadx_frontend_packed_floats / _pack_host.  Ignored by _logmel_ex / _stft_ft
+                          callers' kernels (they take the dense tables, which every blob carries) */
 } vadx_frontend_cfg;
+
+/* Which fold (0 = none) the reference's windowed DFT table admits for this geometry: the table must equal, about the window
+ * centre, an even real / odd imaginary pair to within what the f16 residual carries (1.5e-4 of the table scale). */
+int vadx_frontend_fold_kind(const vadx_frontend_cfg *cfg, const float *cos_tab, const float *sin_tab, int n_fft);
+
 
 size_t vadx_frontend_packed_floats(const vadx_frontend_cfg *cfg);
 /* Host repack of the reference tables (cos/sin [n_bins][n_fft] windowed, fbank [n_mels][n_bins]);

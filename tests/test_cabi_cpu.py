@@ -259,3 +259,67 @@ def test_audio_io_numpy_fallback_matches_audioop(tmp_path):
         finally:
             audio_io._audioop = saved
         assert saved is audioop and got.dtype == np.int16 and np.array_equal(got, want), (nch, width, rate)
+
+
+@pytest.mark.parametrize("preset,kind", [("fsmn", 2), ("marblenet", 1), ("firered", 1)])
+def test_folded_dft_tables_reproduce_the_reference_table(lib, preset, kind):
+    """Table-level proof of the folded DFT product on the host: the blob's symmetric tables E / O (over mirror pairs of taps) and
+    its f16 residual RX / IX give, in double arithmetic on random frames, the power spectrum of the reference's own float32
+    table to ~1e-7 -- i.e. fold + residual is that table, up to the f16 rounding of a term that is itself ~6e-5 of the sum."""
+    from vadx import frontend, tables
+    p = frontend.PRESETS[preset]
+    n_fft, win, hop = p["n_fft"], p["win"], p["hop"]
+    cos_t, sin_t = tables.windowed_dft(n_fft, tables.analysis_window(p["window"], win, n_fft, p["variant"]), p["variant"])
+    c, s = tables.as_np(cos_t), tables.as_np(sin_t)
+    cfg = _lib.FrontendCfg()
+    cfg.prep, cfg.k0, cfg.k1 = p["prep"], p["k"][0], p["k"][1]
+    cfg.center_pad = n_fft // 2 if p["center"] else 0
+    cfg.tap0, cfg.taps = ((n_fft - win) // 2 if win < n_fft else 0), min(win, n_fft)
+    cfg.hop, cfg.n_bins, cfg.n_mels, cfg.log_mode, cfg.log_floor = hop, n_fft // 2 + 1, 80, p["log_mode"], p["log_floor"]
+    cfg.frames, cfg.window_len = 101, 16000
+    assert lib.vadx_frontend_fold_kind(ctypes.byref(cfg), c.ctypes.data, s.ctypes.data, n_fft) == kind
+    dense_floats = lib.vadx_frontend_packed_floats(ctypes.byref(cfg))
+    cfg.fold = kind
+    n = lib.vadx_frontend_packed_floats(ctypes.byref(cfg))
+    blob, mel_kb = np.zeros(n, np.float32), np.zeros(10, np.int32)
+    fb = np.zeros((80, cfg.n_bins), np.float32)
+    assert lib.vadx_frontend_pack_host(ctypes.byref(cfg), c.ctypes.data, s.ctypes.data, n_fft, fb.ctypes.data, blob.ctypes.data,
+                                       mel_kb.ctypes.data) == 0
+    XLD, nyq = 68, int(cfg.n_bins % 16 == 1)
+    nbt = cfg.n_bins // 16 if nyq else (cfg.n_bins + 15) // 16
+    plan = blob[n - 32:].view(np.int32).reshape(8, 4)
+    regions = [r for r in plan if r[0] > 0]
+    Pb, Kb32 = int(sum(r[0] for r in regions)), (cfg.taps + 31) // 32
+    ka, kb = [], []                                   # tap of either member of pair p; -1 = the row of zeros
+    for blocks, offA, offB, strB in regions:
+        for t in range(16 * blocks):
+            ra, rb = offA // XLD + t, offB // XLD + (t if strB > 0 else -t)
+            ka.append((offA % XLD) * hop + ra if ra < hop else -1)
+            kb.append((offB % XLD) * hop + rb if rb < hop else -1)
+    ka, kb = np.array(ka), np.array(kb)
+    fold = blob[dense_floats:dense_floats + (nbt + nyq) * 32 * Pb * 16]
+    r_i, k_i = np.meshgrid(np.arange((nbt + nyq) * 32), np.arange(Pb * 16), indexing="ij")
+    ldw = Pb * 16
+    fm = fold[(r_i // 16) * 16 * ldw + (k_i // 16) * 256 + (((k_i % 16) // 4) * 16 + r_i % 16) * 4 + k_i % 4].astype(np.float64)
+    res = blob[dense_floats + fold.size:n - 32].view(np.float16).astype(np.float64).reshape(nbt + nyq, 2, Kb32, 4, 16, 8) / 8192.0
+    res = res.transpose(0, 1, 4, 2, 3, 5).reshape(nbt + nyq, 2, 16, Kb32 * 32)[..., :cfg.taps]        # [tile][RX|IX][bin in tile][tap]
+    rng = np.random.default_rng(kind)
+    x = rng.standard_normal((5, cfg.taps))
+    xz = np.concatenate([x, np.zeros((5, 1))], axis=1)                       # index -1 = 0
+    valid = (ka >= 0)[None, :]
+    u, v = np.where(valid, xz[:, ka] + xz[:, kb], 0.0), np.where(valid, xz[:, ka] - xz[:, kb], 0.0)
+    R, I = c[:, cfg.tap0:cfg.tap0 + cfg.taps].astype(np.float64), s[:, cfg.tap0:cfg.tap0 + cfg.taps].astype(np.float64)
+    want = (x @ R.T) ** 2 + (x @ I.T) ** 2                                    # [frame][bin]
+    got = np.zeros_like(want)
+    for t in range(nbt):
+        bins = np.arange(16 * t, min(16 * t + 16, cfg.n_bins - nyq))
+        re = u @ fm[t * 32:t * 32 + 16].T + x @ res[t, 0].T
+        im = v @ fm[t * 32 + 16:t * 32 + 32].T + x @ res[t, 1].T
+        got[:, bins] = (re ** 2 + im ** 2)[:, :len(bins)]
+    if nyq:                                           # the last bin's own tile: u x row 0 -> re', v x row 17 -> im'; residual rows 0, 1 of part 0
+        re = u @ fm[nbt * 32] + x @ res[nbt, 0, 0]
+        im = v @ fm[nbt * 32 + 17] + x @ res[nbt, 0, 1]
+        got[:, -1] = re ** 2 + im ** 2
+    scale = (np.abs(x) @ np.abs(R).T) ** 2
+    assert np.abs(got - want).max() / scale.max() < 2e-7
+    assert (np.abs(got - want) / scale).max() < 2e-7

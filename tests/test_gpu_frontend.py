@@ -138,3 +138,76 @@ def test_resampled_firered_session_matches_reference_fixture(golden, rate):
     probs = sess.run(None, {"audio": a})[0]
     assert probs.shape == g[f"firered_{rate}_probs"].shape
     np.testing.assert_allclose(probs, g[f"firered_{rate}_probs"], rtol=0, atol=1e-4)
+
+
+def exact_logmel(preset, windows_i16):
+    """The oracle's chain with the float32 prep and the float32 TABLE BITS of the reference, everything after them in double.
+    Returns (log-mel [W,T,80], amplitude scale [W,T,80] = sqrt(strongest bin power of the frame x largest weight of the mel row):
+    what the round-off of the frame's largest spectral line amounts to in each mel band)."""
+    if preset == "fsmn":
+        a = ostft.prep_fsmn(windows_i16).double()
+        w = ostft.padded_window(400, 512, "hamming", "v1")
+        c, s = ostft.dft_tables(512, w, "v1")
+        fb = omel.melscale_fbanks(257, 20, 8000, 80, 16000, None, "htk").t().unsqueeze(0).double()
+        re, im = ostft.stft(a, c.double(), s.double(), 160, True)
+        scale = ((re * re + im * im).amax(dim=1).unsqueeze(-1) * fb[0].amax(dim=1)).sqrt()
+        return omel.log_mel(re, im, fb, 1e-5, "clamp").transpose(1, 2), scale
+    a = ostft.prep_two_tap(windows_i16, 1.0 / 32768.0).double()
+    w = ostft.padded_window(400, 512, "hann_sym", "v2")
+    c, s = ostft.dft_tables(512, w, "v2")
+    fb = omel.melscale_fbanks(257, 0, 8000, 80, 16000, "slaney", "slaney").t().unsqueeze(0).double()
+    re, im = ostft.stft(a, c.double(), s.double(), 160, True)
+    scale = ((re * re + im * im).amax(dim=1).unsqueeze(-1) * fb[0].amax(dim=1)).sqrt()
+    return omel.log_mel(re, im, fb, 1e-7, "add").transpose(1, 2), scale
+
+
+@pytest.mark.parametrize("preset,L,kind", [("fsmn", 16000, 2), ("marblenet", 40000, 1), ("marblenet", 16000, 1), ("firered", 16000, 1),
+                                           ("fsmn", 5280, 2), ("firered", 2560, 1)])
+def test_folded_dft_is_the_dense_product(preset, L, kind):
+    """Table-level proof of the folded DFT product (mirror-paired taps about the window centre + f16 residual, csrc/frontend.hip
+    "Folded DFT"): the same clips through the dense f32 product and the folded one, both against the double-precision evaluation
+    of the SAME float32 table.  In amplitude (sqrt of the mel energy) relative to the frame's strongest spectral line -- the scale
+    float32 round-off of a length-400 product lives on -- the folded product is within 3e-7 of the exact one and of the dense one,
+    and its mean log-mel error equals the dense product's (both are float32 accumulation orders of one sum).  On the log scale the
+    rare worst case sits on bands 60+ dB below the frame's peak, where either order keeps only a few digits."""
+    B = 6
+    clips = weights.burst_clips(B, L, seed=L + kind)
+    clips[0, : min(L, 3000)] = 0
+    clips[1] = (clips[1].astype(np.int32) // 64).astype(np.int16)            # a quiet clip: a few LSBs
+    rng = np.random.default_rng(L)
+    clips[2] = rng.integers(-32768, 32767, size=L, dtype=np.int16)            # full-scale white noise
+    clips[3] = (32000 * np.sin(2 * np.pi * 1000.37 / 16000 * np.arange(L))).astype(np.int16)      # one loud tone: 60 dB of leakage range
+    fd = frontend.Frontend(preset, L, fold=False)
+    ff = frontend.Frontend(preset, L, fold=True)
+    assert fd.fold == 0 and ff.fold == kind
+    d = fd.logmel(clips).cpu().numpy().astype(np.float64)
+    f = ff.logmel(clips).cpu().numpy().astype(np.float64)
+    assert d.shape == f.shape and np.isfinite(f).all()
+    if preset != "firered":
+        ex, scale = (t.numpy() for t in exact_logmel(preset, T(clips).unsqueeze(1)))
+        scale = np.maximum(scale, 1e-30)
+    else:
+        ex = d
+
+    def amp(z):
+        return np.exp(0.5 * z)
+    floor = np.log({"fsmn": 1e-5, "marblenet": 1e-7, "firered": 1e-7}[preset]) + 2.0
+    big = (ex > floor) & (ex > ex.max(axis=-1, keepdims=True) - 18.0)      # log scale: bands within 78 dB of the frame's strongest one
+    assert np.abs(f - d)[big].max() < 1e-3, np.abs(f - d)[big].max()
+    if preset != "firered":
+        # 3e-7 of the frame's strongest line, plus the float32 resolution of the stored log-mel itself (values up to 30: 2 ulp = 4e-6
+        # on the log scale = 2e-6 relative on the amplitude)
+        tol = 3e-7 * scale + 2e-6 * amp(ex)
+        assert (np.abs(amp(f) - amp(d)) <= tol).all(), (np.abs(amp(f) - amp(d)) / tol).max()
+        assert (np.abs(amp(f) - amp(ex)) <= tol).all(), (np.abs(amp(f) - amp(ex)) / tol).max()
+        assert (np.abs(amp(d) - amp(ex)) <= tol).all()
+        ed, ef = np.abs(d - ex)[big], np.abs(f - ex)[big]
+        assert ef.mean() <= max(1.25 * ed.mean(), 1e-7), (ef.mean(), ed.mean())
+        print("fold", preset, L, "worst err / tol: fold %.2f dense %.2f; log err mean fold %.2e dense %.2e, max fold %.2e dense %.2e" % (
+            (np.abs(amp(f) - amp(ex)) / tol).max(), (np.abs(amp(d) - amp(ex)) / tol).max(), ef.mean(), ed.mean(), ef.max(), ed.max()))
+
+
+def test_folded_frontend_is_the_default_and_can_be_turned_off(monkeypatch):
+    assert frontend.Frontend("fsmn", 16000).fold == 2 and frontend.Frontend("marblenet", 16000).fold == 1
+    monkeypatch.setenv("VADX_FRONTEND_FOLD", "0")
+    assert frontend.Frontend("fsmn", 16000).fold == 0

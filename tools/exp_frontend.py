@@ -1,5 +1,5 @@
 """Front-end cycle accounting (development aid): library built with -DFE_EXP=1 sums thread-0 clock64 deltas per phase.
-   python tools/exp_frontend.py build ;  (GPU box) python tools/exp_frontend.py run"""
+   python tools/exp_frontend.py build <tag> [-DFE_WHATIF=n ...] ;  (GPU box) python tools/exp_frontend.py run <tag>"""
 import ctypes as C
 import os
 import subprocess
@@ -7,14 +7,21 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "voice-activity-detection-vad-onnx_amd")
-LIB = os.path.join(PKG, "_exp", "libvadx_fe1.so")
+TAG = sys.argv[2] if len(sys.argv) > 2 else "fe1"
+LIB = os.path.join(PKG, "_exp", "libvadx_%s.so" % TAG)
 SRC = ["capi.hip", "silero.hip", "frontend.hip", "fsmn.hip", "firered.hip", "marblenet.hip", "dfsmn.hip", "ingest.hip"]
 NAMES = ["staging: barrier wait", "DFT GEMM + power", "last bin + zero pad rows", "mel GEMM + log + store", "staging: own work (wave 0)"]
 
-if sys.argv[1] == "build":
+if sys.argv[1] == "build":          # frontend.hip rebuilt with -DFE_EXP=1 (+ extra -D flags), linked with the product's other objects
+    sys.path.insert(0, ROOT)
+    import vadx  # noqa: F401
+    from vadx import build as vbuild
+    vbuild.build(verbose=False)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DFE_EXP=1"]
-                          + [os.path.join(PKG, "csrc", s) for s in SRC] + ["-o", LIB])
+    obj = os.path.join(os.path.dirname(LIB), "frontend_%s.o" % TAG)
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + vbuild.FLAGS + ["-DFE_EXP=1"] + sys.argv[3:] + ["-c", os.path.join(PKG, "csrc", "frontend.hip"), "-o", obj])
+    objs = [obj if s == "frontend.hip" else os.path.join(vbuild.OBJ, s.replace(".hip", ".o")) for s in vbuild.SOURCES]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
     print("built", LIB)
 else:
     os.environ["VADX_LIBRARY"] = LIB
@@ -24,8 +31,9 @@ else:
     from vadx import _lib, frontend, weights
     h = _lib.lib()
     h.vadx_frontend_debug_cycles.argtypes = [C.c_void_p, C.c_int]
-    for preset, n in (("marblenet", 89431), ("fsmn", 16000), ("firered", 16000)):
-        fe = frontend.Frontend(preset, n)
+    for preset, n, fold in (("marblenet", 89431, False), ("marblenet", 89431, True), ("fsmn", 16000, False), ("fsmn", 16000, True),
+                            ("firered", 16000, False), ("firered", 16000, True)):
+        fe = frontend.Frontend(preset, n, fold=fold)
         clips = torch.from_numpy(weights.burst_clips(64, n, seed=5)).cuda().repeat(32 if n > 20000 else 256, 1)
         fe.logmel(clips); torch.cuda.synchronize()
         buf = (C.c_ulonglong * 8)()
@@ -34,6 +42,6 @@ else:
         a.record(); fe.logmel(clips); b.record(); torch.cuda.synchronize()
         h.vadx_frontend_debug_cycles(buf, 0)
         tot = sum(buf[:5])
-        print("%s: %d clips x %d samples, %.2f ms" % (preset, clips.shape[0], n, a.elapsed_time(b)))
+        print("%s (%s): %d clips x %d samples, %.2f ms" % (preset, "folded" if fold else "dense", clips.shape[0], n, a.elapsed_time(b)))
         for nm, v in zip(NAMES, buf[:5]):
             print("   %-30s %6.2f %%" % (nm, 100.0 * v / tot))

@@ -33,7 +33,7 @@ class FrontendCfg(C.Structure):
     _fields_ = [("prep", C.c_int), ("k0", C.c_float), ("k1", C.c_float), ("center_pad", C.c_int),
                 ("tap0", C.c_int), ("taps", C.c_int), ("hop", C.c_int), ("n_bins", C.c_int),
                 ("n_mels", C.c_int), ("log_mode", C.c_int), ("log_floor", C.c_float), ("frames", C.c_int),
-                ("window_len", C.c_int), ("in_window_len", C.c_int), ("rs_scale", C.c_float)]
+                ("window_len", C.c_int), ("in_window_len", C.c_int), ("rs_scale", C.c_float), ("fold", C.c_int)]
 
 
 class FsmnDims(C.Structure):
@@ -116,6 +116,7 @@ SIGNATURES = {
     "vadx_silero_segments": (_I, [_P, _I, _I, _P, C.POINTER(SileroSegParams), _P, _P, _I, _P]),
     "vadx_frontend_packed_floats": (_Z, [C.POINTER(FrontendCfg)]),
     "vadx_frontend_pack_host": (_I, [C.POINTER(FrontendCfg), _P, _P, _I, _P, _P, _P]),
+    "vadx_frontend_fold_kind": (_I, [C.POINTER(FrontendCfg), _P, _P, _I]),
     "vadx_frontend_logmel": (_I, [C.POINTER(FrontendCfg), _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
     "vadx_fsmn_packed_floats": (_Z, [C.POINTER(FsmnDims)]),
     "vadx_fsmn_pack_host": (_I, [C.POINTER(FsmnDims), C.POINTER(FsmnWeightsHost), _P]),

@@ -15,13 +15,21 @@
 //     time-major output [window][frame][mel] (mel contiguous: LFR rows are contiguous slices).
 #include "common.h"
 
+#include <math.h>
 #include <string.h>
+
+#include <vector>
 
 #include <type_traits>
 
 // FE_EXP: development-only cycle accounting (tools/exp_frontend.py)
 #ifndef FE_EXP
 #define FE_EXP 0
+#endif
+// FE_WHATIF: development-only switches of the folded kernel (results are wrong when set): 1 no residual product, 2 every table fragment
+// from block 0 (L1 instead of L2), 4 no u / v additions, 8 no symmetric product
+#ifndef FE_WHATIF
+#define FE_WHATIF 0
 #endif
 #if FE_EXP
 __device__ unsigned long long fe_dbg[8];
@@ -46,6 +54,11 @@ constexpr int X_LD = 36;          // X2 row stride  (>= TF + max passes, % 8 == 
 constexpr int P_LD = 36;          // power row stride (>= TF, % 8 == 4, 16-B aligned rows)
 constexpr int MAX_PASSES = 4;
 constexpr int MAX_MEL_TILES = 8;
+constexpr int MAX_REGIONS = 8;
+constexpr int XF_LD = 68;         // folded kernel: X2 and power row stride (64 frames + passes - 1 <= 67, % 8 == 4)
+constexpr int TF_FOLD = 64;       // frames per full tile of the folded kernel
+constexpr double FOLD_MAX_RATIO = 1.5e-4;   // residual / table scale the f16 product may carry (x 2^-11 each operand: ~1.5e-7)
+constexpr float RES_SCALE = 8192.f;   // residual table entries are stored as f16(value * 2^13)
 
 struct Dev {
     // geometry
@@ -62,9 +75,130 @@ struct Dev {
     int off_dft, off_nyq, off_mel;    // float offsets in the packed blob
     int tiles32, tiles16;   // per window: number of 32-frame tiles, then 16-frame tiles
     int out_stride, out_off; // floats per output frame row / first column (lets several streams share one row)
+    // folded DFT (cfg.fold != 0): pair regions of the symmetric part, the f16 residual, the 64-frame tiling
+    int fold, f_regions, f_blocks[MAX_REGIONS], f_offA[MAX_REGIONS], f_offB[MAX_REGIONS], f_strB[MAX_REGIONS];
+    int f_Pb, f_Kb32;       // 16-pair blocks of the symmetric part / 32-tap blocks of the residual
+    int off_fold, off_res, off_plan;  // float offsets of the folded tables in the blob; off_plan: int32 [region][blocks, offA, offB, strB]
+                                      // (the kernel reads the regions from there: indexing the by-value Dev arrays dynamically costs scratch)
+    float f_xscale, f_rinv; // power-of-two scale of the f16 samples; 1 / (f_xscale * RES_SCALE)
+    int tiles64, tail32, tail16;
 };
 
 static int round16(int x) { return (x + 15) & ~15; }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Folded DFT (cfg.fold): only |X|^2 leaves the log-mel kernel, so the spectrum may be rotated by any per-bin phase.  About the
+// window's centre c (rotation by 2 pi b c / n_fft) the real table row is even in the tap index and the imaginary row odd -- up
+// to what the reference's float32 table arithmetic left (|residual| ~ 6e-5 of the table scale for its three front-ends).  Taps
+// are therefore taken in mirror pairs (k, k' = T - k):
+//     re' = sum_p E[p] (x_k + x_k')  + sum_k RX[k] x_k        im' = sum_p O[p] (x_k - x_k')  + sum_k IX[k] x_k
+// E / O = f32 even / odd parts of the rotated REFERENCE table (half the f32 MFMAs of the dense product), RX / IX = the table
+// minus what E / O reproduce, computed in double from the table's own bits and applied as an f16 MFMA product on f16 copies of
+// the samples (16x the f32 rate; |RX| 2^-11 |x| 2^-11 relative rounding on a term that is itself 6e-5 of the sum).
+// kind 1: c = tap0 + (taps-1)/2 (symmetric windows), kind 2: c = tap0 + taps/2 (periodic windows: tap 0 has no partner and is
+// paired with a row of zeros, tap taps/2 is its own partner).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct FoldPair { int k, kp, kind; };          // kind 0: (k, kp); 1: k == kp; 2: k with the zero row; -1: padding (zero weights)
+struct FoldPlan {
+    int T, regions, blocks[MAX_REGIONS], offA[MAX_REGIONS], offB[MAX_REGIONS], strB[MAX_REGIONS];
+    std::vector<FoldPair> pairs;               // padded: 16 per block, region after region
+};
+
+static int fold_plan(const vadx_frontend_cfg *c, int kind, FoldPlan *pl) {
+    const int taps = c->taps, hop = c->hop;
+    pl->T = kind == 1 ? taps - 1 : taps;
+    pl->regions = 0;
+    pl->pairs.clear();
+    std::vector<FoldPair> seq;
+    int k = kind == 1 ? 0 : 1;
+    for (; k < pl->T - k; ++k) seq.push_back(FoldPair{k, pl->T - k, 0});
+    if (k == pl->T - k && k < taps) seq.push_back(FoldPair{k, k, 1});
+    auto close_region = [&](int first, int last, bool zero_partner) -> int {      // seq[first..last]
+        if (pl->regions >= MAX_REGIONS) return -1;
+        const int len = last - first + 1, nb = (len + 15) / 16, rg = pl->regions++;
+        const int k0 = seq[first].k, kp0 = seq[first].kp;
+        pl->blocks[rg] = nb;
+        pl->offA[rg] = (k0 % hop) * XF_LD + k0 / hop;
+        if (k0 % hop + 16 * nb > hop + 16) return -1;                             // padding rows must stay inside X2 (hop + 16 rows)
+        if (zero_partner) { pl->offB[rg] = hop * XF_LD; pl->strB[rg] = XF_LD; }
+        else {
+            pl->offB[rg] = (kp0 % hop) * XF_LD + kp0 / hop; pl->strB[rg] = -XF_LD;
+            if (kp0 % hop - (16 * nb - 1) < 0) return -1;
+        }
+        for (int t = 0; t < 16 * nb; ++t) pl->pairs.push_back(t < len ? seq[first + t] : FoldPair{0, 0, -1});
+        return 0;
+    };
+    int first = 0;
+    for (int e = 1; e <= (int)seq.size(); ++e)
+        if (e == (int)seq.size() || seq[e].k / hop != seq[first].k / hop || seq[e].kp / hop != seq[first].kp / hop) {
+            if (e > first && close_region(first, e - 1, false)) return -1;
+            first = e;
+        }
+    if (kind == 2) {                           // tap 0 alone
+        seq.push_back(FoldPair{0, 0, 2});
+        if (close_region((int)seq.size() - 1, (int)seq.size() - 1, true)) return -1;
+    }
+    std::vector<int> seen(taps, 0);            // every tap exactly once
+    for (const FoldPair &pr : pl->pairs) {
+        if (pr.kind < 0) continue;
+        seen[pr.k]++;
+        if (pr.kind == 0) seen[pr.kp]++;
+    }
+    for (int t = 0; t < taps; ++t) if (seen[t] != 1) return -1;
+    return 0;
+}
+
+// E / O [n_bins][P] (f32) and RX / IX [n_bins][taps] (double) of the reference table for one plan; returns max |RX|,|IX| and max |table|
+static void fold_tables(const vadx_frontend_cfg *c, const FoldPlan &pl, const float *cos_tab, const float *sin_tab, int n_fft,
+                        std::vector<float> &E, std::vector<float> &O, std::vector<double> &RX, std::vector<double> &IX,
+                        double *res_max, double *tab_max) {
+    const int P = (int)pl.pairs.size(), taps = c->taps, nb = c->n_bins;
+    const double cen = c->tap0 + pl.T / 2.0, two_pi = 6.283185307179586476925286766559;
+    std::vector<float> e2((size_t)nb * P), o2((size_t)nb * P);
+    std::vector<double> rx2((size_t)nb * taps), ix2((size_t)nb * taps), Rr(taps), Ir(taps);
+    double best = -1.0;
+    *tab_max = 0.0;
+    for (int sgn = 1; sgn >= -1; sgn -= 2) {
+        double rmax = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            const double phi = sgn * two_pi * b * cen / n_fft, cp = cos(phi), sp = sin(phi);
+            for (int t = 0; t < taps; ++t) {
+                const double R = cos_tab[(size_t)b * n_fft + c->tap0 + t], I = sin_tab[(size_t)b * n_fft + c->tap0 + t];
+                Rr[t] = cp * R - sp * I; Ir[t] = sp * R + cp * I;
+                if (fabs(R) > *tab_max) *tab_max = fabs(R);
+                if (fabs(I) > *tab_max) *tab_max = fabs(I);
+            }
+            for (int p = 0; p < P; ++p) {
+                const FoldPair &pr = pl.pairs[p];
+                float e = 0.f, o = 0.f;
+                if (pr.kind == 0) {
+                    e = (float)(0.5 * (Rr[pr.k] + Rr[pr.kp])); o = (float)(0.5 * (Ir[pr.k] - Ir[pr.kp]));
+                    rx2[(size_t)b * taps + pr.k] = Rr[pr.k] - (double)e; rx2[(size_t)b * taps + pr.kp] = Rr[pr.kp] - (double)e;
+                    ix2[(size_t)b * taps + pr.k] = Ir[pr.k] - (double)o; ix2[(size_t)b * taps + pr.kp] = Ir[pr.kp] + (double)o;
+                } else if (pr.kind == 1) {      // u = 2 x, v = 0
+                    e = (float)(0.5 * Rr[pr.k]);
+                    rx2[(size_t)b * taps + pr.k] = Rr[pr.k] - 2.0 * (double)e; ix2[(size_t)b * taps + pr.k] = Ir[pr.k];
+                } else if (pr.kind == 2) {      // u = v = x
+                    e = (float)Rr[pr.k]; o = (float)Ir[pr.k];
+                    rx2[(size_t)b * taps + pr.k] = Rr[pr.k] - (double)e; ix2[(size_t)b * taps + pr.k] = Ir[pr.k] - (double)o;
+                }
+                e2[(size_t)b * P + p] = e; o2[(size_t)b * P + p] = o;
+            }
+        }
+        for (size_t t = 0; t < rx2.size(); ++t) { rmax = fmax(rmax, fabs(rx2[t])); rmax = fmax(rmax, fabs(ix2[t])); }
+        if (best < 0.0 || rmax < best) { best = rmax; E = e2; O = o2; RX = rx2; IX = ix2; }
+    }
+    *res_max = best;
+}
+
+// LDS of the folded kernel: X2 [hop + 16][XF_LD] f32 | XS [XF_LD][hop + 8] f16, both reused by the power rows [Fp][XF_LD]; then the
+// partial sums of the last-bin tile [8 waves][2][64]
+static size_t fold_pw_off_bytes(const Dev *d) {
+    const size_t stage = (size_t)(d->hop + 16) * XF_LD * 4 + (size_t)XF_LD * (d->hop + 8) * 2, pw = (size_t)d->Fp * XF_LD * 4;
+    return ((stage > pw ? stage : pw) + 15) & ~(size_t)15;
+}
+static size_t fold_lds_bytes(const Dev *d) { return fold_pw_off_bytes(d) + 8 * 2 * 64 * 4; }
 
 static int derive(const vadx_frontend_cfg *c, Dev *d) {
     memset(d, 0, sizeof(*d));
@@ -100,7 +234,40 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     d->tiles16 = (rem + 15) / 16;
     if (rem > 16) { d->tiles32 += 1; d->tiles16 = 0; }
     d->out_stride = c->n_mels; d->out_off = 0;
+    if (c->fold) {
+        if (c->fold != 1 && c->fold != 2) return -1;
+        if (!(c->prep <= 2 || c->prep >= 6) || d->nbt > 16) return -1;      // int16-derived samples; two power tiles per wave
+        if (TF_FOLD + d->passes - 1 >= XF_LD || c->hop < 32) return -1;
+        FoldPlan pl;
+        if (fold_plan(c, c->fold, &pl)) return -1;
+        d->fold = c->fold; d->f_regions = pl.regions; d->f_Pb = 0;
+        for (int r = 0; r < pl.regions; ++r) {
+            d->f_blocks[r] = pl.blocks[r]; d->f_offA[r] = pl.offA[r]; d->f_offB[r] = pl.offB[r]; d->f_strB[r] = pl.strB[r];
+            d->f_Pb += pl.blocks[r];
+        }
+        d->f_Kb32 = (c->taps + 31) / 32;
+        d->off_fold = d->off_mel + d->n_mels * d->Fp;
+        d->off_res = d->off_fold + (d->nbt + d->nyq) * 32 * d->f_Pb * 16;
+        d->off_plan = d->off_res + (d->nbt + d->nyq) * 2 * d->f_Kb32 * vadx::FRAG;
+        // bound of |sample| after prep: the f16 copies carry x * 2^e with |x + x'| 2^e <= 32768
+        float M = 65536.f * 1.97f;                                                          // prep 0
+        if (c->prep == 1 || c->prep >= 6) M = 32768.f * (fabsf(c->k0) + fabsf(c->k1));
+        else if (c->prep == 2) M = 65536.f * fabsf(c->k1);
+        if (!(M > 0.f)) return -1;
+        d->f_xscale = exp2f(floorf(log2f(16384.f / M)));
+        d->f_rinv = 1.0f / (d->f_xscale * RES_SCALE);
+        d->tiles64 = c->frames / TF_FOLD;
+        const int rem64 = c->frames - d->tiles64 * TF_FOLD;
+        if (rem64 > 48) d->tiles64 += 1;
+        else { d->tail32 = rem64 > 16 ? 1 : 0; d->tail16 = (rem64 > 32 || (rem64 > 0 && rem64 <= 16)) ? 1 : 0; }
+        if (fold_lds_bytes(d) > 80 * 1024) return -1;
+    }
     return 0;
+}
+
+static size_t packed_total(const Dev &d) {
+    if (d.fold) return (size_t)d.off_plan + 4 * MAX_REGIONS;
+    return (size_t)d.off_mel + (size_t)d.n_mels * d.Fp;
 }
 
 // log of the mel energies: v_log_f32 (1 ulp in log2) times ln 2 instead of the library logf (~25 VALU instructions per value; VALU
@@ -110,18 +277,15 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
 #endif
 __device__ __forceinline__ float FE_LOG(float x) { return FE_FAST_LOG ? __builtin_amdgcn_logf(x) * 0.6931471805599453f : logf(x); }
 
-struct FtOut { float *ptr; int tile0, c_total, c_off; };      // COMPLEX: FT destination (re -> c_off, im -> c_off+1)
+// Phase 0 of both tile bodies: prep + polyphase staging  X2[r][g] = s'[(f0+g)*hop + r]  for g < cols (XLD = row stride of X2).
+// HALF: the same samples also go, scaled by the power of two `xscale` and rounded to f16, to XS[g][r] (row pitch xs_pitch
+// halves) -- the operand of the folded kernel's residual product.
+__device__ __forceinline__ _Float16 to_half_sat(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
 
-template <int MT, bool COMPLEX = false>
-__device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict__ P, const int16_t *__restrict__ win,
-                                          const float *__restrict__ fwin, float mean, int f0, float *__restrict__ out_win,
-                                          float *X2, float *PW, FtOut ft = FtOut{nullptr, 0, 0, 0}) {
+template <int XLD, bool HALF>
+__device__ __forceinline__ void stage_tile(const Dev &d, const int16_t *__restrict__ win, const float *__restrict__ fwin, float mean,
+                                           int f0, int cols, float *X2, _Float16 *XS, int xs_pitch, float xscale) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, i = lane & 15;
-    constexpr int NF = MT * 16;
-    const int cols = NF + d.passes - 1;
-
-    FE_T0();
     // ---- phase 0: prep + polyphase staging  X2[r][g] = s'[(f0+g)*hop + r]
     // wave = column g, lane = row r (+64 j): consecutive lanes read consecutive samples, no divisions.  All loads of a
     // column are issued first and UNCONDITIONALLY (indices clamped, values selected afterwards; which sources exist is
@@ -169,7 +333,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
                     }
                     v = PREP == 3 ? npe : (PREP == 4 ? ape : __fsub_rn(npe, __fmul_rn(d.k0, ape)));   // 5: echo = near - k0*aec
                 }
-                if (r < d.hop) X2[r * X_LD + g] = in ? v : 0.f;
+                if (r < d.hop) { const float sv = in ? v : 0.f; X2[r * XLD + g] = sv; if (HALF) XS[g * xs_pitch + r] = to_half_sat(__fmul_rn(sv, xscale)); }
             }
         }
     };
@@ -224,7 +388,7 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
                     const float p1 = __fadd_rn(__fmul_rn(xd[j], d.k0), __fmul_rn(xb[j], d.k1));
                     v = __fadd_rn(__fmul_rn(l0, p0), __fmul_rn(l1, p1));
                 }
-                if (r < d.hop) X2[r * X_LD + g] = in ? v : 0.f;
+                if (r < d.hop) { const float sv = in ? v : 0.f; X2[r * XLD + g] = sv; if (HALF) XS[g * xs_pitch + r] = to_half_sat(__fmul_rn(sv, xscale)); }
             }
         }
     };
@@ -242,6 +406,54 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
     };
     if (d.hop <= 192) stage_any(std::integral_constant<int, 3>{});
     else stage_any(std::integral_constant<int, 5>{});
+}
+
+// Phase 2 of both tile bodies: banded mel GEMM over the power rows PW[bin][frame] (row stride p_ld) + log, D rows = mel (SWAP) so
+// each lane stores 4 consecutive mels
+template <int MT>
+__device__ __forceinline__ void mel_phase(const Dev &d, const float *__restrict__ P, const float *PW, int p_ld, int f0,
+                                          float *__restrict__ out_win) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    for (int mtile = wave; mtile < d.nmt; mtile += THREADS / 64) {
+        f32x4 acc[1][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int lo = d.mel_kb_lo[mtile], hi = d.mel_kb_hi[mtile];
+        const float *const wrow[1] = {vadx::frag_ptr(P + d.off_mel, d.Fp, mtile, lo * 16, lane)};
+        int moff[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16;
+        if (hi > lo) vadx::gemm_rt_simple<1, MT, true>(acc, PW + lo * 16 * p_ld, p_ld, moff, wrow, hi - lo, lane);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int f = f0 + mt * 16 + i;
+            if (f < d.frames) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m = acc[0][mt][r];
+                    v[r] = FE_LOG(d.log_mode ? __fadd_rn(m, d.log_floor) : fmaxf(m, d.log_floor));
+                }
+                *reinterpret_cast<f32x4 *>(out_win + (size_t)f * d.out_stride + d.out_off + mtile * 16 + 4 * q) = v;
+            }
+        }
+    }
+}
+
+struct FtOut { float *ptr; int tile0, c_total, c_off; };      // COMPLEX: FT destination (re -> c_off, im -> c_off+1)
+
+template <int MT, bool COMPLEX = false>
+__device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict__ P, const int16_t *__restrict__ win,
+                                          const float *__restrict__ fwin, float mean, int f0, float *__restrict__ out_win,
+                                          float *X2, float *PW, FtOut ft = FtOut{nullptr, 0, 0, 0}) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, i = lane & 15;
+    constexpr int NF = MT * 16;
+    const int cols = NF + d.passes - 1;
+
+    FE_T0();
+    // ---- phase 0: prep + polyphase staging  X2[r][g] = s'[(f0+g)*hop + r]  (stage_tile)
+    stage_tile<X_LD, false>(d, win, fwin, mean, f0, cols, X2, nullptr, 0, 0.f);
     FE_ACC(4);
     __syncthreads();
     FE_ACC(0);
@@ -326,32 +538,228 @@ __device__ __forceinline__ void tile_body(const Dev &d, const float *__restrict_
     __syncthreads();
     FE_ACC(2);
 
-    // ---- phase 2: banded mel GEMM + log, D rows = mel (SWAP) so each lane stores 4 consecutive mels
-    for (int mtile = wave; mtile < d.nmt; mtile += THREADS / 64) {
-        f32x4 acc[1][MT];
+    mel_phase<MT>(d, P, PW, P_LD, f0, out_win);
+    FE_ACC(3);
+}
+
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) f16x8 *global_f16x8_ptr;
+__device__ __forceinline__ f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// One tile of MT*16 frames of the folded kernel (see "Folded DFT" above).  Phase 1 keeps the power of the wave's (at most two)
+// bin tiles in registers: the power rows reuse the LDS of X2 / XS once every wave is done with them.
+template <int MT>
+__device__ __forceinline__ void fold_tile(const Dev &d, const float *__restrict__ P, const int16_t *__restrict__ win, float mean,
+                                          int f0, float *__restrict__ out_win, float *lds, float *NQ) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, i = lane & 15;
+    constexpr int NF = MT * 16;
+    const int cols = NF + d.passes - 1, xs_pitch = d.hop + 8;
+    float *X2 = lds, *PW = lds;
+    _Float16 *XS = reinterpret_cast<_Float16 *>(lds + (d.hop + 16) * XF_LD);
+
+    FE_T0();
+    for (int e = tid; e < 16 * XF_LD; e += THREADS) X2[d.hop * XF_LD + e] = 0.f;                      // the zero rows (lone taps, padding pairs)
+    for (int e = tid; e < xs_pitch; e += THREADS) XS[cols * xs_pitch + e] = (_Float16)0.f;            // column read by the residual's padded taps
+    stage_tile<XF_LD, true>(d, win, nullptr, mean, f0, cols, X2, XS, xs_pitch, d.f_xscale);
+    FE_ACC(4);
+    __syncthreads();
+    FE_ACC(0);
+
+    auto load_x = [&](const float *pa, const float *pb, int strB, int j, float (&xa)[MT], float (&xb)[MT]) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int lo = d.mel_kb_lo[mtile], hi = d.mel_kb_hi[mtile];
-        const float *const wrow[1] = {vadx::frag_ptr(P + d.off_mel, d.Fp, mtile, lo * 16, lane)};
-        int moff[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16;
-        if (hi > lo) vadx::gemm_rt_simple<1, MT, true>(acc, PW + lo * 16 * P_LD, P_LD, moff, wrow, hi - lo, lane);
+        for (int mt = 0; mt < MT; ++mt) { xa[mt] = pa[j * XF_LD + mt * 16]; xb[mt] = pb[j * strB + mt * 16]; }
+    };
+    auto fold_step = [&](const float (&xa)[MT], const float (&xb)[MT], float e, float o, f32x4 (&are)[MT], f32x4 (&aim)[MT]) {
+        float u[MT], v[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int f = f0 + mt * 16 + i;
-            if (f < d.frames) {
-                f32x4 v;
+            u[mt] = (FE_WHATIF & 4) ? xa[mt] : __fadd_rn(xa[mt], xb[mt]);
+            v[mt] = (FE_WHATIF & 4) ? xb[mt] : __fsub_rn(xa[mt], xb[mt]);
+        }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float m = acc[0][mt][r];
-                    v[r] = FE_LOG(d.log_mode ? __fadd_rn(m, d.log_floor) : fmaxf(m, d.log_floor));
-                }
-                *reinterpret_cast<f32x4 *>(out_win + (size_t)f * d.out_stride + d.out_off + mtile * 16 + 4 * q) = v;
+        for (int mt = 0; mt < MT; ++mt) {
+            are[mt] = vadx::mfma16(u[mt], e, are[mt]);
+            aim[mt] = vadx::mfma16(v[mt], o, aim[mt]);
+        }
+    };
+    // 16 pairs (4 k-steps) of the symmetric part: u -> real accumulators, v -> imaginary ones
+    auto fold_block = [&](const f32x4 &e4, const f32x4 &o4, const float *pa, const float *pb, int strB, f32x4 (&are)[MT], f32x4 (&aim)[MT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float u[MT], v[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float xa = pa[j * XF_LD + mt * 16], xb = pb[j * strB + mt * 16];
+                u[mt] = __fadd_rn(xa, xb); v[mt] = __fsub_rn(xa, xb);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                are[mt] = vadx::mfma16(u[mt], e4[j], are[mt]);
+                aim[mt] = vadx::mfma16(v[mt], o4[j], aim[mt]);
             }
         }
+    };
+    const int Kp = d.f_Pb * 16;
+    const int *__restrict__ plan = reinterpret_cast<const int *>(P + d.off_plan);
+    if (d.nyq) {
+        // last bin (n_bins % 16 == 1): its 16-pair blocks and 32-tap residual blocks are dealt round-robin to the eight waves; the B tile of
+        // the u product carries E in row 0, the one of the v product O in row 1, so one accumulator holds (re', im') in columns 0, 1
+        f32x4 na[MT], nr[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { na[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; nr[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const f16x8 *rf = reinterpret_cast<const f16x8 *>(P + d.off_res + (size_t)(d.nbt * 2) * d.f_Kb32 * vadx::FRAG) + lane;
+        for (int S = wave; S < d.f_Kb32; S += THREADS / 64) {
+            const f16x8 w = *(global_f16x8_ptr)(rf + S * 64);
+            const int k = 32 * S + 8 * q, a = k / d.hop, r = k - a * d.hop;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                nr[mt] = mfma16h(*reinterpret_cast<const f16x8 *>(XS + (mt * 16 + i + a) * xs_pitch + r), w, nr[mt]);
+        }
+        const float *fe = vadx::frag_ptr(P + d.off_fold, Kp, d.nbt * 2, 0, lane), *fo = vadx::frag_ptr(P + d.off_fold, Kp, d.nbt * 2 + 1, 0, lane);
+        int gb = 0;
+        for (int rg = 0; rg < d.f_regions; ++rg) {
+            const int nblk = plan[4 * rg], strB = plan[4 * rg + 3];
+            const float *pa = X2 + plan[4 * rg + 1] + 4 * q * XF_LD + i, *pb = X2 + plan[4 * rg + 2] + 4 * q * strB + i;
+            for (int S = 0; S < nblk; ++S, ++gb) {
+                if ((gb & 7) != wave) continue;
+                fold_block(vadx::ldg4(fe + vadx::FRAG * gb), vadx::ldg4(fo + vadx::FRAG * gb), pa + 16 * S * XF_LD, pb + 16 * S * strB, strB, na, na);
+            }
+        }
+        if (i < 2)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = __fmaf_rn(nr[mt][r], d.f_rinv, na[mt][r]);
+                *reinterpret_cast<f32x4 *>(NQ + (wave * 2 + i) * 64 + mt * 16 + 4 * q) = t;
+            }
     }
+    f32x4 pw[2][MT];
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        const int bt = wave + slot * (THREADS / 64);
+        if (bt < d.nbt) {
+            f32x4 acc[2][MT];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // residual (f16): RX -> real, IX -> imaginary, both against the f16 samples of the frame; the samples of block S + 1 and the
+            // table fragments of block S + 1 are requested before the MFMAs of block S issue
+            if (!(FE_WHATIF & 1)) {
+                const f16x8 *rre = reinterpret_cast<const f16x8 *>(P + d.off_res + (size_t)(bt * 2) * d.f_Kb32 * vadx::FRAG) + lane;
+                const f16x8 *rim = rre + d.f_Kb32 * 64;
+                f16x8 wr = *(global_f16x8_ptr)(rre), wi = *(global_f16x8_ptr)(rim);
+                int a = 0, r = 8 * q;
+                while (r >= d.hop) { r -= d.hop; ++a; }
+                f16x8 xc[MT], xn[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xc[mt] = *reinterpret_cast<const f16x8 *>(XS + (mt * 16 + i + a) * xs_pitch + r);
+                for (int S = 0; S < d.f_Kb32; ++S) {
+                    const int Sn = S + 1 < d.f_Kb32 ? S + 1 : S;
+                    const f16x8 wrn = *(global_f16x8_ptr)(rre + ((FE_WHATIF & 2) ? 0 : Sn) * 64), win_ = *(global_f16x8_ptr)(rim + ((FE_WHATIF & 2) ? 0 : Sn) * 64);
+                    if (S + 1 < d.f_Kb32) {
+                        r += 32;
+                        while (r >= d.hop) { r -= d.hop; ++a; }
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xn[mt] = *reinterpret_cast<const f16x8 *>(XS + (mt * 16 + i + a) * xs_pitch + r);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[0][mt] = mfma16h(xc[mt], wr, acc[0][mt]);
+                        acc[1][mt] = mfma16h(xc[mt], wi, acc[1][mt]);
+                    }
+                    wr = wrn; wi = win_;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xc[mt] = xn[mt];
+                }
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[a2][mt] *= d.f_rinv;
+            }
+            // symmetric part (f32): table fragments one block ahead, LDS operands one k-step ahead (two register sets alternate)
+            if (!(FE_WHATIF & 8)) {
+                const float *fe = vadx::frag_ptr(P + d.off_fold, Kp, bt * 2, 0, lane), *fo = vadx::frag_ptr(P + d.off_fold, Kp, bt * 2 + 1, 0, lane);
+                f32x4 ec = vadx::ldg4(fe), oc = vadx::ldg4(fo);
+                int gb = 0;
+                for (int rg = 0; rg < d.f_regions; ++rg) {
+                    const int nblk = plan[4 * rg], strB = plan[4 * rg + 3];
+                    const float *pa = X2 + plan[4 * rg + 1] + 4 * q * XF_LD + i, *pb = X2 + plan[4 * rg + 2] + 4 * q * strB + i;
+                    float xa0[MT], xb0[MT], xa1[MT], xb1[MT];
+                    load_x(pa, pb, strB, 0, xa0, xb0);
+                    for (int S = 0; S < nblk; ++S, ++gb) {
+                        const int gn = (FE_WHATIF & 2) ? 0 : (gb + 1 < d.f_Pb ? gb + 1 : gb);
+                        const f32x4 en = vadx::ldg4(fe + vadx::FRAG * gn), on = vadx::ldg4(fo + vadx::FRAG * gn);
+                        const float *pas = pa + 16 * S * XF_LD, *pbs = pb + 16 * S * strB;
+                        const int Sn = S + 1 < nblk ? S + 1 : S;
+                        load_x(pas, pbs, strB, 1, xa1, xb1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fold_step(xa0, xb0, ec[0], oc[0], acc[0], acc[1]);
+                        load_x(pas, pbs, strB, 2, xa0, xb0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fold_step(xa1, xb1, ec[1], oc[1], acc[0], acc[1]);
+                        load_x(pas, pbs, strB, 3, xa1, xb1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fold_step(xa0, xb0, ec[2], oc[2], acc[0], acc[1]);
+                        load_x(pa + 16 * Sn * XF_LD, pb + 16 * Sn * strB, strB, 0, xa0, xb0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fold_step(xa1, xb1, ec[3], oc[3], acc[0], acc[1]);
+                        ec = en; oc = on;
+                    }
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pw[slot][mt][r] = __fadd_rn(__fmul_rn(acc[0][mt][r], acc[0][mt][r]), __fmul_rn(acc[1][mt][r], acc[1][mt][r]));
+        }
+    }
+    FE_ACC(1);
+    __syncthreads();                     // every wave is done with X2 / XS: the power rows take their place
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        const int bt = wave + slot * (THREADS / 64);
+        if (bt < d.nbt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4 *>(&PW[(bt * 16 + i) * XF_LD + mt * 16 + 4 * q]) = pw[slot][mt];
+    }
+    if (d.nyq) {
+        if (tid < NF) {
+            float re = 0.f, im = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < THREADS / 64; ++w8) { re += NQ[(w8 * 2) * 64 + tid]; im += NQ[(w8 * 2 + 1) * 64 + tid]; }
+            PW[(d.n_bins - 1) * XF_LD + tid] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+        }
+    }
+    for (int e = tid; e < (d.Fp - d.n_bins) * NF; e += THREADS) {      // padded power rows: 0 x 0 in the mel GEMM
+        const int r = e / NF, c2 = e - r * NF;
+        PW[(d.n_bins + r) * XF_LD + c2] = 0.f;
+    }
+    __syncthreads();
+    FE_ACC(2);
+    mel_phase<MT>(d, P, PW, XF_LD, f0, out_win);
     FE_ACC(3);
+}
+
+__global__ __launch_bounds__(THREADS, 2) void frontend_fold_kernel(
+    Dev d, const float *__restrict__ P, const int16_t *__restrict__ audio, long long row_stride,
+    long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ out, int nq_off) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles = d.tiles64 + d.tail32 + d.tail16;
+    const int widx = blockIdx.x / tiles, tile = blockIdx.x - widx * tiles;
+    const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
+    const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
+    float *out_win = out + (size_t)widx * d.frames * d.out_stride;
+    const float mean = means ? means[widx] : 0.f;
+    float *NQ = lds + nq_off;
+    if (tile < d.tiles64) fold_tile<4>(d, P, win, mean, tile * TF_FOLD, out_win, lds, NQ);
+    else if (d.tail32 && tile == d.tiles64) fold_tile<2>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
+    else fold_tile<1>(d, P, win, mean, d.tiles64 * TF_FOLD + 32 * d.tail32, out_win, lds, NQ);
 }
 
 __global__ __launch_bounds__(THREADS, 4) void frontend_logmel_kernel(
@@ -414,7 +822,7 @@ using namespace vadx::frontend;
 extern "C" size_t vadx_frontend_packed_floats(const vadx_frontend_cfg *cfg) {
     Dev d;
     if (!cfg || derive(cfg, &d)) return 0;
-    return (size_t)d.off_mel + (size_t)d.n_mels * d.Fp;
+    return packed_total(d);
 }
 
 // Tables on the host in the reference's own layout: cos_tab/sin_tab [n_bins][n_fft] (windowed, the
@@ -425,7 +833,7 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
     VADX_REQUIRE(cfg && cos_tab && sin_tab && fbank && packed_host && mel_kb, "vadx_frontend_pack_host: NULL argument");
     VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_frontend_pack_host: unsupported geometry (hop %% 16, n_mels %% 16, passes <= 4)");
     VADX_REQUIRE(cfg->tap0 >= 0 && cfg->tap0 + cfg->taps <= n_fft, "vadx_frontend_pack_host: taps outside n_fft");
-    const size_t total = (size_t)d.off_mel + (size_t)d.n_mels * d.Fp;
+    const size_t total = packed_total(d);
     memset(packed_host, 0, total * sizeof(float));
     // taps outside [tap0, tap0+taps) must be zero in the reference table (centre-padded window)
     for (int f = 0; f < d.n_bins; ++f)
@@ -469,7 +877,74 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
     vadx::frag_major_inplace(packed_host + d.off_dft, d.nbt * 32, d.Kp);
     if (d.nyq) vadx::frag_major_inplace(packed_host + d.off_nyq, 16, d.Kp);
     vadx::frag_major_inplace(packed_host + d.off_mel, d.n_mels, d.Fp);
+    if (d.fold) {
+        FoldPlan pl;
+        VADX_REQUIRE(fold_plan(cfg, cfg->fold, &pl) == 0, "vadx_frontend_pack_host: no fold plan for this geometry");
+        std::vector<float> E, O;
+        std::vector<double> RX, IX;
+        double res_max = 0.0, tab_max = 0.0;
+        fold_tables(cfg, pl, cos_tab, sin_tab, n_fft, E, O, RX, IX, &res_max, &tab_max);
+        VADX_REQUIRE(res_max <= FOLD_MAX_RATIO * tab_max && res_max * RES_SCALE < 30000.0,
+                     "vadx_frontend_pack_host: table is not symmetric enough about the window centre for cfg.fold = %d (residual %.3g of %.3g): "
+                     "ask vadx_frontend_fold_kind", cfg->fold, res_max, tab_max);
+        const int P = d.f_Pb * 16, ntl = d.nbt + d.nyq, last = d.n_bins - 1;
+        float *fm = packed_host + d.off_fold;                      // [ntl][E rows 0..15 | O rows 16..31][P]
+        for (int t = 0; t < d.nbt; ++t)
+            for (int i = 0; i < 16; ++i) {
+                const int f = t * 16 + i;
+                if (f >= d.n_bins || (d.nyq && f == last)) continue;
+                memcpy(fm + (size_t)(t * 32 + i) * P, E.data() + (size_t)f * P, P * sizeof(float));
+                memcpy(fm + (size_t)(t * 32 + 16 + i) * P, O.data() + (size_t)f * P, P * sizeof(float));
+            }
+        if (d.nyq) {           // u tile: E in row 0; v tile: O in row 1
+            memcpy(fm + (size_t)(d.nbt * 32) * P, E.data() + (size_t)last * P, P * sizeof(float));
+            memcpy(fm + (size_t)(d.nbt * 32 + 16 + 1) * P, O.data() + (size_t)last * P, P * sizeof(float));
+        }
+        vadx::frag_major_inplace(fm, ntl * 32, P);
+        int32_t *pi = reinterpret_cast<int32_t *>(packed_host + d.off_plan);
+        for (int r = 0; r < d.f_regions; ++r) { pi[4 * r] = d.f_blocks[r]; pi[4 * r + 1] = d.f_offA[r]; pi[4 * r + 2] = d.f_offB[r]; pi[4 * r + 3] = d.f_strB[r]; }
+        _Float16 *rh = reinterpret_cast<_Float16 *>(packed_host + d.off_res);      // [ntl][RX | IX][Kb32][64 lanes][8]
+        for (int t = 0; t < ntl; ++t)
+            for (int part = 0; part < 2; ++part)
+                for (int S = 0; S < d.f_Kb32; ++S)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int i = lane & 15, k = 32 * S + 8 * (lane >> 4) + e;
+                            double v = 0.0;
+                            if (k < d.taps) {
+                                if (t < d.nbt) {
+                                    const int f = t * 16 + i;
+                                    if (f < d.n_bins && !(d.nyq && f == last)) v = (part ? IX : RX)[(size_t)f * d.taps + k];
+                                } else if (part == 0 && i < 2) v = (i ? IX : RX)[(size_t)last * d.taps + k];
+                            }
+                            rh[((((size_t)t * 2 + part) * d.f_Kb32 + S) * 64 + lane) * 8 + e] = (_Float16)(float)(v * RES_SCALE);
+                        }
+    }
     return VADX_OK;
+}
+
+// Which fold the reference table admits: 1 / 2 (see "Folded DFT") or 0 -- the geometry has no plan, or the table is further from
+// the symmetric model than the f16 residual may carry (FOLD_MAX_RATIO of the table scale).  The caller stores the answer in cfg.fold
+// BEFORE vadx_frontend_packed_floats / vadx_frontend_pack_host / the launches.
+extern "C" int vadx_frontend_fold_kind(const vadx_frontend_cfg *cfg, const float *cos_tab, const float *sin_tab, int n_fft) {
+    if (!cfg || !cos_tab || !sin_tab) return 0;
+    int best = 0;
+    double best_res = 0.0;
+    for (int kind = 1; kind <= 2; ++kind) {
+        vadx_frontend_cfg c = *cfg;
+        c.fold = kind;
+        Dev d;
+        if (c.tap0 < 0 || c.tap0 + c.taps > n_fft || derive(&c, &d)) continue;
+        FoldPlan pl;
+        if (fold_plan(&c, kind, &pl)) continue;
+        std::vector<float> E, O;
+        std::vector<double> RX, IX;
+        double res_max = 0.0, tab_max = 0.0;
+        fold_tables(&c, pl, cos_tab, sin_tab, n_fft, E, O, RX, IX, &res_max, &tab_max);
+        if (!(res_max <= FOLD_MAX_RATIO * tab_max && res_max * RES_SCALE < 30000.0)) continue;
+        if (!best || res_max < best_res) { best = kind; best_res = res_max; }
+    }
+    return best;
 }
 
 extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host,
@@ -494,6 +969,16 @@ extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *p
                            (long long)win_stride, windows_per_clip, (int)nwin, cfg->window_len, scale, means_ws);
         VADX_HIP_TRY(hipGetLastError());
         means = means_ws;
+    }
+    if (d.fold) {
+        const size_t flds = fold_lds_bytes(&d);
+        const long long nblk = nwin * (d.tiles64 + d.tail32 + d.tail16);
+        VADX_REQUIRE(nblk < (1LL << 31), "vadx_frontend_logmel: too many tiles");
+        VADX_DYN_LDS(frontend_fold_kernel, 80 * 1024);
+        hipLaunchKernelGGL(frontend_fold_kernel, dim3((unsigned)nblk), dim3(THREADS), flds, st, d, packed, audio, (long long)row_stride,
+                           (long long)win_stride, windows_per_clip, means, out, (int)(fold_pw_off_bytes(&d) / 4));
+        VADX_HIP_TRY(hipGetLastError());
+        return VADX_OK;
     }
     const size_t lds = ((size_t)d.hop * X_LD + (size_t)d.Fp * P_LD) * sizeof(float);      // FSMN / FireRed: 52 992 B -- three workgroups per CU (it was 2.3 KB more: two)
     VADX_REQUIRE(lds <= 160 * 1024, "vadx_frontend_logmel: geometry needs %zu B of LDS", lds);

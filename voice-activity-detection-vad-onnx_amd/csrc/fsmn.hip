@@ -84,7 +84,7 @@ static int derive(const vadx_fsmn_dims *c, Dev *d) {
 //   cin/cout: FIR caches of this stream, [layer][128][19] (global); cout may alias cin
 //   ps     : LDS, receives P(silence) for frames f0 .. f0+nvalid-1
 template <int MTT>
-__device__ __noinline__ void tile(const Dev &d, const float *__restrict__ Pk, const float *__restrict__ lm,
+__device__ __forceinline__ void tile(const Dev &d, const float *__restrict__ Pk, const float *__restrict__ lm,
                                      int f0, int nvalid, const float *const *cin, float *const *cout,
                                      float *bufA, float *bufB, float *bufP, float *ps, float *red) {
     const int tid = threadIdx.x;

@@ -3,6 +3,7 @@ thin wrapper over `vadx_frontend_logmel` (csrc/frontend.hip).  Reference rows a1
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -38,8 +39,11 @@ def resampled_length(in_len, in_sample_rate):
 class Frontend:
     """Device-resident packed tables for one preset and one window length."""
 
-    def __init__(self, preset, window_len, device="cuda:0", n_mels=80, sample_rate=16000, in_sample_rate=16000):
-        """window_len = samples per window IN THE AUDIO BUFFER.  in_sample_rate != 16000 reproduces the exports built with
+    def __init__(self, preset, window_len, device="cuda:0", n_mels=80, sample_rate=16000, in_sample_rate=16000, fold=None):
+        """fold: None = take the folded DFT product wherever the reference table admits it (`vadx_frontend_fold_kind`; the
+        environment variable VADX_FRONTEND_FOLD=0 turns it off process-wide), False = dense product (the table-level parity tests
+        compare the two), True = require it.
+        window_len = samples per window IN THE AUDIO BUFFER.  in_sample_rate != 16000 reproduces the exports built with
         IN_SAMPLE_RATE set (Export_NVIDIA_MarbleNet_VAD.py:237-254, FireRedVAD/Export_FireRedVAD.py:431-449): the graph itself
         resamples each window to 16 kHz with F.interpolate(linear, align_corners=False), before the pre-emphasis when the
         input rate is higher, after it when lower (two-tap presets only)."""
@@ -81,12 +85,19 @@ class Frontend:
         self.cfg = cfg
         self.n_mels = n_mels
         L = _lib.lib()
+        cos_n, sin_n, fb_n = tables.as_np(cos_t), tables.as_np(sin_t), tables.as_np(fb)
+        required = fold is True
+        if fold is None:
+            fold = os.environ.get("VADX_FRONTEND_FOLD", "1") != "0" and p["mel"][0] != "zeros"
+        cfg.fold = int(L.vadx_frontend_fold_kind(C.byref(cfg), cos_n.ctypes.data, sin_n.ctypes.data, n_fft)) if fold else 0
+        if required and not cfg.fold:
+            raise ValueError("this table / geometry has no folded DFT product")
+        self.fold = cfg.fold
         n = L.vadx_frontend_packed_floats(C.byref(cfg))
         if n == 0:
             raise ValueError("front-end geometry not supported by the HIP kernel (hop % 16, n_mels % 16, <= 4 passes)")
         packed = np.zeros(n, dtype=np.float32)
         self.mel_kb = np.zeros(2 * (n_mels // 16), dtype=np.int32)
-        cos_n, sin_n, fb_n = tables.as_np(cos_t), tables.as_np(sin_t), tables.as_np(fb)
         _lib.check(L.vadx_frontend_pack_host(C.byref(cfg), cos_n.ctypes.data, sin_n.ctypes.data, n_fft,
                                              fb_n.ctypes.data, packed.ctypes.data, self.mel_kb.ctypes.data))
         self.packed = torch.from_numpy(packed).to(self.device)
