@@ -49,6 +49,26 @@ def flop_frontend_frame(n_bins, taps, n_mels=80):
     return 2 * (2 * n_bins * taps) + 3 * n_bins + 2 * n_mels * n_bins
 
 
+def flop_frontend_frame_folded(n_bins, taps, n_mels=80):
+    """(f32 flops, f16 flops) one frame ISSUES in the folded front-end product (csrc/frontend.hip "Folded DFT"): the symmetric part
+    multiplies taps/2 mirror pairs per table row in f32 MFMAs, the residual all taps in f16 MFMAs (16x the f32 rate); power + mel as
+    in flop_frontend_frame."""
+    pairs = (taps + 1) // 2
+    return 2 * (2 * n_bins * pairs) + 3 * n_bins + 2 * n_mels * n_bins, 2 * (2 * n_bins * taps)
+
+
+def _roof_frontend(frames, n_bins, taps, ms, tag):
+    """Roofline entry of the folded front-end kernel: `achieved` = f32-MFMA flops issued + the f16 residual's flops at their f32 time
+    equivalent (/16), against the f32 MFMA peak; `dense_equivalent_achieved` = what the reference's dense product would need."""
+    f32, f16 = flop_frontend_frame_folded(n_bins, taps)
+    r = _roof("frontend_fold_kernel", frames * (f32 + f16 / 16.0), ms, tag, "frontend_fold_kernel",
+              note="folded DFT product: f32 flops issued + f16 residual flops / 16 (its MFMA rate is 16x); dense_equivalent = the reference's "
+                   "dense cos + sin product")
+    r["f32_flop_per_launch"], r["f16_flop_per_launch"] = frames * f32, frames * f16
+    r["dense_equivalent_achieved"] = frames * flop_frontend_frame(n_bins, taps) / (ms * 1e-3) / 1e12
+    return r
+
+
 def flop_fsmn_frame(d=None):
     from vadx import weights
     d = dict(weights.FSMN_DIMS if d is None else d)
@@ -384,8 +404,7 @@ def fsmn_c3(torch, device, reps, cpu, clips=4096, log=lambda m: None):
            "clips": clips, "samples_per_clip": n, "windows_per_clip": W, "ms": ms,
            "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split,
            "roofline": _roof("fsmn_clips_kernel", frames10 * flop_fsmn_frame(), net_ms, "fsmn", "fsmn_clips_kernel"),
-           "roofline_frontend": _roof("frontend_logmel_kernel", frames10 * flop_frontend_frame(257, 400),
-                                      split.get("vadx_frontend_logmel", ms), "fsmn", "frontend_logmel_kernel"),
+           "roofline_frontend": _roof_frontend(frames10, 257, 400, split.get("vadx_frontend_logmel", ms), "fsmn"),
            "hbm": _hbm(clips * (padded * 2 + (W * (eng.T - lb) + lb)), ms, "fsmn"), "cpu_baseline": None}
     del audio
     if cpu:
@@ -410,7 +429,7 @@ def marblenet_c4(torch, device, reps, cpu, clips=8192, log=lambda m: None, tag="
                        "-> per-20-ms speech probabilities",
            "clips": clips, "samples_per_clip": n, "ms": ms, "frames_per_s": clips * n / 512 / (ms * 1e-3),
            "kernel_ms": split, "kernel_calls": calls,
-           "roofline": _roof("frontend_logmel_kernel", clips * T * flop_frontend_frame(257, 400), fe_ms, tag, "frontend_logmel_kernel"),
+           "roofline": _roof_frontend(clips * T, 257, 400, fe_ms, tag),
            "roofline_net": _roof("marblenet encoder+decoder launches", clips * Tout * flop_marblenet_out_frame(), net_ms, tag, "vadx::marblenet::",
                                  note="sum of the encoder / classifier entries in kernel_ms (fused block pairs, single blocks, tail)"),
            "hbm": _hbm(clips * (n * 2 + 2 * Tout * 4), ms, tag), "cpu_baseline": None}
@@ -435,8 +454,7 @@ def firered_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None):
            "clips": clips, "samples_per_clip": n, "ms": ms, "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split,
            "roofline": _roof("firered_kernel", frames10 * flop_firered_frame(), split.get("vadx_firered_run", ms), "firered",
                              "firered_kernel"),
-           "roofline_frontend": _roof("frontend_logmel_kernel", frames10 * flop_frontend_frame(201, 400),
-                                      split.get("vadx_frontend_logmel", ms), "firered", "frontend_logmel_kernel"),
+           "roofline_frontend": _roof_frontend(frames10, 201, 400, split.get("vadx_frontend_logmel", ms), "firered"),
            "hbm": _hbm(clips * (n * 2 + W * 98 * 4), ms, "firered"), "cpu_baseline": None}
     del audio
     if cpu:
