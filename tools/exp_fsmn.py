@@ -12,10 +12,16 @@ SRC = ["capi.hip", "silero.hip", "frontend.hip", "fsmn.hip", "firered.hip", "mar
 NAMES = ["stage", "in_linear1", "in_linear2", "cache load (x4)", "linear (x4)", "FIR + cache store (x4)", "affine (x4)", "out1 + out2", "softmax",
          "barrier waits of wave 0 (after every section)"]
 
-if sys.argv[1] == "build":
+if sys.argv[1] == "build":          # fsmn.hip rebuilt with -DFS_EXP=1, linked with the product's other objects
+    sys.path.insert(0, ROOT)
+    import vadx  # noqa: F401
+    from vadx import build as vbuild
+    vbuild.build(verbose=False)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DFS_EXP=1"]
-                          + [os.path.join(PKG, "csrc", s) for s in SRC] + ["-o", LIB])
+    obj = os.path.join(os.path.dirname(LIB), "fsmn_exp.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + vbuild.FLAGS + ["-DFS_EXP=1"] + sys.argv[2:] + ["-c", os.path.join(PKG, "csrc", "fsmn.hip"), "-o", obj])
+    objs = [obj if s == "fsmn.hip" else os.path.join(vbuild.OBJ, s.replace(".hip", ".o")) for s in vbuild.SOURCES]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
     print("built", LIB)
 else:
     os.environ["VADX_LIBRARY"] = LIB

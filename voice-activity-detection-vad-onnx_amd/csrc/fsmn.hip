@@ -87,7 +87,8 @@ template <int MTT>
 __device__ __forceinline__ void tile(const Dev &d, const float *__restrict__ Pk, const float *__restrict__ lm,
                                      int f0, int nvalid, const float *const *cin, float *const *cout,
                                      float *bufA, float *bufB, float *bufP, float *ps, float *red) {
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));          // per tile: nothing derived from the thread index is hoisted out of the tile / window loops
     constexpr int NF = MTT * 16;
 
     FS_T0();

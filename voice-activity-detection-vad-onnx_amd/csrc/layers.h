@@ -23,7 +23,11 @@ struct LayerArgs {
 // weight load, i.e. latency-bound -- FSMN's in_linear1 took 20 % of the kernel for 13 % of its MFMAs.)
 template <int MTT, bool AFFINE>
 __device__ __forceinline__ void layer(const LayerArgs &a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // opaque to the optimiser: a layer called inside a loop over tiles / windows is loop-invariant in everything but its LDS contents, and
+    // LICM hoists every layer's per-lane weight pointers out of that loop (FSMN: 238 VGPRs spilled, 16 MB of scratch per XCD thrashing L2)
+    asm volatile("" : "+v"(lane), "+v"(wave));
+    const int q = lane >> 4, i = lane & 15;
     const int NW = blockDim.x >> 6;
     const int full = (a.ntiles / NW) * NW;
     // rounds are taken two at a time (n-tiles nt and nt + NW side by side: 2*MTT accumulators, one pipeline fill and
