@@ -53,9 +53,6 @@ extern "C" int vadx_cfb_debug_cycles(unsigned long long *out, int reset) {
 #define CFB_MARK(slot) do {} while (0)
 #define CFB_FLUSH(base) do {} while (0)
 #endif
-#ifndef CFB_PRIO
-#define CFB_PRIO 3
-#endif
 
 namespace vadx {
 namespace dfsmn_cfb {
@@ -71,9 +68,7 @@ struct ViewW {
 
 constexpr int F = 160, CH = 20, CF = 81, NTH = 512;                 // bins, channels, ceps bins, threads
 constexpr int KSF = 40, KSI = 41;                                   // k-steps of the forward / inverse table
-constexpr int RP = 64, OP = 128;
 constexpr int TBLF_FLOATS = 10 * KSF * 64, TBLI_FLOATS = 10 * KSI * 64;
-constexpr int RED_FLOATS = 8 * 16 * 6 + 16 * 8;
 
 // Global access as UNIFORM base + unsigned 32-bit BYTE offset: the form the hardware addresses as (scalar base, 32-bit lane offset).
 // An element offset would have to be scaled by four in 64 bits (it may overflow 32), i.e. one 64-bit address pair per access.
@@ -133,14 +128,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Wave specialisation.  Waves 0-3 ("producers", one per SIMD) run the block's small convs, the gate arithmetic and the statistics
-// for one bin each per iteration -- short dependent MFMA chains, transcendentals, global loads and stores; waves 4-7 ("DFT waves",
-// one per SIMD: waves w and w + 4 share a SIMD) do nothing but accumulate the length-160 DFT of what the producers wrote an
-// iteration earlier: 50 independent MFMAs per k-step on 200 accumulator registers.  One LDS-only barrier per iteration.  The first
-// version ran both kinds of work in alternating phases on all eight waves and left the matrix pipe idle through every producer
-// phase (117 us per 20-channel tile against 53 us of MFMA issue time); here the SIMD interleaves the two streams itself.
-constexpr int GPR = 12 * 16 + 16;                  // producer ring: 12 bin slots per channel (+16: the k-quarters 16 banks apart)
-constexpr int NPROD = 4;
 constexpr int WSP = 20, WS_TILE = 16 * WSP, WS_FLOATS = 2 * WS_TILE;      // per-wave 16 x 16 transpose scratch (two tiles), pitch 20: D-layout writes of the four lane
                                                    // quarters land 16 banks apart, rows stay 16-byte aligned for ds_read_b128
 

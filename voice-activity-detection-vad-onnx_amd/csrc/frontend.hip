@@ -78,10 +78,10 @@ struct Dev {
     // folded DFT (cfg.fold != 0): pair regions of the symmetric part, the f16 residual, the 64-frame tiling
     int fold, f_regions, f_blocks[MAX_REGIONS], f_offA[MAX_REGIONS], f_offB[MAX_REGIONS], f_strB[MAX_REGIONS];
     int f_Pb, f_Kb32;       // 16-pair blocks of the symmetric part / 32-tap blocks of the residual
-    int off_fold, off_res, off_plan;  // float offsets of the folded tables in the blob; off_plan: int32 [region][blocks, offA, offB, strB]
+    int off_fold, off_res, off_plan;  // float offsets of the folded tables in the blob; off_plan: int32 [region][blocks, offA, offB, strB], then [mel tile][lo, hi]
                                       // (the kernel reads the regions from there: indexing the by-value Dev arrays dynamically costs scratch)
     float f_xscale, f_rinv; // power-of-two scale of the f16 samples; 1 / (f_xscale * RES_SCALE)
-    int tiles64, tail32, tail16;
+    int tiles64, tail_mt;   // 64-frame tiles of a window, then ONE tail tile of tail_mt m-tiles (0: none; 1 - 3: 16 - 48 frames)
 };
 
 static int round16(int x) { return (x + 15) & ~15; }
@@ -258,15 +258,15 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
         d->f_rinv = 1.0f / (d->f_xscale * RES_SCALE);
         d->tiles64 = c->frames / TF_FOLD;
         const int rem64 = c->frames - d->tiles64 * TF_FOLD;
-        if (rem64 > 48) d->tiles64 += 1;
-        else { d->tail32 = rem64 > 16 ? 1 : 0; d->tail16 = (rem64 > 32 || (rem64 > 0 && rem64 <= 16)) ? 1 : 0; }
+        d->tail_mt = (rem64 + 15) / 16;
+        if (d->tail_mt == 4) { d->tiles64 += 1; d->tail_mt = 0; }
         if (fold_lds_bytes(d) > 80 * 1024) return -1;
     }
     return 0;
 }
 
 static size_t packed_total(const Dev &d) {
-    if (d.fold) return (size_t)d.off_plan + 4 * MAX_REGIONS;
+    if (d.fold) return (size_t)d.off_plan + 4 * MAX_REGIONS + 2 * MAX_MEL_TILES;
     return (size_t)d.off_mel + (size_t)d.n_mels * d.Fp;
 }
 
@@ -410,15 +410,17 @@ __device__ __forceinline__ void stage_tile(const Dev &d, const int16_t *__restri
 
 // Phase 2 of both tile bodies: banded mel GEMM over the power rows PW[bin][frame] (row stride p_ld) + log, D rows = mel (SWAP) so
 // each lane stores 4 consecutive mels
+// (bands: the folded kernel reads [mel tile][lo, hi] from the blob -- with its four tile variants inlined, the dynamic index into the
+// by-value Dev arrays made the compiler keep a 384-byte copy of Dev in scratch)
 template <int MT>
 __device__ __forceinline__ void mel_phase(const Dev &d, const float *__restrict__ P, const float *PW, int p_ld, int f0,
-                                          float *__restrict__ out_win) {
+                                          float *__restrict__ out_win, const int *__restrict__ bands = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
     for (int mtile = wave; mtile < d.nmt; mtile += THREADS / 64) {
         f32x4 acc[1][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int lo = d.mel_kb_lo[mtile], hi = d.mel_kb_hi[mtile];
+        const int lo = bands ? bands[2 * mtile] : d.mel_kb_lo[mtile], hi = bands ? bands[2 * mtile + 1] : d.mel_kb_hi[mtile];
         const float *const wrow[1] = {vadx::frag_ptr(P + d.off_mel, d.Fp, mtile, lo * 16, lane)};
         int moff[MT];
 #pragma unroll
@@ -567,23 +569,6 @@ __device__ __forceinline__ void fold_tile(const Dev &d, const float *__restrict_
     __syncthreads();
     FE_ACC(0);
 
-    auto load_x = [&](const float *pa, const float *pb, int strB, int j, float (&xa)[MT], float (&xb)[MT]) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { xa[mt] = pa[j * XF_LD + mt * 16]; xb[mt] = pb[j * strB + mt * 16]; }
-    };
-    auto fold_step = [&](const float (&xa)[MT], const float (&xb)[MT], float e, float o, f32x4 (&are)[MT], f32x4 (&aim)[MT]) {
-        float u[MT], v[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            u[mt] = (FE_WHATIF & 4) ? xa[mt] : __fadd_rn(xa[mt], xb[mt]);
-            v[mt] = (FE_WHATIF & 4) ? xb[mt] : __fsub_rn(xa[mt], xb[mt]);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            are[mt] = vadx::mfma16(u[mt], e, are[mt]);
-            aim[mt] = vadx::mfma16(v[mt], o, aim[mt]);
-        }
-    };
     // 16 pairs (4 k-steps) of the symmetric part: u -> real accumulators, v -> imaginary ones
     auto fold_block = [&](const f32x4 &e4, const f32x4 &o4, const float *pa, const float *pb, int strB, f32x4 (&are)[MT], f32x4 (&aim)[MT]) {
 #pragma unroll
@@ -592,7 +577,8 @@ __device__ __forceinline__ void fold_tile(const Dev &d, const float *__restrict_
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const float xa = pa[j * XF_LD + mt * 16], xb = pb[j * strB + mt * 16];
-                u[mt] = __fadd_rn(xa, xb); v[mt] = __fsub_rn(xa, xb);
+                u[mt] = (FE_WHATIF & 4) ? xa : __fadd_rn(xa, xb);
+                v[mt] = (FE_WHATIF & 4) ? xb : __fsub_rn(xa, xb);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -681,7 +667,8 @@ __device__ __forceinline__ void fold_tile(const Dev &d, const float *__restrict_
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc[a2][mt] *= d.f_rinv;
             }
-            // symmetric part (f32): table fragments one block ahead, LDS operands one k-step ahead (two register sets alternate)
+            // symmetric part (f32): table fragments one block ahead (requesting the LDS operands a k-step ahead as well, on two register
+            // sets, measured no gain: four waves per SIMD already cover that latency)
             if (!(FE_WHATIF & 8)) {
                 const float *fe = vadx::frag_ptr(P + d.off_fold, Kp, bt * 2, 0, lane), *fo = vadx::frag_ptr(P + d.off_fold, Kp, bt * 2 + 1, 0, lane);
                 f32x4 ec = vadx::ldg4(fe), oc = vadx::ldg4(fo);
@@ -689,25 +676,11 @@ __device__ __forceinline__ void fold_tile(const Dev &d, const float *__restrict_
                 for (int rg = 0; rg < d.f_regions; ++rg) {
                     const int nblk = plan[4 * rg], strB = plan[4 * rg + 3];
                     const float *pa = X2 + plan[4 * rg + 1] + 4 * q * XF_LD + i, *pb = X2 + plan[4 * rg + 2] + 4 * q * strB + i;
-                    float xa0[MT], xb0[MT], xa1[MT], xb1[MT];
-                    load_x(pa, pb, strB, 0, xa0, xb0);
                     for (int S = 0; S < nblk; ++S, ++gb) {
                         const int gn = (FE_WHATIF & 2) ? 0 : (gb + 1 < d.f_Pb ? gb + 1 : gb);
                         const f32x4 en = vadx::ldg4(fe + vadx::FRAG * gn), on = vadx::ldg4(fo + vadx::FRAG * gn);
-                        const float *pas = pa + 16 * S * XF_LD, *pbs = pb + 16 * S * strB;
-                        const int Sn = S + 1 < nblk ? S + 1 : S;
-                        load_x(pas, pbs, strB, 1, xa1, xb1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        fold_step(xa0, xb0, ec[0], oc[0], acc[0], acc[1]);
-                        load_x(pas, pbs, strB, 2, xa0, xb0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        fold_step(xa1, xb1, ec[1], oc[1], acc[0], acc[1]);
-                        load_x(pas, pbs, strB, 3, xa1, xb1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        fold_step(xa0, xb0, ec[2], oc[2], acc[0], acc[1]);
-                        load_x(pa + 16 * Sn * XF_LD, pb + 16 * Sn * strB, strB, 0, xa0, xb0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        fold_step(xa1, xb1, ec[3], oc[3], acc[0], acc[1]);
+                        __builtin_amdgcn_sched_barrier(0);      // the next block's table fragments are requested before this block's MFMAs issue
+                        fold_block(ec, oc, pa + 16 * S * XF_LD, pb + 16 * S * strB, strB, acc[0], acc[1]);
                         ec = en; oc = on;
                     }
                 }
@@ -742,15 +715,15 @@ __device__ __forceinline__ void fold_tile(const Dev &d, const float *__restrict_
     }
     __syncthreads();
     FE_ACC(2);
-    mel_phase<MT>(d, P, PW, XF_LD, f0, out_win);
+    mel_phase<MT>(d, P, PW, XF_LD, f0, out_win, plan + 4 * MAX_REGIONS);
     FE_ACC(3);
 }
 
-__global__ __launch_bounds__(THREADS, 2) void frontend_fold_kernel(
+__global__ __launch_bounds__(THREADS, 4) void frontend_fold_kernel(
     Dev d, const float *__restrict__ P, const int16_t *__restrict__ audio, long long row_stride,
     long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ out, int nq_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tiles = d.tiles64 + d.tail32 + d.tail16;
+    const int tiles = d.tiles64 + (d.tail_mt ? 1 : 0);
     const int widx = blockIdx.x / tiles, tile = blockIdx.x - widx * tiles;
     const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
     const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
@@ -758,8 +731,9 @@ __global__ __launch_bounds__(THREADS, 2) void frontend_fold_kernel(
     const float mean = means ? means[widx] : 0.f;
     float *NQ = lds + nq_off;
     if (tile < d.tiles64) fold_tile<4>(d, P, win, mean, tile * TF_FOLD, out_win, lds, NQ);
-    else if (d.tail32 && tile == d.tiles64) fold_tile<2>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
-    else fold_tile<1>(d, P, win, mean, d.tiles64 * TF_FOLD + 32 * d.tail32, out_win, lds, NQ);
+    else if (d.tail_mt == 3) fold_tile<3>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
+    else if (d.tail_mt == 2) fold_tile<2>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
+    else fold_tile<1>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
 }
 
 __global__ __launch_bounds__(THREADS, 4) void frontend_logmel_kernel(
@@ -903,6 +877,7 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
         vadx::frag_major_inplace(fm, ntl * 32, P);
         int32_t *pi = reinterpret_cast<int32_t *>(packed_host + d.off_plan);
         for (int r = 0; r < d.f_regions; ++r) { pi[4 * r] = d.f_blocks[r]; pi[4 * r + 1] = d.f_offA[r]; pi[4 * r + 2] = d.f_offB[r]; pi[4 * r + 3] = d.f_strB[r]; }
+        for (int mt = 0; mt < d.nmt; ++mt) { pi[4 * MAX_REGIONS + 2 * mt] = mel_kb[2 * mt]; pi[4 * MAX_REGIONS + 2 * mt + 1] = mel_kb[2 * mt + 1]; }      // the mel bands, for the kernel
         _Float16 *rh = reinterpret_cast<_Float16 *>(packed_host + d.off_res);      // [ntl][RX | IX][Kb32][64 lanes][8]
         for (int t = 0; t < ntl; ++t)
             for (int part = 0; part < 2; ++part)
@@ -972,7 +947,7 @@ extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *p
     }
     if (d.fold) {
         const size_t flds = fold_lds_bytes(&d);
-        const long long nblk = nwin * (d.tiles64 + d.tail32 + d.tail16);
+        const long long nblk = nwin * (d.tiles64 + (d.tail_mt ? 1 : 0));
         VADX_REQUIRE(nblk < (1LL << 31), "vadx_frontend_logmel: too many tiles");
         VADX_DYN_LDS(frontend_fold_kernel, 80 * 1024);
         hipLaunchKernelGGL(frontend_fold_kernel, dim3((unsigned)nblk), dim3(THREADS), flds, st, d, packed, audio, (long long)row_stride,
