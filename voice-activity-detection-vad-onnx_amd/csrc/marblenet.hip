@@ -11,6 +11,24 @@
 #include "common.h"
 #include "layers.h"
 
+// MB_EXP: development-only cycle accounting of jasper_block2_kernel (tools/exp_marblenet.py): per-section clock64 sums of thread 0
+#ifndef MB_EXP
+#define MB_EXP 0
+#endif
+#if MB_EXP
+__device__ unsigned long long mb_dbg[16];
+#define MB_T0() long long mb_t_ = clock64()
+#define MB_ACC(slot) do { if (threadIdx.x == 0) { const long long n_ = clock64(); atomicAdd(&mb_dbg[slot], (unsigned long long)(n_ - mb_t_)); mb_t_ = n_; } } while (0)
+extern "C" int vadx_marblenet_debug_cycles(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mb_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mb_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define MB_T0() do {} while (0)
+#define MB_ACC(slot) do {} while (0)
+#endif
+
 #include <math.h>
 
 namespace vadx {
@@ -206,6 +224,7 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TILE;
     const float *xb = x + (long long)b * c.cin * c.T;
     const int tin0 = t0 - 2 * PAD;
+    MB_T0();
     // ---- stage the block input (channel-first source: lane = time, wave = channel), unconditional clamped loads
     for (int ch0 = 0; ch0 < c.cinp; ch0 += 8 * (THREADS / 64)) {
         float v[8];
@@ -221,12 +240,16 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
             if (lane < WIN0 && ch < c.cinp) IN[ch * IN_LD + lane] = (ch < c.cin && ti >= 0 && ti < c.T) ? v[u] : 0.f;
         }
     }
+    MB_ACC(0);
     __syncthreads();
+    MB_ACC(7);
     {   // residual 1x1 of the block input (frames t0 .. t0 + 31 sit at column 2 PAD), before the input is overwritten
         LayerArgs r{rw, c.cinp, c.c2 / 16, 1, c.cinp / 16, 0, 0, rb, 0, IN, IN_LD, 2 * PAD, ROUT, A_LD, 0, nullptr, nullptr};
         layer<2, false>(r);
     }
+    MB_ACC(1);
     __syncthreads();                // every residual operand is read: depthwise 0 may overwrite IN
+    MB_ACC(7);
     // ---- depthwise 0 IN PLACE: register-window FIR, item = (channel, 8 outputs).  The six items of a channel are six neighbouring
     // lanes of ONE wave: a wave's window reads all precede its writes in program order (the FMAs in between depend on them), and
     // no two waves share a channel, so the overwrite needs no further barrier.
@@ -253,12 +276,16 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
             for (int o = 0; o < 8; ++o) row[o] = o8[o];
         }
     }
+    MB_ACC(2);
     __syncthreads();
+    MB_ACC(7);
     {   // pointwise 0 + folded BN + ReLU on 48 columns
         LayerArgs a{pw0, c.cinp, c.c1 / 16, 1, c.cinp / 16, 0, 0, b0, 1, D0, IN_LD, 0, H1, H_LD, 0, nullptr, nullptr};
         layer<3, false>(a);
     }
+    MB_ACC(3);
     __syncthreads();
+    MB_ACC(7);
     // ---- depthwise 1 on H1 (column j = frame t0 - PAD + j; frames outside the clip are the conv's zero padding)
     for (int it = tid; it < c.c1 * (TILE / 8); it += THREADS) {
         const int ch = it / (TILE / 8), m0 = 8 * (it - ch * (TILE / 8));
@@ -282,17 +309,22 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
 #pragma unroll
         for (int o = 0; o < 8; ++o) D1[ch * A_LD + m0 + o] = o8[o];     // D1 sits in IN's region (D0 is dead since the barrier above)
     }
+    MB_ACC(4);
     __syncthreads();                // every H1 read is done: OUT may overwrite it
+    MB_ACC(7);
     {
         LayerArgs a{pw1, c.c1, c.c2 / 16, 1, c.c1 / 16, 0, 0, b1, 0, D1, A_LD, 0, OUT, A_LD, 0, nullptr, nullptr};
         layer<2, false>(a);
     }
+    MB_ACC(5);
     __syncthreads();
+    MB_ACC(7);
     float *yb = y + (long long)b * c.c2 * c.T;
     for (int e = tid; e < c.c2 * TILE; e += THREADS) {
         const int ch = e / TILE, m = e - ch * TILE;
         if (t0 + m < c.T) yb[(long long)ch * c.T + t0 + m] = fmaxf(OUT[ch * A_LD + m] + ROUT[ch * A_LD + m], 0.f);
     }
+    MB_ACC(6);
 }
 
 // ---------------------------------------------------------------------------------------------
