@@ -46,11 +46,13 @@ def oracle_logmel(preset, windows_i16):
     ("firered", 16000, 2, 16000, 3),
     ("firered", 2560, 1, 2560, 2),
 ])
-def test_logmel_matches_oracle(preset, L, W, stride, B):
+@pytest.mark.parametrize("fold", [True, False])
+def test_logmel_matches_oracle(preset, L, W, stride, B, fold):
     n = (W - 1) * stride + L
     clips = weights.burst_clips(B, n, seed=L + W + B)
     clips[0, : min(n, 3000)] = 0                         # exact digital silence -> exercises the log floor
-    fe = frontend.Frontend(preset, L)
+    fe = frontend.Frontend(preset, L, fold=fold)
+    assert (fe.fold != 0) == fold
     out = fe.logmel(clips, windows_per_clip=W, win_stride=stride).cpu().numpy()
     wins = np.stack([clips[b, w * stride:w * stride + L] for b in range(B) for w in range(W)])
     ref = oracle_logmel(preset, T(wins).unsqueeze(1)).numpy()
@@ -87,14 +89,17 @@ def test_logmel_large_batch_invariance():
     ("firered", 8000, 8000, 2), ("firered", 48000, 48000, 1), ("firered", 44100, 44100, 2), ("firered", 22050, 12345, 1),
     ("marblenet", 8000, 8000, 2), ("marblenet", 48000, 48000, 1), ("marblenet", 32000, 20001, 1), ("marblenet", 11025, 30000, 2),
 ])
-def test_resampled_logmel_matches_oracle(preset, rate, L, W):
-    """prep 6 (interpolate, then pre-emphasis: input rate above 16 kHz) and prep 7 (pre-emphasis, then interpolate: below) of
+@pytest.mark.parametrize("fold", [True, False])
+def test_resampled_logmel_matches_oracle(preset, rate, L, W, fold):
+    """(both DFT products: the folded one is what sessions run, the dense one is the fallback)
+    prep 6 (interpolate, then pre-emphasis: input rate above 16 kHz) and prep 7 (pre-emphasis, then interpolate: below) of
     the fused kernel vs torch's own F.interpolate in the oracle (Export_NVIDIA_MarbleNet_VAD.py:237-254,
     FireRedVAD/Export_FireRedVAD.py:431-449)."""
     from oracle import marblenet as omb
     B = 2
     clips = weights.burst_clips(B, W * L, seed=rate + L)
-    fe = frontend.Frontend(preset, L, in_sample_rate=rate)
+    fe = frontend.Frontend(preset, L, in_sample_rate=rate, fold=fold)
+    assert (fe.fold != 0) == fold
     assert fe.cfg.prep == (6 if rate > 16000 else 7) and fe.window_len == int(np.floor(L * (1.0 / (rate / 16000.0))))
     out = fe.logmel(clips, windows_per_clip=W).cpu().numpy()
     wins = T(np.stack([clips[b, w * L:(w + 1) * L] for b in range(B) for w in range(W)])).unsqueeze(1)
