@@ -105,8 +105,9 @@ def test_full_size_config4_properties():
 
 
 def test_fused_blocks_equal_the_per_sub_block_launches():
-    """The fused residual-block / tail kernels against the ten per-sub-block launches they replace (same FIR and GEMM
-    order per element: scores agree to float32 round-off), including a clip shorter than one tile and a ragged last tile."""
+    """The fused residual-block / tail kernels against the ten per-sub-block launches they replace (same FIR order per element;
+    the fused blocks sum each 1x1 conv's K in two halves, the per-sub-block launches in one run: scores agree to float32
+    round-off), including a clip shorter than one tile and a ragged last tile."""
     w = weights.marblenet_synthetic(7)
     eng = marblenet.MarbleNetEngine(w)
     assert eng.fused
@@ -117,5 +118,5 @@ def test_fused_blocks_equal_the_per_sub_block_launches():
         r0, r1, rlen = eng.run(clips)
         eng.fused = True
         assert slen == rlen and s1.shape == r1.shape
-        np.testing.assert_allclose(s1.cpu().numpy(), r1.cpu().numpy(), rtol=0, atol=2e-6)
-        np.testing.assert_allclose(s0.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(s1.cpu().numpy(), r1.cpu().numpy(), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(s0.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=5e-6)

@@ -210,6 +210,61 @@ struct Blk2 {
 };
 constexpr int W1 = 48, H_LD = 52;
 
+// GEMM of the fused block: 64 output channels = four row tiles for eight waves.  As whole-tile work items (layer<>) that was one
+// (row tile, column tile) chain per wave opened by an L2 round trip -- the three GEMMs took 61 % of the kernel for 1.5 us of MFMA
+// issue per tile.  Here wave = (row tile nt = wave & 3, K half kh = wave >> 2): every wave multiplies its half of K for ALL MT column
+// tiles, its weight fragments (KB/2 <= 4 of them) are requested a phase EARLY (kgemm_pre: before the depthwise filter in front of
+// the GEMM) and the two halves meet in the destination rows: the kh = 1 wave stores its partial tile, the kh = 0 wave adds its own
+// and the bias behind a barrier -- a fixed order, so the result is reproducible.
+struct KPre { f32x4 w[4]; };
+
+__device__ __forceinline__ KPre kgemm_pre(const float *__restrict__ W, int kdim) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    asm volatile("" : "+v"(lane), "+v"(wave));
+    const int nt = wave & 3, kh = wave >> 2, nb = kdim >> 5;      // 16-k blocks per half: 2 (K = 64) or 4 (K = 128)
+    const float *base = vadx::frag_ptr(W, kdim, nt, 16 * kh * nb, lane);
+    KPre p;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p.w[u] = vadx::ldg4(base + vadx::FRAG * (u < nb ? u : nb - 1));      // unconditional, clamped
+    return p;
+}
+
+template <int MT>
+__device__ __forceinline__ void kgemm(const KPre &p, int kdim, const float *act, int lda, int acol0, float *dst, int ldd,
+                                      const float *__restrict__ bias, bool relu) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    asm volatile("" : "+v"(lane), "+v"(wave));
+    const int q = lane >> 4, i = lane & 15, nt = wave & 3, kh = wave >> 2, nb = kdim >> 5;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *ap = act + (16 * kh * nb + 4 * q) * lda + acol0 + i;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (u < nb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = vadx::mfma16(ap[(16 * u + j) * lda + mt * 16], p.w[u][j], acc[mt]);
+        }
+    }
+    float *dp = dst + (nt * 16 + i) * ldd + 4 * q;
+    if (kh == 1)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4 *>(dp + mt * 16) = acc[mt];
+    __syncthreads();
+    if (kh == 0) {
+        const float b = bias[nt * 16 + i];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(dp + mt * 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = (v[r] + acc[mt][r]) + b; if (relu) v[r] = fmaxf(v[r], 0.f); }
+            *reinterpret_cast<f32x4 *>(dp + mt * 16) = v;
+        }
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     Blk2 c, const float *__restrict__ dw0, const float *__restrict__ pw0, const float *__restrict__ b0,
@@ -225,6 +280,7 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     const float *xb = x + (long long)b * c.cin * c.T;
     const int tin0 = t0 - 2 * PAD;
     MB_T0();
+    const KPre wres = kgemm_pre(rw, c.cinp);                 // in flight while the input tile is staged
     // ---- stage the block input (channel-first source: lane = time, wave = channel), unconditional clamped loads
     for (int ch0 = 0; ch0 < c.cinp; ch0 += 8 * (THREADS / 64)) {
         float v[8];
@@ -243,10 +299,9 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     MB_ACC(0);
     __syncthreads();
     MB_ACC(7);
-    {   // residual 1x1 of the block input (frames t0 .. t0 + 31 sit at column 2 PAD), before the input is overwritten
-        LayerArgs r{rw, c.cinp, c.c2 / 16, 1, c.cinp / 16, 0, 0, rb, 0, IN, IN_LD, 2 * PAD, ROUT, A_LD, 0, nullptr, nullptr};
-        layer<2, false>(r);
-    }
+    const KPre wpw0 = kgemm_pre(pw0, c.cinp);                // pointwise 0's weights: in flight through the residual GEMM and depthwise 0
+    // residual 1x1 of the block input (frames t0 .. t0 + 31 sit at column 2 PAD), before the input is overwritten
+    kgemm<2>(wres, c.cinp, IN, IN_LD, 2 * PAD, ROUT, A_LD, rb, false);
     MB_ACC(1);
     __syncthreads();                // every residual operand is read: depthwise 0 may overwrite IN
     MB_ACC(7);
@@ -279,10 +334,9 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     MB_ACC(2);
     __syncthreads();
     MB_ACC(7);
-    {   // pointwise 0 + folded BN + ReLU on 48 columns
-        LayerArgs a{pw0, c.cinp, c.c1 / 16, 1, c.cinp / 16, 0, 0, b0, 1, D0, IN_LD, 0, H1, H_LD, 0, nullptr, nullptr};
-        layer<3, false>(a);
-    }
+    const KPre wpw1 = kgemm_pre(pw1, c.c1);                  // pointwise 1's weights: in flight through pointwise 0 and depthwise 1
+    // pointwise 0 + folded BN + ReLU on 48 columns
+    kgemm<3>(wpw0, c.cinp, D0, IN_LD, 0, H1, H_LD, b0, true);
     MB_ACC(3);
     __syncthreads();
     MB_ACC(7);
@@ -312,10 +366,7 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     MB_ACC(4);
     __syncthreads();                // every H1 read is done: OUT may overwrite it
     MB_ACC(7);
-    {
-        LayerArgs a{pw1, c.c1, c.c2 / 16, 1, c.c1 / 16, 0, 0, b1, 0, D1, A_LD, 0, OUT, A_LD, 0, nullptr, nullptr};
-        layer<2, false>(a);
-    }
+    kgemm<2>(wpw1, c.c1, D1, A_LD, 0, OUT, A_LD, b1, false);
     MB_ACC(5);
     __syncthreads();
     MB_ACC(7);
