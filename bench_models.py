@@ -530,7 +530,7 @@ def marblenet_c4_sharded(torch, device, dist, rank, world, reps=3, clips=8192, l
     if feed:
         try:
             host = vfeed.pin(audio.cpu())
-            f = vfeed.HostPcmFeed(device, n, 256)      # tools/feed_sweep.py: 64 clips 40.9 ms, 128 31.3, 256 27.0, 512 27.3, 1024 28.4 (upload alone 25.5)
+            f = vfeed.HostPcmFeed(device, n, max(64, min(256, (hi - lo) // 8)))      # at least eight chunks per shard; tools/feed_sweep.py, 8192 clips: 64 clips 40.9 ms, 128 31.3, 256 27.0, 512 27.3, 1024 28.4 (upload alone 25.5)
             ref = eng.run(audio)
             got = eng.run_from_host(host, feed=f)
             same = bool(torch.equal(got[1], ref[1]))
