@@ -162,8 +162,10 @@ typedef struct vadx_frontend_cfg {
     float rs_scale;    /* prep 6 / 7: source samples per output sample, float32(1 / scale_factor) as torch computes it */
     int   fold;        /* 0: dense DFT product.  1 / 2: folded product of vadx_frontend_logmel (mirror-paired taps about the window
                           centre + f16 residual; same table bits, half the f32 MFMAs) -- the value vadx_frontend_fold_kind returned
-                          for this table; set it before vadx_frontend_packed_floats / _pack_host.  Ignored by _logmel_ex / _stft_ft
-                          callers' kernels (they take the dense tables, which every blob carries) */
+                          for this table; set it before vadx_frontend_packed_floats / _pack_host.  3: opt-in, periodic windows centred on
+                          n_fft/2 only (FSMN): time x frequency fold, a quarter of the dense MACs, noisier on bands far below the
+                          frame's peak (csrc/frontend.hip "kind 3"); _pack_host refuses it for a table that does not admit it.
+                          Ignored by _logmel_ex / _stft_ft callers' kernels (they take the dense tables, which every blob carries) */
 } vadx_frontend_cfg;
 
 /* Which fold (0 = none) the reference's windowed DFT table admits for this geometry: the table must equal, about the window

@@ -323,3 +323,85 @@ def test_folded_dft_tables_reproduce_the_reference_table(lib, preset, kind):
     scale = (np.abs(x) @ np.abs(R).T) ** 2
     assert np.abs(got - want).max() / scale.max() < 2e-7
     assert (np.abs(got - want) / scale).max() < 2e-7
+
+
+def test_kind3_fold_tables_reproduce_the_reference_table(lib):
+    """FSMN's periodic window admits the opt-in time x frequency fold (kind 3: four sums per bin b < 128 give bins b and 256 - b).  Same
+    table-level proof as above: the blob's E / O over the kernel's own slot plan plus the four f16 residual tables per row tile, in
+    double on random frames, give the power spectrum of the reference's float32 table for all 257 bins."""
+    from vadx import frontend, tables
+    p = frontend.PRESETS["fsmn"]
+    n_fft, win, hop = p["n_fft"], p["win"], p["hop"]
+    cos_t, sin_t = tables.windowed_dft(n_fft, tables.analysis_window(p["window"], win, n_fft, p["variant"]), p["variant"])
+    c, s = tables.as_np(cos_t), tables.as_np(sin_t)
+    cfg = _lib.FrontendCfg()
+    cfg.prep, cfg.k0, cfg.k1 = p["prep"], p["k"][0], p["k"][1]
+    cfg.center_pad, cfg.tap0, cfg.taps = n_fft // 2, (n_fft - win) // 2, win
+    cfg.hop, cfg.n_bins, cfg.n_mels, cfg.log_mode, cfg.log_floor = hop, n_fft // 2 + 1, 80, p["log_mode"], p["log_floor"]
+    cfg.frames, cfg.window_len = 101, 16000
+    assert lib.vadx_frontend_fold_kind(ctypes.byref(cfg), c.ctypes.data, s.ctypes.data, n_fft) == 2      # kind 3 is opt-in, never the default answer
+    dense_floats = lib.vadx_frontend_packed_floats(ctypes.byref(cfg))
+    cfg.fold = 3
+    n = lib.vadx_frontend_packed_floats(ctypes.byref(cfg))
+    blob, mel_kb = np.zeros(n, np.float32), np.zeros(10, np.int32)
+    fb = np.zeros((80, cfg.n_bins), np.float32)
+    assert lib.vadx_frontend_pack_host(ctypes.byref(cfg), c.ctypes.data, s.ctypes.data, n_fft, fb.ctypes.data, blob.ctypes.data,
+                                       mel_kb.ctypes.data) == 0
+    XLD, taps, nq, ntl, Kb32 = 68, cfg.taps, n_fft // 4, n_fft // 64 + 1, (cfg.taps + 31) // 32
+    # sizes: fold matrix ntl*32*Pb*16 floats, residual ntl*4*Kb32*256 floats, plan Pb*32 ints, bands 16 ints
+    Pb = (n - dense_floats - 16 - ntl * 4 * Kb32 * 256) // (ntl * 32 * 16 + 32)
+    assert dense_floats + ntl * 32 * Pb * 16 + ntl * 4 * Kb32 * 256 + Pb * 32 + 16 == n and Pb % 2 == 0
+    o_fold, o_res = dense_floats, dense_floats + ntl * 32 * Pb * 16
+    o_plan = o_res + ntl * 4 * Kb32 * 256
+    plan = blob[o_plan:o_plan + Pb * 32].view(np.int32).reshape(Pb, 4, 2, 4)          # [block][q][A|B][j]
+    def tap(off):
+        r, col = off // XLD, off % XLD
+        return np.where(r < hop, col * hop + r, -1)
+    ka = tap(plan[:, :, 0, :]).reshape(Pb * 16)                                         # contraction index 16 S + 4 q + j
+    kb = tap(plan[:, :, 1, :]).reshape(Pb * 16)
+    ldw = Pb * 16
+    r_i, k_i = np.meshgrid(np.arange(ntl * 32), np.arange(ldw), indexing="ij")
+    fm = blob[o_fold:o_res][(r_i // 16) * 16 * ldw + (k_i // 16) * 256 + (((k_i % 16) // 4) * 16 + r_i % 16) * 4 + k_i % 4].astype(np.float64)
+    res = blob[o_res:o_plan].view(np.float16).astype(np.float64).reshape(ntl, 4, Kb32, 4, 16, 8) / 8192.0
+    res = res.transpose(0, 1, 4, 2, 3, 5).reshape(ntl, 4, 16, Kb32 * 32)[..., :taps]  # [tile][accumulator][bin in tile][tap]
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((5, taps))
+    xz = np.concatenate([x, np.zeros((5, 1))], axis=1)
+    u, v = xz[:, ka] + xz[:, kb], xz[:, ka] - xz[:, kb]
+    even = np.arange(ldw) < ldw // 2
+    R, I = c[:, cfg.tap0:cfg.tap0 + taps].astype(np.float64), s[:, cfg.tap0:cfg.tap0 + taps].astype(np.float64)
+    want = (x @ R.T) ** 2 + (x @ I.T) ** 2
+    got = np.zeros_like(want)
+    for t in range(ntl - 1):
+        E, O = fm[t * 32:t * 32 + 16], fm[t * 32 + 16:t * 32 + 32]
+        A = (u * even) @ E.T + x @ res[t, 0].T
+        C = (v * even) @ O.T + x @ res[t, 1].T
+        B = (u * ~even) @ E.T + x @ res[t, 2].T
+        D = (v * ~even) @ O.T + x @ res[t, 3].T
+        bins = np.arange(16 * t, 16 * t + 16)
+        got[:, bins] = (A + B) ** 2 + (C + D) ** 2
+        got[:, 2 * nq - bins] = (A - B) ** 2 + (C - D) ** 2
+    t = ntl - 1
+    re = u @ fm[t * 32] + x @ res[t, 0, 0]
+    im = v @ fm[t * 32 + 17] + x @ res[t, 0, 1]
+    got[:, nq] = re ** 2 + im ** 2
+    scale = (np.abs(x) @ np.abs(R).T) ** 2
+    assert (np.abs(got - want) / scale).max() < 2e-7, (np.abs(got - want) / scale).max()
+
+
+def test_kind3_fold_is_refused_where_the_table_does_not_admit_it(lib):
+    from vadx import frontend, tables
+    p = frontend.PRESETS["marblenet"]                       # symmetric Hann: mirror pairs mix the parities
+    cos_t, sin_t = tables.windowed_dft(512, tables.analysis_window(p["window"], 400, 512, p["variant"]), p["variant"])
+    c, s = tables.as_np(cos_t), tables.as_np(sin_t)
+    cfg = _lib.FrontendCfg()
+    cfg.prep, cfg.k0, cfg.k1 = p["prep"], p["k"][0], p["k"][1]
+    cfg.center_pad, cfg.tap0, cfg.taps = 256, 56, 400
+    cfg.hop, cfg.n_bins, cfg.n_mels, cfg.log_mode, cfg.log_floor = 160, 257, 80, p["log_mode"], p["log_floor"]
+    cfg.frames, cfg.window_len, cfg.fold = 101, 16000, 3
+    n = lib.vadx_frontend_packed_floats(ctypes.byref(cfg))
+    assert n > 0                                            # the geometry has a plan; the TABLE is what fails
+    blob, mel_kb = np.zeros(n, np.float32), np.zeros(10, np.int32)
+    fb = np.zeros((80, 257), np.float32)
+    assert lib.vadx_frontend_pack_host(ctypes.byref(cfg), c.ctypes.data, s.ctypes.data, 512, fb.ctypes.data, blob.ctypes.data, mel_kb.ctypes.data) != 0
+    assert b"kind-3" in lib.vadx_last_error()

@@ -166,15 +166,18 @@ def exact_logmel(preset, windows_i16):
     return omel.log_mel(re, im, fb, 1e-7, "add").transpose(1, 2), scale
 
 
-@pytest.mark.parametrize("preset,L,kind", [("fsmn", 16000, 2), ("marblenet", 40000, 1), ("marblenet", 16000, 1), ("firered", 16000, 1),
-                                           ("fsmn", 5280, 2), ("firered", 2560, 1)])
+@pytest.mark.parametrize("preset,L,kind", [("fsmn", 16000, 3), ("fsmn", 16000, 2), ("marblenet", 40000, 1), ("marblenet", 16000, 1),
+                                           ("firered", 16000, 1), ("fsmn", 5280, 3), ("fsmn", 5280, 2), ("firered", 2560, 1), ("fsmn", 800, 3)])
 def test_folded_dft_is_the_dense_product(preset, L, kind):
     """Table-level proof of the folded DFT product (mirror-paired taps about the window centre + f16 residual, csrc/frontend.hip
     "Folded DFT"): the same clips through the dense f32 product and the folded one, both against the double-precision evaluation
     of the SAME float32 table.  In amplitude (sqrt of the mel energy) relative to the frame's strongest spectral line -- the scale
     float32 round-off of a length-400 product lives on -- the folded product is within 3e-7 of the exact one and of the dense one,
     and its mean log-mel error equals the dense product's (both are float32 accumulation orders of one sum).  On the log scale the
-    rare worst case sits on bands 60+ dB below the frame's peak, where either order keeps only a few digits."""
+    rare worst case sits on bands 60+ dB below the frame's peak, where either order keeps only a few digits.
+    kind 3 (opt-in time x frequency fold, FSMN only) is held to its own, documented bounds: a weak bin inherits round-off relative to
+    its STRONG mirror bin, so the bound relative to the frame's strongest line is twice the dense product's, bands within 26 dB of
+    the frame's peak are as exact as the dense product's, and the mean log-mel error stays within 2.5 x."""
     B = 6
     clips = weights.burst_clips(B, L, seed=L + kind)
     clips[0, : min(L, 3000)] = 0
@@ -183,8 +186,8 @@ def test_folded_dft_is_the_dense_product(preset, L, kind):
     clips[2] = rng.integers(-32768, 32767, size=L, dtype=np.int16)            # full-scale white noise
     clips[3] = (32000 * np.sin(2 * np.pi * 1000.37 / 16000 * np.arange(L))).astype(np.int16)      # one loud tone: 60 dB of leakage range
     fd = frontend.Frontend(preset, L, fold=False)
-    ff = frontend.Frontend(preset, L, fold=True)
-    assert fd.fold == 0 and ff.fold == kind
+    ff = frontend.Frontend(preset, L, fold=kind)
+    assert fd.fold == 0 and ff.fold == kind and frontend.Frontend(preset, L, fold=True).fold == (2 if preset == "fsmn" else kind)
     d = fd.logmel(clips).cpu().numpy().astype(np.float64)
     f = ff.logmel(clips).cpu().numpy().astype(np.float64)
     assert d.shape == f.shape and np.isfinite(f).all()
@@ -198,16 +201,20 @@ def test_folded_dft_is_the_dense_product(preset, L, kind):
         return np.exp(0.5 * z)
     floor = np.log({"fsmn": 1e-5, "marblenet": 1e-7, "firered": 1e-7}[preset]) + 2.0
     big = (ex > floor) & (ex > ex.max(axis=-1, keepdims=True) - 18.0)      # log scale: bands within 78 dB of the frame's strongest one
-    assert np.abs(f - d)[big].max() < 1e-3, np.abs(f - d)[big].max()
+    assert np.abs(f - d)[big].max() < (5e-3 if kind == 3 else 1e-3), np.abs(f - d)[big].max()
     if preset != "firered":
         # 3e-7 of the frame's strongest line, plus the float32 resolution of the stored log-mel itself (values up to 30: 2 ulp = 4e-6
         # on the log scale = 2e-6 relative on the amplitude)
         tol = 3e-7 * scale + 2e-6 * amp(ex)
-        assert (np.abs(amp(f) - amp(d)) <= tol).all(), (np.abs(amp(f) - amp(d)) / tol).max()
-        assert (np.abs(amp(f) - amp(ex)) <= tol).all(), (np.abs(amp(f) - amp(ex)) / tol).max()
+        tolf = (6e-7 if kind == 3 else 3e-7) * scale + 2e-6 * amp(ex)
+        assert (np.abs(amp(f) - amp(d)) <= tolf).all(), (np.abs(amp(f) - amp(d)) / tolf).max()
+        assert (np.abs(amp(f) - amp(ex)) <= tolf).all(), (np.abs(amp(f) - amp(ex)) / tolf).max()
         assert (np.abs(amp(d) - amp(ex)) <= tol).all()
         ed, ef = np.abs(d - ex)[big], np.abs(f - ex)[big]
-        assert ef.mean() <= max(1.25 * ed.mean(), 1e-7), (ef.mean(), ed.mean())
+        assert ef.mean() <= max((2.5 if kind == 3 else 1.25) * ed.mean(), 1e-7), (ef.mean(), ed.mean())
+        if kind == 3:
+            near = big & (ex > ex.max(axis=-1, keepdims=True) - 6.0)
+            assert np.abs(f - ex)[near].max() < 2e-5, np.abs(f - ex)[near].max()
         print("fold", preset, L, "worst err / tol: fold %.2f dense %.2f; log err mean fold %.2e dense %.2e, max fold %.2e dense %.2e" % (
             (np.abs(amp(f) - amp(ex)) / tol).max(), (np.abs(amp(d) - amp(ex)) / tol).max(), ef.mean(), ed.mean(), ef.max(), ed.max()))
 
@@ -216,3 +223,5 @@ def test_folded_frontend_is_the_default_and_can_be_turned_off(monkeypatch):
     assert frontend.Frontend("fsmn", 16000).fold == 2 and frontend.Frontend("marblenet", 16000).fold == 1
     monkeypatch.setenv("VADX_FRONTEND_FOLD", "0")
     assert frontend.Frontend("fsmn", 16000).fold == 0
+    monkeypatch.setenv("VADX_FRONTEND_FOLD", "3")           # opt-in kind 3: taken where the table admits it, the default kind elsewhere
+    assert frontend.Frontend("fsmn", 16000).fold == 3 and frontend.Frontend("marblenet", 16000).fold == 1

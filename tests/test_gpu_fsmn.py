@@ -238,3 +238,27 @@ def test_whole_clip_flags_with_asymmetric_thresholds(spk, sil):
         flags = eng.flags(torch.from_numpy(padded[None]), W, speaking_score=spk, silence_score=sil).cpu().numpy()[0].astype(bool)
         assert np.array_equal(flags, np.array(want_flags, bool))
         assert got[b] == want_ts
+
+
+def test_kind3_frontend_keeps_the_scores_and_decisions(monkeypatch):
+    """The opt-in time x frequency fold of the log-mel front-end (VADX_FRONTEND_FOLD=3; noisier on bands far below a frame's peak,
+    csrc/frontend.hip "kind 3") against the default front-end through the whole FSMN path: P(silence) within the 1e-4 score bar and
+    the same silence flags on every clip."""
+    from vadx import timestamps as ts
+    w = weights.fsmn_synthetic(11)
+    base = weights.burst_clips(6, 80000, seed=17)
+    eng = fsmn.FsmnEngine(w)
+    lb, stride = eng.grid()
+    noise = np.random.default_rng(3).standard_normal((6, 40000))
+    rows = np.stack([fsmn.pad_to_window_grid(ts.normalize_to_int16(base[b].astype(np.float32)), 16000, stride, noise[b]) for b in range(6)])
+    W = (rows.shape[1] - eng.L) // stride + 1
+    clips = torch.from_numpy(rows).cuda()
+    flags = eng.flags(clips, W).cpu().numpy()
+    lm, _ = eng.features(clips, W, stride)
+    monkeypatch.setenv("VADX_FRONTEND_FOLD", "3")
+    eng3 = fsmn.FsmnEngine(w)
+    assert eng3.fe.fold == 3 and eng.fe.fold == 2
+    flags3 = eng3.flags(clips, W).cpu().numpy()
+    lm3, _ = eng3.features(clips, W, stride)
+    assert np.array_equal(flags, flags3)
+    assert float((lm - lm3).abs().max()) < 5e-3

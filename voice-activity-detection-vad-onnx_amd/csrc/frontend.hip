@@ -18,6 +18,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include <type_traits>
@@ -192,6 +193,120 @@ static void fold_tables(const vadx_frontend_cfg *c, const FoldPlan &pl, const fl
     *res_max = best;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// kind 3 = kind 2 composed with the FREQUENCY fold (periodic windows centred on an integer c, n_fft % 64 == 0).  With m = n - c the
+// rotated rows of bins b and b' = n_fft/2 - b satisfy  R'[b'][m] = (-1)^m R'[b][m],  I'[b'][m] = -(-1)^m I'[b][m]  (cos / sin of
+// pi m - w_b m), and the mirror pairs (m, -m) of kind 2 keep the parity of m.  So per bin b < n_fft/4 the four sums
+//     Ce = sum_{m even} E u,  Co = sum_{m odd} E u,  Se = sum_{m even} O v,  So = sum_{m odd} O v
+// give BOTH bins:  |X_b|^2 = (Ce + Co)^2 + (Se + So)^2,  |X_b'|^2 = (Ce - Co)^2 + (Se - So)^2  -- a quarter of the dense MACs.
+// Bin n_fft/4 is its own mirror (its own K-split tile, as the last bin of kinds 1 / 2).  What the reference's float32 rows hold beyond
+// this model (both rows of a mirror pair against the E / O of row b) rides in f16 residual tables that feed the same four
+// accumulators: (RX_b + RX_b')/2 -> Ce, (RX_b - RX_b')/2 -> Co, (IX_b +- IX_b')/2 -> Se, So (sign of the b' row chosen by fit).
+// Pairs are addressed through a per-slot offset table (two LDS word offsets per pair; a row of zeros for lone taps and padding),
+// 16 slots = one block, slot tau of a block <-> MFMA contraction index (q, j) with tau = 2 q + (j & 1) + 8 (j >> 1): the four lane
+// quarters of a k-step then read X2 rows four apart (pairs of one parity class are two rows apart), i.e. 16 banks apart.
+// OPT-IN (cfg.fold = 3; vadx_frontend_fold_kind never answers 3): Ce and Co each grow to half of the STRONG bin of a mirror pair, so the
+// weak one, Ce - Co, inherits float32 round-off relative to its partner -- measured against the double evaluation of the same table,
+// bands within 26 dB of the frame's peak are as accurate as the dense product (<= 7e-6 on the log-mel), bands 50 - 70 dB down 2e-4 and
+// the few beyond 1e-3 (dense: 4e-5 / 1e-4); FSMN's scores and decisions still meet the 1e-4 / bit-exact bar.  34 % faster than kind 2.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Fold3Plan {
+    int Pc, Pb;                          // slots per parity class (multiple of 16), blocks in all (2 Pc / 16)
+    std::vector<int> ka, kb, sgn;        // per slot: tap of the first member / of its partner (-1: the zero row; ka = -1: padding), class parity
+};
+
+static int fold3_slot_tau(int kappa) { const int q = kappa >> 2, j = kappa & 3; return 2 * q + (j & 1) + 8 * (j >> 1); }
+
+static int fold3_plan(const vadx_frontend_cfg *c, int n_fft, Fold3Plan *pl) {
+    const int taps = c->taps, h = taps / 2;
+    if (taps % 2 || n_fft % 64 || c->n_bins != n_fft / 2 + 1 || c->tap0 + h != n_fft / 2) return -1;      // centre n_fft / 2: rotation = (-1)^b
+    std::vector<int> ea, eb, oa, ob;
+    for (int m = 1; m < h; ++m) { ((m & 1) ? oa : ea).push_back(h + m); ((m & 1) ? ob : eb).push_back(h - m); }
+    ea.push_back(h); eb.push_back(-1);                      // m = 0: alone (u = v = x)
+    ea.push_back(0); eb.push_back(-1);                      // m = -h (even: taps % 4 == 0 is implied by n_fft % 64 == 0 and the centre) alone
+    if (h & 1) return -1;
+    const size_t pc = ((std::max(ea.size(), oa.size()) + 15) / 16) * 16;
+    pl->Pc = (int)pc; pl->Pb = (int)(2 * pc / 16);
+    pl->ka.assign(2 * pc, -1); pl->kb.assign(2 * pc, -1); pl->sgn.assign(2 * pc, 0);
+    for (size_t t = 0; t < ea.size(); ++t) { pl->ka[t] = ea[t]; pl->kb[t] = eb[t]; }
+    for (size_t t = 0; t < oa.size(); ++t) { pl->ka[pc + t] = oa[t]; pl->kb[pc + t] = ob[t]; }
+    for (size_t t = 0; t < 2 * pc; ++t) pl->sgn[t] = t < pc ? 1 : -1;
+    return 0;
+}
+
+// kind-3 tables of the reference table: E / O [n_fft/4 + 1 bins][2 Pc slots] (f32), the four residual rows per bin b < n_fft/4 and the two of
+// bin n_fft/4 (double, [bin][4][taps]); returns the largest residual and the table scale
+static void fold3_tables(const vadx_frontend_cfg *c, const Fold3Plan &pl, const float *cos_tab, const float *sin_tab, int n_fft,
+                         std::vector<float> &E, std::vector<float> &O, std::vector<double> &RES, double *res_max, double *tab_max) {
+    const int taps = c->taps, h = taps / 2, nq = n_fft / 4, P = 2 * pl.Pc;
+    E.assign((size_t)(nq + 1) * P, 0.f); O.assign((size_t)(nq + 1) * P, 0.f); RES.assign((size_t)(nq + 1) * 4 * taps, 0.0);
+    std::vector<double> Rb(taps), Ib(taps), Rm(taps), Im(taps), mre(taps), mim(taps);
+    *res_max = 0.0; *tab_max = 0.0;
+    auto rot = [&](int b, std::vector<double> &R, std::vector<double> &I) {      // rotation about n_fft / 2 = the sign (-1)^b
+        const double sg = (b & 1) ? -1.0 : 1.0;
+        for (int t = 0; t < taps; ++t) {
+            R[t] = sg * cos_tab[(size_t)b * n_fft + c->tap0 + t]; I[t] = sg * sin_tab[(size_t)b * n_fft + c->tap0 + t];
+            *tab_max = fmax(*tab_max, fmax(fabs(R[t]), fabs(I[t])));
+        }
+    };
+    std::vector<double> eb(P), ob(P);
+    for (int b = 0; b <= nq; ++b) {
+        rot(b, Rb, Ib);
+        // even / odd parts of row b over the slots (double)
+        for (int p = 0; p < P; ++p) {
+            const int k = pl.ka[p], kp = pl.kb[p];
+            eb[p] = k < 0 ? 0.0 : (kp >= 0 ? 0.5 * (Rb[k] + Rb[kp]) : Rb[k]);
+            ob[p] = k < 0 ? 0.0 : (kp >= 0 ? 0.5 * (Ib[k] - Ib[kp]) : Ib[k]);
+        }
+        double tau = 1.0;
+        if (b < nq) {
+            // the mirror row carries the same parts up to the parity sign: R'[b'] ~ par E, I'[b'] ~ -par s O, and up to one global sign tau of
+            // its imaginary row (the power does not see it: the sign that fits is taken).  The shared model is the AVERAGE of the two rows'
+            // parts, so that each row's residual carries half of what the reference's rounding put between them (the residual's f16
+            // product is as noisy as the f32 one at 1.2e-4 of the table scale, and negligible at half that).
+            rot(n_fft / 2 - b, Rm, Im);
+            double fit = 0.0;
+            for (int p = 0; p < P; ++p) {
+                const int k = pl.ka[p], kp = pl.kb[p];
+                if (k < 0) continue;
+                const double om = kp >= 0 ? 0.5 * (Im[k] - Im[kp]) : Im[k];
+                fit += -pl.sgn[p] * om * ob[p];
+            }
+            tau = fit >= 0.0 ? 1.0 : -1.0;
+            for (int p = 0; p < P; ++p) {
+                const int k = pl.ka[p], kp = pl.kb[p];
+                if (k < 0) continue;
+                const double em = pl.sgn[p] * (kp >= 0 ? 0.5 * (Rm[k] + Rm[kp]) : Rm[k]);
+                const double om = -pl.sgn[p] * tau * (kp >= 0 ? 0.5 * (Im[k] - Im[kp]) : Im[k]);
+                eb[p] = 0.5 * (eb[p] + em); ob[p] = 0.5 * (ob[p] + om);
+            }
+        }
+        std::fill(mre.begin(), mre.end(), 0.0); std::fill(mim.begin(), mim.end(), 0.0);
+        for (int p = 0; p < P; ++p) {
+            const int k = pl.ka[p], kp = pl.kb[p];
+            if (k < 0) continue;
+            const float e = (float)eb[p], o = (float)ob[p];
+            if (kp >= 0) { mre[kp] = e; mim[kp] = -(double)o; }
+            mre[k] = e; mim[k] = o;
+            E[(size_t)b * P + p] = e; O[(size_t)b * P + p] = o;
+        }
+        double *res = RES.data() + (size_t)b * 4 * taps;
+        if (b == nq) {                                      // its own mirror: plain residual rows (re, im)
+            for (int t = 0; t < taps; ++t) { res[t] = Rb[t] - mre[t]; res[taps + t] = Ib[t] - mim[t]; }
+        } else {
+            for (int t = 0; t < taps; ++t) {
+                const double par = ((t - h) & 1) ? -1.0 : 1.0;
+                const double rb = Rb[t] - mre[t], ib = Ib[t] - mim[t];
+                const double rm = Rm[t] - par * mre[t], im = tau * Im[t] + par * mim[t];      // residual of tau * Im against -par * mim
+                // accumulators: A = Ce + .., B = Co + .. with A + B = re'_b, A - B = re'_b';  C = Se + .., D = So + .. with C + D = im'_b, C - D = -tau im'_b'
+                res[t] = 0.5 * (rb + rm); res[2 * taps + t] = 0.5 * (rb - rm);
+                res[taps + t] = 0.5 * (ib - im); res[3 * taps + t] = 0.5 * (ib + im);
+            }
+        }
+        for (int t = 0; t < (b == nq ? 2 : 4) * taps; ++t) *res_max = fmax(*res_max, fabs(res[t]));
+    }
+}
+
 // LDS of the folded kernel: X2 [hop + 16][XF_LD] f32 | XS [XF_LD][hop + 8] f16, both reused by the power rows [Fp][XF_LD]; then the
 // partial sums of the last-bin tile [8 waves][2][64]
 static size_t fold_pw_off_bytes(const Dev *d) {
@@ -235,20 +350,30 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     if (rem > 16) { d->tiles32 += 1; d->tiles16 = 0; }
     d->out_stride = c->n_mels; d->out_off = 0;
     if (c->fold) {
-        if (c->fold != 1 && c->fold != 2) return -1;
+        if (c->fold < 1 || c->fold > 3) return -1;
         if (!(c->prep <= 2 || c->prep >= 6) || d->nbt > 16) return -1;      // int16-derived samples; two power tiles per wave
         if (TF_FOLD + d->passes - 1 >= XF_LD || c->hop < 32) return -1;
-        FoldPlan pl;
-        if (fold_plan(c, c->fold, &pl)) return -1;
-        d->fold = c->fold; d->f_regions = pl.regions; d->f_Pb = 0;
-        for (int r = 0; r < pl.regions; ++r) {
-            d->f_blocks[r] = pl.blocks[r]; d->f_offA[r] = pl.offA[r]; d->f_offB[r] = pl.offB[r]; d->f_strB[r] = pl.strB[r];
-            d->f_Pb += pl.blocks[r];
-        }
+        d->fold = c->fold;
         d->f_Kb32 = (c->taps + 31) / 32;
         d->off_fold = d->off_mel + d->n_mels * d->Fp;
-        d->off_res = d->off_fold + (d->nbt + d->nyq) * 32 * d->f_Pb * 16;
-        d->off_plan = d->off_res + (d->nbt + d->nyq) * 2 * d->f_Kb32 * vadx::FRAG;
+        if (c->fold == 3) {
+            Fold3Plan p3;
+            if (fold3_plan(c, 2 * (c->n_bins - 1), &p3)) return -1;
+            d->f_Pb = p3.Pb;
+            const int ntl3 = (c->n_bins - 1) / 32 + 1;                                  // tiles of bins 0 .. n_fft/4 - 1, then bin n_fft/4's own
+            d->off_res = d->off_fold + ntl3 * 32 * d->f_Pb * 16;
+            d->off_plan = d->off_res + ntl3 * 4 * d->f_Kb32 * vadx::FRAG;
+        } else {
+            FoldPlan pl;
+            if (fold_plan(c, c->fold, &pl)) return -1;
+            d->f_regions = pl.regions; d->f_Pb = 0;
+            for (int r = 0; r < pl.regions; ++r) {
+                d->f_blocks[r] = pl.blocks[r]; d->f_offA[r] = pl.offA[r]; d->f_offB[r] = pl.offB[r]; d->f_strB[r] = pl.strB[r];
+                d->f_Pb += pl.blocks[r];
+            }
+            d->off_res = d->off_fold + (d->nbt + d->nyq) * 32 * d->f_Pb * 16;
+            d->off_plan = d->off_res + (d->nbt + d->nyq) * 2 * d->f_Kb32 * vadx::FRAG;
+        }
         // bound of |sample| after prep: the f16 copies carry x * 2^e with |x + x'| 2^e <= 32768
         float M = 65536.f * 1.97f;                                                          // prep 0
         if (c->prep == 1 || c->prep >= 6) M = 32768.f * (fabsf(c->k0) + fabsf(c->k1));
@@ -266,6 +391,7 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
 }
 
 static size_t packed_total(const Dev &d) {
+    if (d.fold == 3) return (size_t)d.off_plan + (size_t)d.f_Pb * 32 + 2 * MAX_MEL_TILES;      // [block][quarter][offA x 4 | offB x 4], then the mel bands
     if (d.fold) return (size_t)d.off_plan + 4 * MAX_REGIONS + 2 * MAX_MEL_TILES;
     return (size_t)d.off_mel + (size_t)d.n_mels * d.Fp;
 }
@@ -412,7 +538,7 @@ __device__ __forceinline__ void stage_tile(const Dev &d, const int16_t *__restri
 // each lane stores 4 consecutive mels
 // (bands: the folded kernel reads [mel tile][lo, hi] from the blob -- with its four tile variants inlined, the dynamic index into the
 // by-value Dev arrays made the compiler keep a 384-byte copy of Dev in scratch)
-template <int MT>
+template <int MT, bool BANDS = false>
 __device__ __forceinline__ void mel_phase(const Dev &d, const float *__restrict__ P, const float *PW, int p_ld, int f0,
                                           float *__restrict__ out_win, const int *__restrict__ bands = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
@@ -420,7 +546,7 @@ __device__ __forceinline__ void mel_phase(const Dev &d, const float *__restrict_
         f32x4 acc[1][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int lo = bands ? bands[2 * mtile] : d.mel_kb_lo[mtile], hi = bands ? bands[2 * mtile + 1] : d.mel_kb_hi[mtile];
+        const int lo = BANDS ? bands[2 * mtile] : d.mel_kb_lo[mtile], hi = BANDS ? bands[2 * mtile + 1] : d.mel_kb_hi[mtile];
         const float *const wrow[1] = {vadx::frag_ptr(P + d.off_mel, d.Fp, mtile, lo * 16, lane)};
         int moff[MT];
 #pragma unroll
@@ -715,7 +841,7 @@ __device__ __forceinline__ void fold_tile(const Dev &d, const float *__restrict_
     }
     __syncthreads();
     FE_ACC(2);
-    mel_phase<MT>(d, P, PW, XF_LD, f0, out_win, plan + 4 * MAX_REGIONS);
+    mel_phase<MT, true>(d, P, PW, XF_LD, f0, out_win, plan + 4 * MAX_REGIONS);
     FE_ACC(3);
 }
 
@@ -734,6 +860,185 @@ __global__ __launch_bounds__(THREADS, 4) void frontend_fold_kernel(
     else if (d.tail_mt == 3) fold_tile<3>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
     else if (d.tail_mt == 2) fold_tile<2>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
     else fold_tile<1>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
+}
+
+// One tile of MT*16 frames of the kind-3 kernel (time x frequency fold, see "kind 3" above): wave w owns bins 16 w .. 16 w + 15 AND
+// their mirrors n_fft/2 - b through four accumulator sets (Ce, Se, Co, So); bin n_fft/4 is K-split over the waves like the last bin
+// of kinds 1 / 2.  Eight row tiles on eight waves: no second round.
+template <int MT>
+__device__ __forceinline__ void fold3_tile(const Dev &d, const float *__restrict__ P, const int16_t *__restrict__ win, float mean,
+                                           int f0, float *__restrict__ out_win, float *lds, float *NQ) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, i = lane & 15;
+    constexpr int NF = MT * 16;
+    const int cols = NF + d.passes - 1, xs_pitch = d.hop + 8;
+    float *X2 = lds, *PW = lds;
+    _Float16 *XS = reinterpret_cast<_Float16 *>(lds + (d.hop + 16) * XF_LD);
+    const int nq = (d.n_bins - 1) >> 1, nt3 = nq >> 4;            // bin n_fft/4; row tiles below it (8 for 257 bins)
+    const int Kp = d.f_Pb * 16, pbc = d.f_Pb >> 1;                // pair slots; blocks per parity class
+    const int *__restrict__ plan = reinterpret_cast<const int *>(P + d.off_plan);
+
+    FE_T0();
+    for (int e = tid; e < 16 * XF_LD; e += THREADS) X2[d.hop * XF_LD + e] = 0.f;                      // the zero rows (lone taps, padding pairs)
+    for (int e = tid; e < xs_pitch; e += THREADS) XS[cols * xs_pitch + e] = (_Float16)0.f;            // column read by the residual's padded taps
+    stage_tile<XF_LD, true>(d, win, nullptr, mean, f0, cols, X2, XS, xs_pitch, d.f_xscale);
+    FE_ACC(4);
+    __syncthreads();
+    FE_ACC(0);
+
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) i32x4 *global_i32x4_ptr;
+    // 16 pair slots (4 k-steps) of one parity class: u -> `are`, v -> `aim`; the slots' X2 offsets come from the blob
+    auto block3 = [&](const f32x4 &e4, const f32x4 &o4, const i32x4 &oa, const i32x4 &ob, f32x4 (&are)[MT], f32x4 (&aim)[MT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float *pa = X2 + oa[j] + i, *pb = X2 + ob[j] + i;
+            float u[MT], v[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float xa = pa[mt * 16], xb = pb[mt * 16];
+                u[mt] = __fadd_rn(xa, xb); v[mt] = __fsub_rn(xa, xb);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                are[mt] = vadx::mfma16(u[mt], e4[j], are[mt]);
+                aim[mt] = vadx::mfma16(v[mt], o4[j], aim[mt]);
+            }
+        }
+    };
+    const int *po = plan + q * 8;                                  // this lane quarter's offsets of block S: po + 32 S
+    {   // bin n_fft/4 (its own mirror): blocks dealt round-robin to the waves; u tile row 0 = E, v tile row 1 = O -> one accumulator holds (re', im')
+        f32x4 na[MT], nr[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { na[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; nr[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const f16x8 *rf = reinterpret_cast<const f16x8 *>(P + d.off_res + (size_t)(nt3 * 4) * d.f_Kb32 * vadx::FRAG) + lane;
+        for (int S = wave; S < d.f_Kb32; S += THREADS / 64) {
+            const f16x8 w = *(global_f16x8_ptr)(rf + S * 64);
+            const int k = 32 * S + 8 * q, a = k / d.hop, r = k - a * d.hop;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                nr[mt] = mfma16h(*reinterpret_cast<const f16x8 *>(XS + (mt * 16 + i + a) * xs_pitch + r), w, nr[mt]);
+        }
+        const float *fe = vadx::frag_ptr(P + d.off_fold, Kp, nt3 * 2, 0, lane), *fo = vadx::frag_ptr(P + d.off_fold, Kp, nt3 * 2 + 1, 0, lane);
+        for (int S = wave; S < d.f_Pb; S += THREADS / 64) {
+            const i32x4 oa = *(global_i32x4_ptr)(po + 32 * S), ob = *(global_i32x4_ptr)(po + 32 * S + 4);
+            block3(vadx::ldg4(fe + vadx::FRAG * S), vadx::ldg4(fo + vadx::FRAG * S), oa, ob, na, na);
+        }
+        if (i < 2)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = __fmaf_rn(nr[mt][r], d.f_rinv, na[mt][r]);
+                *reinterpret_cast<f32x4 *>(NQ + (wave * 2 + i) * 64 + mt * 16 + 4 * q) = t;
+            }
+    }
+    f32x4 pw[2][MT];                                              // power of bins b (slot 0) and n_fft/2 - b (slot 1)
+    if (wave < nt3) {
+        const int bt = wave;
+        f32x4 acc[4][MT];                                         // Ce, Se, Co, So
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {   // residual (f16): four tables against the f16 samples of the frame, one per accumulator set
+            const f16x8 *rb = reinterpret_cast<const f16x8 *>(P + d.off_res + (size_t)(bt * 4) * d.f_Kb32 * vadx::FRAG) + lane;
+            const int rs = d.f_Kb32 * 64;
+            f16x8 w0 = *(global_f16x8_ptr)(rb), w1 = *(global_f16x8_ptr)(rb + rs), w2 = *(global_f16x8_ptr)(rb + 2 * rs), w3 = *(global_f16x8_ptr)(rb + 3 * rs);
+            int a = 0, r = 8 * q;
+            while (r >= d.hop) { r -= d.hop; ++a; }
+            for (int S = 0; S < d.f_Kb32; ++S) {
+                const int Sn = S + 1 < d.f_Kb32 ? S + 1 : S;
+                const f16x8 n0 = *(global_f16x8_ptr)(rb + Sn * 64), n1 = *(global_f16x8_ptr)(rb + rs + Sn * 64);
+                const f16x8 n2 = *(global_f16x8_ptr)(rb + 2 * rs + Sn * 64), n3 = *(global_f16x8_ptr)(rb + 3 * rs + Sn * 64);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f16x8 xb = *reinterpret_cast<const f16x8 *>(XS + (mt * 16 + i + a) * xs_pitch + r);
+                    acc[0][mt] = mfma16h(xb, w0, acc[0][mt]);
+                    acc[1][mt] = mfma16h(xb, w1, acc[1][mt]);
+                    acc[2][mt] = mfma16h(xb, w2, acc[2][mt]);
+                    acc[3][mt] = mfma16h(xb, w3, acc[3][mt]);
+                }
+                w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+                r += 32;
+                while (r >= d.hop) { r -= d.hop; ++a; }
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < 4; ++a2)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[a2][mt] *= d.f_rinv;
+        }
+        // symmetric part (f32): table fragments and slot offsets one block ahead; even-class blocks feed (Ce, Se), odd-class blocks (Co, So)
+        const float *fe = vadx::frag_ptr(P + d.off_fold, Kp, bt * 2, 0, lane), *fo = vadx::frag_ptr(P + d.off_fold, Kp, bt * 2 + 1, 0, lane);
+        f32x4 ec = vadx::ldg4(fe), oc = vadx::ldg4(fo);
+        i32x4 ac = *(global_i32x4_ptr)(po), bc = *(global_i32x4_ptr)(po + 4);
+        for (int S = 0; S < pbc; ++S) {
+            const f32x4 en = vadx::ldg4(fe + vadx::FRAG * (S + 1)), on = vadx::ldg4(fo + vadx::FRAG * (S + 1));      // (block pbc exists: the odd class)
+            const i32x4 an = *(global_i32x4_ptr)(po + 32 * (S + 1)), bn = *(global_i32x4_ptr)(po + 32 * (S + 1) + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            block3(ec, oc, ac, bc, acc[0], acc[1]);
+            ec = en; oc = on; ac = an; bc = bn;
+        }
+        for (int S = pbc; S < d.f_Pb; ++S) {
+            const int Sn = S + 1 < d.f_Pb ? S + 1 : S;
+            const f32x4 en = vadx::ldg4(fe + vadx::FRAG * Sn), on = vadx::ldg4(fo + vadx::FRAG * Sn);
+            const i32x4 an = *(global_i32x4_ptr)(po + 32 * Sn), bn = *(global_i32x4_ptr)(po + 32 * Sn + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            block3(ec, oc, ac, bc, acc[2], acc[3]);
+            ec = en; oc = on; ac = an; bc = bn;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float re = __fadd_rn(acc[0][mt][r], acc[2][mt][r]), im = __fadd_rn(acc[1][mt][r], acc[3][mt][r]);
+                const float rm = __fsub_rn(acc[0][mt][r], acc[2][mt][r]), imm = __fsub_rn(acc[1][mt][r], acc[3][mt][r]);
+                pw[0][mt][r] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+                pw[1][mt][r] = __fadd_rn(__fmul_rn(rm, rm), __fmul_rn(imm, imm));
+            }
+    }
+    FE_ACC(1);
+    __syncthreads();                     // every wave is done with X2 / XS: the power rows take their place
+    if (wave < nt3) {
+        const int b = wave * 16 + i;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            *reinterpret_cast<f32x4 *>(&PW[b * XF_LD + mt * 16 + 4 * q]) = pw[0][mt];
+            *reinterpret_cast<f32x4 *>(&PW[(2 * nq - b) * XF_LD + mt * 16 + 4 * q]) = pw[1][mt];
+        }
+    }
+    if (tid < NF) {
+        float re = 0.f, im = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < THREADS / 64; ++w8) { re += NQ[(w8 * 2) * 64 + tid]; im += NQ[(w8 * 2 + 1) * 64 + tid]; }
+        PW[nq * XF_LD + tid] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    }
+    for (int e = tid; e < (d.Fp - d.n_bins) * NF; e += THREADS) {      // padded power rows: 0 x 0 in the mel GEMM
+        const int r = e / NF, c2 = e - r * NF;
+        PW[(d.n_bins + r) * XF_LD + c2] = 0.f;
+    }
+    __syncthreads();
+    FE_ACC(2);
+    mel_phase<MT, true>(d, P, PW, XF_LD, f0, out_win, plan + d.f_Pb * 32);
+    FE_ACC(3);
+}
+
+__global__ __launch_bounds__(THREADS, 4) void frontend_fold3_kernel(
+    Dev d, const float *__restrict__ P, const int16_t *__restrict__ audio, long long row_stride,
+    long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ out, int nq_off) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles = d.tiles64 + (d.tail_mt ? 1 : 0);
+    const int widx = blockIdx.x / tiles, tile = blockIdx.x - widx * tiles;
+    const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
+    const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
+    float *out_win = out + (size_t)widx * d.frames * d.out_stride;
+    const float mean = means ? means[widx] : 0.f;
+    float *NQ = lds + nq_off;
+    if (tile < d.tiles64) fold3_tile<4>(d, P, win, mean, tile * TF_FOLD, out_win, lds, NQ);
+    else if (d.tail_mt == 3) fold3_tile<3>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
+    else if (d.tail_mt == 2) fold3_tile<2>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
+    else fold3_tile<1>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
 }
 
 __global__ __launch_bounds__(THREADS, 4) void frontend_logmel_kernel(
@@ -851,7 +1156,52 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
     vadx::frag_major_inplace(packed_host + d.off_dft, d.nbt * 32, d.Kp);
     if (d.nyq) vadx::frag_major_inplace(packed_host + d.off_nyq, 16, d.Kp);
     vadx::frag_major_inplace(packed_host + d.off_mel, d.n_mels, d.Fp);
-    if (d.fold) {
+    if (d.fold == 3) {
+        Fold3Plan p3;
+        VADX_REQUIRE(fold3_plan(cfg, n_fft, &p3) == 0, "vadx_frontend_pack_host: no kind-3 fold plan for this geometry");
+        std::vector<float> E, O;
+        std::vector<double> RES;
+        double res_max = 0.0, tab_max = 0.0;
+        fold3_tables(cfg, p3, cos_tab, sin_tab, n_fft, E, O, RES, &res_max, &tab_max);
+        VADX_REQUIRE(res_max <= FOLD_MAX_RATIO * tab_max && res_max * RES_SCALE < 30000.0,
+                     "vadx_frontend_pack_host: table is too far from the kind-3 model (residual %.3g of %.3g): ask vadx_frontend_fold_kind", res_max, tab_max);
+        const int P = 2 * p3.Pc, nq = n_fft / 4, nt3 = nq / 16, ntl3 = nt3 + 1;
+        // columns in MFMA contraction order: column 16 S + kappa of a row = slot 16 S + tau(kappa)
+        auto put_cols = [&](float *dst, const float *src) { for (int cidx = 0; cidx < P; ++cidx) dst[cidx] = src[(cidx & ~15) + fold3_slot_tau(cidx & 15)]; };
+        float *fm = packed_host + d.off_fold;                      // [ntl3][E rows 0..15 | O rows 16..31][P]
+        for (int t = 0; t < nt3; ++t)
+            for (int i = 0; i < 16; ++i) {
+                put_cols(fm + (size_t)(t * 32 + i) * P, E.data() + (size_t)(t * 16 + i) * P);
+                put_cols(fm + (size_t)(t * 32 + 16 + i) * P, O.data() + (size_t)(t * 16 + i) * P);
+            }
+        put_cols(fm + (size_t)(nt3 * 32) * P, E.data() + (size_t)nq * P);                 // bin n_fft/4: u tile row 0 = E, v tile row 1 = O
+        put_cols(fm + (size_t)(nt3 * 32 + 17) * P, O.data() + (size_t)nq * P);
+        vadx::frag_major_inplace(fm, ntl3 * 32, P);
+        _Float16 *rh = reinterpret_cast<_Float16 *>(packed_host + d.off_res);           // [ntl3][4 accumulators][Kb32][64 lanes][8]
+        for (int t = 0; t < ntl3; ++t)
+            for (int a = 0; a < 4; ++a)
+                for (int S = 0; S < d.f_Kb32; ++S)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int i = lane & 15, k = 32 * S + 8 * (lane >> 4) + e;
+                            double v = 0.0;
+                            if (k < d.taps) {
+                                if (t < nt3) v = RES[((size_t)(t * 16 + i) * 4 + a) * d.taps + k];
+                                else if (a == 0 && i < 2) v = RES[((size_t)nq * 4 + i) * d.taps + k];      // rows 0, 1 = (re, im) residual of bin n_fft/4
+                            }
+                            rh[((((size_t)t * 4 + a) * d.f_Kb32 + S) * 64 + lane) * 8 + e] = (_Float16)(float)(v * RES_SCALE);
+                        }
+        int32_t *pi = reinterpret_cast<int32_t *>(packed_host + d.off_plan);          // [block][quarter q][offA j0..3 | offB j0..3]: LDS word offsets in X2
+        auto off = [&](int k) { return k < 0 ? d.hop * XF_LD : (k % d.hop) * XF_LD + k / d.hop; };
+        for (int S = 0; S < p3.Pb; ++S)
+            for (int q = 0; q < 4; ++q)
+                for (int j = 0; j < 4; ++j) {
+                    const int slot = 16 * S + fold3_slot_tau(4 * q + j);
+                    pi[(S * 4 + q) * 8 + j] = off(p3.ka[slot]);
+                    pi[(S * 4 + q) * 8 + 4 + j] = off(p3.kb[slot]);
+                }
+        for (int mt = 0; mt < d.nmt; ++mt) { pi[p3.Pb * 32 + 2 * mt] = mel_kb[2 * mt]; pi[p3.Pb * 32 + 2 * mt + 1] = mel_kb[2 * mt + 1]; }
+    } else if (d.fold) {
         FoldPlan pl;
         VADX_REQUIRE(fold_plan(cfg, cfg->fold, &pl) == 0, "vadx_frontend_pack_host: no fold plan for this geometry");
         std::vector<float> E, O;
@@ -898,7 +1248,7 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
     return VADX_OK;
 }
 
-// Which fold the reference table admits: 1 / 2 (see "Folded DFT") or 0 -- the geometry has no plan, or the table is further from
+// Which fold the reference table admits by default: 1 / 2 (see "Folded DFT") or 0 -- the geometry has no plan, or the table is further from
 // the symmetric model than the f16 residual may carry (FOLD_MAX_RATIO of the table scale).  The caller stores the answer in cfg.fold
 // BEFORE vadx_frontend_packed_floats / vadx_frontend_pack_host / the launches.
 extern "C" int vadx_frontend_fold_kind(const vadx_frontend_cfg *cfg, const float *cos_tab, const float *sin_tab, int n_fft) {
@@ -949,6 +1299,13 @@ extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *p
         const size_t flds = fold_lds_bytes(&d);
         const long long nblk = nwin * (d.tiles64 + (d.tail_mt ? 1 : 0));
         VADX_REQUIRE(nblk < (1LL << 31), "vadx_frontend_logmel: too many tiles");
+        if (d.fold == 3) {
+            VADX_DYN_LDS(frontend_fold3_kernel, 80 * 1024);
+            hipLaunchKernelGGL(frontend_fold3_kernel, dim3((unsigned)nblk), dim3(THREADS), flds, st, d, packed, audio, (long long)row_stride,
+                               (long long)win_stride, windows_per_clip, means, out, (int)(fold_pw_off_bytes(&d) / 4));
+            VADX_HIP_TRY(hipGetLastError());
+            return VADX_OK;
+        }
         VADX_DYN_LDS(frontend_fold_kernel, 80 * 1024);
         hipLaunchKernelGGL(frontend_fold_kernel, dim3((unsigned)nblk), dim3(THREADS), flds, st, d, packed, audio, (long long)row_stride,
                            (long long)win_stride, windows_per_clip, means, out, (int)(fold_pw_off_bytes(&d) / 4));

@@ -42,7 +42,8 @@ class Frontend:
     def __init__(self, preset, window_len, device="cuda:0", n_mels=80, sample_rate=16000, in_sample_rate=16000, fold=None):
         """fold: None = take the folded DFT product wherever the reference table admits it (`vadx_frontend_fold_kind`; the
         environment variable VADX_FRONTEND_FOLD=0 turns it off process-wide), False = dense product (the table-level parity tests
-        compare the two), True = require it.
+        compare the two), True = require it, 1 / 2 / 3 = that kind (pack_host refuses a kind the table does not admit).
+        VADX_FRONTEND_FOLD=3 opts into kind 3 (time x frequency fold: faster, noisier on weak bands) wherever a table admits it.
         window_len = samples per window IN THE AUDIO BUFFER.  in_sample_rate != 16000 reproduces the exports built with
         IN_SAMPLE_RATE set (Export_NVIDIA_MarbleNet_VAD.py:237-254, FireRedVAD/Export_FireRedVAD.py:431-449): the graph itself
         resamples each window to 16 kHz with F.interpolate(linear, align_corners=False), before the pre-emphasis when the
@@ -87,9 +88,22 @@ class Frontend:
         L = _lib.lib()
         cos_n, sin_n, fb_n = tables.as_np(cos_t), tables.as_np(sin_t), tables.as_np(fb)
         required = fold is True
+        kind = int(fold) if (not isinstance(fold, bool) and isinstance(fold, int) and fold > 0) else None      # a specific kind
+        env = os.environ.get("VADX_FRONTEND_FOLD", "1")
+        from_env = False
         if fold is None:
-            fold = os.environ.get("VADX_FRONTEND_FOLD", "1") != "0" and p["mel"][0] != "zeros"
-        cfg.fold = int(L.vadx_frontend_fold_kind(C.byref(cfg), cos_n.ctypes.data, sin_n.ctypes.data, n_fft)) if fold else 0
+            fold = env != "0" and p["mel"][0] != "zeros"
+            if fold and env == "3":
+                kind, from_env = 3, True                      # opt-in: the time x frequency fold wherever the table admits it
+        auto = lambda: int(L.vadx_frontend_fold_kind(C.byref(cfg), cos_n.ctypes.data, sin_n.ctypes.data, n_fft))      # noqa: E731
+        cfg.fold = kind if kind else (auto() if fold else 0)
+        if from_env:
+            # requested through the environment: fall back to the default kind where kind 3 does not apply (symmetric windows, other geometries)
+            probe = np.zeros(max(1, L.vadx_frontend_packed_floats(C.byref(cfg))), dtype=np.float32)
+            kb = np.zeros(2 * (n_mels // 16), dtype=np.int32)
+            if probe.size <= 1 or L.vadx_frontend_pack_host(C.byref(cfg), cos_n.ctypes.data, sin_n.ctypes.data, n_fft, fb_n.ctypes.data,
+                                                            probe.ctypes.data, kb.ctypes.data) != 0:
+                cfg.fold = auto()
         if required and not cfg.fold:
             raise ValueError("this table / geometry has no folded DFT product")
         self.fold = cfg.fold
