@@ -225,3 +225,37 @@ def test_folded_frontend_is_the_default_and_can_be_turned_off(monkeypatch):
     assert frontend.Frontend("fsmn", 16000).fold == 0
     monkeypatch.setenv("VADX_FRONTEND_FOLD", "3")           # opt-in kind 3: taken where the table admits it, the default kind elsewhere
     assert frontend.Frontend("fsmn", 16000).fold == 3 and frontend.Frontend("marblenet", 16000).fold == 1
+
+
+@pytest.mark.parametrize("n_fft,win,hop,window,variant,center", [
+    (512, 320, 160, "hann_sym", "v2", True),       # two full passes
+    (512, 512, 128, "hann_sym", "v2", True),       # four passes, window = n_fft
+    (256, 200, 80, "hamming", "v1", True),         # periodic window, small transform (129 bins: last-bin tile), hop 80
+    (512, 400, 192, "hamming", "v1", True),        # hop 192: three passes of 192 + 16
+    (400, 400, 96, "povey", "v2", False),          # snip-edges, 201 bins, hop 96: five passes -> no fold plan, dense kernel
+    (1024, 640, 160, "hann_sym", "v2", True),      # 513 bins: more row tiles than the folded kernel takes -> dense kernel
+])
+def test_folded_product_on_other_geometries(n_fft, win, hop, window, variant, center):
+    """The C ABI takes any geometry: wherever vadx_frontend_fold_kind admits a fold the folded kernel must agree with the dense one
+    (same table bits), and where it does not (too many passes / bins) the dense kernel runs."""
+    preset = dict(n_fft=n_fft, win=win, hop=hop, window=window, variant=variant, center=center, prep=1,
+                  k=(-0.97 / 32768.0, 1.0 / 32768.0), mel=("torchaudio", 0, 8000, "slaney", "slaney"), log_mode=1, log_floor=1e-7)
+    L = 20000
+    clips = weights.burst_clips(4, L, seed=n_fft + hop)
+    clips[0, :2000] = 0
+    try:
+        fd = frontend.Frontend(preset, L, fold=False)
+    except ValueError:
+        pytest.skip("geometry outside the front-end kernel altogether")
+    ff = frontend.Frontend(preset, L)
+    d = fd.logmel(clips).cpu().numpy().astype(np.float64)
+    f = ff.logmel(clips).cpu().numpy().astype(np.float64)
+    assert np.isfinite(f).all() and d.shape == f.shape
+    if n_fft == 1024 or hop == 96:
+        assert ff.fold == 0
+    elif window == "hann_sym":
+        assert ff.fold == 1, ff.fold
+    print("geometry", n_fft, win, hop, window, "-> fold", ff.fold)       # (a pair region whose padding would leave X2 has no plan: dense kernel)
+    big = d > d.max(axis=-1, keepdims=True) - 18.0
+    assert np.abs(f - d)[big].max() < 1e-3, np.abs(f - d)[big].max()
+    assert np.abs(f - d)[big].mean() < 5e-6, np.abs(f - d)[big].mean()
