@@ -13,6 +13,10 @@
 //   * power spectrum goes to LDS k-major [bin][frame]; mel = second MFMA GEMM that only visits the
 //     16-bin blocks each 16-mel tile actually touches (triangular filters are banded); log epilogue,
 //     time-major output [window][frame][mel] (mel contiguous: LFR rows are contiguous slices).
+// Three kernels share the staging and the mel + log phase: the dense product above (frontend_logmel_kernel: DFSMN's feature streams,
+// the raw STFT, any geometry without a fold plan), and two FOLDED products of the log-mel path on 64-frame tiles
+// (frontend_fold_kernel: mirror-paired taps + f16 residual, kinds 1 / 2, the default of the FSMN / MarbleNet / FireRed front-ends;
+// frontend_fold3_kernel: time x frequency fold, opt-in) -- see "Folded DFT" below.
 #include "common.h"
 
 #include <math.h>
