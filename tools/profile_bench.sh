@@ -37,8 +37,8 @@ for f in glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if "vadx" not in row["Kernel_Name"]: continue
         acc[(short(row["Kernel_Name"]), int(row["Grid_Size_X"]))].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-    p("# per (kernel, grid) dispatch durations from the kernel trace [ns]: n, mean, min, max")
-    for (k, g), v in sorted(acc.items()): p(f"{k:46s} grid={g:10d} n={len(v):3d} mean={sum(v)/len(v):14.1f} min={min(v):12d} max={max(v):12d}")
+    p("# per (kernel, grid) dispatch durations from the kernel trace [ns]: n, mean, median, min, max")
+    for (k, g), v in sorted(acc.items()): p(f"{k:46s} grid={g:10d} n={len(v):3d} mean={sum(v)/len(v):14.1f} median={sorted(v)[len(v)//2]:12d} min={min(v):12d} max={max(v):12d}")
 for name in ("fetch", "write", "sq", "sq2"):
     for f in glob.glob(out + f"/{name}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
