@@ -1,6 +1,6 @@
 """Edge-case probe (development aid): tiny / boundary inputs through every engine vs the oracle."""
 import sys, os, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import vadx
 from vadx import silero, firered, fsmn, marblenet, weights

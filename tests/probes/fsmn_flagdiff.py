@@ -1,7 +1,7 @@
 """FSMN silence flags of the three front-end products (dense, kind 2 = default, kind 3 = opt-in) against the CPU oracle on the first N
-clips of bench config 3 (development aid; the oracle takes ~30 s per 1024 clips on 8 threads).   python tools/fsmn_flagdiff.py"""
+clips of bench config 3 (development aid; the oracle takes ~30 s per 1024 clips on 8 threads).   python tests/probes/fsmn_flagdiff.py"""
 import os, sys, time, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import vadx
 from vadx import fsmn, weights
 from oracle import fsmn as ofs
