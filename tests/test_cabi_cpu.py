@@ -209,7 +209,7 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
 
 
 def test_product_never_imports_the_oracle():
-    """oracle/ is test infrastructure: the product package and the shim must not import it; bench.py / bench_models.py may,
+    """oracle/ is test infrastructure: the product package, the shim and tools/ must not import it; bench.py / bench_models.py may,
     inside their cpu_baseline*() functions only; __graft_entry__ in build() / smoke() only."""
     import ast
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -231,6 +231,7 @@ def test_product_never_imports_the_oracle():
         return set(hits)
 
     product = [os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py")] + [os.path.join(root, "vadx.py")]
+    product += [os.path.join(root, "tools", f) for f in os.listdir(os.path.join(root, "tools")) if f.endswith(".py")]      # the development tools too
     for path in product:
         assert not oracle_imports(path), path
     assert oracle_imports(os.path.join(root, "bench.py")) <= {"cpu_baseline"}
