@@ -34,9 +34,15 @@ if __name__ == "__main__":
     os.makedirs(EXP, exist_ok=True)
     for n in ids:
         lib = os.path.join(EXP, f"libvadx_f{n}.so")
-        if sys.argv[1] == "build":
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                                   f"-DFR_EXP={n}"] + [os.path.join(PKG, "csrc", s) for s in SRC] + ["-o", lib])
+        if sys.argv[1] == "build":          # firered.hip rebuilt with -DFR_EXP=n, linked with the product's other objects
+            sys.path.insert(0, ROOT)
+            import vadx  # noqa: F401
+            from vadx import build as vbuild
+            vbuild.build(verbose=False)
+            obj = os.path.join(EXP, f"firered_f{n}.o")
+            subprocess.check_call(["/opt/rocm/bin/hipcc"] + vbuild.FLAGS + [f"-DFR_EXP={n}", "-c", os.path.join(PKG, "csrc", "firered.hip"), "-o", obj])
+            objs = [obj if s == "firered.hip" else os.path.join(vbuild.OBJ, s.replace(".hip", ".o")) for s in vbuild.SOURCES]
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
             print("built", lib)
         else:
             r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=dict(os.environ, VADX_LIBRARY=lib),

@@ -125,6 +125,15 @@ __device__ __forceinline__ void tile(const Dev &d, const float *__restrict__ Pk,
     FS_ACC(1);
     __syncthreads();
     FS_ACC(9);
+    // FIR caches: the five values a thread carries into bufP's history columns are requested one layer EARLY (layer 0's before in_linear2,
+    // layer l + 1's before layer l's linear), so the round trip to the global cache hides behind a GEMM instead of opening every layer
+    constexpr int NH = (PROJ * HIST + THREADS - 1) / THREADS;
+    auto cache_fetch = [&](int l, float (&hv)[NH]) {
+#pragma unroll
+        for (int u = 0; u < NH; ++u) { const int e = tid + THREADS * u; hv[u] = ldg1(cin[l] + (e < PROJ * HIST ? e : PROJ * HIST - 1)); }
+    };
+    float hv[NH];
+    cache_fetch(0, hv);
     // in_linear2 + ReLU
     a = LayerArgs{Pk + d.off_in2, d.Ap, d.Lp / 16, 1, d.Ap / 16, 0, 0, Pk + d.off_b2, 1,
                   bufP, A_LD, 0, bufA, A_LD, 0, nullptr, nullptr};
@@ -135,16 +144,13 @@ __device__ __forceinline__ void tile(const Dev &d, const float *__restrict__ Pk,
 
     for (int l = 0; l < NLAYER; ++l) {
         // history columns 1..19 of bufP <- cache (previous tile / previous chunk)
-        {   // all five loads of a thread are issued back to back (clamped index), then stored
-            constexpr int NH = (PROJ * HIST + THREADS - 1) / THREADS;
-            float hv[NH];
-#pragma unroll
-            for (int u = 0; u < NH; ++u) { const int e = tid + THREADS * u; hv[u] = ldg1(cin[l] + (e < PROJ * HIST ? e : PROJ * HIST - 1)); }
+        {
 #pragma unroll
             for (int u = 0; u < NH; ++u) {
                 const int e = tid + THREADS * u, ch = e / HIST, h = e - ch * HIST;
                 if (e < PROJ * HIST) bufP[ch * P_LD + 1 + h] = hv[u];
             }
+            cache_fetch(l + 1 < NLAYER ? l + 1 : l, hv);      // next layer's values (the last iteration's request is unused)
         }
         FS_ACC(3);
         a = LayerArgs{Pk + d.off_lin[l], d.Lp, PROJ / 16, 1, d.Lp / 16, 0, 0, nullptr, 0,
