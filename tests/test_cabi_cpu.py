@@ -288,7 +288,9 @@ def test_folded_dft_tables_reproduce_the_reference_table(lib, preset, kind):
                                        mel_kb.ctypes.data) == 0
     XLD, nyq = 68, int(cfg.n_bins % 16 == 1)
     nbt = cfg.n_bins // 16 if nyq else (cfg.n_bins + 15) // 16
-    plan = blob[n - 48:n - 16].view(np.int32).reshape(8, 4)                    # the blob ends with [8 regions][4] + [8 mel tiles][2] int32
+    plan = blob[n - 52:n - 20].view(np.int32).reshape(8, 4)                    # the blob ends with [8 regions][4] + [8 mel tiles][2] + [4] int32
+    # a last-bin (Nyquist) tile keeps one part: the even one about an integer centre, the odd one about a half-integer centre
+    assert int(blob[n - 4:].view(np.int32)[0]) == ((2 if kind == 2 else 1) if cfg.n_bins % 16 == 1 else 0)
     regions = [r for r in plan if r[0] > 0]
     Pb, Kb32 = int(sum(r[0] for r in regions)), (cfg.taps + 31) // 32
     ka, kb = [], []                                   # tap of either member of pair p; -1 = the row of zeros
@@ -302,7 +304,7 @@ def test_folded_dft_tables_reproduce_the_reference_table(lib, preset, kind):
     r_i, k_i = np.meshgrid(np.arange((nbt + nyq) * 32), np.arange(Pb * 16), indexing="ij")
     ldw = Pb * 16
     fm = fold[(r_i // 16) * 16 * ldw + (k_i // 16) * 256 + (((k_i % 16) // 4) * 16 + r_i % 16) * 4 + k_i % 4].astype(np.float64)
-    res = blob[dense_floats + fold.size:n - 48].view(np.float16).astype(np.float64).reshape(nbt + nyq, 2, Kb32, 4, 16, 8) / 8192.0
+    res = blob[dense_floats + fold.size:n - 52].view(np.float16).astype(np.float64).reshape(nbt + nyq, 2, Kb32, 4, 16, 8) / 8192.0
     res = res.transpose(0, 1, 4, 2, 3, 5).reshape(nbt + nyq, 2, 16, Kb32 * 32)[..., :cfg.taps]        # [tile][RX|IX][bin in tile][tap]
     rng = np.random.default_rng(kind)
     x = rng.standard_normal((5, cfg.taps))

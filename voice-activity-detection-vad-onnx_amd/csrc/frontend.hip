@@ -396,7 +396,7 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
 
 static size_t packed_total(const Dev &d) {
     if (d.fold == 3) return (size_t)d.off_plan + (size_t)d.f_Pb * 32 + 2 * MAX_MEL_TILES;      // [block][quarter][offA x 4 | offB x 4], then the mel bands
-    if (d.fold) return (size_t)d.off_plan + 4 * MAX_REGIONS + 2 * MAX_MEL_TILES;
+    if (d.fold) return (size_t)d.off_plan + 4 * MAX_REGIONS + 2 * MAX_MEL_TILES + 4;      // + last-bin mode (one int, padded to four)
     return (size_t)d.off_mel + (size_t)d.n_mels * d.Fp;
 }
 
@@ -719,6 +719,7 @@ __device__ __forceinline__ void fold_tile(const Dev &d, const float *__restrict_
     };
     const int Kp = d.f_Pb * 16;
     const int *__restrict__ plan = reinterpret_cast<const int *>(P + d.off_plan);
+    const int last_mode = plan[4 * MAX_REGIONS + 2 * MAX_MEL_TILES];      // 0: both products of the last bin's tile, 1: v x O only, 2: u x E only
     if (d.nyq) {
         // last bin (n_bins % 16 == 1): its 16-pair blocks and 32-tap residual blocks are dealt round-robin to the eight waves; the B tile of
         // the u product carries E in row 0, the one of the v product O in row 1, so one accumulator holds (re', im') in columns 0, 1
@@ -740,7 +741,17 @@ __device__ __forceinline__ void fold_tile(const Dev &d, const float *__restrict_
             const float *pa = X2 + plan[4 * rg + 1] + 4 * q * XF_LD + i, *pb = X2 + plan[4 * rg + 2] + 4 * q * strB + i;
             for (int S = 0; S < nblk; ++S, ++gb) {
                 if ((gb & 7) != wave) continue;
-                fold_block(vadx::ldg4(fe + vadx::FRAG * gb), vadx::ldg4(fo + vadx::FRAG * gb), pa + 16 * S * XF_LD, pb + 16 * S * strB, strB, na, na);
+                const float *pas = pa + 16 * S * XF_LD, *pbs = pb + 16 * S * strB;
+                if (last_mode == 0) fold_block(vadx::ldg4(fe + vadx::FRAG * gb), vadx::ldg4(fo + vadx::FRAG * gb), pas, pbs, strB, na, na);
+                else {                           // one of the two parts is null (packed into the residual): half the MFMAs
+                    const f32x4 w4 = vadx::ldg4((last_mode == 2 ? fe : fo) + vadx::FRAG * gb);
+                    const float sg = last_mode == 2 ? 1.f : -1.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            na[mt] = vadx::mfma16(__fadd_rn(pas[j * XF_LD + mt * 16], __fmul_rn(sg, pbs[j * strB + mt * 16])), w4[j], na[mt]);
+                }
             }
         }
         if (i < 2)
@@ -1247,7 +1258,31 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
                 memcpy(fm + (size_t)(t * 32 + i) * P, E.data() + (size_t)f * P, P * sizeof(float));
                 memcpy(fm + (size_t)(t * 32 + 16 + i) * P, O.data() + (size_t)f * P, P * sizeof(float));
             }
+        int last_mode = 0;     // the last bin's tile: 0 both products, 1 only v x O, 2 only u x E
         if (d.nyq) {           // u tile: E in row 0; v tile: O in row 1
+            // For the Nyquist bin one of the two parts is round-off of the reference's table (cos / sin of pi n is 0 or +-1): about a half-integer
+            // centre its even part, about an integer centre its odd part.  Such a part (below 1e-3 of the table scale) joins the residual rows and
+            // its 16-pair MFMAs are skipped (half of the last-bin tile: 2.5 % of the kernel's f32 MFMAs).
+            double emax = 0.0, omax = 0.0;
+            for (int p2 = 0; p2 < P; ++p2) { emax = fmax(emax, fabs((double)E[(size_t)last * P + p2])); omax = fmax(omax, fabs((double)O[(size_t)last * P + p2])); }
+            if (emax < 1e-3 * tab_max) last_mode = 1;
+            else if (omax < 1e-3 * tab_max) last_mode = 2;
+            for (int p2 = 0; p2 < P && last_mode; ++p2) {
+                const FoldPair &pr = pl.pairs[p2];
+                if (pr.kind < 0) continue;
+                float &e = E[(size_t)last * P + p2], &o = O[(size_t)last * P + p2];
+                double *rx = RX.data() + (size_t)last * d.taps, *ix = IX.data() + (size_t)last * d.taps;
+                if (last_mode == 1) {          // the model's real part E u goes back into RX
+                    if (pr.kind == 0) { rx[pr.k] += e; rx[pr.kp] += e; } else if (pr.kind == 1) rx[pr.k] += 2.0 * e; else rx[pr.k] += e;
+                    e = 0.f;
+                } else {                        // the model's imaginary part O v goes back into IX
+                    if (pr.kind == 0) { ix[pr.k] += o; ix[pr.kp] -= o; } else if (pr.kind == 2) ix[pr.k] += o;
+                    o = 0.f;
+                }
+            }
+            for (int t2 = 0; t2 < d.taps && last_mode; ++t2)
+                VADX_REQUIRE(fabs(RX[(size_t)last * d.taps + t2]) * RES_SCALE < 30000.0 && fabs(IX[(size_t)last * d.taps + t2]) * RES_SCALE < 30000.0,
+                             "vadx_frontend_pack_host: last-bin residual out of the f16 range");
             memcpy(fm + (size_t)(d.nbt * 32) * P, E.data() + (size_t)last * P, P * sizeof(float));
             memcpy(fm + (size_t)(d.nbt * 32 + 16 + 1) * P, O.data() + (size_t)last * P, P * sizeof(float));
         }
@@ -1255,6 +1290,7 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
         int32_t *pi = reinterpret_cast<int32_t *>(packed_host + d.off_plan);
         for (int r = 0; r < d.f_regions; ++r) { pi[4 * r] = d.f_blocks[r]; pi[4 * r + 1] = d.f_offA[r]; pi[4 * r + 2] = d.f_offB[r]; pi[4 * r + 3] = d.f_strB[r]; }
         for (int mt = 0; mt < d.nmt; ++mt) { pi[4 * MAX_REGIONS + 2 * mt] = mel_kb[2 * mt]; pi[4 * MAX_REGIONS + 2 * mt + 1] = mel_kb[2 * mt + 1]; }      // the mel bands, for the kernel
+        pi[4 * MAX_REGIONS + 2 * MAX_MEL_TILES] = last_mode;
         _Float16 *rh = reinterpret_cast<_Float16 *>(packed_host + d.off_res);      // [ntl][RX | IX][Kb32][64 lanes][8]
         for (int t = 0; t < ntl; ++t)
             for (int part = 0; part < 2; ++part)
