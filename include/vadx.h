@@ -27,7 +27,7 @@ extern "C" {
 #define VADX_ENOSPACE   -2   /* workspace / output capacity too small */
 #define VADX_EHIP       -3   /* a HIP runtime call failed */
 
-int         vadx_abi_version(void);
+int         vadx_abi_version(void);      /* 3 (round 3: vadx_frontend_cfg grew `fold`; vadx_frontend_fold_kind, vadx_dfsmn_cfb_*, _lstm_t_ex, _ft_repack) */
 const char *vadx_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ def test_header_symbols_exported(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"libvadx.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.vadx_abi_version() == 2
+    assert lib.vadx_abi_version() == 3
 
 
 def test_pack_host_layout(lib):
