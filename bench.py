@@ -20,7 +20,8 @@ line.  Besides the contract keys it carries
   * `cpu_baseline`: the oracle driven like the reference drives ORT, on this host's cores (N = 1, rank 0), beside the reference's
     own published README figure.
 The line is kept under 6 KB (the driver records its tail); everything it summarises -- per-entry-point splits, every roofline
-object in full, sample descriptions -- is written by rank 0 to `--detail` (default profiles/r03_bench_detail.json).
+object in full, sample descriptions -- is written by rank 0 to `--detail` (default gpurun_out/bench_detail.json: scratch;
+the copy to keep is committed under profiles/ deliberately).
 `--dry-run` replaces the device work by a sleep and RCCL by gloo so the launch / barrier / collect path can be tested
 on a CPU-only box; its line says so (`data`: "dry-run") and carries no measurement.
 """
@@ -94,6 +95,24 @@ def profiled_traffic(kernel="silero_encode_kernel"):
         write, g2 = _kernel_counter(path, kernel, "WRITE_SIZE")
         if fetch is not None and write is not None and g1 == g2:
             best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT), "grid_threads": g1}
+    return best
+
+
+def profiled_launch_ms(kernel="silero_encode_kernel"):
+    """n / mean / median launch duration [ms] of the LARGEST grid of `kernel` in the newest committed profile (the "per (kernel, grid)
+    dispatch durations" block tools/profile_bench.sh writes from the kernel trace).  Reported BESIDE the line's own figure: the line's
+    `roofline.achieved` uses the mean of THIS run's HIP events (`launch_ms.basis`), the profile is another run on another box."""
+    import glob
+    import re
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "SUMMARY.txt"))):
+        grid = -1
+        for line in open(path):
+            m = re.search(r"grid=\s*(\d+)\s+n=\s*(\d+)\s+mean=\s*([\d.]+)\s+median=\s*(\d+)", line)
+            if m and kernel in line and int(m.group(1)) >= grid:
+                grid = int(m.group(1))
+                best = {"n": int(m.group(2)), "mean": float(m.group(3)) * 1e-6, "median": float(m.group(4)) * 1e-6,
+                        "source": os.path.relpath(path, ROOT)}
     return best
 
 
@@ -250,7 +269,12 @@ def compact_line(full, detail_path=None):
                         "valu_per_mfma": r4(mix.get("valu_per_mfma")), "ceiling_frac": r4(mix.get("ceiling_frac")),
                         "traffic_source": ro.get("traffic_source")}
     if full.get("encoder_launch_ms"):
-        line["roofline"]["launch_ms"] = {k: (r4(v) if isinstance(v, float) else v) for k, v in full["encoder_launch_ms"].items()}
+        lm = full["encoder_launch_ms"]
+        line["roofline"]["launch_ms"] = {k: (r4(v) if isinstance(v, float) else v) for k, v in lm.items() if k not in ("basis", "committed_profile")}
+        line["roofline"]["launch_ms"]["basis"] = "mean of this run's HIP events"
+        cp_ = lm.get("committed_profile")
+        if cp_:
+            line["roofline"]["launch_ms"]["profile"] = {"n": cp_["n"], "mean": r4(cp_["mean"]), "median": r4(cp_["median"])}
     line["roofline_recurrent"] = {"kernel": rr["kernel"], "achieved": r4(rr["achieved"]), "frac": r4(rr["frac"])}
     line["hbm"] = {"algorithmic_bytes_per_frame": hb["algorithmic_bytes_per_frame"], "achieved_GBps": r4(hb["achieved_GBps"]),
                    "peak_GBps": hb["peak_GBps"], "frac": r4(hb["frac"]), "traffic_ratio": r4(hb["traffic_ratio"])}
@@ -297,7 +321,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-feed", action="store_true", help="skip the PCIe-inclusive (pinned, double-buffered upload) measurement")
     ap.add_argument("--secondary-reps", type=int, default=3)
     ap.add_argument("--no-c4-sharded", action="store_true", help="skip BASELINE config 4 strong-sharded over the ranks")
-    ap.add_argument("--detail", default=os.path.join(ROOT, "profiles", "r03_bench_detail.json"),
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
                     help="where rank 0 writes the full (long) result object; '' = nowhere")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only: gloo + sleep instead of RCCL + kernels (launch-path test)")
     return ap.parse_args(argv)
@@ -456,7 +480,9 @@ def main(argv=None):
     # (the contract's `roofline.achieved` is on the AVERAGE launch duration; the median and the extremes go to the detail file so that a
     #  profile taken on another box can be compared with the middle of this run, not with a mean that one slow launch moved)
     enc_all = sorted(e[0].elapsed_time(e[1]) for e in events)
-    enc_stats = {"mean": enc_ms, "median": float(np.median(enc_all)), "min": enc_all[0], "max": enc_all[-1], "launches": len(enc_all)}
+    enc_stats = {"mean": enc_ms, "median": float(np.median(enc_all)), "min": enc_all[0], "max": enc_all[-1], "launches": len(enc_all),
+                 "basis": "roofline.achieved uses `mean` = the average of this run's HIP-event launch durations",
+                 "committed_profile": profiled_launch_ms("silero_encode_kernel") if (B, T) == (CLIPS_PER_GPU, STEPS_PER_CLIP) else None}
     assert int(counts.max().item()) <= cap, "segment table overflow"
     assert bool(torch.isfinite(probs).all())
     n_seg = int(counts.sum().item())
@@ -469,6 +495,9 @@ def main(argv=None):
     # ---- the same batch from pinned host int16, upload overlapped with compute (every rank feeds its own GPU at once)
     feed = None
     if not args.no_feed:
+        # rank-local set-up (a pinned allocation can be refused) first, then the ranks AGREE before the section with barriers and
+        # all-reduces: a rank that bailed out alone would leave the others waiting in them (shard.all_ok)
+        err, pipe, host = None, None, None
         try:
             host = torch.empty((B, SAMPLES), dtype=torch.int16, pin_memory=True)
             host.copy_(pcm)
@@ -478,6 +507,10 @@ def main(argv=None):
             pipe = FeedPipeline(torch, eng, L, host, probs, segs, counts, lens, prm, cap)
             for _ in range(max(1, args.warmup)):
                 pipe.step()
+            torch.cuda.synchronize()
+        except Exception as e:                                       # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        if shard.all_ok(dist, err is None, device):
             fence()
             t1 = time.perf_counter()
             for _ in range(args.steps):
@@ -498,10 +531,10 @@ def main(argv=None):
                     "upload_alone_GBps": up_bytes / up_s / 1e9, "pcie_peak_GBps": 63.0,
                     "scores_bit_identical_to_resident_f32_path": same}
             log(f"feed-inclusive: {feed['ms_per_step']:.2f} ms/step, upload alone {up_s * 1e3:.1f} ms ({feed['upload_alone_GBps']:.1f} GB/s)")
-            del pipe, host
-        except Exception as e:                                       # noqa: BLE001  (pinned allocation can be refused)
-            feed = {"error": f"{type(e).__name__}: {e}"}
-            log(f"feed-inclusive mode failed: {feed['error']}")
+        else:
+            feed = {"error": err or "another rank could not set its host feed up"}
+            log(f"feed-inclusive mode skipped on every rank: {feed['error']}")
+        del pipe, host
     del pcm
 
     rtf_b1 = None
@@ -525,6 +558,8 @@ def main(argv=None):
             c4s = bench_models.marblenet_c4_sharded(torch, device, dist, rank, world, max(2, args.secondary_reps), log=log,
                                                     feed=not args.no_feed)
         except Exception as e:                               # noqa: BLE001
+            if dist is not None:                             # the leg holds barriers: a rank that swallowed its error would hang the rest
+                raise
             c4s = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
     if world == 1 and not args.no_secondary:

@@ -131,6 +131,28 @@ def flop_dfsmn_window(T=101, TA=51, F=160, ch=20):
     return out
 
 
+def flop_dfsmn_by_entry(fused, T=101, TA=51, F=160, ch=20):
+    """The same arithmetic attributed to the C-ABI entry point that EXECUTES it (flop_dfsmn_window groups it by the reference's
+    stages).  fused: the gated blocks run as cfb_front -> lstm_f -> cfb_back, so the gate / input / (3,1) convs and the forward DFT
+    belong to cfb_front, the CepsUnit linear and the inverse DFT to cfb_back, and the pw_conv launches that remain are in_ch_lstm's
+    linear, in_conv and out_conv (round 3 priced those three launches with all of pw_conv's flops: frac 2.46).  The two time-LSTM
+    output linears run inside the lstm_t kernels either way.  Sums to flop_dfsmn_window()['total'] minus front-end / istft / mask-net."""
+    st = flop_dfsmn_window(T, TA, F, ch)
+    lin_t = 2 * T * F * (2 * ch * ch + ch * 2 * ch)
+    lin_in = 2 * T * F * 2 * ch * ch                                           # in_ch_lstm.linear (40 -> 20): a pw_conv launch
+    lin_ceps = 2 * T * 10 * 81 * 2 * ch * 2 * ch                               # CepsUnit linear (40 -> 40 on 81 bins)
+    e = {"lstm_t": st["lstm_t"] + lin_t, "lstm_f": st["lstm_f"] - lin_in - lin_ceps}
+    if fused:
+        e["cfb_front"], e["cfb_back"] = st["cfb_front"], st["cfb_back"]
+        e["pw_conv"] = lin_in + 2 * T * F * ((4 + ch) * ch + 3 * ch * 2)
+        e["dft_f"] = 0
+    else:
+        e["pw_conv"] = st["pw_conv"] - lin_t + lin_in + lin_ceps
+        e["dft_f"] = st["dft_f"]
+        e["cfb_front"] = e["cfb_back"] = 0
+    return e
+
+
 # ------------------------------------------------------------------------------------------------ helpers
 def synth_pcm16(torch, device, batch, samples, seed, loud=3000.0, quiet=30.0):
     """int16 burst clips generated on the GPU (every clip unique): 0.5-2 s segments alternating N(0,loud) / N(0,quiet)
@@ -498,6 +520,7 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
     split, calls = _trace(run)
     fl = flop_dfsmn_window()
     nwin = clips * W
+    fle = flop_dfsmn_by_entry(fused=split.get("vadx_dfsmn_cfb_front", 0.0) > 0)
     groups = {"lstm_f": split.get("vadx_dfsmn_lstm_f", 0.0), "dft_f": split.get("vadx_dfsmn_dft_f", 0.0),
               "pw_conv": split.get("vadx_dfsmn_pw_conv", 0.0), "lstm_t": split.get("vadx_dfsmn_lstm_t", 0.0) + split.get("vadx_dfsmn_lstm_t_ex", 0.0),
               "cfb_front": split.get("vadx_dfsmn_cfb_front", 0.0), "cfb_back": split.get("vadx_dfsmn_cfb_back", 0.0)}
@@ -509,10 +532,10 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
            "clip_pairs": clips, "samples_per_clip": n, "windows": nwin, "ms": ms,
            "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split, "kernel_calls": calls,
            "flop_per_window": fl,
-           "roofline": _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fl[dom], groups[dom], "dfsmn", dom,
+           "roofline": _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fle[dom], groups[dom], "dfsmn", dom,
                              note="all launches of the entry point that takes the most time; flops as the reference computes them "
                                   "(the kernel issues more: 20 output channels pad to 32 MFMA rows)"),
-           "roofline_by_entry": {k: _roof(f"vadx_dfsmn_{k}", nwin * fl[k], v, "dfsmn", k) for k, v in groups.items() if v > 0},
+           "roofline_by_entry": {k: _roof(f"vadx_dfsmn_{k}", nwin * fle[k], v, "dfsmn", k) for k, v in groups.items() if v > 0},
            "roofline_whole_pass": _roof("all DFSMN launches", nwin * fl["total"], ms),
            "hbm": _hbm(clips * (2 * padded * 2 + W * eng.T_A * 4), ms, "dfsmn"), "cpu_baseline": None}
     del near, far
@@ -549,17 +572,23 @@ def marblenet_c4_sharded(torch, device, dist, rank, world, reps=3, clips=8192, l
     out = {"workload": f"MarbleNet v2.0 f32, {clips} clips x {n} samples strong-sharded over {world} GPU(s), no collective",
            "clips": clips, "n_gpus": world, "shard": [lo, hi], "ms": el * 1e3, "frames_per_s": clips * n / 512 / el, "scaling": "strong"}
     if feed:
+        # Everything that can fail on ONE rank (pinned allocation, the feed's buffers, the first runs) happens locally first; the ranks
+        # then AGREE (all_ok) before any of them enters timed(), whose barriers / all-reduces every rank must reach.
+        err, host, f, same = None, None, None, None
         try:
             host = vfeed.pin(audio.cpu())
             f = vfeed.HostPcmFeed(device, n, max(64, min(256, (hi - lo) // 8)))      # at least eight chunks per shard; tools/feed_sweep.py, 8192 clips: 64 clips 40.9 ms, 128 31.3, 256 27.0, 512 27.3, 1024 28.4 (upload alone 25.5)
             ref = eng.run(audio)
             got = eng.run_from_host(host, feed=f)
             same = bool(torch.equal(got[1], ref[1]))
-            elf = timed(lambda: eng.run_from_host(host, feed=f))
+        except Exception as e:                               # noqa: BLE001  (pinned allocation can be refused)
+            err = f"{type(e).__name__}: {e}"
+        if shard.all_ok(dist, err is None, device):
+            elf = timed(lambda: eng.run_from_host(host, feed=f))     # a failure in here is fatal for the job on every rank: not caught
             out["feed"] = {"ms": elf * 1e3, "frames_per_s": clips * n / 512 / elf, "upload_bytes_per_gpu": (hi - lo) * n * 2,
                            "scores_bit_identical_to_resident": same}
-        except Exception as e:                               # noqa: BLE001  (pinned allocation can be refused)
-            out["feed"] = {"error": f"{type(e).__name__}: {e}"}
+        else:
+            out["feed"] = {"error": err or "another rank could not set its host feed up"}
     log(f"marblenet_c4 sharded x{world}: {out['ms']:.2f} ms")
     return out
 

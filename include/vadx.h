@@ -27,7 +27,12 @@ extern "C" {
 #define VADX_ENOSPACE   -2   /* workspace / output capacity too small */
 #define VADX_EHIP       -3   /* a HIP runtime call failed */
 
-int         vadx_abi_version(void);      /* 3 (round 3: vadx_frontend_cfg grew `fold`; vadx_frontend_fold_kind, vadx_dfsmn_cfb_*, _lstm_t_ex, _ft_repack) */
+/* THE ABI number: the library (csrc/capi.hip), the ctypes binding (vadx._lib.ABI_VERSION, parsed from this line),
+ * the C client (tests/c/cabi_silero.c) and __graft_entry__.build() all read it from here and nowhere else.
+ * 3: vadx_frontend_cfg grew `fold`; vadx_frontend_fold_kind, vadx_dfsmn_cfb_*, _lstm_t_ex, _ft_repack (round 3). */
+#define VADX_ABI_VERSION 3
+
+int         vadx_abi_version(void);      /* == VADX_ABI_VERSION of the header the library was built from */
 const char *vadx_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------

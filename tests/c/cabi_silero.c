@@ -40,7 +40,7 @@ int main(int argc, char **argv) {
     hw.lstm_w_ih = w + off[9]; hw.lstm_w_hh = w + off[10]; hw.lstm_b_ih = w + off[11]; hw.lstm_b_hh = w + off[12];
     hw.dec_w = w + off[13]; hw.dec_b = w + off[14];
 
-    if (vadx_abi_version() != 3) { fprintf(stderr, "unexpected ABI version\n"); return 1; }
+    if (vadx_abi_version() != VADX_ABI_VERSION) { fprintf(stderr, "unexpected ABI version\n"); return 1; }
     const size_t npk = vadx_silero_packed_floats();
     float *pk_host = (float *)malloc(npk * sizeof(float));
     CHECK_VADX(vadx_silero_pack_host(&hw, pk_host));

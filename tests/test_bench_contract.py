@@ -42,6 +42,13 @@ def test_secondary_flop_formulas():
     assert d["total"] == sum(v for k, v in d.items() if k not in ("total", "cfb_front", "cfb_back"))      # the fused kernels regroup pw_conv / dft_f work
     assert d["cfb_front"] + d["cfb_back"] < d["pw_conv"] + d["dft_f"] + d["lstm_f"]
     assert 5.5e9 < d["total"] < 6.5e9 and d["lstm_f"] > d["lstm_t"] > d["istft"]
+    # per ENTRY POINT: either execution (fused gated blocks or the six-launch chain) accounts for the same ICCRN arithmetic, and the
+    # three pw_conv launches the fused pass keeps carry only their own flops (round 3 priced them with all of pw_conv's: frac 2.46)
+    net = d["lstm_f"] + d["dft_f"] + d["pw_conv"] + d["lstm_t"]
+    for fused in (False, True):
+        e = bm.flop_dfsmn_by_entry(fused)
+        assert sum(e.values()) == net and all(v >= 0 for v in e.values())
+    assert bm.flop_dfsmn_by_entry(True)["pw_conv"] < 0.05 * d["pw_conv"]
 
 
 def test_cpu_baseline_is_bounded_and_reports_the_protocol():
@@ -119,3 +126,7 @@ def test_secondary_workloads_small():
         out = fn(torch, dev, 1, 0, **kw)
         assert out["ms"] > 0 and out["frames_per_s"] > 0 and 0 < out["roofline"]["frac"] < 1, out
         assert 0 < out["hbm"]["frac"] < 1 and sum(out["kernel_ms"].values()) <= out["ms"] * 1.5
+        for key, ro in out.items():                  # no timed kernel may be credited with more work than the pipe can do
+            if key.startswith("roofline") and isinstance(ro, dict):
+                for r in (ro.values() if key == "roofline_by_entry" else [ro]):
+                    assert 0 <= r["frac"] <= 1, (key, r)

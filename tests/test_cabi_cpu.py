@@ -27,7 +27,21 @@ def test_header_symbols_exported(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"libvadx.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.vadx_abi_version() == 3
+    assert lib.vadx_abi_version() == _lib.ABI_VERSION
+
+
+def test_graft_entry_abi_check(lib):
+    """One number, one place: include/vadx.h's VADX_ABI_VERSION is what capi.hip returns, what vadx._lib expects, what the C
+    client compares with and what __graft_entry__.build() asserts (round 3 ended with that last one stale and build() raising)."""
+    import __graft_entry__ as g
+    hdr = open(os.path.join(ROOT, "include", "vadx.h")).read()
+    n = int(re.search(r"^#define\s+VADX_ABI_VERSION\s+(\d+)", hdr, flags=re.M).group(1))
+    assert _lib.ABI_VERSION == n
+    assert g.check_abi(lib) == n
+    for rel in ("voice-activity-detection-vad-onnx_amd/csrc/capi.hip", "tests/c/cabi_silero.c", "__graft_entry__.py"):
+        src = open(os.path.join(ROOT, rel)).read()
+        assert not re.search(r"abi_version\(\)\s*[!=]=\s*\d", src), f"{rel} compares the ABI with a literal"
+        assert not re.search(r"vadx_abi_version\(void\)\s*\{\s*return\s+\d", src), f"{rel} returns a literal ABI number"
 
 
 def test_pack_host_layout(lib):

@@ -10,7 +10,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 run() {  # name, steps, warmup, extra rocprof args...
   local name=$1 steps=$2 warm=$3; shift 3
   timeout 600 rocprofv3 --kernel-trace --output-format csv "$@" -d "$OUT/$name" -o "$name" -- \
-      python3 bench.py --steps "$steps" --warmup "$warm" --no-cpu-baseline --no-secondary --no-feed > "$OUT/$name.bench.json" 2> "$OUT/$name.err.log"
+      python3 bench.py --steps "$steps" --warmup "$warm" --no-cpu-baseline --no-secondary --no-feed --no-c4-sharded --detail "" > "$OUT/$name.bench.json" 2> "$OUT/$name.err.log"
   echo "== $name rc=$?"; tail -c 300 "$OUT/$name.bench.json"; echo
 }
 run stats 5 2 --stats

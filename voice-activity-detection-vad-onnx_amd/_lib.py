@@ -10,6 +10,19 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VADX_LIBRARY") or os.path.join(HERE, "libvadx.so")     # override: a differently built libvadx
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "vadx.h")
+
+
+def _header_abi_version():
+    """`#define VADX_ABI_VERSION n` of include/vadx.h -- the one place the ABI number is written."""
+    import re
+    m = re.search(r"^#define\s+VADX_ABI_VERSION\s+(\d+)\s*$", open(HEADER_PATH).read(), flags=re.M)
+    if not m:
+        raise RuntimeError(f"{HEADER_PATH}: no '#define VADX_ABI_VERSION <n>' line")
+    return int(m.group(1))
+
+
+ABI_VERSION = _header_abi_version()
 
 
 class VadxError(RuntimeError):
@@ -183,6 +196,10 @@ def _load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the .so does not export it
             fn.restype, fn.argtypes = res, args
+        got = handle.vadx_abi_version()
+        if got != ABI_VERSION:
+            raise VadxError(f"{LIB_PATH} was built as ABI {got}, include/vadx.h says {ABI_VERSION}: rebuild it "
+                            "(python -m vadx.build --force)")
         _lib = handle
     return _lib
 

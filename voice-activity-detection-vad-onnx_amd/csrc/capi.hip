@@ -12,7 +12,7 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace vadx
 
-extern "C" int vadx_abi_version(void) { return 3; }      // 3: vadx_frontend_cfg.fold, the DFSMN gated-block entry points (round 3)
+extern "C" int vadx_abi_version(void) { return VADX_ABI_VERSION; }      // include/vadx.h is the one place the number lives
 extern "C" const char *vadx_last_error(void) { return vadx::g_err; }
 
 extern "C" size_t vadx_frag_major_floats(int rows, int cols) {

@@ -32,6 +32,15 @@ class HostPcmFeed:
         self.N, self.chunk, self.streams = int(n_samples), max(1, int(chunk_clips)), int(streams)
         self.buf = [[t.empty((self.chunk, self.N), dtype=t.int16, device=self.device) for _ in range(self.streams)] for _ in range(2)]
         self.copy_stream = t.cuda.Stream(device=self.device)
+        # The buffers were just handed out by the caching allocator on the CURRENT stream: a block it recycled may still be read by
+        # launches queued there.  The copy stream therefore starts behind everything the allocating stream has queued so far, and the
+        # buffers are tied to both streams (record_stream) so that dropping the feed cannot return them while either still uses them.
+        with t.cuda.device(self.device):
+            alloc = t.cuda.current_stream()
+            self.copy_stream.wait_stream(alloc)
+            for pair in self.buf:
+                for b in pair:
+                    b.record_stream(self.copy_stream)
         self.ready = [t.cuda.Event() for _ in range(2)]
         self.free = [t.cuda.Event() for _ in range(2)]
         self.in_use = [False, False]
@@ -50,6 +59,9 @@ class HostPcmFeed:
         out = []
         with t.cuda.device(self.device):
             comp = t.cuda.current_stream()
+            for pair in self.buf:                            # a caller on another stream than the allocating one: tie the buffers to it too
+                for b in pair:
+                    b.record_stream(comp)
             for k2, b0 in enumerate(range(0, B, self.chunk)):
                 nb, k = min(self.chunk, B - b0), k2 & 1
                 with t.cuda.stream(self.copy_stream):

@@ -54,6 +54,18 @@ def max_over_ranks(dist, value, device="cpu"):
     return float(t.item())
 
 
+def all_ok(dist, ok, device="cpu"):
+    """True only if EVERY rank says ok (MIN all-reduce).  Any rank-local step that may fail -- a pinned allocation, an OOM -- is
+    followed by this before the ranks enter a section with barriers / all-reduces: a rank that bailed out alone would otherwise leave
+    the others waiting in the collective until the launcher's timeout."""
+    if dist is None:
+        return bool(ok)
+    import torch
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
 def gather_ragged(dist, local_results):
     """Per-clip result lists of every rank, concatenated in rank (= clip) order, on every rank."""
     if dist is None:
