@@ -29,8 +29,9 @@ extern "C" {
 
 /* THE ABI number: the library (csrc/capi.hip), the ctypes binding (vadx._lib.ABI_VERSION, parsed from this line),
  * the C client (tests/c/cabi_silero.c) and __graft_entry__.build() all read it from here and nowhere else.
- * 3: vadx_frontend_cfg grew `fold`; vadx_frontend_fold_kind, vadx_dfsmn_cfb_*, _lstm_t_ex, _ft_repack (round 3). */
-#define VADX_ABI_VERSION 3
+ * 3: vadx_frontend_cfg grew `fold`; vadx_frontend_fold_kind, vadx_dfsmn_cfb_*, _lstm_t_ex, _ft_repack (round 3).
+ * 4: vadx_silero_encoder_mode; the Silero packed blob grew the bf16 x 3 weight fragments (round 4). */
+#define VADX_ABI_VERSION 4
 
 int         vadx_abi_version(void);      /* == VADX_ABI_VERSION of the header the library was built from */
 const char *vadx_last_error(void);
@@ -134,6 +135,13 @@ typedef struct vadx_silero_seg_params {
 int vadx_silero_segments(const float *probs, int batch, int steps, const int64_t *n_samples,
                          const vadx_silero_seg_params *params, int64_t *segments, int32_t *counts,
                          int cap, void *stream);
+
+/* Which encoder kernel vadx_silero_step / _clips / _encode* launch (process-wide): 0 = exact-f32 MFMAs (v_mfma_f32_16x16x4_f32),
+ * 1 = bf16 x 3 split products (every constant-weight GEMM as six v_mfma_f32_16x16x32_bf16 per K = 32 step on exactly split
+ * operands: float32-class accuracy at 6/16 of the matrix time, csrc/split3.h).  Both read the same packed blob and write the same
+ * workspace.  Any other `mode` only queries.  Returns the previous mode; the initial one comes from VADX_SILERO_ENCODER
+ * ("f32" | "split").  Replaces nothing in the reference: onnxruntime has one CPU kernel set. */
+int vadx_silero_encoder_mode(int mode);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused signal front-end: int16 PCM -> prep -> framed windowed DFT against the

@@ -49,6 +49,20 @@ def net_forward(w, x, state):
     return torch.sigmoid(logit), torch.stack([h1, c1])
 
 
+def input_projection(w, x):
+    """The state-independent part of one call, in the dtype of `w` / `x` (tests evaluate it in float64 to rank two kernels' float32
+    errors): x [B,576] -> W_ih feat + b_ih + b_hh [B,512] in torch gate order, the quantity the encoder kernels hand the recurrent
+    kernel.  Same graph as net_forward up to `feat`."""
+    xp = F.pad(x.unsqueeze(1), (0, 64), mode="reflect")
+    spec = F.conv1d(xp, w["stft_basis"].unsqueeze(1), stride=128)
+    re, im = spec[:, :129], spec[:, 129:]
+    y = torch.sqrt(re * re + im * im)
+    strides = (1, 2, 2, 1)
+    for i in range(4):
+        y = F.relu(F.conv1d(y, w[f"enc{i}_w"], w[f"enc{i}_b"], stride=strides[i], padding=1))
+    return y.squeeze(-1) @ w["lstm_w_ih"].t() + w["lstm_b_ih"] + w["lstm_b_hh"]
+
+
 class OnnxWrapperOracle:
     """State/context carry around the network call.
     ref: Silero/modeling_modified/utils_vad.py:69-146 (validation :69-85, reset :87-91,

@@ -21,9 +21,57 @@ def T(x):
     return torch.from_numpy(np.ascontiguousarray(x))
 
 
+@pytest.fixture(autouse=True, params=["f32", "split"])
+def encoder(request):
+    """Every test of this file runs on both encoder kernels: exact-f32 MFMAs and bf16 x 3 split products (csrc/silero_split.hip)."""
+    prev = silero.encoder_mode(request.param)
+    yield request.param
+    silero.encoder_mode(prev)
+
+
 @pytest.fixture(scope="module")
 def engine():
     return silero.SileroEngine(weights.silero_synthetic(1234))
+
+
+def gx_of(engine, audio):
+    """The encoder's output for audio f32 [B,N] as [T][B][512] (torch gate order), decoded from the workspace layout
+    [T][B/16][8 waves][4 gates][64 lanes = 16 q + clip][4 units]: unit = 16 wave + 4 q + r."""
+    B, N = audio.shape
+    engine.encode(audio)
+    ws = engine._ws
+    Tn, G = (N + 511) // 512, (B + 15) // 16
+    g = ws[:Tn * G * 8192 * 4].view(torch.float32).view(Tn, G, 8, 4, 4, 16, 4)      # t, group, wave, gate, q, clip, r
+    g = g.permute(0, 1, 5, 3, 2, 4, 6).reshape(Tn, G * 16, 512)                     # t, (group, clip), (gate, wave, q, r)
+    return g[:, :B]
+
+
+def test_split_products_are_as_exact_as_f32_products(engine):
+    """The proof that lets the split-product encoder stand in for the exact-f32 one: against a FLOAT64 evaluation of the same float32
+    weights and samples (oracle.input_projection), the bf16 x 3 encoder's error is no larger than 1.25 x the f32-MFMA encoder's --
+    on the quantity both hand the recurrent kernel, for silence, LSB-level noise, full-scale noise, a loud tone and bursts."""
+    n = 5120
+    rng = np.random.default_rng(11)
+    clips = weights.burst_clips(27, n, seed=21).astype(np.float32)
+    clips[0] = 0
+    clips[1] = rng.integers(-1, 2, n)
+    clips[2] = rng.integers(-32768, 32768, n)
+    clips[3] = np.round(30000 * np.sin(2 * np.pi * 1000.0 / 16000 * np.arange(n)))
+    clips[4] = np.round(300 * np.sin(2 * np.pi * 3999.0 / 16000 * np.arange(n))) + rng.integers(-2, 3, n)
+    x = torch.from_numpy(clips * np.float32(0.000030517578))
+    w64 = {k: T(v).double() for k, v in weights.silero_synthetic(1234).items()}
+    xp = torch.cat([torch.zeros(27, 64), x], dim=1).double()
+    ref = torch.stack([osil.input_projection(w64, xp[:, 512 * t:512 * t + 576]) for t in range(n // 512)])      # [T][B][512]
+    err = {}
+    for mode in ("f32", "split"):
+        silero.encoder_mode(mode)
+        err[mode] = (gx_of(engine, x.cuda()).double().cpu() - ref).abs()
+    scale = float(ref.abs().max())
+    print(f"gx scale {scale:.3g}: max err f32 {float(err['f32'].max()):.3e} split {float(err['split'].max()):.3e}; "
+          f"mean f32 {float(err['f32'].mean()):.3e} split {float(err['split'].mean()):.3e}")
+    assert float(err["f32"].max()) < 2e-5 * max(scale, 1.0)                      # the f32 encoder itself is sane
+    assert float(err["split"].max()) <= 1.25 * float(err["f32"].max())
+    assert float(err["split"].mean()) <= 1.25 * float(err["f32"].mean())
 
 
 @pytest.fixture(scope="module")

@@ -14,14 +14,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "voice-activity-detection-vad-onnx_amd")
 EXP = os.path.join(PKG, "_exp")
-SRC = ["capi.hip", "silero.hip"]
+SRC = ["capi.hip", "silero.hip", "silero_split.hip"]
+SPLIT = os.environ.get("EXP_SPLIT", "1") == "1"          # EXP_SPLIT=0: the exact-f32 encoder (silero_encode_kernel) instead of the split-product one
 
 
 def build(ids):
     os.makedirs(EXP, exist_ok=True)
     for n in ids:
         out = os.path.join(EXP, f"libvadx_exp{n}.so")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-DVADX_EXP={n}"]
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-DVADX_EXP={n}",
+               f"-DVADX_SILERO_ENCODER_DEFAULT={1 if SPLIT else 0}"]
         cmd += [os.path.join(PKG, "csrc", s) for s in SRC] + ["-o", out]
         subprocess.check_call(cmd)
         print("built", out)
@@ -78,7 +80,16 @@ for a, b in ev:
     a.record(); rec(); b.record()
 torch.cuda.synchronize()
 tr = [a.elapsed_time(b) for a, b in ev]
-if hasattr(h, "vadx_silero_debug_cycles"):
+if hasattr(h, "vadx_silero_split_debug_cycles") and %d:
+    buf = (C.c_ulonglong * 16)()
+    h.vadx_silero_split_debug_cycles(buf, 1)
+    enc(); torch.cuda.synchronize()
+    h.vadx_silero_split_debug_cycles(buf, 0)
+    tot = sum(buf) or 1
+    names = {0: "stage X", 1: "STFT fold + bin 64", 2: "|.| planes", 3: "bin 64 slot", 4: "conv1", 5: "conv1 store", 6: "conv2", 7: "conv3", 8: "conv4", 9: "W_ih + gx store"}
+    print("PHASES (share of wave-0 cycles, sum over workgroups):", ", ".join(f"{names.get(k, k)} {100.0 * v / tot:.1f}%%" for k, v in enumerate(buf) if v),
+          "| cycles per tile: %%.0f" %% (tot / (B // 16 * T)))
+elif hasattr(h, "vadx_silero_debug_cycles"):
     buf = (C.c_ulonglong * 16)()
     h.vadx_silero_debug_cycles(buf, 1)
     enc(); torch.cuda.synchronize()
@@ -95,7 +106,7 @@ print("EXP", os.path.basename(os.environ["VADX_LIBRARY"]), "encode ms mean %%.3f
 def run(ids):
     for n in ids:
         env = dict(os.environ, VADX_LIBRARY=os.path.join(EXP, f"libvadx_exp{n}.so"))
-        r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, 1 if SPLIT else 0)], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in r.stdout.splitlines() if l.startswith("EXP")]
         for ph in [l for l in r.stdout.splitlines() if l.startswith("PHASES")]:
             print(ph, flush=True)

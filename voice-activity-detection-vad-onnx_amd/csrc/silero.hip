@@ -10,10 +10,20 @@
 //   silero_lstm_kernel   : one persistent workgroup per 16 clips; W_hh (512x128 f32 = 256 KB) lives
 //       in the VGPRs of its 8 waves for all T steps; h is exchanged through double-buffered LDS.
 //   silero_segments_kernel: get_speech_timestamps' state machine, one clip per thread.
-#include "common.h"
+#include "silero_common.h"
+#include "split3.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+
+#ifndef VADX_SILERO_ENCODER_DEFAULT
+// 0 = exact-f32 MFMA encoder, 1 = bf16 x 3 split-product encoder (silero_split.hip).  The split encoder is the default since
+// tests/test_gpu_silero.py::test_split_products_are_as_exact_as_f32_products showed it CLOSER to the float64 evaluation of the same
+// float32 network than the f32-MFMA encoder (max 9.3e-6 against 1.6e-5 on gx of scale 30, mean 2.1e-7 against 3.4e-7) and every
+// parity test of that file passes on both.
+#define VADX_SILERO_ENCODER_DEFAULT 1
+#endif
 
 // VADX_EXP: development-only what-if switches for tools/exp_encoder.py (results are wrong when set).
 #ifndef VADX_EXP
@@ -44,35 +54,6 @@ extern "C" int vadx_silero_debug_cycles(unsigned long long *out, int reset) {
 namespace vadx {
 namespace silero {
 
-// ---- packed weight blob (float offsets) -------------------------------------------------------
-// Encoder GEMM weights are stored FRAGMENT-MAJOR: [16-row tile][16-k block S][lane = 16q+i][4], i.e. exactly the
-// f32x4 each lane feeds to the four MFMAs of block S (row 16*tile+i, k = 16S+4q+j).  One wave-wide load is then
-// one contiguous 1 KB run (8 full cache lines) instead of 16 half-used lines of a row-major matrix.
-constexpr int OFF_STFT = 0;                        // [8 waves][re16|im16][256]  (bins 0..127), k-permuted per 16
-constexpr int OFF_NYQ = OFF_STFT + 256 * 256;      // [2][256]                   (bin 128 re, im)
-constexpr int C1_KP = 128;                         // input channels 0..127 on MFMA; channel 128 (Nyquist) on VALU
-// conv1 runs in the Winograd F(4,3) domain (see "phase 2"): 6 transformed weight planes U_j = G g instead of 3 taps
-constexpr int OFF_C1 = OFF_NYQ + 2 * 256;          // [8 oc tiles][6 planes][8 blocks][FRAG]
-constexpr int OFF_C1N = OFF_C1 + 128 * 6 * C1_KP;  // [128][8]  the six transformed taps of input channel 128 (+2 pad)
-constexpr int OFF_B1 = OFF_C1N + 128 * 8;          // [128]
-constexpr int OFF_C2 = OFF_B1 + 128;               // [4 oc tiles][3 taps x 8 blocks][FRAG]
-constexpr int OFF_B2 = OFF_C2 + 64 * 3 * 128;      // [64]
-constexpr int OFF_C3 = OFF_B2 + 64;                // [4 oc tiles][2 taps x 4 blocks][FRAG]  taps 1,2 (tap 0 only sees padding)
-constexpr int OFF_B3 = OFF_C3 + 64 * 2 * 64;       // [64]
-constexpr int OFF_C4 = OFF_B3 + 64;                // [8 oc tiles][4 blocks][FRAG]  tap 1 only
-constexpr int OFF_B4 = OFF_C4 + 128 * 64;          // [128]
-constexpr int OFF_IH = OFF_B4 + 128;               // [4 gates][8 unit tiles][8 blocks][FRAG]
-constexpr int OFF_BG = OFF_IH + 512 * 128;         // [512] b_ih + b_hh
-constexpr int OFF_HH = OFF_BG + 512;               // [512][128]
-constexpr int OFF_DW = OFF_HH + 512 * 128;         // [128]
-constexpr int OFF_DB = OFF_DW + 128;               // [1] (+3 pad)
-// Folded STFT basis (used when the table has the DFT's time and frequency symmetries, see pack_host and
-// stft_fold_class): symmetrised coefficients of bins 0..63 for the even-n / odd-n classes.
-constexpr int OFF_SF = OFF_DB + 4;                 // [4 bin tiles][E|O][re|im][4 blocks][FRAG]
-constexpr int OFF_S0 = OFF_SF + 4 * 2 * 2 * 4 * 256;   // [2][64]   the n = 0 column (re, im) of bins 0..63
-constexpr int OFF_B64 = OFF_S0 + 128;              // [2][128] bin 64, time-folded (re, im), n = 1..128; then [4]: n = 0 (re, im)
-constexpr int OFF_FOLD = OFF_B64 + 256 + 4;        // [1] (+3 pad)  1.0 = folded pass valid
-constexpr int PACKED_FLOATS = OFF_FOLD + 4;
 
 // ---- encoder LDS map (floats): 52 624 B per workgroup => THREE workgroups per CU ------------------
 // One region is reused by every phase; a phase whose output would overwrite its own input keeps the
@@ -86,7 +67,6 @@ constexpr int PACKED_FLOATS = OFF_FOLD + 4;
 //   -> A3 [64][16 (+4)], A4 [128][16 (+4)]   (A1 is dead after conv2)
 // Conv zero padding is never stored: the Winograd input transform is written for zero frames -1 and 4, and the taps of
 // conv2..4 that would read padding are simply not issued.
-constexpr int X_LDM = 642;
 constexpr int V_LD = 100, A1_LD = 68, A2_LD = 36, A3_LD = 20, A4_LD = 20;
 constexpr int V_SCR = 129 * V_LD;                  // fold: [8 waves][2][16 clips]; dense: [4 frames][16 clips]
 constexpr int R0_FLOATS = V_SCR + 256;             // 13156  (X: 16*642 = 10272; A1 + A2: 128*68 + 64*36 = 11008)
@@ -101,84 +81,6 @@ __device__ constexpr float WINO_BT[6][4] = {{0.f, -5.f, 0.f, 1.f}, {-4.f, -4.f, 
                                             {-2.f, -1.f, 2.f, 1.f}, {2.f, -1.f, -2.f, 1.f}, {4.f, 0.f, -5.f, 0.f}};
 constexpr int ENC_THREADS = 512;
 
-// gx: per (t, group) 8 waves x 4 gates x 64 lanes x 4 floats
-constexpr int GX_TILE_FLOATS = 8 * 4 * 256;
-
-// m-major operand variant of gemm_pass for the STFT: act element (m, k) at act[m*ldm + k], this lane's
-// m = lane&15, the k consumed by (block S, sub-step j, quarter q) is 16S + q + 4j (the basis rows are
-// packed with the matching permutation, so weights still arrive as one 16-B load per block).
-template <int NT, int MT, int KB>
-__device__ __forceinline__ void gemm_pass_mmajor(f32x4 (&acc)[NT][MT], const float *act, int ldm,
-                                                 const int (&koff)[MT], const float *const (&wrow)[NT], int lane) {
-    const int q = lane >> 4, i = lane & 15;
-    const float *ap = act + i * ldm + q;
-    f32x4 wcur[NT], wnxt[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wcur[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 4 * q);
-#pragma unroll 1
-    for (int S = 0; S < KB; ++S) {
-        const int Sn = (S + 1 < KB) ? S + 1 : S;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wnxt[nt] = *reinterpret_cast<const f32x4 *>(wrow[nt] + 16 * Sn + 4 * q);
-        const float *aps = ap + 16 * S;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float av[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = aps[4 * j + koff[mt]];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float wj = wcur[nt][j];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(av[mt], wj, acc[nt][mt]);
-            }
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wcur[nt] = wnxt[nt];
-    }
-}
-
-// Folded STFT pass.  A windowed real-DFT basis (symmetric window) has two symmetries that the dense 258x256
-// conv ignores:
-//   time      c[k][256-n] =  c[k][n],  s[k][256-n] = -s[k][n]        -> contract x[n] +- x[256-n] over n = 1..128
-//   frequency c[128-k][n] = (-1)^n c[k][n],  s[128-k][n] = -(-1)^n s[k][n]
-//                                                                    -> bins k and 128-k share the partial sums over
-//                                                                       even n (E) and odd n (O): X[k] = E + O, X[128-k] = +-(E - O)
-// so bins 0..63 (4 tiles) over two 64-long contractions give all of bins 0..63 and 65..128: a quarter of the dense
-// pass's MFMAs, for two VALU adds per operand pair.  (Bin 64 pairs with itself and goes through the VALU.)
-// X is staged de-interleaved: per clip row an even-sample plane [0..320] and an odd-sample plane [321..641], so the
-// contraction index of either class walks its plane with unit stride (bank = 2*clip + q: conflict free).
-// Class E: n = 2m + 2 (plane index m + 1, mirror 127 - m); class O: n = 2m + 1 (plane index m, mirror 127 - m);
-// contraction slot (block S, sub-step j, quarter q) <-> m = 16S + q + 4j.
-constexpr int X_ODD = 322;            // offset of the odd plane inside a clip row (even: the staging code stores sample pairs 8 B wide)
-__device__ __forceinline__ void stft_fold_class(f32x4 (&are)[2], f32x4 (&aim)[2], const float *fwd, const float *rev,
-                                                const float *wre, const float *wim) {
-    f32x4 cre = *reinterpret_cast<const f32x4 *>(wre), cim = *reinterpret_cast<const f32x4 *>(wim);
-#pragma unroll
-    for (int S = 0; S < 4; ++S) {
-        const int Sn = (S + 1 < 4) ? S + 1 : S;
-        const f32x4 nre = *reinterpret_cast<const f32x4 *>(wre + FRAG * Sn);
-        const f32x4 nim = *reinterpret_cast<const f32x4 *>(wim + FRAG * Sn);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // (forming the two frames' operands as f32x2 pairs for v_pk_add_f32 -- half the adds -- costs more in register
-            // shuffles than it saves: 291 instead of 199 VALU instructions in this loop)
-            float e[2], o[2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const float a = fwd[16 * S + 4 * j + 64 * f], b = rev[64 * f - 16 * S - 4 * j];
-                e[f] = a + b;
-                o[f] = a - b;
-            }
-#pragma unroll
-            for (int f = 0; f < 2; ++f) are[f] = mfma16(e[f], cre[j], are[f]);
-#pragma unroll
-            for (int f = 0; f < 2; ++f) aim[f] = mfma16(o[f], cim[j], aim[f]);
-        }
-        cre = nre;
-        cim = nim;
-    }
-}
 
 // k-major pass that accumulates into acc[0][A0 .. A0+MT) of a wider accumulator array
 template <int MT, int KB, int A0, int AN>
@@ -205,10 +107,6 @@ __device__ __forceinline__ void gemm_pass_sub(f32x4 (&acc)[1][AN], const float *
 // Three Winograd planes side by side: acc[p] += V_p x U_p over KB blocks of 16 input channels.  Plane p's activations sit
 // 16 columns further right in the same LDS rows, its weights KB fragments further in this lane's stream; the three
 // accumulators alternate, so consecutive MFMAs are independent.
-// |STFT| magnitude: the bare v_sqrt_f32 (1 ulp).  sqrtf() is the correctly rounded, denormal-safe library routine -- about fifteen
-// VALU instructions per value -- and on gfx950 VALU work does not hide under v_mfma_f32_16x16x4_f32: the two ADD UP on a SIMD
-// (tools/mfma_valu_overlap.sh: 15.2 ns per MFMA alone, +1.8 ns per v_fma_f32 placed beside it, one or two waves per SIMD alike).
-__device__ __forceinline__ float mag_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 template <int KB>
 __device__ __forceinline__ void gemm_planes3(f32x4 &a0, f32x4 &a1, f32x4 &a2, const float *act, int lda, const float *w, int lane) {
@@ -274,24 +172,6 @@ __device__ __forceinline__ f32x4 gemm_chain(const float *act, int lda, const flo
     return acc0 + acc1;
 }
 
-// Sample fetch of phase 0: the reference feeds Silero float32 = int16 * 0.000030517578 (Silero/Inference_Silero_VAD_ONNX.py:83);
-// the PCM16 instantiation reads the int16 samples themselves (half the HBM read, no f32 copy of the batch) and applies
-// that very multiplication -- one f32 rounding, bit-identical to the host-side product.
-template <typename SampleT> struct SampleIO;
-template <> struct SampleIO<float> {
-    static constexpr int VEC_ALIGN = 16;
-    static __device__ __forceinline__ f32x4 load4(const float *p, float) { return *reinterpret_cast<const f32x4 *>(p); }
-    static __device__ __forceinline__ float load1(const float *p, float) { return *p; }
-};
-template <> struct SampleIO<int16_t> {
-    static constexpr int VEC_ALIGN = 8;
-    static __device__ __forceinline__ f32x4 load4(const int16_t *p, float scale) {
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
-        const s16x4 v = *reinterpret_cast<const s16x4 *>(p);
-        return f32x4{(float)v[0] * scale, (float)v[1] * scale, (float)v[2] * scale, (float)v[3] * scale};
-    }
-    static __device__ __forceinline__ float load1(const int16_t *p, float scale) { return (float)*p * scale; }
-};
 
 template <typename SampleT>
 __global__ __launch_bounds__(ENC_THREADS, 6) void silero_encode_kernel(
@@ -1050,7 +930,65 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
     memcpy(p + OFF_HH, w->lstm_w_hh, 512 * 128 * sizeof(float));
     memcpy(p + OFF_DW, w->dec_w, 128 * sizeof(float));
     p[OFF_DB] = w->dec_b[0];
+    // ---- the same conv / W_ih weights as bf16 x 3 fragments for the split-product encoder (silero_split.hip, split3.h)
+    for (int rt = 0; rt < 8; ++rt)
+        for (int kc = 0; kc < 4; ++kc)
+            for (int tap = 0; tap < 3; ++tap) {
+                float *f3 = p + OFF_Q1 + (size_t)(((rt * 4 + kc) * 3 + tap) * 3) * QF;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) {
+                        const int slot = 32 * kc + k, bin = slot <= 64 ? slot : 192 - slot;        // the order the STFT pass leaves the bins in
+                        vadx::qfrag_put(f3, i, k, w->enc_w[0][((size_t)(16 * rt + i) * 129 + bin) * 3 + tap]);
+                    }
+            }
+    for (int co = 0; co < 128; ++co)
+        for (int tap = 0; tap < 3; ++tap) p[OFF_Q1N + co * 4 + tap] = w->enc_w[0][((size_t)co * 129 + 128) * 3 + tap];
+    for (int rt = 0; rt < 4; ++rt)
+        for (int kc = 0; kc < 4; ++kc)
+            for (int tap = 0; tap < 3; ++tap) {
+                float *f3 = p + OFF_Q2 + (size_t)(((rt * 4 + kc) * 3 + tap) * 3) * QF;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) vadx::qfrag_put(f3, i, k, w->enc_w[1][((size_t)(16 * rt + i) * 128 + 32 * kc + k) * 3 + tap]);
+            }
+    for (int rt = 0; rt < 4; ++rt)
+        for (int th = 0; th < 2; ++th)
+            for (int kc = 0; kc < 2; ++kc) {
+                float *f3 = p + OFF_Q3 + (size_t)(((rt * 2 + th) * 2 + kc) * 3) * QF;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) vadx::qfrag_put(f3, i, k, w->enc_w[2][((size_t)(16 * rt + i) * 64 + 32 * kc + k) * 3 + th + 1]);
+            }
+    for (int rt = 0; rt < 8; ++rt)
+        for (int kc = 0; kc < 2; ++kc) {
+            float *f3 = p + OFF_Q4 + (size_t)((rt * 2 + kc) * 3) * QF;
+            for (int i = 0; i < 16; ++i)
+                for (int k = 0; k < 32; ++k) vadx::qfrag_put(f3, i, k, w->enc_w[3][((size_t)(16 * rt + i) * 64 + 32 * kc + k) * 3 + 1]);
+        }
+    for (int wv = 0; wv < 8; ++wv)
+        for (int kc = 0; kc < 4; ++kc)
+            for (int g = 0; g < 4; ++g) {
+                float *f3 = p + OFF_QIH + (size_t)(((wv * 4 + kc) * 4 + g) * 3) * QF;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) vadx::qfrag_put(f3, i, k, w->lstm_w_ih[(size_t)(g * 128 + wv * 16 + i) * 128 + 32 * kc + k]);
+            }
     return VADX_OK;
+}
+
+// Which encoder kernel the launches below use: 0 = exact-f32 MFMAs (silero_encode_kernel), 1 = bf16 x 3 split products
+// (silero_encode_split_kernel).  Process-wide; the default comes from VADX_SILERO_ENCODER ("f32" | "split") at the first use.
+static std::atomic<int> g_encoder_mode{-1};
+static int encoder_mode() {
+    int m = g_encoder_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char *e = getenv("VADX_SILERO_ENCODER");
+        m = (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : ((e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : VADX_SILERO_ENCODER_DEFAULT);
+        g_encoder_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+extern "C" int vadx_silero_encoder_mode(int mode) {
+    const int prev = encoder_mode();
+    if (mode == 0 || mode == 1) g_encoder_mode.store(mode, std::memory_order_relaxed);
+    return prev;
 }
 
 extern "C" size_t vadx_silero_workspace_bytes(int batch, int steps) {
@@ -1076,9 +1014,12 @@ static int silero_encode_launch(const float *packed, const S *src, float in_scal
         vadx::set_error("silero: workspace %zu B < required %zu B", ws_bytes, vadx_silero_workspace_bytes(total_batch, steps));
         return VADX_ENOSPACE;
     }
-    VADX_DYN_LDS(silero_encode_kernel<S>, ENC_LDS_FLOATS * sizeof(float));
     const long long nblk = (long long)G * steps;
     VADX_REQUIRE(nblk < (1LL << 31), "silero: too many tiles (%lld)", nblk);
+    if (encoder_mode() == 1)
+        return silero_encode_split_launch<S>(packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps, Gws, first_group,
+                                             static_cast<float *>(ws), stream);
+    VADX_DYN_LDS(silero_encode_kernel<S>, ENC_LDS_FLOATS * sizeof(float));
     hipLaunchKernelGGL(silero_encode_kernel<S>, dim3((unsigned)nblk), dim3(ENC_THREADS), ENC_LDS_FLOATS * sizeof(float),
                        static_cast<hipStream_t>(stream), packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps,
                        Gws, first_group, static_cast<float *>(ws));

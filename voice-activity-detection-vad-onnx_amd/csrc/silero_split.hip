@@ -1,0 +1,510 @@
+// silero_split.hip -- Silero-VAD v5 (16 kHz) encoder tile kernel on bf16 x 3 split products (csrc/split3.h), gfx950.
+//
+// Same work decomposition, same inputs and the same gx output as silero_encode_kernel (csrc/silero.hip): one workgroup per
+// (16 clips) x (1 window), STFT -> |.| -> conv1..conv4 (+ReLU) -> W_ih x + b.  What changes is the arithmetic of every GEMM whose one
+// operand is a constant (all of them but the STFT's time-folded operand sums): weights split offline into three bf16 planes, activations
+// split once by the lanes that produce them, six v_mfma_f32_16x16x32_bf16 per K = 32 step in place of eight v_mfma_f32_16x16x4_f32 --
+// 6/16 of the matrix time at float32-class accuracy (split3.h), with the VALU work hiding beside the matrix pipe instead of adding to it.
+//   * STFT: the folded float32 pass of silero.hip, operands swapped so that a lane ends up with four consecutive bins of one clip.
+//   * conv1 is the direct three-tap conv (a tap fragment serves up to four frames), 1920 bf16 MFMAs; conv2 480, conv3 96, conv4 96,
+//     W_ih 768: 3360 bf16 + 1024 f32 MFMAs per tile against 4480 f32.
+//   * activations live in LDS as three bf16 planes [k / 8][16 clips][8]: a wave's B-fragment read is one contiguous 1 KiB
+//     (ds_read_b128, conflict-free), a producer lane's four consecutive channels one 8-byte store per plane.
+//   * weights stream from L2 as 1 KiB fragments, 976 KB per tile (877 KB for the f32 kernel); tools/l2_stream_probe.sh: every CU
+//     streaming the same blob sustains 33 - 35 TB/s, this kernel needs ~20.
+// Reference being reproduced: the `session.run` of Silero/modeling_modified/utils_vad.py:116-119 (see silero.hip).
+#include "silero_common.h"
+#include "split3.h"
+
+// VADX_EXP: development-only what-if switches for tools/exp_encoder.py (results are wrong when set): bit 3 no conv2..4 MFMAs, 4 no STFT
+// MFMAs, 5 no conv1 MFMAs, 6 no W_ih MFMAs, 13 every weight fragment from one address (L1 instead of L2), 12 no activation splits
+// (planes written from the raw bits), 14 per-phase cycle accounting of wave 0 (sp_dbg, read with vadx_silero_split_debug_cycles)
+#ifndef VADX_EXP
+#define VADX_EXP 0
+#endif
+#define SP_SKIP(n) ((VADX_EXP >> (n)) & 1)
+#define SP_W(addr) (SP_SKIP(13) ? (P + vadx::silero::OFF_Q1) : (addr))        // what-if: every weight fragment from one (L1-resident) address
+#if (VADX_EXP >> 14) & 1
+__device__ unsigned long long sp_dbg[16];
+#define SP_T0() long long sp_t_ = __builtin_readcyclecounter()
+#define SP_MARK(slot) do { if (threadIdx.x == 0) { const long long n_ = __builtin_readcyclecounter(); atomicAdd(&sp_dbg[slot], (unsigned long long)(n_ - sp_t_)); sp_t_ = n_; } } while (0)
+extern "C" int vadx_silero_split_debug_cycles(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sp_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sp_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define SP_T0() do {} while (0)
+#define SP_MARK(slot) do {} while (0)
+#endif
+
+namespace vadx {
+namespace silero {
+
+constexpr int SP_THREADS = 512;
+// ---- LDS map (BYTES): 71 680 B per workgroup => two workgroups per CU (eight waves of <= 128 VGPRs each)
+//   R0 [0, 49152): X f32 [16 clips][642]  ->  |X| planes [3][4 frames][16 k-groups][16 clips][8 bf16]  ->  conv1 output planes (same shape)
+//                  ->  conv3 output planes [3][8][16][8] at 0 and conv4 output planes [3][16][16][8] at 8192
+//   R1 [49152, 61440): conv2 output planes [3][2 frames][8 k-groups][16][8]
+//   scratch f32 [512]: bin-64 partial sums [8 waves][re|im][16 clips]; Nyquist magnitudes [4 frames][16 clips] at +256
+//   exchange f32 [4 row tiles][2][64 lanes][4]: partial sums of the waves that own the other half of K (conv2, conv3)
+constexpr int SP_PL128 = 16384, SP_FR128 = 4096;
+constexpr int SP_R1 = 49152, SP_PL2 = 4096, SP_FR2 = 2048;
+constexpr int SP_C3 = 0, SP_PL3 = 2048;
+constexpr int SP_C4 = 8192, SP_PL4 = 4096;
+constexpr int SP_SCR = SP_R1 + 12288;
+constexpr int SP_EXC = SP_SCR + 2048;
+constexpr int SP_LDS_BYTES = SP_EXC + 8192;
+static_assert(16 * X_LDM * 4 <= SP_R1 && 3 * SP_PL128 <= SP_R1 && SP_C4 + 3 * SP_PL4 <= SP_R1 && SP_C3 + 3 * SP_PL3 <= SP_C4 &&
+              2 * SP_LDS_BYTES <= 160 * 1024, "split encoder LDS map");
+
+// byte offset of (k-group kg8 = k / 8, clip) inside one plane of one frame
+__device__ __forceinline__ int pl_off(int kg8, int clip) { return (kg8 * 16 + clip) * 16; }
+
+// a producer lane's four consecutive channels 4 g .. 4 g + 3 of clip i: one 8-byte store into each of the three planes
+__device__ __forceinline__ void store_split4(unsigned char *base, int plane_stride, int g, int i, const f32x4 v) {
+    u32x2 p0, p1, p2;
+    split3x4(v, p0, p1, p2);
+    unsigned char *d = base + pl_off(g >> 1, i) + (g & 1) * 8;
+    *reinterpret_cast<u32x2 *>(d) = p0;
+    *reinterpret_cast<u32x2 *>(d + plane_stride) = p1;
+    *reinterpret_cast<u32x2 *>(d + 2 * plane_stride) = p2;
+}
+__device__ __forceinline__ void store_split1(unsigned char *base, int plane_stride, int slot, int i, float v) {
+    unsigned short h0, h1, h2;
+    split3x1(v, h0, h1, h2);
+    unsigned char *d = base + pl_off(slot >> 3, i) + (slot & 7) * 2;
+    *reinterpret_cast<unsigned short *>(d) = h0;
+    *reinterpret_cast<unsigned short *>(d + plane_stride) = h1;
+    *reinterpret_cast<unsigned short *>(d + 2 * plane_stride) = h2;
+}
+// the wave's B fragments (three planes) of the 32-k chunk kc: lane 16 q + i reads k-group 4 kc + q of clip i
+__device__ __forceinline__ void load_b3(bf16x8 (&b)[3], const unsigned char *base, int plane_stride, int kc, int q, int i) {
+    const unsigned char *s = base + pl_off(4 * kc + q, i);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8 *>(s + p * plane_stride);
+}
+__device__ __forceinline__ void load_a3(bf16x8 (&a)[3], const float *frag3, int lane) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[p] = ldq(frag3 + p * QF, lane);
+}
+
+template <typename SampleT>
+__global__ __launch_bounds__(SP_THREADS, 4) void silero_encode_split_kernel(
+    const float *__restrict__ P, const SampleT *__restrict__ audio, float in_scale, long long n_samples,
+    long long row_stride, long long origin, int B, int G, int T, int Gws, int g0, float *__restrict__ gx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *X = reinterpret_cast<float *>(smem);
+    float *scr = reinterpret_cast<float *>(smem + SP_SCR), *nyq = scr + 256;
+    float *exc = reinterpret_cast<float *>(smem + SP_EXC);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, i = lane & 15;
+    const int grp = blockIdx.x % G, t = blockIdx.x / G;
+    const bool fold = P[OFF_FOLD] != 0.f;      // uniform: the basis has the DFT symmetries -> folded STFT pass
+    SP_T0();
+
+    // ---------------- phase 0: the 16 windows (576 samples each) + right reflect pad of 64 (as silero_encode_kernel stages them:
+    // folded pass -> even / odd samples in separate planes of the clip row)
+    auto xslot = [fold](int pp) { return fold ? (pp & 1) * X_ODD + (pp >> 1) : pp; };
+    {
+        const long long base = (long long)t * 512 + origin;
+        const bool vec_ok = ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(audio) & (SampleIO<SampleT>::VEC_ALIGN - 1)) == 0) && n_samples >= 4;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const bool fast = fold && vec_ok && base >= 0 && base + 576 <= n_samples && (long long)grp * 16 + 16 <= B;
+        if (fast) {     // wave w stages clips 2w and 2w+1: wave-uniform row base + 16 * lane bytes, six loads back to back
+            f32x4 xv[2][3];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const SampleT *src = audio + ((long long)grp * 16 + 2 * wv + k2) * row_stride + base;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int f = j < 2 ? lane + 64 * j : min(lane + 128, 143);
+                    xv[k2][j] = SampleIO<SampleT>::load4(src + 4 * f, in_scale);
+                }
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                float *row = X + (2 * wv + k2) * X_LDM;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int f = lane + 64 * j;
+                    if (j < 2 || lane < 16) {
+                        const f32x4 v = xv[k2][j];
+                        *reinterpret_cast<float2 *>(row + 2 * f) = float2{v[0], v[2]};
+                        *reinterpret_cast<float2 *>(row + X_ODD + 2 * f) = float2{v[1], v[3]};
+                        if (f >= 127) {                                               // samples 508..575: reflect pad (0, 64)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const int pp = 4 * f + jj;
+                                if (pp >= 511 && pp <= 574) row[xslot(1150 - pp)] = v[jj];
+                            }
+                        }
+                    }
+                }
+            }
+        } else {        // edge windows, short clips, groups past the batch: clamped unconditional loads, patched per element
+            f32x4 x4[5];
+            if (vec_ok) {
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    const int e = min(tid + SP_THREADS * it, 16 * 144 - 1), c = e / 144, p = 4 * (e - c * 144);
+                    const long long b = (long long)grp * 16 + c, idx = base + p;
+                    const SampleT *src = audio + (b < B ? b : 0) * row_stride;
+                    const long long idc = idx < 0 ? 0 : (idx + 3 < n_samples ? idx : ((n_samples - 4) & ~3LL));
+                    x4[it] = SampleIO<SampleT>::load4(src + idc, in_scale);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int e = tid + SP_THREADS * it;             // 16 clips x 144 float4
+                if (e < 16 * 144) {
+                    const int c = e / 144, p = 4 * (e - c * 144);
+                    const long long b = (long long)grp * 16 + c;
+                    const bool bvalid = b < B;
+                    const SampleT *src = audio + (bvalid ? b : 0) * row_stride;
+                    const long long idx = base + p;
+                    float v[4];
+                    if (vec_ok && bvalid && idx >= 0 && idx + 3 < n_samples) {
+                        v[0] = x4[it][0]; v[1] = x4[it][1]; v[2] = x4[it][2]; v[3] = x4[it][3];
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            v[jj] = (bvalid && idx + jj >= 0 && idx + jj < n_samples) ? SampleIO<SampleT>::load1(src + idx + jj, in_scale) : 0.f;
+                    }
+                    float *row = X + c * X_LDM;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int pp = p + jj;
+                        row[xslot(pp)] = v[jj];
+                        if (pp >= 511 && pp <= 574) row[xslot(1150 - pp)] = v[jj];       // reflect pad (0,64)
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    SP_MARK(0);
+
+    // ---------------- phase 1: STFT (float32 MFMAs, table = A operand) -> magnitudes -> the three bf16 planes of conv1's input.
+    // Input-channel slot s of conv1: s <= 64 = bin s, s = 64 + k = bin 128 - k; bin 128 (Nyquist) goes to the scratch.
+    if (fold) {
+        const int tl = wave & 3, fp = wave >> 2;      // wave = (bin tile tl, frame pair fp): bins k = 16 tl + 4 q + r and 128 - k
+        float b64re = 0.f, b64im = 0.f;               // bin 64 (its own mirror) on the VALU: wave = (frame wave & 3, half of n = 1..128)
+        {
+            const int f = wave & 3, h = wave >> 2, n0 = h * 64 + q * 16;
+            const float *xr = X + i * X_LDM + 64 * f;
+            f32x4 cre = ldg4(P + OFF_B64 + n0), cim = ldg4(P + OFF_B64 + 128 + n0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int un = u + 1 < 4 ? u + 1 : u;
+                const f32x4 nre = ldg4(P + OFF_B64 + n0 + 4 * un), nim = ldg4(P + OFF_B64 + 128 + n0 + 4 * un);
+#pragma unroll
+                for (int k3 = 0; k3 < 4; ++k3) {
+                    const int n = n0 + 4 * u + k3 + 1;                                // 1..128, mirror 256 - n
+                    const float a = xr[(n & 1) * X_ODD + (n >> 1)], b = xr[(n & 1) * X_ODD + ((256 - n) >> 1)];
+                    b64re = fmaf(a + b, cre[k3], b64re);
+                    b64im = fmaf(a - b, cim[k3], b64im);
+                }
+                cre = nre;
+                cim = nim;
+            }
+            b64re += __shfl_xor(b64re, 16); b64re += __shfl_xor(b64re, 32);
+            b64im += __shfl_xor(b64im, 16); b64im += __shfl_xor(b64im, 32);
+            if (h == 0) {                                                             // the n = 0 tap
+                const float x0 = xr[0];
+                b64re = fmaf(x0, P[OFF_B64 + 256], b64re);
+                b64im = fmaf(x0, P[OFF_B64 + 257], b64im);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 ere[2], eim[2], ore[2], oim[2];
+        const f32x4 c0 = ldg4(P + OFF_S0 + tl * 16 + 4 * q), s0 = ldg4(P + OFF_S0 + 64 + tl * 16 + 4 * q);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const float x0 = X[i * X_LDM + 64 * (2 * fp + f)];                        // n = 0 belongs to the even class
+            ere[f] = c0 * x0;
+            eim[f] = s0 * x0;
+            ore[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            oim[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!SP_SKIP(4)) {
+            const float *row = X + i * X_LDM + 128 * fp;
+            const float *wt = P + OFF_SF + tl * 16 * FRAG + lane * 4;                 // [E|O][re|im][4 blocks]
+            stft_fold_class<true>(ere, eim, row + 1 + q, row + 127 - q, wt, wt + 4 * FRAG);
+            stft_fold_class<true>(ore, oim, row + X_ODD + q, row + X_ODD + 127 - q, wt + 8 * FRAG, wt + 12 * FRAG);
+        }
+        f32x4 mk[2], mn[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = ere[f][r] + ore[f][r], pi = eim[f][r] + oim[f][r];
+                const float nr = ere[f][r] - ore[f][r], ni = eim[f][r] - oim[f][r];
+                mk[f][r] = mag_sqrt(pr * pr + pi * pi);
+                mn[f][r] = mag_sqrt(nr * nr + ni * ni);
+            }
+        __syncthreads();          // every wave is done reading X: the planes may now overwrite it
+        SP_MARK(1);
+        const int g = 4 * tl + q;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            unsigned char *fr = smem + (2 * fp + f) * SP_FR128;
+            store_split4(fr, SP_PL128, g, i, mk[f]);                  // slots 4 g + r        = bins 4 g + r
+            store_split4(fr, SP_PL128, 16 + g, i, mn[f]);             // slots 64 + 4 g + r   = bins 128 - (4 g + r); g = 0, r = 0 is bin 128:
+            if (g == 0) nyq[(2 * fp + f) * 16 + i] = mn[f][0];        //   it goes to the scratch, and slot 64 is rewritten below with bin 64
+        }
+        if (q == 0) { scr[wave * 32 + i] = b64re; scr[wave * 32 + 16 + i] = b64im; }
+        __syncthreads();
+        SP_MARK(2);
+        if (tid < 64) {                                               // bin 64: frame tid / 16, clip tid % 16
+            const int f = tid >> 4, c = tid & 15;
+            const float re = scr[f * 32 + c] + scr[(f + 4) * 32 + c], im = scr[f * 32 + 16 + c] + scr[(f + 4) * 32 + 16 + c];
+            store_split1(smem + f * SP_FR128, SP_PL128, 64, c, mag_sqrt(re * re + im * im));
+        }
+    } else {
+        // dense pass (a basis without the DFT symmetries): wave w = bins 16 w .. 16 w + 15, all four frames
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *const wrow[2] = {P + OFF_STFT + (wave * 32 + i) * 256, P + OFF_STFT + (wave * 32 + 16 + i) * 256};
+        const int koff[4] = {0, 128, 256, 384};
+        gemm_pass_mmajor<2, 4, 16, true>(acc, X, X_LDM, koff, wrow, lane);
+        float nyqv = 0.f;
+        if (wave < 4) {   // Nyquist bin: frame f = wave, lane = (clip i, k-quarter q)
+            const float *nre = P + OFF_NYQ + q * 64, *nim = P + OFF_NYQ + 256 + q * 64;
+            const float *xp = X + i * X_LDM + 128 * wave + q * 64;
+            float sre = 0.f, sim = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) {
+                const float x = xp[k];
+                sre = fmaf(x, nre[k], sre);
+                sim = fmaf(x, nim[k], sim);
+            }
+            sre += __shfl_xor(sre, 16); sre += __shfl_xor(sre, 32);
+            sim += __shfl_xor(sim, 16); sim += __shfl_xor(sim, 32);
+            nyqv = mag_sqrt(sre * sre + sim * sim);
+        }
+        __syncthreads();          // every wave is done reading X
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            f32x4 m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = mag_sqrt(acc[0][f][r] * acc[0][f][r] + acc[1][f][r] * acc[1][f][r]);
+            unsigned char *fr = smem + f * SP_FR128;
+            if (wave < 4) store_split4(fr, SP_PL128, 4 * wave + q, i, m);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bin = 16 * wave + 4 * q + r;
+                    store_split1(fr, SP_PL128, bin == 64 ? 64 : 192 - bin, i, m[r]);
+                }
+            }
+        }
+        if (wave < 4 && q == 0) nyq[wave * 16 + i] = nyqv;
+    }
+    __syncthreads();
+    SP_MARK(3);
+
+    // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU -- direct: out[f] = sum_tap W[tap] in[f + tap - 1], wave = 16 output channels
+    {
+        const int rt = wave;
+        f32x4 hi[4], lo[4];
+        {   // bias + input channel 128 (the Nyquist bin) on the VALU
+            const f32x4 bias = ldg4(P + OFF_B1 + 16 * rt + 4 * q);
+            f32x4 wn[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wn[r] = ldg4(P + OFF_Q1N + (16 * rt + 4 * q + r) * 4);
+            float nq[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) nq[f] = nyq[f * 16 + i];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaf(wn[r][1], nq[f], bias[r]);
+                    if (f > 0) v = fmaf(wn[r][0], nq[f - 1], v);
+                    if (f < 3) v = fmaf(wn[r][2], nq[f + 1], v);
+                    hi[f][r] = v;
+                }
+                lo[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const float *wq = P + OFF_Q1 + rt * (4 * 3 * 3 * QF);
+        bf16x8 a[2][3];
+        load_a3(a[0], SP_W(wq), lane);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            bf16x8 b[4][3];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) load_b3(b[f], smem + f * SP_FR128, SP_PL128, kc, q, i);
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const int s = kc * 3 + tap;
+                if (s + 1 < 12) load_a3(a[(s + 1) & 1], SP_W(wq + (s + 1) * 3 * QF), lane);
+                const bf16x8 (&ac)[3] = a[s & 1];
+                // six products per (frame, tap), frames innermost so that consecutive MFMAs hit different accumulators
+#define SP_TERM(AP, BP, ACC)                                                                  \
+    _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                           \
+        const int fi = f + tap - 1;                                                           \
+        if (fi >= 0 && fi < 4 && !SP_SKIP(5)) ACC[f] = mfma_bf16(ac[AP], b[fi][BP], ACC[f]);  \
+    }
+                SP_TERM(2, 0, lo) SP_TERM(1, 1, lo) SP_TERM(0, 2, lo) SP_TERM(1, 0, lo) SP_TERM(0, 1, lo) SP_TERM(0, 0, hi)
+#undef SP_TERM
+            }
+        }
+        __syncthreads();          // every wave is done reading the |X| planes: conv1's output may now overwrite them
+        SP_MARK(4);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = fmaxf(hi[f][r] + lo[f][r], 0.f);
+            store_split4(smem + f * SP_FR128, SP_PL128, 4 * rt + q, i, y);
+        }
+    }
+    __syncthreads();
+    SP_MARK(5);
+
+    // ---------------- phase 3: conv2 128->64, k3 s2 p1, ReLU: out frame o reads in frames 2 o - 1 .. 2 o + 1; wave = (16 channels, half of K)
+    {
+        const int rt = wave & 3, kh = wave >> 2;
+        f32x4 hi[2], lo[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) { hi[o] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[o] = hi[o]; }
+        const float *wq = P + OFF_Q2 + (rt * 4 + 2 * kh) * (3 * 3 * QF);
+        bf16x8 a[2][3];
+        load_a3(a[0], SP_W(wq), lane);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 b[4][3];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) load_b3(b[f], smem + f * SP_FR128, SP_PL128, 2 * kh + kk, q, i);
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const int s = kk * 3 + tap;
+                if (s + 1 < 6) load_a3(a[(s + 1) & 1], SP_W(wq + (s + 1) * 3 * QF), lane);
+                const bf16x8 (&ac)[3] = a[s & 1];
+#define SP_TERM(AP, BP, ACC)                                                                  \
+    _Pragma("unroll") for (int o = 0; o < 2; ++o) {                                           \
+        const int fi = 2 * o + tap - 1;                                                       \
+        if (fi >= 0 && !SP_SKIP(3)) ACC[o] = mfma_bf16(ac[AP], b[fi][BP], ACC[o]);            \
+    }
+                SP_TERM(2, 0, lo) SP_TERM(1, 1, lo) SP_TERM(0, 2, lo) SP_TERM(1, 0, lo) SP_TERM(0, 1, lo) SP_TERM(0, 0, hi)
+#undef SP_TERM
+            }
+        }
+        f32x4 s2[2] = {hi[0] + lo[0], hi[1] + lo[1]};
+        if (kh == 1) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) *reinterpret_cast<f32x4 *>(exc + ((rt * 2 + o) * 64 + lane) * 4) = s2[o];
+        }
+        __syncthreads();
+        if (kh == 0) {
+            const f32x4 bias = ldg4(P + OFF_B2 + 16 * rt + 4 * q);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const f32x4 other = *reinterpret_cast<const f32x4 *>(exc + ((rt * 2 + o) * 64 + lane) * 4);
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(s2[o][r] + other[r] + bias[r], 0.f);
+                store_split4(smem + SP_R1 + o * SP_FR2, SP_PL2, 4 * rt + q, i, y);
+            }
+        }
+    }
+    __syncthreads();
+    SP_MARK(6);
+
+    // ---------------- phase 4: conv3 64->64, k3 s2 p1, ReLU (one output frame; tap 0 reads padding): wave = (16 channels, tap 1 | 2)
+    {
+        const int rt = wave & 3, th = wave >> 2;      // tap th + 1 reads conv2's frame th
+        f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = hi;
+        const float *wq = P + OFF_Q3 + (rt * 2 + th) * (2 * 3 * QF);
+        bf16x8 a[2][3], b[2][3];
+        load_a3(a[0], SP_W(wq), lane);
+        load_a3(a[1], SP_W(wq + 3 * QF), lane);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) load_b3(b[kc], smem + SP_R1 + th * SP_FR2, SP_PL2, kc, q, i);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) if (!SP_SKIP(3)) mfma_split6(a[kc], b[kc], hi, lo);
+        f32x4 s3 = hi + lo;
+        if (th == 1) *reinterpret_cast<f32x4 *>(exc + (rt * 64 + lane) * 4) = s3;
+        __syncthreads();
+        if (th == 0) {
+            const f32x4 bias = ldg4(P + OFF_B3 + 16 * rt + 4 * q);
+            const f32x4 other = *reinterpret_cast<const f32x4 *>(exc + (rt * 64 + lane) * 4);
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = fmaxf(s3[r] + other[r] + bias[r], 0.f);
+            store_split4(smem + SP_C3, SP_PL3, 4 * rt + q, i, y);
+        }
+    }
+    __syncthreads();
+    SP_MARK(7);
+
+    // ---------------- phase 5: conv4 64->128, k3 s1 p1, ReLU (one frame in / out: centre tap only)
+    {
+        const int rt = wave;
+        f32x4 hi = ldg4(P + OFF_B4 + 16 * rt + 4 * q), lo = {0.f, 0.f, 0.f, 0.f};
+        const float *wq = P + OFF_Q4 + rt * (2 * 3 * QF);
+        bf16x8 a[2][3], b[2][3];
+        load_a3(a[0], SP_W(wq), lane);
+        load_a3(a[1], SP_W(wq + 3 * QF), lane);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) load_b3(b[kc], smem + SP_C3, SP_PL3, kc, q, i);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) if (!SP_SKIP(3)) mfma_split6(a[kc], b[kc], hi, lo);
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = fmaxf(hi[r] + lo[r], 0.f);
+        store_split4(smem + SP_C4, SP_PL4, 4 * rt + q, i, y);
+    }
+    __syncthreads();
+    SP_MARK(8);
+
+    // ---------------- phase 6: LSTM input projection, gate-major (D rows = hidden units 16 wave + 4 q + r, columns = clips)
+    {
+        f32x4 hi[4], lo[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            hi[g] = ldg4(P + OFF_BG + g * 128 + wave * 16 + 4 * q);
+            lo[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float *wq = P + OFF_QIH + wave * (4 * 4 * 3 * QF);
+        bf16x8 a[2][3];
+        load_a3(a[0], SP_W(wq), lane);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            bf16x8 b[3];
+            load_b3(b, smem + SP_C4, SP_PL4, kc, q, i);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int s = kc * 4 + g;
+                if (s + 1 < 16) load_a3(a[(s + 1) & 1], SP_W(wq + (s + 1) * 3 * QF), lane);
+                if (!SP_SKIP(6)) mfma_split6(a[s & 1], b, hi[g], lo[g]);
+            }
+        }
+        float *dst = gx + ((size_t)t * Gws + g0 + grp) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = hi[g] + lo[g];
+    }
+    SP_MARK(9);
+}
+
+template <typename S>
+int silero_encode_split_launch(const float *packed, const S *src, float in_scale, long long n_valid, long long row_stride,
+                               long long origin, int batch, int G, int steps, int Gws, int first_group, float *gx, void *stream) {
+    VADX_DYN_LDS(silero_encode_split_kernel<S>, SP_LDS_BYTES);
+    const long long nblk = (long long)G * steps;
+    hipLaunchKernelGGL(silero_encode_split_kernel<S>, dim3((unsigned)nblk), dim3(SP_THREADS), SP_LDS_BYTES, static_cast<hipStream_t>(stream),
+                       packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps, Gws, first_group, gx);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+template int silero_encode_split_launch<float>(const float *, const float *, float, long long, long long, long long, int, int, int, int, int, float *, void *);
+template int silero_encode_split_launch<int16_t>(const float *, const int16_t *, float, long long, long long, long long, int, int, int, int, int, float *, void *);
+
+}  // namespace silero
+}  // namespace vadx

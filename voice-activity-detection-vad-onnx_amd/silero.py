@@ -37,6 +37,19 @@ def _as_weight_dict(path_or_weights):
 WORKSPACE_CAP_BYTES = 8 << 30     # clips(): above this the gate-preactivation workspace is reused span by span
 
 
+ENCODER_MODES = {"f32": 0, "split": 1}
+
+
+def encoder_mode(mode=None):
+    """Which encoder kernel the launches use, process-wide (include/vadx.h: vadx_silero_encoder_mode): "f32" = exact-f32 MFMAs,
+    "split" = bf16 x 3 split products (float32-class accuracy at 6/16 of the matrix time).  Returns the mode that was active;
+    `None` only queries.  The initial mode comes from VADX_SILERO_ENCODER."""
+    names = {v: k for k, v in ENCODER_MODES.items()}
+    if mode is not None and mode not in ENCODER_MODES:
+        raise ValueError(f"encoder mode must be one of {sorted(ENCODER_MODES)}, got {mode!r}")
+    return names[_lib.lib().vadx_silero_encoder_mode(-1 if mode is None else ENCODER_MODES[mode])]
+
+
 class SileroEngine:
     """Device-resident packed weights + workspace; thin wrappers over the C ABI."""
 
