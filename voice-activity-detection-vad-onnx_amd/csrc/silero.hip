@@ -970,6 +970,13 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
                 for (int i = 0; i < 16; ++i)
                     for (int k = 0; k < 32; ++k) vadx::qfrag_put(f3, i, k, w->lstm_w_ih[(size_t)(g * 128 + wv * 16 + i) * 128 + 32 * kc + k]);
             }
+    for (int wv = 0; wv < 8; ++wv)
+        for (int g = 0; g < 4; ++g)
+            for (int kc = 0; kc < 4; ++kc) {
+                float *f3 = p + OFF_QHH + (size_t)(((wv * 4 + g) * 4 + kc) * 3) * QF;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) vadx::qfrag_put(f3, i, k, w->lstm_w_hh[(size_t)(g * 128 + wv * 16 + i) * 128 + 32 * kc + k]);
+            }
     return VADX_OK;
 }
 
@@ -1036,6 +1043,8 @@ static int silero_recur_launch(const float *packed, const void *ws, size_t ws_by
         return VADX_ENOSPACE;
     }
     const int G = (batch + 15) / 16;
+    if (encoder_mode() == 1)
+        return silero_lstm_split_launch(packed, static_cast<const float *>(ws), state0, batch, G, steps, probs, probs_stride, state_n, stream);
     hipLaunchKernelGGL(silero_lstm_kernel, dim3(G), dim3(LSTM_THREADS), LSTM_LDS_FLOATS * sizeof(float),
                        static_cast<hipStream_t>(stream), packed, static_cast<const float *>(ws), state0, batch, G, steps,
                        probs, probs_stride, state_n);

@@ -46,7 +46,8 @@ constexpr int OFF_Q2 = OFF_Q1N + 128 * 4;                 // [4 oc tiles][4 chun
 constexpr int OFF_Q3 = OFF_Q2 + 4 * 4 * 3 * 3 * QF;       // [4 oc tiles][2 taps (1, 2)][2 chunks][3 planes][QF]
 constexpr int OFF_Q4 = OFF_Q3 + 4 * 2 * 2 * 3 * QF;       // [8 oc tiles][2 chunks][3 planes][QF]   centre tap
 constexpr int OFF_QIH = OFF_Q4 + 8 * 2 * 3 * QF;          // [8 unit tiles][4 chunks][4 gates][3 planes][QF]
-constexpr int PACKED_FLOATS = OFF_QIH + 8 * 4 * 4 * 3 * QF;
+constexpr int OFF_QHH = OFF_QIH + 8 * 4 * 4 * 3 * QF;     // [8 unit tiles][4 gates][4 chunks][3 planes][QF]   W_hh for the split recurrent kernel
+constexpr int PACKED_FLOATS = OFF_QHH + 8 * 4 * 4 * 3 * QF;
 
 constexpr int X_LDM = 642;            // staged window row: 576 samples + 64 reflect pad (+2: bank = 2 clip + q, conflict free)
 // gx: per (t, group) 8 waves x 4 gates x 64 lanes x 4 floats
@@ -159,6 +160,9 @@ template <> struct SampleIO<int16_t> {
 template <typename S>
 int silero_encode_split_launch(const float *packed, const S *src, float in_scale, long long n_valid, long long row_stride,
                                long long origin, int batch, int G, int steps, int Gws, int first_group, float *gx, void *stream);
+
+int silero_lstm_split_launch(const float *packed, const float *gx, const float *state0, int batch, int G, int steps, float *probs,
+                             long long probs_stride, float *state_n, void *stream);
 
 }  // namespace silero
 }  // namespace vadx

@@ -493,6 +493,136 @@ __global__ __launch_bounds__(SP_THREADS, 4) void silero_encode_split_kernel(
     SP_MARK(9);
 }
 
+// ---- persistent LSTM on split products ---------------------------------------------------------
+// Same decomposition as silero_lstm_kernel (silero.hip): one persistent workgroup per 16 clips, wave w owns hidden units 16 w .. 16 w + 15
+// of all four gates, W_hh resident for the whole clip, h exchanged through double-buffered LDS, one barrier per step.  W_hh x h runs as
+// bf16 x 3 split products: 96 v_mfma_f32_16x16x32_bf16 per wave and step instead of 128 v_mfma_f32_16x16x4_f32 (6/16 of the matrix
+// time).  W_hh's planes 0 and 1 stay in VGPRs (128 registers, as many as the f32 rows took); plane 2 -- used by one product in six -- sits in
+// LDS in fragment order (128 KB, one copy per CU: a wave reads its 1 KiB fragments back with ds_read_b128).  h is split by the lanes that
+// produce it (four consecutive units of one clip = one 8-byte store per plane).
+constexpr int LS_H = 0;                          // h planes [2 buffers][3 planes][16 k-groups][16 clips][8 bf16] = 2 x 12 288 B
+constexpr int LS_HPL = 4096, LS_HBUF = 12288;
+constexpr int LS_PART = 2 * LS_HBUF;             // f32 [2][8 waves][16 clips]
+constexpr int LS_W2 = LS_PART + 1024;            // W_hh plane 2: [8 waves][4 gates][4 chunks][64 lanes][16 B] = 131 072 B
+constexpr int LS_BYTES = LS_W2 + 131072;
+static_assert(LS_BYTES <= 160 * 1024, "split LSTM LDS map");
+
+__global__ __launch_bounds__(512, 2) void silero_lstm_split_kernel(
+    const float *__restrict__ P, const float *__restrict__ gx, const float *__restrict__ state0,
+    int B, int G, int T, float *__restrict__ probs, long long probs_stride, float *__restrict__ state_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *part = reinterpret_cast<float *>(smem + LS_PART);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int grp = blockIdx.x;
+    const long long b = (long long)grp * 16 + n;
+    const bool bvalid = b < B;
+    const int u0 = wave * 16 + 4 * q;             // this lane's 4 hidden units
+
+    // W_hh fragments of this wave's 4 gate tiles: planes 0, 1 -> 128 VGPRs for the whole clip, plane 2 -> LDS
+    bf16x8 a[4][4][2];
+    {
+        const float *wq = P + OFF_QHH + (size_t)wave * (4 * 4 * 3 * QF);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const float *f3 = wq + (g * 4 + kc) * 3 * QF;
+                a[g][kc][0] = ldq(f3, lane);
+                a[g][kc][1] = ldq(f3 + QF, lane);
+                *reinterpret_cast<bf16x8 *>(smem + LS_W2 + (((wave * 4 + g) * 4 + kc) * 64 + lane) * 16) = ldq(f3 + 2 * QF, lane);
+            }
+    }
+    const f32x4 dw = ldg4(P + OFF_DW + u0);
+    const float db = P[OFF_DB];
+
+    f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
+    if (state0 != nullptr && bvalid) {
+        h = *reinterpret_cast<const f32x4 *>(state0 + b * 128 + u0);
+        c = *reinterpret_cast<const f32x4 *>(state0 + ((long long)B + b) * 128 + u0);
+    }
+    store_split4(smem + LS_H, LS_HPL, 4 * wave + q, n, h);
+    __syncthreads();
+
+    const float *gsrc = gx + (size_t)grp * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
+    const size_t gstep = (size_t)G * GX_TILE_FLOATS;
+    f32x4 gcur[4], gnxt[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gcur[g] = *reinterpret_cast<const f32x4 *>(gsrc + g * 256);
+
+    const unsigned char *w2 = smem + LS_W2 + (size_t)(wave * 16 * 64 + lane) * 16;
+    int cur = 0;
+    for (int t = 0; t < T; ++t) {
+        const int tn = (t + 1 < T) ? t + 1 : t;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gnxt[g] = *reinterpret_cast<const f32x4 *>(gsrc + tn * gstep + g * 256);
+
+        f32x4 hi[4], lo[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { hi[g] = gcur[g]; lo[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const unsigned char *hb = smem + LS_H + cur * LS_HBUF;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            bf16x8 bb[3];
+            load_b3(bb, hb, LS_HPL, kc, q, n);
+            bf16x8 a2[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a2[g] = *reinterpret_cast<const bf16x8 *>(w2 + (g * 4 + kc) * 64 * 16);
+            // the six products, gates innermost so that consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lo[g] = mfma_bf16(a2[g], bb[0], lo[g]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lo[g] = mfma_bf16(a[g][kc][1], bb[1], lo[g]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lo[g] = mfma_bf16(a[g][kc][0], bb[2], lo[g]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lo[g] = mfma_bf16(a[g][kc][1], bb[0], lo[g]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lo[g] = mfma_bf16(a[g][kc][0], bb[1], lo[g]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) hi[g] = mfma_bf16(a[g][kc][0], bb[0], hi[g]);
+        }
+        float dpart = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ig = gate_sigmoid(hi[0][r] + lo[0][r]), fg = gate_sigmoid(hi[1][r] + lo[1][r]);
+            const float gg = gate_tanh(hi[2][r] + lo[2][r]), og = gate_sigmoid(hi[3][r] + lo[3][r]);
+            c[r] = fg * c[r] + ig * gg;
+            h[r] = og * gate_tanh(c[r]);
+            dpart = fmaf(dw[r], fmaxf(h[r], 0.f), dpart);
+        }
+        const int nxt = cur ^ 1;
+        store_split4(smem + LS_H + nxt * LS_HBUF, LS_HPL, 4 * wave + q, n, h);
+        dpart += __shfl_xor(dpart, 16);
+        dpart += __shfl_xor(dpart, 32);
+        if (q == 0) part[(nxt * 8 + wave) * 16 + n] = dpart;
+        __syncthreads();
+        if (wave == 0 && lane < 16 && bvalid) {
+            float s = db;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += part[(nxt * 8 + w) * 16 + lane];
+            probs[b * probs_stride + t] = sigmoidf_(s);
+        }
+        cur = nxt;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gcur[g] = gnxt[g];
+    }
+    if (state_n != nullptr && bvalid) {
+        *reinterpret_cast<f32x4 *>(state_n + b * 128 + u0) = h;
+        *reinterpret_cast<f32x4 *>(state_n + ((long long)B + b) * 128 + u0) = c;
+    }
+}
+
+int silero_lstm_split_launch(const float *packed, const float *gx, const float *state0, int batch, int G, int steps, float *probs,
+                             long long probs_stride, float *state_n, void *stream) {
+    VADX_DYN_LDS(silero_lstm_split_kernel, LS_BYTES);
+    hipLaunchKernelGGL(silero_lstm_split_kernel, dim3(G), dim3(512), LS_BYTES, static_cast<hipStream_t>(stream), packed, gx, state0, batch, G,
+                       steps, probs, probs_stride, state_n);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
 template <typename S>
 int silero_encode_split_launch(const float *packed, const S *src, float in_scale, long long n_valid, long long row_stride,
                                long long origin, int batch, int G, int steps, int Gws, int first_group, float *gx, void *stream) {
