@@ -64,6 +64,29 @@ FLOP_RECUR = 2 * MAC_HH
 MFMA_PER_TILE = 1024 + 1536 + 640 + 128 + 128 + 1024
 FLOP_ENCODE_ISSUED = MFMA_PER_TILE * 2048 // 16
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = f32 vector rate
+# The split-product kernels (csrc/split3.h: every constant-weight GEMM as SIX v_mfma_f32_16x16x32_bf16 per K = 32 step on exactly split
+# float32 operands) are priced against the f32-EQUIVALENT peak of that pipe: the dense bf16 MFMA peak / 6 -- never against 157.3.
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# split-product encoder (csrc/silero_split.hip), per 16-window tile: the folded STFT stays on f32 MFMAs (1024), everything else is
+# bf16 MFMAs in groups of six: direct conv1 1920, conv2 480, conv3 96, conv4 96, W_ih 768 = 3360, i.e. 560 K = 32 steps of 16 x 16 outputs
+SPLIT_F32_MFMA_PER_TILE = 1024
+SPLIT_BF16_MFMA_PER_TILE = 1920 + 480 + 96 + 96 + 768
+FLOP_SPLIT_F32_PART = SPLIT_F32_MFMA_PER_TILE * 2048 // 16                  # per window, on the f32 pipe
+FLOP_SPLIT_BF16_PART = SPLIT_BF16_MFMA_PER_TILE // 6 * 16384 // 16          # per window, f32-equivalent flops of the split products
+
+
+def encoder_roofline(mode, frames, enc_ms):
+    """(achieved TFLOP/s, peak TFLOP/s, flop per frame, note) of one encoder launch.  f32 kernel: issued f32-MFMA flops against 157.3.
+    Split kernel: f32 flops of the STFT part + f32-EQUIVALENT flops of the split products, against the peak of that mix = total flops /
+    (f32 part / 157.3 + split part / (2500 / 6)) -- the time the two matrix pipes need at their own peaks, back to back."""
+    if mode != "split":
+        return frames * FLOP_ENCODE_ISSUED / (enc_ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS, FLOP_ENCODE_ISSUED, "issued f32-MFMA flops"
+    fl = FLOP_SPLIT_F32_PART + FLOP_SPLIT_BF16_PART
+    t_min = FLOP_SPLIT_F32_PART / PEAK_F32_MFMA_TFLOPS + FLOP_SPLIT_BF16_PART / PEAK_SPLIT_TFLOPS          # 1e-12 s per frame
+    return frames * fl / (enc_ms * 1e-3) / 1e12, fl / t_min, fl, (
+        f"{FLOP_SPLIT_F32_PART} f32-MFMA flops (STFT) + {FLOP_SPLIT_BF16_PART} f32-equivalent flops of bf16 x 3 split products per frame; peak = "
+        "that mix at 157.3 and 2500 / 6 TFLOP/s")
 PEAK_HBM_GBPS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak
 # SURVEY 8(d): algorithmic HBM bytes per 512-sample window on the Silero path = 2048 B of float32 PCM in (as the reference
 # feeds it) + one 4-byte score out.  The encoder -> LSTM intermediate `gx` (2048 B written + 2048 B read per window) is
@@ -135,6 +158,11 @@ def instruction_mix(kernel="silero_encode_kernel"):
                     "model": f"{NS_PER_MFMA} ns per v_mfma_f32_16x16x4_f32 + {NS_PER_VALU} ns per VALU instruction per SIMD, additive "
                              "(tools/mfma_valu_overlap.sh)", "source": os.path.relpath(path, ROOT)}
     return best
+
+
+def enc_kernel_name():
+    from vadx import silero
+    return "silero_encode_split_kernel" if silero.encoder_mode() == "split" else "silero_encode_kernel"
 
 
 def synth_batch(torch, device, batch, samples, seed, pcm16=False):
@@ -482,7 +510,7 @@ def main(argv=None):
     enc_all = sorted(e[0].elapsed_time(e[1]) for e in events)
     enc_stats = {"mean": enc_ms, "median": float(np.median(enc_all)), "min": enc_all[0], "max": enc_all[-1], "launches": len(enc_all),
                  "basis": "roofline.achieved uses `mean` = the average of this run's HIP-event launch durations",
-                 "committed_profile": profiled_launch_ms("silero_encode_kernel") if (B, T) == (CLIPS_PER_GPU, STEPS_PER_CLIP) else None}
+                 "committed_profile": profiled_launch_ms(enc_kernel_name()) if (B, T) == (CLIPS_PER_GPU, STEPS_PER_CLIP) else None}
     assert int(counts.max().item()) <= cap, "segment table overflow"
     assert bool(torch.isfinite(probs).all())
     n_seg = int(counts.sum().item())
@@ -490,7 +518,11 @@ def main(argv=None):
 
     frames_per_step = world * B * T
     value = frames_per_step * args.steps / elapsed
-    achieved = (B * T * FLOP_ENCODE_ISSUED) / (enc_ms * 1e-3) / 1e12
+    enc_mode = silero.encoder_mode()
+    enc_kernel = "silero_encode_split_kernel" if enc_mode == "split" else "silero_encode_kernel"
+    rec_kernel = "silero_lstm_split_kernel" if enc_mode == "split" else "silero_lstm_kernel"
+    achieved, enc_peak, enc_flop, enc_note = encoder_roofline(enc_mode, B * T, enc_ms)
+    rec_peak = PEAK_SPLIT_TFLOPS if enc_mode == "split" else PEAK_F32_MFMA_TFLOPS
 
     # ---- the same batch from pinned host int16, upload overlapped with compute (every rank feeds its own GPU at once)
     feed = None
@@ -570,9 +602,14 @@ def main(argv=None):
 
     if rank == 0:
         full = (B, T) == (CLIPS_PER_GPU, STEPS_PER_CLIP)
-        tr_enc = profiled_traffic("silero_encode_kernel") if full else None
-        tr_rec = profiled_traffic("silero_lstm_kernel") if full else None
-        mix_enc = instruction_mix("silero_encode_kernel") if full else None
+        tr_enc = profiled_traffic(enc_kernel) if full else None
+        tr_rec = profiled_traffic(rec_kernel) if full else None
+        # the additive VALU : MFMA cost model was measured for f32-input MFMAs (they share the vector datapath); beside bf16 MFMAs VALU work
+        # hides (tools/bf16x3_probe.sh), so the split kernels carry the counts without a model ceiling
+        mix_enc = instruction_mix(enc_kernel) if full else None
+        if mix_enc and enc_mode == "split":
+            mix_enc["ceiling_frac"] = None
+            mix_enc["model"] = "none: VALU instructions hide beside bf16 MFMAs (tools/bf16x3_probe.sh)"
         algo_launch = B * T * ALGO_BYTES_PER_WINDOW
         step_traffic = (tr_enc["bytes"] + tr_rec["bytes"]) if (tr_enc and tr_rec) else None
         step_s = elapsed / args.steps
@@ -583,33 +620,36 @@ def main(argv=None):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Silero-VAD f32, batch=4096 synthetic 10 s @16 kHz clips per GPU "
                                    "(STFT conv + conv1d stack + LSTM cell HIP, seeded synthetic weights)",
+                       "arithmetic": ("float32 results from bf16 x 3 exact-split products on the bf16 matrix pipe (csrc/split3.h)" if enc_mode == "split"
+                                      else "float32 MFMAs (v_mfma_f32_16x16x4_f32)"),
                        "clips_per_gpu": B, "samples_per_clip": SAMPLES, "frames_per_clip": T,
                        "parallelism": f"clip-sharded x{world}, no collective"},
             "per_gpu_value": value / world, "rtf_batch1": rtf_b1,
-            "kernel_ms": {"silero_encode_kernel": enc_ms, "silero_lstm_kernel": rec_ms, "silero_segments_kernel": seg_ms},
+            "kernel_ms": {enc_kernel: enc_ms, rec_kernel: rec_ms, "silero_segments_kernel": seg_ms},
             "encoder_launch_ms": enc_stats,
             "segments_found": n_seg,
             # achieved = the flops the kernel's algorithm needs (MFMA-issued: folded DFT, no padding taps) / its time;
             # the reference's dense arithmetic would count FLOP_ENCODE per frame ("dense_equivalent").
             # Bytes follow SURVEY 8(d): algorithmic = 2048 B f32 PCM in + 4 B score out per window; `traffic` = the encoder
             # launch's counted HBM bytes (it also writes the 2048 B/window gx intermediate the LSTM kernel re-reads).
-            "roofline": {"bound": "mfma", "kernel": "silero_encode_kernel", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": enc_kernel, "achieved": achieved,
+                         "peak": enc_peak, "unit": "TFLOP/s", "frac": achieved / enc_peak,
+                         "arithmetic": enc_mode, "flops_counted": enc_note,
                          "traffic": tr_enc["bytes"] if tr_enc else None, "traffic_unit": "B/launch",
                          "traffic_source": tr_enc["source"] if tr_enc else None,
                          "algorithmic_bytes_per_launch": algo_launch,
                          "traffic_ratio": (tr_enc["bytes"] / algo_launch) if tr_enc else None,
-                         "flop_per_frame": FLOP_ENCODE_ISSUED, "frames_per_launch": B * T,
+                         "flop_per_frame": enc_flop, "frames_per_launch": B * T,
                          "dense_equivalent": {"flop_per_frame": FLOP_ENCODE,
-                                              "achieved": achieved * FLOP_ENCODE / FLOP_ENCODE_ISSUED},
+                                              "achieved": achieved * FLOP_ENCODE / enc_flop},
                          # what this kernel's own instruction mix allows of the peak (VALU time adds to f32-MFMA time on gfx950)
                          "instruction_mix": mix_enc},
             # the recurrent kernel is matrix-pipe work too (W_hh x h, 16 clips = one MFMA tile wide): its own fraction
-            "roofline_recurrent": {"bound": "mfma", "kernel": "silero_lstm_kernel", "flop_per_frame": FLOP_RECUR,
-                                   "achieved": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "roofline_recurrent": {"bound": "mfma", "kernel": rec_kernel, "flop_per_frame": FLOP_RECUR,
+                                   "achieved": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12, "peak": rec_peak, "arithmetic": enc_mode,
+                                   "unit": "TFLOP/s", "frac": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12 / rec_peak,
                                    "traffic": tr_rec["bytes"] if tr_rec else None,
-                                   "instruction_mix": instruction_mix("silero_lstm_kernel") if full else None},
+                                   "instruction_mix": instruction_mix(rec_kernel) if full else None},
             # the north star's HBM view of the whole step: SURVEY 8(d) algorithmic bytes / step time against 8 TB/s, and what
             # the step really moves (encoder + LSTM launches, PMC) over the algorithmic bytes
             "hbm": {"algorithmic_bytes_per_frame": ALGO_BYTES_PER_WINDOW, "algorithmic_bytes_per_step": algo_launch,

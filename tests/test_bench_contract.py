@@ -48,7 +48,7 @@ def test_secondary_flop_formulas():
     for fused in (False, True):
         e = bm.flop_dfsmn_by_entry(fused)
         assert sum(e.values()) == net and all(v >= 0 for v in e.values())
-    assert bm.flop_dfsmn_by_entry(True)["pw_conv"] < 0.05 * d["pw_conv"]
+    assert bm.flop_dfsmn_by_entry(True)["pw_conv"] < 0.06 * d["pw_conv"]
 
 
 def test_cpu_baseline_is_bounded_and_reports_the_protocol():

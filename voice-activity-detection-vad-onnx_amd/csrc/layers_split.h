@@ -1,0 +1,143 @@
+// layers_split.h -- dense layer on LDS-resident activations as bf16 x 3 split products (csrc/split3.h): the split-product counterpart of
+// layers.h for the FSMN / FireRed nets.
+//
+// Activations are three bf16 planes [k / 8][NCOL columns][8] (NCOL a multiple of 16: a wave's ds_read_b128 of one (k-group, 16 columns)
+// block per quarter is conflict-free); weights are A fragments [n-tile][32-k chunk][plane][QFRAG] streamed from L2 one chunk ahead.
+// A layer chooses its output orientation by which operand the weights are:
+//   OUT_PLANES  weights = A operand: D rows = output channels, a lane holds four consecutive channels of one column -> one 8-byte store
+//               into each plane of the next layer's input (bias, ReLU, split3 in the epilogue);
+//   OUT_F32     activations = A operand: D rows = columns (frames), a lane holds four consecutive frames of one channel -> one 16-byte
+//               float32 store into a k-major [channel][frame] buffer (the FIR's input with its history columns, the softmax's logits).
+// Same fragments either way (lane 16 g + i supplies eight consecutive k of row / column i).
+#pragma once
+#include "common.h"
+#include "split3.h"
+
+namespace vadx {
+
+struct QLayerArgs {
+    const float *W;                 // A fragments of tile nt: W + nt * nchunks * 3 * QFRAG; chunk kc, plane p at (kc * 3 + p) * QFRAG
+    int ntiles, nchunks;
+    const float *bias;              // [ntiles * 16] or nullptr
+    int relu;
+    const unsigned char *act;       // input planes (LDS), plane p at act + p * act_pl
+    int act_pl;
+    unsigned char *dst;             // OUT_PLANES: planes base, plane stride dst_pl, NCOL = dst_ncol; OUT_F32: float buffer
+    int dst_pl, dst_ncol;           // OUT_F32: dst_ncol = row stride in floats, dst_pl = first column
+    float *exch;                    // LDS scratch (>= MTT * 256 floats) for a leftover n-tile split over K halves (may be nullptr if ntiles % 8 == 0)
+};
+
+// One group of NT n-tiles x MTT column tiles.  baddr(kgrp, mt) -> byte offset (inside a plane) of this lane's 16-byte B block of
+// k-group kgrp in column tile mt, or of a block of zeros when kgrp lies beyond the layer's K.
+template <int NT, int MTT, bool OUT_PLANES, typename BAddr>
+__device__ __forceinline__ void qgemm_group(f32x4 (&hi)[NT][MTT], f32x4 (&lo)[NT][MTT], const float *const (&w)[NT], int kc0, int kc1,
+                                            const unsigned char *act, int act_pl, BAddr baddr, int lane) {
+    const int q = lane >> 4;
+    bf16x8 a0[NT][3], a1[NT][3];
+    auto load_a = [&](int kc, bf16x8 (&a)[NT][3]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[nt][p] = ldq(w[nt] + (size_t)(kc * 3 + p) * QFRAG, lane);
+    };
+    auto step = [&](int kc, const bf16x8 (&a)[NT][3]) {
+        bf16x8 b[MTT][3];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
+            const unsigned char *s = act + baddr(4 * kc + q, mt);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[mt][p] = *reinterpret_cast<const bf16x8 *>(s + p * act_pl);
+        }
+        // six products per (n-tile, column tile), tiles innermost: consecutive MFMAs hit different accumulators
+#define QL_TERM(AP, BP, ACC)                                                                                                   \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int mt = 0; mt < MTT; ++mt)                       \
+        ACC[nt][mt] = OUT_PLANES ? mfma_bf16(a[nt][AP], b[mt][BP], ACC[nt][mt]) : mfma_bf16(b[mt][BP], a[nt][AP], ACC[nt][mt]);
+        QL_TERM(2, 0, lo) QL_TERM(1, 1, lo) QL_TERM(0, 2, lo) QL_TERM(1, 0, lo) QL_TERM(0, 1, lo) QL_TERM(0, 0, hi)
+#undef QL_TERM
+    };
+    load_a(kc0, a0);
+    for (int kc = kc0; kc < kc1; kc += 2) {
+        if (kc + 1 < kc1) load_a(kc + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);      // the next chunk's fragments are requested before this chunk's MFMAs issue
+        step(kc, a0);
+        if (kc + 1 < kc1) {
+            if (kc + 2 < kc1) load_a(kc + 2, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            step(kc + 1, a1);
+        }
+    }
+}
+
+template <int MTT, bool OUT_PLANES>
+__device__ __forceinline__ void qlayer_store(const QLayerArgs &a, int nt, int mt, f32x4 v, int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    if (OUT_PLANES) {
+        if (a.bias) v += ldg4(a.bias + nt * 16 + 4 * q);
+        if (a.relu)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        u32x2 p0, p1, p2;
+        split3x4(v, p0, p1, p2);
+        const int g = 4 * nt + q;
+        unsigned char *d = a.dst + ((g >> 1) * a.dst_ncol + mt * 16 + i) * 16 + (g & 1) * 8;
+        *reinterpret_cast<u32x2 *>(d) = p0;
+        *reinterpret_cast<u32x2 *>(d + a.dst_pl) = p1;
+        *reinterpret_cast<u32x2 *>(d + 2 * a.dst_pl) = p2;
+    } else {
+        const float b = a.bias ? ldg1(a.bias + nt * 16 + i) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] += b; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
+        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(a.dst) + (nt * 16 + i) * a.dst_ncol + a.dst_pl + mt * 16 + 4 * q) = v;
+    }
+}
+
+// dst = W x act (+bias, ReLU).  n-tiles go to the waves round-robin, two rounds side by side where there are that many; one leftover
+// n-tile (9 tiles on 8 waves) is split into (column tile, K half) items whose halves meet through `exch` in a fixed order.
+template <int MTT, bool OUT_PLANES, typename BAddr>
+__device__ __forceinline__ void qlayer(const QLayerArgs &a, BAddr baddr) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    asm volatile("" : "+v"(lane), "+v"(wave));      // nothing per-lane is hoisted out of the enclosing tile / window loops (layers.h)
+    const int NW = blockDim.x >> 6;
+    const int full = (a.ntiles / NW) * NW;
+    const size_t tstride = (size_t)a.nchunks * 3 * QFRAG;
+    int nt0 = wave;
+    for (; nt0 + NW < full; nt0 += 2 * NW) {
+        f32x4 hi[2][MTT], lo[2][MTT];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) { hi[h][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[h][mt] = hi[h][mt]; }
+        const float *const w[2] = {a.W + nt0 * tstride, a.W + (nt0 + NW) * tstride};
+        qgemm_group<2, MTT, OUT_PLANES>(hi, lo, w, 0, a.nchunks, a.act, a.act_pl, baddr, lane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) qlayer_store<MTT, OUT_PLANES>(a, nt0 + h * NW, mt, hi[h][mt] + lo[h][mt], lane);
+    }
+    for (; nt0 < full; nt0 += NW) {
+        f32x4 hi[1][MTT], lo[1][MTT];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) { hi[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[0][mt] = hi[0][mt]; }
+        const float *const w[1] = {a.W + nt0 * tstride};
+        qgemm_group<1, MTT, OUT_PLANES>(hi, lo, w, 0, a.nchunks, a.act, a.act_pl, baddr, lane);
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) qlayer_store<MTT, OUT_PLANES>(a, nt0, mt, hi[0][mt] + lo[0][mt], lane);
+    }
+    if (a.ntiles > full) {          // (uniform) one leftover tile: item = (column tile, K half)
+        const int nt = full, half = (a.nchunks + 1) / 2;
+        const float *const w[1] = {a.W + nt * tstride};
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        const int mt_w = wave % MTT, kh = wave / MTT;           // waves 0 .. 2 MTT - 1 carry an item
+        if (wave < 2 * MTT) {
+            f32x4 hi[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}}, lo[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+            auto b1 = [&](int kgrp, int) { return baddr(kgrp, mt_w); };
+            qgemm_group<1, 1, OUT_PLANES>(hi, lo, w, kh ? half : 0, kh ? a.nchunks : half, a.act, a.act_pl, b1, lane);
+            s = hi[0][0] + lo[0][0];
+            if (kh == 1) *reinterpret_cast<f32x4 *>(a.exch + (mt_w * 64 + lane) * 4) = s;
+        }
+        __syncthreads();
+        if (wave < MTT) qlayer_store<MTT, OUT_PLANES>(a, nt, mt_w, s + *reinterpret_cast<const f32x4 *>(a.exch + (mt_w * 64 + lane) * 4), lane);
+    }
+}
+
+}  // namespace vadx
