@@ -30,8 +30,14 @@ extern "C" {
 /* THE ABI number: the library (csrc/capi.hip), the ctypes binding (vadx._lib.ABI_VERSION, parsed from this line),
  * the C client (tests/c/cabi_silero.c) and __graft_entry__.build() all read it from here and nowhere else.
  * 3: vadx_frontend_cfg grew `fold`; vadx_frontend_fold_kind, vadx_dfsmn_cfb_*, _lstm_t_ex, _ft_repack (round 3).
- * 4: vadx_silero_encoder_mode; the Silero packed blob grew the bf16 x 3 weight fragments (round 4). */
+ * 4: vadx_silero_encoder_mode, vadx_gemm_mode; the Silero / FSMN packed blobs grew the bf16 x 3 weight fragments (round 4). */
 #define VADX_ABI_VERSION 4
+
+/* Arithmetic of the FSMN / FireRed dense layers, process-wide: 0 = exact-f32 MFMAs, 1 = bf16 x 3 split products (float32 operands
+ * split exactly into three bf16 terms, six bf16 MFMAs per K = 32 step: float32-class accuracy at 6/16 of the matrix time, csrc/split3.h).
+ * Any other `mode` only queries.  Returns the previous mode; the initial one comes from VADX_GEMM ("f32" | "split").  (Silero has its own
+ * switch, vadx_silero_encoder_mode.) */
+int         vadx_gemm_mode(int mode);
 
 int         vadx_abi_version(void);      /* == VADX_ABI_VERSION of the header the library was built from */
 const char *vadx_last_error(void);

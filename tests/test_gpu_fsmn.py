@@ -5,12 +5,20 @@ import pytest
 import torch
 
 import vadx  # noqa: F401
-from vadx import fsmn, weights
+from vadx import _lib, fsmn, weights
 from oracle import fsmn as ofs
 from oracle import postproc as opp
 
 pytestmark = pytest.mark.gpu
 ATOL = 1e-4
+
+
+@pytest.fixture(autouse=True, params=["f32", "split"])
+def gemm(request):
+    """Every test of this file runs on both arithmetics of the dense layers: exact-f32 MFMAs and bf16 x 3 split products."""
+    prev = _lib.gemm_mode(request.param)
+    yield request.param
+    _lib.gemm_mode(prev)
 
 
 def T(x):

@@ -114,6 +114,7 @@ _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 # name -> (restype, argtypes); every symbol include/vadx.h declares
 SIGNATURES = {
     "vadx_abi_version": (_I, []),
+    "vadx_gemm_mode": (_I, [_I]),
     "vadx_last_error": (C.c_char_p, []),
     "vadx_silero_packed_floats": (_Z, []),
     "vadx_silero_pack_host": (_I, [C.POINTER(SileroWeightsHost), _P]),
@@ -253,6 +254,18 @@ class trace:
             self.ms[name] = self.ms.get(name, 0.0) + e0.elapsed_time(e1)
             self.calls[name] = self.calls.get(name, 0) + 1
         return False
+
+
+GEMM_MODES = {"f32": 0, "split": 1}
+
+
+def gemm_mode(mode=None):
+    """Arithmetic of the FSMN / FireRed dense layers, process-wide (include/vadx.h: vadx_gemm_mode): "f32" MFMAs or "split" = bf16 x 3
+    split products.  Returns the mode that was active; None only queries."""
+    if mode is not None and mode not in GEMM_MODES:
+        raise ValueError(f"gemm mode must be one of {sorted(GEMM_MODES)}, got {mode!r}")
+    prev = lib().vadx_gemm_mode(-1 if mode is None else GEMM_MODES[mode])
+    return {v: k for k, v in GEMM_MODES.items()}[prev]
 
 
 def check(rc, exc=VadxError):

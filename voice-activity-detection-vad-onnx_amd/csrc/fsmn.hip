@@ -13,6 +13,7 @@
 // reference's cache_0..3 tensors) and the adaptive noise floor exactly like the reference loop.
 #include "common.h"
 #include "layers.h"
+#include "layers_split.h"
 
 #include <math.h>
 #include <string.h>
@@ -54,7 +55,12 @@ struct Dev {
     int off_in1, off_b1, off_mean, off_var, off_in2, off_b2;
     int off_lin[NLAYER], off_fir[NLAYER], off_aff[NLAYER], off_baff[NLAYER];
     int off_out1, off_bo1, off_out2, off_bo2, total;
+    // bf16 x 3 split-product copies of the dense layers (layers_split.h): A fragments [n-tile][32-k chunk][plane][QFRAG]
+    int split_ok;                                   // 0: dims outside the split tile's LDS map (Ap, A2p <= 160, Lp, Op <= 256)
+    int nch_A, nch_L, nch_A2;                       // 32-k chunks of an A- / L- / A2-wide input
+    int q_in1, q_b1, q_mbar, q_in2, q_lin[NLAYER], q_aff[NLAYER], q_out1, q_out2;
 };
+constexpr int NCH_IN1 = 13;                         // 5 x 80 LFR features = 400 -> 13 chunks of 32 (k-groups 50, 51 read a row of zeros)
 
 static int r16(int x) { return (x + 15) & ~15; }
 
@@ -75,6 +81,16 @@ static int derive(const vadx_fsmn_dims *c, Dev *d) {
     }
     d->off_out1 = take(d->A2p * d->Lp); d->off_bo1 = take(d->A2p);
     d->off_out2 = take(d->Op * d->A2p); d->off_bo2 = take(d->Op);
+    d->nch_A = (d->Ap + 31) / 32; d->nch_L = (d->Lp + 31) / 32; d->nch_A2 = (d->A2p + 31) / 32;
+    d->split_ok = d->Ap <= 160 && d->A2p <= 160 && d->Lp <= 256 && d->Op <= 256;
+    d->q_in1 = take(d->Ap / 16 * NCH_IN1 * 3 * QFRAG); d->q_b1 = take(d->Ap); d->q_mbar = take(NMEL);
+    d->q_in2 = take(d->Lp / 16 * d->nch_A * 3 * QFRAG);
+    for (int l = 0; l < NLAYER; ++l) {
+        d->q_lin[l] = take(PROJ / 16 * d->nch_L * 3 * QFRAG);
+        d->q_aff[l] = take(d->Lp / 16 * (PROJ / 32) * 3 * QFRAG);
+    }
+    d->q_out1 = take(d->A2p / 16 * d->nch_L * 3 * QFRAG);
+    d->q_out2 = take(d->Op / 16 * d->nch_A2 * 3 * QFRAG);
     d->total = o;
     return 0;
 }
@@ -230,6 +246,212 @@ __device__ __forceinline__ void tile(const Dev &d, const float *__restrict__ Pk,
     FS_ACC(8);
 }
 
+
+// ---- the same tile on bf16 x 3 split products (layers_split.h) ---------------------------------------------------------------------
+// Every dense layer runs as six v_mfma_f32_16x16x32_bf16 per K = 32 step on exactly split float32 operands (6/16 of the f32-MFMA matrix
+// time, float32-class accuracy).  Activations that feed a GEMM live in LDS as three bf16 planes [k / 8][frame][8]; the two float32
+// buffers that remain are the FIR's input P [128][history ++ frames] and the softmax's logits.
+//   * CMVN: the reference's (x + mean) * var on the LFR features moves into the first layer, W1' = W1 var, b1' = b1 + W1' (mean - mbar),
+//     evaluated in double on the host; the staged log-mel is pre-centred with mbar = the centre LFR position's means (one float32
+//     add), so that the products keep the magnitude of centred features.  Re-association only.
+//   * the FIR thread owns four consecutive channels x four frames, so its outputs leave as one 8-byte store per plane and frame.
+// LDS map (bytes), 160 KB with the small block -- tensors of one phase never overlap (H = planes of an A-wide tensor padded to 160
+// channels, HL = planes of an L-wide tensor [256][64], P = float32 [128][84], FO = FIR output planes [128][64]):
+//   in1: LM @61440 -> H1 @0        in2: H1 @0 -> HL @61440 ("mid")
+//   even layer: HL mid -> P @0 -> FO @110592 -> HL @0 ("low")         odd layer: HL low -> P @98304 -> FO @0 -> HL mid
+//   out1: HL mid -> H2 @0          out2: H2 @0 -> logits f32 [256][68] @61440
+constexpr int SQ_H = 0, SQ_LM = 61440, SQ_HLM = 61440, SQ_HLL = 0, SQ_PE = 0, SQ_PO = 98304, SQ_FOH = 110592, SQ_FOL = 0, SQ_LOG = 61440;
+constexpr int SQ_ARENA = 159744, SQ_LDS_BYTES = SQ_ARENA + SMALL * 4;
+static_assert(SQ_HLM + 256 * 64 * 6 <= SQ_ARENA && SQ_FOH + 128 * 64 * 6 <= SQ_ARENA && SQ_PO + BUFP * 4 <= SQ_FOH + 128 * 64 * 6 &&
+              SQ_LOG + 256 * A_LD * 4 <= SQ_ARENA && SQ_LM + 11 * 80 * 16 * 3 <= SQ_ARENA && 160 * 64 * 6 <= SQ_HLM && SQ_LDS_BYTES <= 160 * 1024,
+              "split tile LDS map");
+
+template <int MTT>
+__device__ __forceinline__ void tile_split(const Dev &d, const float *__restrict__ Pk, const float *__restrict__ lm,
+                                           int f0, int nvalid, const float *const *cin, float *const *cout,
+                                           unsigned char *smem, float *ps, float *red) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    constexpr int NF = MTT * 16, NCL = NF + 16;             // columns of a plane row: frames (log-mel: + LFR context)
+    const int lane = tid & 63, i = lane & 15;
+    auto grp_pl = [](int kgrps, int ncol) { return kgrps * ncol * 16; };      // bytes of one plane
+
+    FS_T0();
+    // ---- zero rows: k-groups of the A-wide tensors beyond Ap (their weights are zero, the operand must be finite), the log-mel's row 10
+    {
+        const int kg0 = d.Ap / 8, kg1 = 4 * d.nch_A, pl = grp_pl(kg1, NF);
+        for (int e = tid; e < 3 * (kg1 - kg0) * NF; e += THREADS) {
+            const int p = e / ((kg1 - kg0) * NF), r = e - p * (kg1 - kg0) * NF;
+            *reinterpret_cast<f32x4 *>(smem + SQ_H + p * pl + (kg0 * NF + r) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int e = tid; e < 3 * NCL; e += THREADS) {
+            const int p = e / NCL, c = e - p * NCL;
+            *reinterpret_cast<f32x4 *>(smem + SQ_LM + p * grp_pl(11, NCL) + (10 * NCL + c) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // ---- stage log-mel with LFR edge replication, pre-centred, as planes: column c = frame clamp(f0 + c - 2), item = (column, 4 mels)
+    {
+        constexpr int NE = (NF + 4) * (NMEL / 4), NIT = (NE + THREADS - 1) / THREADS;
+        f32x4 v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int e = min(tid + THREADS * u, NE - 1), c = e / (NMEL / 4), mg = e - c * (NMEL / 4);
+            int fr = f0 + c - 2;
+            fr = fr < 0 ? 0 : (fr > d.T - 1 ? d.T - 1 : fr);
+            v[u] = __builtin_nontemporal_load((vadx::global_f32x4_ptr)(lm + (size_t)fr * NMEL + 4 * mg));
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int e = tid + THREADS * u, c = e / (NMEL / 4), mg = e - c * (NMEL / 4);
+            if (e < NE) {
+                const f32x4 x = v[u] + ldg4(Pk + d.q_mbar + 4 * mg);
+                u32x2 p0, p1, p2;
+                split3x4(x, p0, p1, p2);
+                unsigned char *dp = smem + SQ_LM + ((mg >> 1) * NCL + c) * 16 + (mg & 1) * 8;
+                *reinterpret_cast<u32x2 *>(dp) = p0;
+                *reinterpret_cast<u32x2 *>(dp + grp_pl(11, NCL)) = p1;
+                *reinterpret_cast<u32x2 *>(dp + 2 * grp_pl(11, NCL)) = p2;
+            }
+        }
+    }
+    FS_ACC(0);
+    __syncthreads();
+    FS_ACC(9);
+
+    auto plain = [&](int ncol) { return [=](int kgrp, int mt) { return (kgrp * ncol + mt * 16 + i) * 16; }; };
+    QLayerArgs a;
+    // in_linear1: K = 5 LFR positions x 80 mels = 50 k-groups; k-group G = (position j = G / 10, mel group G % 10) reads column + j
+    a = QLayerArgs{Pk + d.q_in1, d.Ap / 16, NCH_IN1, Pk + d.q_b1, 0, smem + SQ_LM, grp_pl(11, NCL), smem + SQ_H, grp_pl(4 * d.nch_A, NF), NF, nullptr};
+    qlayer<MTT, true>(a, [=](int G, int mt) { const int j = G / 10, mg = G - 10 * j; return G < 50 ? (mg * NCL + mt * 16 + i + j) * 16 : (10 * NCL + mt * 16 + i) * 16; });
+    FS_ACC(1);
+    __syncthreads();
+    FS_ACC(9);
+    constexpr int NH = (PROJ * HIST + THREADS - 1) / THREADS;
+    auto cache_fetch = [&](int l, float (&hv)[NH]) {
+#pragma unroll
+        for (int u = 0; u < NH; ++u) { const int e = tid + THREADS * u; hv[u] = ldg1(cin[l] + (e < PROJ * HIST ? e : PROJ * HIST - 1)); }
+    };
+    float hv[NH];
+    cache_fetch(0, hv);
+    // in_linear2 + ReLU
+    a = QLayerArgs{Pk + d.q_in2, d.Lp / 16, d.nch_A, Pk + d.off_b2, 1, smem + SQ_H, grp_pl(4 * d.nch_A, NF), smem + SQ_HLM, grp_pl(4 * d.nch_L, NF), NF, nullptr};
+    qlayer<MTT, true>(a, plain(NF));
+    FS_ACC(2);
+    __syncthreads();
+    FS_ACC(9);
+
+    for (int l = 0; l < NLAYER; ++l) {
+        const bool even = (l & 1) == 0;
+        unsigned char *HLin = smem + (even ? SQ_HLM : SQ_HLL), *HLout = smem + (even ? SQ_HLL : SQ_HLM);
+        float *bufP = reinterpret_cast<float *>(smem + (even ? SQ_PE : SQ_PO));
+        unsigned char *FO = smem + (even ? SQ_FOH : SQ_FOL);
+        {   // history columns 1..19 of P <- cache (previous tile / previous chunk)
+#pragma unroll
+            for (int u = 0; u < NH; ++u) {
+                const int e = tid + THREADS * u, ch = e / HIST, h = e - ch * HIST;
+                if (e < PROJ * HIST) bufP[ch * P_LD + 1 + h] = hv[u];
+            }
+            cache_fetch(l + 1 < NLAYER ? l + 1 : l, hv);
+        }
+        FS_ACC(3);
+        a = QLayerArgs{Pk + d.q_lin[l], PROJ / 16, d.nch_L, nullptr, 0, HLin, grp_pl(4 * d.nch_L, NF), reinterpret_cast<unsigned char *>(bufP), P_CUR, P_LD, nullptr};
+        qlayer<MTT, false>(a, plain(NF));
+        FS_ACC(4);
+        __syncthreads();
+        FS_ACC(9);
+        {   // FIR + skip: thread = (4 consecutive channels, 4 frames); the four channels of a frame leave as one 8-byte store per plane
+            const int cg = tid >> 4, fg = tid & 15;
+            if (fg < NF / 4) {
+                f32x4 o[4];                                               // o[t][c]
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int ch = 4 * cg + c;
+                    const float *wf = Pk + d.off_fir[l] + ch * LORDER;
+                    float w[LORDER], v[24];
+#pragma unroll
+                    for (int k4 = 0; k4 < LORDER / 4; ++k4) {
+                        const f32x4 w4 = ldg4(wf + 4 * k4);
+                        w[4 * k4] = w4[0]; w[4 * k4 + 1] = w4[1]; w[4 * k4 + 2] = w4[2]; w[4 * k4 + 3] = w4[3];
+                    }
+                    const float *row = bufP + ch * P_LD + 4 * fg;         // v[1 + s] = seq[s] of the f32 tile (column 1 + 4 fg + s)
+#pragma unroll
+                    for (int b4 = 0; b4 < 6; ++b4) {
+                        const f32x4 x4 = *reinterpret_cast<const f32x4 *>(row + 4 * b4);
+                        v[4 * b4] = x4[0]; v[4 * b4 + 1] = x4[1]; v[4 * b4 + 2] = x4[2]; v[4 * b4 + 3] = x4[3];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int k = 0; k < LORDER; ++k) s = fmaf(w[k], v[1 + t + k], s);
+                        o[t][c] = v[1 + t + HIST] + s;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    u32x2 p0, p1, p2;
+                    split3x4(o[t], p0, p1, p2);
+                    unsigned char *dp = FO + ((cg >> 1) * NF + 4 * fg + t) * 16 + (cg & 1) * 8;
+                    *reinterpret_cast<u32x2 *>(dp) = p0;
+                    *reinterpret_cast<u32x2 *>(dp + grp_pl(PROJ / 8, NF)) = p1;
+                    *reinterpret_cast<u32x2 *>(dp + 2 * grp_pl(PROJ / 8, NF)) = p2;
+                }
+            }
+            for (int e = tid; e < PROJ * HIST; e += THREADS) {            // new cache = last 19 entries of (history ++ valid frames)
+                const int c2 = e / HIST, h = e - c2 * HIST;
+                stg1(cout[l] + e, bufP[c2 * P_LD + 1 + nvalid + h]);
+            }
+        }
+        FS_ACC(5);
+        __syncthreads();
+        FS_ACC(9);
+        a = QLayerArgs{Pk + d.q_aff[l], d.Lp / 16, PROJ / 32, Pk + d.off_baff[l], 1, FO, grp_pl(PROJ / 8, NF), HLout, grp_pl(4 * d.nch_L, NF), NF, nullptr};
+        qlayer<MTT, true>(a, plain(NF));
+        FS_ACC(6);
+        __syncthreads();
+        FS_ACC(9);
+    }
+    {   // zero rows of the A2-wide tensor (region 0 is free again)
+        const int kg0 = d.A2p / 8, kg1 = 4 * d.nch_A2, pl = grp_pl(kg1, NF);
+        for (int e = tid; e < 3 * (kg1 - kg0) * NF; e += THREADS) {
+            const int p = e / ((kg1 - kg0) * NF), r = e - p * (kg1 - kg0) * NF;
+            *reinterpret_cast<f32x4 *>(smem + SQ_H + p * pl + (kg0 * NF + r) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    a = QLayerArgs{Pk + d.q_out1, d.A2p / 16, d.nch_L, Pk + d.off_bo1, 0, smem + SQ_HLM, grp_pl(4 * d.nch_L, NF), smem + SQ_H, grp_pl(4 * d.nch_A2, NF), NF, nullptr};
+    qlayer<MTT, true>(a, plain(NF));
+    __syncthreads();
+    float *logits = reinterpret_cast<float *>(smem + SQ_LOG);
+    a = QLayerArgs{Pk + d.q_out2, d.Op / 16, d.nch_A2, Pk + d.off_bo2, 0, smem + SQ_H, grp_pl(4 * d.nch_A2, NF), reinterpret_cast<unsigned char *>(logits), 0, A_LD, nullptr};
+    qlayer<MTT, false>(a, plain(NF));
+    FS_ACC(7);
+    __syncthreads();
+    FS_ACC(9);
+    {   // softmax over the O logits of each frame, keep class 0 (as tile<>)
+        const int m = tid & 63, part = tid >> 6;
+        float mx = -INFINITY;
+        if (m < NF) for (int n = part; n < d.O; n += NW) mx = fmaxf(mx, logits[n * A_LD + m]);
+        red[part * 64 + m] = mx;
+        __syncthreads();
+        float gm = red[m];
+#pragma unroll
+        for (int p2 = 1; p2 < NW; ++p2) gm = fmaxf(gm, red[p2 * 64 + m]);
+        __syncthreads();
+        float sm = 0.f;
+        if (m < NF) for (int n = part; n < d.O; n += NW) sm += expf(logits[n * A_LD + m] - gm);
+        red[part * 64 + m] = sm;
+        __syncthreads();
+        if (part == 0 && m < nvalid) {
+            float tot = 0.f;
+#pragma unroll
+            for (int p2 = 0; p2 < NW; ++p2) tot += red[p2 * 64 + m];
+            ps[f0 + m] = expf(logits[m] - gm) / tot;
+        }
+        __syncthreads();
+    }
+    FS_ACC(8);
+}
+
 // score gate of one chunk (FSMN/Export_FSMN_VAD.py:87-101): returns noisy_dB (NaN if no frame is "noise")
 __device__ __forceinline__ float gate(const Dev &d, const float *ps, const float *__restrict__ db, float thr,
                                       float noise_db, unsigned char *__restrict__ score_out, float *__restrict__ psil_out,
@@ -260,19 +482,29 @@ __device__ __forceinline__ float gate(const Dev &d, const float *ps, const float
     return tot / cnt;                      // 0/0 -> NaN like torch's mean of an empty tensor
 }
 
+template <bool SPLIT>
 __device__ __forceinline__ void run_chunk(const Dev &d, const float *Pk, const float *lm, const float *const *cin,
                                           float *const *cout, float *lds) {
-    float *bufA = lds, *bufB = lds + BUFA, *bufP = bufB + BUFB, *small = bufP + BUFP;
+    float *bufA = lds, *bufB = lds + BUFA, *bufP = bufB + BUFB;
+    float *small = SPLIT ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(lds) + SQ_ARENA) : bufP + BUFP;
     float *ps = small, *red = small + 128;
+    unsigned char *smem = reinterpret_cast<unsigned char *>(lds);
     int f0 = 0;
     bool first = true;
     while (f0 < d.T) {
         const int left = d.T - f0;
         const float *const *ci = first ? cin : cout;         // later tiles continue from the updated cache
-        if (left > 48) tile<4>(d, Pk, lm, f0, left < 64 ? left : 64, ci, cout, bufA, bufB, bufP, ps, red), f0 += 64;
-        else if (left > 32) tile<3>(d, Pk, lm, f0, left, ci, cout, bufA, bufB, bufP, ps, red), f0 += 48;
-        else if (left > 16) tile<2>(d, Pk, lm, f0, left, ci, cout, bufA, bufB, bufP, ps, red), f0 += 32;
-        else tile<1>(d, Pk, lm, f0, left, ci, cout, bufA, bufB, bufP, ps, red), f0 += 16;
+        if (SPLIT) {
+            if (left > 48) tile_split<4>(d, Pk, lm, f0, left < 64 ? left : 64, ci, cout, smem, ps, red), f0 += 64;
+            else if (left > 32) tile_split<3>(d, Pk, lm, f0, left, ci, cout, smem, ps, red), f0 += 48;
+            else if (left > 16) tile_split<2>(d, Pk, lm, f0, left, ci, cout, smem, ps, red), f0 += 32;
+            else tile_split<1>(d, Pk, lm, f0, left, ci, cout, smem, ps, red), f0 += 16;
+        } else {
+            if (left > 48) tile<4>(d, Pk, lm, f0, left < 64 ? left : 64, ci, cout, bufA, bufB, bufP, ps, red), f0 += 64;
+            else if (left > 32) tile<3>(d, Pk, lm, f0, left, ci, cout, bufA, bufB, bufP, ps, red), f0 += 48;
+            else if (left > 16) tile<2>(d, Pk, lm, f0, left, ci, cout, bufA, bufB, bufP, ps, red), f0 += 32;
+            else tile<1>(d, Pk, lm, f0, left, ci, cout, bufA, bufB, bufP, ps, red), f0 += 16;
+        }
         first = false;
     }
 }
@@ -285,14 +517,15 @@ struct RunArgs {
 };
 
 // ORT-boundary equivalent: one chunk per stream, B independent streams.
+template <bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void fsmn_run_kernel(Dev d, const float *__restrict__ Pk, RunArgs r) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x;
     const float *cin[NLAYER]; float *cout[NLAYER];
 #pragma unroll
     for (int l = 0; l < NLAYER; ++l) { cin[l] = r.cin[l] + (size_t)b * PROJ * HIST; cout[l] = r.cout[l] + (size_t)b * PROJ * HIST; }
-    run_chunk(d, Pk, r.logmel + (size_t)b * d.T * NMEL, cin, cout, lds);
-    float *small = lds + BUFA + BUFB + BUFP;
+    run_chunk<SPLIT>(d, Pk, r.logmel + (size_t)b * d.T * NMEL, cin, cout, lds);
+    float *small = SPLIT ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(lds) + SQ_ARENA) : lds + BUFA + BUFB + BUFP;
     const float noisy = gate(d, small, r.db + (size_t)b * d.T, r.thr[b], r.noise_db[b], r.score + (size_t)b * d.T,
                              r.psil ? r.psil + (size_t)b * d.T : nullptr, small + 640, small + 128);
     if (threadIdx.x == 0) r.noisy_db[b] = noisy;
@@ -309,10 +542,11 @@ struct ClipArgs {
 };
 
 // Whole clips: the reference's while-loop (Inference_FSMN_VAD_ONNX.py:176-234), one workgroup per clip.
+template <bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void fsmn_clips_kernel(Dev d, const float *__restrict__ Pk, ClipArgs c) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, tid = threadIdx.x;
-    float *small = lds + BUFA + BUFB + BUFP;
+    float *small = SPLIT ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(lds) + SQ_ARENA) : lds + BUFA + BUFB + BUFP;
     float *ps = small, *red = small + 128, *sc = small + 640, *cnt = small + 768;
     float *cbase = c.cache + (size_t)b * NLAYER * PROJ * HIST;
     for (int e = tid; e < NLAYER * PROJ * HIST; e += THREADS) cbase[e] = 0.f;
@@ -326,7 +560,7 @@ __global__ __launch_bounds__(THREADS, 2) void fsmn_clips_kernel(Dev d, const flo
     unsigned char *fl = c.flags + (size_t)b * nflags;
     for (int k = 0; k < c.W; ++k) {
         const size_t widx = (size_t)b * c.W + k;
-        run_chunk(d, Pk, c.logmel + widx * d.T * NMEL, cin, cout, lds);
+        run_chunk<SPLIT>(d, Pk, c.logmel + widx * d.T * NMEL, cin, cout, lds);
         const float noisy = gate(d, ps, c.db + widx * d.T, c.thr, noise, nullptr, nullptr, sc, red);
         // look-ahead vote: cnt[i] = #{ j in [1,lb) : sc[i+j] != 0 }
         if (tid < c.slide) {
@@ -405,6 +639,7 @@ __global__ void fsmn_energy_kernel(const int16_t *__restrict__ audio, long long 
 }  // namespace vadx
 
 using namespace vadx::fsmn;
+using vadx::QFRAG;
 
 extern "C" size_t vadx_fsmn_packed_floats(const vadx_fsmn_dims *dims) {
     Dev d;
@@ -442,12 +677,40 @@ extern "C" int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_w
     }
     vadx::frag_major_inplace(p + d.off_out1, d.A2p, d.Lp);
     vadx::frag_major_inplace(p + d.off_out2, d.Op, d.A2p);
+    // ---- bf16 x 3 split-product copies (layers_split.h): A fragments [n-tile][chunk][plane][QFRAG] from the ORIGINAL row-major weights
+    auto qmat = [&](int off, int rows, int nch, auto wfn) {            // wfn(row, k) -> weight (0 outside the matrix)
+        for (int nt = 0; nt < (rows + 15) / 16; ++nt)
+            for (int kc = 0; kc < nch; ++kc) {
+                float *f3 = p + off + (size_t)((nt * nch + kc) * 3) * vadx::QFRAG;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) vadx::qfrag_put(f3, i, k, wfn(16 * nt + i, 32 * kc + k));
+            }
+    };
+    // in_linear1 with the CMVN folded in (double): W1' = W1 var, b1' = b1 + sum_k W1' (mean_k - mbar_{k % 80}), mbar = the centre LFR position's means
+    for (int m = 0; m < NMEL; ++m) p[d.q_mbar + m] = w->cmvn_means[2 * NMEL + m];
+    qmat(d.q_in1, d.Ap, NCH_IN1, [&](int r, int k) {
+        return (r < d.A && k < 400) ? (float)((double)w->in1_w[(size_t)r * 400 + k] * (double)w->cmvn_vars[k]) : 0.f; });
+    for (int r = 0; r < d.A; ++r) {
+        double acc = (double)w->in1_b[r];
+        for (int k = 0; k < 400; ++k)
+            acc += (double)(float)((double)w->in1_w[(size_t)r * 400 + k] * (double)w->cmvn_vars[k]) * ((double)w->cmvn_means[k] - (double)p[d.q_mbar + k % NMEL]);
+        p[d.q_b1 + r] = (float)acc;
+    }
+    qmat(d.q_in2, d.Lp, d.nch_A, [&](int r, int k) { return (r < d.L && k < d.A) ? w->in2_w[(size_t)r * d.A + k] : 0.f; });
+    for (int l = 0; l < NLAYER; ++l) {
+        qmat(d.q_lin[l], PROJ, d.nch_L, [&](int r, int k) { return k < d.L ? w->lin_w[l][(size_t)r * d.L + k] : 0.f; });
+        qmat(d.q_aff[l], d.Lp, PROJ / 32, [&](int r, int k) { return r < d.L ? w->aff_w[l][(size_t)r * PROJ + k] : 0.f; });
+    }
+    qmat(d.q_out1, d.A2p, d.nch_L, [&](int r, int k) { return (r < d.A2 && k < d.L) ? w->out1_w[(size_t)r * d.L + k] : 0.f; });
+    qmat(d.q_out2, d.Op, d.nch_A2, [&](int r, int k) { return (r < d.O && k < d.A2) ? w->out2_w[(size_t)r * d.A2 + k] : 0.f; });
     return VADX_OK;
 }
 
 static int set_lds_attr() {
-    VADX_DYN_LDS(fsmn_run_kernel, LDS_FLOATS * sizeof(float));
-    VADX_DYN_LDS(fsmn_clips_kernel, LDS_FLOATS * sizeof(float));
+    VADX_DYN_LDS(fsmn_run_kernel<false>, LDS_FLOATS * sizeof(float));
+    VADX_DYN_LDS(fsmn_clips_kernel<false>, LDS_FLOATS * sizeof(float));
+    VADX_DYN_LDS(fsmn_run_kernel<true>, SQ_LDS_BYTES);
+    VADX_DYN_LDS(fsmn_clips_kernel<true>, SQ_LDS_BYTES);
     return VADX_OK;
 }
 
@@ -481,8 +744,11 @@ extern "C" int vadx_fsmn_run(const vadx_fsmn_dims *dims, const float *packed, co
         VADX_REQUIRE(cache_in[l] && cache_out[l], "vadx_fsmn_run: NULL cache %d", l);
         r.cin[l] = cache_in[l]; r.cout[l] = cache_out[l];
     }
-    hipLaunchKernelGGL(fsmn_run_kernel, dim3(batch), dim3(THREADS), LDS_FLOATS * sizeof(float),
-                       static_cast<hipStream_t>(stream), d, packed, r);
+    if (vadx::gemm_mode() == 1 && d.split_ok)
+        hipLaunchKernelGGL(fsmn_run_kernel<true>, dim3(batch), dim3(THREADS), SQ_LDS_BYTES, static_cast<hipStream_t>(stream), d, packed, r);
+    else
+        hipLaunchKernelGGL(fsmn_run_kernel<false>, dim3(batch), dim3(THREADS), LDS_FLOATS * sizeof(float),
+                           static_cast<hipStream_t>(stream), d, packed, r);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }
@@ -506,8 +772,11 @@ extern "C" int vadx_fsmn_clips(const vadx_fsmn_dims *dims, const float *packed, 
     c.slide = d.T - lp->look_backward; c.thr = lp->one_minus_speech_threshold; c.noise0 = lp->noise_db_init;
     c.snr = lp->snr_threshold; c.speaking = lp->speaking_score; c.silence_score = lp->silence_score;
     c.flags = flags; c.noise_trace = noise_trace;
-    hipLaunchKernelGGL(fsmn_clips_kernel, dim3(batch), dim3(THREADS), LDS_FLOATS * sizeof(float),
-                       static_cast<hipStream_t>(stream), d, packed, c);
+    if (vadx::gemm_mode() == 1 && d.split_ok)
+        hipLaunchKernelGGL(fsmn_clips_kernel<true>, dim3(batch), dim3(THREADS), SQ_LDS_BYTES, static_cast<hipStream_t>(stream), d, packed, c);
+    else
+        hipLaunchKernelGGL(fsmn_clips_kernel<false>, dim3(batch), dim3(THREADS), LDS_FLOATS * sizeof(float),
+                           static_cast<hipStream_t>(stream), d, packed, c);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }

@@ -24,7 +24,7 @@ struct QLayerArgs {
     int act_pl;
     unsigned char *dst;             // OUT_PLANES: planes base, plane stride dst_pl, NCOL = dst_ncol; OUT_F32: float buffer
     int dst_pl, dst_ncol;           // OUT_F32: dst_ncol = row stride in floats, dst_pl = first column
-    float *exch;                    // LDS scratch (>= MTT * 256 floats) for a leftover n-tile split over K halves (may be nullptr if ntiles % 8 == 0)
+    float *exch;                    // unused (kept so that the argument lists of the two layer families line up)
 };
 
 // One group of NT n-tiles x MTT column tiles.  baddr(kgrp, mt) -> byte offset (inside a plane) of this lane's 16-byte B block of
@@ -91,8 +91,8 @@ __device__ __forceinline__ void qlayer_store(const QLayerArgs &a, int nt, int mt
     }
 }
 
-// dst = W x act (+bias, ReLU).  n-tiles go to the waves round-robin, two rounds side by side where there are that many; one leftover
-// n-tile (9 tiles on 8 waves) is split into (column tile, K half) items whose halves meet through `exch` in a fixed order.
+// dst = W x act (+bias, ReLU).  n-tiles go to the waves round-robin, two rounds side by side where there are that many; leftover
+// n-tiles (9 tiles on 8 waves) run as single (n-tile, column tile) items.
 template <int MTT, bool OUT_PLANES, typename BAddr>
 __device__ __forceinline__ void qlayer(const QLayerArgs &a, BAddr baddr) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -123,20 +123,14 @@ __device__ __forceinline__ void qlayer(const QLayerArgs &a, BAddr baddr) {
 #pragma unroll
         for (int mt = 0; mt < MTT; ++mt) qlayer_store<MTT, OUT_PLANES>(a, nt0, mt, hi[0][mt] + lo[0][mt], lane);
     }
-    if (a.ntiles > full) {          // (uniform) one leftover tile: item = (column tile, K half)
-        const int nt = full, half = (a.nchunks + 1) / 2;
+    // leftover n-tiles (9 tiles on 8 waves): (n-tile, column tile) items, one 16 x 16 output tile each
+    for (int item = wave; item < (a.ntiles - full) * MTT; item += NW) {
+        const int nt = full + item / MTT, mt_w = item - (item / MTT) * MTT;
+        f32x4 hi[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}}, lo[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
         const float *const w[1] = {a.W + nt * tstride};
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        const int mt_w = wave % MTT, kh = wave / MTT;           // waves 0 .. 2 MTT - 1 carry an item
-        if (wave < 2 * MTT) {
-            f32x4 hi[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}}, lo[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-            auto b1 = [&](int kgrp, int) { return baddr(kgrp, mt_w); };
-            qgemm_group<1, 1, OUT_PLANES>(hi, lo, w, kh ? half : 0, kh ? a.nchunks : half, a.act, a.act_pl, b1, lane);
-            s = hi[0][0] + lo[0][0];
-            if (kh == 1) *reinterpret_cast<f32x4 *>(a.exch + (mt_w * 64 + lane) * 4) = s;
-        }
-        __syncthreads();
-        if (wave < MTT) qlayer_store<MTT, OUT_PLANES>(a, nt, mt_w, s + *reinterpret_cast<const f32x4 *>(a.exch + (mt_w * 64 + lane) * 4), lane);
+        auto b1 = [&](int kgrp, int) { return baddr(kgrp, mt_w); };
+        qgemm_group<1, 1, OUT_PLANES>(hi, lo, w, 0, a.nchunks, a.act, a.act_pl, b1, lane);
+        qlayer_store<MTT, OUT_PLANES>(a, nt, mt_w, hi[0][0] + lo[0][0], lane);
     }
 }
 
