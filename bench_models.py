@@ -57,13 +57,33 @@ def flop_frontend_frame_folded(n_bins, taps, n_mels=80):
     return 2 * (2 * n_bins * pairs) + 3 * n_bins + 2 * n_mels * n_bins, 2 * (2 * n_bins * taps)
 
 
-def _roof_frontend(frames, n_bins, taps, ms, tag):
-    """Roofline entry of the folded front-end kernel: `achieved` = f32-MFMA flops issued + the f16 residual's flops at their f32 time
-    equivalent (/16), against the f32 MFMA peak; `dense_equivalent_achieved` = what the reference's dense product would need."""
+PEAK_SPLIT_TFLOPS = 2500.0 / 6.0      # f32-equivalent peak of bf16 x 3 split products: the dense bf16 MFMA peak / 6 (csrc/split3.h)
+
+
+def _roof_frontend(frames, n_bins, taps, ms, tag, fold=None):
+    """Roofline entry of the front-end kernel.  fold 4 (default: dense DFT product on bf16 x 3 split operands): `achieved` = the reference's
+    dense arithmetic (cos + sin products; power, dense mel) over the launch time, `peak` = what that mix could do with the DFT at the
+    split products' f32-equivalent peak (2500 / 6 TFLOP/s) and the mel GEMM at the f32-MFMA peak -- never 157.3 for the split part.
+    fold 1 / 2 (folded f32 product): f32-MFMA flops issued + the f16 residual's flops at their f32 time equivalent (/16), against 157.3;
+    `dense_equivalent_achieved` = what the reference's dense product would need."""
+    if fold is None:
+        fold = int(os.environ.get("VADX_FRONTEND_FOLD", "4"))
+    if fold == 4:
+        f_dft, f_rest = 2 * (2 * n_bins * taps), 3 * n_bins + 2 * 80 * n_bins
+        total = frames * (f_dft + f_rest)
+        t_min = frames * (f_dft / PEAK_SPLIT_TFLOPS + f_rest / PEAK_F32_MFMA_TFLOPS)          # 1e-12 s
+        r = _roof("frontend_split_kernel", total, ms, tag, "frontend_split_kernel",
+                  note="dense DFT product as bf16 x 3 split products: flops as the reference computes them; peak = the DFT part at 2500 / 6 "
+                       "TFLOP/s (f32-equivalent peak of the split products) + the power / mel part at the f32-MFMA peak")
+        r["peak"] = total / t_min
+        r["frac"] = r["achieved"] / r["peak"]
+        r["arithmetic"] = "split"
+        r["dense_equivalent_achieved"] = r["achieved"]
+        return r
     f32, f16 = flop_frontend_frame_folded(n_bins, taps)
     r = _roof("frontend_fold_kernel", frames * (f32 + f16 / 16.0), ms, tag, "frontend_fold_kernel",
-              note="folded DFT product: f32 flops issued + f16 residual flops / 16 (its MFMA rate is 16x); dense_equivalent = the reference's "
-                   "dense cos + sin product")
+              note="folded DFT product: algorithmic f32 flops of the fold (taps / 2 mirror pairs per table row; dense mel counted, the kernel's "
+                   "banded mel issues fewer) + f16 residual flops / 16 (its MFMA rate is 16x); dense_equivalent = the reference's dense cos + sin product")
     r["f32_flop_per_launch"], r["f16_flop_per_launch"] = frames * f32, frames * f16
     r["dense_equivalent_achieved"] = frames * flop_frontend_frame(n_bins, taps) / (ms * 1e-3) / 1e12
     return r
@@ -286,11 +306,18 @@ def profiled_pass_traffic(tag):
     return best
 
 
-def _roof(kernel, flop, ms, tag=None, kernel_substr=None, note=None):
+def _gemm_split():
+    from vadx import _lib
+    return _lib.gemm_mode() == "split"
+
+
+def _roof(kernel, flop, ms, tag=None, kernel_substr=None, note=None, split=False):
+    """split: the kernel's GEMMs run as bf16 x 3 split products -> priced against their f32-equivalent peak (2500 / 6), not 157.3"""
     ach = flop / (ms * 1e-3) / 1e12
     tr = profiled_kernel_traffic(tag, kernel_substr) if tag else None
-    r = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-         "frac": ach / PEAK_F32_MFMA_TFLOPS, "flop_per_launch": flop, "ms": ms,
+    peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    r = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "arithmetic": "split" if split else "f32",
+         "frac": ach / peak, "flop_per_launch": flop, "ms": ms,
          "traffic": tr["bytes"] if tr else None, "traffic_unit": "B per pass (all launches of the kernel)",
          "traffic_source": tr["source"] if tr else None,
          "traffic_GBps": (tr["bytes"] / (ms * 1e-3) / 1e9) if tr else None}
@@ -425,7 +452,7 @@ def fsmn_c3(torch, device, reps, cpu, clips=4096, log=lambda m: None):
                        f"{stride}, noise-floor feedback and look-ahead vote on device)",
            "clips": clips, "samples_per_clip": n, "windows_per_clip": W, "ms": ms,
            "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split,
-           "roofline": _roof("fsmn_clips_kernel", frames10 * flop_fsmn_frame(), net_ms, "fsmn", "fsmn_clips_kernel"),
+           "roofline": _roof("fsmn_clips_kernel", frames10 * flop_fsmn_frame(), net_ms, "fsmn", "fsmn_clips_kernel", split=_gemm_split()),
            "roofline_frontend": _roof_frontend(frames10, 257, 400, split.get("vadx_frontend_logmel", ms), "fsmn"),
            "hbm": _hbm(clips * (padded * 2 + (W * (eng.T - lb) + lb)), ms, "fsmn"), "cpu_baseline": None}
     # NOT the default path, reported beside it: the opt-in time x frequency fold of the front-end (VADX_FRONTEND_FOLD=3: a quarter of the

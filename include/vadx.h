@@ -170,7 +170,8 @@ typedef struct vadx_frontend_cfg {
     float k0, k1;
     int   center_pad;  /* zeros on each side of the window (n_fft/2, or 0 for snip-edges) */
     int   tap0, taps;  /* non-zero span of the centre-padded analysis window inside n_fft */
-    int   hop;         /* multiple of 16 */
+    int   hop;         /* multiple of 16, <= 320, and taps <= 4 * hop (at most four hops per analysis window): any other geometry is REFUSED
+                          (vadx_frontend_packed_floats returns 0, the other entry points VADX_EINVAL) -- there is no slower generic path */
     int   n_bins;      /* n_fft/2+1 */
     int   n_mels;      /* multiple of 16 */
     int   log_mode;    /* 0: log(max(x,floor))   1: log(x+floor) */
@@ -184,6 +185,9 @@ typedef struct vadx_frontend_cfg {
                           for this table; set it before vadx_frontend_packed_floats / _pack_host.  3: opt-in, periodic windows centred on
                           n_fft/2 only (FSMN): time x frequency fold, a quarter of the dense MACs, noisier on bands far below the
                           frame's peak (csrc/frontend.hip "kind 3"); _pack_host refuses it for a table that does not admit it.
+                          4: dense product of the reference table itself on bf16 x 3 exactly split operands (csrc/split3.h: six bf16
+                          MFMAs per 32 taps, float32-class accuracy, no symmetry assumption about the table); hop 160, preps 0 - 2,
+                          taps <= 512 -- the Python front-end's default where it applies.
                           Ignored by _logmel_ex / _stft_ft callers' kernels (they take the dense tables, which every blob carries) */
 } vadx_frontend_cfg;
 

@@ -46,13 +46,13 @@ def oracle_logmel(preset, windows_i16):
     ("firered", 16000, 2, 16000, 3),
     ("firered", 2560, 1, 2560, 2),
 ])
-@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("fold", [True, False, 4])
 def test_logmel_matches_oracle(preset, L, W, stride, B, fold):
     n = (W - 1) * stride + L
     clips = weights.burst_clips(B, n, seed=L + W + B)
     clips[0, : min(n, 3000)] = 0                         # exact digital silence -> exercises the log floor
     fe = frontend.Frontend(preset, L, fold=fold)
-    assert (fe.fold != 0) == fold
+    assert (fe.fold != 0) == bool(fold) and (fold != 4 or fe.fold == 4)      # 4 = dense product on bf16 x 3 split operands
     out = fe.logmel(clips, windows_per_clip=W, win_stride=stride).cpu().numpy()
     wins = np.stack([clips[b, w * stride:w * stride + L] for b in range(B) for w in range(W)])
     ref = oracle_logmel(preset, T(wins).unsqueeze(1)).numpy()
@@ -167,7 +167,9 @@ def exact_logmel(preset, windows_i16):
 
 
 @pytest.mark.parametrize("preset,L,kind", [("fsmn", 16000, 3), ("fsmn", 16000, 2), ("marblenet", 40000, 1), ("marblenet", 16000, 1),
-                                           ("firered", 16000, 1), ("fsmn", 5280, 3), ("fsmn", 5280, 2), ("firered", 2560, 1), ("fsmn", 800, 3)])
+                                           ("firered", 16000, 1), ("fsmn", 5280, 3), ("fsmn", 5280, 2), ("firered", 2560, 1), ("fsmn", 800, 3),
+                                           ("fsmn", 16000, 4), ("marblenet", 40000, 4), ("marblenet", 16000, 4), ("firered", 16000, 4),
+                                           ("fsmn", 5280, 4), ("firered", 2560, 4), ("fsmn", 800, 4)])
 def test_folded_dft_is_the_dense_product(preset, L, kind):
     """Table-level proof of the folded DFT product (mirror-paired taps about the window centre + f16 residual, csrc/frontend.hip
     "Folded DFT"): the same clips through the dense f32 product and the folded one, both against the double-precision evaluation
@@ -177,7 +179,9 @@ def test_folded_dft_is_the_dense_product(preset, L, kind):
     rare worst case sits on bands 60+ dB below the frame's peak, where either order keeps only a few digits.
     kind 3 (opt-in time x frequency fold, FSMN only) is held to its own, documented bounds: a weak bin inherits round-off relative to
     its STRONG mirror bin, so the bound relative to the frame's strongest line is twice the dense product's, bands within 26 dB of
-    the frame's peak are as exact as the dense product's, and the mean log-mel error stays within 2.5 x."""
+    the frame's peak are as exact as the dense product's, and the mean log-mel error stays within 2.5 x.
+    kind 4 (dense product on bf16 x 3 exactly split operands, csrc/split3.h) is held to the bounds of kinds 1 / 2: no larger error than
+    1.25 x the dense f32-MFMA product's against the double evaluation of the same table."""
     B = 6
     clips = weights.burst_clips(B, L, seed=L + kind)
     clips[0, : min(L, 3000)] = 0
@@ -187,7 +191,7 @@ def test_folded_dft_is_the_dense_product(preset, L, kind):
     clips[3] = (32000 * np.sin(2 * np.pi * 1000.37 / 16000 * np.arange(L))).astype(np.int16)      # one loud tone: 60 dB of leakage range
     fd = frontend.Frontend(preset, L, fold=False)
     ff = frontend.Frontend(preset, L, fold=kind)
-    assert fd.fold == 0 and ff.fold == kind and frontend.Frontend(preset, L, fold=True).fold == (2 if preset == "fsmn" else kind)
+    assert fd.fold == 0 and ff.fold == kind and frontend.Frontend(preset, L, fold=True).fold == (2 if preset == "fsmn" else 1)
     d = fd.logmel(clips).cpu().numpy().astype(np.float64)
     f = ff.logmel(clips).cpu().numpy().astype(np.float64)
     assert d.shape == f.shape and np.isfinite(f).all()
@@ -219,7 +223,12 @@ def test_folded_dft_is_the_dense_product(preset, L, kind):
             (np.abs(amp(f) - amp(ex)) / tol).max(), (np.abs(amp(d) - amp(ex)) / tol).max(), ef.mean(), ed.mean(), ef.max(), ed.max()))
 
 
-def test_folded_frontend_is_the_default_and_can_be_turned_off(monkeypatch):
+def test_split_frontend_is_the_default_and_can_be_turned_off(monkeypatch):
+    """Default = kind 4 (dense product on bf16 x 3 split operands) where the geometry has it; VADX_FRONTEND_FOLD selects the others."""
+    monkeypatch.delenv("VADX_FRONTEND_FOLD", raising=False)
+    assert frontend.Frontend("fsmn", 16000).fold == 4 and frontend.Frontend("marblenet", 16000).fold == 4 and frontend.Frontend("firered", 16000).fold == 4
+    assert frontend.Frontend("marblenet", 48000, in_sample_rate=48000).fold == 1      # the in-graph resampling preps are not staged by kind 4: folded f32 product
+    monkeypatch.setenv("VADX_FRONTEND_FOLD", "1")           # round 3's default: the folded f32 product the table admits
     assert frontend.Frontend("fsmn", 16000).fold == 2 and frontend.Frontend("marblenet", 16000).fold == 1
     monkeypatch.setenv("VADX_FRONTEND_FOLD", "0")
     assert frontend.Frontend("fsmn", 16000).fold == 0
@@ -227,34 +236,42 @@ def test_folded_frontend_is_the_default_and_can_be_turned_off(monkeypatch):
     assert frontend.Frontend("fsmn", 16000).fold == 3 and frontend.Frontend("marblenet", 16000).fold == 1
 
 
-@pytest.mark.parametrize("n_fft,win,hop,window,variant,center", [
-    (512, 320, 160, "hann_sym", "v2", True),       # two full passes
-    (512, 512, 128, "hann_sym", "v2", True),       # four passes, window = n_fft
-    (256, 200, 80, "hamming", "v1", True),         # periodic window, small transform (129 bins: last-bin tile), hop 80
-    (512, 400, 192, "hamming", "v1", True),        # hop 192: three passes of 192 + 16
-    (400, 400, 96, "povey", "v2", False),          # snip-edges, 201 bins, hop 96: five passes -> no fold plan, dense kernel
-    (1024, 640, 160, "hann_sym", "v2", True),      # 513 bins: more row tiles than the folded kernel takes -> dense kernel
+@pytest.mark.parametrize("n_fft,win,hop,window,variant,center,want_default,want_f32fold", [
+    (512, 320, 160, "hann_sym", "v2", True, 4, 1),          # two full passes; hop 160: split-product dense kernel by default
+    (512, 512, 128, "hann_sym", "v2", True, 1, 1),          # four passes, window = n_fft; hop 128: folded f32 product
+    (256, 200, 80, "hamming", "v1", True, None, None),      # periodic window, small transform (129 bins: last-bin tile), hop 80
+    (512, 400, 192, "hamming", "v1", True, None, None),     # hop 192: three passes of 192 + 16
+    (400, 400, 96, "povey", "v2", False, "refused", None),  # snip-edges, 201 bins, hop 96: FIVE passes -- outside the kernels (include/vadx.h: at most four)
+    (1024, 640, 160, "hann_sym", "v2", True, 0, 0),         # 513 bins / 640 taps: beyond the folded and split kernels -> dense f32 kernel
 ])
-def test_folded_product_on_other_geometries(n_fft, win, hop, window, variant, center):
-    """The C ABI takes any geometry: wherever vadx_frontend_fold_kind admits a fold the folded kernel must agree with the dense one
-    (same table bits), and where it does not (too many passes / bins) the dense kernel runs."""
+def test_folded_product_on_other_geometries(n_fft, win, hop, window, variant, center, want_default, want_f32fold, monkeypatch):
+    """The C ABI takes any geometry with hop % 16 == 0, hop <= 320 and at most four hops per window: wherever a faster product applies
+    (kind 4 split-product dense at hop 160, else the fold vadx_frontend_fold_kind admits) it must agree with the dense f32 kernel
+    (same table bits), where none does the dense kernel runs, and a geometry outside the kernels is REFUSED loudly, never skipped."""
     preset = dict(n_fft=n_fft, win=win, hop=hop, window=window, variant=variant, center=center, prep=1,
                   k=(-0.97 / 32768.0, 1.0 / 32768.0), mel=("torchaudio", 0, 8000, "slaney", "slaney"), log_mode=1, log_floor=1e-7)
     L = 20000
     clips = weights.burst_clips(4, L, seed=n_fft + hop)
     clips[0, :2000] = 0
-    try:
-        fd = frontend.Frontend(preset, L, fold=False)
-    except ValueError:
-        pytest.skip("geometry outside the front-end kernel altogether")
+    monkeypatch.delenv("VADX_FRONTEND_FOLD", raising=False)
+    if want_default == "refused":
+        with pytest.raises(ValueError, match="not supported by the HIP kernel"):
+            frontend.Frontend(preset, L, fold=False)
+        return
+    fd = frontend.Frontend(preset, L, fold=False)
     ff = frontend.Frontend(preset, L)
     d = fd.logmel(clips).cpu().numpy().astype(np.float64)
     f = ff.logmel(clips).cpu().numpy().astype(np.float64)
     assert np.isfinite(f).all() and d.shape == f.shape
-    if n_fft == 1024 or hop == 96:
-        assert ff.fold == 0
-    elif window == "hann_sym":
-        assert ff.fold == 1, ff.fold
+    if want_default is not None:
+        assert ff.fold == want_default, ff.fold
+    monkeypatch.setenv("VADX_FRONTEND_FOLD", "1")           # the folded f32 product, where the table admits one
+    f1 = frontend.Frontend(preset, L)
+    if want_f32fold is not None:
+        assert f1.fold == want_f32fold, f1.fold
+    g = f1.logmel(clips).cpu().numpy().astype(np.float64)
+    big1 = d > d.max(axis=-1, keepdims=True) - 18.0
+    assert np.abs(g - d)[big1].max() < 1e-3 and np.abs(g - d)[big1].mean() < 5e-6
     print("geometry", n_fft, win, hop, window, "-> fold", ff.fold)       # (a pair region whose padding would leave X2 has no plan: dense kernel)
     big = d > d.max(axis=-1, keepdims=True) - 18.0
     assert np.abs(f - d)[big].max() < 1e-3, np.abs(f - d)[big].max()

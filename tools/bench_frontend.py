@@ -12,7 +12,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 for preset, n, B in (("marblenet", 960000, 1024), ("fsmn", 16000, 16384), ("firered", 16000, 16384), ("marblenet", 89431, 2048)):
     clips = torch.from_numpy(weights.burst_clips(64, n, seed=5)).cuda().repeat(B // 64, 1)
     line = "%-10s %5d x %7d:" % (preset, B, n)
-    for fold in (False, True):
+    for fold in (False, True, 4):
         fe = frontend.Frontend(preset, n, fold=fold)
         out = fe.logmel(clips)
         torch.cuda.synchronize()
@@ -22,6 +22,6 @@ for preset, n, B in (("marblenet", 960000, 1024), ("fsmn", 16000, 16384), ("fire
             fe.logmel(clips, out=out)
         b.record()
         torch.cuda.synchronize()
-        line += "   %s %8.3f ms" % ("fold " if fold else "dense", a.elapsed_time(b) / iters)
+        line += "   %s %8.3f ms" % ({False: "dense", True: "fold ", 4: "split"}[fold], a.elapsed_time(b) / iters)
         del out
     print(line, flush=True)

@@ -31,8 +31,8 @@ else:
     from vadx import _lib, frontend, weights
     h = _lib.lib()
     h.vadx_frontend_debug_cycles.argtypes = [C.c_void_p, C.c_int]
-    for preset, n, fold in (("marblenet", 89431, False), ("marblenet", 89431, True), ("fsmn", 16000, False), ("fsmn", 16000, True),
-                            ("firered", 16000, False), ("firered", 16000, True)):
+    for preset, n, fold in (("marblenet", 89431, True), ("marblenet", 89431, 4), ("fsmn", 16000, True), ("fsmn", 16000, 4),
+                            ("firered", 16000, True), ("firered", 16000, 4)):
         fe = frontend.Frontend(preset, n, fold=fold)
         clips = torch.from_numpy(weights.burst_clips(64, n, seed=5)).cuda().repeat(32 if n > 20000 else 256, 1)
         fe.logmel(clips); torch.cuda.synchronize()
@@ -42,6 +42,6 @@ else:
         a.record(); fe.logmel(clips); b.record(); torch.cuda.synchronize()
         h.vadx_frontend_debug_cycles(buf, 0)
         tot = sum(buf[:5])
-        print("%s (%s): %d clips x %d samples, %.2f ms" % (preset, "folded" if fold else "dense", clips.shape[0], n, a.elapsed_time(b)))
+        print("%s (%s): %d clips x %d samples, %.2f ms" % (preset, {False: "dense", True: "folded", 4: "split dense"}[fold], clips.shape[0], n, a.elapsed_time(b)))
         for nm, v in zip(NAMES, buf[:5]):
             print("   %-30s %6.2f %%" % (nm, 100.0 * v / tot))

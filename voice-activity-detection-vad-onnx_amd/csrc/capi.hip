@@ -17,7 +17,7 @@ void set_error(const char *fmt, ...) {
 
 // Arithmetic of the FSMN / FireRed dense layers (process-wide): 0 = f32 MFMAs, 1 = bf16 x 3 split products (csrc/split3.h)
 #ifndef VADX_GEMM_MODE_DEFAULT
-#define VADX_GEMM_MODE_DEFAULT 0
+#define VADX_GEMM_MODE_DEFAULT 1       // split products: every FSMN parity test passes on both arithmetics (tests/test_gpu_fsmn.py)
 #endif
 namespace vadx {
 static std::atomic<int> g_gemm_mode{-1};

@@ -18,6 +18,7 @@
 // (frontend_fold_kernel: mirror-paired taps + f16 residual, kinds 1 / 2, the default of the FSMN / MarbleNet / FireRed front-ends;
 // frontend_fold3_kernel: time x frequency fold, opt-in) -- see "Folded DFT" below.
 #include "common.h"
+#include "layers_split.h"
 
 #include <math.h>
 #include <string.h>
@@ -87,6 +88,8 @@ struct Dev {
                                       // (the kernel reads the regions from there: indexing the by-value Dev arrays dynamically costs scratch)
     float f_xscale, f_rinv; // power-of-two scale of the f16 samples; 1 / (f_xscale * RES_SCALE)
     int tiles64, tail_mt;   // 64-frame tiles of a window, then ONE tail tile of tail_mt m-tiles (0: none; 1 - 3: 16 - 48 frames)
+    // split-product dense DFT (cfg.fold == 4): A fragments of the reference table at off_fold, [bin tile][re | im][32-tap chunk][plane][QFRAG]
+    int s_nch, s_nbt;       // 32-tap chunks of a table row; 16-bin tiles (the last one zero-padded)
 };
 
 static int round16(int x) { return (x + 15) & ~15; }
@@ -353,6 +356,21 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     d->tiles16 = (rem + 15) / 16;
     if (rem > 16) { d->tiles32 += 1; d->tiles16 = 0; }
     d->out_stride = c->n_mels; d->out_off = 0;
+    if (c->fold == 4) {
+        // dense product on bf16 x 3 split operands (frontend_split_kernel): the flat sample planes need hop = 160 (their skew), the
+        // staging knows the int16 preps 0 - 2
+        if (c->hop != 160 || c->prep > 2 || c->taps > 512) return -1;
+        d->fold = 4;
+        d->s_nch = (c->taps + 31) / 32;
+        d->s_nbt = (c->n_bins + 15) / 16;
+        d->off_fold = d->off_mel + d->n_mels * d->Fp;
+        d->off_plan = d->off_fold + d->s_nbt * 2 * d->s_nch * 3 * vadx::QFRAG;
+        d->tiles64 = c->frames / TF_FOLD;
+        const int rem64 = c->frames - d->tiles64 * TF_FOLD;
+        d->tail_mt = (rem64 + 15) / 16;
+        if (d->tail_mt == 4) { d->tiles64 += 1; d->tail_mt = 0; }
+        return 0;
+    }
     if (c->fold) {
         if (c->fold < 1 || c->fold > 3) return -1;
         if (!(c->prep <= 2 || c->prep >= 6) || d->nbt > 16) return -1;      // int16-derived samples; two power tiles per wave
@@ -395,6 +413,7 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
 }
 
 static size_t packed_total(const Dev &d) {
+    if (d.fold == 4) return (size_t)d.off_plan + 2 * MAX_MEL_TILES + 4;                       // + the mel bands
     if (d.fold == 3) return (size_t)d.off_plan + (size_t)d.f_Pb * 32 + 2 * MAX_MEL_TILES;      // [block][quarter][offA x 4 | offB x 4], then the mel bands
     if (d.fold) return (size_t)d.off_plan + 4 * MAX_REGIONS + 2 * MAX_MEL_TILES + 4;      // + last-bin mode (one int, padded to four)
     return (size_t)d.off_mel + (size_t)d.n_mels * d.Fp;
@@ -1079,6 +1098,131 @@ __global__ __launch_bounds__(THREADS, 4) void frontend_fold3_kernel(
     else fold3_tile<1>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, lds, NQ);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Dense DFT product on bf16 x 3 split operands (cfg.fold == 4; csrc/split3.h, layers_split.h).  The reference's own float32 table, split
+// exactly into three bf16 planes on the host, times the prepped samples, split exactly by the lanes that stage them: six
+// v_mfma_f32_16x16x32_bf16 per 32 taps, i.e. 6/16 of the dense f32 product's matrix time and 3/4 of the folded f32 product's -- with no
+// fold plan, no residual table and no symmetry assumption about the table (any window, any centre).
+//   * a tile of 64 frames needs 63 hop + taps CONSECUTIVE prepped samples; they sit in LDS once, as three flat bf16 planes.  The eight
+//     taps 8 G .. 8 G + 7 of frame c are the 16-byte block 20 c + G of a plane (hop = 160 = 20 blocks): the MFMA's B fragment is read
+//     straight out of the sample stream, frames overlap for free.  Block b lives at slot b + 2 (b / 80) (the skew spreads frames 4 apart
+//     over different banks).
+//   * wave = bin tile (real and imaginary rows side by side, all four column tiles); the power goes to PW[bin][frame] float32 for the
+//     banded mel GEMM + log of the other kernels (mel_phase).
+// LDS: planes 3 x 21.5 KB | power rows [Fp][68] f32 (74 KB at 257 bins): one workgroup per CU, eight waves of <= 256 VGPRs.
+__device__ __forceinline__ int sq_slot(int b) { return b + 2 * ((b * 3277) >> 18); }      // b / 80 for b < 13 000
+constexpr int SQ_BLOCKS = 63 * 20 + 4 * 16;                                               // blocks of a 64-frame tile, taps <= 512
+constexpr int SQ_PLANE_BYTES = (SQ_BLOCKS + 2 * (SQ_BLOCKS / 80) + 2 + 7) / 8 * 8 * 16;
+static size_t split_lds_bytes(const Dev *d) { return 3 * (size_t)SQ_PLANE_BYTES + (size_t)d->Fp * XF_LD * 4; }
+
+template <int MT>
+__device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict__ P, const int16_t *__restrict__ win, float mean,
+                                           int f0, float *__restrict__ out_win, unsigned char *smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, i = lane & 15;
+    constexpr int NF = MT * 16;
+    float *PW = reinterpret_cast<float *>(smem + 3 * SQ_PLANE_BYTES);
+    FE_T0();
+    // ---- phase 0: prep + split: item = block of eight consecutive samples (all nine loads unconditional, from clamped indices)
+    {
+        const int n0 = f0 * d.hop + d.tap0 - d.center_pad, nblk = (NF - 1) * 20 + 4 * d.s_nch;
+        for (int b0 = tid; b0 < nblk; b0 += THREADS) {
+            float x[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                const int n = n0 + 8 * b0 + e - 1;
+                x[e] = (float)win[n < 0 ? 0 : (n >= d.window_len ? d.window_len - 1 : n)];
+            }
+            f32x4 v[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int n = n0 + 8 * b0 + e;
+                const float xc = x[e + 1], xm = n > 0 ? x[e] : 0.f;
+                float r;
+                if (d.prep == 0) {            // FSMN: (x - mean) - 0.97 (x[-1] - mean), first sample kept
+                    const float a = __fsub_rn(xc, mean);
+                    r = (n > 0) ? __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn(x[e], mean))) : a;
+                } else if (d.prep == 1) {     // two-tap conv with zero history
+                    r = __fadd_rn(__fmul_rn(xm, d.k0), __fmul_rn(xc, d.k1));
+                } else {                      // scale, then remove the window mean
+                    r = __fsub_rn(__fmul_rn(xc, d.k1), mean);
+                }
+                v[e >> 2][e & 3] = (n >= 0 && n < d.window_len) ? r : 0.f;
+            }
+            u32x2 a0, a1, a2, b0v, b1v, b2v;
+            vadx::split3x4(v[0], a0, a1, a2);
+            vadx::split3x4(v[1], b0v, b1v, b2v);
+            unsigned char *dp = smem + sq_slot(b0) * 16;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u32x4 *>(dp) = u32x4{a0[0], a0[1], b0v[0], b0v[1]};
+            *reinterpret_cast<u32x4 *>(dp + SQ_PLANE_BYTES) = u32x4{a1[0], a1[1], b1v[0], b1v[1]};
+            *reinterpret_cast<u32x4 *>(dp + 2 * SQ_PLANE_BYTES) = u32x4{a2[0], a2[1], b2v[0], b2v[1]};
+        }
+    }
+    FE_ACC(4);
+    __syncthreads();
+    FE_ACC(0);
+    // ---- phase 1: DFT as split products, |.|^2 -> PW[bin][frame]
+    const float *tab = P + d.off_fold;
+    const size_t tstride = (size_t)d.s_nch * 3 * vadx::QFRAG;
+    const int full = (d.s_nbt / (THREADS / 64)) * (THREADS / 64);
+    for (int bt = wave; bt < full; bt += THREADS / 64) {
+        f32x4 hi[2][MT], lo[2][MT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { hi[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][mt] = hi[a][mt]; }
+        const float *const w[2] = {tab + (size_t)(2 * bt) * tstride, tab + (size_t)(2 * bt + 1) * tstride};
+        vadx::qgemm_group<2, MT, true>(hi, lo, w, 0, d.s_nch, smem, SQ_PLANE_BYTES,
+                                       [=](int G, int mt) { return sq_slot(20 * (16 * mt + i) + G) * 16; }, lane);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float re = hi[0][mt][r] + lo[0][mt][r], im = hi[1][mt][r] + lo[1][mt][r];
+                PW[(bt * 16 + 4 * q + r) * XF_LD + mt * 16 + i] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+            }
+    }
+    // the bin tiles that do not fill a round of eight (17 tiles: the last one; 13 tiles: five) go out as (bin tile, column tile) items, so
+    // that the last round costs a quarter of a full one instead of leaving most waves idle behind one or five busy ones
+    for (int item = wave; item < (d.s_nbt - full) * MT; item += THREADS / 64) {
+        const int bt = full + item / MT, mt1 = item - (item / MT) * MT;
+        f32x4 hi[2][1], lo[2][1];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { hi[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][0] = hi[a][0]; }
+        const float *const w[2] = {tab + (size_t)(2 * bt) * tstride, tab + (size_t)(2 * bt + 1) * tstride};
+        vadx::qgemm_group<2, 1, true>(hi, lo, w, 0, d.s_nch, smem, SQ_PLANE_BYTES,
+                                      [=](int G, int) { return sq_slot(20 * (16 * mt1 + i) + G) * 16; }, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float re = hi[0][0][r] + lo[0][0][r], im = hi[1][0][r] + lo[1][0][r];
+            PW[(bt * 16 + 4 * q + r) * XF_LD + mt1 * 16 + i] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+        }
+    }
+    FE_ACC(1);
+    __syncthreads();
+    FE_ACC(2);
+    mel_phase<MT, true>(d, P, PW, XF_LD, f0, out_win, reinterpret_cast<const int *>(P + d.off_plan));
+    FE_ACC(3);
+}
+
+__global__ __launch_bounds__(THREADS, 2) void frontend_split_kernel(
+    Dev d, const float *__restrict__ P, const int16_t *__restrict__ audio, long long row_stride,
+    long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsmem[];
+    const int tiles = d.tiles64 + (d.tail_mt ? 1 : 0);
+    const int widx = blockIdx.x / tiles, tile = blockIdx.x - widx * tiles;
+    const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
+    const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
+    float *out_win = out + (size_t)widx * d.frames * d.out_stride;
+    const float mean = means ? means[widx] : 0.f;
+    if (tile < d.tiles64) split_tile<4>(d, P, win, mean, tile * TF_FOLD, out_win, fsmem);
+    else if (d.tail_mt == 3) split_tile<3>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
+    else if (d.tail_mt == 2) split_tile<2>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
+    else split_tile<1>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
+}
+
 __global__ __launch_bounds__(THREADS, 4) void frontend_logmel_kernel(
     Dev d, const float *__restrict__ P, const int16_t *__restrict__ audio, long long row_stride,
     long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ out,
@@ -1194,6 +1338,22 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
     vadx::frag_major_inplace(packed_host + d.off_dft, d.nbt * 32, d.Kp);
     if (d.nyq) vadx::frag_major_inplace(packed_host + d.off_nyq, 16, d.Kp);
     vadx::frag_major_inplace(packed_host + d.off_mel, d.n_mels, d.Fp);
+    if (d.fold == 4) {          // the reference table itself, split exactly into three bf16 planes: [bin tile][re | im][chunk][plane][QFRAG]
+        for (int bt = 0; bt < d.s_nbt; ++bt)
+            for (int part = 0; part < 2; ++part)
+                for (int kc = 0; kc < d.s_nch; ++kc) {
+                    float *f3 = packed_host + d.off_fold + (size_t)(((bt * 2 + part) * d.s_nch + kc) * 3) * vadx::QFRAG;
+                    for (int i = 0; i < 16; ++i)
+                        for (int k = 0; k < 32; ++k) {
+                            const int f = bt * 16 + i, t = 32 * kc + k;
+                            const float v = (f < d.n_bins && t < d.taps) ? (part ? sin_tab : cos_tab)[(size_t)f * n_fft + cfg->tap0 + t] : 0.f;
+                            vadx::qfrag_put(f3, i, k, v);
+                        }
+                }
+        int32_t *pi = reinterpret_cast<int32_t *>(packed_host + d.off_plan);
+        for (int mt = 0; mt < d.nmt; ++mt) { pi[2 * mt] = mel_kb[2 * mt]; pi[2 * mt + 1] = mel_kb[2 * mt + 1]; }
+        return VADX_OK;
+    }
     if (d.fold == 3) {
         Fold3Plan p3;
         VADX_REQUIRE(fold3_plan(cfg, n_fft, &p3) == 0, "vadx_frontend_pack_host: no kind-3 fold plan for this geometry");
@@ -1357,6 +1517,17 @@ extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *p
                            (long long)win_stride, windows_per_clip, (int)nwin, cfg->window_len, scale, means_ws);
         VADX_HIP_TRY(hipGetLastError());
         means = means_ws;
+    }
+    if (d.fold == 4) {
+        const size_t slds = split_lds_bytes(&d);
+        VADX_REQUIRE(slds <= 160 * 1024, "vadx_frontend_logmel: geometry needs %zu B of LDS", slds);
+        const long long nblk = nwin * (d.tiles64 + (d.tail_mt ? 1 : 0));
+        VADX_REQUIRE(nblk < (1LL << 31), "vadx_frontend_logmel: too many tiles");
+        VADX_DYN_LDS(frontend_split_kernel, 160 * 1024);
+        hipLaunchKernelGGL(frontend_split_kernel, dim3((unsigned)nblk), dim3(THREADS), slds, st, d, packed, audio, (long long)row_stride,
+                           (long long)win_stride, windows_per_clip, means, out);
+        VADX_HIP_TRY(hipGetLastError());
+        return VADX_OK;
     }
     if (d.fold) {
         const size_t flds = fold_lds_bytes(&d);
