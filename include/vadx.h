@@ -322,6 +322,24 @@ int vadx_vadpost(const vadx_vadpost_params *prm, const float *probs, int stride,
                  int batch, int8_t *decisions, int32_t *segments, int32_t *counts, int cap,
                  void *workspace, size_t workspace_bytes, void *stream);
 
+typedef struct vadx_stream_vadpost_params {     /* StreamVadPostprocessor.__init__, FireRedVAD/Export_FireRedVAD.py:1161-1190 */
+    int   smooth_window_size;                   /* <= 16 */
+    float speech_threshold;
+    int   pad_start_frame, min_speech_frame, max_speech_frame, min_silence_frame;
+} vadx_stream_vadpost_params;
+
+size_t vadx_stream_vadpost_state_bytes(int streams);
+/* The streaming decision state machine for `streams` independent streams, one thread per stream: probs f32 [streams][probs_stride]
+ * (`frames` new frames each) -> the segments that END inside this chunk as (start_frame, end_frame) int32 pairs [streams][cap][2]
+ * (0-based frames: multiply by 1 / frames_per_second on the host) + counts [streams] (count > cap => truncated).  `state`
+ * (vadx_stream_vadpost_state_bytes, device) carries the moving-average ring buffer and the machine between calls; reset != 0 starts
+ * every stream from the reference's reset() state; flush != 0 also reports the segment still open after the last frame, as the
+ * reference's process_batch does at the end of its input, without closing it.  Same float32 operations in the same order as the
+ * reference's per-frame loop (its comparisons are float32 under NumPy 2).
+ * Replaces StreamVadPostprocessor.process_batch, FireRedVAD/Export_FireRedVAD.py:1161-1339 (driver Inference_FireRed_ONNX.py:788-822). */
+int vadx_stream_vadpost(const vadx_stream_vadpost_params *prm, const float *probs, int64_t probs_stride, int frames, int streams,
+                        void *state, int reset, int flush, int32_t *segments, int32_t *counts, int cap, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * MarbleNet building blocks: one fused launch per Jasper sub-block
  * (depthwise conv -> pointwise 1x1 + folded BatchNorm [-> + residual 1x1] -> ReLU) and the frame

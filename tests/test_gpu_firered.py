@@ -172,3 +172,51 @@ def test_stream_detect_batch_vs_oracle():
     solo, solo_track = eng.stream_detect(clips[2:3], post=post, return_probs=True)
     assert np.array_equal(solo_track[0], track[2]) and solo[0] == segs[2]
     assert any(len(s) for s in segs)
+
+
+def test_device_stream_postprocessor_matches_reference_fixture(golden):
+    """StreamVadPostprocessorBatch (vadx_stream_vadpost: one thread per stream, state in a device record) against the segments the
+    REFERENCE class produced (fixture): whole tracks, tracks fed 14 frames at a time with the state carried, reset -- bit-exact."""
+    from vadx import vadpost
+    g = golden("firered_stream")
+    for c, cfg in enumerate(g["post_cfgs"]):
+        args = (int(cfg[0]), float(cfg[1]), *[int(v) for v in cfg[2:]])
+        for i in range(int(g["post_n"])):
+            p = g[f"post_probs_{i}"]
+            if len(p) == 0:
+                continue
+            pp = vadpost.StreamVadPostprocessorBatch(*args, streams=1)
+            seg = np.array(pp.process_batch(p[None, :])[0], dtype=np.float64).reshape(-1, 2)
+            assert np.array_equal(seg, g[f"post{c}_seg_{i}"]), (c, i)
+            pp.reset()
+            pieces = [np.array(pp.process_batch(p[None, k:k + 14])[0], dtype=np.float64).reshape(-1, 2) for k in range(0, len(p), 14)]
+            assert np.array_equal(np.concatenate(pieces), g[f"post{c}_chunked_{i}"]), (c, i)
+            pp.reset()
+            again = np.array(pp.process_batch(p[None, :])[0], dtype=np.float64).reshape(-1, 2)
+            assert np.array_equal(again, g[f"post{c}_seg_{i}"]), (c, i)
+
+
+@pytest.mark.parametrize("cfg", [(5, 0.4, 5, 8, 2000, 20), (3, 0.5, 2, 4, 60, 6), (1, 0.5, 0, 1, 25, 1), (16, 0.35, 20, 3, 40, 9)])
+def test_device_stream_postprocessor_many_streams_equals_the_host_class(cfg):
+    """300 streams in one launch per chunk (ragged chunk sizes), every stream identical to the host class fed the same chunks."""
+    from vadx import vadpost
+    rng = np.random.default_rng(sum(int(v * 10) for v in cfg))
+    S, n = 300, 700
+    tracks = rng.random((S, n), dtype=np.float32)
+    tracks[1] = 0.0                                                # never speech
+    tracks[2] = 0.99                                               # one segment, split at max_speech
+    for s_ in range(3, S, 3):                                      # bursty tracks: long runs either side of the threshold
+        edges = np.sort(rng.integers(0, n, 12))
+        for a, b in zip(edges[::2], edges[1::2]):
+            tracks[s_, a:b] = 0.6 + 0.4 * tracks[s_, a:b]
+        tracks[s_] = np.where(tracks[s_] > 0.6, tracks[s_], 0.3 * tracks[s_]).astype(np.float32)
+    tracks[4, 100:110] = np.float32(cfg[1])                        # frames exactly on the threshold
+    dev = vadpost.StreamVadPostprocessorBatch(*cfg, streams=S)
+    host = [vadpost.StreamVadPostprocessor(*cfg) for _ in range(S)]
+    pos = 0
+    for size in (1, 13, 160, 7, 256, 263):
+        got = dev.process_batch(torch.from_numpy(tracks[:, pos:pos + size]).cuda())
+        for s_ in range(S):
+            assert got[s_] == host[s_].process_batch(tracks[s_, pos:pos + size].copy()), (s_, pos)
+        pos += size
+    assert pos == n and any(len(x) for x in got)

@@ -265,7 +265,7 @@ def test_kind3_frontend_keeps_the_scores_and_decisions(monkeypatch):
     lm, _ = eng.features(clips, W, stride)
     monkeypatch.setenv("VADX_FRONTEND_FOLD", "3")
     eng3 = fsmn.FsmnEngine(w)
-    assert eng3.fe.fold == 3 and eng.fe.fold == 2
+    assert eng3.fe.fold == 3 and eng.fe.fold == 4      # the default front-end: dense product on bf16 x 3 split operands
     flags3 = eng3.flags(clips, W).cpu().numpy()
     lm3, _ = eng3.features(clips, W, stride)
     assert np.array_equal(flags, flags3)

@@ -85,6 +85,11 @@ class VadPostParams(C.Structure):
                 ("extend_speech_frame", C.c_int)]
 
 
+class StreamVadPostParams(C.Structure):
+    _fields_ = [("smooth_window_size", C.c_int), ("speech_threshold", C.c_float), ("pad_start_frame", C.c_int),
+                ("min_speech_frame", C.c_int), ("max_speech_frame", C.c_int), ("min_silence_frame", C.c_int)]
+
+
 class SepConvCfg(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("cin", "cout", "kernel", "stride", "dilation", "depthwise", "residual_cin", "relu")]
 
@@ -147,6 +152,8 @@ SIGNATURES = {
     "vadx_frag_major_floats": (C.c_size_t, [_I, _I]),
     "vadx_frag_major_host": (_I, [_P, _I, _I, _P]),
     "vadx_firered_stream_run": (_I, [C.POINTER(FireRedCfg), _P, _P, _I, _P, _P, _P, _P]),
+    "vadx_stream_vadpost_state_bytes": (_Z, [_I]),
+    "vadx_stream_vadpost": (_I, [C.POINTER(StreamVadPostParams), _P, _L, _I, _I, _P, _I, _I, _P, _P, _I, _P]),
     "vadx_vadpost_workspace_bytes": (_Z, [_I, _I]),
     "vadx_vadpost": (_I, [C.POINTER(VadPostParams), _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "vadx_sepconv_block": (_I, [C.POINTER(SepConvCfg), _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _I, _I, _P]),

@@ -604,6 +604,106 @@ extern "C" int vadx_vadpost(const vadx_vadpost_params *prm, const float *probs, 
 }
 
 
+
+// ---- StreamVadPostprocessor on device (FireRedVAD/Export_FireRedVAD.py:1161-1339): one thread per stream, the state carried between
+// chunks in a 32-word record per stream.  Same float32 operations in the same order as the reference's per-frame loop (ring-buffer moving
+// average: sum += p - buf[k]; sum / count; compare with the float32 threshold), same four-state machine, forced split at max_speech.
+namespace vadx {
+namespace firered {
+struct StreamPostDev { int ws; float thr; int pad_start, min_sp, max_sp, min_si; };
+constexpr int SP_WORDS = 32, SP_MAXWS = 16;      // record: [0,16) window buffer, 16 sum, 17 pos, 18 count, 19 frame_cnt, 20 state, 21 speech_cnt,
+                                                 // 22 silence_cnt, 23 hit_max, 24 last_start, 25 last_end
+__global__ void stream_vadpost_kernel(StreamPostDev q, const float *__restrict__ probs, long long stride, int frames, int streams,
+                                      float *__restrict__ state, int reset, int flush, int *__restrict__ segs, int *__restrict__ counts, int cap) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= streams) return;
+    float *rec = state + (size_t)s * SP_WORDS;
+    int *ri = reinterpret_cast<int *>(rec);
+    float buf[SP_MAXWS];
+    float sum = 0.f;
+    int pos = 0, cnt = 0, fc = 0, st = 0, sp = 0, si = 0, hit = 0, last_start = -1, last_end = -1;
+    if (!reset) {
+#pragma unroll
+        for (int k = 0; k < SP_MAXWS; ++k) buf[k] = rec[k];
+        sum = rec[16]; pos = ri[17]; cnt = ri[18]; fc = ri[19]; st = ri[20]; sp = ri[21]; si = ri[22]; hit = ri[23]; last_start = ri[24]; last_end = ri[25];
+    } else {
+#pragma unroll
+        for (int k = 0; k < SP_MAXWS; ++k) buf[k] = 0.f;
+    }
+    int *out = segs + (size_t)s * cap * 2, n = 0;
+    auto emit = [&](int a, int b) { if (n < cap) { out[2 * n] = a; out[2 * n + 1] = b; } ++n; };
+    const float *pr = probs + (size_t)s * stride;
+    for (int t = 0; t < frames; ++t) {
+        const float p = pr[t];
+        ++fc;
+        float sm = p;
+        if (q.ws > 1) {
+            float old = 0.f;
+#pragma unroll
+            for (int k = 0; k < SP_MAXWS; ++k) if (k == pos) { old = buf[k]; buf[k] = p; }      // (register array: no dynamic indexing)
+            sum = __fadd_rn(sum, __fsub_rn(p, old));
+            pos = pos + 1 == q.ws ? 0 : pos + 1;
+            if (cnt < q.ws) ++cnt;
+            sm = __fdiv_rn(sum, (float)cnt);
+        }
+        const bool speech = sm >= q.thr;
+        int e0 = 0, e1 = 0;
+        bool ended = false;
+        if (hit) { last_start = fc; hit = 0; }           // a forced split re-opens a segment on the next frame
+        auto close = [&]() { e0 = last_start; e1 = fc; ended = true; last_start = -1; last_end = fc; };
+        if (st == 0) {
+            if (speech) { st = 1; sp = 1; } else { ++si; sp = 0; }
+        } else if (st == 1) {
+            if (speech) {
+                ++sp;
+                if (sp >= q.min_sp) {
+                    st = 2;
+                    int a = fc - sp + 1 - q.pad_start;
+                    a = a < 1 ? 1 : a;
+                    last_start = a > last_end + 1 ? a : last_end + 1;
+                    si = 0;
+                }
+            } else { st = 0; si = 1; sp = 0; }
+        } else {
+            ++sp;
+            if (speech) {
+                st = 2; si = 0;
+                if (sp >= q.max_sp) { hit = 1; sp = 0; close(); }
+            } else if (st == 2) { st = 3; si = 1; }
+            else {
+                ++si;
+                if (si >= q.min_si) { st = 0; sp = 0; close(); }
+            }
+        }
+        if (ended && e0 > 0) emit(e0 - 1 > 0 ? e0 - 1 : 0, e1 - 1 > 0 ? e1 - 1 : 0);
+    }
+    if (flush && last_start > 0) emit(last_start - 1 > 0 ? last_start - 1 : 0, fc - 1);      // unterminated segment at the end of the stream
+    counts[s] = n;
+#pragma unroll
+    for (int k = 0; k < SP_MAXWS; ++k) rec[k] = buf[k];
+    rec[16] = sum; ri[17] = pos; ri[18] = cnt; ri[19] = fc; ri[20] = st; ri[21] = sp; ri[22] = si; ri[23] = hit; ri[24] = last_start; ri[25] = last_end;
+}
+}  // namespace firered
+}  // namespace vadx
+
+extern "C" size_t vadx_stream_vadpost_state_bytes(int streams) { return streams > 0 ? (size_t)streams * vadx::firered::SP_WORDS * 4 : 0; }
+
+extern "C" int vadx_stream_vadpost(const vadx_stream_vadpost_params *prm, const float *probs, int64_t probs_stride, int frames, int streams,
+                                   void *state, int reset, int flush, int32_t *segments, int32_t *counts, int cap, void *stream) {
+    VADX_REQUIRE(prm && probs && state && segments && counts, "vadx_stream_vadpost: NULL argument");
+    VADX_REQUIRE(streams > 0 && frames >= 0 && cap > 0 && probs_stride >= frames, "vadx_stream_vadpost: streams / frames / cap / stride");
+    vadx::firered::StreamPostDev q;
+    q.ws = prm->smooth_window_size < 1 ? 1 : prm->smooth_window_size;
+    VADX_REQUIRE(q.ws <= vadx::firered::SP_MAXWS, "vadx_stream_vadpost: smooth_window_size %d > %d", q.ws, vadx::firered::SP_MAXWS);
+    q.thr = prm->speech_threshold;
+    q.pad_start = prm->pad_start_frame > q.ws ? prm->pad_start_frame : q.ws;
+    q.min_sp = prm->min_speech_frame; q.max_sp = prm->max_speech_frame; q.min_si = prm->min_silence_frame;
+    hipLaunchKernelGGL(vadx::firered::stream_vadpost_kernel, dim3((streams + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), q, probs,
+                       (long long)probs_stride, frames, streams, static_cast<float *>(state), reset, flush, segments, counts, cap);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
 extern "C" int vadx_firered_stream_run(const vadx_firered_cfg *cfg, const float *packed, const float *logmel, int streams,
                                        const float *caches_in, float *caches_out, float *probs, void *stream) {
     Dev d;

@@ -144,8 +144,13 @@ class FireRedEngine:
             parts.append(pr[:, 0, :])
             pos = end
         nvalid = valid_frame_count(n)
-        track = t.cat(parts, dim=1)[:, :nvalid].cpu().numpy() if parts else np.zeros((B, 0), np.float32)
-        out = [_vadpost.StreamVadPostprocessor(*post).process_batch(track[b]) for b in range(B)]
+        if not parts or nvalid == 0:
+            out, track = [[] for _ in range(B)], np.zeros((B, 0), np.float32)
+            return (out, track) if return_probs else out
+        track_dev = t.cat(parts, dim=1)[:, :nvalid].contiguous()
+        # the decisions of all streams in one launch (vadx_stream_vadpost: one thread per stream), not a host loop over streams
+        out = _vadpost.StreamVadPostprocessorBatch(*post, streams=B, device=self.device).process_batch(track_dev)
+        track = track_dev.cpu().numpy()
         return (out, track) if return_probs else out
 
     def detect(self, clips_i16, pad_noise=None, post=(5, 0.4, 20, 2000, 20, 5, 0), return_probs=False):

@@ -186,3 +186,54 @@ class StreamVadPostprocessor:
         if self.last_speech_start_frame > 0:             # unterminated segment at the end of the stream
             found.append((max(0, self.last_speech_start_frame - 1) * inv_fps, (self.frame_cnt - 1) * inv_fps))
         return found
+
+
+class StreamVadPostprocessorBatch:
+    """`StreamVadPostprocessor` for MANY streams at once, on the device: one thread per stream, the state (moving-average ring buffer,
+    four-state machine, counters) carried in a device record between `process_batch` calls (include/vadx.h: vadx_stream_vadpost).
+    Same constructor arguments as the reference class (FireRedVAD/Export_FireRedVAD.py:1161-1190); `process_batch(track)` takes
+    probabilities float32 [streams, frames] (device tensor or array) and returns, per stream, what the reference's process_batch
+    returns for that chunk: the (start_s, end_s) of every segment that ended in it, plus the segment still open after its last
+    frame (as the reference reports it) -- bit-identical to running the host class per stream."""
+
+    def __init__(self, smooth_window_size, speech_threshold, pad_start_frame, min_speech_frame, max_speech_frame,
+                 min_silence_frame, frames_per_second=100, streams=1, device="cuda:0", cap=None):
+        import ctypes as C
+        self.torch = t = _lib.require_gpu()
+        self.device = t.device(device)
+        self.streams, self.cap, self.frames_per_second = int(streams), cap, frames_per_second      # cap None: what a chunk can hold at most
+        self.prm = _lib.StreamVadPostParams(int(smooth_window_size), float(np.float32(speech_threshold)), int(pad_start_frame),
+                                            int(min_speech_frame), int(max_speech_frame), int(min_silence_frame))
+        if max(1, int(smooth_window_size)) > 16:
+            raise ValueError("smooth_window_size > 16 is outside the device kernel's ring buffer")
+        self._C = C
+        nbytes = _lib.lib().vadx_stream_vadpost_state_bytes(self.streams)
+        self.state = t.zeros(nbytes, dtype=t.uint8, device=self.device)
+        self._fresh = True
+
+    def reset(self):
+        self._fresh = True
+
+    def process_batch(self, track, flush=True):
+        t, C = self.torch, self._C
+        x = track if t.is_tensor(track) else t.from_numpy(np.ascontiguousarray(track, dtype=np.float32))
+        x = x.to(device=self.device, dtype=t.float32)
+        if x.dim() != 2 or x.shape[0] != self.streams:
+            raise ValueError(f"track must be [{self.streams}, frames], got {tuple(x.shape)}")
+        if x.shape[1] == 0:
+            return [[] for _ in range(self.streams)]
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        cap = int(self.cap) if self.cap else int(x.shape[1]) // 2 + 2      # a segment takes a speech and a silence frame; + the open one
+        segs = t.empty((self.streams, cap, 2), dtype=t.int32, device=self.device)
+        counts = t.empty((self.streams,), dtype=t.int32, device=self.device)
+        with t.cuda.device(self.device):
+            _lib.check(_lib.lib().vadx_stream_vadpost(C.byref(self.prm), x.data_ptr(), _lib.row_stride(x), int(x.shape[1]), self.streams,
+                                                      self.state.data_ptr(), 1 if self._fresh else 0, 1 if flush else 0,
+                                                      segs.data_ptr(), counts.data_ptr(), cap, _lib.stream_ptr()))
+        self._fresh = False
+        cn, sg = counts.cpu().numpy(), segs.cpu().numpy()
+        if int(cn.max()) > cap:
+            raise _lib.VadxError(f"stream post-processor: {int(cn.max())} segments in one chunk exceed cap={cap}")
+        inv_fps = 1.0 / self.frames_per_second
+        return [[(int(a) * inv_fps, int(b) * inv_fps) for a, b in sg[s, :cn[s]].tolist()] for s in range(self.streams)]
