@@ -1,6 +1,7 @@
 """GPU parity: FireRed DetectModel + device VadPostprocessor vs reference fixtures / oracle."""
 import numpy as np
 import pytest
+from conftest import chain_or_threshold
 import torch
 
 import vadx  # noqa: F401
@@ -74,6 +75,7 @@ def test_whole_clip_segments(n):
     clips = weights.burst_clips(B, n, seed=n)
     noise = np.random.default_rng(4).standard_normal((B, 20000))
     got, track, dec = eng.detect(clips, pad_noise=noise, return_probs=True) if firered.valid_frame_count(n) else (eng.detect(clips, pad_noise=noise), None, None)
+    full_chain = 0
     for b in range(B):
         want_seg, want_p, want_dec = ofr.run_clip(fe, ow, clips[b], noise[b])
         if track is not None:
@@ -82,11 +84,12 @@ def test_whole_clip_segments(n):
             d2 = opp.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0).process(track[b].cpu().numpy())
             assert np.array_equal(dec[b].cpu().numpy(), d2)
             assert got[b] == opp.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0).decision_to_segment(d2, n / 16000)
-            if np.array_equal(d2, want_dec):
-                assert got[b] == want_seg
+            if chain_or_threshold(opp.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0), track[b].cpu().numpy(), want_p, d2, want_dec, got[b], want_seg):
+                full_chain += 1
                 assert [(int(s * 16000), int(e * 16000)) for s, e in got[b]] == [(int(s * 16000), int(e * 16000)) for s, e in want_seg]
         else:
             assert got[b] == want_seg == []
+    assert track is None or full_chain >= 1          # of three clips at least one took the whole chain (a clip may sit on a threshold)
 
 
 def test_full_size_config5_properties():

@@ -2,6 +2,7 @@
 (encoder restated from the published NeMo config: parity unpinned, see oracle/marblenet.py)."""
 import numpy as np
 import pytest
+from conftest import chain_or_threshold
 import torch
 
 import vadx  # noqa: F401
@@ -57,10 +58,8 @@ def test_whole_clip_segments(n, window):
         d2 = opost.process(track[b].cpu().numpy())
         assert np.array_equal(dec[b].cpu().numpy(), d2)
         assert got[b] == opost.decision_to_segment(d2, n / 16000)
-        if np.array_equal(d2, want_dec):
-            full_chain += 1
-            assert got[b] == want_seg
-    assert full_chain >= 1          # not every clip may sit on a threshold
+        full_chain += chain_or_threshold(opost, track[b].cpu().numpy(), want_p, d2, want_dec, got[b], want_seg)
+    assert full_chain >= 1          # a clip may sit on a threshold (checked by chain_or_threshold), not all of them
 
 
 def test_ten_minute_clip_in_one_dynamic_window():
@@ -79,8 +78,7 @@ def test_ten_minute_clip_in_one_dynamic_window():
     d2 = opost.process(track[0].cpu().numpy())
     assert np.array_equal(dec[0].cpu().numpy(), d2)
     assert got[0] == opost.decision_to_segment(d2, n / 16000) and len(got[0]) > 20
-    if np.array_equal(d2, want_dec):
-        assert got[0] == want_seg
+    chain_or_threshold(opost, track[0].cpu().numpy(), want_p, d2, want_dec, got[0], want_seg)      # whole chain, or a frame ON the threshold
 
 
 def test_full_size_config4_properties():
