@@ -5,10 +5,19 @@ import pytest
 import torch
 
 import vadx  # noqa: F401
-from vadx import dfsmn, weights
+from vadx import _lib, dfsmn, weights
 from oracle import dfsmn as od
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["f32", "split"])
+def gemm(request):
+    """Every test of this file runs on both arithmetics of the kernels that have both (the CepsUnit's frequency-axis LSTM): exact-f32
+    MFMAs and bf16 x 3 split products."""
+    prev = _lib.gemm_mode(request.param)
+    yield request.param
+    _lib.gemm_mode(prev)
 
 
 def T(x):

@@ -10,6 +10,7 @@
 // LSTM recurrences keep h and c in registers: with gate rows ordered (unit-quad q, gate r) the D
 // fragment of step t is exactly the B fragment of step t+1 -- no LDS, no shuffles.
 #include "common.h"
+#include "split3.h"
 #include "layers.h"
 
 #include <math.h>
@@ -814,6 +815,142 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void l
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// lstm_f on bf16 x 3 split products (csrc/split3.h), CepsUnit geometry (IN = 40, hidden 20).  Same decomposition as lstm_f_kernel<40>:
+// one wave per direction, gate rows ordered so that the cell update is lane-local, x streamed through the wave's private LDS chunks.
+// The step's matrix product is ONE GEMM over the concatenated operand [h (20) ; x (40) ; 1 (bias)] = 61 of the 64 k-slots of two
+// 32-k chunks: 5 row tiles x 2 chunks x 6 = 60 v_mfma_f32_16x16x32_bf16 (1020 matrix cycles) instead of 75 v_mfma_f32_16x16x4_f32
+// (2400), and the gate arithmetic hides beside the bf16 matrix pipe instead of adding to it.
+//   k-slot map (same for the weights' A fragments and the operand's B fragment; lane 16 g + i supplies slots e = 0..7 of group g):
+//     chunk 0: e < 5 -> h of unit 4 e + g (the lane's OWN cell outputs: the new h is the next step's operand without any
+//              cross-lane traffic, as in the f32 kernel);  e = 5..7 -> x channel 3 g + e - 5
+//     chunk 1: x channel 12 + 8 g + e (< 40), channel 40 = the constant 1.0 whose "weight" is b_ih + b_hh, beyond: zero
+// Weights are split by each lane at kernel start from the torch layouts (80 loads + splits; the workgroups are persistent over tiles).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3x8(const float (&v)[8], bf16x8 &p0, bf16x8 &p1, bf16x8 &p2) {
+    u32x2 a0, a1, a2, b0, b1, b2;
+    split3x4(f32x4{v[0], v[1], v[2], v[3]}, a0, a1, a2);
+    split3x4(f32x4{v[4], v[5], v[6], v[7]}, b0, b1, b2);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    union { u32x4 u; bf16x8 h; } c0, c1, c2;
+    c0.u = u32x4{a0[0], a0[1], b0[0], b0[1]}; c1.u = u32x4{a1[0], a1[1], b1[0], b1[1]}; c2.u = u32x4{a2[0], a2[1], b2[0], b2[1]};
+    p0 = c0.h; p1 = c1.h; p2 = c2.h;
+}
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void lstm_f_split_kernel(LstmFArgs p, int tiles) {
+    constexpr int IN = 40, H = 20, MT = 5, NB = 2;
+    constexpr int CH_FLOATS = NB * IN * 16, NLD = NB * IN / 16;
+    __shared__ __attribute__((aligned(16))) float xs[2][2][CH_FLOATS];      // [direction][buffer]
+    __shared__ bf16x8 w2s[2][MT][2][64];              // plane 2 of the weights (used by one product in six): 20 KB, read back per step
+    const int lane = threadIdx.x & 63, dir = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    const int grow = (i & 3) * H + (i >> 2);          // A-fragment row i <-> gate (i&3), unit-in-quad (i>>2)
+    bf16x8 wa[MT][2][2];                              // [row tile][chunk][plane 0, 1]: 80 VGPRs, resident for every tile of this workgroup
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = grow + 4 * mt;
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v0[e] = e < 5 ? p.w_hh[dir][(size_t)row * H + 4 * e + q] : p.w_ih[dir][(size_t)row * IN + 3 * q + e - 5];
+            const int ch = 12 + 8 * q + e;
+            v1[e] = ch < IN ? p.w_ih[dir][(size_t)row * IN + ch] : (ch == IN ? p.b_ih[dir][row] + p.b_hh[dir][row] : 0.f);
+        }
+        bf16x8 t2;
+        split3x8(v0, wa[mt][0][0], wa[mt][0][1], t2);
+        w2s[dir][mt][0][lane] = t2;
+        split3x8(v1, wa[mt][1][0], wa[mt][1][1], t2);
+        w2s[dir][mt][1][lane] = t2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // w2s is written and read by the same wave only
+    __builtin_amdgcn_wave_barrier();
+    const int tq = lane & 3;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    float h[MT], c[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { h[mt] = 0.f; c[mt] = 0.f; }
+    f32x4 ln_mean, ln_inv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ln_mean[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2];
+        ln_inv[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2 + 1];
+    }
+    const int nchunk = (p.F + NB - 1) / NB;
+    auto bin_of = [&](int ck, int b) { const int st = ck * NB + b; return dir ? p.F - 1 - st : st; };
+    f32x4 pre[NLD];
+    float lw[NLD], lb[NLD];
+    auto request = [&](int ck) {
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int row = (lane >> 2) + 16 * r, b = row / IN, ch = row - b * IN, f = bin_of(ck, b);
+            const int fcl = f < 0 ? 0 : (f >= p.F ? p.F - 1 : f);        // unconditional (clamped) loads; bins past the end are never used
+            pre[r] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + ch, p.F, fcl) + 4 * tq);
+            lw[r] = p.ln.w[ch * p.F + fcl]; lb[r] = p.ln.b[ch * p.F + fcl];
+        }
+    };
+    auto park = [&](float *dst) {
+#pragma unroll
+        for (int r = 0; r < NLD; ++r)
+            *reinterpret_cast<f32x4 *>(dst + ((lane >> 2) + 16 * r) * 16 + 4 * tq) = (pre[r] - ln_mean) * ln_inv * lw[r] + lb[r];
+    };
+    __builtin_amdgcn_wave_barrier();                  // the previous tile's last reads of xs precede this tile's first park
+    request(0);
+    park(xs[dir][0]);
+    if (nchunk > 1) request(1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const float *xb = xs[dir][ck & 1];
+        if (ck + 1 < nchunk) {
+            park(xs[dir][(ck + 1) & 1]);                  // the buffer last read by chunk ck - 1
+            if (ck + 2 < nchunk) request(ck + 2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll 1
+        for (int b = 0; b < NB; ++b) {
+            const int f = bin_of(ck, b);
+            if (f < 0 || f >= p.F) break;
+            const float *xrow = xb + b * IN * 16 + i;
+            float v0[8], v1[8];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) v0[e] = h[e];
+#pragma unroll
+            for (int e = 5; e < 8; ++e) v0[e] = xrow[(3 * q + e - 5) * 16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = 12 + 8 * q + e;               // (q is per-lane: clamp the read, select afterwards)
+                const float xv = xrow[(ch < IN ? ch : IN - 1) * 16];
+                v1[e] = ch < IN ? xv : (ch == IN ? 1.0f : 0.f);
+            }
+            bf16x8 b0[3], b1[3];
+            split3x8(v0, b0[0], b0[1], b0[2]);
+            split3x8(v1, b1[0], b1[1], b1[2]);
+            // ONE accumulator per row tile, small products first (at 256 VGPRs the separate accumulator of the small products spilled
+            // into the chunk code; measured on its own -- tools/bf16x3_probe.sh "s6" -- the single accumulator is still closer to the float64
+            // product than the f32 MFMA chain: 1.4e-7 against 2.5e-7 of sum |w x|).  Row tiles innermost: consecutive MFMAs are independent.
+            f32x4 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define LF_TERM(CH, BF, AP, BP) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(wa[mt][CH][AP], BF[BP], acc[mt]);
+#define LF_TERM2(CH, BF) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(w2s[dir][mt][CH][lane], BF[0], acc[mt]);
+            LF_TERM2(0, b0) LF_TERM(0, b0, 1, 1) LF_TERM(0, b0, 0, 2) LF_TERM2(1, b1) LF_TERM(1, b1, 1, 1) LF_TERM(1, b1, 0, 2)
+            LF_TERM(0, b0, 1, 0) LF_TERM(0, b0, 0, 1) LF_TERM(1, b1, 1, 0) LF_TERM(1, b1, 0, 1) LF_TERM(0, b0, 0, 0) LF_TERM(1, b1, 0, 0)
+#undef LF_TERM
+#undef LF_TERM2
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 a = acc[mt];
+                const float ig = gate_sigmoid(a[0]), fg = gate_sigmoid(a[1]), gg = gate_tanh(a[2]), og = gate_sigmoid(a[3]);
+                c[mt] = fg * c[mt] + ig * gg;
+                h[mt] = og * gate_tanh(c[mt]);
+                p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + dir * H + 4 * mt + q, p.F, f) + i] = h[mt];
+            }
+        }
+    }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // alpha_scale (DFSMN_VAD.forward :326-335): x4 = [mix_re, mix_im, |alpha| * far_re, |alpha| * far_im] with
 //   alpha[f][t] = linear2_j( linear1( [pow_far, pow_mix][t-9+j] ) ),  pow = re^2 + im^2, zero history.
@@ -1441,6 +1578,8 @@ extern "C" int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, c
     p.in = mkview(in); p.ln = mkln(ln); p.out = mkvieww(out); p.F = F;
     for (int d = 0; d < 2; ++d) { p.w_ih[d] = w_ih[d]; p.w_hh[d] = w_hh[d]; p.b_ih[d] = b_ih[d]; p.b_hh[d] = b_hh[d]; }
     if (in->c == 4) hipLaunchKernelGGL(lstm_f_kernel<4>, dim3(tiles), dim3(128), 0, static_cast<hipStream_t>(stream), p);
+    else if (in->c == 40 && vadx::gemm_mode() == 1)      // split products: persistent workgroups (each lane splits its weights once), four per CU
+        hipLaunchKernelGGL(lstm_f_split_kernel, dim3(tiles < 1024 ? tiles : 1024), dim3(128), 0, static_cast<hipStream_t>(stream), p, tiles);
     else if (in->c == 40) hipLaunchKernelGGL(lstm_f_kernel<40>, dim3(tiles), dim3(128), 0, static_cast<hipStream_t>(stream), p);
     else { vadx::set_error("vadx_dfsmn_lstm_f: input channels must be 4 or 40"); return VADX_EINVAL; }
     VADX_HIP_TRY(hipGetLastError());
