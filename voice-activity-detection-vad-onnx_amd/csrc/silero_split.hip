@@ -89,18 +89,28 @@ __device__ __forceinline__ void load_a3(bf16x8 (&a)[3], const float *frag3, int 
     for (int p = 0; p < 3; ++p) a[p] = ldq(frag3 + p * QF, lane);
 }
 
-template <typename SampleT>
-__global__ __launch_bounds__(SP_THREADS, 4) void silero_encode_split_kernel(
+// HALVES = 2 (an experiment kept for the record, not the default -- see VADX_SPLIT_HALVES): a 1024-thread workgroup whose two halves
+// encode two neighbouring tiles in lockstep, each in its own LDS region.  Same registers, same LDS and the same 16 waves per CU as two
+// 512-thread workgroups, but the halves stream the SAME weight fragments at the same moment, so the second request of every line is an
+// L1 hit instead of an L2 read (the weight stream out of L2 is the kernel's largest stall: tools/exp_encoder.py, "every fragment from
+// one address" 5.77 -> 4.51 ms).
+template <typename SampleT, int HALVES>
+__global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_kernel(
     const float *__restrict__ P, const SampleT *__restrict__ audio, float in_scale, long long n_samples,
     long long row_stride, long long origin, int B, int G, int T, int Gws, int g0, float *__restrict__ gx) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int half = HALVES > 1 ? (int)(threadIdx.x >> 9) : 0;
+    unsigned char *smem = smem_all + half * SP_LDS_BYTES;
     float *X = reinterpret_cast<float *>(smem);
     float *scr = reinterpret_cast<float *>(smem + SP_SCR), *nyq = scr + 256;
     float *exc = reinterpret_cast<float *>(smem + SP_EXC);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & (SP_THREADS - 1), lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, i = lane & 15;
-    const int grp = blockIdx.x % G, t = blockIdx.x / G;
+    const long long tile_raw = (long long)blockIdx.x * HALVES + half, ntile = (long long)G * T;
+    const bool tile_ok = tile_raw < ntile;                   // an odd tile count leaves the last workgroup's second half without work:
+    const int tile_id = (int)(tile_ok ? tile_raw : ntile - 1);      // it recomputes the last tile (the barriers are workgroup-wide) and stores nothing
+    const int grp = tile_id % G, t = tile_id / G;
     const bool fold = P[OFF_FOLD] != 0.f;      // uniform: the basis has the DFT symmetries -> folded STFT pass
     SP_T0();
 
@@ -487,8 +497,9 @@ __global__ __launch_bounds__(SP_THREADS, 4) void silero_encode_split_kernel(
             }
         }
         float *dst = gx + ((size_t)t * Gws + g0 + grp) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
+        if (tile_ok)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = hi[g] + lo[g];
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = hi[g] + lo[g];
     }
     SP_MARK(9);
 }
@@ -623,12 +634,19 @@ int silero_lstm_split_launch(const float *packed, const float *gx, const float *
     return VADX_OK;
 }
 
+// 1 = one tile per 512-thread workgroup (two independent workgroups per CU); 2 = the lockstep pair.  Measured on one box, B = 4096 x 10 s:
+// 5.75 ms against 6.35 ms -- the L1 hits of the pair do not pay for what the lockstep costs: two independent workgroups sit in DIFFERENT
+// phases most of the time (one in its f32 STFT or its staging while the other streams weights), the pair never does.
+#ifndef VADX_SPLIT_HALVES
+#define VADX_SPLIT_HALVES 1
+#endif
 template <typename S>
 int silero_encode_split_launch(const float *packed, const S *src, float in_scale, long long n_valid, long long row_stride,
                                long long origin, int batch, int G, int steps, int Gws, int first_group, float *gx, void *stream) {
-    VADX_DYN_LDS(silero_encode_split_kernel<S>, SP_LDS_BYTES);
-    const long long nblk = (long long)G * steps;
-    hipLaunchKernelGGL(silero_encode_split_kernel<S>, dim3((unsigned)nblk), dim3(SP_THREADS), SP_LDS_BYTES, static_cast<hipStream_t>(stream),
+    constexpr int HV = VADX_SPLIT_HALVES;
+    VADX_DYN_LDS((silero_encode_split_kernel<S, HV>), SP_LDS_BYTES * HV);
+    const long long nblk = ((long long)G * steps + HV - 1) / HV;
+    hipLaunchKernelGGL((silero_encode_split_kernel<S, HV>), dim3((unsigned)nblk), dim3(SP_THREADS * HV), SP_LDS_BYTES * HV, static_cast<hipStream_t>(stream),
                        packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps, Gws, first_group, gx);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
