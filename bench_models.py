@@ -523,7 +523,7 @@ def firered_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None):
                        "speech probabilities",
            "clips": clips, "samples_per_clip": n, "ms": ms, "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split,
            "roofline": _roof("firered_kernel", frames10 * flop_firered_frame(), split.get("vadx_firered_run", ms), "firered",
-                             "firered_kernel"),
+                             "firered_kernel", split=_gemm_split()),
            "roofline_frontend": _roof_frontend(frames10, 201, 400, split.get("vadx_frontend_logmel", ms), "firered"),
            "hbm": _hbm(clips * (n * 2 + W * 98 * 4), ms, "firered"), "cpu_baseline": None}
     del audio

@@ -10,6 +10,15 @@ from oracle import firered as ofr
 from oracle import postproc as opp
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["f32", "split"])
+def gemm(request):
+    """Every test of this file runs on both arithmetics of the point-wise pairs: exact-f32 MFMAs and bf16 x 3 split products."""
+    from vadx import _lib
+    prev = _lib.gemm_mode(request.param)
+    yield request.param
+    _lib.gemm_mode(prev)
 ATOL = 1e-4
 CFGS = {1234: weights.FIRERED_CFG, 7: dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=2, N2=4, S2=3),
         9: dict(weights.FIRERED_CFG, R=2, M=1, H=48, P=24, N1=5, S1=1, N2=0, S2=0, odim=3)}

@@ -357,20 +357,26 @@ __device__ __forceinline__ void tile_split(const Dev &d, const float *__restrict
         a = QLayerArgs{Pk + d.q_lin[l], PROJ / 16, d.nch_L, nullptr, 0, HLin, grp_pl(4 * d.nch_L, NF), reinterpret_cast<unsigned char *>(bufP), P_CUR, P_LD, nullptr};
         qlayer<MTT, false>(a, plain(NF));
         FS_ACC(4);
+        // the FIR taps of this thread's four channels (80 floats) are requested BEFORE the barrier: their L2 round trip hides behind the
+        // wait for the slowest wave of the GEMM instead of opening the FIR (per channel: load, wait, 80 FMAs -- four times in a row)
+        const int cg = tid >> 4, fg = tid & 15;
+        f32x4 fw[4][LORDER / 4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k4 = 0; k4 < LORDER / 4; ++k4) fw[c][k4] = ldg4(Pk + d.off_fir[l] + (4 * cg + c) * LORDER + 4 * k4);
         __syncthreads();
         FS_ACC(9);
         {   // FIR + skip: thread = (4 consecutive channels, 4 frames); the four channels of a frame leave as one 8-byte store per plane
-            const int cg = tid >> 4, fg = tid & 15;
             if (fg < NF / 4) {
                 f32x4 o[4];                                               // o[t][c]
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int ch = 4 * cg + c;
-                    const float *wf = Pk + d.off_fir[l] + ch * LORDER;
                     float w[LORDER], v[24];
 #pragma unroll
                     for (int k4 = 0; k4 < LORDER / 4; ++k4) {
-                        const f32x4 w4 = ldg4(wf + 4 * k4);
+                        const f32x4 w4 = fw[c][k4];
                         w[4 * k4] = w4[0]; w[4 * k4 + 1] = w4[1]; w[4 * k4 + 2] = w4[2]; w[4 * k4 + 3] = w4[3];
                     }
                     const float *row = bufP + ch * P_LD + 4 * fg;         // v[1 + s] = seq[s] of the f32 tile (column 1 + 4 fg + s)

@@ -42,12 +42,14 @@ __device__ __forceinline__ void qgemm_group(f32x4 (&hi)[NT][MTT], f32x4 (&lo)[NT
     };
     auto step = [&](int kc, const bf16x8 (&a)[NT][3]) {
         bf16x8 b[MTT][3];
+        int boff[MTT];
 #pragma unroll
-        for (int mt = 0; mt < MTT; ++mt) {
-            const unsigned char *s = act + baddr(4 * kc + q, mt);
+        for (int mt = 0; mt < MTT; ++mt) boff[mt] = baddr(4 * kc + q, mt);
+        // plane-major request order: the first products (a2 x b0, a1 x b1 ...) of every column tile can issue after MTT reads have landed
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[mt][p] = *reinterpret_cast<const bf16x8 *>(s + p * act_pl);
-        }
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) b[mt][p] = *reinterpret_cast<const bf16x8 *>(act + boff[mt] + p * act_pl);
         // six products per (n-tile, column tile), tiles innermost: consecutive MFMAs hit different accumulators
 #define QL_TERM(AP, BP, ACC)                                                                                                   \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int mt = 0; mt < MTT; ++mt)                       \
