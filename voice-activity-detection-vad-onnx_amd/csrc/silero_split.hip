@@ -42,19 +42,23 @@ namespace vadx {
 namespace silero {
 
 constexpr int SP_THREADS = 512;
-// ---- LDS map (BYTES): 71 680 B per workgroup => two workgroups per CU (eight waves of <= 128 VGPRs each)
+// ---- LDS map (BYTES): 75 776 B per workgroup => two workgroups per CU (eight waves of <= 128 VGPRs each)
 //   R0 [0, 49152): X f32 [16 clips][642]  ->  |X| planes [3][4 frames][16 k-groups][16 clips][8 bf16]  ->  conv1 output planes (same shape)
 //                  ->  conv3 output planes [3][8][16][8] at 0 and conv4 output planes [3][16][16][8] at 8192
 //   R1 [49152, 61440): conv2 output planes [3][2 frames][8 k-groups][16][8]
 //   scratch f32 [512]: bin-64 partial sums [8 waves][re|im][16 clips]; Nyquist magnitudes [4 frames][16 clips] at +256
-//   exchange f32 [4 row tiles][2][64 lanes][4]: partial sums of the waves that own the other half of K (conv2, conv3)
+//   stash 12 288 B: the first tile's conv4 planes (a workgroup encodes TWO tiles one after the other and runs W_ih once for both: every
+//                   W_ih fragment -- 384 KB per tile, the phase that sat at the L2 ceiling -- then serves 32 columns instead of 16)
+//   exchange f32: partial sums of the waves that own the other half of K -- conv2's inside its own output region, conv3's in R0
 constexpr int SP_PL128 = 16384, SP_FR128 = 4096;
 constexpr int SP_R1 = 49152, SP_PL2 = 4096, SP_FR2 = 2048;
 constexpr int SP_C3 = 0, SP_PL3 = 2048;
 constexpr int SP_C4 = 8192, SP_PL4 = 4096;
 constexpr int SP_SCR = SP_R1 + 12288;
-constexpr int SP_EXC = SP_SCR + 2048;
-constexpr int SP_LDS_BYTES = SP_EXC + 8192;
+constexpr int SP_STASH = SP_SCR + 2048;     // conv4 output planes of the pair's FIRST tile, kept for the joint W_ih phase (12 288 B)
+constexpr int SP_EXC2 = SP_R1;              // conv2's K-half exchange (8 KB) sits in conv2's own output region: read, barrier, then the planes
+constexpr int SP_EXC3 = 32768;              // conv3's (4 KB) in R0 behind its output (conv1's planes are dead by then)
+constexpr int SP_LDS_BYTES = SP_STASH + 12288;
 static_assert(16 * X_LDM * 4 <= SP_R1 && 3 * SP_PL128 <= SP_R1 && SP_C4 + 3 * SP_PL4 <= SP_R1 && SP_C3 + 3 * SP_PL3 <= SP_C4 &&
               2 * SP_LDS_BYTES <= 160 * 1024, "split encoder LDS map");
 
@@ -94,7 +98,7 @@ __device__ __forceinline__ void load_a3(bf16x8 (&a)[3], const float *frag3, int 
 // 512-thread workgroups, but the halves stream the SAME weight fragments at the same moment, so the second request of every line is an
 // L1 hit instead of an L2 read (the weight stream out of L2 is the kernel's largest stall: tools/exp_encoder.py, "every fragment from
 // one address" 5.77 -> 4.51 ms).
-template <typename SampleT, int HALVES>
+template <typename SampleT, int HALVES, int NSUB>
 __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_kernel(
     const float *__restrict__ P, const SampleT *__restrict__ audio, float in_scale, long long n_samples,
     long long row_stride, long long origin, int B, int G, int T, int Gws, int g0, float *__restrict__ gx) {
@@ -103,16 +107,24 @@ __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_ke
     unsigned char *smem = smem_all + half * SP_LDS_BYTES;
     float *X = reinterpret_cast<float *>(smem);
     float *scr = reinterpret_cast<float *>(smem + SP_SCR), *nyq = scr + 256;
-    float *exc = reinterpret_cast<float *>(smem + SP_EXC);
 
-    const int tid = threadIdx.x & (SP_THREADS - 1), lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, i = lane & 15;
-    const long long tile_raw = (long long)blockIdx.x * HALVES + half, ntile = (long long)G * T;
-    const bool tile_ok = tile_raw < ntile;                   // an odd tile count leaves the last workgroup's second half without work:
-    const int tile_id = (int)(tile_ok ? tile_raw : ntile - 1);      // it recomputes the last tile (the barriers are workgroup-wide) and stores nothing
-    const int grp = tile_id % G, t = tile_id / G;
+    int tid0 = threadIdx.x & (SP_THREADS - 1);
+    const long long ntile = (long long)G * T;
     const bool fold = P[OFF_FOLD] != 0.f;      // uniform: the basis has the DFT symmetries -> folded STFT pass
     SP_T0();
+#pragma unroll 1
+    for (int sub = 0; sub < NSUB; ++sub) {
+    // per tile: nothing derived from the thread index is hoisted out of the tile loop (every phase's per-lane LDS offsets and fragment
+    // pointers are loop-invariant; hoisted, they spilled 1.8 KB per lane)
+    asm volatile("" : "+v"(tid0));
+    const int tid = tid0, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, i = lane & 15;
+    // the workgroup's tiles: an odd tile count leaves the last workgroup's last slot without work -- it recomputes the last tile (the
+    // barriers are workgroup-wide) and stores nothing
+    const long long tile_raw = ((long long)blockIdx.x * HALVES + half) * NSUB + sub;
+    const bool tile_ok = tile_raw < ntile;
+    const int tile_id = (int)(tile_ok ? tile_raw : ntile - 1);
+    const int grp = tile_id % G, t = tile_id / G;
 
     // ---------------- phase 0: the 16 windows (576 samples each) + right reflect pad of 64 (as silero_encode_kernel stages them:
     // folded pass -> even / odd samples in separate planes of the clip row)
@@ -385,8 +397,9 @@ __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_ke
 #pragma unroll
         for (int o = 0; o < 2; ++o) { hi[o] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[o] = hi[o]; }
         const float *wq = P + OFF_Q2 + (rt * 4 + 2 * kh) * (3 * 3 * QF);
-        bf16x8 a[2][3];
+        bf16x8 a[3][3];                    // (a step is 6 - 12 MFMAs: the fragment stream runs two steps ahead, see phase 6)
         load_a3(a[0], SP_W(wq), lane);
+        load_a3(a[1], SP_W(wq + 3 * QF), lane);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 b[4][3];
@@ -395,8 +408,8 @@ __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_ke
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const int s = kk * 3 + tap;
-                if (s + 1 < 6) load_a3(a[(s + 1) & 1], SP_W(wq + (s + 1) * 3 * QF), lane);
-                const bf16x8 (&ac)[3] = a[s & 1];
+                if (s + 2 < 6) load_a3(a[(s + 2) % 3], SP_W(wq + (s + 2) * 3 * QF), lane);
+                const bf16x8 (&ac)[3] = a[s % 3];
 #define SP_TERM(AP, BP, ACC)                                                                  \
     _Pragma("unroll") for (int o = 0; o < 2; ++o) {                                           \
         const int fi = 2 * o + tap - 1;                                                       \
@@ -407,19 +420,25 @@ __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_ke
             }
         }
         f32x4 s2[2] = {hi[0] + lo[0], hi[1] + lo[1]};
+        float *exc = reinterpret_cast<float *>(smem + SP_EXC2);
         if (kh == 1) {
 #pragma unroll
             for (int o = 0; o < 2; ++o) *reinterpret_cast<f32x4 *>(exc + ((rt * 2 + o) * 64 + lane) * 4) = s2[o];
         }
         __syncthreads();
+        f32x4 other[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (kh == 0) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) other[o] = *reinterpret_cast<const f32x4 *>(exc + ((rt * 2 + o) * 64 + lane) * 4);
+        }
+        __syncthreads();              // the exchange sits inside the planes' region: every partial sum is read before the first plane store
         if (kh == 0) {
             const f32x4 bias = ldg4(P + OFF_B2 + 16 * rt + 4 * q);
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
-                const f32x4 other = *reinterpret_cast<const f32x4 *>(exc + ((rt * 2 + o) * 64 + lane) * 4);
                 f32x4 y;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = fmaxf(s2[o][r] + other[r] + bias[r], 0.f);
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(s2[o][r] + other[o][r] + bias[r], 0.f);
                 store_split4(smem + SP_R1 + o * SP_FR2, SP_PL2, 4 * rt + q, i, y);
             }
         }
@@ -440,6 +459,7 @@ __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_ke
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) if (!SP_SKIP(3)) mfma_split6(a[kc], b[kc], hi, lo);
         f32x4 s3 = hi + lo;
+        float *exc = reinterpret_cast<float *>(smem + SP_EXC3);
         if (th == 1) *reinterpret_cast<f32x4 *>(exc + (rt * 64 + lane) * 4) = s3;
         __syncthreads();
         if (th == 0) {
@@ -469,37 +489,59 @@ __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_ke
         f32x4 y;
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[r] = fmaxf(hi[r] + lo[r], 0.f);
-        store_split4(smem + SP_C4, SP_PL4, 4 * rt + q, i, y);
+        store_split4(smem + (sub + 1 < NSUB ? SP_STASH : SP_C4), SP_PL4, 4 * rt + q, i, y);      // the last tile's planes stay in R0
     }
     __syncthreads();
     SP_MARK(8);
+    }      // sub
 
-    // ---------------- phase 6: LSTM input projection, gate-major (D rows = hidden units 16 wave + 4 q + r, columns = clips)
+    asm volatile("" : "+v"(tid0));
+    const int tid = tid0, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
+    (void)tid;
+    // ---------------- phase 6: LSTM input projection for the workgroup's NSUB tiles at once, gate-major (D rows = hidden units
+    // 16 wave + 4 q + r, columns = clips): every W_ih fragment is loaded once and multiplies NSUB column tiles
     {
-        f32x4 hi[4], lo[4];
+        f32x4 hi[NSUB][4], lo[NSUB][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            hi[g] = ldg4(P + OFF_BG + g * 128 + wave * 16 + 4 * q);
-            lo[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 bg = ldg4(P + OFF_BG + g * 128 + wave * 16 + 4 * q);
+#pragma unroll
+            for (int sb = 0; sb < NSUB; ++sb) { hi[sb][g] = bg; lo[sb][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
+        // A step here is six MFMAs (one gate): a fragment requested one step ahead has ~100 cycles of this wave's MFMAs (~400 with the SIMD's
+        // other waves) to cross from L2 -- too little (halving the W_ih fragment bytes changed nothing, serving them from L1 did): the
+        // stream runs THREE steps ahead on four rotating register sets.
         const float *wq = P + OFF_QIH + wave * (4 * 4 * 3 * QF);
-        bf16x8 a[2][3];
-        load_a3(a[0], SP_W(wq), lane);
+        constexpr int AHEAD = 3;
+        bf16x8 a[AHEAD + 1][3];
+#pragma unroll
+        for (int s0 = 0; s0 < AHEAD; ++s0) load_a3(a[s0], SP_W(wq + s0 * 3 * QF), lane);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-            bf16x8 b[3];
-            load_b3(b, smem + SP_C4, SP_PL4, kc, q, i);
+            bf16x8 b[NSUB][3];
+#pragma unroll
+            for (int sb = 0; sb < NSUB; ++sb) load_b3(b[sb], smem + (sb + 1 < NSUB ? SP_STASH : SP_C4), SP_PL4, kc, q, i);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int s = kc * 4 + g;
-                if (s + 1 < 16) load_a3(a[(s + 1) & 1], SP_W(wq + (s + 1) * 3 * QF), lane);
-                if (!SP_SKIP(6)) mfma_split6(a[s & 1], b, hi[g], lo[g]);
+                if (s + AHEAD < 16) load_a3(a[(s + AHEAD) % (AHEAD + 1)], SP_W(wq + (s + AHEAD) * 3 * QF), lane);
+                const bf16x8 (&ac)[3] = a[s % (AHEAD + 1)];
+                if (!SP_SKIP(6)) {
+#define SP_TERM(AP, BP, ACC) _Pragma("unroll") for (int sb = 0; sb < NSUB; ++sb) ACC[sb][g] = mfma_bf16(ac[AP], b[sb][BP], ACC[sb][g]);
+                    SP_TERM(2, 0, lo) SP_TERM(1, 1, lo) SP_TERM(0, 2, lo) SP_TERM(1, 0, lo) SP_TERM(0, 1, lo) SP_TERM(0, 0, hi)
+#undef SP_TERM
+                }
             }
         }
-        float *dst = gx + ((size_t)t * Gws + g0 + grp) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
-        if (tile_ok)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = hi[g] + lo[g];
+        for (int sb = 0; sb < NSUB; ++sb) {
+            const long long tile_raw = ((long long)blockIdx.x * HALVES + half) * NSUB + sb;
+            const int tile_id = (int)(tile_raw < ntile ? tile_raw : ntile - 1);
+            float *dst = gx + ((size_t)(tile_id / G) * Gws + g0 + tile_id % G) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
+            if (tile_raw < ntile)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = hi[sb][g] + lo[sb][g];
+        }
     }
     SP_MARK(9);
 }
@@ -634,19 +676,25 @@ int silero_lstm_split_launch(const float *packed, const float *gx, const float *
     return VADX_OK;
 }
 
-// 1 = one tile per 512-thread workgroup (two independent workgroups per CU); 2 = the lockstep pair.  Measured on one box, B = 4096 x 10 s:
-// 5.75 ms against 6.35 ms -- the L1 hits of the pair do not pay for what the lockstep costs: two independent workgroups sit in DIFFERENT
-// phases most of the time (one in its f32 STFT or its staging while the other streams weights), the pair never does.
+// VADX_SPLIT_HALVES: 1 = 512-thread workgroups (two independent ones per CU); 2 = the lockstep pair.  Measured on one box, B = 4096 x 10 s
+// (one tile per workgroup half): 5.75 ms against 6.35 ms -- the L1 hits of the pair do not pay for what the lockstep costs: two
+// independent workgroups sit in DIFFERENT phases most of the time (one in its f32 STFT or its staging while the other streams
+// weights), the pair never does.
+// VADX_SPLIT_NSUB: tiles a workgroup encodes one after the other before ONE joint W_ih phase (2: every W_ih fragment serves 32 columns,
+// at the price of the first tile's conv4 planes in a 12 KB stash and one more barrier in conv2).
 #ifndef VADX_SPLIT_HALVES
 #define VADX_SPLIT_HALVES 1
+#endif
+#ifndef VADX_SPLIT_NSUB
+#define VADX_SPLIT_NSUB 1       // 2 measured no faster on the same box (5.61 against 5.59 ms): the W_ih phase waits on fragment LATENCY, not on L2 bandwidth
 #endif
 template <typename S>
 int silero_encode_split_launch(const float *packed, const S *src, float in_scale, long long n_valid, long long row_stride,
                                long long origin, int batch, int G, int steps, int Gws, int first_group, float *gx, void *stream) {
-    constexpr int HV = VADX_SPLIT_HALVES;
-    VADX_DYN_LDS((silero_encode_split_kernel<S, HV>), SP_LDS_BYTES * HV);
-    const long long nblk = ((long long)G * steps + HV - 1) / HV;
-    hipLaunchKernelGGL((silero_encode_split_kernel<S, HV>), dim3((unsigned)nblk), dim3(SP_THREADS * HV), SP_LDS_BYTES * HV, static_cast<hipStream_t>(stream),
+    constexpr int HV = VADX_SPLIT_HALVES, NS = VADX_SPLIT_NSUB;
+    VADX_DYN_LDS((silero_encode_split_kernel<S, HV, NS>), SP_LDS_BYTES * HV);
+    const long long nblk = ((long long)G * steps + HV * NS - 1) / (HV * NS);
+    hipLaunchKernelGGL((silero_encode_split_kernel<S, HV, NS>), dim3((unsigned)nblk), dim3(SP_THREADS * HV), SP_LDS_BYTES * HV, static_cast<hipStream_t>(stream),
                        packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps, Gws, first_group, gx);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
