@@ -43,5 +43,8 @@ else:
         h.vadx_frontend_debug_cycles(buf, 0)
         tot = sum(buf[:5])
         print("%s (%s): %d clips x %d samples, %.2f ms" % (preset, {False: "dense", True: "folded", 4: "split dense"}[fold], clips.shape[0], n, a.elapsed_time(b)))
+        print("   sum of wave-0 clock deltas over workgroups / kernel time: %.1f M ticks per ms" % (tot / 1e6 / a.elapsed_time(b)))
+        if buf[6]:
+            print("   clock64 / wall_clock64 (100 MHz) over the workgroups: %.1f -> shader clock %.2f GHz" % (buf[5] / buf[6], buf[5] / buf[6] / 10.0))
         for nm, v in zip(NAMES, buf[:5]):
             print("   %-30s %6.2f %%" % (nm, 100.0 * v / tot))

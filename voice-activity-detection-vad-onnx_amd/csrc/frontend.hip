@@ -359,7 +359,7 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     if (c->fold == 4) {
         // dense product on bf16 x 3 split operands (frontend_split_kernel): the flat sample planes need hop = 160 (their skew), the
         // staging knows the int16 preps 0 - 2
-        if (c->hop != 160 || c->prep > 2 || c->taps > 512) return -1;
+        if (c->hop != 160 || c->prep > 2 || c->taps > 512 || c->n_bins > 17 * 16) return -1;
         d->fold = 4;
         d->s_nch = (c->taps + 31) / 32;
         d->s_nbt = (c->n_bins + 15) / 16;
@@ -561,11 +561,33 @@ __device__ __forceinline__ void stage_tile(const Dev &d, const int16_t *__restri
 // each lane stores 4 consecutive mels
 // (bands: the folded kernel reads [mel tile][lo, hi] from the blob -- with its four tile variants inlined, the dynamic index into the
 // by-value Dev arrays made the compiler keep a 384-byte copy of Dev in scratch)
-template <int MT, bool BANDS = false>
+template <int MT, bool BANDS = false, int NWV = THREADS / 64>
 __device__ __forceinline__ void mel_phase(const Dev &d, const float *__restrict__ P, const float *PW, int p_ld, int f0,
                                           float *__restrict__ out_win, const int *__restrict__ bands = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
-    for (int mtile = wave; mtile < d.nmt; mtile += THREADS / 64) {
+    auto finish = [&](int mtile, int mt, const f32x4 &a) {
+        const int f = f0 + mt * 16 + i;
+        if (f < d.frames) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = FE_LOG(d.log_mode ? __fadd_rn(a[r], d.log_floor) : fmaxf(a[r], d.log_floor));
+            *reinterpret_cast<f32x4 *>(out_win + (size_t)f * d.out_stride + d.out_off + mtile * 16 + 4 * q) = v;
+        }
+    };
+    if (NWV < 8) {
+        // few waves (the split kernel's four): (mel tile, column tile) items -- five mel tiles would be two rounds with one busy wave
+        for (int item = wave; item < d.nmt * MT; item += NWV) {
+            const int mtile = item / MT, mt1 = item - mtile * MT;
+            f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+            const int lo = BANDS ? bands[2 * mtile] : d.mel_kb_lo[mtile], hi = BANDS ? bands[2 * mtile + 1] : d.mel_kb_hi[mtile];
+            const float *const wrow[1] = {vadx::frag_ptr(P + d.off_mel, d.Fp, mtile, lo * 16, lane)};
+            const int moff[1] = {mt1 * 16};
+            if (hi > lo) vadx::gemm_rt_simple<1, 1, true>(acc, PW + lo * 16 * p_ld, p_ld, moff, wrow, hi - lo, lane);
+            finish(mtile, mt1, acc[0][0]);
+        }
+        return;
+    }
+    for (int mtile = wave; mtile < d.nmt; mtile += NWV) {
         f32x4 acc[1][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -576,18 +598,7 @@ __device__ __forceinline__ void mel_phase(const Dev &d, const float *__restrict_
         for (int mt = 0; mt < MT; ++mt) moff[mt] = mt * 16;
         if (hi > lo) vadx::gemm_rt_simple<1, MT, true>(acc, PW + lo * 16 * p_ld, p_ld, moff, wrow, hi - lo, lane);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int f = f0 + mt * 16 + i;
-            if (f < d.frames) {
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float m = acc[0][mt][r];
-                    v[r] = FE_LOG(d.log_mode ? __fadd_rn(m, d.log_floor) : fmaxf(m, d.log_floor));
-                }
-                *reinterpret_cast<f32x4 *>(out_win + (size_t)f * d.out_stride + d.out_off + mtile * 16 + 4 * q) = v;
-            }
-        }
+        for (int mt = 0; mt < MT; ++mt) finish(mtile, mt, acc[0][mt]);
     }
 }
 
@@ -1110,24 +1121,33 @@ __global__ __launch_bounds__(THREADS, 4) void frontend_fold3_kernel(
 //     over different banks).
 //   * wave = bin tile (real and imaginary rows side by side, all four column tiles); the power goes to PW[bin][frame] float32 for the
 //     banded mel GEMM + log of the other kernels (mel_phase).
-// LDS: planes 3 x 21.5 KB | power rows [Fp][68] f32 (74 KB at 257 bins): one workgroup per CU, eight waves of <= 256 VGPRs.
+// LDS: planes 3 x 21.5 KB, then the power rows [Fp][68] f32 (74 KB at 257 bins) in their place: two workgroups of four waves per CU.
 __device__ __forceinline__ int sq_slot(int b) { return b + 2 * ((b * 3277) >> 18); }      // b / 80 for b < 13 000
 constexpr int SQ_BLOCKS = 63 * 20 + 4 * 16;                                               // blocks of a 64-frame tile, taps <= 512
 constexpr int SQ_PLANE_BYTES = (SQ_BLOCKS + 2 * (SQ_BLOCKS / 80) + 2 + 7) / 8 * 8 * 16;
-static size_t split_lds_bytes(const Dev *d) { return 3 * (size_t)SQ_PLANE_BYTES + (size_t)d->Fp * XF_LD * 4; }
+constexpr int SQ_THREADS = 256, SQ_WAVES = SQ_THREADS / 64;
+static size_t split_lds_bytes(const Dev *d) {
+    const size_t pw = (size_t)d->Fp * XF_LD * 4;
+    return pw > 3 * (size_t)SQ_PLANE_BYTES ? pw : 3 * (size_t)SQ_PLANE_BYTES;
+}
 
+// Four waves per workgroup and <= 80 KB of LDS: TWO workgroups per CU, each in a phase of its own -- one stages or runs its mel GEMM
+// (VALU, loads, f32 MFMA) while the other's split products own the bf16 pipe.  The power rows take the PLANES' place: a wave keeps the
+// power of its bin tiles in registers (<= 4 rounds x MT fragments) until every wave has read its last sample block.
 template <int MT>
 __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict__ P, const int16_t *__restrict__ win, float mean,
                                            int f0, float *__restrict__ out_win, unsigned char *smem) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, i = lane & 15;
     constexpr int NF = MT * 16;
-    float *PW = reinterpret_cast<float *>(smem + 3 * SQ_PLANE_BYTES);
+    float *PW = reinterpret_cast<float *>(smem);
     FE_T0();
     // ---- phase 0: prep + split: item = block of eight consecutive samples (all nine loads unconditional, from clamped indices)
     {
         const int n0 = f0 * d.hop + d.tap0 - d.center_pad, nblk = (NF - 1) * 20 + 4 * d.s_nch;
-        for (int b0 = tid; b0 < nblk; b0 += THREADS) {
+        for (int b0 = tid; b0 < nblk; b0 += SQ_THREADS) {
             float x[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) {
@@ -1163,11 +1183,16 @@ __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict
     FE_ACC(4);
     __syncthreads();
     FE_ACC(0);
-    // ---- phase 1: DFT as split products, |.|^2 -> PW[bin][frame]
+    // ---- phase 1: DFT as split products, |.|^2 kept in registers
     const float *tab = P + d.off_fold;
     const size_t tstride = (size_t)d.s_nch * 3 * vadx::QFRAG;
-    const int full = (d.s_nbt / (THREADS / 64)) * (THREADS / 64);
-    for (int bt = wave; bt < full; bt += THREADS / 64) {
+    // rounds of four bin tiles; one leftover tile (17 = 4 x 4 + 1, 13 = 3 x 4 + 1) goes out as (bin tile, column tile) items instead of
+    // a round with one busy wave; two or three leftover tiles are a (partial) round of their own (s_nbt <= 17: at most four rounds)
+    const int rem = d.s_nbt & 3, rounds = (d.s_nbt >> 2) + (rem > 1 ? 1 : 0);
+    f32x4 pw[4][MT], pl = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < rounds; ++r) {
+        const int bt = 4 * r + wave;
+        if (bt >= d.s_nbt) break;                  // (wave-uniform; no barrier below)
         f32x4 hi[2][MT], lo[2][MT];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1176,18 +1201,24 @@ __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict
         const float *const w[2] = {tab + (size_t)(2 * bt) * tstride, tab + (size_t)(2 * bt + 1) * tstride};
         vadx::qgemm_group<2, MT, true>(hi, lo, w, 0, d.s_nch, smem, SQ_PLANE_BYTES,
                                        [=](int G, int mt) { return sq_slot(20 * (16 * mt + i) + G) * 16; }, lane);
+        f32x4 p[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float re = hi[0][mt][r] + lo[0][mt][r], im = hi[1][mt][r] + lo[1][mt][r];
-                PW[(bt * 16 + 4 * q + r) * XF_LD + mt * 16 + i] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+            for (int rr = 0; rr < 4; ++rr) {
+                const float re = hi[0][mt][rr] + lo[0][mt][rr], im = hi[1][mt][rr] + lo[1][mt][rr];
+                p[mt][rr] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
             }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {         // (constant indices: the rows stay in registers)
+            if (r == 0) pw[0][mt] = p[mt];
+            else if (r == 1) pw[1][mt] = p[mt];
+            else if (r == 2) pw[2][mt] = p[mt];
+            else pw[3][mt] = p[mt];
+        }
     }
-    // the bin tiles that do not fill a round of eight (17 tiles: the last one; 13 tiles: five) go out as (bin tile, column tile) items, so
-    // that the last round costs a quarter of a full one instead of leaving most waves idle behind one or five busy ones
-    for (int item = wave; item < (d.s_nbt - full) * MT; item += THREADS / 64) {
-        const int bt = full + item / MT, mt1 = item - (item / MT) * MT;
+    if (rem == 1 && wave < MT) {
+        const int bt = d.s_nbt - 1, mt1 = wave;
         f32x4 hi[2][1], lo[2][1];
 #pragma unroll
         for (int a = 0; a < 2; ++a) { hi[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][0] = hi[a][0]; }
@@ -1195,19 +1226,33 @@ __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict
         vadx::qgemm_group<2, 1, true>(hi, lo, w, 0, d.s_nch, smem, SQ_PLANE_BYTES,
                                       [=](int G, int) { return sq_slot(20 * (16 * mt1 + i) + G) * 16; }, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float re = hi[0][0][r] + lo[0][0][r], im = hi[1][0][r] + lo[1][0][r];
-            PW[(bt * 16 + 4 * q + r) * XF_LD + mt1 * 16 + i] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+        for (int rr = 0; rr < 4; ++rr) {
+            const float re = hi[0][0][rr] + lo[0][0][rr], im = hi[1][0][rr] + lo[1][0][rr];
+            pl[rr] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
         }
     }
     FE_ACC(1);
-    __syncthreads();
+    __syncthreads();                               // every sample block has been read: the power rows take the planes' place
     FE_ACC(2);
-    mel_phase<MT, true>(d, P, PW, XF_LD, f0, out_win, reinterpret_cast<const int *>(P + d.off_plan));
+    for (int r = 0; r < rounds; ++r) {
+        const int bt = 4 * r + wave;
+        if (bt >= d.s_nbt) break;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = r == 0 ? pw[0][mt] : (r == 1 ? pw[1][mt] : (r == 2 ? pw[2][mt] : pw[3][mt]));
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) PW[(bt * 16 + 4 * q + rr) * XF_LD + mt * 16 + i] = v[rr];
+        }
+    }
+    if (rem == 1 && wave < MT)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) PW[((d.s_nbt - 1) * 16 + 4 * q + rr) * XF_LD + wave * 16 + i] = pl[rr];
+    __syncthreads();
+    mel_phase<MT, true, SQ_WAVES>(d, P, PW, XF_LD, f0, out_win, reinterpret_cast<const int *>(P + d.off_plan));
     FE_ACC(3);
 }
 
-__global__ __launch_bounds__(THREADS, 2) void frontend_split_kernel(
+__global__ __launch_bounds__(SQ_THREADS, 2) void frontend_split_kernel(
     Dev d, const float *__restrict__ P, const int16_t *__restrict__ audio, long long row_stride,
     long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsmem[];
@@ -1217,10 +1262,19 @@ __global__ __launch_bounds__(THREADS, 2) void frontend_split_kernel(
     const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
     float *out_win = out + (size_t)widx * d.frames * d.out_stride;
     const float mean = means ? means[widx] : 0.f;
+#if FE_EXP
+    const long long fe_c0 = clock64(), fe_w0 = wall_clock64();
+#endif
     if (tile < d.tiles64) split_tile<4>(d, P, win, mean, tile * TF_FOLD, out_win, fsmem);
     else if (d.tail_mt == 3) split_tile<3>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
     else if (d.tail_mt == 2) split_tile<2>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
     else split_tile<1>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
+#if FE_EXP
+    if (threadIdx.x == 0) {     // shader clock against the constant 100 MHz counter
+        atomicAdd(&fe_dbg[5], (unsigned long long)(clock64() - fe_c0));
+        atomicAdd(&fe_dbg[6], (unsigned long long)(wall_clock64() - fe_w0));
+    }
+#endif
 }
 
 __global__ __launch_bounds__(THREADS, 4) void frontend_logmel_kernel(
@@ -1524,7 +1578,7 @@ extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *p
         const long long nblk = nwin * (d.tiles64 + (d.tail_mt ? 1 : 0));
         VADX_REQUIRE(nblk < (1LL << 31), "vadx_frontend_logmel: too many tiles");
         VADX_DYN_LDS(frontend_split_kernel, 160 * 1024);
-        hipLaunchKernelGGL(frontend_split_kernel, dim3((unsigned)nblk), dim3(THREADS), slds, st, d, packed, audio, (long long)row_stride,
+        hipLaunchKernelGGL(frontend_split_kernel, dim3((unsigned)nblk), dim3(SQ_THREADS), slds, st, d, packed, audio, (long long)row_stride,
                            (long long)win_stride, windows_per_clip, means, out);
         VADX_HIP_TRY(hipGetLastError());
         return VADX_OK;

@@ -38,7 +38,12 @@ __device__ __forceinline__ void qgemm_group(f32x4 (&hi)[NT][MTT], f32x4 (&lo)[NT
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) a[nt][p] = ldq(w[nt] + (size_t)(kc * 3 + p) * QFRAG, lane);
+            for (int p = 0; p < 3; ++p) {
+#if defined(QG_WHATIF) && (QG_WHATIF & 1)
+                if (kc > kc0) { a[nt][p] = a0[nt][p]; continue; }     // what-if: the weight stream costs nothing
+#endif
+                a[nt][p] = ldq(w[nt] + (size_t)(kc * 3 + p) * QFRAG, lane);
+            }
     };
     auto step = [&](int kc, const bf16x8 (&a)[NT][3]) {
         bf16x8 b[MTT][3];
@@ -49,7 +54,13 @@ __device__ __forceinline__ void qgemm_group(f32x4 (&hi)[NT][MTT], f32x4 (&lo)[NT
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) b[mt][p] = *reinterpret_cast<const bf16x8 *>(act + boff[mt] + p * act_pl);
+            for (int mt = 0; mt < MTT; ++mt) {
+#if defined(QG_WHATIF) && (QG_WHATIF & 2)
+                b[mt][p] = a[0][p];                 // what-if: the activation reads cost nothing
+                continue;
+#endif
+                b[mt][p] = *reinterpret_cast<const bf16x8 *>(act + boff[mt] + p * act_pl);
+            }
         // six products per (n-tile, column tile), tiles innermost: consecutive MFMAs hit different accumulators
 #define QL_TERM(AP, BP, ACC)                                                                                                   \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int mt = 0; mt < MTT; ++mt)                       \
