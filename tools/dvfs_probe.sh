@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void k(int mode, int iters, const float *sr
 int main() {
     std::vector<float> h(8192);
     srand(7);
-    for (auto &v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    for (auto &v : h) v = (float)(rand() % 20001) / 20000.0f - 0.5f;
     float *src, *sink; unsigned long long *clk;
     hipMalloc(&src, 8192 * 4); hipMalloc(&sink, 4096); hipMalloc(&clk, 16);
     hipMemcpy(src, h.data(), 8192 * 4, hipMemcpyHostToDevice);
@@ -85,7 +85,7 @@ int main() {
             unsigned long long c[2]; hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost);
             const double waves = (m == 6 ? 4 : 8) * 256.0, n = waves * iters[m] * mf[m];
             printf("%-5s %8.3f ms  shader clock %.2f GHz  %7.1f G MFMA/s  %7.1f TFLOP/s  cycles per MFMA and SIMD %.1f\n", names[m], ms,
-                   (double)c[0] / c[1] / 10.0, n / ms / 1e6, n * flop[m] / ms / 1e9, n ? (double)c[0] / 256 * 4 / n * (256.0) / 1.0 / 1.0 * 1.0 / 1.0 : 0.0);
+                   (double)c[0] / c[1] / 10.0, n / ms / 1e6, n * flop[m] / ms / 1e9, n ? (double)c[0] / 256.0 * 1024.0 / n : 0.0);
         }
     return 0;
 }

@@ -55,6 +55,24 @@ struct Cfg {
     int cin, cout, k, stride, dil, pad, has_dw, cres, relu, cinp, coutp, cresp, in_ld, out_alias;
 };
 
+// A FIR thread's register window / its eight outputs as 16-byte LDS accesses (rows and window starts are multiples of four floats).
+// As single floats the window reads of a wave fell on 8 of the 32 banks (every address a multiple of four floats apart: row strides
+// = 4 mod 8, starts = 0 mod 8) -- four-way conflicts on every read, half of all LDS cycles of these kernels (profiles/r03_marblenet).
+template <int N>
+__device__ __forceinline__ void window_load(float (&win)[N], const float *row) {
+#pragma unroll
+    for (int v = 0; v < (N + 3) / 4; ++v) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(row + 4 * v);      // (the last one may read <= 3 floats of row padding)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * v + e < N) win[4 * v + e] = t[e];
+    }
+}
+__device__ __forceinline__ void store8(float *dst, const float (&o)[8]) {
+    *reinterpret_cast<f32x4 *>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+}
+
 // KT / DT / ST: compile-time kernel size, dilation and stride of the depthwise stage (0 = take them from `c` at run
 // time: the generic fallback).  With constants the FIR is a register-window filter -- a thread owns 8 consecutive
 // outputs of one channel, reads its (8-1)*stride + (k-1)*dil + 1 inputs and its k taps ONCE, and everything after
@@ -145,15 +163,16 @@ __global__ __launch_bounds__(THREADS, 2) void sepconv_block_kernel(
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) wk[kk] = dw_w[cc * KK + kk];
                 const float *row = IN + ch * IN_LD + m0 * (ST ? ST : 1);
-#pragma unroll
-                for (int u = 0; u < WIN; ++u) win[u] = row[u];
+                window_load(win, row);
+                float o8[8];
 #pragma unroll
                 for (int o = 0; o < 8; ++o) {
                     float s2 = 0.f;
 #pragma unroll
                     for (int kk = 0; kk < KK; ++kk) s2 = fmaf(wk[kk], win[o * (ST ? ST : 1) + kk * (DT ? DT : 1)], s2);
-                    D[ch * A_LD + m0 + o] = ch < c.cin ? s2 : 0.f;
+                    o8[o] = ch < c.cin ? s2 : 0.f;
                 }
+                store8(D + ch * A_LD + m0, o8);
             }
         } else {
             for (int e = tid; e < c.cinp * TILE; e += THREADS) {
@@ -299,7 +318,11 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     MB_ACC(0);
     __syncthreads();
     MB_ACC(7);
-    const KPre wpw0 = kgemm_pre(pw0, c.cinp);                // pointwise 0's weights: in flight through the residual GEMM and depthwise 0
+    // pointwise 0's weights: in flight through the residual GEMM and depthwise 0 -- except at K = 17, whose 24-value window + 17 taps +
+    // 16 prefetched weight registers no longer fit the 80 VGPRs of six waves per SIMD (20 B of scratch per lane doubled the kernel's
+    // HBM writes): there they are requested behind the filter
+    KPre wpw0;
+    if (K < 17) wpw0 = kgemm_pre(pw0, c.cinp);
     // residual 1x1 of the block input (frames t0 .. t0 + 31 sit at column 2 PAD), before the input is overwritten
     kgemm<2>(wres, c.cinp, IN, IN_LD, 2 * PAD, ROUT, A_LD, rb, false);
     MB_ACC(1);
@@ -316,8 +339,7 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) wk[kk] = dw0[cc * K + kk];
             float *row = IN + ch * IN_LD + m0;
-#pragma unroll
-            for (int u = 0; u < 7 + K; ++u) win[u] = row[u];
+            window_load(win, row);
             float o8[8];
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
@@ -327,14 +349,15 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
                 o8[o] = ch < c.cin ? s2 : 0.f;
             }
             __builtin_amdgcn_wave_barrier();                // keep every lane's reads above every lane's writes in the schedule
-#pragma unroll
-            for (int o = 0; o < 8; ++o) row[o] = o8[o];
+            store8(row, o8);
         }
     }
+    if (K >= 17) wpw0 = kgemm_pre(pw0, c.cinp);
     MB_ACC(2);
     __syncthreads();
     MB_ACC(7);
-    const KPre wpw1 = kgemm_pre(pw1, c.c1);                  // pointwise 1's weights: in flight through pointwise 0 and depthwise 1
+    KPre wpw1;                                               // pointwise 1's weights: in flight through pointwise 0 and depthwise 1
+    if (K < 17) wpw1 = kgemm_pre(pw1, c.c1);
     // pointwise 0 + folded BN + ReLU on 48 columns
     kgemm<3>(wpw0, c.cinp, D0, IN_LD, 0, H1, H_LD, b0, true);
     MB_ACC(3);
@@ -347,10 +370,11 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) wk[kk] = dw1[ch * K + kk];
         const float *row = H1 + ch * H_LD + m0;
+        window_load(win, row);
 #pragma unroll
         for (int u = 0; u < 7 + K; ++u) {
             const int fr = t0 - PAD + m0 + u;
-            win[u] = (fr >= 0 && fr < c.T) ? row[u] : 0.f;
+            win[u] = (fr >= 0 && fr < c.T) ? win[u] : 0.f;
         }
         float o8[8];
 #pragma unroll
@@ -360,9 +384,9 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
             for (int kk = 0; kk < K; ++kk) s2 = fmaf(wk[kk], win[o + kk], s2);
             o8[o] = s2;
         }
-#pragma unroll
-        for (int o = 0; o < 8; ++o) D1[ch * A_LD + m0 + o] = o8[o];     // D1 sits in IN's region (D0 is dead since the barrier above)
+        store8(D1 + ch * A_LD + m0, o8);                                // D1 sits in IN's region (D0 is dead since the barrier above)
     }
+    if (K >= 17) wpw1 = kgemm_pre(pw1, c.c1);
     MB_ACC(4);
     __syncthreads();                // every H1 read is done: OUT may overwrite it
     MB_ACC(7);
@@ -424,15 +448,16 @@ __global__ __launch_bounds__(THREADS, 6) void marblenet_tail_kernel(
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) wk[kk] = dw[ch * K + kk];
         const float *row = IN + ch * IN_LD + m0;
-#pragma unroll
-        for (int u = 0; u < 7 + (K - 1) * DIL + 1; ++u) win[u] = row[u];
+        window_load(win, row);
+        float o8[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             float s2 = 0.f;
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) s2 = fmaf(wk[kk], win[o + kk * DIL], s2);
-            D[ch * A_LD + m0 + o] = s2;
+            o8[o] = s2;
         }
+        store8(D + ch * A_LD + m0, o8);
     }
     __syncthreads();
     {
