@@ -31,7 +31,7 @@ extern "C" {
  * the C client (tests/c/cabi_silero.c) and __graft_entry__.build() all read it from here and nowhere else.
  * 3: vadx_frontend_cfg grew `fold`; vadx_frontend_fold_kind, vadx_dfsmn_cfb_*, _lstm_t_ex, _ft_repack (round 3).
  * 4: vadx_silero_encoder_mode, vadx_gemm_mode; the Silero / FSMN packed blobs grew the bf16 x 3 weight fragments (round 4). */
-#define VADX_ABI_VERSION 4
+#define VADX_ABI_VERSION 5
 
 /* Arithmetic of the FSMN / FireRed dense layers, process-wide: 0 = exact-f32 MFMAs, 1 = bf16 x 3 split products (float32 operands
  * split exactly into three bf16 terms, six bf16 MFMAs per K = 32 step: float32-class accuracy at 6/16 of the matrix time, csrc/split3.h).
@@ -436,6 +436,11 @@ int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float 
  *           (zero for bin 0 and bins > 80); out_fix [20][10][64]: q = 0 -> conv31(ln1_w)[c][16 m + i], q = 1 -> conv31(ln1_b) + bias. */
 typedef struct vadx_dfsmn_cfb_weights {
     const float *ln0_w, *gate_w, *in_w, *in_b, *front_tab, *conv_w, *fwd_tbl, *fwd_fix, *lin_w, *lin_b, *inv_tbl, *out_fix;
+    /* ABI 5: the two DFT tables as bf16 x 3 split A fragments (csrc/split3.h) for the split-product kernels (vadx_gemm_mode 1), or NULL
+     * (the f32-MFMA kernels run then): fwd_tbl_q [10 row tiles][5 chunks of 32 bins][3 planes][256 floats], lane 16 g + i of a fragment
+     * holds T[16 tile + i][32 chunk + 8 g + e], e = 0..7, as eight bf16;  inv_tbl_q [10][6 chunks][3][256]: columns 0..80 = real parts
+     * of bins 0..80, 96 + k = imaginary part of bin k (k = 1..79), the rest zero. */
+    const float *fwd_tbl_q, *inv_tbl_q;
 } vadx_dfsmn_cfb_weights;
 int vadx_dfsmn_cfb_front(const vadx_dfsmn_cfb_weights *w, const vadx_ft_view *a, const vadx_ft_view *b, const float *stats0,
                          float *y1, float *stats1, float *li, float *stats_li, int tiles, void *stream);

@@ -51,8 +51,16 @@ if hasattr(h, "vadx_cfb_debug_cycles"):
              12: "back D: prologue", 13: "back D: LDS reads + MFMAs", 14: "back D: barrier wait", 15: "back D: epilogue"}
     tot_p, tot_d = sum(buf[k] for k in (8, 9, 10, 11)), sum(buf[k] for k in (12, 13, 14, 15))
     for k, n in names.items():
-        print("   %-36s %6.2f %% of its wave" % (n, 100.0 * buf[k] / (tot_p if k < 12 else tot_d)))
+        print("   %-36s %6.2f %% of its wave" % (n, 100.0 * buf[k] / max(1, tot_p if k < 12 else tot_d)))
     print("   cycles per tile: producer %.0f, DFT wave %.0f" % (tot_p / tiles, tot_d / tiles))
+    h.vadx_cfb_debug_cycles(buf, 1)
+    front(); torch.cuda.synchronize()
+    h.vadx_cfb_debug_cycles(buf, 1)
+    tot = sum(buf[16:21])
+    if tot:
+        for k, n in enumerate(("split front: convs of ten bins", "split front: barrier", "split front: DFT k-step", "split front: barrier", "split front: epilogue")):
+            print("   %-36s %6.2f %% of wave 0" % (n, 100.0 * buf[16 + k] / tot))
+        print("   cycles per tile: %.0f" % (tot / tiles))
 """
 
 if __name__ == "__main__":

@@ -104,7 +104,7 @@ class FtLn(C.Structure):
 
 class DfsmnCfbWeights(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("ln0_w", "gate_w", "in_w", "in_b", "front_tab", "conv_w", "fwd_tbl", "fwd_fix", "lin_w", "lin_b",
-                                          "inv_tbl", "out_fix")]
+                                          "inv_tbl", "out_fix", "fwd_tbl_q", "inv_tbl_q")]
 
 
 class DfsmnMaskWeights(C.Structure):

@@ -25,6 +25,7 @@
 // correction is ONE extra MFMA k-step per tile with A = (TW, TB) and B = (-mean, std + eps).  Re-association only: the block's
 // output equals the unfused chain's to float32 rounding (tests/test_gpu_dfsmn.py).
 #include "common.h"
+#include "split3.h"
 
 #include <type_traits>
 
@@ -661,6 +662,442 @@ __global__ __launch_bounds__(NTH) void cfb_back_kernel(BackArgs p) {
     CFB_FLUSH(8);
 }
 
+// =====================================================================================================================================
+// The same two halves on bf16 x 3 exact-split products (csrc/split3.h): every matrix product of the block whose one operand is a
+// constant -- the 1x1 convs, the (3,1) conv, the 160 x 160 forward / inverse DFT tables, CepsUnit's Linear -- runs as six
+// v_mfma_f32_16x16x32_bf16 per K = 32 step.  The streaming structure follows the K granularity:
+//   * the frequency axis goes in FIVE groups of 32 bins = one bf16 k-step of the DFT; the table is streamed from L2 as split fragments
+//     (three planes no longer fit LDS), the DFT of all 20 channels of a 16-frame tile stays in registers as before (wave (cg, mg):
+//     channels 5 cg .. + 4, row tiles 5 mg .. + 4);
+//   * per group, wave w runs the 1x1 convs + gate arithmetic of bins 32 g + 4 w .. + 3, leaves ln1_w gx in its four ring slots and
+//     ln2_w r as its half k-group of the group's B planes | barrier A | every wave runs the (3,1) conv of output bins 32 g + 4 w - 1 ..
+//     + 2 from its own slots and its lower neighbour's last two (wave 0: the carry slots wave 7 left behind the previous group) and
+//     the group's DFT k-step | barrier B.
+// K orders are free, so the 1x1 convs take their input channels five per lane quarter (20 channels = one k-step, 3 of 8 slots zero),
+// and the (3,1) conv takes (tap, channel quad) pairs: the ring holds 8-byte (quad, frame) units, exactly what a producer lane stores.
+constexpr int RQ_ROW = 256, RQ_PLANE = CH * 4 * RQ_ROW;                    // B planes of one group: [channel][k-group][16 frames][8 bins] bf16
+constexpr int RING_SLOT = 5 * 16 * 8, RING_PLANE = 4 * RING_SLOT, RING_WAVE = 3 * RING_PLANE;      // [4 slots][5 quads][16 frames][4 ch] bf16 per plane
+constexpr int CARRY_PLANE = 2 * RING_SLOT;                                 // bins 32 g - 2, 32 g - 1 of the previous group
+constexpr int QF_B = 1024;                                                 // bytes of one bf16 A fragment
+template <int CIN> constexpr int front_split_lds() { return 3 * RQ_PLANE + 8 * RING_WAVE + 3 * CARRY_PLANE + (2 * 2 * 3 + 2 * 2 * (CIN / 20) * 3) * QF_B; }
+static_assert(front_split_lds<40>() <= 160 * 1024, "LDS budget of cfb_front_split");
+static_assert((8 * WS_FLOATS + 8 * 16 * 6 + 64 + 256) * 4 <= 3 * RQ_PLANE, "the split front kernel's epilogue scratch aliases the B planes");
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// five float32 values (k-slots 0..4 of a lane's eight; 5..7 are zero) -> the lane's B fragment in each plane
+__device__ __forceinline__ void split5(const float (&v)[5], bf16x8 (&b)[3]) {
+    unsigned t0[5], t1[5], t2[5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        t0[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(t0[e] & 0xffff0000u);
+        t1[e] = __float_as_uint(r1);
+        t2[e] = __float_as_uint(r1 - __uint_as_float(t1[e] & 0xffff0000u));
+    }
+    b[0] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_perm(t0[1], t0[0], 0x07060302u), __builtin_amdgcn_perm(t0[3], t0[2], 0x07060302u), t0[4] >> 16, 0u});
+    b[1] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_perm(t1[1], t1[0], 0x07060302u), __builtin_amdgcn_perm(t1[3], t1[2], 0x07060302u), t1[4] >> 16, 0u});
+    b[2] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_perm(t2[1], t2[0], 0x07060302u), __builtin_amdgcn_perm(t2[3], t2[2], 0x07060302u), t2[4] >> 16, 0u});
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char *p) { return *reinterpret_cast<const bf16x8 *>(p); }
+// element k (wave-uniform, run-time) of a register vector: four selects instead of a scratch round trip
+__device__ __forceinline__ void set_k(f32x4 &v, int k, float x) {
+    v[0] = k == 0 ? x : v[0]; v[1] = k == 1 ? x : v[1]; v[2] = k == 2 ? x : v[2]; v[3] = k == 3 ? x : v[3];
+}
+
+struct FrontQArgs {
+    FrontArgs f;
+    const float *tbl_q;           // forward table as split A fragments [10 row tiles][5 chunks][3 planes][QFRAG]
+};
+
+template <int CIN>
+__global__ __launch_bounds__(NTH) void cfb_front_split_kernel(FrontQArgs pq) {
+    const FrontArgs &p = pq.f;
+    constexpr int KC = CIN / 20;
+    extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
+    unsigned char *RQ = qlds;                                   // 3 planes
+    unsigned char *RING = RQ + 3 * RQ_PLANE;                    // [8 waves][3 planes][4 slots]
+    unsigned char *CARRY = RING + 8 * RING_WAVE;                // [3 planes][2 slots]
+    unsigned char *W31 = CARRY + 3 * CARRY_PLANE;               // [2 row tiles][2 chunks][3 planes] fragments
+    unsigned char *WG = W31 + 2 * 2 * 3 * QF_B;                 // [2][KC][3]
+    unsigned char *WI = WG + 2 * KC * 3 * QF_B;
+    float *WS = reinterpret_cast<float *>(RQ);                  // epilogue only (the planes are dead then): [8 waves][2 tiles] transpose scratch
+    float *RED = WS + 8 * WS_FLOATS;                            //   "          : reduction scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, i = lane & 15;
+    // ---- weights -> split A fragments in LDS (once per launch: the workgroup is persistent)
+    for (int e = tid; e < 2 * 2 * 64 * 8; e += NTH) {           // (3,1) conv: slot 8 g + el <-> pair u = 2 g + el / 4 = (tap u / 5, quad u % 5)
+        const int el = e & 7, l = (e >> 3) & 63, ck = (e >> 9) & 1, m = e >> 10;
+        const int u = 2 * (4 * ck + (l >> 4)) + (el >> 2);
+        // (second row tile: channel 16 + j on row 4 j -- a lane's D rows 4 q .. 4 q + 3 then hold ONE real channel, 16 + q, in r = 0)
+        const int row = m == 0 ? (l & 15) : (((l & 3) == 0) ? 16 + ((l & 15) >> 2) : -1);
+        const float w = (u < 15 && row >= 0) ? p.w.conv_w[row * 60 + (u / 5) * 20 + 4 * (u % 5) + (el & 3)] : 0.f;
+        unsigned short h0, h1, h2;
+        split3x1(w, h0, h1, h2);
+        unsigned short *d = reinterpret_cast<unsigned short *>(W31 + (m * 2 + ck) * 3 * QF_B) + l * 8 + el;
+        d[0] = h0; d[QF_B / 2] = h1; d[QF_B] = h2;
+    }
+    for (int e = tid; e < 2 * KC * 64 * 8; e += NTH) {          // 1x1 convs: slot 8 q + el of chunk ck <-> channel 20 ck + 5 q + el (el < 5)
+        const int el = e & 7, l = (e >> 3) & 63, ck = (e >> 9) % KC, m = (e >> 9) / KC;
+        const int ch = 20 * ck + 5 * (l >> 4) + el, row = m == 0 ? (l & 15) : (((l & 3) == 0) ? 16 + ((l & 15) >> 2) : -1);
+        const float wg = (el < 5 && row >= 0) ? p.w.gate_w[row * CIN + ch] : 0.f, wi = (el < 5 && row >= 0) ? p.w.in_w[row * CIN + ch] : 0.f;
+        unsigned short h0, h1, h2;
+        split3x1(wg, h0, h1, h2);
+        unsigned short *d = reinterpret_cast<unsigned short *>(WG + (m * KC + ck) * 3 * QF_B) + l * 8 + el;
+        d[0] = h0; d[QF_B / 2] = h1; d[QF_B] = h2;
+        split3x1(wi, h0, h1, h2);
+        d = reinterpret_cast<unsigned short *>(WI + (m * KC + ck) * 3 * QF_B) + l * 8 + el;
+        d[0] = h0; d[QF_B / 2] = h1; d[QF_B] = h2;
+    }
+    float bi[2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bi[0][r] = p.w.in_b[4 * q + r]; bi[1][r] = r == 0 ? p.w.in_b[16 + q] : 0.f; }
+    unsigned char *ring = RING + wave * RING_WAVE;
+    // the (3,1) conv's B operand: k-group 4 chunk + q is the pairs u = 2 (4 chunk + q) + half; (tap, byte offset inside a slot) per (chunk, half)
+    int c31_tap[2][2], c31_off[2][2];
+    bool c31_ok[2][2];
+#pragma unroll
+    for (int ck = 0; ck < 2; ++ck)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int u = 2 * (4 * ck + q) + h;
+            c31_ok[ck][h] = u < 15;
+            c31_tap[ck][h] = u < 15 ? u / 5 : 0;
+            c31_off[ck][h] = ((u < 15 ? u % 5 : 0) * 16 + i) * 8;
+        }
+    const int cg = wave >> 1, mg = wave & 1;       // DFT tiles: channels 5 cg .. + 4, row tiles 5 mg .. + 4; tile jj = (jj / 5, jj % 5)
+    float *ws = WS + wave * WS_FLOATS;
+    __syncthreads();
+    CFB_T0();
+
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        f32x4 acc[25];
+#pragma unroll
+        for (int jj = 0; jj < 25; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float mean0 = p.stats0[((size_t)tile * 16 + i) * 2], inv0 = p.stats0[((size_t)tile * 16 + i) * 2 + 1];
+        const float mi0 = mean0 * inv0;
+        const float *abase = p.a.ptr + ((size_t)tile * p.a.c_total + p.a.c_off) * F * 16;
+        const float *bbase = p.b.ptr ? p.b.ptr + ((size_t)tile * p.b.c_total + p.b.c_off) * F * 16 : abase;
+        float *y1_t = p.y1 + (size_t)tile * (CH * F * 16);
+        Acc1 sg, sr;
+        sg.init(); sr.init();
+        if (wave == 7)                                          // bins -2, -1: the zero padding of the (3,1) conv
+            for (int e = lane; e < 3 * CARRY_PLANE / 8; e += 64) reinterpret_cast<u32x2 *>(CARRY)[e] = u32x2{0u, 0u};
+        float xn[KC][5], wn[KC][5];
+        auto load_x = [&](int f) {
+            const unsigned fc = (unsigned)min(f, F - 1);
+            unsigned lql = (unsigned)((5 * q) * F * 16 + i), lqw = (unsigned)(5 * q * F);
+            asm volatile("" : "+v"(lql), "+v"(lqw));
+#pragma unroll
+            for (int ck = 0; ck < KC; ++ck)
+#pragma unroll
+                for (int e = 0; e < 5; ++e) {
+                    // (uniform base per channel slot + ONE per-lane offset: the slot strides are beyond a load's immediate offset, and as
+                    // per-lane additions they were two vector instructions per load)
+                    xn[ck][e] = (CFB_EXP & 2) ? 0.25f * (float)e : ldg1o((ck == 0 ? abase : bbase) + e * F * 16, 4u * (lql + fc * 16u));
+                    wn[ck][e] = (CFB_EXP & 2) ? 1.5f : ldg1o(p.w.ln0_w + (20 * ck + e) * F, 4u * (lqw + fc));
+                }
+        };
+        load_x(4 * wave);
+        for (int g = 0; g < F / 32; ++g) {
+            // ---- 1x1 convs + gate arithmetic of bins 32 g + 4 w + k
+            f32x4 rw0[4], rw1 = {0.f, 0.f, 0.f, 0.f};           // ln2_w r of the four bins: [channel 4 q + r][bin k]; of channel 16 + q
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rw0[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {                       // (not unrolled: hoisted together the four bins' operands spill)
+                const int f = 32 * g + 4 * wave + k;
+                // this bin's table rows (L2) are requested first: a wave's loads retire in order, and they are needed behind this bin's MFMAs
+                unsigned qv = (unsigned)q;
+                asm volatile("" : "+v"(qv));
+                f32x4 ta[4];
+                float tb[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    ta[t] = (CFB_EXP & 8192) ? f32x4{0.5f, 0.25f, 1.f, 2.f} : ldg4o(p.w.front_tab + (f * 4 + t) * CH, 16u * qv);
+                    tb[t] = (CFB_EXP & 8192) ? 0.5f : ldg1o(p.w.front_tab + (f * 4 + t) * CH + 16, 4u * qv);
+                }
+                f32x4 agh[2], agl[2], aih[2], ail[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    agh[m] = f32x4{0.f, 0.f, 0.f, 0.f}; agl[m] = agh[m]; ail[m] = agh[m];
+                    aih[m] = f32x4{bi[m][0], bi[m][1], bi[m][2], bi[m][3]};
+                }
+#pragma unroll
+                for (int ck = 0; ck < KC; ++ck) {
+                    bf16x8 bg[3], wa[2][3];
+                    float xw[5];
+#pragma unroll
+                    for (int e = 0; e < 5; ++e) xw[e] = xn[ck][e] * wn[ck][e];
+                    split5(xw, bg);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) wa[m][pl] = lds_frag(WG + ((m * KC + ck) * 3 + pl) * QF_B + lane * 16);
+                    mfma_split6(wa[0], bg, agh[0], agl[0]);
+                    mfma_split6(wa[1], bg, agh[1], agl[1]);
+                }
+#pragma unroll
+                for (int ck = 0; ck < KC; ++ck) {
+                    bf16x8 bx[3], wa[2][3];
+                    split5(xn[ck], bx);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) wa[m][pl] = lds_frag(WI + ((m * KC + ck) * 3 + pl) * QF_B + lane * 16);
+                    mfma_split6(wa[0], bx, aih[0], ail[0]);
+                    mfma_split6(wa[1], bx, aih[1], ail[1]);
+                }
+                // the next bin's input rows (HBM) behind this bin's MFMAs: their registers were this bin's operands until here (a second
+                // set, requested a whole bin ahead, measured no faster and spilled at 40 input channels)
+                load_x(k < 3 ? f + 1 : f + 29);               // the next bin of this wave (k = 3: the next group's first)
+                unsigned char *slot_w = ring + k * RING_SLOT;
+                {   // channels 4 q + r
+                    const f32x4 ag = agh[0] + agl[0], ai = aih[0] + ail[0];
+                    f32x4 gxw;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // LN0 commuted behind the gate conv: inv0 * (Wg (w0 x)) + (Wg b0 + bias) - mean0 inv0 (Wg w0)
+                        const float pre = fmaf(inv0, ag[r], fmaf(-mi0, ta[0][r], ta[1][r]));
+                        const float gt = (CFB_EXP & 32) ? pre : gate_sigmoid(pre), xi = ai[r], gx = gt * xi, rr = xi - gx;
+                        if (g == 0 && k == 0 && r == 0) { sg.K = gx; sr.K = rr; }      // the tile's first value of this lane: the shifts
+                        sg.addk(gx); sr.addk(rr);
+                        set_k(rw0[r], k, rr * ta[3][r]);
+                        gxw[r] = gx * ta[2][r];
+                    }
+                    u32x2 p0, p1, p2;
+                    split3x4(gxw, p0, p1, p2);
+                    unsigned char *d = slot_w + (q * 16 + i) * 8;
+                    *reinterpret_cast<u32x2 *>(d) = p0;
+                    *reinterpret_cast<u32x2 *>(d + RING_PLANE) = p1;
+                    *reinterpret_cast<u32x2 *>(d + 2 * RING_PLANE) = p2;
+                }
+                {   // channel 16 + q (row 4 q of the second tile)
+                    const float pre = fmaf(inv0, agh[1][0] + agl[1][0], fmaf(-mi0, tb[0], tb[1]));
+                    const float gt = (CFB_EXP & 32) ? pre : gate_sigmoid(pre), xi = aih[1][0] + ail[1][0], gx = gt * xi, rr = xi - gx;
+                    sg.addk(gx); sr.addk(rr);
+                    set_k(rw1, k, rr * tb[3]);
+                    unsigned short h0, h1, h2;
+                    split3x1(gx * tb[2], h0, h1, h2);
+                    unsigned short *d = reinterpret_cast<unsigned short *>(slot_w + (4 * 16 + i) * 8) + q;
+                    d[0] = h0; d[RING_PLANE / 2] = h1; d[RING_PLANE] = h2;
+                }
+            }
+            if (!(CFB_EXP & 4096)) {
+                // ln2_w r of the four bins -> positions 4 (w & 1) .. + 3 of k-group w / 2 of each channel's row: one 8-byte store per plane
+                unsigned char *d0 = RQ + (wave >> 1) * RQ_ROW + i * 16 + 8 * (wave & 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    u32x2 p0, p1, p2;
+                    split3x4(rw0[r], p0, p1, p2);
+                    unsigned char *d = d0 + (4 * q + r) * 4 * RQ_ROW;
+                    *reinterpret_cast<u32x2 *>(d) = p0;
+                    *reinterpret_cast<u32x2 *>(d + RQ_PLANE) = p1;
+                    *reinterpret_cast<u32x2 *>(d + 2 * RQ_PLANE) = p2;
+                }
+                u32x2 p0, p1, p2;
+                split3x4(rw1, p0, p1, p2);
+                unsigned char *d = d0 + (16 + q) * 4 * RQ_ROW;
+                *reinterpret_cast<u32x2 *>(d) = p0;
+                *reinterpret_cast<u32x2 *>(d + RQ_PLANE) = p1;
+                *reinterpret_cast<u32x2 *>(d + 2 * RQ_PLANE) = p2;
+            }
+            CFB_MARK(0);
+            lds_barrier();                                       // A: the group's ring slots and B planes are complete
+            CFB_MARK(1);
+            // ---- (3,1) conv of output bins fo = 32 g + 4 w - 1 + k (wave 7 of the last group: bin 159 too) from the bins fo - 1 .. fo + 1:
+            // relative to this wave's slot 0 they are r = k + tap - 2 in [-2, 3] (4: bin 160, zero)
+            // the DFT k-step's first two table fragments are requested before the (3,1) conv's y1 stores enter the memory queue
+            const float *tq = pq.tbl_q + ((size_t)(5 * mg) * (F / 32) + g) * 3 * QFRAG;
+            int lane_t = lane;
+            asm volatile("" : "+v"(lane_t));
+            bf16x8 tfr[3][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) tfr[u][pl] = ldq(tq + ((size_t)u * (F / 32) * 3 + pl) * QFRAG, lane_t);
+            {
+                const unsigned char *below = wave > 0 ? ring - RING_WAVE + 2 * RING_SLOT : CARRY;      // bins r = -2, -1 (slot pitch RING_SLOT either way)
+                const int below_pl = wave > 0 ? RING_PLANE : CARRY_PLANE;
+                const int nout = (g == F / 32 - 1 && wave == 7) ? 5 : 4;
+                unsigned qv = (unsigned)q, iv = (unsigned)i;
+                asm volatile("" : "+v"(qv), "+v"(iv));
+#pragma unroll 1
+                for (int k = 0; k < nout; ++k) {
+                    const int fo = 32 * g + 4 * wave - 1 + k;
+                    if (fo < 0) continue;
+                    f32x4 a3h[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, a3l[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int ck = 0; ck < 2; ++ck) {
+                        bf16x8 b3[3];
+                        const unsigned char *src[2];
+                        int spl[2];
+                        bool ok[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int r = k + c31_tap[ck][h] - 2;              // per lane
+                            ok[h] = c31_ok[ck][h] && r < 4;
+                            const int rc = r < 4 ? r : 3;
+                            src[h] = (rc < 0 ? below + (rc + 2) * RING_SLOT : ring + rc * RING_SLOT) + c31_off[ck][h];
+                            spl[h] = rc < 0 ? below_pl : RING_PLANE;
+                        }
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            u32x2 lo2 = *reinterpret_cast<const u32x2 *>(src[0] + pl * spl[0]);
+                            u32x2 hi2 = *reinterpret_cast<const u32x2 *>(src[1] + pl * spl[1]);
+                            if (!ok[0]) lo2 = u32x2{0u, 0u};
+                            if (!ok[1]) hi2 = u32x2{0u, 0u};
+                            b3[pl] = __builtin_bit_cast(bf16x8, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]});
+                        }
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            bf16x8 wa[3];
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) wa[pl] = lds_frag(W31 + ((m * 2 + ck) * 3 + pl) * QF_B + lane * 16);
+                            mfma_split6(wa, b3, a3h[m], a3l[m]);
+                        }
+                    }
+                    const unsigned o = qv * (unsigned)(4 * F * 16) + iv + (unsigned)(fo * 16);
+                    const f32x4 y0 = a3h[0] + a3l[0];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stg1o(y1_t, 4u * (o + (unsigned)(r * F * 16)), y0[r]);
+                    stg1o(y1_t, 4u * ((16u + qv) * (unsigned)(F * 16) + iv + (unsigned)(fo * 16)), a3h[1][0] + a3l[1][0]);
+                }
+            }
+            CFB_MARK(2);
+            // ---- the group's DFT k-step: 25 tiles, six products each into ONE accumulator (a lo set would be 100 more registers)
+            {
+                bf16x8 bq[5][3];
+#pragma unroll
+                for (int c5 = 0; c5 < 5; ++c5)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) bq[c5][pl] = lds_frag(RQ + pl * RQ_PLANE + (((5 * cg + c5) * 4 + q) * 16 + i) * 16);
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    bf16x8 (&cur)[3] = tfr[u % 3];
+                    if (u + 2 < 5) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) tfr[(u + 2) % 3][pl] = ldq(tq + ((size_t)(u + 2) * (F / 32) * 3 + pl) * QFRAG, lane_t);
+                    }
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[2], bq[c5][0], acc[c5 * 5 + u]);
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[1], bq[c5][1], acc[c5 * 5 + u]);
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[0], bq[c5][2], acc[c5 * 5 + u]);
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[1], bq[c5][0], acc[c5 * 5 + u]);
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[0], bq[c5][1], acc[c5 * 5 + u]);
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[0], bq[c5][0], acc[c5 * 5 + u]);
+                }
+            }
+            CFB_MARK(3);
+            lds_barrier();                                       // B: every read of this group's slots and planes is done
+            CFB_MARK(1);
+            if (wave == 7)                                       // bins 32 g + 30, 32 g + 31 for wave 0's (3,1) conv behind the next barrier A
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    for (int e = lane; e < CARRY_PLANE / 8; e += 64)
+                        reinterpret_cast<u32x2 *>(CARRY + pl * CARRY_PLANE)[e] = reinterpret_cast<const u32x2 *>(ring + pl * RING_PLANE + 2 * RING_SLOT)[e];
+        }
+        // ---- LayerNorm statistics of gx (LN1, handed to cfb_back) and r (LN2, applied below): every wave saw one bin in eight
+        float n1, m1, M1, n2, m2, M2;
+        sg.finish(n1, m1, M1);
+        sr.finish(n2, m2, M2);
+        chan_merge_q(n1, m1, M1);
+        chan_merge_q(n2, m2, M2);
+        if (lane < 16) {
+            float *o = RED + (wave * 16 + i) * 6;
+            o[0] = n1; o[1] = m1; o[2] = M1; o[3] = n2; o[4] = m2; o[5] = M2;
+        }
+        lds_barrier();
+        float *RES = RED + 8 * 16 * 6;
+        if (tid < 16) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float *o = RED + (w * 16 + tid) * 6;
+                chan_merge(a0, a1, a2, o[0], o[1], o[2]);
+                chan_merge(c0, c1, c2, o[3], o[4], o[5]);
+            }
+            const float inv1 = 1.0f / (sqrtf(a2 / (a0 - 1.f)) + 1e-6f), sd2 = sqrtf(c2 / (c0 - 1.f)) + 1e-6f;
+            p.stats1[((size_t)tile * 16 + tid) * 2] = a1;
+            p.stats1[((size_t)tile * 16 + tid) * 2 + 1] = inv1;
+            RES[tid * 4] = c1; RES[tid * 4 + 1] = sd2; RES[tid * 4 + 2] = 1.0f / sd2;
+        }
+        lds_barrier();
+        const float mean2 = RES[i * 4], sd2 = RES[i * 4 + 1], inv2 = RES[i * 4 + 2];
+        const float bfix = q == 0 ? -mean2 : (q == 1 ? sd2 : 0.f);
+        float ssum = 0.f;
+        int lane_l = lane, ql = q, il = i;
+        asm volatile("" : "+v"(lane_l), "+v"(ql), "+v"(il));
+        const float *fix_w = p.w.fwd_fix + ((5 * cg) * 10 + 5 * mg) * 64;
+        const unsigned lane_u = (unsigned)lane_l;
+        {
+            float fx[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) fx[u] = ldg1o(fix_w, 4u * (lane_u + (unsigned)(u * 64)));
+#pragma unroll
+            for (int jj = 0; jj < 25; ++jj) {
+                acc[jj] = mfma16(fx[jj % 5], bfix, acc[jj]);
+                if (jj + 5 < 25) fx[jj % 5] = ldg1o(fix_w, 4u * (lane_u + (unsigned)((((jj + 5) / 5) * 10 + (jj + 5) % 5) * 64)));
+                acc[jj] *= inv2;
+                ssum += (acc[jj][0] + acc[jj][1]) + (acc[jj][2] + acc[jj][3]);
+            }
+        }
+        // ---- statistics of S over (40 channels, 81 bins): 160 stored values + 2 structural zeros per channel, two passes in registers
+        float *RD = RES + 64;
+        ssum = sum_q(ssum);
+        if (lane < 16) RD[wave * 16 + i] = ssum;
+        lds_barrier();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += RD[w * 16 + i];
+        const float nS = (float)(2 * CH * CF), meanS = tot / nS;
+        float dsum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 25; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = acc[jj][r] - meanS; dsum = fmaf(d, d, dsum); }
+        dsum = sum_q(dsum);
+        if (lane < 16) RD[128 + wave * 16 + i] = dsum;
+        lds_barrier();
+        if (tid < 16) {
+            float M = 2.f * CH * meanS * meanS;                  // the imaginary parts of bins 0 and 80
+#pragma unroll
+            for (int w = 0; w < 8; ++w) M += RD[128 + w * 16 + tid];
+            p.stats_li[((size_t)tile * 16 + tid) * 2] = meanS;
+            p.stats_li[((size_t)tile * 16 + tid) * 2 + 1] = 1.0f / (sqrtf(M / (nS - 1.f)) + 1e-6f);
+        }
+        // ---- S -> li[40][81]: table rows 0..80 = cos bins of channel c, rows 81..159 = sin bins 1..79 of channel 20 + c; one 16-byte
+        // store per lane and tile through the wave's transpose scratch
+        {
+            float *li_t = p.li + (size_t)tile * (2 * CH * CF * 16);
+            CFB_FENCE();
+            put_d(ws, ql, il, acc[0]);
+#pragma unroll
+            for (int jj = 0; jj < 25; ++jj) {
+                const int c = 5 * cg + jj / 5, m = 5 * mg + jj % 5;
+                CFB_FENCE();
+                if (jj + 1 < 25) put_d(ws + ((jj + 1) & 1) * WS_TILE, ql, il, acc[jj + 1]);
+                CFB_FENCE();
+                const f32x4 v = get_rows(ws + (jj & 1) * WS_TILE, lane_l);
+                CFB_FENCE();
+                const int row = 16 * m + (lane_l >> 2);
+                const int ch = row <= 80 ? c : CH + c, bin = row <= 80 ? row : row - 80;
+                stg4o(li_t, 4u * (unsigned)((ch * CF + bin) * 16 + 4 * (lane_l & 3)), v);
+            }
+            for (int e = tid; e < CH * 2 * 16; e += NTH)
+                li_t[((CH + (e >> 5)) * CF + (((e >> 4) & 1) ? 80 : 0)) * 16 + (e & 15)] = 0.f;
+        }
+        lds_barrier();                              // the scratch aliases the planes
+        CFB_MARK(4);
+    }
+    CFB_FLUSH(16);
+}
+
 static int cu_count() {
     static int n = 0;
     if (!n) {
@@ -700,6 +1137,19 @@ extern "C" int vadx_dfsmn_cfb_front(const vadx_dfsmn_cfb_weights *w, const vadx_
     VADX_REQUIRE(p.a.c % 4 == 0, "vadx_dfsmn_cfb_front: the first view must hold a multiple of 4 channels (a k-step does not straddle the views)");
     const unsigned grid = (unsigned)(tiles < cu_count() ? tiles : cu_count());
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (vadx::gemm_mode() == 1 && w->fwd_tbl_q && (cin == 20 || cin == 40) && p.a.c == 20) {
+        // bf16 x 3 split products (VADX_GEMM=f32 / vadx_gemm_mode(0) selects the f32-MFMA kernels below)
+        FrontQArgs pq{p, w->fwd_tbl_q};
+        if (cin == 20) {
+            VADX_DYN_LDS(cfb_front_split_kernel<20>, front_split_lds<20>());
+            hipLaunchKernelGGL(cfb_front_split_kernel<20>, dim3(grid), dim3(NTH), front_split_lds<20>(), st, pq);
+        } else {
+            VADX_DYN_LDS(cfb_front_split_kernel<40>, front_split_lds<40>());
+            hipLaunchKernelGGL(cfb_front_split_kernel<40>, dim3(grid), dim3(NTH), front_split_lds<40>(), st, pq);
+        }
+        VADX_HIP_TRY(hipGetLastError());
+        return VADX_OK;
+    }
     if (cin == 20) {
         VADX_DYN_LDS(cfb_front_kernel<20>, front_lds_bytes<20>());
         hipLaunchKernelGGL(cfb_front_kernel<20>, dim3(grid), dim3(NTH), front_lds_bytes<20>(), st, p);

@@ -193,6 +193,20 @@ class Iccrn:
             out[:, :, 16:32] = b.reshape(CH, 10, 16)
             return out
 
+        def qfrag(tbl):
+            """[160][K] float32 table -> bf16 x 3 split A fragments [10 row tiles][K / 32 chunks][3 planes][256 floats] (csrc/split3.h):
+            x = t0 + t1 + t2 exactly, by truncation; lane 16 g + i of a fragment holds tbl[16 tile + i][32 chunk + 8 g + e], e = 0..7"""
+            x = np.ascontiguousarray(tbl, dtype=np.float32)
+            chunks = x.shape[1] // 32
+            planes = []
+            for _ in range(3):
+                hi = (x.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+                planes.append((hi.view(np.uint32) >> 16).astype(np.uint16))
+                x = x - hi                                                    # exact in float32
+            pl = np.stack(planes, 0).reshape(3, 10, 16, chunks, 4, 8)        # [plane][tile][i][chunk][g][e]
+            out = np.ascontiguousarray(np.transpose(pl, (1, 3, 0, 4, 2, 5)))  # [tile][chunk][plane][g][i][e]
+            return out.reshape(10, chunks, 3, 512).view(np.float32)
+
         fwd = self.tbl_fwd.cpu().numpy().astype(np.float64)                  # [160 rows][160 f]
         inv = self.tbl_inv.cpu().numpy().astype(np.float64)                  # [160 f][160 k: re 0..80 | im 1..79]
         def inv_col(s_, q):
@@ -226,6 +240,7 @@ class Iccrn:
         cw.front_tab = dev(np.transpose(tab, (2, 0, 1)))                                  # [160][4][20]
         cw.fwd_tbl = dev(frag(fwd, 40, lambda s_, q: 4 * s_ + q))
         cw.fwd_fix = dev(fix(ln2_w @ fwd.T, ln2_b @ fwd.T))
+        cw.fwd_tbl_q = dev(qfrag(self.tbl_fwd.cpu().numpy()))
         cw.lin_w, cw.lin_b = dev(lw), dev(lb)
         cw.inv_tbl = dev(frag(inv, 41, inv_col))
         cw.out_fix = dev(fix(conv31(ln1_w), conv31(ln1_b) + w[name + ".conv.bias"].astype(np.float64)[:CH, None]))
