@@ -551,6 +551,8 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
     groups = {"lstm_f": split.get("vadx_dfsmn_lstm_f", 0.0), "dft_f": split.get("vadx_dfsmn_dft_f", 0.0),
               "pw_conv": split.get("vadx_dfsmn_pw_conv", 0.0), "lstm_t": split.get("vadx_dfsmn_lstm_t", 0.0) + split.get("vadx_dfsmn_lstm_t_ex", 0.0),
               "cfb_front": split.get("vadx_dfsmn_cfb_front", 0.0), "cfb_back": split.get("vadx_dfsmn_cfb_back", 0.0)}
+    # entries whose matrix products run as bf16 x 3 split products (vadx_gemm_mode 1): priced against the f32-equivalent peak of that pipe
+    on_split = {"lstm_f", "cfb_front", "cfb_back"} if _gemm_split() else set()
     dom = max(groups, key=groups.get)
     if dom == "pw_conv":                                     # (only the unfused chain is dominated by the HBM-bound pw_conv launches)
         dom = max((k for k in groups if k != "pw_conv"), key=groups.get)
@@ -559,10 +561,10 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
            "clip_pairs": clips, "samples_per_clip": n, "windows": nwin, "ms": ms,
            "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split, "kernel_calls": calls,
            "flop_per_window": fl,
-           "roofline": _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fle[dom], groups[dom], "dfsmn", dom,
+           "roofline": _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fle[dom], groups[dom], "dfsmn", dom, split=dom in on_split,
                              note="all launches of the entry point that takes the most time; flops as the reference computes them "
                                   "(the kernel issues more: 20 output channels pad to 32 MFMA rows)"),
-           "roofline_by_entry": {k: _roof(f"vadx_dfsmn_{k}", nwin * fle[k], v, "dfsmn", k) for k, v in groups.items() if v > 0},
+           "roofline_by_entry": {k: _roof(f"vadx_dfsmn_{k}", nwin * fle[k], v, "dfsmn", k, split=k in on_split) for k, v in groups.items() if v > 0},
            "roofline_whole_pass": _roof("all DFSMN launches", nwin * fl["total"], ms),
            "hbm": _hbm(clips * (2 * padded * 2 + W * eng.T_A * 4), ms, "dfsmn"), "cpu_baseline": None}
     del near, far

@@ -438,8 +438,9 @@ typedef struct vadx_dfsmn_cfb_weights {
     const float *ln0_w, *gate_w, *in_w, *in_b, *front_tab, *conv_w, *fwd_tbl, *fwd_fix, *lin_w, *lin_b, *inv_tbl, *out_fix;
     /* ABI 5: the two DFT tables as bf16 x 3 split A fragments (csrc/split3.h) for the split-product kernels (vadx_gemm_mode 1), or NULL
      * (the f32-MFMA kernels run then): fwd_tbl_q [10 row tiles][5 chunks of 32 bins][3 planes][256 floats], lane 16 g + i of a fragment
-     * holds T[16 tile + i][32 chunk + 8 g + e], e = 0..7, as eight bf16;  inv_tbl_q [10][6 chunks][3][256]: columns 0..80 = real parts
-     * of bins 0..80, 96 + k = imaginary part of bin k (k = 1..79), the rest zero. */
+     * holds T[16 tile + i][32 chunk + 8 g + e], e = 0..7, as eight bf16;  inv_tbl_q [10][5 chunks][3][256], same fragment layout, with
+     * the 160 columns (81 real + 79 imaginary parts) ordered so that chunk j = [re of ceps bins 16 j .. 16 j + 15 | im of the same
+     * bins] and the slot of the non-existent im of bin 0 holds re of bin 80. */
     const float *fwd_tbl_q, *inv_tbl_q;
 } vadx_dfsmn_cfb_weights;
 int vadx_dfsmn_cfb_front(const vadx_dfsmn_cfb_weights *w, const vadx_ft_view *a, const vadx_ft_view *b, const float *stats0,

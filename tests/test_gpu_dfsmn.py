@@ -77,6 +77,28 @@ def test_fused_cfb_equals_the_unfused_chain(wts, name, cin, frames, chunks):
     torch.testing.assert_close(sf[valid], su[valid], rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("name,cin,frames,chunks", [("cfb_e2", 20, 101, 3), ("cfb_d5", 20, 16, 300)])
+def test_opt_in_split_second_half_equals_the_unfused_chain(wts, monkeypatch, gemm, name, cin, frames, chunks):
+    """cfb_back on split products (VADX_CFB_BACK=split; opt-in: measured no faster than the f32-MFMA kernel, this half waits on its
+    64-byte rows, not on the matrix pipe): inverse DFT with the 81 + 79 parts ordered as five k-steps, bin 80 riding in the slot of the
+    non-existent im of bin 0 -- same block as the six-launch chain."""
+    _lib.gemm_mode("split")                                   # (the opt-in kernel exists on the split arithmetic only; the fixture restores the mode)
+    monkeypatch.setenv("VADX_CFB_BACK", "split")
+    w, _ = wts
+    net = dfsmn.Iccrn(w)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(chunks, cin, 160, frames, generator=g) * 0.9 + 0.3
+    xin = dfsmn.to_ft(torch, x, net.device)
+    out_f = dfsmn.FT(torch, net.device, chunks, frames, 20, 160)
+    out_u = dfsmn.FT(torch, net.device, chunks, frames, 20, 160)
+    net.cfb(name, xin.view(), None, out_f.view(), chunks, frames)
+    monkeypatch.delenv("VADX_CFB_BACK")
+    net.cfb_unfused(name, xin.view(), None, out_u.view(), chunks, frames)
+    got, want = dfsmn.from_ft(out_f, chunks).cpu(), dfsmn.from_ft(out_u, chunks).cpu()
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("chunks,frames", [(3, 101), (4200, 16)])       # 21 tiles: two workgroups per tile; 4200: one
 def test_fused_layernorm_statistics_match_the_separate_pass(wts, chunks, frames):
     """The partial statistics pw_conv emits while writing a tensor, merged (one tensor and a channel concatenation of

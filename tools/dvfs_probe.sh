@@ -84,8 +84,8 @@ int main() {
             float ms; hipEventElapsedTime(&ms, a, b);
             unsigned long long c[2]; hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost);
             const double waves = (m == 6 ? 4 : 8) * 256.0, n = waves * iters[m] * mf[m];
-            printf("%-5s %8.3f ms  shader clock %.2f GHz  %7.1f G MFMA/s  %7.1f TFLOP/s  cycles per MFMA and SIMD %.1f\n", names[m], ms,
-                   (double)c[0] / c[1] / 10.0, n / ms / 1e6, n * flop[m] / ms / 1e9, n ? (double)c[0] / 256.0 * 1024.0 / n : 0.0);
+            printf("%-5s %8.3f ms  shader clock %.2f GHz  %7.1f G MFMA/s  %7.1f TFLOP/s  SIMD cycles per MFMA %.1f\n", names[m], ms,
+                   (double)c[0] / c[1] / 10.0, n / ms / 1e6, n * flop[m] / ms / 1e9, n ? (double)c[0] / c[1] * 1e8 * ms * 1e-3 * 1024.0 / n : 0.0);
         }
     return 0;
 }

@@ -27,6 +27,8 @@
 #include "common.h"
 #include "split3.h"
 
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 // CFB_EXP: development-only what-if switches (bit mask; results are wrong when set; tools/exp_cfb.py): 1 no workgroup barriers in the
@@ -1098,6 +1100,292 @@ __global__ __launch_bounds__(NTH) void cfb_front_split_kernel(FrontQArgs pq) {
     CFB_FLUSH(16);
 }
 
+// ---- second half on split products.  CepsUnit's Linear 40 -> 40 (K = 40 as two k-steps of 5 channels per lane quarter) and the pinv
+// inverse DFT.  The inverse contracts over 81 real + 79 imaginary parts = 160 values = FIVE bf16 k-steps with no padding once the
+// k order is chosen freely: k-step j holds [re of ceps bins 16 j .. 16 j + 15 | im of the same bins], and the one slot that is
+// structurally zero (im of bin 0) carries re of bin 80.  Per k-step, wave w runs the Linear + complex product of bins 16 j + 2 w,
+// 16 j + 2 w + 1 (wave 7 also bin 80, in step 0, where there is no DFT work yet) -> OB[j & 1] (4-byte stores: two consecutive bins of
+// a (channel, part, frame) row), and accumulates the DFT k-step j - 1 from OB[(j - 1) & 1]; one barrier per step.
+constexpr int back_split_lds() { return 2 * 3 * RQ_PLANE + 3 * 2 * 3 * QF_B; }
+static_assert(back_split_lds() <= 160 * 1024, "LDS budget of cfb_back_split");
+static_assert((8 * WS_FLOATS + 256 + 64) * 4 <= 2 * 3 * RQ_PLANE, "the split back kernel's scratch aliases the B planes");
+
+struct BackQArgs {
+    BackArgs b;
+    const float *tbl_q;           // pinv inverse table as split A fragments [10 row tiles][5 k-steps][3 planes][QFRAG], k order as above
+};
+
+__global__ __launch_bounds__(NTH) void cfb_back_split_kernel(BackQArgs pq) {
+    const BackArgs &p = pq.b;
+    extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
+    unsigned char *OBQ = qlds;                                  // [2][3 planes][20 ch][4 k-groups: re lo, re hi, im lo, im hi][16 frames][8 bins]
+    unsigned char *WLQ = OBQ + 2 * 3 * RQ_PLANE;                // [3 row tiles][2 chunks][3 planes] fragments of the Linear
+    float *WS = reinterpret_cast<float *>(OBQ);                 // prologue / epilogue only: [8 waves][2 tiles] transpose scratch
+    float *RED = WS + 8 * WS_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, i = lane & 15;
+    // Linear 40 -> 40 (rows permuted on the host so that a lane's four D rows are (re c, re c+1, im c, im c+1), c = 8 mt + 2 q):
+    // slot 8 q + el of chunk ck <-> input channel 20 ck + 5 q + el (el < 5)
+    for (int e = tid; e < 3 * 2 * 64 * 8; e += NTH) {
+        const int el = e & 7, l = (e >> 3) & 63, ck = (e >> 9) & 1, m = e >> 10;
+        const float w = el < 5 ? p.w.lin_w[(m * 16 + (l & 15)) * 40 + 20 * ck + 5 * (l >> 4) + el] : 0.f;
+        unsigned short h0, h1, h2;
+        split3x1(w, h0, h1, h2);
+        unsigned short *d = reinterpret_cast<unsigned short *>(WLQ + (m * 2 + ck) * 3 * QF_B) + l * 8 + el;
+        d[0] = h0; d[QF_B / 2] = h1; d[QF_B] = h2;
+    }
+    float bl[3][4];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bl[m][r] = p.w.lin_b[m * 16 + 4 * q + r];
+    const int cg = wave >> 1, mg = wave & 1;           // DFT tiles: channels 5 cg .. + 4, row tiles 5 mg .. + 4; tile jj = (jj / 5, jj % 5)
+    float *ws = WS + wave * WS_FLOATS;
+    __syncthreads();
+
+    f32x4 acc[25];
+    const unsigned rowoff = (unsigned)((lane >> 2) * 16 + 4 * (lane & 3) + ((5 * cg) * F + 16 * (5 * mg)) * 16);
+    auto y1_load = [&](int tile) {                  // the accumulators START as y1 (row layout; transposed below)
+        const float *y1_t = p.y1 + (size_t)tile * (CH * F * 16);
+#pragma unroll
+        for (int jj = 0; jj < 25; ++jj) acc[jj] = ldg4o(y1_t, 4u * (rowoff + (unsigned)(((jj / 5) * F + 16 * (jj % 5)) * 16)));
+    };
+    if ((int)blockIdx.x < p.tiles) y1_load(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        const float *hf_t = p.hf + (size_t)tile * (2 * CH * CF * 16);
+        const float *li_t = p.li + (size_t)tile * (2 * CH * CF * 16);
+        float hn[2][5], sn[12];                     // operands of the NEXT bin of this wave
+        auto load_h = [&](int bin) {
+            unsigned lql = (unsigned)((5 * q) * CF * 16 + i + bin * 16);
+            asm volatile("" : "+v"(lql));
+#pragma unroll
+            for (int ck = 0; ck < 2; ++ck)
+#pragma unroll
+                for (int e = 0; e < 5; ++e) hn[ck][e] = ldg1o(hf_t + (20 * ck + e) * CF * 16, 4u * lql);
+        };
+        auto load_s = [&](int bin) {
+            unsigned lil = (unsigned)(i + bin * 16);
+            asm volatile("" : "+v"(lil));
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int ca = min(8 * m + 2 * q, CH - 2);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    sn[4 * m + h2] = ldg1o(li_t, 4u * (lil + (unsigned)((ca + h2) * CF * 16)));
+                    sn[4 * m + 2 + h2] = ldg1o(li_t, 4u * (lil + (unsigned)((CH + ca + h2) * CF * 16)));
+                }
+            }
+        };
+        load_h(2 * wave);
+        load_s(2 * wave);
+        // ---- acc = inv1 * (y1 - mean1 * CW) + CB: y1 arrived as one 16-byte load per lane and tile (requested during the previous
+        // tile's epilogue), is turned into the MFMA D layout through the wave's LDS scratch; the (CW, CB) term is one k-step
+        const float mean1 = p.stats1[((size_t)tile * 16 + i) * 2], inv1 = p.stats1[((size_t)tile * 16 + i) * 2 + 1];
+        const float bfix = q == 0 ? -mean1 * inv1 : (q == 1 ? 1.f : 0.f);
+        int ql = q, il = i, lane_l = lane;
+        asm volatile("" : "+v"(ql), "+v"(il), "+v"(lane_l));
+        const float *fix_w = p.w.out_fix + ((5 * cg) * 10 + 5 * mg) * 64;
+        const unsigned lane_u = (unsigned)lane_l;
+        {
+            float fx[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) fx[u] = ldg1o(fix_w, 4u * (lane_u + (unsigned)(u * 64)));
+            CFB_FENCE();
+            put_rows(ws, lane_l, acc[0]);
+#pragma unroll
+            for (int jj = 0; jj < 25; ++jj) {
+                CFB_FENCE();
+                if (jj + 1 < 25) put_rows(ws + ((jj + 1) & 1) * WS_TILE, lane_l, acc[jj + 1]);
+                CFB_FENCE();
+                f32x4 d = get_d(ws + (jj & 1) * WS_TILE, ql, il);
+                CFB_FENCE();
+                d *= inv1;
+                acc[jj] = mfma16(fx[jj % 5], bfix, d);
+                if (jj + 5 < 25) fx[jj % 5] = ldg1o(fix_w, 4u * (lane_u + (unsigned)((((jj + 5) / 5) * 10 + (jj + 5) % 5) * 64)));
+            }
+        }
+        lds_barrier();                              // the scratch aliases the planes
+        for (int g = 0; g <= F / 32; ++g) {
+            if (g < F / 32) {
+                // ---- Linear + complex product of bins 16 g + 2 w, + 1 (g = 0, wave 7: bin 80 as a third)
+                const int nb = (g == 0 && wave == 7) ? 3 : 2;
+                float o_re[3][2][2], o_im[3][2][2];             // [m][h2][bin of the pair]
+                unsigned char *obw = OBQ + (g & 1) * 3 * RQ_PLANE;
+#pragma unroll 1
+                for (int b2 = 0; b2 < nb; ++b2) {
+                    const int bin = b2 < 2 ? 16 * g + 2 * wave + b2 : CF - 1;
+                    // the bin after this one in the wave's sequence (the last one's successor is never used: any valid bin)
+                    const int nxt = b2 + 1 < nb ? (b2 == 0 ? bin + 1 : CF - 1) : min(16 * (g + 1) + 2 * wave, CF - 1);
+                    f32x4 Ph[3], Pl[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) { Ph[m] = f32x4{bl[m][0], bl[m][1], bl[m][2], bl[m][3]}; Pl[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                    for (int ck = 0; ck < 2; ++ck) {
+                        bf16x8 bh[3];
+                        split5(hn[ck], bh);
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) {
+                            bf16x8 wa[3];
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) wa[pl] = lds_frag(WLQ + ((m * 2 + ck) * 3 + pl) * QF_B + lane * 16);
+                            mfma_split6(wa, bh, Ph[m], Pl[m]);
+                        }
+                    }
+                    load_h(nxt);
+                    float pr_[3][2][2];                         // [m][h2][re | im]
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const f32x4 P = Ph[m] + Pl[m];
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const float sre = sn[4 * m + h2], sim = sn[4 * m + 2 + h2], pr = P[h2], pi = P[2 + h2];
+                            pr_[m][h2][0] = pr * sre - pi * sim;
+                            pr_[m][h2][1] = pr * sim + pi * sre;
+                        }
+                    }
+                    load_s(nxt);
+                    if (b2 < 2) {
+#pragma unroll
+                        for (int m = 0; m < 3; ++m)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                if (b2 == 0) { o_re[m][h2][0] = pr_[m][h2][0]; o_im[m][h2][0] = pr_[m][h2][1]; }
+                                else { o_re[m][h2][1] = pr_[m][h2][0]; o_im[m][h2][1] = pr_[m][h2][1]; }
+                            }
+                    } else {
+                        // bin 80: its real part rides in the slot of im (bin 0) = position 0 of k-group 2 of step 0
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) {
+                            const int ca = 8 * m + 2 * q;
+                            if (ca < CH) {
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+                                    unsigned short t0, t1, t2;
+                                    split3x1(pr_[m][h2][0], t0, t1, t2);
+                                    unsigned short *d = reinterpret_cast<unsigned short *>(obw + (((ca + h2) * 4 + 2) * 16 + i) * 16);
+                                    d[0] = t0; d[RQ_PLANE / 2] = t1; d[RQ_PLANE] = t2;
+                                }
+                            }
+                        }
+                    }
+                }
+                // the pair's two bins -> positions 2 (w & 3), + 1 of k-group w / 4 (re) and 2 + w / 4 (im): one 4-byte store per plane
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int ca = 8 * m + 2 * q;
+                    if (ca < CH) {
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            unsigned p0, p1, p2;
+                            unsigned char *d = obw + (((ca + h2) * 4 + (wave >> 2)) * 16 + i) * 16 + 4 * (wave & 3);
+                            split3x2(o_re[m][h2][0], o_re[m][h2][1], p0, p1, p2);
+                            *reinterpret_cast<unsigned *>(d) = p0;
+                            *reinterpret_cast<unsigned *>(d + RQ_PLANE) = p1;
+                            *reinterpret_cast<unsigned *>(d + 2 * RQ_PLANE) = p2;
+                            split3x2(o_im[m][h2][0], o_im[m][h2][1], p0, p1, p2);
+                            d += 2 * RQ_ROW;
+                            if (g == 0 && wave == 0) {          // im of bin 0 does not exist: its slot is bin 80's (wave 7 writes it)
+                                reinterpret_cast<unsigned short *>(d)[1] = (unsigned short)(p0 >> 16);
+                                reinterpret_cast<unsigned short *>(d + RQ_PLANE)[1] = (unsigned short)(p1 >> 16);
+                                reinterpret_cast<unsigned short *>(d + 2 * RQ_PLANE)[1] = (unsigned short)(p2 >> 16);
+                            } else {
+                                *reinterpret_cast<unsigned *>(d) = p0;
+                                *reinterpret_cast<unsigned *>(d + RQ_PLANE) = p1;
+                                *reinterpret_cast<unsigned *>(d + 2 * RQ_PLANE) = p2;
+                            }
+                        }
+                    }
+                }
+            }
+            if (g > 0) {
+                // ---- inverse DFT k-step g - 1: 25 tiles, six products each
+                const unsigned char *obr = OBQ + ((g - 1) & 1) * 3 * RQ_PLANE;
+                const float *tq = pq.tbl_q + ((size_t)(5 * mg) * (F / 32) + (g - 1)) * 3 * QFRAG;
+                int lane_t = lane;
+                asm volatile("" : "+v"(lane_t));
+                bf16x8 tfr[3][3];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) tfr[u][pl] = ldq(tq + ((size_t)u * (F / 32) * 3 + pl) * QFRAG, lane_t);
+                bf16x8 bq[5][3];
+#pragma unroll
+                for (int c5 = 0; c5 < 5; ++c5)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) bq[c5][pl] = lds_frag(obr + pl * RQ_PLANE + (((5 * cg + c5) * 4 + q) * 16 + i) * 16);
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    bf16x8 (&cur)[3] = tfr[u % 3];
+                    if (u + 2 < 5) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) tfr[(u + 2) % 3][pl] = ldq(tq + ((size_t)(u + 2) * (F / 32) * 3 + pl) * QFRAG, lane_t);
+                    }
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[2], bq[c5][0], acc[c5 * 5 + u]);
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[1], bq[c5][1], acc[c5 * 5 + u]);
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[0], bq[c5][2], acc[c5 * 5 + u]);
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[1], bq[c5][0], acc[c5 * 5 + u]);
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[0], bq[c5][1], acc[c5 * 5 + u]);
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) acc[c5 * 5 + u] = mfma_bf16(cur[0], bq[c5][0], acc[c5 * 5 + u]);
+                }
+            }
+            lds_barrier();
+        }
+        // ---- out: one 16-byte store per lane and tile; as a tile's registers leave, the NEXT tile's y1 is requested into them, so that
+        // its latency passes under this epilogue's reductions; (count, mean, M2) of the output per frame for the next LayerNorm
+        float ssum = 0.f, dsum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 25; ++jj) ssum += (acc[jj][0] + acc[jj][1]) + (acc[jj][2] + acc[jj][3]);
+        ssum = sum_q(ssum);
+        if (lane < 16) RED[wave * 16 + i] = ssum;
+        lds_barrier();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += RED[w * 16 + i];
+        const float nO = (float)(CH * F), meanO = tot / nO;
+#pragma unroll
+        for (int jj = 0; jj < 25; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = acc[jj][r] - meanO; dsum = fmaf(d, d, dsum); }
+        dsum = sum_q(dsum);
+        if (lane < 16) RED[128 + wave * 16 + i] = dsum;
+        float *out_t = p.out.ptr + ((size_t)tile * p.out.c_total + p.out.c_off) * (F * 16);
+        const int next = tile + gridDim.x;
+        const float *y1_n = p.y1 + (size_t)(next < p.tiles ? next : tile) * (CH * F * 16);
+        unsigned ro = rowoff;
+        asm volatile("" : "+v"(ql), "+v"(il), "+v"(lane_l), "+v"(ro));
+        CFB_FENCE();
+        put_d(ws, ql, il, acc[0]);
+#pragma unroll
+        for (int jj = 0; jj < 25; ++jj) {
+            const unsigned off = ro + (unsigned)(((jj / 5) * F + 16 * (jj % 5)) * 16);
+            CFB_FENCE();
+            if (jj + 1 < 25) put_d(ws + ((jj + 1) & 1) * WS_TILE, ql, il, acc[jj + 1]);
+            CFB_FENCE();
+            const f32x4 v = get_rows(ws + (jj & 1) * WS_TILE, lane_l);
+            CFB_FENCE();
+            stg4o(out_t, 4u * off, v);
+            if (jj >= 1)        // tile jj - 1's registers are free now: the next tile's y1 lands in them during the reductions below
+                acc[jj - 1] = ldg4o(y1_n, 4u * (ro + (unsigned)((((jj - 1) / 5) * F + 16 * ((jj - 1) % 5)) * 16)));
+        }
+        acc[24] = ldg4o(y1_n, 4u * (ro + (unsigned)((4 * F + 16 * 4) * 16)));
+        lds_barrier();
+        if (p.part && tid < 16) {
+            float M = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) M += RED[128 + w * 16 + tid];
+            float *o = p.part + (((size_t)tile * VADX_DFSMN_STAT_PARTS) * 16 + tid) * 4;
+            o[0] = nO; o[1] = meanO; o[2] = M; o[3] = 0.f;
+            float *z = o + 16 * 4;
+            z[0] = z[1] = z[2] = z[3] = 0.f;
+        }
+    }
+}
+
 static int cu_count() {
     static int n = 0;
     if (!n) {
@@ -1172,6 +1460,16 @@ extern "C" int vadx_dfsmn_cfb_back(const vadx_dfsmn_cfb_weights *w, const float 
     p.out = ViewW{const_cast<float *>(out->ptr), out->c_total, out->c_off, out->c};
     p.part = part; p.tiles = tiles;
     const unsigned grid = (unsigned)(tiles < cu_count() ? tiles : cu_count());
+    // The split-product form of this half is opt-in (VADX_CFB_BACK=split): measured no faster than the f32-MFMA kernel (0.975 against
+    // 0.943 ms per 3584 tiles) -- this half moves 824 KB per tile in 64-byte rows and waits on them, not on the matrix pipe.
+    const char *back_env = getenv("VADX_CFB_BACK");
+    if (vadx::gemm_mode() == 1 && w->inv_tbl_q && back_env && !strcmp(back_env, "split")) {
+        BackQArgs pq{p, w->inv_tbl_q};
+        VADX_DYN_LDS(cfb_back_split_kernel, back_split_lds());
+        hipLaunchKernelGGL(cfb_back_split_kernel, dim3(grid), dim3(NTH), back_split_lds(), static_cast<hipStream_t>(stream), pq);
+        VADX_HIP_TRY(hipGetLastError());
+        return VADX_OK;
+    }
     VADX_DYN_LDS(cfb_back_kernel, back_lds_bytes());
     hipLaunchKernelGGL(cfb_back_kernel, dim3(grid), dim3(NTH), back_lds_bytes(), static_cast<hipStream_t>(stream), p);
     VADX_HIP_TRY(hipGetLastError());

@@ -76,6 +76,17 @@ __device__ __forceinline__ void split3x4(const f32x4 x, u32x2 &p0, u32x2 &p1, u3
     p2 = u32x2{__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u)};
 }
 
+// two float32 values (consecutive k of one column) -> their three planes, two bf16 (4 bytes) each
+__device__ __forceinline__ void split3x2(float x0, float x1, unsigned &p0, unsigned &p1, unsigned &p2) {
+    const unsigned a = __float_as_uint(x0), b = __float_as_uint(x1);
+    const float ra = x0 - __uint_as_float(a & 0xffff0000u), rb = x1 - __uint_as_float(b & 0xffff0000u);
+    const unsigned a1 = __float_as_uint(ra), b1 = __float_as_uint(rb);
+    const float sa = ra - __uint_as_float(a1 & 0xffff0000u), sb = rb - __uint_as_float(b1 & 0xffff0000u);
+    p0 = __builtin_amdgcn_perm(b, a, 0x07060302u);
+    p1 = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
+
 // one float32 value -> its three bf16 terms
 __device__ __forceinline__ void split3x1(float x, unsigned short &h0, unsigned short &h1, unsigned short &h2) {
     const unsigned xb = __float_as_uint(x);

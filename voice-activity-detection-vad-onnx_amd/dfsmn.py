@@ -243,6 +243,15 @@ class Iccrn:
         cw.fwd_tbl_q = dev(qfrag(self.tbl_fwd.cpu().numpy()))
         cw.lin_w, cw.lin_b = dev(lw), dev(lb)
         cw.inv_tbl = dev(frag(inv, 41, inv_col))
+        # split-product kernel: k-step j = [re of ceps bins 16 j .. 16 j + 15 | im of the same bins]; im of bin 0 does not exist, its
+        # slot carries re of bin 80 (160 = 81 + 79 values: five k-steps without padding)
+        perm = np.empty(F_BINS, np.int64)
+        for j in range(5):
+            for s_ in range(32):
+                b_ = 16 * j + (s_ & 15)
+                perm[32 * j + s_] = b_ if s_ < 16 else (80 if b_ == 0 else 80 + b_)
+        assert sorted(perm.tolist()) == list(range(F_BINS))
+        cw.inv_tbl_q = dev(qfrag(self.tbl_inv.cpu().numpy()[:, perm]))
         cw.out_fix = dev(fix(conv31(ln1_w), conv31(ln1_b) + w[name + ".conv.bias"].astype(np.float64)[:CH, None]))
         self._cfb_cache[name] = (cw, keep)
         return self._cfb_cache[name]
