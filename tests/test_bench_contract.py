@@ -29,6 +29,11 @@ def test_flop_and_byte_accounting_and_committed_profile():
     assert rec is not None and 0.95 * windows * 2048 < rec["bytes"] < 1.10 * windows * 2052
     ratio = (tr["bytes"] + rec["bytes"]) / (windows * bench.ALGO_BYTES_PER_WINDOW)
     assert 2.8 < ratio < 3.3                           # the gx round trip: design traffic, reported as hbm.traffic_ratio
+    # the split-product kernel set (round 4, the default) moves the same tensors: its committed profile must say so too
+    trs, recs = bench.profiled_traffic("silero_encode_split_kernel"), bench.profiled_traffic("silero_lstm_split_kernel")
+    assert trs is not None and recs is not None and trs["source"].startswith("profiles/r04")
+    assert 0.95 * windows * 4096 < trs["bytes"] < 1.10 * windows * 4096
+    assert 0.95 * windows * 2048 < recs["bytes"] < 1.10 * windows * 2052
 
 
 def test_secondary_flop_formulas():

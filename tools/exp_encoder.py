@@ -85,6 +85,9 @@ if hasattr(h, "vadx_silero_split_debug_cycles") and %d:
     h.vadx_silero_split_debug_cycles(buf, 1)
     enc(); torch.cuda.synchronize()
     h.vadx_silero_split_debug_cycles(buf, 0)
+    if buf[15]:
+        print("PHASES shader clock over the workgroups: %%.2f GHz (s_memtime / 100 MHz counter)" %% (buf[14] / buf[15] / 10.0))
+    buf[14] = buf[15] = 0
     tot = sum(buf) or 1
     names = {0: "stage X", 1: "STFT fold + bin 64", 2: "|.| planes", 3: "bin 64 slot", 4: "conv1", 5: "conv1 store", 6: "conv2", 7: "conv3", 8: "conv4", 9: "W_ih + gx store"}
     print("PHASES (share of wave-0 cycles, sum over workgroups):", ", ".join(f"{names.get(k, k)} {100.0 * v / tot:.1f}%%" for k, v in enumerate(buf) if v),

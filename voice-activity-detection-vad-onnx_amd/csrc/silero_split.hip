@@ -26,7 +26,9 @@
 #define SP_W(addr) (SP_SKIP(13) ? (P + vadx::silero::OFF_Q1) : (addr))        // what-if: every weight fragment from one (L1-resident) address
 #if (VADX_EXP >> 14) & 1
 __device__ unsigned long long sp_dbg[16];
-#define SP_T0() long long sp_t_ = __builtin_readcyclecounter()
+#define SP_T0() long long sp_t_ = __builtin_readcyclecounter(); const long long sp_c0_ = sp_t_, sp_w0_ = wall_clock64()
+// slots 14 / 15: shader cycles and 100 MHz ticks of the whole workgroup -> the clock the kernel sustains
+#define SP_CLK() do { if (threadIdx.x == 0) { atomicAdd(&sp_dbg[14], (unsigned long long)(__builtin_readcyclecounter() - sp_c0_)); atomicAdd(&sp_dbg[15], (unsigned long long)(wall_clock64() - sp_w0_)); } } while (0)
 #define SP_MARK(slot) do { if (threadIdx.x == 0) { const long long n_ = __builtin_readcyclecounter(); atomicAdd(&sp_dbg[slot], (unsigned long long)(n_ - sp_t_)); sp_t_ = n_; } } while (0)
 extern "C" int vadx_silero_split_debug_cycles(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sp_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
@@ -36,6 +38,7 @@ extern "C" int vadx_silero_split_debug_cycles(unsigned long long *out, int reset
 #else
 #define SP_T0() do {} while (0)
 #define SP_MARK(slot) do {} while (0)
+#define SP_CLK() do {} while (0)
 #endif
 
 namespace vadx {
@@ -544,6 +547,7 @@ __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_ke
         }
     }
     SP_MARK(9);
+    SP_CLK();
 }
 
 // ---- persistent LSTM on split products ---------------------------------------------------------
