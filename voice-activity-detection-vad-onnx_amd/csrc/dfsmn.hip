@@ -1629,6 +1629,10 @@ extern "C" int vadx_dfsmn_lstm_t_ex(int which, const vadx_ft_view *in, const vad
         constexpr int NTILE = 4;
         constexpr size_t lds2 = (size_t)(10 * 5 * 64 + 3 * 10 * 10 * 64 + 2 * 10 * 64 + 2 * 10 * 16 + NTILE * 2 * 40 * 16) * sizeof(float);
         p.nunits = (int)grid;
+        // (a split-product form of this kernel -- one GEMM per layer and step over [h ; x ; 1], planes 0 / 1 of the weights as LDS fragments,
+        // plane 2 of each layer's first two chunks in its waves' registers -- was built and measured: 27.6 ms per 3060 windows against
+        // 26.4 with a dependent chain per row tile, 33.8 with the products tile-interleaved (184 B of scratch per lane in the step): 162 KB
+        // of split weights do not fit beside the h exchange in LDS, and 80 resident registers leave the step no room.  Removed.)
         VADX_DYN_LDS((lstm_t2_kernel<20, 40, 2, 0, NTILE>), lds2);
         hipLaunchKernelGGL((lstm_t2_kernel<20, 40, 2, 0, NTILE>), dim3((grid + NTILE - 1) / NTILE), dim3(128 * NTILE), lds2, st, p);
     } else {                     // out_ch_lstm: in 40, hidden 20, 1 layer, Linear 20->40
