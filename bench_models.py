@@ -552,7 +552,8 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
               "pw_conv": split.get("vadx_dfsmn_pw_conv", 0.0), "lstm_t": split.get("vadx_dfsmn_lstm_t", 0.0) + split.get("vadx_dfsmn_lstm_t_ex", 0.0),
               "cfb_front": split.get("vadx_dfsmn_cfb_front", 0.0), "cfb_back": split.get("vadx_dfsmn_cfb_back", 0.0)}
     # entries whose matrix products run as bf16 x 3 split products (vadx_gemm_mode 1): priced against the f32-equivalent peak of that pipe
-    on_split = {"lstm_f", "cfb_front", "cfb_back"} if _gemm_split() else set()
+    # (cfb_back's split form is opt-in, VADX_CFB_BACK=split: by default that half runs its f32-MFMA kernel)
+    on_split = ({"lstm_f", "cfb_front"} | ({"cfb_back"} if os.environ.get("VADX_CFB_BACK") == "split" else set())) if _gemm_split() else set()
     dom = max(groups, key=groups.get)
     if dom == "pw_conv":                                     # (only the unfused chain is dominated by the HBM-bound pw_conv launches)
         dom = max((k for k in groups if k != "pw_conv"), key=groups.get)
