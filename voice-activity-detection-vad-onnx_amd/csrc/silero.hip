@@ -884,6 +884,9 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
                         const int slot = 16 * (m / 16) + 4 * (m % 4) + (m % 16) / 4;     // m = 16S + q + 4j -> slot 16S + 4q + j
                         p[frag(OFF_SF + (size_t)((tl * 2 + cls) * 2 + 0) * 4 * FRAG, i, slot)] = cv;
                         p[frag(OFF_SF + (size_t)((tl * 2 + cls) * 2 + 1) * 4 * FRAG, i, slot)] = sv;
+                        // the same coefficients as split fragments (silero_split.hip's STFT), pairs in natural order
+                        vadx::qfrag_put(p + OFF_QSF + (size_t)((((tl * 2 + cls) * 2 + 0) * 2 + m / 32) * 3) * QF, i, m % 32, cv);
+                        vadx::qfrag_put(p + OFF_QSF + (size_t)((((tl * 2 + cls) * 2 + 1) * 2 + m / 32) * 3) * QF, i, m % 32, sv);
                     }
                 p[OFF_S0 + k] = 0.5f * (re[k * 256] + re[(128 - k) * 256]);
                 p[OFF_S0 + 64 + k] = 0.5f * (im[k * 256] - im[(128 - k) * 256]);

@@ -47,7 +47,10 @@ constexpr int OFF_Q3 = OFF_Q2 + 4 * 4 * 3 * 3 * QF;       // [4 oc tiles][2 taps
 constexpr int OFF_Q4 = OFF_Q3 + 4 * 2 * 2 * 3 * QF;       // [8 oc tiles][2 chunks][3 planes][QF]   centre tap
 constexpr int OFF_QIH = OFF_Q4 + 8 * 2 * 3 * QF;          // [8 unit tiles][4 chunks][4 gates][3 planes][QF]
 constexpr int OFF_QHH = OFF_QIH + 8 * 4 * 4 * 3 * QF;     // [8 unit tiles][4 gates][4 chunks][3 planes][QF]   W_hh for the split recurrent kernel
-constexpr int PACKED_FLOATS = OFF_QHH + 8 * 4 * 4 * 3 * QF;
+// folded STFT basis (OFF_SF's coefficients) as split fragments: [4 bin tiles][E|O][re|im][2 chunks of 32 pairs][3 planes][QF]; pair m of
+// the class = sample n = 2 m + 2 (E) / 2 m + 1 (O), in natural order
+constexpr int OFF_QSF = OFF_QHH + 8 * 4 * 4 * 3 * QF;
+constexpr int PACKED_FLOATS = OFF_QSF + 4 * 2 * 2 * 2 * 3 * QF;
 
 constexpr int X_LDM = 642;            // staged window row: 576 samples + 64 reflect pad (+2: bank = 2 clip + q, conflict free)
 // gx: per (t, group) 8 waves x 4 gates x 64 lanes x 4 floats

@@ -23,6 +23,14 @@
 #define VADX_EXP 0
 #endif
 #define SP_SKIP(n) ((VADX_EXP >> (n)) & 1)
+// VADX_SPLIT_STFT = 1 (or bit 15 of VADX_EXP): the folded STFT itself on split products -- built, parity-green on every test of
+// tests/test_gpu_silero.py, and measured EQUAL to the f32-MFMA fold (5.60 against 5.62 ms per launch): it issues 96 bf16 instead of 128
+// f32 MFMAs per wave and tile but streams 384 KB of table fragments per tile instead of 128 KB, and the fragment stream out of L2 is what
+// holds this kernel (every fragment from one L1-resident address: 4.10 ms with this STFT, 4.65 with the f32 fold, 5.95 as shipped on
+// the same box).  Not the default.
+#ifndef VADX_SPLIT_STFT
+#define VADX_SPLIT_STFT ((VADX_EXP >> 15) & 1)
+#endif
 #define SP_W(addr) (SP_SKIP(13) ? (P + vadx::silero::OFF_Q1) : (addr))        // what-if: every weight fragment from one (L1-resident) address
 #if (VADX_EXP >> 14) & 1
 __device__ unsigned long long sp_dbg[16];
@@ -213,7 +221,128 @@ __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_ke
 
     // ---------------- phase 1: STFT (float32 MFMAs, table = A operand) -> magnitudes -> the three bf16 planes of conv1's input.
     // Input-channel slot s of conv1: s <= 64 = bin s, s = 64 + k = bin 128 - k; bin 128 (Nyquist) goes to the scratch.
-    if (fold) {
+    if (fold && VADX_SPLIT_STFT) {
+        // ---- the folded STFT itself on split products.  The fold's operands are sums / differences of sample PAIRS: per frame f and pair
+        // index n = 1..128, e = x[128 f + n] + x[128 f + 256 - n] (cos part), o = the difference (sin part), in two classes (even / odd n:
+        // the frequency fold).  Thread (clip, class, four consecutive pairs of the class) reads its 32 samples out of X ONCE, into
+        // registers; the four frames then go in two pairs: its e / o values as 8-byte stores into the pair's B planes (which take X's
+        // place: [E e | E o | O e | O o][plane][k-group][2 frames x 16 clips][8]) | barrier | wave (bin tile, frame of the pair): four
+        // accumulators (E re, E im, O re, O im) x two k-steps x six products | barrier.  96 bf16 MFMAs per wave and tile instead of 128 f32,
+        // no operand arithmetic beside the matrix instructions.
+        const int cls = wave >> 2, pc = tid & 15, pj = (tid >> 4) & 15;
+        float xa[4][4], xb[4][4];                     // [frame][k]: the pair's two samples (plane indices: see stft_fold_class)
+        {
+            const float *row = X + pc * X_LDM + (cls ? X_ODD : 1) + 4 * pj, *rowb = X + pc * X_LDM + (cls ? X_ODD : 0) + 127 - 4 * pj;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { xa[f][k] = row[64 * f + k]; xb[f][k] = rowb[64 * f - k]; }
+        }
+        const int tl = wave >> 1, ct = wave & 1;      // GEMM role: bins 16 tl + 4 q + r (and 128 - them), frame 2 pair + ct, clip i
+        float x0p[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) x0p[pr] = X[i * X_LDM + 64 * (2 * pr + ct)];        // n = 0 belongs to the even class
+        float b64re = 0.f, b64im = 0.f;               // bin 64 (its own mirror) on the VALU: wave = (frame wave & 3, half of n = 1..128)
+        {
+            const int f = wave & 3, h = wave >> 2, n0 = h * 64 + q * 16;
+            const float *xr = X + i * X_LDM + 64 * f;
+            f32x4 cre = ldg4(P + OFF_B64 + n0), cim = ldg4(P + OFF_B64 + 128 + n0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int un = u + 1 < 4 ? u + 1 : u;
+                const f32x4 nre = ldg4(P + OFF_B64 + n0 + 4 * un), nim = ldg4(P + OFF_B64 + 128 + n0 + 4 * un);
+#pragma unroll
+                for (int k3 = 0; k3 < 4; ++k3) {
+                    const int n = n0 + 4 * u + k3 + 1;                                // 1..128, mirror 256 - n
+                    const float a = xr[(n & 1) * X_ODD + (n >> 1)], b = xr[(n & 1) * X_ODD + ((256 - n) >> 1)];
+                    b64re = fmaf(a + b, cre[k3], b64re);
+                    b64im = fmaf(a - b, cim[k3], b64im);
+                }
+                cre = nre;
+                cim = nim;
+            }
+            b64re += __shfl_xor(b64re, 16); b64re += __shfl_xor(b64re, 32);
+            b64im += __shfl_xor(b64im, 16); b64im += __shfl_xor(b64im, 32);
+            if (h == 0) {                                                             // the n = 0 tap
+                const float x0 = xr[0];
+                b64re = fmaf(x0, P[OFF_B64 + 256], b64re);
+                b64im = fmaf(x0, P[OFF_B64 + 257], b64im);
+            }
+        }
+        const f32x4 c0 = ldg4(P + OFF_S0 + tl * 16 + 4 * q), s0 = ldg4(P + OFF_S0 + 64 + tl * 16 + 4 * q);
+        __syncthreads();          // every sample is in registers: the pair planes may overwrite X
+        SP_MARK(1);
+        f32x4 mk[2], mn[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            // ---- this thread's e / o values of the pair's two frames -> planes
+#pragma unroll
+            for (int fl = 0; fl < 2; ++fl) {
+                f32x4 ev, ov;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ev[k] = xa[2 * pr + fl][k] + xb[2 * pr + fl][k]; ov[k] = xa[2 * pr + fl][k] - xb[2 * pr + fl][k]; }
+                unsigned char *d = smem + ((2 * cls) * 3 * 8 + (pj >> 1)) * 512 + (16 * fl + pc) * 16 + 8 * (pj & 1);
+                u32x2 p0, p1, p2;
+                split3x4(ev, p0, p1, p2);
+                *reinterpret_cast<u32x2 *>(d) = p0;
+                *reinterpret_cast<u32x2 *>(d + 8 * 512) = p1;
+                *reinterpret_cast<u32x2 *>(d + 16 * 512) = p2;
+                split3x4(ov, p0, p1, p2);
+                *reinterpret_cast<u32x2 *>(d + 24 * 512) = p0;
+                *reinterpret_cast<u32x2 *>(d + 32 * 512) = p1;
+                *reinterpret_cast<u32x2 *>(d + 40 * 512) = p2;
+            }
+            __syncthreads();
+            // ---- the pair's GEMM: (class, part) = (E re, E im, O re, O im) x two k-steps
+            f32x4 hi[4], lo[4];
+            hi[0] = c0 * x0p[pr];
+            hi[1] = s0 * x0p[pr];
+            hi[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            hi[3] = hi[2];
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) lo[a4] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!SP_SKIP(4)) {
+                const float *wq = P + OFF_QSF + (size_t)tl * (2 * 2 * 2 * 3 * QF);
+                bf16x8 a[2][3];
+                load_a3(a[0], SP_W(wq), lane);
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {          // s8 = (class, part, chunk): the fragment order of OFF_QSF
+                    if (s8 + 1 < 8) load_a3(a[(s8 + 1) & 1], SP_W(wq + (s8 + 1) * 3 * QF), lane);
+                    bf16x8 b[3];
+                    const unsigned char *bp = smem + ((s8 >> 1) * 3 * 8 + 4 * (s8 & 1) + q) * 512 + (16 * ct + i) * 16;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8 *>(bp + pl * 8 * 512);
+                    mfma_split6(a[s8 & 1], b, hi[s8 >> 1], lo[s8 >> 1]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ere = hi[0][r] + lo[0][r], eim = hi[1][r] + lo[1][r], ore = hi[2][r] + lo[2][r], oim = hi[3][r] + lo[3][r];
+                const float pre = ere + ore, pim = eim + oim, nre = ere - ore, nim = eim - oim;
+                mk[pr][r] = mag_sqrt(pre * pre + pim * pim);
+                mn[pr][r] = mag_sqrt(nre * nre + nim * nim);
+            }
+            __syncthreads();      // every wave is done reading the pair's planes
+        }
+        SP_MARK(1);
+        const int g = 4 * tl + q;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int f = 2 * pr + ct;
+            unsigned char *fr = smem + f * SP_FR128;
+            store_split4(fr, SP_PL128, g, i, mk[pr]);                 // slots 4 g + r        = bins 4 g + r
+            store_split4(fr, SP_PL128, 16 + g, i, mn[pr]);            // slots 64 + 4 g + r   = bins 128 - (4 g + r); g = 0, r = 0 is bin 128:
+            if (g == 0) nyq[f * 16 + i] = mn[pr][0];                  //   it goes to the scratch, and slot 64 is rewritten below with bin 64
+        }
+        if (q == 0) { scr[wave * 32 + i] = b64re; scr[wave * 32 + 16 + i] = b64im; }
+        __syncthreads();
+        SP_MARK(2);
+        if (tid < 64) {                                               // bin 64: frame tid / 16, clip tid % 16
+            const int f = tid >> 4, c = tid & 15;
+            const float re = scr[f * 32 + c] + scr[(f + 4) * 32 + c], im = scr[f * 32 + 16 + c] + scr[(f + 4) * 32 + 16 + c];
+            store_split1(smem + f * SP_FR128, SP_PL128, 64, c, mag_sqrt(re * re + im * im));
+        }
+    } else if (fold) {
         const int tl = wave & 3, fp = wave >> 2;      // wave = (bin tile tl, frame pair fp): bins k = 16 tl + 4 q + r and 128 - k
         float b64re = 0.f, b64im = 0.f;               // bin 64 (its own mirror) on the VALU: wave = (frame wave & 3, half of n = 1..128)
         {
