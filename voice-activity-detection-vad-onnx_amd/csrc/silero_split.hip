@@ -17,7 +17,7 @@
 #include "split3.h"
 
 // VADX_EXP: development-only what-if switches for tools/exp_encoder.py (results are wrong when set): bit 3 no conv2..4 MFMAs, 4 no STFT
-// MFMAs, 5 no conv1 MFMAs, 6 no W_ih MFMAs, 13 every weight fragment from one address (L1 instead of L2), 12 no activation splits
+// MFMAs, 5 no conv1 MFMAs, 6 no W_ih MFMAs, 11 no W_ih phase at all (neither fragments nor MFMAs), 13 every weight fragment from one address (L1 instead of L2), 12 no activation splits
 // (planes written from the raw bits), 14 per-phase cycle accounting of wave 0 (sp_dbg, read with vadx_silero_split_debug_cycles)
 #ifndef VADX_EXP
 #define VADX_EXP 0
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_ke
         constexpr int AHEAD = 3;
         bf16x8 a[AHEAD + 1][3];
 #pragma unroll
-        for (int s0 = 0; s0 < AHEAD; ++s0) load_a3(a[s0], SP_W(wq + s0 * 3 * QF), lane);
+        for (int s0 = 0; s0 < AHEAD; ++s0) load_a3(a[s0], SP_W(wq + (SP_SKIP(11) ? 0 : s0) * 3 * QF), lane);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             bf16x8 b[NSUB][3];
@@ -656,9 +656,9 @@ __global__ __launch_bounds__(SP_THREADS * HALVES, 4) void silero_encode_split_ke
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int s = kc * 4 + g;
-                if (s + AHEAD < 16) load_a3(a[(s + AHEAD) % (AHEAD + 1)], SP_W(wq + (s + AHEAD) * 3 * QF), lane);
+                if (s + AHEAD < 16 && !SP_SKIP(11)) load_a3(a[(s + AHEAD) % (AHEAD + 1)], SP_W(wq + (s + AHEAD) * 3 * QF), lane);
                 const bf16x8 (&ac)[3] = a[s % (AHEAD + 1)];
-                if (!SP_SKIP(6)) {
+                if (!SP_SKIP(6) && !SP_SKIP(11)) {
 #define SP_TERM(AP, BP, ACC) _Pragma("unroll") for (int sb = 0; sb < NSUB; ++sb) ACC[sb][g] = mfma_bf16(ac[AP], b[sb][BP], ACC[sb][g]);
                     SP_TERM(2, 0, lo) SP_TERM(1, 1, lo) SP_TERM(0, 2, lo) SP_TERM(1, 0, lo) SP_TERM(0, 1, lo) SP_TERM(0, 0, hi)
 #undef SP_TERM
