@@ -149,6 +149,15 @@ int vadx_silero_segments(const float *probs, int batch, int steps, const int64_t
  * ("f32" | "split").  Replaces nothing in the reference: onnxruntime has one CPU kernel set. */
 int vadx_silero_encoder_mode(int mode);
 
+/* Mode 2 = fp16 x 2 split products (csrc/split2.h: every product, the STFT included, as three v_mfma_f32_16x16x32_f16 per K = 32 step
+ * on operands represented to one float32 ulp by two round-to-nearest fp16 terms).  fp16 terms do not have float32's exponent range:
+ * the mode-2 kernels keep the largest |activation| they split and raise a sticky flag inside the packed blob when one left the fp16
+ * range (|x| > 65504), or when the blob cannot run in this mode at all (a weight outside the range, an STFT basis without the DFT
+ * symmetries).  This call copies the flag (0 = every result since the last reset is valid) and, when non-zero, the largest magnitude
+ * seen to the host (it synchronises `stream`); reset != 0 clears it.  A flagged batch must be recomputed in mode 1, whose bf16 terms
+ * have float32's range (vadx.silero.SileroEngine does so). */
+int vadx_silero_range_flag(const float *packed, int reset, uint32_t *flag_host, float *amax_host, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused signal front-end: int16 PCM -> prep -> framed windowed DFT against the
  * reference's own float32 table -> |.|^2 -> mel -> log.

@@ -134,6 +134,7 @@ SIGNATURES = {
     "vadx_silero_recur_span": (_I, [_P, _P, _Z, _I, _I, _P, _P, _L, _P, _P]),
     "vadx_silero_segments": (_I, [_P, _I, _I, _P, C.POINTER(SileroSegParams), _P, _P, _I, _P]),
     "vadx_silero_encoder_mode": (_I, [_I]),
+    "vadx_silero_range_flag": (_I, [_P, _I, _P, _P, _P]),
     "vadx_frontend_packed_floats": (_Z, [C.POINTER(FrontendCfg)]),
     "vadx_frontend_pack_host": (_I, [C.POINTER(FrontendCfg), _P, _P, _I, _P, _P, _P]),
     "vadx_frontend_fold_kind": (_I, [C.POINTER(FrontendCfg), _P, _P, _I]),

@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(HERE, "libvadx.so")
 TEST_HOOKS_SRC = os.path.join(ROOT, "tests", "hip")
 TEST_HOOKS_LIB = os.path.join(TEST_HOOKS_SRC, "libvadx_testhooks.so")
-SOURCES = ["capi.hip", "silero.hip", "silero_split.hip", "frontend.hip", "fsmn.hip", "firered.hip", "marblenet.hip", "dfsmn.hip", "dfsmn_cfb.hip", "ingest.hip"]
+SOURCES = ["capi.hip", "silero.hip", "silero_split.hip", "silero_h2.hip", "frontend.hip", "fsmn.hip", "firered.hip", "marblenet.hip", "dfsmn.hip", "dfsmn_cfb.hip", "ingest.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -12,6 +12,7 @@
 //   silero_segments_kernel: get_speech_timestamps' state machine, one clip per thread.
 #include "silero_common.h"
 #include "split3.h"
+#include "split2.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -840,6 +841,7 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
     memcpy(p + OFF_NYQ + 256, w->stft_basis + (size_t)257 * 256, 256 * sizeof(float));
     // fragment-major slot of element (row i of its tile, contraction index k) inside a tile that starts at `base`
     auto frag = [](size_t base, int i, int k) { return base + ((size_t)(k / 16) * 64 + ((k % 16) / 4) * 16 + i) * 4 + (k % 4); };
+    float hmax = 0.f;       // largest |weight| handed to the fp16 x 2 fragments (must stay inside the fp16 range)
     {   // folded basis: valid when the table has the time symmetry c[k][256-n] == c[k][n], s[k][256-n] == -s[k][n]
         // (n = 1..127; s[k][128] == 0) AND the frequency symmetry c[128-k][n] == (-1)^n c[k][n],
         // s[128-k][n] == -(-1)^n s[k][n], both up to f32 rounding of the table (1e-6 of the largest entry) -- which
@@ -887,6 +889,9 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
                         // the same coefficients as split fragments (silero_split.hip's STFT), pairs in natural order
                         vadx::qfrag_put(p + OFF_QSF + (size_t)((((tl * 2 + cls) * 2 + 0) * 2 + m / 32) * 3) * QF, i, m % 32, cv);
                         vadx::qfrag_put(p + OFF_QSF + (size_t)((((tl * 2 + cls) * 2 + 1) * 2 + m / 32) * 3) * QF, i, m % 32, sv);
+                        // ... and as fp16 x 2 fragment pairs (silero_h2.hip)
+                        hmax = fmaxf(hmax, vadx::hfrag_put(p + OFF_HSF + (size_t)((((tl * 2 + cls) * 2 + 0) * 2 + m / 32) * 2) * HF, i, m % 32, cv));
+                        hmax = fmaxf(hmax, vadx::hfrag_put(p + OFF_HSF + (size_t)((((tl * 2 + cls) * 2 + 1) * 2 + m / 32) * 2) * HF, i, m % 32, sv));
                     }
                 p[OFF_S0 + k] = 0.5f * (re[k * 256] + re[(128 - k) * 256]);
                 p[OFF_S0 + 64 + k] = 0.5f * (im[k * 256] - im[(128 - k) * 256]);
@@ -898,6 +903,13 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
             }
             p[OFF_B64 + 256] = re[64 * 256];
             p[OFF_B64 + 257] = im[64 * 256];
+            // bin 64 as row 0 of a fifth bin tile of the fp16 x 2 STFT (its coefficients are OFF_B64's, per class)
+            for (int cls = 0; cls < 2; ++cls)
+                for (int m = 0; m < 64; ++m) {
+                    const int n = cls ? 2 * m + 1 : 2 * m + 2;
+                    hmax = fmaxf(hmax, vadx::hfrag_put(p + OFF_HSF + (size_t)((((4 * 2 + cls) * 2 + 0) * 2 + m / 32) * 2) * HF, 0, m % 32, p[OFF_B64 + n - 1]));
+                    hmax = fmaxf(hmax, vadx::hfrag_put(p + OFF_HSF + (size_t)((((4 * 2 + cls) * 2 + 1) * 2 + m / 32) * 2) * HF, 0, m % 32, p[OFF_B64 + 128 + n - 1]));
+                }
         }
     }
     {   // conv1 in the Winograd F(4,3) domain: U_j[co][ci] = sum_t G[j][t] g[co][ci][t], evaluated in float64
@@ -980,6 +992,53 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
                 for (int i = 0; i < 16; ++i)
                     for (int k = 0; k < 32; ++k) vadx::qfrag_put(f3, i, k, w->lstm_w_hh[(size_t)(g * 128 + wv * 16 + i) * 128 + 32 * kc + k]);
             }
+    // ---- ... and as fp16 x 2 fragment pairs for silero_h2.hip (split2.h), same orders
+    for (int rt = 0; rt < 8; ++rt)
+        for (int kc = 0; kc < 4; ++kc)
+            for (int tap = 0; tap < 3; ++tap) {
+                float *f2 = p + OFF_H1 + (size_t)(((rt * 4 + kc) * 3 + tap) * 2) * HF;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) {
+                        const int slot = 32 * kc + k, bin = slot <= 64 ? slot : 192 - slot;
+                        hmax = fmaxf(hmax, vadx::hfrag_put(f2, i, k, w->enc_w[0][((size_t)(16 * rt + i) * 129 + bin) * 3 + tap]));
+                    }
+            }
+    for (int rt = 0; rt < 4; ++rt)
+        for (int kc = 0; kc < 4; ++kc)
+            for (int tap = 0; tap < 3; ++tap) {
+                float *f2 = p + OFF_H2 + (size_t)(((rt * 4 + kc) * 3 + tap) * 2) * HF;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) hmax = fmaxf(hmax, vadx::hfrag_put(f2, i, k, w->enc_w[1][((size_t)(16 * rt + i) * 128 + 32 * kc + k) * 3 + tap]));
+            }
+    for (int rt = 0; rt < 4; ++rt)
+        for (int th = 0; th < 2; ++th)
+            for (int kc = 0; kc < 2; ++kc) {
+                float *f2 = p + OFF_H3 + (size_t)(((rt * 2 + th) * 2 + kc) * 2) * HF;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) hmax = fmaxf(hmax, vadx::hfrag_put(f2, i, k, w->enc_w[2][((size_t)(16 * rt + i) * 64 + 32 * kc + k) * 3 + th + 1]));
+            }
+    for (int rt = 0; rt < 8; ++rt)
+        for (int kc = 0; kc < 2; ++kc) {
+            float *f2 = p + OFF_H4 + (size_t)((rt * 2 + kc) * 2) * HF;
+            for (int i = 0; i < 16; ++i)
+                for (int k = 0; k < 32; ++k) hmax = fmaxf(hmax, vadx::hfrag_put(f2, i, k, w->enc_w[3][((size_t)(16 * rt + i) * 64 + 32 * kc + k) * 3 + 1]));
+        }
+    for (int wv = 0; wv < 8; ++wv)
+        for (int kc = 0; kc < 4; ++kc)
+            for (int g = 0; g < 4; ++g) {
+                float *f2 = p + OFF_HIH + (size_t)(((wv * 4 + kc) * 4 + g) * 2) * HF;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) hmax = fmaxf(hmax, vadx::hfrag_put(f2, i, k, w->lstm_w_ih[(size_t)(g * 128 + wv * 16 + i) * 128 + 32 * kc + k]));
+            }
+    for (int wv = 0; wv < 8; ++wv)
+        for (int g = 0; g < 4; ++g)
+            for (int kc = 0; kc < 4; ++kc) {
+                float *f2 = p + OFF_HHH + (size_t)(((wv * 4 + g) * 4 + kc) * 2) * HF;
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 32; ++k) hmax = fmaxf(hmax, vadx::hfrag_put(f2, i, k, w->lstm_w_hh[(size_t)(g * 128 + wv * 16 + i) * 128 + 32 * kc + k]));
+            }
+    // the fp16 x 2 kernels need the folded STFT pass and every weight inside the fp16 range (NaN fails the comparison too)
+    p[OFF_HFLAG] = (p[OFF_FOLD] != 0.f && hmax <= vadx::H_MAX) ? 1.f : 0.f;
     return VADX_OK;
 }
 
@@ -990,15 +1049,31 @@ static int encoder_mode() {
     int m = g_encoder_mode.load(std::memory_order_relaxed);
     if (m < 0) {
         const char *e = getenv("VADX_SILERO_ENCODER");
-        m = (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : ((e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : VADX_SILERO_ENCODER_DEFAULT);
+        m = (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : ((e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 :
+            ((e && (!strcmp(e, "h2") || !strcmp(e, "2"))) ? 2 : VADX_SILERO_ENCODER_DEFAULT));
         g_encoder_mode.store(m, std::memory_order_relaxed);
     }
     return m;
 }
 extern "C" int vadx_silero_encoder_mode(int mode) {
     const int prev = encoder_mode();
-    if (mode == 0 || mode == 1) g_encoder_mode.store(mode, std::memory_order_relaxed);
+    if (mode >= 0 && mode <= 2) g_encoder_mode.store(mode, std::memory_order_relaxed);
     return prev;
+}
+
+// The fp16 x 2 kernels' sticky range flag (silero_common.h: OFF_HFLAG): copies the two words [flag, bits of the largest |activation|]
+// to the host (synchronises `stream`) and, with reset != 0, clears them on the device.
+extern "C" int vadx_silero_range_flag(const float *packed, int reset, uint32_t *flag_host, float *amax_host, void *stream) {
+    VADX_REQUIRE(packed && flag_host, "vadx_silero_range_flag: NULL argument");
+    uint32_t w[2] = {0, 0};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VADX_HIP_TRY(hipMemcpyAsync(w, packed + OFF_HFLAG + 1, sizeof(w), hipMemcpyDeviceToHost, st));
+    VADX_HIP_TRY(hipStreamSynchronize(st));
+    if (reset && (w[0] | w[1]))
+        VADX_HIP_TRY(hipMemsetAsync(const_cast<float *>(packed) + OFF_HFLAG + 1, 0, sizeof(w), st));
+    *flag_host = w[0];
+    if (amax_host) memcpy(amax_host, &w[1], sizeof(float));
+    return VADX_OK;
 }
 
 extern "C" size_t vadx_silero_workspace_bytes(int batch, int steps) {
@@ -1026,6 +1101,9 @@ static int silero_encode_launch(const float *packed, const S *src, float in_scal
     }
     const long long nblk = (long long)G * steps;
     VADX_REQUIRE(nblk < (1LL << 31), "silero: too many tiles (%lld)", nblk);
+    if (encoder_mode() == 2)
+        return silero_encode_h2_launch<S>(packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps, Gws, first_group,
+                                          static_cast<float *>(ws), stream);
     if (encoder_mode() == 1)
         return silero_encode_split_launch<S>(packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps, Gws, first_group,
                                              static_cast<float *>(ws), stream);
@@ -1046,6 +1124,8 @@ static int silero_recur_launch(const float *packed, const void *ws, size_t ws_by
         return VADX_ENOSPACE;
     }
     const int G = (batch + 15) / 16;
+    if (encoder_mode() == 2)
+        return silero_lstm_h2_launch(packed, static_cast<const float *>(ws), state0, batch, G, steps, probs, probs_stride, state_n, stream);
     if (encoder_mode() == 1)
         return silero_lstm_split_launch(packed, static_cast<const float *>(ws), state0, batch, G, steps, probs, probs_stride, state_n, stream);
     hipLaunchKernelGGL(silero_lstm_kernel, dim3(G), dim3(LSTM_THREADS), LSTM_LDS_FLOATS * sizeof(float),

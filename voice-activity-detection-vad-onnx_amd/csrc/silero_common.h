@@ -50,7 +50,23 @@ constexpr int OFF_QHH = OFF_QIH + 8 * 4 * 4 * 3 * QF;     // [8 unit tiles][4 ga
 // folded STFT basis (OFF_SF's coefficients) as split fragments: [4 bin tiles][E|O][re|im][2 chunks of 32 pairs][3 planes][QF]; pair m of
 // the class = sample n = 2 m + 2 (E) / 2 m + 1 (O), in natural order
 constexpr int OFF_QSF = OFF_QHH + 8 * 4 * 4 * 3 * QF;
-constexpr int PACKED_FLOATS = OFF_QSF + 4 * 2 * 2 * 2 * 3 * QF;
+// ---- fp16 x 2 encoder (csrc/silero_h2.hip, csrc/split2.h): the same weights as fragment PAIRS (h0 plane, h1 * 2^11 plane; one fragment =
+// HF floats = 64 lanes x 8 fp16), in the order each wave streams them
+constexpr int HF = 256;                                   // = vadx::HFRAG
+constexpr int OFF_H1 = OFF_QSF + 4 * 2 * 2 * 2 * 3 * QF;  // conv1 [8 oc tiles][4 chunks][3 taps][2 planes][HF], input slots as OFF_Q1
+constexpr int OFF_H2 = OFF_H1 + 8 * 4 * 3 * 2 * HF;       // conv2 [4 oc tiles][4 chunks][3 taps][2][HF]
+constexpr int OFF_H3 = OFF_H2 + 4 * 4 * 3 * 2 * HF;       // conv3 [4 oc tiles][2 taps (1, 2)][2 chunks][2][HF]
+constexpr int OFF_H4 = OFF_H3 + 4 * 2 * 2 * 2 * HF;       // conv4 [8 oc tiles][2 chunks][2][HF]   centre tap
+constexpr int OFF_HIH = OFF_H4 + 8 * 2 * 2 * HF;          // W_ih [8 unit tiles][4 chunks][4 gates][2][HF]
+constexpr int OFF_HHH = OFF_HIH + 8 * 4 * 4 * 2 * HF;     // W_hh [8 unit tiles][4 gates][4 chunks][2][HF]
+// folded STFT basis: [5 bin tiles][E|O][re|im][2 chunks of 32 pairs][2][HF]; tiles 0..3 = bins 0..63 (OFF_SF's coefficients), tile 4 row 0 =
+// bin 64 (OFF_B64's time-folded coefficients, rows 1..15 zero); pair m of the class = sample n = 2 m + 2 (E) / 2 m + 1 (O)
+constexpr int OFF_HSF = OFF_HHH + 8 * 4 * 4 * 2 * HF;
+// [0] 1.0 = the fp16 x 2 kernels may run on this blob (every weight inside the fp16 range, folded basis); [1] sticky range flag, written
+// by the kernels as an unsigned (non-zero: some activation left the fp16 range, the batch must be recomputed on the bf16 x 3 kernels);
+// [2] bits of the largest |activation| seen by a flagged workgroup; [3] pad
+constexpr int OFF_HFLAG = OFF_HSF + 5 * 2 * 2 * 2 * 2 * HF;
+constexpr int PACKED_FLOATS = OFF_HFLAG + 4;
 
 constexpr int X_LDM = 642;            // staged window row: 576 samples + 64 reflect pad (+2: bank = 2 clip + q, conflict free)
 // gx: per (t, group) 8 waves x 4 gates x 64 lanes x 4 floats
@@ -163,6 +179,13 @@ template <> struct SampleIO<int16_t> {
 template <typename S>
 int silero_encode_split_launch(const float *packed, const S *src, float in_scale, long long n_valid, long long row_stride,
                                long long origin, int batch, int G, int steps, int Gws, int first_group, float *gx, void *stream);
+
+// csrc/silero_h2.hip: the fp16 x 2 encoder and recurrent kernels (arguments as the bf16 x 3 launches)
+template <typename S>
+int silero_encode_h2_launch(const float *packed, const S *src, float in_scale, long long n_valid, long long row_stride,
+                            long long origin, int batch, int G, int steps, int Gws, int first_group, float *gx, void *stream);
+int silero_lstm_h2_launch(const float *packed, const float *gx, const float *state0, int batch, int G, int steps, float *probs,
+                          long long probs_stride, float *state_n, void *stream);
 
 int silero_lstm_split_launch(const float *packed, const float *gx, const float *state0, int batch, int G, int steps, float *probs,
                              long long probs_stride, float *state_n, void *stream);

@@ -37,7 +37,7 @@ def _as_weight_dict(path_or_weights):
 WORKSPACE_CAP_BYTES = 8 << 30     # clips(): above this the gate-preactivation workspace is reused span by span
 
 
-ENCODER_MODES = {"f32": 0, "split": 1}
+ENCODER_MODES = {"f32": 0, "split": 1, "h2": 2}
 
 
 def encoder_mode(mode=None):
