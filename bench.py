@@ -74,12 +74,33 @@ SPLIT_F32_MFMA_PER_TILE = 1024
 SPLIT_BF16_MFMA_PER_TILE = 1920 + 480 + 96 + 96 + 768
 FLOP_SPLIT_F32_PART = SPLIT_F32_MFMA_PER_TILE * 2048 // 16                  # per window, on the f32 pipe
 FLOP_SPLIT_BF16_PART = SPLIT_BF16_MFMA_PER_TILE // 6 * 16384 // 16          # per window, f32-equivalent flops of the split products
+# fp16 x 2 kernels (csrc/split2.h, csrc/silero_h2.hip): THREE v_mfma_f32_16x16x32_f16 per K = 32 step, the folded STFT included -- priced
+# against the dense fp16 MFMA peak / 3.  Per 16-window tile: STFT 480 (bin 64 as a fifth bin tile), conv1 960, conv2 240, conv3 48,
+# conv4 48, W_ih 384 = 2160 MFMAs = 720 K = 32 steps of 16 x 16 outputs.
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense fp16 MFMA peak (= bf16)
+PEAK_H2_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
+H2_MFMA_PER_TILE = 480 + 960 + 240 + 48 + 48 + 384
+FLOP_H2 = H2_MFMA_PER_TILE // 3 * 16384 // 16                               # per window, f32-equivalent flops
+# What the chip sustains of a pipe's nominal peak when that pipe is kept busy (it clocks to its power budget): shader clock under a
+# back-to-back MFMA stream / the 2.4 GHz the nominal peaks assume.  f32 and bf16: profiles/r04_dvfs_probe.txt (2.14 - 2.20 and 1.99 - 2.01
+# GHz); fp16: profiles/r05_f16x2_probe.txt (2.07 - 2.15 GHz under three-MFMA groups).  `frac_of_sustained` = achieved / (peak x this).
+SUSTAINED_OF_NOMINAL = {"f32": 0.87, "split": 0.80, "h2": 0.86}
+SUSTAINED_SOURCE = "profiles/r04_dvfs_probe.txt (f32, bf16), profiles/r05_f16x2_probe.txt (fp16)"
+ENC_KERNELS = {"f32": "silero_encode_kernel", "split": "silero_encode_split_kernel", "h2": "silero_encode_h2_kernel"}
+REC_KERNELS = {"f32": "silero_lstm_kernel", "split": "silero_lstm_split_kernel", "h2": "silero_lstm_h2_kernel"}
+ARITH_TEXT = {"f32": "float32 MFMAs (v_mfma_f32_16x16x4_f32)",
+              "split": "float32 results from bf16 x 3 exact-split products on the bf16 matrix pipe (csrc/split3.h)",
+              "h2": "float32 results from fp16 x 2 split products on the fp16 matrix pipe: operands to one float32 ulp by two round-to-nearest "
+                    "fp16 terms, three MFMAs per K = 32 step, range-checked (csrc/split2.h)"}
 
 
 def encoder_roofline(mode, frames, enc_ms):
     """(achieved TFLOP/s, peak TFLOP/s, flop per frame, note) of one encoder launch.  f32 kernel: issued f32-MFMA flops against 157.3.
     Split kernel: f32 flops of the STFT part + f32-EQUIVALENT flops of the split products, against the peak of that mix = total flops /
     (f32 part / 157.3 + split part / (2500 / 6)) -- the time the two matrix pipes need at their own peaks, back to back."""
+    if mode == "h2":
+        return frames * FLOP_H2 / (enc_ms * 1e-3) / 1e12, PEAK_H2_TFLOPS, FLOP_H2, (
+            f"{FLOP_H2} f32-equivalent flops of fp16 x 2 split products per frame (folded STFT included); peak = 2500 / 3 TFLOP/s")
     if mode != "split":
         return frames * FLOP_ENCODE_ISSUED / (enc_ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS, FLOP_ENCODE_ISSUED, "issued f32-MFMA flops"
     fl = FLOP_SPLIT_F32_PART + FLOP_SPLIT_BF16_PART
@@ -144,25 +165,30 @@ def profiled_launch_ms(kernel="silero_encode_kernel"):
 NS_PER_MFMA, NS_PER_VALU = 13.7, 0.93
 
 
-def instruction_mix(kernel="silero_encode_kernel"):
-    """MFMA / VALU instruction counts per launch of `kernel` (SQ_INSTS_* of the newest committed PMC summary) and the fraction of
-    the f32-MFMA peak that mix could reach if nothing but issue time were spent: MFMA / (MFMA + VALU * 0.93 / 13.7)."""
+def instruction_mix(kernel="silero_encode_kernel", arithmetic="f32"):
+    """MFMA / VALU instruction counts per launch of `kernel` (SQ_INSTS_* of the newest committed PMC summary) and -- for f32-MFMA kernels
+    ONLY -- the fraction of the f32-MFMA peak that mix could reach if nothing but issue time were spent: MFMA / (MFMA + VALU * 0.93 / 13.7).
+    The additive model was measured for f32-input MFMAs, which share the vector datapath; beside bf16 / fp16 MFMAs VALU work hides
+    (tools/bf16x3_probe.sh, tools/f16x2_probe.sh), so a split-product kernel carries the counts and NO model ceiling."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "SUMMARY.txt"))):
         mfma, g1 = _kernel_counter(path, kernel, "SQ_INSTS_MFMA")
         valu, g2 = _kernel_counter(path, kernel, "SQ_INSTS_VALU")
         if mfma and valu and g1 == g2:
-            best = {"mfma_insts": mfma, "valu_insts": valu, "valu_per_mfma": valu / mfma,
+            best = {"mfma_insts": mfma, "valu_insts": valu, "valu_per_mfma": valu / mfma, "arithmetic": arithmetic,
                     "ceiling_frac": mfma * NS_PER_MFMA / (mfma * NS_PER_MFMA + valu * NS_PER_VALU),
                     "model": f"{NS_PER_MFMA} ns per v_mfma_f32_16x16x4_f32 + {NS_PER_VALU} ns per VALU instruction per SIMD, additive "
                              "(tools/mfma_valu_overlap.sh)", "source": os.path.relpath(path, ROOT)}
+            if arithmetic != "f32":
+                best["ceiling_frac"] = None
+                best["model"] = "none: VALU instructions hide beside bf16 / fp16 MFMAs (tools/bf16x3_probe.sh, tools/f16x2_probe.sh)"
     return best
 
 
 def enc_kernel_name():
     from vadx import silero
-    return "silero_encode_split_kernel" if silero.encoder_mode() == "split" else "silero_encode_kernel"
+    return ENC_KERNELS[silero.encoder_mode()]
 
 
 def synth_batch(torch, device, batch, samples, seed, pcm16=False):
@@ -467,16 +493,17 @@ def main(argv=None):
                             min_silence_duration_ms=250)     # Silero/Inference_Silero_VAD_ONNX.py:88-96
     ws = eng._workspace(B, T)
     st = _lib.stream_ptr()
+    cfg = eng.cfg()                     # the arithmetic rides with every call (include/vadx.h: vadx_silero_cfg)
 
     def step(ev=None):
         if ev:
             ev[0].record()
         _lib.check(L.vadx_silero_encode(eng.packed.data_ptr(), audio.data_ptr(), B, SAMPLES, _lib.row_stride(audio),
-                                        ws.data_ptr(), ws.numel(), st))
+                                        ws.data_ptr(), ws.numel(), st, cfg))
         if ev:
             ev[1].record()
         _lib.check(L.vadx_silero_recur(eng.packed.data_ptr(), ws.data_ptr(), ws.numel(), B, T, None,
-                                       probs.data_ptr(), None, st))
+                                       probs.data_ptr(), None, st, cfg))
         if ev:
             ev[2].record()
         _lib.check(L.vadx_silero_segments(probs.data_ptr(), B, T, lens.data_ptr(), C.byref(prm), segs.data_ptr(),
@@ -513,16 +540,18 @@ def main(argv=None):
                  "committed_profile": profiled_launch_ms(enc_kernel_name()) if (B, T) == (CLIPS_PER_GPU, STEPS_PER_CLIP) else None}
     assert int(counts.max().item()) <= cap, "segment table overflow"
     assert bool(torch.isfinite(probs).all())
+    range_flag = eng.range_flag()       # fp16 x 2 kernels: no activation of the timed steps may have left the fp16 range (outside the timed region)
+    assert range_flag[0] == 0, f"fp16 range flag raised during the timed steps: {range_flag}"
     n_seg = int(counts.sum().item())
     probs_resident = probs.clone()
 
     frames_per_step = world * B * T
     value = frames_per_step * args.steps / elapsed
     enc_mode = silero.encoder_mode()
-    enc_kernel = "silero_encode_split_kernel" if enc_mode == "split" else "silero_encode_kernel"
-    rec_kernel = "silero_lstm_split_kernel" if enc_mode == "split" else "silero_lstm_kernel"
+    enc_kernel, rec_kernel = ENC_KERNELS[enc_mode], REC_KERNELS[enc_mode]
     achieved, enc_peak, enc_flop, enc_note = encoder_roofline(enc_mode, B * T, enc_ms)
-    rec_peak = PEAK_SPLIT_TFLOPS if enc_mode == "split" else PEAK_F32_MFMA_TFLOPS
+    rec_peak = {"f32": PEAK_F32_MFMA_TFLOPS, "split": PEAK_SPLIT_TFLOPS, "h2": PEAK_H2_TFLOPS}[enc_mode]
+    sustained = SUSTAINED_OF_NOMINAL[enc_mode]
 
     # ---- the same batch from pinned host int16, upload overlapped with compute (every rank feeds its own GPU at once)
     feed = None
@@ -606,10 +635,7 @@ def main(argv=None):
         tr_rec = profiled_traffic(rec_kernel) if full else None
         # the additive VALU : MFMA cost model was measured for f32-input MFMAs (they share the vector datapath); beside bf16 MFMAs VALU work
         # hides (tools/bf16x3_probe.sh), so the split kernels carry the counts without a model ceiling
-        mix_enc = instruction_mix(enc_kernel) if full else None
-        if mix_enc and enc_mode == "split":
-            mix_enc["ceiling_frac"] = None
-            mix_enc["model"] = "none: VALU instructions hide beside bf16 MFMAs (tools/bf16x3_probe.sh)"
+        mix_enc = instruction_mix(enc_kernel, enc_mode) if full else None
         algo_launch = B * T * ALGO_BYTES_PER_WINDOW
         step_traffic = (tr_enc["bytes"] + tr_rec["bytes"]) if (tr_enc and tr_rec) else None
         step_s = elapsed / args.steps
@@ -620,8 +646,7 @@ def main(argv=None):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Silero-VAD f32, batch=4096 synthetic 10 s @16 kHz clips per GPU "
                                    "(STFT conv + conv1d stack + LSTM cell HIP, seeded synthetic weights)",
-                       "arithmetic": ("float32 results from bf16 x 3 exact-split products on the bf16 matrix pipe (csrc/split3.h)" if enc_mode == "split"
-                                      else "float32 MFMAs (v_mfma_f32_16x16x4_f32)"),
+                       "arithmetic": ARITH_TEXT[enc_mode],
                        "clips_per_gpu": B, "samples_per_clip": SAMPLES, "frames_per_clip": T,
                        "parallelism": f"clip-sharded x{world}, no collective"},
             "per_gpu_value": value / world, "rtf_batch1": rtf_b1,
@@ -634,6 +659,8 @@ def main(argv=None):
             # launch's counted HBM bytes (it also writes the 2048 B/window gx intermediate the LSTM kernel re-reads).
             "roofline": {"bound": "mfma", "kernel": enc_kernel, "achieved": achieved,
                          "peak": enc_peak, "unit": "TFLOP/s", "frac": achieved / enc_peak,
+                         "frac_of_sustained": achieved / (enc_peak * sustained), "sustained_of_nominal": sustained,
+                         "sustained_source": SUSTAINED_SOURCE,
                          "arithmetic": enc_mode, "flops_counted": enc_note,
                          "traffic": tr_enc["bytes"] if tr_enc else None, "traffic_unit": "B/launch",
                          "traffic_source": tr_enc["source"] if tr_enc else None,
@@ -648,8 +675,9 @@ def main(argv=None):
             "roofline_recurrent": {"bound": "mfma", "kernel": rec_kernel, "flop_per_frame": FLOP_RECUR,
                                    "achieved": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12, "peak": rec_peak, "arithmetic": enc_mode,
                                    "unit": "TFLOP/s", "frac": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12 / rec_peak,
+                                   "frac_of_sustained": B * T * FLOP_RECUR / (rec_ms * 1e-3) / 1e12 / (rec_peak * sustained),
                                    "traffic": tr_rec["bytes"] if tr_rec else None,
-                                   "instruction_mix": instruction_mix(rec_kernel) if full else None},
+                                   "instruction_mix": instruction_mix(rec_kernel, enc_mode) if full else None},
             # the north star's HBM view of the whole step: SURVEY 8(d) algorithmic bytes / step time against 8 TB/s, and what
             # the step really moves (encoder + LSTM launches, PMC) over the algorithmic bytes
             "hbm": {"algorithmic_bytes_per_frame": ALGO_BYTES_PER_WINDOW, "algorithmic_bytes_per_step": algo_launch,

@@ -30,8 +30,26 @@ extern "C" {
 /* THE ABI number: the library (csrc/capi.hip), the ctypes binding (vadx._lib.ABI_VERSION, parsed from this line),
  * the C client (tests/c/cabi_silero.c) and __graft_entry__.build() all read it from here and nowhere else.
  * 3: vadx_frontend_cfg grew `fold`; vadx_frontend_fold_kind, vadx_dfsmn_cfb_*, _lstm_t_ex, _ft_repack (round 3).
- * 4: vadx_silero_encoder_mode, vadx_gemm_mode; the Silero / FSMN packed blobs grew the bf16 x 3 weight fragments (round 4). */
-#define VADX_ABI_VERSION 5
+ * 4: vadx_silero_encoder_mode, vadx_gemm_mode; the Silero / FSMN packed blobs grew the bf16 x 3 weight fragments (round 4).
+ * 5: vadx_dfsmn_cfb_weights grew fwd_tbl_q / inv_tbl_q (the struct must be zero-initialised at its ABI-5 size: an ABI-4 caller's shorter
+ *    struct would have the new pointers read past its end -- the version check is the guard); vadx_stream_vadpost* (round 4).
+ * 6: the arithmetic of an entry point comes WITH THE CALL (VADX_ARITH_* in a cfg / dims struct) instead of process-wide switches:
+ *    vadx_silero_encoder_mode and vadx_gemm_mode are gone, every Silero launch takes a trailing `const vadx_silero_cfg *`;
+ *    VADX_ARITH_F16X2 (fp16 x 2 split products) + vadx_silero_range_flag; the Silero packed blob grew the fp16 fragments (round 5). */
+#define VADX_ABI_VERSION 6
+
+/* Arithmetic of the products whose one operand is a constant (every weight matrix, every DFT table) -- float32 RESULTS in all of them:
+ *   F32     v_mfma_f32_16x16x4_f32 on the float32 operands themselves;
+ *   BF16X3  operands split EXACTLY into three bf16 terms, six v_mfma_f32_16x16x32_bf16 per K = 32 step (csrc/split3.h): float32-class
+ *           accuracy at 6/16 of the matrix time, float32's exponent range;
+ *   F16X2   operands represented to one float32 ulp by two round-to-nearest fp16 terms, three v_mfma_f32_16x16x32_f16 per K = 32 step
+ *           (csrc/split2.h): float32-class accuracy at 3/16 of the matrix time; activations must stay inside the fp16 range (|x| <= 65504),
+ *           which the kernels check (vadx_silero_range_flag);
+ *   AUTO    the library's default for the entry point (what a zero-initialised cfg selects). */
+#define VADX_ARITH_AUTO   0
+#define VADX_ARITH_F32    1
+#define VADX_ARITH_BF16X3 2
+#define VADX_ARITH_F16X2  3
 
 /* Arithmetic of the FSMN / FireRed dense layers, process-wide: 0 = exact-f32 MFMAs, 1 = bf16 x 3 split products (float32 operands
  * split exactly into three bf16 terms, six bf16 MFMAs per K = 32 step: float32-class accuracy at 6/16 of the matrix time, csrc/split3.h).
@@ -58,6 +76,14 @@ typedef struct vadx_silero_weights_host {
     const float *dec_w, *dec_b;
 } vadx_silero_weights_host;
 
+/* Per-call configuration of the Silero launches; NULL = all defaults.  Zero-initialise it. */
+typedef struct vadx_silero_cfg {
+    int32_t arithmetic;     /* VADX_ARITH_*: AUTO = F16X2.  The three kernel sets read the same packed blob and write the same workspace, so the
+                             * encoder and recurrent launches of one batch may even differ.  Replaces nothing in the reference: onnxruntime has
+                             * one CPU kernel set. */
+    int32_t reserved[3];    /* must be zero */
+} vadx_silero_cfg;
+
 /* Number of floats of the packed (kernel-layout) weight blob. */
 size_t vadx_silero_packed_floats(void);
 /* Repack on the host (init time only); the caller uploads `packed_host` to the device once.
@@ -74,7 +100,7 @@ size_t vadx_silero_workspace_bytes(int batch, int steps);
  * sr must be 16000 (the reference wrapper's '16k' model path, utils_vad.py:62-64). */
 int vadx_silero_step(const float *packed, const float *input, const float *state, int64_t sr,
                      int batch, float *out, float *state_n,
-                     void *workspace, size_t workspace_bytes, void *stream);
+                     void *workspace, size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg);
 
 /* Whole clips, batched: audio f32 [B][row_stride] (first n_samples valid per row, +-1 scale),
  * zero state and zero context at t=0, last window zero-padded; probs f32 [B][T], T = ceil(n/512).
@@ -83,27 +109,27 @@ int vadx_silero_step(const float *packed, const float *input, const float *state
  * OnnxWrapper.audio_forward, utils_vad.py:130-146 (context carry :111-114,:123 is done in-kernel). */
 int vadx_silero_clips(const float *packed, const float *audio, int batch, int64_t n_samples,
                       int64_t row_stride, float *probs, float *state_n,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      void *workspace, size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg);
 
 /* The two halves of vadx_silero_clips as separate launches (same buffers, same results), so a
  * harness can time the state-independent encoder (STFT conv + conv stack + W_ih, the dominant
  * kernel) and the recurrent kernel separately.  `steps` = ceil(n_samples/512). */
 int vadx_silero_encode(const float *packed, const float *audio, int batch, int64_t n_samples,
-                       int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream);
+                       int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg);
 /* The same encoder fed int16 PCM: sample = (float)pcm * scale in one f32 rounding -- with scale = 0.000030517578f exactly the
  * float32 array the reference script builds on the host (Silero/Inference_Silero_VAD_ONNX.py:83), so results are
  * bit-identical to vadx_silero_encode on that array while the upload and the HBM read are half the bytes. */
 int vadx_silero_encode_pcm16(const float *packed, const int16_t *audio, float scale, int batch, int64_t n_samples,
-                             int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream);
+                             int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg);
 /* A slice of the batch: clips [first_clip, first_clip + batch) of a workspace laid out for total_batch clips (first_clip a
  * multiple of 16).  Lets the encoder of one uploaded chunk run while the next chunk is still crossing PCIe (bench.py's
  * feed-inclusive mode, SURVEY 8e "pinned-host staging double-buffered per GPU"); one vadx_silero_recur over total_batch
  * follows.  Results are identical to a single vadx_silero_encode_pcm16 over the whole batch. */
 int vadx_silero_encode_pcm16_part(const float *packed, const int16_t *audio, float scale, int batch, int64_t n_samples,
                                   int64_t row_stride, int first_clip, int total_batch, void *workspace,
-                                  size_t workspace_bytes, void *stream);
+                                  size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg);
 int vadx_silero_recur(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
-                      int steps, const float *state0, float *probs, float *state_n, void *stream);
+                      int steps, const float *state0, float *probs, float *state_n, void *stream, const vadx_silero_cfg *cfg);
 
 /* The same two launches over a SPAN of windows [first_step, first_step + n_steps) of the clips, for recordings whose
  * whole-clip workspace (32 KB per 16-clip group and window) is too large: the caller walks the spans in order on one
@@ -115,10 +141,10 @@ int vadx_silero_recur(const float *packed, const void *workspace, size_t workspa
  * span k+1's encoder was measured and gains nothing: both kernels are matrix-pipe-bound) */
 int vadx_silero_encode_span(const float *packed, const float *audio, int batch, int64_t n_samples,
                             int64_t row_stride, int first_step, int n_steps, void *workspace,
-                            size_t workspace_bytes, void *stream);
+                            size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg);
 int vadx_silero_recur_span(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
                            int n_steps, const float *state0, float *probs, int64_t probs_stride,
-                           float *state_n, void *stream);
+                           float *state_n, void *stream, const vadx_silero_cfg *cfg);
 
 /* Parameters of the segmenter; defaults of get_speech_timestamps (utils_vad.py:248-263). */
 typedef struct vadx_silero_seg_params {
@@ -142,20 +168,13 @@ int vadx_silero_segments(const float *probs, int batch, int steps, const int64_t
                          const vadx_silero_seg_params *params, int64_t *segments, int32_t *counts,
                          int cap, void *stream);
 
-/* Which encoder kernel vadx_silero_step / _clips / _encode* launch (process-wide): 0 = exact-f32 MFMAs (v_mfma_f32_16x16x4_f32),
- * 1 = bf16 x 3 split products (every constant-weight GEMM as six v_mfma_f32_16x16x32_bf16 per K = 32 step on exactly split
- * operands: float32-class accuracy at 6/16 of the matrix time, csrc/split3.h).  Both read the same packed blob and write the same
- * workspace.  Any other `mode` only queries.  Returns the previous mode; the initial one comes from VADX_SILERO_ENCODER
- * ("f32" | "split").  Replaces nothing in the reference: onnxruntime has one CPU kernel set. */
-int vadx_silero_encoder_mode(int mode);
-
-/* Mode 2 = fp16 x 2 split products (csrc/split2.h: every product, the STFT included, as three v_mfma_f32_16x16x32_f16 per K = 32 step
- * on operands represented to one float32 ulp by two round-to-nearest fp16 terms).  fp16 terms do not have float32's exponent range:
- * the mode-2 kernels keep the largest |activation| they split and raise a sticky flag inside the packed blob when one left the fp16
+/* VADX_ARITH_F16X2 (csrc/split2.h: every product, the STFT included, as three v_mfma_f32_16x16x32_f16 per K = 32 step on operands
+ * represented to one float32 ulp by two round-to-nearest fp16 terms).  fp16 terms do not have float32's exponent range: the F16X2
+ * kernels keep the largest |activation| they split and raise a sticky flag inside the packed blob when one left the fp16
  * range (|x| > 65504), or when the blob cannot run in this mode at all (a weight outside the range, an STFT basis without the DFT
  * symmetries).  This call copies the flag (0 = every result since the last reset is valid) and, when non-zero, the largest magnitude
- * seen to the host (it synchronises `stream`); reset != 0 clears it.  A flagged batch must be recomputed in mode 1, whose bf16 terms
- * have float32's range (vadx.silero.SileroEngine does so). */
+ * seen to the host (it synchronises `stream`); reset != 0 clears it.  A flagged batch must be recomputed with VADX_ARITH_BF16X3, whose
+ * bf16 terms have float32's range (vadx.silero.SileroEngine does so). */
 int vadx_silero_range_flag(const float *packed, int reset, uint32_t *flag_host, float *amax_host, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

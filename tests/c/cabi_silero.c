@@ -67,12 +67,12 @@ int main(int argc, char **argv) {
     CHECK_HIP(hipMemcpyAsync(lens, lens_host, B * sizeof(int64_t), hipMemcpyHostToDevice, stream));
 
     /* the two library calls of the hot path, stream-ordered behind the uploads */
-    CHECK_VADX(vadx_silero_clips(pk, audio, B, N, N, probs, NULL, ws, ws_bytes, stream));
+    CHECK_VADX(vadx_silero_clips(pk, audio, B, N, N, probs, NULL, ws, ws_bytes, stream, NULL));
     vadx_silero_seg_params prm = {0.5, -1.0, 16000, 250.0, 1e30, 100.0, 30.0, 98.0, 1};
     CHECK_VADX(vadx_silero_segments(probs, B, T, lens, &prm, segs, counts, CAP, stream));
 
     /* error path: a sample rate the reference wrapper rejects must come back as VADX_EINVAL with its message */
-    if (vadx_silero_step(pk, audio, audio, 44100, 1, probs, probs, ws, ws_bytes, stream) != VADX_EINVAL) {
+    if (vadx_silero_step(pk, audio, audio, 44100, 1, probs, probs, ws, ws_bytes, stream, NULL) != VADX_EINVAL) {
         fprintf(stderr, "sr=44100 was not rejected\n");
         return 4;
     }

@@ -1,6 +1,6 @@
 """first GPU check of the fp16 x 2 Silero kernels: gx against the float64 oracle for all three kernel sets, step/clips vs oracle, timing"""
 import sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os; R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch, ctypes as C
 import vadx
 from vadx import _lib, silero, weights
@@ -24,7 +24,7 @@ for mode in ("f32", "split", "h2"):
     e = (gx_of(eng, x.cuda()).double().cpu() - ref).abs()
     print(mode, "gx err max %.3e mean %.3e  (scale %.3g)" % (float(e.max()), float(e.mean()), float(ref.abs().max())), " per-clip max:", ["%.1e" % float(e[:, c].max()) for c in range(6)])
 flag = C.c_uint32(0); am = C.c_float(0)
-_lib.check(_lib.lib().vadx_silero_range_flag(eng.packed.data_ptr(), 1, C.byref(flag), C.byref(am), _lib.stream_ptr()))
+flag.value, am.value = eng.range_flag()
 print("range flag", flag.value, am.value)
 # step + clips vs oracle
 ow = {k: T(v) for k, v in weights.silero_synthetic(1234).items()}
@@ -44,9 +44,9 @@ for mode in ("split", "h2"):
 silero.encoder_mode("h2")
 big = torch.from_numpy((rng.standard_normal((16, 5120)) * 3000).astype(np.float32)).cuda()
 eng.encode(big); torch.cuda.synchronize()
-_lib.check(_lib.lib().vadx_silero_range_flag(eng.packed.data_ptr(), 1, C.byref(flag), C.byref(am), _lib.stream_ptr()))
+flag.value, am.value = eng.range_flag()
 print("range flag after huge audio", flag.value, am.value)
-_lib.check(_lib.lib().vadx_silero_range_flag(eng.packed.data_ptr(), 1, C.byref(flag), C.byref(am), _lib.stream_ptr()))
+flag.value, am.value = eng.range_flag()
 print("range flag after reset", flag.value, am.value)
 # timing at the bench shape
 B, N = 4096, 160000
@@ -61,5 +61,5 @@ for mode in ("split", "h2"):
         pr = eng.recur(B, (N + 511) // 512, torch.empty((B, (N + 511) // 512), dtype=torch.float32, device="cuda"))
         torch.cuda.synchronize(); t2 = time.perf_counter()
         print(mode, "encode %.3f ms  recur %.3f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
-_lib.check(_lib.lib().vadx_silero_range_flag(eng.packed.data_ptr(), 1, C.byref(flag), C.byref(am), _lib.stream_ptr()))
+flag.value, am.value = eng.range_flag()
 print("range flag after bench", flag.value, am.value)

@@ -21,9 +21,10 @@ def T(x):
     return torch.from_numpy(np.ascontiguousarray(x))
 
 
-@pytest.fixture(autouse=True, params=["f32", "split"])
+@pytest.fixture(autouse=True, params=["f32", "split", "h2"])
 def encoder(request):
-    """Every test of this file runs on both encoder kernels: exact-f32 MFMAs and bf16 x 3 split products (csrc/silero_split.hip)."""
+    """Every test of this file runs on all three kernel sets: exact-f32 MFMAs, bf16 x 3 split products (csrc/silero_split.hip) and
+    fp16 x 2 split products (csrc/silero_h2.hip, the default)."""
     prev = silero.encoder_mode(request.param)
     yield request.param
     silero.encoder_mode(prev)
@@ -47,9 +48,10 @@ def gx_of(engine, audio):
 
 
 def test_split_products_are_as_exact_as_f32_products(engine):
-    """The proof that lets the split-product encoder stand in for the exact-f32 one: against a FLOAT64 evaluation of the same float32
-    weights and samples (oracle.input_projection), the bf16 x 3 encoder's error is no larger than 1.25 x the f32-MFMA encoder's --
-    on the quantity both hand the recurrent kernel, for silence, LSB-level noise, full-scale noise, a loud tone and bursts."""
+    """The proof that lets the split-product encoders stand in for the exact-f32 one: against a FLOAT64 evaluation of the same float32
+    weights and samples (oracle.input_projection), the bf16 x 3 encoder's error AND the fp16 x 2 encoder's are no larger than 1.25 x the
+    f32-MFMA encoder's -- on the quantity all three hand the recurrent kernel, for silence, LSB-level noise, full-scale noise, a loud
+    tone and bursts."""
     n = 5120
     rng = np.random.default_rng(11)
     clips = weights.burst_clips(27, n, seed=21).astype(np.float32)
@@ -63,15 +65,55 @@ def test_split_products_are_as_exact_as_f32_products(engine):
     xp = torch.cat([torch.zeros(27, 64), x], dim=1).double()
     ref = torch.stack([osil.input_projection(w64, xp[:, 512 * t:512 * t + 576]) for t in range(n // 512)])      # [T][B][512]
     err = {}
-    for mode in ("f32", "split"):
+    for mode in ("f32", "split", "h2"):
         silero.encoder_mode(mode)
         err[mode] = (gx_of(engine, x.cuda()).double().cpu() - ref).abs()
+    assert engine.range_flag() == (0, 0.0)                                       # nothing left the fp16 range
     scale = float(ref.abs().max())
-    print(f"gx scale {scale:.3g}: max err f32 {float(err['f32'].max()):.3e} split {float(err['split'].max()):.3e}; "
-          f"mean f32 {float(err['f32'].mean()):.3e} split {float(err['split'].mean()):.3e}")
+    print(f"gx scale {scale:.3g}: max err f32 {float(err['f32'].max()):.3e} split {float(err['split'].max()):.3e} h2 {float(err['h2'].max()):.3e}; "
+          f"mean f32 {float(err['f32'].mean()):.3e} split {float(err['split'].mean()):.3e} h2 {float(err['h2'].mean()):.3e}")
     assert float(err["f32"].max()) < 2e-5 * max(scale, 1.0)                      # the f32 encoder itself is sane
-    assert float(err["split"].max()) <= 1.25 * float(err["f32"].max())
-    assert float(err["split"].mean()) <= 1.25 * float(err["f32"].mean())
+    for mode in ("split", "h2"):
+        assert float(err[mode].max()) <= 1.25 * float(err["f32"].max())
+        assert float(err[mode].mean()) <= 1.25 * float(err["f32"].mean())
+
+
+def test_fp16_range_protocol(engine, oracle_w):
+    """fp16 terms stop at 65504: audio far outside +-1 drives an activation beyond it, the fp16 x 2 kernels raise the blob's sticky flag, and
+    the engine recomputes that batch on bf16 x 3 -- same scores as asking for "split" outright.  In-range audio never flags."""
+    rng = np.random.default_rng(3)
+    loud = torch.from_numpy((rng.standard_normal((18, 4096)) * 3000).astype(np.float32)).cuda()
+    prev = silero.encoder_mode("split")
+    want = engine.clips(loud)
+    silero.encoder_mode("h2")
+    n0 = engine.range_fallbacks
+    got = engine.clips(loud)
+    assert engine.range_fallbacks == n0 + 1 and torch.equal(got, want)
+    engine.encode(loud)
+    flag, amax = engine.range_flag()
+    assert flag == 1 and amax > 65504.0
+    assert engine.range_flag() == (0, 0.0)                                       # the read-back cleared it
+    ok = torch.from_numpy((rng.standard_normal((18, 4096)) * 0.3).astype(np.float32))
+    p = engine.clips(ok.cuda())
+    assert engine.range_fallbacks == n0 + 1
+    np.testing.assert_allclose(p.cpu().numpy(), osil.OnnxWrapperOracle(oracle_w).audio_forward(ok, 16000).numpy(), rtol=0, atol=ATOL)
+    silero.encoder_mode(prev)
+
+
+def test_blob_that_cannot_run_on_fp16_falls_back(oracle_w):
+    """A weight beyond the fp16 range (or an STFT basis without the DFT symmetries) is found at pack time: the engine then never
+    selects the fp16 x 2 kernels, and a direct F16X2 launch on such a blob raises the flag instead of computing."""
+    w = weights.silero_synthetic(1234)
+    w["enc1_w"] = w["enc1_w"].copy()
+    w["enc1_w"][3, 5, 1] = 1.0e5
+    eng = silero.SileroEngine(w)
+    assert not eng.h2_ok
+    prev = silero.encoder_mode("h2")
+    assert eng.mode() == "split"
+    x = torch.zeros((16, 1024), dtype=torch.float32, device="cuda")
+    eng.encode(x, mode="h2")
+    assert eng.range_flag()[0] == 2
+    silero.encoder_mode(prev)
 
 
 @pytest.fixture(scope="module")
@@ -138,11 +180,16 @@ def test_step_rejects_bad_arguments(engine):
     o = torch.zeros((1, 1), device="cuda")
     ws = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
     rc = L.vadx_silero_step(engine.packed.data_ptr(), x.data_ptr(), s.data_ptr(), 8000, 1, o.data_ptr(), s.data_ptr(),
-                            ws.data_ptr(), ws.numel(), None)
+                            ws.data_ptr(), ws.numel(), None, engine.cfg())
     assert rc == -1 and b"16000" in L.vadx_last_error()
     rc = L.vadx_silero_step(engine.packed.data_ptr(), x.data_ptr(), s.data_ptr(), 16000, 1, o.data_ptr(), s.data_ptr(),
-                            ws.data_ptr(), 16, None)
+                            ws.data_ptr(), 16, None, engine.cfg())
     assert rc == -2
+    bad = _lib.SileroCfg()
+    bad.arithmetic = 7
+    rc = L.vadx_silero_step(engine.packed.data_ptr(), x.data_ptr(), s.data_ptr(), 16000, 1, o.data_ptr(), s.data_ptr(),
+                            ws.data_ptr(), ws.numel(), None, ctypes.byref(bad))
+    assert rc == -1 and b"VADX_ARITH" in L.vadx_last_error()
 
 
 # ------------------------------------------------------------------ whole clips (context carry in-kernel)
@@ -293,7 +340,7 @@ def test_spanned_schedule_is_bitwise_identical(engine, batch, n, span):
     want = torch.empty((batch, steps), dtype=torch.float32, device="cuda")
     st_want = torch.empty((2, batch, 128), dtype=torch.float32, device="cuda")
     _lib.check(L.vadx_silero_clips(engine.packed.data_ptr(), a.data_ptr(), batch, n, _lib.row_stride(a), want.data_ptr(),
-                                   st_want.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+                                   st_want.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(), engine.cfg()))
     torch.cuda.synchronize()
     got = torch.full((batch, steps), -1.0, dtype=torch.float32, device="cuda")
     st = engine.clips_spanned(a, n, got, span=span)
@@ -314,12 +361,12 @@ def test_span_entries_reject_bad_spans(engine):
     ws = engine._workspace(16, 4)
     L = _lib.lib()
     assert L.vadx_silero_encode_span(engine.packed.data_ptr(), a.data_ptr(), 16, 2048, 2048, 3, 2, ws.data_ptr(), ws.numel(),
-                                     _lib.stream_ptr()) != 0     # windows 3..4 of a 4-window clip
+                                     _lib.stream_ptr(), engine.cfg()) != 0     # windows 3..4 of a 4-window clip
     assert L.vadx_silero_encode_span(engine.packed.data_ptr(), a.data_ptr(), 16, 2048, 2048, -1, 2, ws.data_ptr(), ws.numel(),
-                                     _lib.stream_ptr()) != 0
+                                     _lib.stream_ptr(), engine.cfg()) != 0
     p = torch.zeros((16, 4), dtype=torch.float32, device="cuda")
     assert L.vadx_silero_recur_span(engine.packed.data_ptr(), ws.data_ptr(), ws.numel(), 16, 4, None, p.data_ptr(), 3, None,
-                                    _lib.stream_ptr()) != 0      # probs_stride < n_steps
+                                    _lib.stream_ptr(), engine.cfg()) != 0      # probs_stride < n_steps
 
 
 # ------------------------------------------------------------------ int16 PCM straight into the encoder
@@ -352,11 +399,11 @@ def test_pcm16_part_encodes_fill_one_workspace(engine):
     for b0, nb in ((48, 32), (0, 16), (16, 32)):
         part = pcm[b0:b0 + nb].contiguous()
         _lib.check(L.vadx_silero_encode_pcm16_part(engine.packed.data_ptr(), part.data_ptr(), engine.PCM16_SCALE, nb, n, n, b0, B,
-                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr(), engine.cfg()))
     got = engine.recur(B, steps, torch.empty((B, steps), dtype=torch.float32, device="cuda"))
     assert torch.equal(got, want)
     bad = lambda b0, nb: L.vadx_silero_encode_pcm16_part(engine.packed.data_ptr(), pcm.data_ptr(), engine.PCM16_SCALE, nb, n, n,   # noqa: E731
-                                                         b0, B, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                                                         b0, B, ws.data_ptr(), ws.numel(), _lib.stream_ptr(), engine.cfg())
     assert bad(8, 16) != 0 and bad(64, 32) != 0 and bad(-16, 16) != 0
 
 

@@ -14,16 +14,21 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "voice-activity-detection-vad-onnx_amd")
 EXP = os.path.join(PKG, "_exp")
-SRC = ["capi.hip", "silero.hip", "silero_split.hip"]
-SPLIT = os.environ.get("EXP_SPLIT", "1") == "1"          # EXP_SPLIT=0: the exact-f32 encoder (silero_encode_kernel) instead of the split-product one
+SRC = ["capi.hip", "silero.hip", "silero_split.hip", "silero_h2.hip"]
+if os.environ.get("EXP_FULL") == "1":     # every source: a library the ctypes binding (vadx._lib, VADX_LIBRARY=...) can load
+    SRC += ["frontend.hip", "fsmn.hip", "firered.hip", "marblenet.hip", "dfsmn.hip", "dfsmn_cfb.hip", "ingest.hip"]
+MODE = int(os.environ.get("EXP_SPLIT", "2"))             # EXP_SPLIT=0: the exact-f32 encoder, 1: bf16 x 3 (silero_split.hip), 2: fp16 x 2 (silero_h2.hip)
+SPLIT = MODE == 1
+DEFS = os.environ.get("EXP_DEFS", "").split()            # extra -D switches, e.g. EXP_DEFS="-DVADX_H2_NSUB=1"; EXP_TAG names the library
+TAG = os.environ.get("EXP_TAG", "")
 
 
 def build(ids):
     os.makedirs(EXP, exist_ok=True)
     for n in ids:
-        out = os.path.join(EXP, f"libvadx_exp{n}.so")
+        out = os.path.join(EXP, f"libvadx_exp{TAG}{n}.so")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-DVADX_EXP={n}",
-               f"-DVADX_SILERO_ENCODER_DEFAULT={1 if SPLIT else 0}"]
+               f"-DVADX_SILERO_ENCODER_DEFAULT={MODE}"] + DEFS
         cmd += [os.path.join(PKG, "csrc", s) for s in SRC] + ["-o", out]
         subprocess.check_call(cmd)
         print("built", out)
@@ -59,15 +64,15 @@ pk = torch.from_numpy(packed).cuda()
 audio = bench.synth_batch(torch, torch.device("cuda:0"), B, N, 1234)
 nws = h.vadx_silero_workspace_bytes(B, T)
 ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
-h.vadx_silero_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_size_t, C.c_void_p]
+h.vadx_silero_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def enc():
-    rc = h.vadx_silero_encode(pk.data_ptr(), audio.data_ptr(), B, N, audio.stride(0), ws.data_ptr(), nws, st)
+    rc = h.vadx_silero_encode(pk.data_ptr(), audio.data_ptr(), B, N, audio.stride(0), ws.data_ptr(), nws, st, None)     # cfg NULL = the library's default (-DVADX_SILERO_ENCODER_DEFAULT)
     assert rc == 0, h.vadx_last_error()
-h.vadx_silero_recur.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+h.vadx_silero_recur.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 probs = torch.empty((B, T), dtype=torch.float32, device="cuda")
 def rec():
-    rc = h.vadx_silero_recur(pk.data_ptr(), ws.data_ptr(), nws, B, T, None, probs.data_ptr(), None, st)
+    rc = h.vadx_silero_recur(pk.data_ptr(), ws.data_ptr(), nws, B, T, None, probs.data_ptr(), None, st, None)
     assert rc == 0, h.vadx_last_error()
 for _ in range(2): enc(); rec()
 torch.cuda.synchronize()
@@ -80,7 +85,19 @@ for a, b in ev:
     a.record(); rec(); b.record()
 torch.cuda.synchronize()
 tr = [a.elapsed_time(b) for a, b in ev]
-if hasattr(h, "vadx_silero_split_debug_cycles") and %d:
+if hasattr(h, "vadx_silero_h2_debug_cycles") and %d == 2:
+    buf = (C.c_ulonglong * 16)()
+    h.vadx_silero_h2_debug_cycles(buf, 1)
+    enc(); torch.cuda.synchronize()
+    h.vadx_silero_h2_debug_cycles(buf, 0)
+    if buf[15]:
+        print("PHASES shader clock over the workgroups: %%.2f GHz (s_memtime / 100 MHz counter)" %% (buf[14] / buf[15] / 10.0))
+    buf[14] = buf[15] = 0
+    tot = sum(buf) or 1
+    names = {0: "stage X", 1: "samples -> regs", 2: "e/o planes", 3: "STFT GEMM + |.|", 4: "|X| planes + bin 64", 5: "conv1", 6: "conv1 store", 7: "conv2", 8: "conv3", 9: "conv4", 10: "W_ih + gx store"}
+    print("PHASES (share of wave-0 cycles, sum over workgroups):", ", ".join(f"{names.get(k, k)} {100.0 * v / tot:.1f}%%" for k, v in enumerate(buf) if v),
+          "| cycles per tile: %%.0f" %% (tot / (B // 16 * T)))
+elif hasattr(h, "vadx_silero_split_debug_cycles") and %d == 1:
     buf = (C.c_ulonglong * 16)()
     h.vadx_silero_split_debug_cycles(buf, 1)
     enc(); torch.cuda.synchronize()
@@ -108,8 +125,8 @@ print("EXP", os.path.basename(os.environ["VADX_LIBRARY"]), "encode ms mean %%.3f
 
 def run(ids):
     for n in ids:
-        env = dict(os.environ, VADX_LIBRARY=os.path.join(EXP, f"libvadx_exp{n}.so"))
-        r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, 1 if SPLIT else 0)], env=env, capture_output=True, text=True, timeout=300)
+        env = dict(os.environ, VADX_LIBRARY=os.path.join(EXP, f"libvadx_exp{TAG}{n}.so"))
+        r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, MODE, MODE)], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in r.stdout.splitlines() if l.startswith("EXP")]
         for ph in [l for l in r.stdout.splitlines() if l.startswith("PHASES")]:
             print(ph, flush=True)

@@ -7,12 +7,17 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vadx  # noqa: E402,F401
-from vadx import firered, fsmn, marblenet, weights  # noqa: E402
+from vadx import firered, fsmn, marblenet, silero, weights  # noqa: E402
 from vadx import timestamps as ts  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "firered"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-if which == "firered":
+if which == "silero":         # the headline shape: 4096 x 10 s, encoder + recurrent kernels of the mode VADX_SILERO_ENCODER selects
+    eng = silero.SileroEngine(weights.silero_synthetic(1234))
+    big = (torch.from_numpy(weights.burst_clips(64, 160000, seed=1)).cuda().repeat(64, 1).float() * 0.000030517578).contiguous()
+    probs = torch.empty((4096, 313), dtype=torch.float32, device="cuda")
+    fn = lambda: (eng.encode(big), eng.recur(4096, 313, probs))      # noqa: E731
+elif which == "firered":
     eng = firered.FireRedEngine(weights.firered_synthetic(1234))
     big = torch.from_numpy(weights.burst_clips(32, 160000, seed=321)).cuda().repeat(16, 1)       # 512 clips
     fn = lambda: eng.run(big, 10)      # noqa: E731

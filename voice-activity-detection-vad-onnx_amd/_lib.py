@@ -14,12 +14,20 @@ HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "vadx.h")
 
 
 def _header_abi_version():
-    """`#define VADX_ABI_VERSION n` of include/vadx.h -- the one place the ABI number is written."""
+    """`#define VADX_ABI_VERSION n` of include/vadx.h -- the one place the ABI number is written.  A deployment that ships only this
+    package and libvadx.so has no header: build.py then left the number it compiled against in _abi.py next to the library."""
     import re
-    m = re.search(r"^#define\s+VADX_ABI_VERSION\s+(\d+)\s*$", open(HEADER_PATH).read(), flags=re.M)
-    if not m:
-        raise RuntimeError(f"{HEADER_PATH}: no '#define VADX_ABI_VERSION <n>' line")
-    return int(m.group(1))
+    if os.path.exists(HEADER_PATH):
+        with open(HEADER_PATH) as fh:
+            m = re.search(r"^#define\s+VADX_ABI_VERSION\s+(\d+)\s*$", fh.read(), flags=re.M)
+        if not m:
+            raise RuntimeError(f"{HEADER_PATH}: no '#define VADX_ABI_VERSION <n>' line")
+        return int(m.group(1))
+    try:
+        from ._abi import ABI_VERSION as built       # written by build.py
+        return int(built)
+    except ImportError as e:
+        raise RuntimeError(f"neither {HEADER_PATH} nor {os.path.join(HERE, '_abi.py')} exists: cannot tell which ABI this binding expects") from e
 
 
 ABI_VERSION = _header_abi_version()
@@ -33,6 +41,14 @@ class SileroWeightsHost(C.Structure):
     _fields_ = [("stft_basis", C.c_void_p), ("enc_w", C.c_void_p * 4), ("enc_b", C.c_void_p * 4),
                 ("lstm_w_ih", C.c_void_p), ("lstm_w_hh", C.c_void_p), ("lstm_b_ih", C.c_void_p),
                 ("lstm_b_hh", C.c_void_p), ("dec_w", C.c_void_p), ("dec_b", C.c_void_p)]
+
+
+class SileroCfg(C.Structure):
+    """vadx_silero_cfg (include/vadx.h): per-call configuration of the Silero launches"""
+    _fields_ = [("arithmetic", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+ARITH = {"auto": 0, "f32": 1, "split": 2, "bf16x3": 2, "h2": 3, "f16x2": 3}       # VADX_ARITH_*
 
 
 class SileroSegParams(C.Structure):
@@ -124,16 +140,16 @@ SIGNATURES = {
     "vadx_silero_packed_floats": (_Z, []),
     "vadx_silero_pack_host": (_I, [C.POINTER(SileroWeightsHost), _P]),
     "vadx_silero_workspace_bytes": (_Z, [_I, _I]),
-    "vadx_silero_step": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _Z, _P]),
-    "vadx_silero_clips": (_I, [_P, _P, _I, _L, _L, _P, _P, _P, _Z, _P]),
-    "vadx_silero_encode": (_I, [_P, _P, _I, _L, _L, _P, _Z, _P]),
-    "vadx_silero_encode_pcm16": (_I, [_P, _P, C.c_float, _I, _L, _L, _P, _Z, _P]),
-    "vadx_silero_encode_pcm16_part": (_I, [_P, _P, C.c_float, _I, _L, _L, _I, _I, _P, _Z, _P]),
-    "vadx_silero_recur": (_I, [_P, _P, _Z, _I, _I, _P, _P, _P, _P]),
-    "vadx_silero_encode_span": (_I, [_P, _P, _I, _L, _L, _I, _I, _P, _Z, _P]),
-    "vadx_silero_recur_span": (_I, [_P, _P, _Z, _I, _I, _P, _P, _L, _P, _P]),
+    # (every Silero launch ends with (stream, const vadx_silero_cfg *); None = the library's defaults)
+    "vadx_silero_step": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _Z, _P, _P]),
+    "vadx_silero_clips": (_I, [_P, _P, _I, _L, _L, _P, _P, _P, _Z, _P, _P]),
+    "vadx_silero_encode": (_I, [_P, _P, _I, _L, _L, _P, _Z, _P, _P]),
+    "vadx_silero_encode_pcm16": (_I, [_P, _P, C.c_float, _I, _L, _L, _P, _Z, _P, _P]),
+    "vadx_silero_encode_pcm16_part": (_I, [_P, _P, C.c_float, _I, _L, _L, _I, _I, _P, _Z, _P, _P]),
+    "vadx_silero_recur": (_I, [_P, _P, _Z, _I, _I, _P, _P, _P, _P, _P]),
+    "vadx_silero_encode_span": (_I, [_P, _P, _I, _L, _L, _I, _I, _P, _Z, _P, _P]),
+    "vadx_silero_recur_span": (_I, [_P, _P, _Z, _I, _I, _P, _P, _L, _P, _P, _P]),
     "vadx_silero_segments": (_I, [_P, _I, _I, _P, C.POINTER(SileroSegParams), _P, _P, _I, _P]),
-    "vadx_silero_encoder_mode": (_I, [_I]),
     "vadx_silero_range_flag": (_I, [_P, _I, _P, _P, _P]),
     "vadx_frontend_packed_floats": (_Z, [C.POINTER(FrontendCfg)]),
     "vadx_frontend_pack_host": (_I, [C.POINTER(FrontendCfg), _P, _P, _I, _P, _P, _P]),

@@ -65,7 +65,17 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    _write_abi()
     return LIB
+
+
+def _write_abi():
+    """The ABI number this library was compiled against, next to it (read by _lib when the header does not travel with the package)."""
+    import re
+    with open(os.path.join(ROOT, "include", "vadx.h")) as fh:
+        n = int(re.search(r"^#define\s+VADX_ABI_VERSION\s+(\d+)\s*$", fh.read(), flags=re.M).group(1))
+    with open(os.path.join(HERE, "_abi.py"), "w") as fh:
+        fh.write(f'"""written by build.py: the VADX_ABI_VERSION of the include/vadx.h libvadx.so was built from"""\nABI_VERSION = {n}\n')
 
 
 def build_test_hooks(force=False, verbose=True):

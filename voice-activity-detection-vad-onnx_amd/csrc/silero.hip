@@ -23,7 +23,7 @@
 // tests/test_gpu_silero.py::test_split_products_are_as_exact_as_f32_products showed it CLOSER to the float64 evaluation of the same
 // float32 network than the f32-MFMA encoder (max 9.3e-6 against 1.6e-5 on gx of scale 30, mean 2.1e-7 against 3.4e-7) and every
 // parity test of that file passes on both.
-#define VADX_SILERO_ENCODER_DEFAULT 1
+#define VADX_SILERO_ENCODER_DEFAULT 2
 #endif
 
 // VADX_EXP: development-only what-if switches for tools/exp_encoder.py (results are wrong when set).
@@ -1042,24 +1042,21 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
     return VADX_OK;
 }
 
-// Which encoder kernel the launches below use: 0 = exact-f32 MFMAs (silero_encode_kernel), 1 = bf16 x 3 split products
-// (silero_encode_split_kernel).  Process-wide; the default comes from VADX_SILERO_ENCODER ("f32" | "split") at the first use.
-static std::atomic<int> g_encoder_mode{-1};
-static int encoder_mode() {
-    int m = g_encoder_mode.load(std::memory_order_relaxed);
-    if (m < 0) {
-        const char *e = getenv("VADX_SILERO_ENCODER");
-        m = (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : ((e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 :
-            ((e && (!strcmp(e, "h2") || !strcmp(e, "2"))) ? 2 : VADX_SILERO_ENCODER_DEFAULT));
-        g_encoder_mode.store(m, std::memory_order_relaxed);
+// Which kernel set a launch uses comes with the call (include/vadx.h: vadx_silero_cfg.arithmetic); NULL / VADX_ARITH_AUTO = the
+// library's default.  Internal numbering: 0 = exact-f32 MFMAs, 1 = bf16 x 3 (silero_split.hip), 2 = fp16 x 2 (silero_h2.hip).
+static int arith_of(const vadx_silero_cfg *cfg) {
+    const int a = cfg ? cfg->arithmetic : VADX_ARITH_AUTO;
+    switch (a) {
+        case VADX_ARITH_AUTO: return VADX_SILERO_ENCODER_DEFAULT;
+        case VADX_ARITH_F32: return 0;
+        case VADX_ARITH_BF16X3: return 1;
+        case VADX_ARITH_F16X2: return 2;
+        default: return -1;
     }
-    return m;
 }
-extern "C" int vadx_silero_encoder_mode(int mode) {
-    const int prev = encoder_mode();
-    if (mode >= 0 && mode <= 2) g_encoder_mode.store(mode, std::memory_order_relaxed);
-    return prev;
-}
+#define VADX_SILERO_ARITH(cfg, who)                                                                               \
+    const int arith = arith_of(cfg);                                                                              \
+    VADX_REQUIRE(arith >= 0, who ": cfg->arithmetic=%d is not one of VADX_ARITH_*", (cfg) ? (cfg)->arithmetic : 0)
 
 // The fp16 x 2 kernels' sticky range flag (silero_common.h: OFF_HFLAG): copies the two words [flag, bits of the largest |activation|]
 // to the host (synchronises `stream`) and, with reset != 0, clears them on the device.
@@ -1085,7 +1082,8 @@ extern "C" size_t vadx_silero_workspace_bytes(int batch, int steps) {
 template <typename S>
 static int silero_encode_launch(const float *packed, const S *src, float in_scale, long long n_valid, long long row_stride,
                                 long long origin, int batch, int steps, void *ws, size_t ws_bytes, void *stream,
-                                int first_group = 0, int total_batch = 0) {
+                                const vadx_silero_cfg *cfg, int first_group = 0, int total_batch = 0) {
+    VADX_SILERO_ARITH(cfg, "silero");
     VADX_REQUIRE(packed && src && ws, "silero: NULL pointer argument");
     VADX_REQUIRE(batch > 0 && steps > 0, "silero: batch=%d steps=%d must be positive", batch, steps);
     VADX_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
@@ -1101,10 +1099,10 @@ static int silero_encode_launch(const float *packed, const S *src, float in_scal
     }
     const long long nblk = (long long)G * steps;
     VADX_REQUIRE(nblk < (1LL << 31), "silero: too many tiles (%lld)", nblk);
-    if (encoder_mode() == 2)
+    if (arith == 2)
         return silero_encode_h2_launch<S>(packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps, Gws, first_group,
                                           static_cast<float *>(ws), stream);
-    if (encoder_mode() == 1)
+    if (arith == 1)
         return silero_encode_split_launch<S>(packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps, Gws, first_group,
                                              static_cast<float *>(ws), stream);
     VADX_DYN_LDS(silero_encode_kernel<S>, ENC_LDS_FLOATS * sizeof(float));
@@ -1116,7 +1114,9 @@ static int silero_encode_launch(const float *packed, const S *src, float in_scal
 }
 
 static int silero_recur_launch(const float *packed, const void *ws, size_t ws_bytes, int batch, int steps,
-                               const float *state0, float *probs, long long probs_stride, float *state_n, void *stream) {
+                               const float *state0, float *probs, long long probs_stride, float *state_n, void *stream,
+                               const vadx_silero_cfg *cfg) {
+    VADX_SILERO_ARITH(cfg, "silero");
     VADX_REQUIRE(packed && ws && probs, "silero: NULL pointer argument");
     VADX_REQUIRE(batch > 0 && steps > 0, "silero: batch=%d steps=%d must be positive", batch, steps);
     if (ws_bytes < vadx_silero_workspace_bytes(batch, steps)) {
@@ -1124,9 +1124,9 @@ static int silero_recur_launch(const float *packed, const void *ws, size_t ws_by
         return VADX_ENOSPACE;
     }
     const int G = (batch + 15) / 16;
-    if (encoder_mode() == 2)
+    if (arith == 2)
         return silero_lstm_h2_launch(packed, static_cast<const float *>(ws), state0, batch, G, steps, probs, probs_stride, state_n, stream);
-    if (encoder_mode() == 1)
+    if (arith == 1)
         return silero_lstm_split_launch(packed, static_cast<const float *>(ws), state0, batch, G, steps, probs, probs_stride, state_n, stream);
     hipLaunchKernelGGL(silero_lstm_kernel, dim3(G), dim3(LSTM_THREADS), LSTM_LDS_FLOATS * sizeof(float),
                        static_cast<hipStream_t>(stream), packed, static_cast<const float *>(ws), state0, batch, G, steps,
@@ -1137,33 +1137,33 @@ static int silero_recur_launch(const float *packed, const void *ws, size_t ws_by
 
 static int silero_run(const float *packed, const float *src, long long n_valid, long long row_stride,
                       long long origin, int batch, int steps, const float *state0, float *probs,
-                      long long probs_stride, float *state_n, void *ws, size_t ws_bytes, void *stream) {
-    int rc = silero_encode_launch(packed, src, 1.0f, n_valid, row_stride, origin, batch, steps, ws, ws_bytes, stream);
+                      long long probs_stride, float *state_n, void *ws, size_t ws_bytes, void *stream, const vadx_silero_cfg *cfg) {
+    int rc = silero_encode_launch(packed, src, 1.0f, n_valid, row_stride, origin, batch, steps, ws, ws_bytes, stream, cfg);
     if (rc != VADX_OK) return rc;
-    return silero_recur_launch(packed, ws, ws_bytes, batch, steps, state0, probs, probs_stride, state_n, stream);
+    return silero_recur_launch(packed, ws, ws_bytes, batch, steps, state0, probs, probs_stride, state_n, stream, cfg);
 }
 
 extern "C" int vadx_silero_encode(const float *packed, const float *audio, int batch, int64_t n_samples,
-                                  int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream) {
+                                  int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg) {
     VADX_REQUIRE(n_samples > 0 && row_stride >= n_samples, "vadx_silero_encode: n_samples=%lld row_stride=%lld",
                  (long long)n_samples, (long long)row_stride);
     const long long steps = (n_samples + 511) / 512;
     VADX_REQUIRE(steps < (1LL << 30), "vadx_silero_encode: clip too long");
-    return silero_encode_launch(packed, audio, 1.0f, n_samples, row_stride, -64, batch, (int)steps, workspace, workspace_bytes, stream);
+    return silero_encode_launch(packed, audio, 1.0f, n_samples, row_stride, -64, batch, (int)steps, workspace, workspace_bytes, stream, cfg);
 }
 
 extern "C" int vadx_silero_encode_pcm16(const float *packed, const int16_t *audio, float scale, int batch, int64_t n_samples,
-                                        int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream) {
+                                        int64_t row_stride, void *workspace, size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg) {
     VADX_REQUIRE(n_samples > 0 && row_stride >= n_samples, "vadx_silero_encode_pcm16: n_samples=%lld row_stride=%lld",
                  (long long)n_samples, (long long)row_stride);
     const long long steps = (n_samples + 511) / 512;
     VADX_REQUIRE(steps < (1LL << 30), "vadx_silero_encode_pcm16: clip too long");
-    return silero_encode_launch(packed, audio, scale, n_samples, row_stride, -64, batch, (int)steps, workspace, workspace_bytes, stream);
+    return silero_encode_launch(packed, audio, scale, n_samples, row_stride, -64, batch, (int)steps, workspace, workspace_bytes, stream, cfg);
 }
 
 extern "C" int vadx_silero_encode_pcm16_part(const float *packed, const int16_t *audio, float scale, int batch, int64_t n_samples,
                                              int64_t row_stride, int first_clip, int total_batch, void *workspace,
-                                             size_t workspace_bytes, void *stream) {
+                                             size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg) {
     VADX_REQUIRE(n_samples > 0 && row_stride >= n_samples, "vadx_silero_encode_pcm16_part: n_samples=%lld row_stride=%lld",
                  (long long)n_samples, (long long)row_stride);
     VADX_REQUIRE(first_clip >= 0 && first_clip % 16 == 0 && first_clip + batch <= total_batch,
@@ -1172,50 +1172,50 @@ extern "C" int vadx_silero_encode_pcm16_part(const float *packed, const int16_t 
     const long long steps = (n_samples + 511) / 512;
     VADX_REQUIRE(steps < (1LL << 30), "vadx_silero_encode_pcm16_part: clip too long");
     return silero_encode_launch(packed, audio, scale, n_samples, row_stride, -64, batch, (int)steps, workspace, workspace_bytes, stream,
-                                first_clip / 16, total_batch);
+                                cfg, first_clip / 16, total_batch);
 }
 
 extern "C" int vadx_silero_recur(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
-                                 int steps, const float *state0, float *probs, float *state_n, void *stream) {
-    return silero_recur_launch(packed, workspace, workspace_bytes, batch, steps, state0, probs, steps, state_n, stream);
+                                 int steps, const float *state0, float *probs, float *state_n, void *stream, const vadx_silero_cfg *cfg) {
+    return silero_recur_launch(packed, workspace, workspace_bytes, batch, steps, state0, probs, steps, state_n, stream, cfg);
 }
 
 extern "C" int vadx_silero_encode_span(const float *packed, const float *audio, int batch, int64_t n_samples,
                                        int64_t row_stride, int first_step, int n_steps, void *workspace,
-                                       size_t workspace_bytes, void *stream) {
+                                       size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg) {
     VADX_REQUIRE(n_samples > 0 && row_stride >= n_samples, "vadx_silero_encode_span: n_samples=%lld row_stride=%lld",
                  (long long)n_samples, (long long)row_stride);
     const long long steps = (n_samples + 511) / 512;
     VADX_REQUIRE(first_step >= 0 && n_steps > 0 && (long long)first_step + n_steps <= steps,
                  "vadx_silero_encode_span: span [%d, %d + %d) outside the clip's %lld windows", first_step, first_step, n_steps, steps);
     return silero_encode_launch(packed, audio, 1.0f, n_samples, row_stride, (long long)first_step * 512 - 64, batch, n_steps,
-                                workspace, workspace_bytes, stream);
+                                workspace, workspace_bytes, stream, cfg);
 }
 
 extern "C" int vadx_silero_recur_span(const float *packed, const void *workspace, size_t workspace_bytes, int batch,
                                       int n_steps, const float *state0, float *probs, int64_t probs_stride,
-                                      float *state_n, void *stream) {
+                                      float *state_n, void *stream, const vadx_silero_cfg *cfg) {
     VADX_REQUIRE(probs_stride >= n_steps, "vadx_silero_recur_span: probs_stride=%lld < n_steps=%d", (long long)probs_stride, n_steps);
-    return silero_recur_launch(packed, workspace, workspace_bytes, batch, n_steps, state0, probs, probs_stride, state_n, stream);
+    return silero_recur_launch(packed, workspace, workspace_bytes, batch, n_steps, state0, probs, probs_stride, state_n, stream, cfg);
 }
 
 extern "C" int vadx_silero_step(const float *packed, const float *input, const float *state, int64_t sr,
                                 int batch, float *out, float *state_n, void *workspace,
-                                size_t workspace_bytes, void *stream) {
+                                size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg) {
     VADX_REQUIRE(sr == 16000, "Supported sampling rates: [16000] (got %lld)", (long long)sr);
     VADX_REQUIRE(state && state_n, "vadx_silero_step: state / state_n must not be NULL");
-    return silero_run(packed, input, 576, 576, 0, batch, 1, state, out, 1, state_n, workspace, workspace_bytes, stream);
+    return silero_run(packed, input, 576, 576, 0, batch, 1, state, out, 1, state_n, workspace, workspace_bytes, stream, cfg);
 }
 
 extern "C" int vadx_silero_clips(const float *packed, const float *audio, int batch, int64_t n_samples,
                                  int64_t row_stride, float *probs, float *state_n, void *workspace,
-                                 size_t workspace_bytes, void *stream) {
+                                 size_t workspace_bytes, void *stream, const vadx_silero_cfg *cfg) {
     VADX_REQUIRE(n_samples > 0 && row_stride >= n_samples, "vadx_silero_clips: n_samples=%lld row_stride=%lld",
                  (long long)n_samples, (long long)row_stride);
     const long long steps = (n_samples + 511) / 512;
     VADX_REQUIRE(steps < (1LL << 30), "vadx_silero_clips: clip too long");
     return silero_run(packed, audio, n_samples, row_stride, -64, batch, (int)steps, nullptr, probs, steps,
-                      state_n, workspace, workspace_bytes, stream);
+                      state_n, workspace, workspace_bytes, stream, cfg);
 }
 
 extern "C" int vadx_silero_segments(const float *probs, int batch, int steps, const int64_t *n_samples,

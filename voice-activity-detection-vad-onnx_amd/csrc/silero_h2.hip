@@ -25,6 +25,30 @@
 #define VADX_EXP 0
 #endif
 #define H2_SKIP(n) ((VADX_EXP >> (n)) & 1)
+// H2_XP: which phases request their first weight fragments BEFORE the barrier that ends the phase in front of them (bit 0 STFT, 1 conv1,
+// 2 conv2, 3 conv4 / W_ih), bit 4: conv2 requests its whole stream (six sets) up front
+#ifndef H2_XP
+#define H2_XP 1
+#endif
+#define H2_XP_ON(n) ((H2_XP >> (n)) & 1)
+// Every phase re-derives its thread indices from a laundered copy of the thread id: nothing computed from them (LDS offsets, fragment
+// pointers of LATER phases) can then be hoisted to the top of the tile loop, where it would sit in registers -- or in scratch -- through
+// every phase in between.
+#define H2_IDS()                                                                                           \
+    int t_ = tid0;                                                                                         \
+    asm volatile("" : "+v"(t_));                                                                           \
+    const int tid = t_, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;                    \
+    (void)tid; (void)lane; (void)wave; (void)q; (void)i
+// how many steps ahead of the MFMAs each phase's fragment stream runs (register sets = steps + 1)
+#ifndef H2_AHS
+#define H2_AHS 2      // STFT
+#endif
+#ifndef H2_AH1
+#define H2_AH1 2      // conv1
+#endif
+#ifndef H2_AHI
+#define H2_AHI 2      // W_ih (two tiles per workgroup)
+#endif
 #define H2_W(addr) (H2_SKIP(13) ? (P + vadx::silero::OFF_H1) : (addr))
 #if (VADX_EXP >> 14) & 1
 __device__ unsigned long long h2_dbg[16];
@@ -40,6 +64,20 @@ extern "C" int vadx_silero_h2_debug_cycles(unsigned long long *out, int reset) {
 #define H2_T0() do {} while (0)
 #define H2_MARK(slot) do {} while (0)
 #define H2_CLK() do {} while (0)
+#endif
+
+// H2_DUMP (debugging): per (tile, stage) an order-independent checksum of the LDS region the stage just produced, into a caller's buffer
+// (vadx_silero_h2_dump): stage 0 operand planes, 1 |X| planes + scratch, 2 conv1 planes, 3 conv2 planes
+#ifndef H2_DUMP
+#define H2_DUMP 0
+#endif
+#if H2_DUMP
+__device__ unsigned *h2_dump_ptr;
+extern "C" int vadx_silero_h2_dump(unsigned *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(h2_dump_ptr), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
+#define H2_SUM(stage, base, bytes) do { unsigned acc_ = 0; for (int o_ = threadIdx.x * 4; o_ < (bytes); o_ += 512 * 4) acc_ += *reinterpret_cast<const unsigned *>(smem + (base) + o_) * (unsigned)(2 * o_ + 1); \
+    atomicAdd(h2_dump_ptr + (size_t)tile_id * 4 + (stage), acc_); } while (0)
+#else
+#define H2_SUM(stage, base, bytes) do {} while (0)
 #endif
 
 namespace vadx {
@@ -58,7 +96,10 @@ constexpr int H2_EO_PL = 8192, H2_EO_KG = 1024;                 // one (class, e
 constexpr int H2_PL128 = 16384, H2_FR128 = 4096;
 constexpr int H2_SCR = 32768;                                   // f32 scratch [512]: nyq at +0, bin-64 partials at +256 floats
 constexpr int H2_EXC2 = 36864, H2_EXC3 = 45056;
-constexpr int H2_R1 = 65536, H2_T2 = 8192, H2_PL2 = 4096, H2_FR2 = 2048;
+#ifndef H2_R1_BASE
+#define H2_R1_BASE 65536      // debugging: 53248 keeps every LDS address below 64 KB (NSUB = 1 only)
+#endif
+constexpr int H2_R1 = H2_R1_BASE, H2_T2 = 8192, H2_PL2 = 4096, H2_FR2 = 2048;
 constexpr int H2_C3 = 0, H2_T3 = 4096, H2_PL3 = 2048;
 constexpr int H2_C4 = 8192, H2_T4 = 8192, H2_PL4 = 4096;
 constexpr int H2_LDS_BYTES = H2_R1 + 2 * H2_T2;
@@ -93,7 +134,13 @@ __device__ __forceinline__ void load_a2(f16x8 (&a)[2], const float *frag2, int l
 }
 
 template <typename SampleT, int NSUB>
-__global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
+#ifndef H2_WAVES_PER_SIMD
+#define H2_WAVES_PER_SIMD 4
+#endif
+#ifndef H2_LDS_PAD
+#define H2_LDS_PAD 0          // debugging: extra dynamic LDS per workgroup (> 0 forces one workgroup per CU)
+#endif
+__global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h2_kernel(
     const float *__restrict__ P, const SampleT *__restrict__ audio, float in_scale, long long n_samples,
     long long row_stride, long long origin, int B, int G, int T, int Gws, int g0, float *__restrict__ gx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -108,12 +155,12 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
         return;
     }
     H2_T0();
+    // Cross-phase fragment prefetch: the first sets of a phase's weight stream are requested BEFORE the barrier that ends the phase in front of
+    // it (global loads stay in flight across s_barrier, which only waits for lgkmcnt), so the L2 round trip that used to open every phase
+    // runs under the previous phase's epilogue.  pre_* = those sets, named per consumer.
 #pragma unroll 1
     for (int sub = 0; sub < NSUB; ++sub) {
     // per tile: nothing derived from the thread index is hoisted out of the tile loop (see silero_split.hip)
-    asm volatile("" : "+v"(tid0));
-    const int tid = tid0, lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, i = lane & 15;
     // the workgroup's tiles: an odd tile count leaves the last workgroup's last slot without work -- it recomputes the last tile (the
     // barriers are workgroup-wide) and stores nothing
     const long long tile_raw = (long long)blockIdx.x * NSUB + sub;
@@ -124,6 +171,7 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
     // clip row (as silero_encode_kernel stages them for the folded pass)
     auto xslot = [](int pp) { return (pp & 1) * X_ODD + (pp >> 1); };
     {
+        H2_IDS();
         const long long base = (long long)t * 512 + origin;
         const bool vec_ok = ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(audio) & (SampleIO<SampleT>::VEC_ALIGN - 1)) == 0) && n_samples >= 4;
         const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -199,6 +247,13 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
             }
         }
     }
+    f16x8 pre_s[H2_AHS][2];           // the STFT's first sets: in flight while the samples go to registers and the operand planes are built
+    if (H2_XP_ON(0)) {
+        H2_IDS();
+        const float *wq = P + OFF_HSF + (size_t)(wave & 3) * (2 * 2 * 2 * 2 * HF);
+#pragma unroll
+        for (int s0_ = 0; s0_ < H2_AHS; ++s0_) load_a2(pre_s[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+    }
     __syncthreads();
     H2_MARK(0);
 
@@ -207,7 +262,9 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
     // o = the difference (sin part), in two classes (E: n = 2 m + 2, O: n = 2 m + 1: the frequency fold); bins k <= 63 of tile tl:
     //   X[k] = E + O, X[128 - k] = +-(E - O), with E / O = the class's partial sums (silero_common.h: stft_fold_class).
     // Input-channel slot s of conv1: s <= 64 = bin s, s = 64 + k = bin 128 - k; bin 128 (Nyquist) goes to the scratch.
+    f16x8 pre_1[2][2], pre_2[2][2];
     {
+        H2_IDS();
         const int tl = wave & 3, fp = wave >> 2;                  // GEMM role: bins 16 tl + 4 q + r (and 128 - them), frames 2 fp, 2 fp + 1, clip i
         f32x4 mk[2], mn[2];
         float b64[2];
@@ -225,18 +282,36 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
             float x0p[2];                                         // the n = 0 sample of the GEMM role's two frames (even class)
 #pragma unroll
             for (int fr = 0; fr < 2; ++fr) x0p[fr] = X[i * X_LDM + 64 * (2 * fp + fr)];
-            const f32x4 c0 = ldg4(P + OFF_S0 + tl * 16 + 4 * q), s0 = ldg4(P + OFF_S0 + 64 + tl * 16 + 4 * q);
             // bin 64's piece of this wave: (class bc, part bp) of the fifth tile for the wave's two frames; the n = 0 tap rides in the
             // even class's accumulator (row 0 = lanes q = 0, element 0)
             const int bc = (wave >> 1) & 1, bp = wave & 1;
-            const float b64n0 = bc ? 0.f : ldg1(P + OFF_B64 + 256 + bp);
+#if H2_DUMP
+            {   // stage 0: the samples this thread holds, weighted by who holds them
+                unsigned acc_ = 0;
+                for (int f = 0; f < 4; ++f) for (int k = 0; k < 4; ++k) acc_ += (__float_as_uint(xa[f][k]) * 3u + __float_as_uint(xb[f][k])) * (unsigned)(2 * (tid * 16 + f * 4 + k) + 1);
+                atomicAdd(h2_dump_ptr + (size_t)tile_id * 4 + 0, acc_);
+            }
+#endif
             __syncthreads();          // every sample is in registers: the operand planes may overwrite X
             H2_MARK(1);
+#if H2_DUMP
+            unsigned accr_ = 0, acce_ = 0;
+#endif
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 f32x4 ev, ov;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { ev[k] = xa[f][k] + xb[f][k]; ov[k] = xa[f][k] - xb[f][k]; }
+                for (int k = 0; k < 4; ++k) {
+                    // (plain v_add_f32 / v_sub_f32, spelled out: left to the compiler the pair sums become v_pk_add_f32 with a CROSS op_sel swizzle
+                    //  -- xb is read in descending order -- and that form returned wrong sums in roughly every second tile once two workgroups
+                    //  (four waves per SIMD) shared a CU, while the same binary was bit-exact at one workgroup per CU: tests/probes/h2_race.py,
+                    //  DESIGN.md section 4e)
+                    float e_, o_;
+                    asm volatile("v_add_f32 %0, %1, %2" : "=v"(e_) : "v"(xa[f][k]), "v"(xb[f][k]));
+                    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(o_) : "v"(xa[f][k]), "v"(xb[f][k]));
+                    ev[k] = e_;
+                    ov[k] = o_;
+                }
                 unsigned char *d = smem + (cls * 4) * H2_EO_PL + (pj >> 1) * H2_EO_KG + (16 * f + pc) * 16 + 8 * (pj & 1);
                 u32x2 p0, p1;
                 split2x4(ev, p0, p1, amax);
@@ -245,10 +320,21 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
                 split2x4(ov, p0, p1, amax);
                 *reinterpret_cast<u32x2 *>(d + 2 * H2_EO_PL) = p0;
                 *reinterpret_cast<u32x2 *>(d + 3 * H2_EO_PL) = p1;
+#if H2_DUMP
+                for (int k = 0; k < 4; ++k) acce_ += (__float_as_uint(ev[k]) * 5u + __float_as_uint(ov[k])) * (unsigned)(2 * (tid * 16 + f * 4 + k) + 1);
+                accr_ += (p0[0] * 3u + p0[1] * 7u + p1[0] * 11u + p1[1] * 13u) * (unsigned)(2 * (tid * 4 + f) + 1);
+#endif
             }
+#if H2_DUMP
+            atomicAdd(h2_dump_ptr + (size_t)tile_id * 4 + 2, acce_);
+            atomicAdd(h2_dump_ptr + (size_t)tile_id * 4 + 3, accr_);
+#endif
             __syncthreads();
             H2_MARK(2);
+            H2_SUM(1, 0, 65536);
             // ---- the wave's GEMM: (class, part) = (E re, E im, O re, O im) x two chunks x its two frames
+            const f32x4 c0 = ldg4(P + OFF_S0 + tl * 16 + 4 * q), s0 = ldg4(P + OFF_S0 + 64 + tl * 16 + 4 * q);
+            const float b64n0 = bc ? 0.f : ldg1(P + OFF_B64 + 256 + bp);
             f32x4 hi[4][2], mid[4][2];
 #pragma unroll
             for (int fr = 0; fr < 2; ++fr) {
@@ -262,26 +348,40 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
             const float *wb = P + OFF_HSF + (size_t)((4 * 2 + bc) * 2 + bp) * (2 * 2 * HF);
             if (!H2_SKIP(4)) {
                 const float *wq = P + OFF_HSF + (size_t)tl * (2 * 2 * 2 * 2 * HF);
-                constexpr int AH = 2;                     // the fragment stream runs two steps ahead on three rotating register sets
+                constexpr int AH = H2_AHS;
                 f16x8 a[AH + 1][2];
 #pragma unroll
-                for (int s0_ = 0; s0_ < AH; ++s0_) load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+                for (int s0_ = 0; s0_ < AH; ++s0_) {
+                    if (H2_XP_ON(0)) { a[s0_][0] = pre_s[s0_][0]; a[s0_][1] = pre_s[s0_][1]; }
+                    else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+                }
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {          // s8 = (class, part, chunk) in OFF_HSF's order
                     if (s8 + AH < 8) load_a2(a[(s8 + AH) % (AH + 1)], H2_W(wq + (s8 + AH) * 2 * HF), lane);
+                    f16x8 b[2][2];
 #pragma unroll
                     for (int fr = 0; fr < 2; ++fr) {
-                        f16x8 b[2];
                         const unsigned char *bs = smem + ((s8 >> 1) * 2) * H2_EO_PL + (4 * (s8 & 1) + q) * H2_EO_KG + (16 * (2 * fp + fr) + i) * 16;
-                        b[0] = *reinterpret_cast<const f16x8 *>(bs);
-                        b[1] = *reinterpret_cast<const f16x8 *>(bs + H2_EO_PL);
-                        mfma_split3(a[s8 % (AH + 1)], b, hi[s8 >> 1][fr], mid[s8 >> 1][fr]);
+                        b[fr][0] = *reinterpret_cast<const f16x8 *>(bs);
+                        b[fr][1] = *reinterpret_cast<const f16x8 *>(bs + H2_EO_PL);
                     }
+                    const f16x8 (&ac)[2] = a[s8 % (AH + 1)];      // the two frames alternate so that consecutive MFMAs hit different accumulators
+#pragma unroll
+                    for (int fr = 0; fr < 2; ++fr) mid[s8 >> 1][fr] = mfma_f16(ac[1], b[fr][0], mid[s8 >> 1][fr]);
+#pragma unroll
+                    for (int fr = 0; fr < 2; ++fr) mid[s8 >> 1][fr] = mfma_f16(ac[0], b[fr][1], mid[s8 >> 1][fr]);
+#pragma unroll
+                    for (int fr = 0; fr < 2; ++fr) hi[s8 >> 1][fr] = mfma_f16(ac[0], b[fr][0], hi[s8 >> 1][fr]);
                 }
             }
             f16x8 ab[2][2];                               // the bin-64 piece's two chunks: requested before the magnitudes, used after them
             load_a2(ab[0], H2_W(wb), lane);
             load_a2(ab[1], H2_W(wb + 2 * HF), lane);
+            if (H2_XP_ON(1)) {   // conv1's first two sets
+                const float *w1 = P + OFF_H1 + wave * (4 * 3 * 2 * HF);
+                load_a2(pre_1[0], H2_W(w1), lane);
+                load_a2(pre_1[1], H2_W(w1 + 2 * HF), lane);
+            }
 #pragma unroll
             for (int fr = 0; fr < 2; ++fr) {
                 const f32x4 ere = join2(hi[0][fr], mid[0][fr]), eim = join2(hi[1][fr], mid[1][fr]);
@@ -309,15 +409,18 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
         }
         __syncthreads();          // every wave is done reading the operand planes: the |X| planes may overwrite them
         H2_MARK(3);
-        const int g = 4 * tl + q;
+        {
+            H2_IDS();             // (fresh indices: the store offsets below must not be computed -- and parked -- in front of the GEMM)
+            const int g = 4 * (wave & 3) + q;
 #pragma unroll
-        for (int fr = 0; fr < 2; ++fr) {
-            const int f = 2 * fp + fr;
-            unsigned char *frp = smem + f * H2_FR128;
-            store_h4(frp, H2_PL128, g, i, mk[fr], amax);                      // slots 4 g + r        = bins 4 g + r
-            store_h4(frp, H2_PL128, 16 + g, i, mn[fr], amax);                 // slots 64 + 4 g + r   = bins 128 - (4 g + r); g = 0, r = 0 is bin 128:
-            if (g == 0) nyq[f * 16 + i] = mn[fr][0];                          //   it goes to the scratch, and slot 64 is rewritten below with bin 64
-            if (q == 0) b64p[(wave * 2 + fr) * 16 + i] = b64[fr];
+            for (int fr = 0; fr < 2; ++fr) {
+                const int f = 2 * (wave >> 2) + fr;
+                unsigned char *frp = smem + f * H2_FR128;
+                store_h4(frp, H2_PL128, g, i, mk[fr], amax);                  // slots 4 g + r        = bins 4 g + r
+                store_h4(frp, H2_PL128, 16 + g, i, mn[fr], amax);             // slots 64 + 4 g + r   = bins 128 - (4 g + r); g = 0, r = 0 is bin 128:
+                if (g == 0) nyq[f * 16 + i] = mn[fr][0];                      //   it goes to the scratch, and slot 64 is rewritten below with bin 64
+                if (q == 0) b64p[(wave * 2 + fr) * 16 + i] = b64[fr];
+            }
         }
         __syncthreads();
         if (tid < 64) {                                                       // bin 64: frame tid / 16, clip tid % 16
@@ -332,6 +435,7 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
 
     // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU -- direct: out[f] = sum_tap W[tap] in[f + tap - 1], wave = 16 output channels
     {
+        H2_IDS();
         const int rt = wave;
         f32x4 hi[4], mid[4];
         {   // bias + input channel 128 (the Nyquist bin) on the VALU
@@ -355,10 +459,13 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
             }
         }
         const float *wq = P + OFF_H1 + rt * (4 * 3 * 2 * HF);
-        constexpr int AH = 2;
+        constexpr int AH = H2_AH1;
         f16x8 a[AH + 1][2];
 #pragma unroll
-        for (int s0_ = 0; s0_ < AH; ++s0_) load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+        for (int s0_ = 0; s0_ < AH; ++s0_) {
+            if (H2_XP_ON(1)) { a[s0_][0] = pre_1[s0_][0]; a[s0_][1] = pre_1[s0_][1]; }
+            else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+        }
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             f16x8 b[4][2];
@@ -379,6 +486,11 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
 #undef H2_TERM
             }
         }
+        if (H2_XP_ON(2)) {   // conv2's first two sets
+            const float *w2 = P + OFF_H2 + ((wave & 3) * 4 + 2 * (wave >> 2)) * (3 * 2 * HF);
+            load_a2(pre_2[0], H2_W(w2), lane);
+            load_a2(pre_2[1], H2_W(w2 + 2 * HF), lane);
+        }
         __syncthreads();          // every wave is done reading the |X| planes: conv1's output may now overwrite them
         H2_MARK(5);
 #pragma unroll
@@ -395,14 +507,23 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
 
     // ---------------- phase 3: conv2 128->64, k3 s2 p1, ReLU: out frame o reads in frames 2 o - 1 .. 2 o + 1; wave = (16 channels, half of K)
     {
+        H2_IDS();
         const int rt = wave & 3, kh = wave >> 2;
         f32x4 hi[2], mid[2];
 #pragma unroll
         for (int o = 0; o < 2; ++o) { hi[o] = f32x4{0.f, 0.f, 0.f, 0.f}; mid[o] = hi[o]; }
         const float *wq = P + OFF_H2 + (rt * 4 + 2 * kh) * (3 * 2 * HF);
-        f16x8 a[3][2];
-        load_a2(a[0], H2_W(wq), lane);
-        load_a2(a[1], H2_W(wq + 2 * HF), lane);
+        constexpr int RING = H2_XP_ON(4) ? 6 : 3;      // the wave's whole stream (six sets) up front, or two steps ahead on three register sets
+        f16x8 a[RING][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (H2_XP_ON(2)) { a[s][0] = pre_2[s][0]; a[s][1] = pre_2[s][1]; }
+            else load_a2(a[s], H2_W(wq + s * 2 * HF), lane);
+        }
+        if (RING == 6) {
+#pragma unroll
+            for (int s = 2; s < 6; ++s) load_a2(a[s % RING], H2_W(wq + s * 2 * HF), lane);
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f16x8 b[4][2];
@@ -411,8 +532,8 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const int s = kk * 3 + tap;
-                if (s + 2 < 6) load_a2(a[(s + 2) % 3], H2_W(wq + (s + 2) * 2 * HF), lane);
-                const f16x8 (&ac)[2] = a[s % 3];
+                if (RING == 3 && s + 2 < 6) load_a2(a[(s + 2) % RING], H2_W(wq + (s + 2) * 2 * HF), lane);
+                const f16x8 (&ac)[2] = a[s % RING];
 #define H2_TERM(AP, BP, ACC)                                                                  \
     _Pragma("unroll") for (int o = 0; o < 2; ++o) {                                           \
         const int fi = 2 * o + tap - 1;                                                       \
@@ -445,19 +566,27 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
     H2_MARK(7);
     }      // sub
 
-    asm volatile("" : "+v"(tid0));
-    const int tid = tid0, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
-    (void)tid;
+    constexpr int AHEAD = NSUB > 1 ? H2_AHI : 3;      // W_ih's stream runs this many steps ahead
+    f16x8 pre_3[2][2], pre_4[2][2], pre_ih[AHEAD][2];
+    {   H2_IDS();
+        // conv3's two sets (not requested inside the tile loop: a value that only the last iteration defines would be carried, and spilled, around it)
+        const float *w3 = P + OFF_H3 + ((wave & 3) * 2 + (wave >> 2)) * (2 * 2 * HF);
+        load_a2(pre_3[0], H2_W(w3), lane);
+        load_a2(pre_3[1], H2_W(w3 + 2 * HF), lane);
+    }
     // ---------------- phase 4: conv3 64->64, k3 s2 p1, ReLU (one output frame; tap 0 reads padding), both tiles: wave = (16 channels, tap 1 | 2)
     {
+        H2_IDS();
         const int rt = wave & 3, th = wave >> 2;      // tap th + 1 reads conv2's frame th
         f32x4 hi[NSUB], mid[NSUB];
 #pragma unroll
         for (int sb = 0; sb < NSUB; ++sb) { hi[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; mid[sb] = hi[sb]; }
-        const float *wq = P + OFF_H3 + (rt * 2 + th) * (2 * 2 * HF);
-        f16x8 a[2][2];
-        load_a2(a[0], H2_W(wq), lane);
-        load_a2(a[1], H2_W(wq + 2 * HF), lane);
+        if (H2_XP_ON(3)) {   // conv4's two sets
+            const float *w4 = P + OFF_H4 + wave * (2 * 2 * HF);
+            load_a2(pre_4[0], H2_W(w4), lane);
+            load_a2(pre_4[1], H2_W(w4 + 2 * HF), lane);
+        }
+        const f16x8 (&a)[2][2] = pre_3;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
@@ -489,15 +618,23 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
 
     // ---------------- phase 5: conv4 64->128, k3 s1 p1, ReLU (one frame in / out: centre tap only), both tiles
     {
+        H2_IDS();
         const int rt = wave;
         const f32x4 bias = ldg4(P + OFF_B4 + 16 * rt + 4 * q);
         f32x4 hi[NSUB], mid[NSUB];
 #pragma unroll
         for (int sb = 0; sb < NSUB; ++sb) { hi[sb] = bias; mid[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        const float *wq = P + OFF_H4 + rt * (2 * 2 * HF);
-        f16x8 a[2][2];
-        load_a2(a[0], H2_W(wq), lane);
-        load_a2(a[1], H2_W(wq + 2 * HF), lane);
+        if (H2_XP_ON(3)) {   // W_ih's first sets
+            const float *wi = P + OFF_HIH + wave * (4 * 4 * 2 * HF);
+#pragma unroll
+            for (int s0_ = 0; s0_ < AHEAD; ++s0_) load_a2(pre_ih[s0_], H2_W(wi + s0_ * 2 * HF), lane);
+        }
+        if (!H2_XP_ON(3)) {
+            const float *w4 = P + OFF_H4 + wave * (2 * 2 * HF);
+            load_a2(pre_4[0], H2_W(w4), lane);
+            load_a2(pre_4[1], H2_W(w4 + 2 * HF), lane);
+        }
+        const f16x8 (&a)[2][2] = pre_4;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
@@ -521,6 +658,7 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
     // ---------------- phase 6: LSTM input projection for the workgroup's tiles at once, gate-major (D rows = hidden units
     // 16 wave + 4 q + r, columns = clips): every W_ih fragment is loaded once and multiplies NSUB column tiles
     {
+        H2_IDS();
         f32x4 hi[NSUB][4], mid[NSUB][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -529,10 +667,12 @@ __global__ __launch_bounds__(H2_THREADS, 4) void silero_encode_h2_kernel(
             for (int sb = 0; sb < NSUB; ++sb) { hi[sb][g] = bg; mid[sb][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
         const float *wq = P + OFF_HIH + wave * (4 * 4 * 2 * HF);
-        constexpr int AHEAD = NSUB > 1 ? 2 : 3;
         f16x8 a[AHEAD + 1][2];
 #pragma unroll
-        for (int s0_ = 0; s0_ < AHEAD; ++s0_) load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+        for (int s0_ = 0; s0_ < AHEAD; ++s0_) {
+            if (H2_XP_ON(3)) { a[s0_][0] = pre_ih[s0_][0]; a[s0_][1] = pre_ih[s0_][1]; }
+            else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+        }
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             f16x8 b[NSUB][2];
@@ -692,9 +832,10 @@ template <typename S>
 int silero_encode_h2_launch(const float *packed, const S *src, float in_scale, long long n_valid, long long row_stride,
                             long long origin, int batch, int G, int steps, int Gws, int first_group, float *gx, void *stream) {
     constexpr int NS = VADX_H2_NSUB;
-    VADX_DYN_LDS((silero_encode_h2_kernel<S, NS>), H2_LDS_BYTES);
+    constexpr int LDS = (H2_R1 + NS * H2_T2 > 65536 ? H2_R1 + NS * H2_T2 : 65536) + H2_LDS_PAD;
+    VADX_DYN_LDS((silero_encode_h2_kernel<S, NS>), LDS);
     const long long nblk = ((long long)G * steps + NS - 1) / NS;
-    hipLaunchKernelGGL((silero_encode_h2_kernel<S, NS>), dim3((unsigned)nblk), dim3(H2_THREADS), H2_LDS_BYTES, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL((silero_encode_h2_kernel<S, NS>), dim3((unsigned)nblk), dim3(H2_THREADS), LDS, static_cast<hipStream_t>(stream),
                        packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps, Gws, first_group, gx);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;

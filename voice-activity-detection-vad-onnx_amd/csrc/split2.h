@@ -64,7 +64,11 @@ __device__ __forceinline__ f16x8 ldh(const float *frag, int lane) { return *((gl
 
 // four float32 values (consecutive k of one column) -> their two planes, four fp16 (8 bytes) each: v_cvt_pk_f16_f32 (RN) x 2,
 // v_cvt_f32_f16 x 4, v_pk_add_f32 x 2, v_pk_mul_f32 x 2, v_cvt_pk_f16_f32 x 2 = 3 VALU per value.  `amax` is the running max |x|.
+// (fp contraction is OFF inside the split: with it the compiler folds the multiply that PRODUCED x into the residual -- x - h0 becomes
+//  fma(a, b, -h0) on the unrounded product -- and the planes then encode a value that is not the float32 x the caller also keeps, e.g. the
+//  LSTM state a later launch resumes from: tests/test_gpu_silero.py::test_spanned_schedule_is_bitwise_identical caught one-ulp differences.)
 __device__ __forceinline__ void split2x4(const f32x4 x, u32x2 &p0, u32x2 &p1, float &amax) {
+#pragma clang fp contract(off)
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
     const f32x2_ xa = {x[0], x[1]}, xb = {x[2], x[3]};
     const f16x2 a = __builtin_convertvector(xa, f16x2), b = __builtin_convertvector(xb, f16x2);
@@ -77,6 +81,7 @@ __device__ __forceinline__ void split2x4(const f32x4 x, u32x2 &p0, u32x2 &p1, fl
 }
 // one float32 value -> its two fp16 terms
 __device__ __forceinline__ void split2x1(float x, unsigned short &h0, unsigned short &h1, float &amax) {
+#pragma clang fp contract(off)
     const _Float16 a = (_Float16)x;
     const _Float16 b = (_Float16)((x - (float)a) * H1_SCALE);
     h0 = __builtin_bit_cast(unsigned short, a);

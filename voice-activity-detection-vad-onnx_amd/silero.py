@@ -11,6 +11,7 @@ plumbing: tensors in, C-ABI call, tensors out.  No CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import warnings
 
 import numpy as np
@@ -37,17 +38,27 @@ def _as_weight_dict(path_or_weights):
 WORKSPACE_CAP_BYTES = 8 << 30     # clips(): above this the gate-preactivation workspace is reused span by span
 
 
-ENCODER_MODES = {"f32": 0, "split": 1, "h2": 2}
+ENCODER_MODES = {"f32": _lib.ARITH["f32"], "split": _lib.ARITH["split"], "h2": _lib.ARITH["h2"]}      # name -> VADX_ARITH_*
+_default_mode = [None]
 
 
 def encoder_mode(mode=None):
-    """Which encoder kernel the launches use, process-wide (include/vadx.h: vadx_silero_encoder_mode): "f32" = exact-f32 MFMAs,
-    "split" = bf16 x 3 split products (float32-class accuracy at 6/16 of the matrix time).  Returns the mode that was active;
-    `None` only queries.  The initial mode comes from VADX_SILERO_ENCODER."""
-    names = {v: k for k, v in ENCODER_MODES.items()}
-    if mode is not None and mode not in ENCODER_MODES:
-        raise ValueError(f"encoder mode must be one of {sorted(ENCODER_MODES)}, got {mode!r}")
-    return names[_lib.lib().vadx_silero_encoder_mode(-1 if mode is None else ENCODER_MODES[mode])]
+    """The kernel set engines use unless told otherwise per engine (`SileroEngine.arithmetic`): "f32" = exact-f32 MFMAs, "split" =
+    bf16 x 3 exact-split products, "h2" = fp16 x 2 split products (float32-class accuracy at 3/16 of the matrix time; activations
+    outside the fp16 range are detected and the batch recomputed on "split").  A Python-side default only -- the C ABI takes the
+    arithmetic with every call (include/vadx.h: vadx_silero_cfg).  Returns the mode that was active; `None` only queries.  The initial
+    value comes from VADX_SILERO_ENCODER, read once here."""
+    if _default_mode[0] is None:
+        e = os.environ.get("VADX_SILERO_ENCODER", "").strip().lower()
+        _default_mode[0] = {"0": "f32", "1": "split", "2": "h2", "bf16x3": "split", "f16x2": "h2"}.get(e, e) if e else "h2"
+        if _default_mode[0] not in ENCODER_MODES:
+            raise ValueError(f"VADX_SILERO_ENCODER must be one of {sorted(ENCODER_MODES)}, got {e!r}")
+    prev = _default_mode[0]
+    if mode is not None:
+        if mode not in ENCODER_MODES:
+            raise ValueError(f"encoder mode must be one of {sorted(ENCODER_MODES)}, got {mode!r}")
+        _default_mode[0] = mode
+    return prev
 
 
 class SileroEngine:
@@ -77,6 +88,40 @@ class SileroEngine:
         _lib.check(L.vadx_silero_pack_host(C.byref(hw), packed.ctypes.data_as(C.c_void_p)))
         self.packed = torch.from_numpy(packed).to(self.device)
         self._ws = None
+        self.arithmetic = None            # None = the module default (encoder_mode()); or "f32" | "split" | "h2" for this engine
+        self.h2_ok = bool(packed[L.vadx_silero_packed_floats() - 4] != 0.0)      # the blob's fp16 x 2 section is usable (pack-time check)
+        self.range_fallbacks = 0          # batches recomputed on bf16 x 3 because an activation left the fp16 range
+
+    # -- arithmetic selection + the fp16 x 2 range protocol
+    def mode(self):
+        m = self.arithmetic or encoder_mode()
+        return "split" if (m == "h2" and not self.h2_ok) else m
+
+    def cfg(self, mode=None):
+        """ctypes pointer to a vadx_silero_cfg for `mode` (default: this engine's current mode)"""
+        c = _lib.SileroCfg()
+        c.arithmetic = ENCODER_MODES[mode or self.mode()]
+        return C.byref(c)
+
+    def range_flag(self, reset=True):
+        """(flag, largest |activation|) of the fp16 x 2 kernels since the last reset; synchronises the stream (vadx_silero_range_flag)"""
+        flag, amax = C.c_uint32(0), C.c_float(0.0)
+        with self.torch.cuda.device(self.device):
+            _lib.check(_lib.lib().vadx_silero_range_flag(self.packed.data_ptr(), 1 if reset else 0, C.byref(flag), C.byref(amax),
+                                                         _lib.stream_ptr()))
+        return int(flag.value), float(amax.value)
+
+    def _guarded(self, run):
+        """run(mode) -> result.  On "h2" the result stands only if no activation left the fp16 range; otherwise the batch is recomputed on
+        "split" (bf16 terms have float32's range).  One 8-byte read-back + stream synchronisation per guarded call."""
+        m = self.mode()
+        out = run(m)
+        if m == "h2":
+            flag, amax = self.range_flag()
+            if flag:
+                self.range_fallbacks += 1
+                out = run("split")
+        return out
 
     def _check_workspace_cap(self, batch, steps, who):
         """The whole-batch gx workspace is 32 KB per 16-clip group and window; `clips` falls back to spans above WORKSPACE_CAP_BYTES,
@@ -114,11 +159,14 @@ class SileroEngine:
         out = t.empty((B, 1), dtype=t.float32, device=self.device)
         state_n = t.empty_like(state)
         ws = self._workspace(B, 1)
-        with t.cuda.device(self.device):
-            _lib.check(_lib.lib().vadx_silero_step(self.packed.data_ptr(), x.data_ptr(), state.data_ptr(), 16000, B,
-                                                   out.data_ptr(), state_n.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                   _lib.stream_ptr()))
-        return out, state_n
+
+        def run(mode):
+            with t.cuda.device(self.device):
+                _lib.check(_lib.lib().vadx_silero_step(self.packed.data_ptr(), x.data_ptr(), state.data_ptr(), 16000, B,
+                                                       out.data_ptr(), state_n.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                       _lib.stream_ptr(), self.cfg(mode)))
+            return out, state_n
+        return self._guarded(run)
 
     def clips(self, audio, n_samples=None, return_state=False):
         """audio f32 [B,N] (+-1 scale) -> probs [B, ceil(n/512)] on device (zero state/context at t=0)."""
@@ -139,11 +187,14 @@ class SileroEngine:
             state_n = self.clips_spanned(audio, n, probs, state_n)
             return (probs, state_n) if return_state else probs
         ws = self._workspace(B, steps)
-        with t.cuda.device(self.device):
-            _lib.check(_lib.lib().vadx_silero_clips(self.packed.data_ptr(), audio.data_ptr(), B, n, _lib.row_stride(audio),
-                                                    probs.data_ptr(), None if state_n is None else state_n.data_ptr(),
-                                                    ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
-        return (probs, state_n) if return_state else probs
+
+        def run(mode):
+            with t.cuda.device(self.device):
+                _lib.check(_lib.lib().vadx_silero_clips(self.packed.data_ptr(), audio.data_ptr(), B, n, _lib.row_stride(audio),
+                                                        probs.data_ptr(), None if state_n is None else state_n.data_ptr(),
+                                                        ws.data_ptr(), ws.numel(), _lib.stream_ptr(), self.cfg(mode)))
+            return (probs, state_n) if return_state else probs
+        return self._guarded(run)
 
     def clips_spanned(self, audio, n, probs, state=None, span=None):
         """`clips` for recordings whose whole-clip workspace (32 KB per 16-clip group and window) would not fit: the
@@ -160,19 +211,23 @@ class SileroEngine:
         if state is None:
             state = t.empty((2, B, HIDDEN), dtype=t.float32, device=self.device)
         ws = self._workspace(B, min(span, steps))
-        with t.cuda.device(self.device):
-            st = _lib.stream_ptr()
-            for first in range(0, steps, span):
-                ns = min(span, steps - first)
-                _lib.check(L.vadx_silero_encode_span(self.packed.data_ptr(), audio.data_ptr(), B, int(n), _lib.row_stride(audio),
-                                                     first, ns, ws.data_ptr(), ns * tile_bytes, st))
-                _lib.check(L.vadx_silero_recur_span(self.packed.data_ptr(), ws.data_ptr(), ns * tile_bytes, B, ns,
-                                                    None if first == 0 else state.data_ptr(), probs.data_ptr() + 4 * first,
-                                                    steps, state.data_ptr(), st))
-        return state
 
-    def encode(self, audio, n_samples=None):
-        """First half of `clips` as its own launch (fills the workspace); returns (batch, steps)."""
+        def run(mode):
+            with t.cuda.device(self.device):
+                st = _lib.stream_ptr()
+                for first in range(0, steps, span):
+                    ns = min(span, steps - first)
+                    _lib.check(L.vadx_silero_encode_span(self.packed.data_ptr(), audio.data_ptr(), B, int(n), _lib.row_stride(audio),
+                                                         first, ns, ws.data_ptr(), ns * tile_bytes, st, self.cfg(mode)))
+                    _lib.check(L.vadx_silero_recur_span(self.packed.data_ptr(), ws.data_ptr(), ns * tile_bytes, B, ns,
+                                                        None if first == 0 else state.data_ptr(), probs.data_ptr() + 4 * first,
+                                                        steps, state.data_ptr(), st, self.cfg(mode)))
+            return state
+        return self._guarded(run)
+
+    def encode(self, audio, n_samples=None, mode=None):
+        """First half of `clips` as its own launch (fills the workspace); returns (batch, steps).  (The separate halves do not run the
+        fp16 x 2 range protocol themselves: pair them through `clips*`, or call `range_flag()` before trusting an "h2" result.)"""
         t = self.torch
         B, N = audio.shape
         n = int(N if n_samples is None else n_samples)
@@ -180,12 +235,12 @@ class SileroEngine:
         ws = self._workspace(B, steps)
         with t.cuda.device(self.device):
             _lib.check(_lib.lib().vadx_silero_encode(self.packed.data_ptr(), audio.data_ptr(), B, n, _lib.row_stride(audio),
-                                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+                                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr(), self.cfg(mode)))
         return B, steps
 
     PCM16_SCALE = 0.000030517578       # Silero/Inference_Silero_VAD_ONNX.py:83: float32 = int16 * this
 
-    def encode_pcm16(self, pcm, n_samples=None, scale=PCM16_SCALE):
+    def encode_pcm16(self, pcm, n_samples=None, scale=PCM16_SCALE, mode=None):
         """`encode` fed the int16 samples themselves (device tensor [B,N]): the kernel applies the reference's
         int16 -> float32 scaling while staging, bit-identical to encoding `pcm.float() * float32(scale)`."""
         t = self.torch
@@ -198,13 +253,16 @@ class SileroEngine:
         ws = self._workspace(B, steps)
         with t.cuda.device(self.device):
             _lib.check(_lib.lib().vadx_silero_encode_pcm16(self.packed.data_ptr(), pcm.data_ptr(), float(scale), B, n,
-                                                           _lib.row_stride(pcm), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+                                                           _lib.row_stride(pcm), ws.data_ptr(), ws.numel(), _lib.stream_ptr(),
+                                                           self.cfg(mode)))
         return B, steps
 
     def clips_pcm16(self, pcm, n_samples=None, scale=PCM16_SCALE):
         """int16 PCM [B,N] on the device -> probs [B, ceil(n/512)] (encode_pcm16 + recur)."""
-        B, steps = self.encode_pcm16(pcm, n_samples, scale)
-        return self.recur(B, steps, self.torch.empty((B, steps), dtype=self.torch.float32, device=self.device))
+        def run(mode):
+            B, steps = self.encode_pcm16(pcm, n_samples, scale, mode=mode)
+            return self.recur(B, steps, self.torch.empty((B, steps), dtype=self.torch.float32, device=self.device), mode=mode)
+        return self._guarded(run)
 
     def host_feed(self, batch, n_samples, chunk_clips=512):
         """A reusable upload pipeline for `batch` clips of `n_samples` int16 samples held in HOST memory (the host link,
@@ -224,16 +282,18 @@ class SileroEngine:
             feed = HostFeed(self, B, N, chunk_clips)
         elif (feed.B, feed.N) != (B, N) or feed.eng is not self:
             raise ValueError("clips_from_host: the feed was built for another engine or batch shape")
-        feed.encode(host)
-        return self.recur(B, feed.T, t.empty((B, feed.T), dtype=t.float32, device=self.device))
+        def run(mode):
+            feed.encode(host, mode=mode)
+            return self.recur(B, feed.T, t.empty((B, feed.T), dtype=t.float32, device=self.device), mode=mode)
+        return self._guarded(run)
 
-    def recur(self, batch, steps, probs):
+    def recur(self, batch, steps, probs, mode=None):
         """Second half of `clips`: workspace -> probs [B,steps] (zero initial state)."""
         t = self.torch
         ws = self._workspace(batch, steps)
         with t.cuda.device(self.device):
             _lib.check(_lib.lib().vadx_silero_recur(self.packed.data_ptr(), ws.data_ptr(), ws.numel(), batch, steps,
-                                                    None, probs.data_ptr(), None, _lib.stream_ptr()))
+                                                    None, probs.data_ptr(), None, _lib.stream_ptr(), self.cfg(mode)))
         return probs
 
     def segments(self, probs, n_samples, cap=64, **kw):
@@ -278,7 +338,7 @@ class HostFeed:
         self.free = [t.cuda.Event() for _ in range(2)]
         self.in_use = [False, False]
 
-    def encode(self, host_pcm):
+    def encode(self, host_pcm, mode=None):
         """Upload + encode every chunk of host_pcm [B,N] (int16 CPU tensor); afterwards the engine's workspace holds the batch
         (call `engine.recur(B, T, probs)` next, on the same stream)."""
         eng, t = self.eng, self.eng.torch
@@ -299,7 +359,7 @@ class HostFeed:
                     self.ready[k].record(self.copy_stream)
                 comp.wait_event(self.ready[k])
                 _lib.check(L.vadx_silero_encode_pcm16_part(eng.packed.data_ptr(), self.buf[k].data_ptr(), eng.PCM16_SCALE, nb, self.N,
-                                                           self.N, b0, self.B, ws.data_ptr(), ws.numel(), st))
+                                                           self.N, b0, self.B, ws.data_ptr(), ws.numel(), st, eng.cfg(mode)))
                 self.free[k].record(comp)
                 self.in_use[k] = True
         return self.B, self.T
