@@ -51,12 +51,6 @@ extern "C" {
 #define VADX_ARITH_BF16X3 2
 #define VADX_ARITH_F16X2  3
 
-/* Arithmetic of the FSMN / FireRed dense layers, process-wide: 0 = exact-f32 MFMAs, 1 = bf16 x 3 split products (float32 operands
- * split exactly into three bf16 terms, six bf16 MFMAs per K = 32 step: float32-class accuracy at 6/16 of the matrix time, csrc/split3.h).
- * Any other `mode` only queries.  Returns the previous mode; the initial one comes from VADX_GEMM ("f32" | "split").  (Silero has its own
- * switch, vadx_silero_encoder_mode.) */
-int         vadx_gemm_mode(int mode);
-
 int         vadx_abi_version(void);      /* == VADX_ABI_VERSION of the header the library was built from */
 const char *vadx_last_error(void);
 
@@ -257,6 +251,9 @@ typedef struct vadx_fsmn_dims {          /* FunASR FSMN(input 400, proj 128, lor
     int   input_affine_dim, linear_dim, output_affine_dim, output_dim;   /* external config: 140/250/140/248 */
     int   frames;                         /* T = window_len // 160 + 1 (101) */
     float speech_2_noise_ratio;           /* FSMN/Export_FSMN_VAD.py:34,87-92 */
+    int   arithmetic;                     /* VADX_ARITH_* of the dense layers (0 = AUTO = F16X2).  The packed blob carries the weight fragments of
+                                           * THIS arithmetic only: pass the same dims to vadx_fsmn_pack_host and to every launch.  pack_host
+                                           * refuses F16X2 when a weight lies outside the fp16 range (pack BF16X3 then). */
 } vadx_fsmn_dims;
 
 typedef struct vadx_fsmn_weights_host {  /* torch layouts: Linear weight [out][in]; conv_left [128][20] */
@@ -267,6 +264,9 @@ typedef struct vadx_fsmn_weights_host {  /* torch layouts: Linear weight [out][i
 } vadx_fsmn_weights_host;
 
 size_t vadx_fsmn_packed_floats(const vadx_fsmn_dims *dims);
+/* The F16X2 kernels' sticky range flag, as vadx_silero_range_flag: flag != 0 = an activation of some launch since the last reset left the
+ * fp16 range and that launch's results must be recomputed with a BF16X3 blob.  Synchronises `stream`. */
+int vadx_fsmn_range_flag(const vadx_fsmn_dims *dims, const float *packed, int reset, uint32_t *flag_host, float *amax_host, void *stream);
 int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_weights_host *w, float *packed_host);
 
 /* Per-frame energy term of the score gate: log10(sum_512 (y/(sqrt(L)*2e-5))^2 + 2e-5) of the prepped
@@ -309,6 +309,8 @@ int vadx_fsmn_clips(const vadx_fsmn_dims *dims, const float *packed, const float
 typedef struct vadx_firered_cfg {        /* checkpoint `args` (FireRedVAD/Export_FireRedVAD.py:336-337) */
     int idim, R, M, H, P, N1, S1, N2, S2, odim;
     int frames;                           /* frames per window: (L-400)//160+1 = 98 */
+    int arithmetic;                       /* VADX_ARITH_* of the point-wise layer pairs (0 = AUTO = F16X2 where H = 256, P = 128; float32 MFMAs
+                                           * elsewhere).  As vadx_fsmn_dims.arithmetic: the blob carries the fragments of this arithmetic only. */
 } vadx_firered_cfg;
 
 typedef struct vadx_firered_weights_host {   /* torch layouts, 1x1 convs as [out][in] */
@@ -320,6 +322,8 @@ typedef struct vadx_firered_weights_host {   /* torch layouts, 1x1 convs as [out
 } vadx_firered_weights_host;
 
 size_t vadx_firered_packed_floats(const vadx_firered_cfg *cfg);
+/* The F16X2 kernel's sticky range flag, as vadx_silero_range_flag. */
+int vadx_firered_range_flag(const vadx_firered_cfg *cfg, const float *packed, int reset, uint32_t *flag_host, float *amax_host, void *stream);
 int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_firered_weights_host *w, float *packed_host);
 /* logmel f32 [windows][frames][80] (vadx_frontend_logmel, 'firered' geometry) -> probs f32 [windows][odim][frames].
  * Replaces ort_session_A.run([probs], {audio}), FireRedVAD/Inference_FireRed_ONNX.py:567-572
@@ -439,10 +443,11 @@ int vadx_dfsmn_pw_conv(int mode, const vadx_ft_view *a, const vadx_ft_view *b, c
  * part (optional, forward only): partial statistics of out. */
 int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_ft_view *lo, const vadx_ft_ln *ln,
                      const float *tbl, const vadx_ft_view *out, int C, int tiles, float *part, void *stream);
-/* bi-LSTM (hidden 20) along F with the tile's 16 frames as the batch; in->c = 4 or 40; out 40 ch. */
+/* bi-LSTM (hidden 20) along F with the tile's 16 frames as the batch; in->c = 4 or 40; out 40 ch.  arithmetic: VADX_ARITH_* of the
+ * 40-channel (CepsUnit) form -- AUTO = BF16X3, F32 = the float32-MFMA kernel; F16X2 is not built for this kernel and is refused. */
 int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2],
                       const float *const w_hh[2], const float *const b_ih[2], const float *const b_hh[2],
-                      const vadx_ft_view *out, int F, int tiles, void *stream);
+                      const vadx_ft_view *out, int F, int tiles, void *stream, int arithmetic);
 
 /* One gated conv block (CFB :76-93 with its CepsUnit :96-154) as two streaming launches around vadx_dfsmn_lstm_f
  * (csrc/dfsmn_cfb.hip): the block's 20-channel intermediates gx, r, lo, ceps never reach memory.
@@ -464,12 +469,15 @@ int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float 
  *           (zero for bin 0 and bins > 80); out_fix [20][10][64]: q = 0 -> conv31(ln1_w)[c][16 m + i], q = 1 -> conv31(ln1_b) + bias. */
 typedef struct vadx_dfsmn_cfb_weights {
     const float *ln0_w, *gate_w, *in_w, *in_b, *front_tab, *conv_w, *fwd_tbl, *fwd_fix, *lin_w, *lin_b, *inv_tbl, *out_fix;
-    /* ABI 5: the two DFT tables as bf16 x 3 split A fragments (csrc/split3.h) for the split-product kernels (vadx_gemm_mode 1), or NULL
-     * (the f32-MFMA kernels run then): fwd_tbl_q [10 row tiles][5 chunks of 32 bins][3 planes][256 floats], lane 16 g + i of a fragment
+    /* ABI 5: the two DFT tables as bf16 x 3 split A fragments (csrc/split3.h) for the split-product kernels, or NULL (the f32-MFMA
+     * kernels run then): fwd_tbl_q [10 row tiles][5 chunks of 32 bins][3 planes][256 floats], lane 16 g + i of a fragment
      * holds T[16 tile + i][32 chunk + 8 g + e], e = 0..7, as eight bf16;  inv_tbl_q [10][5 chunks][3][256], same fragment layout, with
      * the 160 columns (81 real + 79 imaginary parts) ordered so that chunk j = [re of ceps bins 16 j .. 16 j + 15 | im of the same
      * bins] and the slot of the non-existent im of bin 0 holds re of bin 80. */
     const float *fwd_tbl_q, *inv_tbl_q;
+    /* ABI 6: VADX_ARITH_* of the two halves.  front: AUTO = BF16X3 when fwd_tbl_q is given, else F32.  back: AUTO = F32 (its split form is
+     * no faster: that half waits on 64-byte rows, not on the matrix pipe).  F16X2 is not built for these kernels and is refused. */
+    int32_t front_arithmetic, back_arithmetic;
 } vadx_dfsmn_cfb_weights;
 int vadx_dfsmn_cfb_front(const vadx_dfsmn_cfb_weights *w, const vadx_ft_view *a, const vadx_ft_view *b, const float *stats0,
                          float *y1, float *stats1, float *li, float *stats_li, int tiles, void *stream);

@@ -11,7 +11,7 @@ from oracle import dfsmn as od
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["f32", "split"])
+@pytest.fixture(autouse=True, params=["f32", "split", "h2"])
 def gemm(request):
     """Every test of this file runs on both arithmetics of the kernels that have both (the CepsUnit's frequency-axis LSTM): exact-f32
     MFMAs and bf16 x 3 split products."""
@@ -83,16 +83,16 @@ def test_opt_in_split_second_half_equals_the_unfused_chain(wts, monkeypatch, gem
     64-byte rows, not on the matrix pipe): inverse DFT with the 81 + 79 parts ordered as five k-steps, bin 80 riding in the slot of the
     non-existent im of bin 0 -- same block as the six-launch chain."""
     _lib.gemm_mode("split")                                   # (the opt-in kernel exists on the split arithmetic only; the fixture restores the mode)
-    monkeypatch.setenv("VADX_CFB_BACK", "split")
     w, _ = wts
     net = dfsmn.Iccrn(w)
+    net.cfb_back_split = True                                 # what VADX_CFB_BACK=split sets at construction
     g = torch.Generator().manual_seed(13)
     x = torch.randn(chunks, cin, 160, frames, generator=g) * 0.9 + 0.3
     xin = dfsmn.to_ft(torch, x, net.device)
     out_f = dfsmn.FT(torch, net.device, chunks, frames, 20, 160)
     out_u = dfsmn.FT(torch, net.device, chunks, frames, 20, 160)
     net.cfb(name, xin.view(), None, out_f.view(), chunks, frames)
-    monkeypatch.delenv("VADX_CFB_BACK")
+    net.cfb_back_split = False
     net.cfb_unfused(name, xin.view(), None, out_u.view(), chunks, frames)
     got, want = dfsmn.from_ft(out_f, chunks).cpu(), dfsmn.from_ft(out_u, chunks).cpu()
     assert torch.isfinite(got).all()

@@ -12,9 +12,9 @@ from oracle import postproc as opp
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["f32", "split"])
+@pytest.fixture(autouse=True, params=["f32", "split", "h2"])
 def gemm(request):
-    """Every test of this file runs on both arithmetics of the point-wise pairs: exact-f32 MFMAs and bf16 x 3 split products."""
+    """Every test of this file runs on both arithmetics of the point-wise pairs: exact-f32 MFMAs, bf16 x 3 split products and fp16 x 2 split products (the default)."""
     from vadx import _lib
     prev = _lib.gemm_mode(request.param)
     yield request.param

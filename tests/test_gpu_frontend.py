@@ -46,13 +46,13 @@ def oracle_logmel(preset, windows_i16):
     ("firered", 16000, 2, 16000, 3),
     ("firered", 2560, 1, 2560, 2),
 ])
-@pytest.mark.parametrize("fold", [True, False, 4])
+@pytest.mark.parametrize("fold", [True, False, 4, 5])
 def test_logmel_matches_oracle(preset, L, W, stride, B, fold):
     n = (W - 1) * stride + L
     clips = weights.burst_clips(B, n, seed=L + W + B)
     clips[0, : min(n, 3000)] = 0                         # exact digital silence -> exercises the log floor
     fe = frontend.Frontend(preset, L, fold=fold)
-    assert (fe.fold != 0) == bool(fold) and (fold != 4 or fe.fold == 4)      # 4 = dense product on bf16 x 3 split operands
+    assert (fe.fold != 0) == bool(fold) and (fold not in (4, 5) or fe.fold == fold)      # 4 / 5 = dense product on bf16 x 3 / fp16 x 2 split operands
     out = fe.logmel(clips, windows_per_clip=W, win_stride=stride).cpu().numpy()
     wins = np.stack([clips[b, w * stride:w * stride + L] for b in range(B) for w in range(W)])
     ref = oracle_logmel(preset, T(wins).unsqueeze(1)).numpy()
@@ -61,7 +61,17 @@ def test_logmel_matches_oracle(preset, L, W, stride, B, fold):
     assert np.isfinite(out).all()
     # relative agreement of the mel energies themselves (before log) where they are above the floor
     big = ref > np.log(1e-3)
-    assert err[big].max() < FEAT_ATOL, err[big].max()
+    if fold == 5:
+        # fp16 x 2 operands: same mean error as the other products (1.1e-6 against 1.0e-6), but a band more than 70 dB below its frame's
+        # strongest band -- where every product keeps only a few digits -- may land past 2e-4 (two of 72 128 values at 2.2e-4 / 2.7e-4 in the
+        # fsmn case, tests/probes/fe_kind5.py -> profiles/r05_frontend_kind5_error.txt; kind 4's worst there is 1.8e-4): the 2e-4 bound holds
+        # within 16 log units of the frame's peak band, 5e-4 above the floor elsewhere
+        near = big & (ref > ref.max(axis=-1, keepdims=True) - 16.0)
+        assert err[near].max() < FEAT_ATOL, err[near].max()
+        assert err[big].max() < 5e-4, err[big].max()
+        assert err[big].mean() < 2e-6, err[big].mean()
+    else:
+        assert err[big].max() < FEAT_ATOL, err[big].max()
     assert err.max() < 5e-3, err.max()                   # near-floor values: log amplifies round-off
 
 
@@ -169,7 +179,9 @@ def exact_logmel(preset, windows_i16):
 @pytest.mark.parametrize("preset,L,kind", [("fsmn", 16000, 3), ("fsmn", 16000, 2), ("marblenet", 40000, 1), ("marblenet", 16000, 1),
                                            ("firered", 16000, 1), ("fsmn", 5280, 3), ("fsmn", 5280, 2), ("firered", 2560, 1), ("fsmn", 800, 3),
                                            ("fsmn", 16000, 4), ("marblenet", 40000, 4), ("marblenet", 16000, 4), ("firered", 16000, 4),
-                                           ("fsmn", 5280, 4), ("firered", 2560, 4), ("fsmn", 800, 4)])
+                                           ("fsmn", 5280, 4), ("firered", 2560, 4), ("fsmn", 800, 4),
+                                           ("fsmn", 16000, 5), ("marblenet", 40000, 5), ("marblenet", 16000, 5), ("firered", 16000, 5),
+                                           ("fsmn", 5280, 5), ("firered", 2560, 5), ("fsmn", 800, 5)])
 def test_folded_dft_is_the_dense_product(preset, L, kind):
     """Table-level proof of the folded DFT product (mirror-paired taps about the window centre + f16 residual, csrc/frontend.hip
     "Folded DFT"): the same clips through the dense f32 product and the folded one, both against the double-precision evaluation
@@ -180,8 +192,9 @@ def test_folded_dft_is_the_dense_product(preset, L, kind):
     kind 3 (opt-in time x frequency fold, FSMN only) is held to its own, documented bounds: a weak bin inherits round-off relative to
     its STRONG mirror bin, so the bound relative to the frame's strongest line is twice the dense product's, bands within 26 dB of
     the frame's peak are as exact as the dense product's, and the mean log-mel error stays within 2.5 x.
-    kind 4 (dense product on bf16 x 3 exactly split operands, csrc/split3.h) is held to the bounds of kinds 1 / 2: no larger error than
-    1.25 x the dense f32-MFMA product's against the double evaluation of the same table."""
+    kinds 4 / 5 (dense product on bf16 x 3 exactly split operands, csrc/split3.h / on fp16 x 2 split operands, csrc/split2.h: the default)
+    are held to the bounds of kinds 1 / 2: no larger error than 1.25 x the dense f32-MFMA product's against the double evaluation of the
+    same table."""
     B = 6
     clips = weights.burst_clips(B, L, seed=L + kind)
     clips[0, : min(L, 3000)] = 0
@@ -224,10 +237,12 @@ def test_folded_dft_is_the_dense_product(preset, L, kind):
 
 
 def test_split_frontend_is_the_default_and_can_be_turned_off(monkeypatch):
-    """Default = kind 4 (dense product on bf16 x 3 split operands) where the geometry has it; VADX_FRONTEND_FOLD selects the others."""
+    """Default = kind 5 (dense product on fp16 x 2 split operands) where the geometry has it; VADX_FRONTEND_FOLD selects the others."""
     monkeypatch.delenv("VADX_FRONTEND_FOLD", raising=False)
-    assert frontend.Frontend("fsmn", 16000).fold == 4 and frontend.Frontend("marblenet", 16000).fold == 4 and frontend.Frontend("firered", 16000).fold == 4
-    assert frontend.Frontend("marblenet", 48000, in_sample_rate=48000).fold == 1      # the in-graph resampling preps are not staged by kind 4: folded f32 product
+    assert frontend.Frontend("fsmn", 16000).fold == 5 and frontend.Frontend("marblenet", 16000).fold == 5 and frontend.Frontend("firered", 16000).fold == 5
+    assert frontend.Frontend("marblenet", 48000, in_sample_rate=48000).fold == 1      # the in-graph resampling preps are not staged by kinds 4 / 5: folded f32 product
+    monkeypatch.setenv("VADX_FRONTEND_FOLD", "4")           # round 4's default: the same product on bf16 x 3 split operands
+    assert frontend.Frontend("fsmn", 16000).fold == 4 and frontend.Frontend("marblenet", 48000, in_sample_rate=48000).fold == 1
     monkeypatch.setenv("VADX_FRONTEND_FOLD", "1")           # round 3's default: the folded f32 product the table admits
     assert frontend.Frontend("fsmn", 16000).fold == 2 and frontend.Frontend("marblenet", 16000).fold == 1
     monkeypatch.setenv("VADX_FRONTEND_FOLD", "0")
@@ -237,7 +252,7 @@ def test_split_frontend_is_the_default_and_can_be_turned_off(monkeypatch):
 
 
 @pytest.mark.parametrize("n_fft,win,hop,window,variant,center,want_default,want_f32fold", [
-    (512, 320, 160, "hann_sym", "v2", True, 4, 1),          # two full passes; hop 160: split-product dense kernel by default
+    (512, 320, 160, "hann_sym", "v2", True, 5, 1),          # two full passes; hop 160: split-product dense kernel (fp16 x 2) by default
     (512, 512, 128, "hann_sym", "v2", True, 1, 1),          # four passes, window = n_fft; hop 128: folded f32 product
     (256, 200, 80, "hamming", "v1", True, None, None),      # periodic window, small transform (129 bins: last-bin tile), hop 80
     (512, 400, 192, "hamming", "v1", True, None, None),     # hop 192: three passes of 192 + 16
@@ -246,7 +261,7 @@ def test_split_frontend_is_the_default_and_can_be_turned_off(monkeypatch):
 ])
 def test_folded_product_on_other_geometries(n_fft, win, hop, window, variant, center, want_default, want_f32fold, monkeypatch):
     """The C ABI takes any geometry with hop % 16 == 0, hop <= 320 and at most four hops per window: wherever a faster product applies
-    (kind 4 split-product dense at hop 160, else the fold vadx_frontend_fold_kind admits) it must agree with the dense f32 kernel
+    (kind 5 split-product dense at hop 160, else the fold vadx_frontend_fold_kind admits) it must agree with the dense f32 kernel
     (same table bits), where none does the dense kernel runs, and a geometry outside the kernels is REFUSED loudly, never skipped."""
     preset = dict(n_fft=n_fft, win=win, hop=hop, window=window, variant=variant, center=center, prep=1,
                   k=(-0.97 / 32768.0, 1.0 / 32768.0), mel=("torchaudio", 0, 8000, "slaney", "slaney"), log_mode=1, log_floor=1e-7)

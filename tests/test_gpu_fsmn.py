@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 ATOL = 1e-4
 
 
-@pytest.fixture(autouse=True, params=["f32", "split"])
+@pytest.fixture(autouse=True, params=["f32", "split", "h2"])
 def gemm(request):
-    """Every test of this file runs on both arithmetics of the dense layers: exact-f32 MFMAs and bf16 x 3 split products."""
+    """Every test of this file runs on both arithmetics of the dense layers: exact-f32 MFMAs, bf16 x 3 split products and fp16 x 2 split products (the default)."""
     prev = _lib.gemm_mode(request.param)
     yield request.param
     _lib.gemm_mode(prev)
@@ -265,7 +265,7 @@ def test_kind3_frontend_keeps_the_scores_and_decisions(monkeypatch):
     lm, _ = eng.features(clips, W, stride)
     monkeypatch.setenv("VADX_FRONTEND_FOLD", "3")
     eng3 = fsmn.FsmnEngine(w)
-    assert eng3.fe.fold == 3 and eng.fe.fold == 4      # the default front-end: dense product on bf16 x 3 split operands
+    assert eng3.fe.fold == 3 and eng.fe.fold == 5      # the default front-end: dense product on fp16 x 2 split operands
     flags3 = eng3.flags(clips, W).cpu().numpy()
     lm3, _ = eng3.features(clips, W, stride)
     assert np.array_equal(flags, flags3)

@@ -67,7 +67,7 @@ class FrontendCfg(C.Structure):
 
 class FsmnDims(C.Structure):
     _fields_ = [("input_affine_dim", C.c_int), ("linear_dim", C.c_int), ("output_affine_dim", C.c_int),
-                ("output_dim", C.c_int), ("frames", C.c_int), ("speech_2_noise_ratio", C.c_float)]
+                ("output_dim", C.c_int), ("frames", C.c_int), ("speech_2_noise_ratio", C.c_float), ("arithmetic", C.c_int)]
 
 
 class FsmnWeightsHost(C.Structure):
@@ -85,7 +85,7 @@ class FsmnLoopParams(C.Structure):
 
 
 class FireRedCfg(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("idim", "R", "M", "H", "P", "N1", "S1", "N2", "S2", "odim", "frames")]
+    _fields_ = [(k, C.c_int) for k in ("idim", "R", "M", "H", "P", "N1", "S1", "N2", "S2", "odim", "frames", "arithmetic")]
 
 
 class FireRedWeightsHost(C.Structure):
@@ -120,7 +120,7 @@ class FtLn(C.Structure):
 
 class DfsmnCfbWeights(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("ln0_w", "gate_w", "in_w", "in_b", "front_tab", "conv_w", "fwd_tbl", "fwd_fix", "lin_w", "lin_b",
-                                          "inv_tbl", "out_fix", "fwd_tbl_q", "inv_tbl_q")]
+                                          "inv_tbl", "out_fix", "fwd_tbl_q", "inv_tbl_q")] + [("front_arithmetic", C.c_int32), ("back_arithmetic", C.c_int32)]
 
 
 class DfsmnMaskWeights(C.Structure):
@@ -135,7 +135,6 @@ _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 # name -> (restype, argtypes); every symbol include/vadx.h declares
 SIGNATURES = {
     "vadx_abi_version": (_I, []),
-    "vadx_gemm_mode": (_I, [_I]),
     "vadx_last_error": (C.c_char_p, []),
     "vadx_silero_packed_floats": (_Z, []),
     "vadx_silero_pack_host": (_I, [C.POINTER(SileroWeightsHost), _P]),
@@ -156,12 +155,14 @@ SIGNATURES = {
     "vadx_frontend_fold_kind": (_I, [C.POINTER(FrontendCfg), _P, _P, _I]),
     "vadx_frontend_logmel": (_I, [C.POINTER(FrontendCfg), _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
     "vadx_fsmn_packed_floats": (_Z, [C.POINTER(FsmnDims)]),
+    "vadx_fsmn_range_flag": (_I, [C.POINTER(FsmnDims), _P, _I, _P, _P, _P]),
     "vadx_fsmn_pack_host": (_I, [C.POINTER(FsmnDims), C.POINTER(FsmnWeightsHost), _P]),
     "vadx_fsmn_energy": (_I, [_P, _L, _L, _I, _I, _I, _I, _P, _P, _P]),
     "vadx_fsmn_run": (_I, [C.POINTER(FsmnDims), _P, _P, _P, C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p * 4),
                            _P, _P, _I, _P, _P, _P, _P]),
     "vadx_fsmn_clips": (_I, [C.POINTER(FsmnDims), _P, _P, _P, _I, _I, C.POINTER(FsmnLoopParams), _P, _P, _P, _P]),
     "vadx_firered_packed_floats": (_Z, [C.POINTER(FireRedCfg)]),
+    "vadx_firered_range_flag": (_I, [C.POINTER(FireRedCfg), _P, _I, _P, _P, _P]),
     "vadx_firered_pack_host": (_I, [C.POINTER(FireRedCfg), C.POINTER(FireRedWeightsHost), _P]),
     "vadx_firered_run": (_I, [C.POINTER(FireRedCfg), _P, _P, _I, _P, _P]),
     "vadx_ingest_out_frames": (C.c_int64, [C.c_int64, _I, _I]),
@@ -183,7 +184,7 @@ SIGNATURES = {
                                 C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtView), _I, _I, _I, _I, _I, _P, _P, _P]),
     "vadx_dfsmn_dft_f": (_I, [_I, C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtLn), _P, C.POINTER(FtView), _I, _I, _P, _P]),
     "vadx_dfsmn_lstm_f": (_I, [C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
-                               C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), C.POINTER(FtView), _I, _I, _P]),
+                               C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), C.POINTER(FtView), _I, _I, _P, _I]),
     "vadx_dfsmn_cfb_front": (_I, [C.POINTER(DfsmnCfbWeights), C.POINTER(FtView), C.POINTER(FtView), _P, _P, _P, _P, _P, _I, _P]),
     "vadx_dfsmn_cfb_back": (_I, [C.POINTER(DfsmnCfbWeights), _P, _P, _P, _P, C.POINTER(FtView), _P, _I, _P]),
     "vadx_dfsmn_alpha_scale": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
@@ -280,16 +281,66 @@ class trace:
         return False
 
 
-GEMM_MODES = {"f32": 0, "split": 1}
+GEMM_MODES = {"f32": ARITH["f32"], "split": ARITH["split"], "h2": ARITH["h2"]}      # name -> VADX_ARITH_*
+_gemm_default = [None]
 
 
 def gemm_mode(mode=None):
-    """Arithmetic of the FSMN / FireRed dense layers, process-wide (include/vadx.h: vadx_gemm_mode): "f32" MFMAs or "split" = bf16 x 3
-    split products.  Returns the mode that was active; None only queries."""
-    if mode is not None and mode not in GEMM_MODES:
-        raise ValueError(f"gemm mode must be one of {sorted(GEMM_MODES)}, got {mode!r}")
-    prev = lib().vadx_gemm_mode(-1 if mode is None else GEMM_MODES[mode])
-    return {v: k for k, v in GEMM_MODES.items()}[prev]
+    """The arithmetic FSMN / FireRed / DFSMN engines use for their dense layers unless told otherwise per engine (`engine.arithmetic`):
+    "f32" MFMAs, "split" = bf16 x 3 exact-split products, "h2" = fp16 x 2 split products (the default; activations outside the fp16
+    range are detected and the batch recomputed on "split").  A Python-side default only: the C ABI takes the arithmetic with every
+    cfg / dims struct (include/vadx.h: VADX_ARITH_*).  Returns the mode that was active; None only queries.  Initial value: VADX_GEMM,
+    read once here."""
+    if _gemm_default[0] is None:
+        e = os.environ.get("VADX_GEMM", "").strip().lower()
+        _gemm_default[0] = {"0": "f32", "1": "split", "2": "h2", "bf16x3": "split", "f16x2": "h2"}.get(e, e) if e else "h2"
+        if _gemm_default[0] not in GEMM_MODES:
+            raise ValueError(f"VADX_GEMM must be one of {sorted(GEMM_MODES)}, got {e!r}")
+    prev = _gemm_default[0]
+    if mode is not None:
+        if mode not in GEMM_MODES:
+            raise ValueError(f"gemm mode must be one of {sorted(GEMM_MODES)}, got {mode!r}")
+        _gemm_default[0] = mode
+    return prev
+
+
+class ArithBlobs:
+    """What an engine whose packed blob depends on the arithmetic keeps: one (cfg struct, device blob) per arithmetic, built on first use
+    by `build(mode) -> (cfg, device tensor)` (raising ValueError when the weights cannot be packed for that mode), and the fp16 x 2
+    range protocol around a launch: `guarded(run)` runs `run(mode, cfg, blob)`; on "h2" the result stands only if the kernels' sticky
+    range flag stayed clear (`flag(cfg, blob) -> (flag, amax)`, which synchronises), otherwise the batch is recomputed on "split"."""
+
+    def __init__(self, build, flag):
+        self._build, self._flag = build, flag
+        self._blobs = {}
+        self.arithmetic = None            # None = the module default (gemm_mode()); or "f32" | "split" | "h2"
+        self.h2_ok = True
+        self.range_fallbacks = 0
+
+    def mode(self):
+        m = self.arithmetic or gemm_mode()
+        if m == "h2" and self.h2_ok and "h2" not in self._blobs:
+            try:
+                self._blobs["h2"] = self._build("h2")
+            except ValueError:                # a weight outside the fp16 range (pack_host says so): this engine runs bf16 x 3
+                self.h2_ok = False
+        return "split" if (m == "h2" and not self.h2_ok) else m
+
+    def get(self, mode=None):
+        mode = mode or self.mode()
+        if mode not in self._blobs:
+            self._blobs[mode] = self._build(mode)
+        return self._blobs[mode]
+
+    def guarded(self, run):
+        m = self.mode()
+        out = run(m, *self.get(m))
+        if m == "h2":
+            flag, _ = self._flag(*self.get(m))
+            if flag:
+                self.range_fallbacks += 1
+                out = run("split", *self.get("split"))
+        return out
 
 
 def check(rc, exc=VadxError):

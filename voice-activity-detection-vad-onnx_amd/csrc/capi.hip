@@ -15,28 +15,6 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace vadx
 
-// Arithmetic of the FSMN / FireRed dense layers (process-wide): 0 = f32 MFMAs, 1 = bf16 x 3 split products (csrc/split3.h)
-#ifndef VADX_GEMM_MODE_DEFAULT
-#define VADX_GEMM_MODE_DEFAULT 1       // split products: every FSMN parity test passes on both arithmetics (tests/test_gpu_fsmn.py)
-#endif
-namespace vadx {
-static std::atomic<int> g_gemm_mode{-1};
-int gemm_mode() {
-    int m = g_gemm_mode.load(std::memory_order_relaxed);
-    if (m < 0) {
-        const char *e = getenv("VADX_GEMM");
-        m = (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : ((e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : VADX_GEMM_MODE_DEFAULT);
-        g_gemm_mode.store(m, std::memory_order_relaxed);
-    }
-    return m;
-}
-}  // namespace vadx
-extern "C" int vadx_gemm_mode(int mode) {
-    const int prev = vadx::gemm_mode();
-    if (mode == 0 || mode == 1) vadx::g_gemm_mode.store(mode, std::memory_order_relaxed);
-    return prev;
-}
-
 extern "C" int vadx_abi_version(void) { return VADX_ABI_VERSION; }      // include/vadx.h is the one place the number lives
 extern "C" const char *vadx_last_error(void) { return vadx::g_err; }
 

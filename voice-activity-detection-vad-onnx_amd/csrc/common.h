@@ -13,7 +13,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 namespace vadx {
 
 void set_error(const char *fmt, ...);
-int gemm_mode();        // 0 = f32 MFMAs, 1 = bf16 x 3 split products in the FSMN / FireRed dense layers (capi.hip: vadx_gemm_mode)
 
 #define VADX_HIP_TRY(expr)                                                                   \
     do {                                                                                     \

@@ -1570,15 +1570,17 @@ extern "C" int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_
 
 extern "C" int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2],
                                  const float *const w_hh[2], const float *const b_ih[2], const float *const b_hh[2],
-                                 const vadx_ft_view *out, int F, int tiles, void *stream) {
+                                 const vadx_ft_view *out, int F, int tiles, void *stream, int arithmetic) {
     VADX_REQUIRE(in && in->ptr && out && out->ptr && w_ih && w_hh && b_ih && b_hh && F > 0 && tiles > 0, "vadx_dfsmn_lstm_f: bad argument");
+    VADX_REQUIRE(arithmetic == VADX_ARITH_AUTO || arithmetic == VADX_ARITH_F32 || arithmetic == VADX_ARITH_BF16X3,
+                 "vadx_dfsmn_lstm_f: arithmetic=%d (this kernel has VADX_ARITH_F32 and VADX_ARITH_BF16X3)", arithmetic);
     VADX_REQUIRE(in->c == 40 ? (ln && ln->stats && ln->w && ln->b) : !(ln && ln->stats),
                  "vadx_dfsmn_lstm_f: the 40-channel (CepsUnit) LSTM takes a LayerNorm, the 4-channel one does not");
     LstmFArgs p;
     p.in = mkview(in); p.ln = mkln(ln); p.out = mkvieww(out); p.F = F;
     for (int d = 0; d < 2; ++d) { p.w_ih[d] = w_ih[d]; p.w_hh[d] = w_hh[d]; p.b_ih[d] = b_ih[d]; p.b_hh[d] = b_hh[d]; }
     if (in->c == 4) hipLaunchKernelGGL(lstm_f_kernel<4>, dim3(tiles), dim3(128), 0, static_cast<hipStream_t>(stream), p);
-    else if (in->c == 40 && vadx::gemm_mode() == 1)      // split products: persistent workgroups (each lane splits its weights once), four per CU
+    else if (in->c == 40 && arithmetic != VADX_ARITH_F32)      // split products: persistent workgroups (each lane splits its weights once), four per CU
         hipLaunchKernelGGL(lstm_f_split_kernel, dim3(tiles < 1024 ? tiles : 1024), dim3(128), 0, static_cast<hipStream_t>(stream), p, tiles);
     else if (in->c == 40) hipLaunchKernelGGL(lstm_f_kernel<40>, dim3(tiles), dim3(128), 0, static_cast<hipStream_t>(stream), p);
     else { vadx::set_error("vadx_dfsmn_lstm_f: input channels must be 4 or 40"); return VADX_EINVAL; }

@@ -1425,8 +1425,10 @@ extern "C" int vadx_dfsmn_cfb_front(const vadx_dfsmn_cfb_weights *w, const vadx_
     VADX_REQUIRE(p.a.c % 4 == 0, "vadx_dfsmn_cfb_front: the first view must hold a multiple of 4 channels (a k-step does not straddle the views)");
     const unsigned grid = (unsigned)(tiles < cu_count() ? tiles : cu_count());
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (vadx::gemm_mode() == 1 && w->fwd_tbl_q && (cin == 20 || cin == 40) && p.a.c == 20) {
-        // bf16 x 3 split products (VADX_GEMM=f32 / vadx_gemm_mode(0) selects the f32-MFMA kernels below)
+    VADX_REQUIRE(w->front_arithmetic == VADX_ARITH_AUTO || w->front_arithmetic == VADX_ARITH_F32 || w->front_arithmetic == VADX_ARITH_BF16X3,
+                 "vadx_dfsmn_cfb_front: front_arithmetic=%d (this kernel has VADX_ARITH_F32 and VADX_ARITH_BF16X3)", w->front_arithmetic);
+    if (w->front_arithmetic != VADX_ARITH_F32 && w->fwd_tbl_q && (cin == 20 || cin == 40) && p.a.c == 20) {
+        // bf16 x 3 split products (front_arithmetic = VADX_ARITH_F32 selects the f32-MFMA kernels below)
         FrontQArgs pq{p, w->fwd_tbl_q};
         if (cin == 20) {
             VADX_DYN_LDS(cfb_front_split_kernel<20>, front_split_lds<20>());
@@ -1460,10 +1462,11 @@ extern "C" int vadx_dfsmn_cfb_back(const vadx_dfsmn_cfb_weights *w, const float 
     p.out = ViewW{const_cast<float *>(out->ptr), out->c_total, out->c_off, out->c};
     p.part = part; p.tiles = tiles;
     const unsigned grid = (unsigned)(tiles < cu_count() ? tiles : cu_count());
-    // The split-product form of this half is opt-in (VADX_CFB_BACK=split): measured no faster than the f32-MFMA kernel (0.975 against
-    // 0.943 ms per 3584 tiles) -- this half moves 824 KB per tile in 64-byte rows and waits on them, not on the matrix pipe.
-    const char *back_env = getenv("VADX_CFB_BACK");
-    if (vadx::gemm_mode() == 1 && w->inv_tbl_q && back_env && !strcmp(back_env, "split")) {
+    // The split-product form of this half is opt-in (back_arithmetic = VADX_ARITH_BF16X3): measured no faster than the f32-MFMA kernel
+    // (0.975 against 0.943 ms per 3584 tiles) -- this half moves 824 KB per tile in 64-byte rows and waits on them, not on the matrix pipe.
+    VADX_REQUIRE(w->back_arithmetic == VADX_ARITH_AUTO || w->back_arithmetic == VADX_ARITH_F32 || w->back_arithmetic == VADX_ARITH_BF16X3,
+                 "vadx_dfsmn_cfb_back: back_arithmetic=%d (this kernel has VADX_ARITH_F32 and VADX_ARITH_BF16X3)", w->back_arithmetic);
+    if (w->back_arithmetic == VADX_ARITH_BF16X3 && w->inv_tbl_q) {
         BackQArgs pq{p, w->inv_tbl_q};
         VADX_DYN_LDS(cfb_back_split_kernel, back_split_lds());
         hipLaunchKernelGGL(cfb_back_split_kernel, dim3(grid), dim3(NTH), back_split_lds(), static_cast<hipStream_t>(stream), pq);

@@ -10,7 +10,7 @@
 // depthwise look-back / look-ahead FIRs + skip run on the VALU over the whole window once per block.
 #include "common.h"
 #include "layers.h"
-#include "split3.h"
+#include "split_scheme.h"
 
 #include <math.h>
 #include <string.h>
@@ -39,8 +39,9 @@ struct Dev {
     int off_fc1, off_fc1b, off_fc2, off_fc2b;
     int off_lb[MAX_R], off_la[MAX_R], off_win[MAX_R], off_bfc1[MAX_R], off_bfc1b[MAX_R], off_bfc2[MAX_R];
     int off_dnn[MAX_M], off_dnnb[MAX_M], off_out, off_outb, total;
-    // bf16 x 3 split-product copies of the point-wise pairs (Hp = 256, Pp = 128 only): A fragments [n-tile][32-k chunk][plane][QFRAG]
-    int split_ok, q_fc1, q_fc2, q_bfc1[MAX_R], q_bfc2[MAX_R];
+    // split-product copies of the point-wise pairs (Hp = 256, Pp = 128 only): A fragments [n-tile][32-k chunk][np planes][QFRAG] of the ONE
+    // arithmetic cfg->arithmetic names (split_scheme.h: np = 3 bf16 x 3, 2 fp16 x 2, 0 none = float32 MFMAs)
+    int split_ok, arith, np, off_flag, q_fc1, q_fc2, q_bfc1[MAX_R], q_bfc2[MAX_R];
 };
 
 static int r16(int x) { return (x + 15) & ~15; }
@@ -67,11 +68,17 @@ static int derive(const vadx_firered_cfg *c, Dev *d) {
     for (int m = 0; m < d->M; ++m) { d->off_dnn[m] = take(d->Hp * (m == 0 ? d->Pp : d->Hp)); d->off_dnnb[m] = take(d->Hp); }
     d->off_out = take(16 * d->Hp); d->off_outb = take(16);      // output head padded to one 16-row MFMA tile
     d->split_ok = d->Hp == 256 && d->Pp == 128;
-    if (d->split_ok) {
-        d->q_fc1 = take(16 * 3 * 3 * vadx::QFRAG);                 // 80 mels -> 3 chunks of 32 (k-groups 10, 11 are zero rows)
-        d->q_fc2 = take(8 * 8 * 3 * vadx::QFRAG);
-        for (int r = 1; r < d->R; ++r) { d->q_bfc1[r] = take(16 * 4 * 3 * vadx::QFRAG); d->q_bfc2[r] = take(8 * 8 * 3 * vadx::QFRAG); }
+    // AUTO = fp16 x 2 where the split kernel applies, float32 MFMAs otherwise; an explicit split arithmetic elsewhere is refused
+    d->arith = vadx::arith_internal(c->arithmetic, d->split_ok ? vadx::VADX_AR_H2 : vadx::VADX_AR_F32);
+    if (d->arith < 0 || (d->arith != vadx::VADX_AR_F32 && !d->split_ok)) return -1;
+    d->np = d->arith == vadx::VADX_AR_B3 ? 3 : (d->arith == vadx::VADX_AR_H2 ? 2 : 0);
+    if (d->np) {
+        const int np = d->np;
+        d->q_fc1 = take(16 * 3 * np * vadx::QFRAG);                // 80 mels -> 3 chunks of 32 (k-groups 10, 11 are zero rows)
+        d->q_fc2 = take(8 * 8 * np * vadx::QFRAG);
+        for (int r = 1; r < d->R; ++r) { d->q_bfc1[r] = take(16 * 4 * np * vadx::QFRAG); d->q_bfc2[r] = take(8 * 8 * np * vadx::QFRAG); }
     }
+    d->off_flag = take(4);
     d->total = o;
     return 0;
 }
@@ -259,40 +266,43 @@ __device__ __forceinline__ void pointwise_pair_resident(const Dev &d, const floa
 // H tile | barrier | GEMM 2, activations = A operand: a lane ends with four consecutive frames of one P channel -> one float4 store into
 // dst.  The planes live where the f32 kernel keeps its 32-frame H tile (12 KB + 24 KB = its 36 KB).
 constexpr int QS_PL_SRC = 16 * 16 * 16, QS_PL_H = 32 * 16 * 16;     // bytes of one plane: src tile (<= 128 ch x 16 frames), H tile (256 x 16)
-template <int KC1>
-struct PairSplit { bf16x8 w1[2][KC1][3], w2[8][3]; f32x4 bias1[2]; float bias2; };
+template <typename SC, int KC1>
+struct PairSplit { typename SC::frag w1[2][KC1][SC::NP], w2[8][SC::NP]; f32x4 bias1[2]; float bias2; };
 
-template <int KC1>
-__device__ __forceinline__ void load_pair_split(PairSplit<KC1> &R, const float *Q1, const float *b1, const float *Q2, const float *b2, int tid) {
+template <typename SC, int KC1>
+__device__ __forceinline__ void load_pair_split(PairSplit<SC, KC1> &R, const float *Q1, const float *b1, const float *Q2, const float *b2, int tid) {
+    constexpr int NP = SC::NP;
     const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int kc = 0; kc < KC1; ++kc)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) R.w1[nt][kc][p] = ldq(Q1 + (size_t)(((wave + 8 * nt) * KC1 + kc) * 3 + p) * QFRAG, lane);
+            for (int p = 0; p < NP; ++p) R.w1[nt][kc][p] = SC::ld(Q1 + (size_t)(((wave + 8 * nt) * KC1 + kc) * NP + p) * QFRAG, lane);
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) R.w2[kc][p] = ldq(Q2 + (size_t)((wave * 8 + kc) * 3 + p) * QFRAG, lane);
+        for (int p = 0; p < NP; ++p) R.w2[kc][p] = SC::ld(Q2 + (size_t)((wave * 8 + kc) * NP + p) * QFRAG, lane);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) R.bias1[nt] = ldg4(b1 + (wave + 8 * nt) * 16 + 4 * q);
     R.bias2 = b2 ? ldg1(b2 + wave * 16 + i) : 0.f;
 }
 
-template <int KC1>
+template <typename SC, int KC1>
 __device__ __forceinline__ void pointwise_pair_split(const Dev &d, const float *Q1, const float *b1, int ksrc, const float *src,
-                                                     const float *Q2, const float *b2, bool relu2, float *dst, float *hbuf) {
+                                                     const float *Q2, const float *b2, bool relu2, float *dst, float *hbuf, float &amax) {
+    constexpr int NP = SC::NP;
+    typedef typename SC::frag frag;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));       // per call: the per-lane LDS offsets below are loop-invariant over the blocks, and hoisted out of the block
                                         // loop they stayed live through the FIR (186 registers of its own) and spilled there (layers.h has the same note)
     const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
-    unsigned char *SQ = reinterpret_cast<unsigned char *>(hbuf), *HQ = SQ + 3 * QS_PL_SRC;
-    PairSplit<KC1> R;
-    load_pair_split<KC1>(R, Q1, b1, Q2, b2, tid);
+    unsigned char *SQ = reinterpret_cast<unsigned char *>(hbuf), *HQ = SQ + 3 * QS_PL_SRC;       // (the plane map is sized for three planes; fp16 x 2 uses two of each)
+    PairSplit<SC, KC1> R;
+    load_pair_split<SC, KC1>(R, Q1, b1, Q2, b2, tid);
     if (ksrc < KC1 * 32) {             // k-groups beyond the source's channels (80 mels in 96 slots): rows of zeros, written once
         const int kg0 = ksrc / 8, n = (KC1 * 4 - kg0) * 16;
-        for (int e = tid; e < 3 * n; e += THREADS) {
+        for (int e = tid; e < NP * n; e += THREADS) {
             const int p = e / n, r = e - p * n;
             *reinterpret_cast<f32x4 *>(SQ + p * QS_PL_SRC + (kg0 * 16 + r) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -303,51 +313,42 @@ __device__ __forceinline__ void pointwise_pair_split(const Dev &d, const float *
             f32x4 v;
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = src[(4 * cg + c) * M_LD + f0 + fr];
-            u32x2 p0, p1, p2;
-            split3x4(v, p0, p1, p2);
+            u32x2 pp[NP];
+            SC::split4(v, pp, amax);
             unsigned char *dp = SQ + ((cg >> 1) * 16 + fr) * 16 + (cg & 1) * 8;
-            *reinterpret_cast<u32x2 *>(dp) = p0;
-            *reinterpret_cast<u32x2 *>(dp + QS_PL_SRC) = p1;
-            *reinterpret_cast<u32x2 *>(dp + 2 * QS_PL_SRC) = p2;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2 *>(dp + p * QS_PL_SRC) = pp[p];
         }
     };
     split_tile(0);
     __syncthreads();
     for (int f0 = 0; f0 < d.T; f0 += 16) {
         {   // GEMM 1: H channels 16 (wave + 8 nt) + 4 q + r of frame i
-            f32x4 hi[2], lo[2];
+            f32x4 hi[2][1], lo[2][1];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) { hi[nt] = R.bias1[nt]; lo[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int nt = 0; nt < 2; ++nt) { hi[nt][0] = R.bias1[nt]; lo[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int kc = 0; kc < KC1; ++kc) {
-                bf16x8 b[3];
+                frag b[1][NP], a[2][NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8 *>(SQ + p * QS_PL_SRC + ((4 * kc + q) * 16 + i) * 16);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) lo[nt] = mfma_bf16(R.w1[nt][kc][2], b[0], lo[nt]);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) lo[nt] = mfma_bf16(R.w1[nt][kc][1], b[1], lo[nt]);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) lo[nt] = mfma_bf16(R.w1[nt][kc][0], b[2], lo[nt]);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) lo[nt] = mfma_bf16(R.w1[nt][kc][1], b[0], lo[nt]);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) lo[nt] = mfma_bf16(R.w1[nt][kc][0], b[1], lo[nt]);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) hi[nt] = mfma_bf16(R.w1[nt][kc][0], b[0], hi[nt]);
+                for (int p = 0; p < NP; ++p) {
+                    b[0][p] = SC::lds(SQ + p * QS_PL_SRC + ((4 * kc + q) * 16 + i) * 16);
+                    a[0][p] = R.w1[0][kc][p];
+                    a[1][p] = R.w1[1][kc][p];
+                }
+                SC::template products<2, 1, true>(a, b, hi, lo);
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                f32x4 v;
+                f32x4 v = SC::join(hi[nt][0], lo[nt][0]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(hi[nt][r] + lo[nt][r], 0.f);
-                u32x2 p0, p1, p2;
-                split3x4(v, p0, p1, p2);
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                u32x2 pp[NP];
+                SC::split4(v, pp, amax);
                 const int g = 4 * (wave + 8 * nt) + q;
                 unsigned char *dp = HQ + ((g >> 1) * 16 + i) * 16 + (g & 1) * 8;
-                *reinterpret_cast<u32x2 *>(dp) = p0;
-                *reinterpret_cast<u32x2 *>(dp + QS_PL_H) = p1;
-                *reinterpret_cast<u32x2 *>(dp + 2 * QS_PL_H) = p2;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2 *>(dp + p * QS_PL_H) = pp[p];
             }
         }
         __syncthreads();
@@ -355,22 +356,20 @@ __device__ __forceinline__ void pointwise_pair_split(const Dev &d, const float *
         // the barrier at the end of the iteration publishes both the new src planes and the free H tile
         if (f0 + 16 < d.T) split_tile(f0 + 16);
         {   // GEMM 2 (activations = A operand): frames f0 + 4 q + r of P channel 16 wave + i
-            f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = hi;
+            f32x4 hi[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}}, lo[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
-                bf16x8 b[3];
+                frag b[1][NP], a[1][NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8 *>(HQ + p * QS_PL_H + ((4 * kc + q) * 16 + i) * 16);
-                lo = mfma_bf16(b[0], R.w2[kc][2], lo);
-                lo = mfma_bf16(b[1], R.w2[kc][1], lo);
-                lo = mfma_bf16(b[2], R.w2[kc][0], lo);
-                lo = mfma_bf16(b[0], R.w2[kc][1], lo);
-                lo = mfma_bf16(b[1], R.w2[kc][0], lo);
-                hi = mfma_bf16(b[0], R.w2[kc][0], hi);
+                for (int p = 0; p < NP; ++p) {
+                    b[0][p] = SC::lds(HQ + p * QS_PL_H + ((4 * kc + q) * 16 + i) * 16);
+                    a[0][p] = R.w2[kc][p];
+                }
+                SC::template products<1, 1, false>(a, b, hi, lo);
             }
-            f32x4 v;
+            f32x4 v = SC::join(hi[0][0], lo[0][0]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = (hi[r] + lo[r]) + R.bias2; if (relu2) v[r] = fmaxf(v[r], 0.f); }
+            for (int r = 0; r < 4; ++r) { v[r] = v[r] + R.bias2; if (relu2) v[r] = fmaxf(v[r], 0.f); }
             *reinterpret_cast<f32x4 *>(dst + (wave * 16 + i) * M_LD + f0 + 4 * q) = v;
         }
         __syncthreads();
@@ -396,9 +395,14 @@ __device__ __forceinline__ void pointwise_pair(const Dev &d, const float *W1, co
     }
 }
 
-template <bool SPLIT>
+template <int AR> struct FrSchemeOf { typedef vadx::SchemeB3 type; };
+template <> struct FrSchemeOf<vadx::VADX_AR_H2> { typedef vadx::SchemeH2 type; };
+template <int AR>
 __global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float *__restrict__ Pk,
                                                              const float *__restrict__ logmel, float *__restrict__ probs) {
+    constexpr bool SPLIT = AR != vadx::VADX_AR_F32;
+    typedef typename FrSchemeOf<AR>::type SC;
+    float amax = 0.f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *mem = lds, *p = lds + MEM_F, *h = p + P_F;
     const int tid = threadIdx.x;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float 
     for (int e = tid; e < ((FR_EXP & 32) ? 0 : MAXP * M_LD); e += THREADS) p[e] = 0.f;
     __syncthreads();
     // dfsmn.fc1 (80->H, ReLU) ; dfsmn.fc2 (H->P, bias, ReLU) ; fsmn1
-    if (SPLIT) pointwise_pair_split<3>(d, Pk + d.q_fc1, Pk + d.off_fc1b, NMEL, mem, Pk + d.q_fc2, Pk + d.off_fc2b, true, p, h);
+    if (SPLIT) pointwise_pair_split<SC, 3>(d, Pk + d.q_fc1, Pk + d.off_fc1b, NMEL, mem, Pk + d.q_fc2, Pk + d.off_fc2b, true, p, h, amax);
     else pointwise_pair(d, Pk + d.off_fc1, Pk + d.off_fc1b, NMEL / 16, mem, Pk + d.off_fc2, Pk + d.off_fc2b, 1, p, h);
     for (int e = tid; e < ((FR_EXP & 32) ? 0 : MAXP * M_LD); e += THREADS) mem[e] = 0.f;        // log-mel rows are dead now
     __syncthreads();
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float 
     tk_fir += clock64() - tk_x;
     for (int r = 1; r < d.R; ++r) {      // DFSMNBlock: fc1 (P->H, ReLU) ; fc2 (H->P, no bias) ; fsmn + skip
         tk_x = clock64();
-        if (SPLIT) pointwise_pair_split<4>(d, Pk + d.q_bfc1[r], Pk + d.off_bfc1b[r], d.Pp, mem, Pk + d.q_bfc2[r], nullptr, false, p, h);
+        if (SPLIT) pointwise_pair_split<SC, 4>(d, Pk + d.q_bfc1[r], Pk + d.off_bfc1b[r], d.Pp, mem, Pk + d.q_bfc2[r], nullptr, false, p, h, amax);
         else pointwise_pair(d, Pk + d.off_bfc1[r], Pk + d.off_bfc1b[r], d.Pp / 16, mem, Pk + d.off_bfc2[r], nullptr, 0, p, h);
         tk_pw += clock64() - tk_x;
         tk_x = clock64();
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float 
         float *dbg = probs + (size_t)blockIdx.x * d.odim * d.T;
         dbg[0] = (float)tk_fir; dbg[1] = (float)tk_pw; dbg[2] = (float)(clock64() - tk0);
     }
+    if (AR == vadx::VADX_AR_H2) vadx::range_flag_raise(Pk + d.off_flag, amax);
 }
 
 // ---- streaming variant (FireRedVAD/Export_FireRedVAD.py:479-612): no look-ahead, the look-back context
@@ -700,15 +705,18 @@ extern "C" int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_fi
         vadx::frag_major_inplace(p + d.off_bfc2[r], d.Pp, d.Hp);
     }
     for (int m = 0; m < d.M; ++m) vadx::frag_major_inplace(p + d.off_dnn[m], d.Hp, m == 0 ? d.Pp : d.Hp);
-    if (d.split_ok) {        // bf16 x 3 A fragments [n-tile][chunk][plane][QFRAG] from the ORIGINAL row-major weights
+    if (d.np) {              // split A fragments [n-tile][chunk][np planes][QFRAG] from the ORIGINAL row-major weights, in cfg->arithmetic
+        float wmax = 0.f;
         auto qmat = [&](int off, int rows_p, int nch, const float *W, int rows, int cols) {
             for (int nt = 0; nt < rows_p / 16; ++nt)
                 for (int kc = 0; kc < nch; ++kc) {
-                    float *f3 = p + off + (size_t)((nt * nch + kc) * 3) * vadx::QFRAG;
+                    float *f3 = p + off + (size_t)((nt * nch + kc) * d.np) * vadx::QFRAG;
                     for (int i = 0; i < 16; ++i)
                         for (int k = 0; k < 32; ++k) {
                             const int r = 16 * nt + i, c = 32 * kc + k;
-                            vadx::qfrag_put(f3, i, k, (r < rows && c < cols) ? W[(size_t)r * cols + c] : 0.f);
+                            const float v = (r < rows && c < cols) ? W[(size_t)r * cols + c] : 0.f;
+                            if (d.np == 3) vadx::SchemeB3::put_host(f3, i, k, v, wmax);
+                            else vadx::SchemeH2::put_host(f3, i, k, v, wmax);
                         }
                 }
         };
@@ -718,7 +726,24 @@ extern "C" int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_fi
             qmat(d.q_bfc1[r], d.Hp, 4, w->blk_fc1_w[r], d.H, d.P);
             qmat(d.q_bfc2[r], d.Pp, 8, w->blk_fc2_w[r], d.P, d.H);
         }
+        VADX_REQUIRE(d.arith != vadx::VADX_AR_H2 || wmax <= vadx::H_MAX,
+                     "vadx_firered_pack_host: a weight (|w| up to %g) is outside the fp16 range: pack with cfg->arithmetic = VADX_ARITH_BF16X3", wmax);
     }
+    return VADX_OK;
+}
+
+// The fp16 x 2 kernel's sticky range flag (as vadx_silero_range_flag)
+extern "C" int vadx_firered_range_flag(const vadx_firered_cfg *cfg, const float *packed, int reset, uint32_t *flag_host, float *amax_host, void *stream) {
+    Dev d;
+    VADX_REQUIRE(cfg && packed && flag_host, "vadx_firered_range_flag: NULL argument");
+    VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_firered_range_flag: unsupported config");
+    uint32_t w[2] = {0, 0};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VADX_HIP_TRY(hipMemcpyAsync(w, packed + d.off_flag, sizeof(w), hipMemcpyDeviceToHost, st));
+    VADX_HIP_TRY(hipStreamSynchronize(st));
+    if (reset && (w[0] | w[1])) VADX_HIP_TRY(hipMemsetAsync(const_cast<float *>(packed) + d.off_flag, 0, sizeof(w), st));
+    *flag_host = w[0];
+    if (amax_host) memcpy(amax_host, &w[1], sizeof(float));
     return VADX_OK;
 }
 
@@ -728,12 +753,15 @@ extern "C" int vadx_firered_run(const vadx_firered_cfg *cfg, const float *packed
     VADX_REQUIRE(cfg && packed && logmel && probs, "vadx_firered_run: NULL argument");
     VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_firered_run: unsupported config");
     VADX_REQUIRE(windows > 0, "vadx_firered_run: windows must be positive");
-    VADX_DYN_LDS(firered_kernel<false>, LDS_FLOATS * sizeof(float));
-    VADX_DYN_LDS(firered_kernel<true>, LDS_FLOATS * sizeof(float));
-    if (vadx::gemm_mode() == 1 && d.split_ok)
-        hipLaunchKernelGGL(firered_kernel<true>, dim3(windows), dim3(THREADS), LDS_FLOATS * sizeof(float), static_cast<hipStream_t>(stream), d, packed, logmel, probs);
+    VADX_DYN_LDS(firered_kernel<0>, LDS_FLOATS * sizeof(float));
+    VADX_DYN_LDS(firered_kernel<1>, LDS_FLOATS * sizeof(float));
+    VADX_DYN_LDS(firered_kernel<2>, LDS_FLOATS * sizeof(float));
+    if (d.arith == vadx::VADX_AR_H2)
+        hipLaunchKernelGGL(firered_kernel<2>, dim3(windows), dim3(THREADS), LDS_FLOATS * sizeof(float), static_cast<hipStream_t>(stream), d, packed, logmel, probs);
+    else if (d.arith == vadx::VADX_AR_B3)
+        hipLaunchKernelGGL(firered_kernel<1>, dim3(windows), dim3(THREADS), LDS_FLOATS * sizeof(float), static_cast<hipStream_t>(stream), d, packed, logmel, probs);
     else
-        hipLaunchKernelGGL(firered_kernel<false>, dim3(windows), dim3(THREADS), LDS_FLOATS * sizeof(float),
+        hipLaunchKernelGGL(firered_kernel<0>, dim3(windows), dim3(THREADS), LDS_FLOATS * sizeof(float),
                            static_cast<hipStream_t>(stream), d, packed, logmel, probs);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;

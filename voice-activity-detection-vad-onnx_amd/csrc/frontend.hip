@@ -90,6 +90,11 @@ struct Dev {
     int tiles64, tail_mt;   // 64-frame tiles of a window, then ONE tail tile of tail_mt m-tiles (0: none; 1 - 3: 16 - 48 frames)
     // split-product dense DFT (cfg.fold == 4): A fragments of the reference table at off_fold, [bin tile][re | im][32-tap chunk][plane][QFRAG]
     int s_nch, s_nbt;       // 32-tap chunks of a table row; 16-bin tiles (the last one zero-padded)
+    // cfg.fold == 5: the same product on fp16 x 2 split operands (split_scheme.h: SchemeH2, two planes per fragment).  The prepped samples
+    // are bounded by the int16 input, so they are pre-scaled by a power of two that puts their bound at 2^15 (inside the fp16 range, far
+    // above its subnormals) and the power is scaled back -- both exact: no range check is needed here.
+    int s_np;               // planes per fragment: 3 (fold 4) or 2 (fold 5)
+    float s_xs, s_ps;       // sample pre-scale 2^e, power post-scale 2^(-2e) (1, 1 for fold 4)
 };
 
 static int round16(int x) { return (x + 15) & ~15; }
@@ -356,15 +361,25 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
     d->tiles16 = (rem + 15) / 16;
     if (rem > 16) { d->tiles32 += 1; d->tiles16 = 0; }
     d->out_stride = c->n_mels; d->out_off = 0;
-    if (c->fold == 4) {
-        // dense product on bf16 x 3 split operands (frontend_split_kernel): the flat sample planes need hop = 160 (their skew), the
-        // staging knows the int16 preps 0 - 2
+    if (c->fold == 4 || c->fold == 5) {
+        // dense product on split operands (frontend_split_kernel; 4 = bf16 x 3, 5 = fp16 x 2): the flat sample planes need hop = 160 (their
+        // skew), the staging knows the int16 preps 0 - 2
         if (c->hop != 160 || c->prep > 2 || c->taps > 512 || c->n_bins > 17 * 16) return -1;
-        d->fold = 4;
+        d->fold = c->fold;
+        d->s_np = c->fold == 4 ? 3 : 2;
+        d->s_xs = d->s_ps = 1.f;
+        if (c->fold == 5) {
+            // |prepped sample| <= bound: prep 0 (x - mean) - 0.97 (x[-1] - mean) with |x - mean| < 65536; prep 1 k0 x[-1] + k1 x; prep 2 k1 x - mean
+            const double bound = c->prep == 0 ? 65536.0 * 1.97 : (c->prep == 1 ? 32768.0 * (fabs((double)c->k0) + fabs((double)c->k1)) : 65536.0 * fabs((double)c->k1));
+            if (!(bound > 0.0) || !(bound < 1e30)) return -1;
+            const int e = (int)floor(log2(32768.0 / bound));
+            d->s_xs = (float)ldexp(1.0, e);
+            d->s_ps = (float)ldexp(1.0, -2 * e);
+        }
         d->s_nch = (c->taps + 31) / 32;
         d->s_nbt = (c->n_bins + 15) / 16;
         d->off_fold = d->off_mel + d->n_mels * d->Fp;
-        d->off_plan = d->off_fold + d->s_nbt * 2 * d->s_nch * 3 * vadx::QFRAG;
+        d->off_plan = d->off_fold + d->s_nbt * 2 * d->s_nch * d->s_np * vadx::QFRAG;
         d->tiles64 = c->frames / TF_FOLD;
         const int rem64 = c->frames - d->tiles64 * TF_FOLD;
         d->tail_mt = (rem64 + 15) / 16;
@@ -413,7 +428,7 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
 }
 
 static size_t packed_total(const Dev &d) {
-    if (d.fold == 4) return (size_t)d.off_plan + 2 * MAX_MEL_TILES + 4;                       // + the mel bands
+    if (d.fold == 4 || d.fold == 5) return (size_t)d.off_plan + 2 * MAX_MEL_TILES + 4;       // + the mel bands
     if (d.fold == 3) return (size_t)d.off_plan + (size_t)d.f_Pb * 32 + 2 * MAX_MEL_TILES;      // [block][quarter][offA x 4 | offB x 4], then the mel bands
     if (d.fold) return (size_t)d.off_plan + 4 * MAX_REGIONS + 2 * MAX_MEL_TILES + 4;      // + last-bin mode (one int, padded to four)
     return (size_t)d.off_mel + (size_t)d.n_mels * d.Fp;
@@ -1134,9 +1149,11 @@ static size_t split_lds_bytes(const Dev *d) {
 // Four waves per workgroup and <= 80 KB of LDS: TWO workgroups per CU, each in a phase of its own -- one stages or runs its mel GEMM
 // (VALU, loads, f32 MFMA) while the other's split products own the bf16 pipe.  The power rows take the PLANES' place: a wave keeps the
 // power of its bin tiles in registers (<= 4 rounds x MT fragments) until every wave has read its last sample block.
-template <int MT>
+template <typename SC, int MT>
 __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict__ P, const int16_t *__restrict__ win, float mean,
                                            int f0, float *__restrict__ out_win, unsigned char *smem) {
+    constexpr int NP = SC::NP;
+    float amax = 0.f;             // (the samples are bounded by construction, see Dev::s_xs: nothing reads this)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
@@ -1168,16 +1185,15 @@ __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict
                 } else {                      // scale, then remove the window mean
                     r = __fsub_rn(__fmul_rn(xc, d.k1), mean);
                 }
-                v[e >> 2][e & 3] = (n >= 0 && n < d.window_len) ? r : 0.f;
+                v[e >> 2][e & 3] = (n >= 0 && n < d.window_len) ? (NP == 2 ? __fmul_rn(r, d.s_xs) : r) : 0.f;
             }
-            u32x2 a0, a1, a2, b0v, b1v, b2v;
-            vadx::split3x4(v[0], a0, a1, a2);
-            vadx::split3x4(v[1], b0v, b1v, b2v);
+            u32x2 pa[NP], pb[NP];
+            SC::split4(v[0], pa, amax);
+            SC::split4(v[1], pb, amax);
             unsigned char *dp = smem + sq_slot(b0) * 16;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<u32x4 *>(dp) = u32x4{a0[0], a0[1], b0v[0], b0v[1]};
-            *reinterpret_cast<u32x4 *>(dp + SQ_PLANE_BYTES) = u32x4{a1[0], a1[1], b1v[0], b1v[1]};
-            *reinterpret_cast<u32x4 *>(dp + 2 * SQ_PLANE_BYTES) = u32x4{a2[0], a2[1], b2v[0], b2v[1]};
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4 *>(dp + p * SQ_PLANE_BYTES) = u32x4{pa[p][0], pa[p][1], pb[p][0], pb[p][1]};
         }
     }
     FE_ACC(4);
@@ -1185,7 +1201,7 @@ __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict
     FE_ACC(0);
     // ---- phase 1: DFT as split products, |.|^2 kept in registers
     const float *tab = P + d.off_fold;
-    const size_t tstride = (size_t)d.s_nch * 3 * vadx::QFRAG;
+    const size_t tstride = (size_t)d.s_nch * NP * vadx::QFRAG;
     // rounds of four bin tiles; one leftover tile (17 = 4 x 4 + 1, 13 = 3 x 4 + 1) goes out as (bin tile, column tile) items instead of
     // a round with one busy wave; two or three leftover tiles are a (partial) round of their own (s_nbt <= 17: at most four rounds)
     const int rem = d.s_nbt & 3, rounds = (d.s_nbt >> 2) + (rem > 1 ? 1 : 0);
@@ -1199,15 +1215,17 @@ __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { hi[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][mt] = hi[a][mt]; }
         const float *const w[2] = {tab + (size_t)(2 * bt) * tstride, tab + (size_t)(2 * bt + 1) * tstride};
-        vadx::qgemm_group<2, MT, true>(hi, lo, w, 0, d.s_nch, smem, SQ_PLANE_BYTES,
+        vadx::qgemm_group<SC, 2, MT, true>(hi, lo, w, 0, d.s_nch, smem, SQ_PLANE_BYTES,
                                        [=](int G, int mt) { return sq_slot(20 * (16 * mt + i) + G) * 16; }, lane);
         f32x4 p[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const float re = hi[0][mt][rr] + lo[0][mt][rr], im = hi[1][mt][rr] + lo[1][mt][rr];
+                const f32x4 rev = SC::join(hi[0][mt], lo[0][mt]), imv = SC::join(hi[1][mt], lo[1][mt]);
+                const float re = rev[rr], im = imv[rr];
                 p[mt][rr] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+                if (NP == 2) p[mt][rr] = __fmul_rn(p[mt][rr], d.s_ps);
             }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {         // (constant indices: the rows stay in registers)
@@ -1223,12 +1241,14 @@ __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict
 #pragma unroll
         for (int a = 0; a < 2; ++a) { hi[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][0] = hi[a][0]; }
         const float *const w[2] = {tab + (size_t)(2 * bt) * tstride, tab + (size_t)(2 * bt + 1) * tstride};
-        vadx::qgemm_group<2, 1, true>(hi, lo, w, 0, d.s_nch, smem, SQ_PLANE_BYTES,
+        vadx::qgemm_group<SC, 2, 1, true>(hi, lo, w, 0, d.s_nch, smem, SQ_PLANE_BYTES,
                                       [=](int G, int) { return sq_slot(20 * (16 * mt1 + i) + G) * 16; }, lane);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const float re = hi[0][0][rr] + lo[0][0][rr], im = hi[1][0][rr] + lo[1][0][rr];
+            const f32x4 rev = SC::join(hi[0][0], lo[0][0]), imv = SC::join(hi[1][0], lo[1][0]);
+            const float re = rev[rr], im = imv[rr];
             pl[rr] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+            if (NP == 2) pl[rr] = __fmul_rn(pl[rr], d.s_ps);
         }
     }
     FE_ACC(1);
@@ -1252,6 +1272,7 @@ __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict
     FE_ACC(3);
 }
 
+template <typename SC>
 __global__ __launch_bounds__(SQ_THREADS, 2) void frontend_split_kernel(
     Dev d, const float *__restrict__ P, const int16_t *__restrict__ audio, long long row_stride,
     long long win_stride, int windows_per_clip, const float *__restrict__ means, float *__restrict__ out) {
@@ -1265,10 +1286,10 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void frontend_split_kernel(
 #if FE_EXP
     const long long fe_c0 = clock64(), fe_w0 = wall_clock64();
 #endif
-    if (tile < d.tiles64) split_tile<4>(d, P, win, mean, tile * TF_FOLD, out_win, fsmem);
-    else if (d.tail_mt == 3) split_tile<3>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
-    else if (d.tail_mt == 2) split_tile<2>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
-    else split_tile<1>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
+    if (tile < d.tiles64) split_tile<SC, 4>(d, P, win, mean, tile * TF_FOLD, out_win, fsmem);
+    else if (d.tail_mt == 3) split_tile<SC, 3>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
+    else if (d.tail_mt == 2) split_tile<SC, 2>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
+    else split_tile<SC, 1>(d, P, win, mean, d.tiles64 * TF_FOLD, out_win, fsmem);
 #if FE_EXP
     if (threadIdx.x == 0) {     // shader clock against the constant 100 MHz counter
         atomicAdd(&fe_dbg[5], (unsigned long long)(clock64() - fe_c0));
@@ -1392,18 +1413,21 @@ extern "C" int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float
     vadx::frag_major_inplace(packed_host + d.off_dft, d.nbt * 32, d.Kp);
     if (d.nyq) vadx::frag_major_inplace(packed_host + d.off_nyq, 16, d.Kp);
     vadx::frag_major_inplace(packed_host + d.off_mel, d.n_mels, d.Fp);
-    if (d.fold == 4) {          // the reference table itself, split exactly into three bf16 planes: [bin tile][re | im][chunk][plane][QFRAG]
+    if (d.fold == 4 || d.fold == 5) {   // the reference table itself as split fragments (three bf16 planes, exact, or two fp16 planes): [bin tile][re | im][chunk][plane][QFRAG]
+        float wmax = 0.f;
         for (int bt = 0; bt < d.s_nbt; ++bt)
             for (int part = 0; part < 2; ++part)
                 for (int kc = 0; kc < d.s_nch; ++kc) {
-                    float *f3 = packed_host + d.off_fold + (size_t)(((bt * 2 + part) * d.s_nch + kc) * 3) * vadx::QFRAG;
+                    float *f3 = packed_host + d.off_fold + (size_t)(((bt * 2 + part) * d.s_nch + kc) * d.s_np) * vadx::QFRAG;
                     for (int i = 0; i < 16; ++i)
                         for (int k = 0; k < 32; ++k) {
                             const int f = bt * 16 + i, t = 32 * kc + k;
                             const float v = (f < d.n_bins && t < d.taps) ? (part ? sin_tab : cos_tab)[(size_t)f * n_fft + cfg->tap0 + t] : 0.f;
-                            vadx::qfrag_put(f3, i, k, v);
+                            if (d.s_np == 3) vadx::SchemeB3::put_host(f3, i, k, v, wmax);
+                            else vadx::SchemeH2::put_host(f3, i, k, v, wmax);
                         }
                 }
+        VADX_REQUIRE(d.fold != 5 || wmax <= vadx::H_MAX, "vadx_frontend_pack_host: a table entry (|.| up to %g) is outside the fp16 range: use fold = 4", wmax);
         int32_t *pi = reinterpret_cast<int32_t *>(packed_host + d.off_plan);
         for (int mt = 0; mt < d.nmt; ++mt) { pi[2 * mt] = mel_kb[2 * mt]; pi[2 * mt + 1] = mel_kb[2 * mt + 1]; }
         return VADX_OK;
@@ -1572,14 +1596,20 @@ extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *p
         VADX_HIP_TRY(hipGetLastError());
         means = means_ws;
     }
-    if (d.fold == 4) {
+    if (d.fold == 4 || d.fold == 5) {
         const size_t slds = split_lds_bytes(&d);
         VADX_REQUIRE(slds <= 160 * 1024, "vadx_frontend_logmel: geometry needs %zu B of LDS", slds);
         const long long nblk = nwin * (d.tiles64 + (d.tail_mt ? 1 : 0));
         VADX_REQUIRE(nblk < (1LL << 31), "vadx_frontend_logmel: too many tiles");
-        VADX_DYN_LDS(frontend_split_kernel, 160 * 1024);
-        hipLaunchKernelGGL(frontend_split_kernel, dim3((unsigned)nblk), dim3(SQ_THREADS), slds, st, d, packed, audio, (long long)row_stride,
-                           (long long)win_stride, windows_per_clip, means, out);
+        if (d.fold == 4) {
+            VADX_DYN_LDS(frontend_split_kernel<vadx::SchemeB3>, 160 * 1024);
+            hipLaunchKernelGGL(frontend_split_kernel<vadx::SchemeB3>, dim3((unsigned)nblk), dim3(SQ_THREADS), slds, st, d, packed, audio, (long long)row_stride,
+                               (long long)win_stride, windows_per_clip, means, out);
+        } else {
+            VADX_DYN_LDS(frontend_split_kernel<vadx::SchemeH2>, 160 * 1024);
+            hipLaunchKernelGGL(frontend_split_kernel<vadx::SchemeH2>, dim3((unsigned)nblk), dim3(SQ_THREADS), slds, st, d, packed, audio, (long long)row_stride,
+                               (long long)win_stride, windows_per_clip, means, out);
+        }
         VADX_HIP_TRY(hipGetLastError());
         return VADX_OK;
     }

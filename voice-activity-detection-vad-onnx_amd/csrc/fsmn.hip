@@ -55,7 +55,9 @@ struct Dev {
     int off_in1, off_b1, off_mean, off_var, off_in2, off_b2;
     int off_lin[NLAYER], off_fir[NLAYER], off_aff[NLAYER], off_baff[NLAYER];
     int off_out1, off_bo1, off_out2, off_bo2, total;
-    // bf16 x 3 split-product copies of the dense layers (layers_split.h): A fragments [n-tile][32-k chunk][plane][QFRAG]
+    // split-product copies of the dense layers (layers_split.h): A fragments [n-tile][32-k chunk][np planes][QFRAG] of ONE arithmetic, the one
+    // dims->arithmetic names (split_scheme.h: np = 3 for bf16 x 3, 2 for fp16 x 2, 0 = none: float32 MFMAs on the fragment-major matrices)
+    int arith, np, off_flag;                        // off_flag: [sticky range flag, bits of the largest |x|, pad, pad] of the fp16 x 2 kernels
     int split_ok;                                   // 0: dims outside the split tile's LDS map (Ap, A2p <= 160, Lp, Op <= 256)
     int nch_A, nch_L, nch_A2;                       // 32-k chunks of an A- / L- / A2-wide input
     int q_in1, q_b1, q_mbar, q_in2, q_lin[NLAYER], q_aff[NLAYER], q_out1, q_out2;
@@ -83,14 +85,20 @@ static int derive(const vadx_fsmn_dims *c, Dev *d) {
     d->off_out2 = take(d->Op * d->A2p); d->off_bo2 = take(d->Op);
     d->nch_A = (d->Ap + 31) / 32; d->nch_L = (d->Lp + 31) / 32; d->nch_A2 = (d->A2p + 31) / 32;
     d->split_ok = d->Ap <= 160 && d->A2p <= 160 && d->Lp <= 256 && d->Op <= 256;
-    d->q_in1 = take(d->Ap / 16 * NCH_IN1 * 3 * QFRAG); d->q_b1 = take(d->Ap); d->q_mbar = take(NMEL);
-    d->q_in2 = take(d->Lp / 16 * d->nch_A * 3 * QFRAG);
+    // AUTO = fp16 x 2 where the split tile fits, float32 MFMAs otherwise; an explicit split arithmetic on dims outside the tile is refused
+    d->arith = vadx::arith_internal(c->arithmetic, d->split_ok ? vadx::VADX_AR_H2 : vadx::VADX_AR_F32);
+    if (d->arith < 0 || (d->arith != vadx::VADX_AR_F32 && !d->split_ok)) return -1;
+    d->np = d->arith == vadx::VADX_AR_B3 ? 3 : (d->arith == vadx::VADX_AR_H2 ? 2 : 0);
+    const int np = d->np;
+    d->q_in1 = take(d->Ap / 16 * NCH_IN1 * np * QFRAG); d->q_b1 = take(d->Ap); d->q_mbar = take(NMEL);
+    d->q_in2 = take(d->Lp / 16 * d->nch_A * np * QFRAG);
     for (int l = 0; l < NLAYER; ++l) {
-        d->q_lin[l] = take(PROJ / 16 * d->nch_L * 3 * QFRAG);
-        d->q_aff[l] = take(d->Lp / 16 * (PROJ / 32) * 3 * QFRAG);
+        d->q_lin[l] = take(PROJ / 16 * d->nch_L * np * QFRAG);
+        d->q_aff[l] = take(d->Lp / 16 * (PROJ / 32) * np * QFRAG);
     }
-    d->q_out1 = take(d->A2p / 16 * d->nch_L * 3 * QFRAG);
-    d->q_out2 = take(d->Op / 16 * d->nch_A2 * 3 * QFRAG);
+    d->q_out1 = take(d->A2p / 16 * d->nch_L * np * QFRAG);
+    d->q_out2 = take(d->Op / 16 * d->nch_A2 * np * QFRAG);
+    d->off_flag = take(4);
     d->total = o;
     return 0;
 }
@@ -266,12 +274,13 @@ static_assert(SQ_HLM + 256 * 64 * 6 <= SQ_ARENA && SQ_FOH + 128 * 64 * 6 <= SQ_A
               SQ_LOG + 256 * A_LD * 4 <= SQ_ARENA && SQ_LM + 11 * 80 * 16 * 3 <= SQ_ARENA && 160 * 64 * 6 <= SQ_HLM && SQ_LDS_BYTES <= 160 * 1024,
               "split tile LDS map");
 
-template <int MTT>
+template <typename SC, int MTT>
 __device__ __forceinline__ void tile_split(const Dev &d, const float *__restrict__ Pk, const float *__restrict__ lm,
                                            int f0, int nvalid, const float *const *cin, float *const *cout,
-                                           unsigned char *smem, float *ps, float *red) {
+                                           unsigned char *smem, float *ps, float *red, float &amax) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
+    constexpr int NP = SC::NP;
     constexpr int NF = MTT * 16, NCL = NF + 16;             // columns of a plane row: frames (log-mel: + LFR context)
     const int lane = tid & 63, i = lane & 15;
     auto grp_pl = [](int kgrps, int ncol) { return kgrps * ncol * 16; };      // bytes of one plane
@@ -280,11 +289,11 @@ __device__ __forceinline__ void tile_split(const Dev &d, const float *__restrict
     // ---- zero rows: k-groups of the A-wide tensors beyond Ap (their weights are zero, the operand must be finite), the log-mel's row 10
     {
         const int kg0 = d.Ap / 8, kg1 = 4 * d.nch_A, pl = grp_pl(kg1, NF);
-        for (int e = tid; e < 3 * (kg1 - kg0) * NF; e += THREADS) {
+        for (int e = tid; e < NP * (kg1 - kg0) * NF; e += THREADS) {
             const int p = e / ((kg1 - kg0) * NF), r = e - p * (kg1 - kg0) * NF;
             *reinterpret_cast<f32x4 *>(smem + SQ_H + p * pl + (kg0 * NF + r) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        for (int e = tid; e < 3 * NCL; e += THREADS) {
+        for (int e = tid; e < NP * NCL; e += THREADS) {
             const int p = e / NCL, c = e - p * NCL;
             *reinterpret_cast<f32x4 *>(smem + SQ_LM + p * grp_pl(11, NCL) + (10 * NCL + c) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -305,12 +314,11 @@ __device__ __forceinline__ void tile_split(const Dev &d, const float *__restrict
             const int e = tid + THREADS * u, c = e / (NMEL / 4), mg = e - c * (NMEL / 4);
             if (e < NE) {
                 const f32x4 x = v[u] + ldg4(Pk + d.q_mbar + 4 * mg);
-                u32x2 p0, p1, p2;
-                split3x4(x, p0, p1, p2);
+                u32x2 pp[NP];
+                SC::split4(x, pp, amax);
                 unsigned char *dp = smem + SQ_LM + ((mg >> 1) * NCL + c) * 16 + (mg & 1) * 8;
-                *reinterpret_cast<u32x2 *>(dp) = p0;
-                *reinterpret_cast<u32x2 *>(dp + grp_pl(11, NCL)) = p1;
-                *reinterpret_cast<u32x2 *>(dp + 2 * grp_pl(11, NCL)) = p2;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2 *>(dp + p * grp_pl(11, NCL)) = pp[p];
             }
         }
     }
@@ -322,7 +330,7 @@ __device__ __forceinline__ void tile_split(const Dev &d, const float *__restrict
     QLayerArgs a;
     // in_linear1: K = 5 LFR positions x 80 mels = 50 k-groups; k-group G = (position j = G / 10, mel group G % 10) reads column + j
     a = QLayerArgs{Pk + d.q_in1, d.Ap / 16, NCH_IN1, Pk + d.q_b1, 0, smem + SQ_LM, grp_pl(11, NCL), smem + SQ_H, grp_pl(4 * d.nch_A, NF), NF, nullptr};
-    qlayer<MTT, true>(a, [=](int G, int mt) { const int j = G / 10, mg = G - 10 * j; return G < 50 ? (mg * NCL + mt * 16 + i + j) * 16 : (10 * NCL + mt * 16 + i) * 16; });
+    qlayer<SC, MTT, true>(a, [=](int G, int mt) { const int j = G / 10, mg = G - 10 * j; return G < 50 ? (mg * NCL + mt * 16 + i + j) * 16 : (10 * NCL + mt * 16 + i) * 16; }, amax);
     FS_ACC(1);
     __syncthreads();
     FS_ACC(9);
@@ -335,7 +343,7 @@ __device__ __forceinline__ void tile_split(const Dev &d, const float *__restrict
     cache_fetch(0, hv);
     // in_linear2 + ReLU
     a = QLayerArgs{Pk + d.q_in2, d.Lp / 16, d.nch_A, Pk + d.off_b2, 1, smem + SQ_H, grp_pl(4 * d.nch_A, NF), smem + SQ_HLM, grp_pl(4 * d.nch_L, NF), NF, nullptr};
-    qlayer<MTT, true>(a, plain(NF));
+    qlayer<SC, MTT, true>(a, plain(NF), amax);
     FS_ACC(2);
     __syncthreads();
     FS_ACC(9);
@@ -355,7 +363,7 @@ __device__ __forceinline__ void tile_split(const Dev &d, const float *__restrict
         }
         FS_ACC(3);
         a = QLayerArgs{Pk + d.q_lin[l], PROJ / 16, d.nch_L, nullptr, 0, HLin, grp_pl(4 * d.nch_L, NF), reinterpret_cast<unsigned char *>(bufP), P_CUR, P_LD, nullptr};
-        qlayer<MTT, false>(a, plain(NF));
+        qlayer<SC, MTT, false>(a, plain(NF), amax);
         FS_ACC(4);
         // the FIR taps of this thread's four channels (80 floats) are requested BEFORE the barrier: their L2 round trip hides behind the
         // wait for the slowest wave of the GEMM instead of opening the FIR (per channel: load, wait, 80 FMAs -- four times in a row)
@@ -395,12 +403,11 @@ __device__ __forceinline__ void tile_split(const Dev &d, const float *__restrict
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    u32x2 p0, p1, p2;
-                    split3x4(o[t], p0, p1, p2);
+                    u32x2 pp[NP];
+                    SC::split4(o[t], pp, amax);
                     unsigned char *dp = FO + ((cg >> 1) * NF + 4 * fg + t) * 16 + (cg & 1) * 8;
-                    *reinterpret_cast<u32x2 *>(dp) = p0;
-                    *reinterpret_cast<u32x2 *>(dp + grp_pl(PROJ / 8, NF)) = p1;
-                    *reinterpret_cast<u32x2 *>(dp + 2 * grp_pl(PROJ / 8, NF)) = p2;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2 *>(dp + p * grp_pl(PROJ / 8, NF)) = pp[p];
                 }
             }
             for (int e = tid; e < PROJ * HIST; e += THREADS) {            // new cache = last 19 entries of (history ++ valid frames)
@@ -412,24 +419,24 @@ __device__ __forceinline__ void tile_split(const Dev &d, const float *__restrict
         __syncthreads();
         FS_ACC(9);
         a = QLayerArgs{Pk + d.q_aff[l], d.Lp / 16, PROJ / 32, Pk + d.off_baff[l], 1, FO, grp_pl(PROJ / 8, NF), HLout, grp_pl(4 * d.nch_L, NF), NF, nullptr};
-        qlayer<MTT, true>(a, plain(NF));
+        qlayer<SC, MTT, true>(a, plain(NF), amax);
         FS_ACC(6);
         __syncthreads();
         FS_ACC(9);
     }
     {   // zero rows of the A2-wide tensor (region 0 is free again)
         const int kg0 = d.A2p / 8, kg1 = 4 * d.nch_A2, pl = grp_pl(kg1, NF);
-        for (int e = tid; e < 3 * (kg1 - kg0) * NF; e += THREADS) {
+        for (int e = tid; e < NP * (kg1 - kg0) * NF; e += THREADS) {
             const int p = e / ((kg1 - kg0) * NF), r = e - p * (kg1 - kg0) * NF;
             *reinterpret_cast<f32x4 *>(smem + SQ_H + p * pl + (kg0 * NF + r) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     a = QLayerArgs{Pk + d.q_out1, d.A2p / 16, d.nch_L, Pk + d.off_bo1, 0, smem + SQ_HLM, grp_pl(4 * d.nch_L, NF), smem + SQ_H, grp_pl(4 * d.nch_A2, NF), NF, nullptr};
-    qlayer<MTT, true>(a, plain(NF));
+    qlayer<SC, MTT, true>(a, plain(NF), amax);
     __syncthreads();
     float *logits = reinterpret_cast<float *>(smem + SQ_LOG);
     a = QLayerArgs{Pk + d.q_out2, d.Op / 16, d.nch_A2, Pk + d.off_bo2, 0, smem + SQ_H, grp_pl(4 * d.nch_A2, NF), reinterpret_cast<unsigned char *>(logits), 0, A_LD, nullptr};
-    qlayer<MTT, false>(a, plain(NF));
+    qlayer<SC, MTT, false>(a, plain(NF), amax);
     FS_ACC(7);
     __syncthreads();
     FS_ACC(9);
@@ -488,9 +495,14 @@ __device__ __forceinline__ float gate(const Dev &d, const float *ps, const float
     return tot / cnt;                      // 0/0 -> NaN like torch's mean of an empty tensor
 }
 
-template <bool SPLIT>
+// AR: the arithmetic of the dense layers (split_scheme.h: 0 float32 MFMAs, 1 bf16 x 3, 2 fp16 x 2)
+template <int AR> struct SchemeOf { typedef vadx::SchemeB3 type; };
+template <> struct SchemeOf<vadx::VADX_AR_H2> { typedef vadx::SchemeH2 type; };
+template <int AR>
 __device__ __forceinline__ void run_chunk(const Dev &d, const float *Pk, const float *lm, const float *const *cin,
-                                          float *const *cout, float *lds) {
+                                          float *const *cout, float *lds, float &amax) {
+    constexpr bool SPLIT = AR != vadx::VADX_AR_F32;
+    typedef typename SchemeOf<AR>::type SC;
     float *bufA = lds, *bufB = lds + BUFA, *bufP = bufB + BUFB;
     float *small = SPLIT ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(lds) + SQ_ARENA) : bufP + BUFP;
     float *ps = small, *red = small + 128;
@@ -501,10 +513,10 @@ __device__ __forceinline__ void run_chunk(const Dev &d, const float *Pk, const f
         const int left = d.T - f0;
         const float *const *ci = first ? cin : cout;         // later tiles continue from the updated cache
         if (SPLIT) {
-            if (left > 48) tile_split<4>(d, Pk, lm, f0, left < 64 ? left : 64, ci, cout, smem, ps, red), f0 += 64;
-            else if (left > 32) tile_split<3>(d, Pk, lm, f0, left, ci, cout, smem, ps, red), f0 += 48;
-            else if (left > 16) tile_split<2>(d, Pk, lm, f0, left, ci, cout, smem, ps, red), f0 += 32;
-            else tile_split<1>(d, Pk, lm, f0, left, ci, cout, smem, ps, red), f0 += 16;
+            if (left > 48) tile_split<SC, 4>(d, Pk, lm, f0, left < 64 ? left : 64, ci, cout, smem, ps, red, amax), f0 += 64;
+            else if (left > 32) tile_split<SC, 3>(d, Pk, lm, f0, left, ci, cout, smem, ps, red, amax), f0 += 48;
+            else if (left > 16) tile_split<SC, 2>(d, Pk, lm, f0, left, ci, cout, smem, ps, red, amax), f0 += 32;
+            else tile_split<SC, 1>(d, Pk, lm, f0, left, ci, cout, smem, ps, red, amax), f0 += 16;
         } else {
             if (left > 48) tile<4>(d, Pk, lm, f0, left < 64 ? left : 64, ci, cout, bufA, bufB, bufP, ps, red), f0 += 64;
             else if (left > 32) tile<3>(d, Pk, lm, f0, left, ci, cout, bufA, bufB, bufP, ps, red), f0 += 48;
@@ -523,14 +535,17 @@ struct RunArgs {
 };
 
 // ORT-boundary equivalent: one chunk per stream, B independent streams.
-template <bool SPLIT>
+template <int AR>
 __global__ __launch_bounds__(THREADS, 2) void fsmn_run_kernel(Dev d, const float *__restrict__ Pk, RunArgs r) {
+    constexpr bool SPLIT = AR != vadx::VADX_AR_F32;
+    float amax = 0.f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x;
     const float *cin[NLAYER]; float *cout[NLAYER];
 #pragma unroll
     for (int l = 0; l < NLAYER; ++l) { cin[l] = r.cin[l] + (size_t)b * PROJ * HIST; cout[l] = r.cout[l] + (size_t)b * PROJ * HIST; }
-    run_chunk<SPLIT>(d, Pk, r.logmel + (size_t)b * d.T * NMEL, cin, cout, lds);
+    run_chunk<AR>(d, Pk, r.logmel + (size_t)b * d.T * NMEL, cin, cout, lds, amax);
+    if (AR == vadx::VADX_AR_H2) vadx::range_flag_raise(Pk + d.off_flag, amax);
     float *small = SPLIT ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(lds) + SQ_ARENA) : lds + BUFA + BUFB + BUFP;
     const float noisy = gate(d, small, r.db + (size_t)b * d.T, r.thr[b], r.noise_db[b], r.score + (size_t)b * d.T,
                              r.psil ? r.psil + (size_t)b * d.T : nullptr, small + 640, small + 128);
@@ -548,8 +563,10 @@ struct ClipArgs {
 };
 
 // Whole clips: the reference's while-loop (Inference_FSMN_VAD_ONNX.py:176-234), one workgroup per clip.
-template <bool SPLIT>
+template <int AR>
 __global__ __launch_bounds__(THREADS, 2) void fsmn_clips_kernel(Dev d, const float *__restrict__ Pk, ClipArgs c) {
+    constexpr bool SPLIT = AR != vadx::VADX_AR_F32;
+    float amax = 0.f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, tid = threadIdx.x;
     float *small = SPLIT ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(lds) + SQ_ARENA) : lds + BUFA + BUFB + BUFP;
@@ -566,7 +583,7 @@ __global__ __launch_bounds__(THREADS, 2) void fsmn_clips_kernel(Dev d, const flo
     unsigned char *fl = c.flags + (size_t)b * nflags;
     for (int k = 0; k < c.W; ++k) {
         const size_t widx = (size_t)b * c.W + k;
-        run_chunk<SPLIT>(d, Pk, c.logmel + widx * d.T * NMEL, cin, cout, lds);
+        run_chunk<AR>(d, Pk, c.logmel + widx * d.T * NMEL, cin, cout, lds, amax);
         const float noisy = gate(d, ps, c.db + widx * d.T, c.thr, noise, nullptr, nullptr, sc, red);
         // look-ahead vote: cnt[i] = #{ j in [1,lb) : sc[i+j] != 0 }
         if (tid < c.slide) {
@@ -597,6 +614,7 @@ __global__ __launch_bounds__(THREADS, 2) void fsmn_clips_kernel(Dev d, const flo
         if (c.noise_trace && tid == 0) c.noise_trace[widx] = noise;
         __syncthreads();
     }
+    if (AR == vadx::VADX_AR_H2) vadx::range_flag_raise(Pk + d.off_flag, amax);
 }
 
 // frame energy in dB/10 of the prepped window (FSMN/Export_FSMN_VAD.py:93-97): one workgroup per window
@@ -683,13 +701,19 @@ extern "C" int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_w
     }
     vadx::frag_major_inplace(p + d.off_out1, d.A2p, d.Lp);
     vadx::frag_major_inplace(p + d.off_out2, d.Op, d.A2p);
-    // ---- bf16 x 3 split-product copies (layers_split.h): A fragments [n-tile][chunk][plane][QFRAG] from the ORIGINAL row-major weights
+    // ---- split-product copies (layers_split.h): A fragments [n-tile][chunk][np planes][QFRAG] from the ORIGINAL row-major weights, in the
+    // arithmetic dims->arithmetic names (none for float32 MFMAs)
+    float wmax = 0.f;                                                  // largest |weight| handed to fp16 fragments
     auto qmat = [&](int off, int rows, int nch, auto wfn) {            // wfn(row, k) -> weight (0 outside the matrix)
+        if (d.np == 0) return;
         for (int nt = 0; nt < (rows + 15) / 16; ++nt)
             for (int kc = 0; kc < nch; ++kc) {
-                float *f3 = p + off + (size_t)((nt * nch + kc) * 3) * vadx::QFRAG;
+                float *fr = p + off + (size_t)((nt * nch + kc) * d.np) * vadx::QFRAG;
                 for (int i = 0; i < 16; ++i)
-                    for (int k = 0; k < 32; ++k) vadx::qfrag_put(f3, i, k, wfn(16 * nt + i, 32 * kc + k));
+                    for (int k = 0; k < 32; ++k) {
+                        if (d.np == 3) vadx::SchemeB3::put_host(fr, i, k, wfn(16 * nt + i, 32 * kc + k), wmax);
+                        else vadx::SchemeH2::put_host(fr, i, k, wfn(16 * nt + i, 32 * kc + k), wmax);
+                    }
             }
     };
     // in_linear1 with the CMVN folded in (double): W1' = W1 var, b1' = b1 + sum_k W1' (mean_k - mbar_{k % 80}), mbar = the centre LFR position's means
@@ -709,14 +733,33 @@ extern "C" int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_w
     }
     qmat(d.q_out1, d.A2p, d.nch_L, [&](int r, int k) { return (r < d.A2 && k < d.L) ? w->out1_w[(size_t)r * d.L + k] : 0.f; });
     qmat(d.q_out2, d.Op, d.nch_A2, [&](int r, int k) { return (r < d.O && k < d.A2) ? w->out2_w[(size_t)r * d.A2 + k] : 0.f; });
+    VADX_REQUIRE(d.arith != vadx::VADX_AR_H2 || wmax <= vadx::H_MAX,
+                 "vadx_fsmn_pack_host: a weight (|w| up to %g) is outside the fp16 range: pack with dims->arithmetic = VADX_ARITH_BF16X3", wmax);
+    return VADX_OK;
+}
+
+// The fp16 x 2 kernels' sticky range flag (as vadx_silero_range_flag): [flag, largest |x|] of the launches since the last reset.
+extern "C" int vadx_fsmn_range_flag(const vadx_fsmn_dims *dims, const float *packed, int reset, uint32_t *flag_host, float *amax_host, void *stream) {
+    Dev d;
+    VADX_REQUIRE(dims && packed && flag_host, "vadx_fsmn_range_flag: NULL argument");
+    VADX_REQUIRE(derive(dims, &d) == 0, "vadx_fsmn_range_flag: unsupported dims");
+    uint32_t w[2] = {0, 0};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VADX_HIP_TRY(hipMemcpyAsync(w, packed + d.off_flag, sizeof(w), hipMemcpyDeviceToHost, st));
+    VADX_HIP_TRY(hipStreamSynchronize(st));
+    if (reset && (w[0] | w[1])) VADX_HIP_TRY(hipMemsetAsync(const_cast<float *>(packed) + d.off_flag, 0, sizeof(w), st));
+    *flag_host = w[0];
+    if (amax_host) memcpy(amax_host, &w[1], sizeof(float));
     return VADX_OK;
 }
 
 static int set_lds_attr() {
-    VADX_DYN_LDS(fsmn_run_kernel<false>, LDS_FLOATS * sizeof(float));
-    VADX_DYN_LDS(fsmn_clips_kernel<false>, LDS_FLOATS * sizeof(float));
-    VADX_DYN_LDS(fsmn_run_kernel<true>, SQ_LDS_BYTES);
-    VADX_DYN_LDS(fsmn_clips_kernel<true>, SQ_LDS_BYTES);
+    VADX_DYN_LDS(fsmn_run_kernel<0>, LDS_FLOATS * sizeof(float));
+    VADX_DYN_LDS(fsmn_clips_kernel<0>, LDS_FLOATS * sizeof(float));
+    VADX_DYN_LDS(fsmn_run_kernel<1>, SQ_LDS_BYTES);
+    VADX_DYN_LDS(fsmn_clips_kernel<1>, SQ_LDS_BYTES);
+    VADX_DYN_LDS(fsmn_run_kernel<2>, SQ_LDS_BYTES);
+    VADX_DYN_LDS(fsmn_clips_kernel<2>, SQ_LDS_BYTES);
     return VADX_OK;
 }
 
@@ -750,10 +793,12 @@ extern "C" int vadx_fsmn_run(const vadx_fsmn_dims *dims, const float *packed, co
         VADX_REQUIRE(cache_in[l] && cache_out[l], "vadx_fsmn_run: NULL cache %d", l);
         r.cin[l] = cache_in[l]; r.cout[l] = cache_out[l];
     }
-    if (vadx::gemm_mode() == 1 && d.split_ok)
-        hipLaunchKernelGGL(fsmn_run_kernel<true>, dim3(batch), dim3(THREADS), SQ_LDS_BYTES, static_cast<hipStream_t>(stream), d, packed, r);
+    if (d.arith == vadx::VADX_AR_H2)
+        hipLaunchKernelGGL(fsmn_run_kernel<2>, dim3(batch), dim3(THREADS), SQ_LDS_BYTES, static_cast<hipStream_t>(stream), d, packed, r);
+    else if (d.arith == vadx::VADX_AR_B3)
+        hipLaunchKernelGGL(fsmn_run_kernel<1>, dim3(batch), dim3(THREADS), SQ_LDS_BYTES, static_cast<hipStream_t>(stream), d, packed, r);
     else
-        hipLaunchKernelGGL(fsmn_run_kernel<false>, dim3(batch), dim3(THREADS), LDS_FLOATS * sizeof(float),
+        hipLaunchKernelGGL(fsmn_run_kernel<0>, dim3(batch), dim3(THREADS), LDS_FLOATS * sizeof(float),
                            static_cast<hipStream_t>(stream), d, packed, r);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
@@ -778,10 +823,12 @@ extern "C" int vadx_fsmn_clips(const vadx_fsmn_dims *dims, const float *packed, 
     c.slide = d.T - lp->look_backward; c.thr = lp->one_minus_speech_threshold; c.noise0 = lp->noise_db_init;
     c.snr = lp->snr_threshold; c.speaking = lp->speaking_score; c.silence_score = lp->silence_score;
     c.flags = flags; c.noise_trace = noise_trace;
-    if (vadx::gemm_mode() == 1 && d.split_ok)
-        hipLaunchKernelGGL(fsmn_clips_kernel<true>, dim3(batch), dim3(THREADS), SQ_LDS_BYTES, static_cast<hipStream_t>(stream), d, packed, c);
+    if (d.arith == vadx::VADX_AR_H2)
+        hipLaunchKernelGGL(fsmn_clips_kernel<2>, dim3(batch), dim3(THREADS), SQ_LDS_BYTES, static_cast<hipStream_t>(stream), d, packed, c);
+    else if (d.arith == vadx::VADX_AR_B3)
+        hipLaunchKernelGGL(fsmn_clips_kernel<1>, dim3(batch), dim3(THREADS), SQ_LDS_BYTES, static_cast<hipStream_t>(stream), d, packed, c);
     else
-        hipLaunchKernelGGL(fsmn_clips_kernel<false>, dim3(batch), dim3(THREADS), LDS_FLOATS * sizeof(float),
+        hipLaunchKernelGGL(fsmn_clips_kernel<0>, dim3(batch), dim3(THREADS), LDS_FLOATS * sizeof(float),
                            static_cast<hipStream_t>(stream), d, packed, c);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;

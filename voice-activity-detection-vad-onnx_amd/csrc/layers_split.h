@@ -1,7 +1,7 @@
-// layers_split.h -- dense layer on LDS-resident activations as bf16 x 3 split products (csrc/split3.h): the split-product counterpart of
-// layers.h for the FSMN / FireRed nets.
+// layers_split.h -- dense layer on LDS-resident activations as split products (csrc/split_scheme.h: SC = SchemeB3, bf16 x 3, or SchemeH2,
+// fp16 x 2): the split-product counterpart of layers.h for the FSMN / FireRed nets.
 //
-// Activations are three bf16 planes [k / 8][NCOL columns][8] (NCOL a multiple of 16: a wave's ds_read_b128 of one (k-group, 16 columns)
+// Activations are SC::NP 16-bit planes [k / 8][NCOL columns][8] (NCOL a multiple of 16: a wave's ds_read_b128 of one (k-group, 16 columns)
 // block per quarter is conflict-free); weights are A fragments [n-tile][32-k chunk][plane][QFRAG] streamed from L2 one chunk ahead.
 // A layer chooses its output orientation by which operand the weights are:
 //   OUT_PLANES  weights = A operand: D rows = output channels, a lane holds four consecutive channels of one column -> one 8-byte store
@@ -11,12 +11,12 @@
 // Same fragments either way (lane 16 g + i supplies eight consecutive k of row / column i).
 #pragma once
 #include "common.h"
-#include "split3.h"
+#include "split_scheme.h"
 
 namespace vadx {
 
 struct QLayerArgs {
-    const float *W;                 // A fragments of tile nt: W + nt * nchunks * 3 * QFRAG; chunk kc, plane p at (kc * 3 + p) * QFRAG
+    const float *W;                 // A fragments of tile nt: W + nt * nchunks * NP * QFRAG; chunk kc, plane p at (kc * NP + p) * QFRAG
     int ntiles, nchunks;
     const float *bias;              // [ntiles * 16] or nullptr
     int relu;
@@ -29,44 +29,41 @@ struct QLayerArgs {
 
 // One group of NT n-tiles x MTT column tiles.  baddr(kgrp, mt) -> byte offset (inside a plane) of this lane's 16-byte B block of
 // k-group kgrp in column tile mt, or of a block of zeros when kgrp lies beyond the layer's K.
-template <int NT, int MTT, bool OUT_PLANES, typename BAddr>
+template <typename SC, int NT, int MTT, bool OUT_PLANES, typename BAddr>
 __device__ __forceinline__ void qgemm_group(f32x4 (&hi)[NT][MTT], f32x4 (&lo)[NT][MTT], const float *const (&w)[NT], int kc0, int kc1,
                                             const unsigned char *act, int act_pl, BAddr baddr, int lane) {
     const int q = lane >> 4;
-    bf16x8 a0[NT][3], a1[NT][3];
-    auto load_a = [&](int kc, bf16x8 (&a)[NT][3]) {
+    constexpr int NP = SC::NP;
+    typedef typename SC::frag frag;
+    frag a0[NT][NP], a1[NT][NP];
+    auto load_a = [&](int kc, frag (&a)[NT][NP]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
 #if defined(QG_WHATIF) && (QG_WHATIF & 1)
                 if (kc > kc0) { a[nt][p] = a0[nt][p]; continue; }     // what-if: the weight stream costs nothing
 #endif
-                a[nt][p] = ldq(w[nt] + (size_t)(kc * 3 + p) * QFRAG, lane);
+                a[nt][p] = SC::ld(w[nt] + (size_t)(kc * NP + p) * QFRAG, lane);
             }
     };
-    auto step = [&](int kc, const bf16x8 (&a)[NT][3]) {
-        bf16x8 b[MTT][3];
+    auto step = [&](int kc, const frag (&a)[NT][NP]) {
+        frag b[MTT][NP];
         int boff[MTT];
 #pragma unroll
         for (int mt = 0; mt < MTT; ++mt) boff[mt] = baddr(4 * kc + q, mt);
         // plane-major request order: the first products (a2 x b0, a1 x b1 ...) of every column tile can issue after MTT reads have landed
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int mt = 0; mt < MTT; ++mt) {
 #if defined(QG_WHATIF) && (QG_WHATIF & 2)
                 b[mt][p] = a[0][p];                 // what-if: the activation reads cost nothing
                 continue;
 #endif
-                b[mt][p] = *reinterpret_cast<const bf16x8 *>(act + boff[mt] + p * act_pl);
+                b[mt][p] = SC::lds(act + boff[mt] + p * act_pl);
             }
-        // six products per (n-tile, column tile), tiles innermost: consecutive MFMAs hit different accumulators
-#define QL_TERM(AP, BP, ACC)                                                                                                   \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int mt = 0; mt < MTT; ++mt)                       \
-        ACC[nt][mt] = OUT_PLANES ? mfma_bf16(a[nt][AP], b[mt][BP], ACC[nt][mt]) : mfma_bf16(b[mt][BP], a[nt][AP], ACC[nt][mt]);
-        QL_TERM(2, 0, lo) QL_TERM(1, 1, lo) QL_TERM(0, 2, lo) QL_TERM(1, 0, lo) QL_TERM(0, 1, lo) QL_TERM(0, 0, hi)
-#undef QL_TERM
+        SC::template products<NT, MTT, OUT_PLANES>(a, b, hi, lo);
     };
     load_a(kc0, a0);
     for (int kc = kc0; kc < kc1; kc += 2) {
@@ -81,21 +78,20 @@ __device__ __forceinline__ void qgemm_group(f32x4 (&hi)[NT][MTT], f32x4 (&lo)[NT
     }
 }
 
-template <int MTT, bool OUT_PLANES>
-__device__ __forceinline__ void qlayer_store(const QLayerArgs &a, int nt, int mt, f32x4 v, int lane) {
+template <typename SC, int MTT, bool OUT_PLANES>
+__device__ __forceinline__ void qlayer_store(const QLayerArgs &a, int nt, int mt, f32x4 v, int lane, float &amax) {
     const int q = lane >> 4, i = lane & 15;
     if (OUT_PLANES) {
         if (a.bias) v += ldg4(a.bias + nt * 16 + 4 * q);
         if (a.relu)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        u32x2 p0, p1, p2;
-        split3x4(v, p0, p1, p2);
+        u32x2 pp[SC::NP];
+        SC::split4(v, pp, amax);
         const int g = 4 * nt + q;
         unsigned char *d = a.dst + ((g >> 1) * a.dst_ncol + mt * 16 + i) * 16 + (g & 1) * 8;
-        *reinterpret_cast<u32x2 *>(d) = p0;
-        *reinterpret_cast<u32x2 *>(d + a.dst_pl) = p1;
-        *reinterpret_cast<u32x2 *>(d + 2 * a.dst_pl) = p2;
+#pragma unroll
+        for (int p = 0; p < SC::NP; ++p) *reinterpret_cast<u32x2 *>(d + p * a.dst_pl) = pp[p];
     } else {
         const float b = a.bias ? ldg1(a.bias + nt * 16 + i) : 0.f;
 #pragma unroll
@@ -106,13 +102,13 @@ __device__ __forceinline__ void qlayer_store(const QLayerArgs &a, int nt, int mt
 
 // dst = W x act (+bias, ReLU).  n-tiles go to the waves round-robin, two rounds side by side where there are that many; leftover
 // n-tiles (9 tiles on 8 waves) run as single (n-tile, column tile) items.
-template <int MTT, bool OUT_PLANES, typename BAddr>
-__device__ __forceinline__ void qlayer(const QLayerArgs &a, BAddr baddr) {
+template <typename SC, int MTT, bool OUT_PLANES, typename BAddr>
+__device__ __forceinline__ void qlayer(const QLayerArgs &a, BAddr baddr, float &amax) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     asm volatile("" : "+v"(lane), "+v"(wave));      // nothing per-lane is hoisted out of the enclosing tile / window loops (layers.h)
     const int NW = blockDim.x >> 6;
     const int full = (a.ntiles / NW) * NW;
-    const size_t tstride = (size_t)a.nchunks * 3 * QFRAG;
+    const size_t tstride = (size_t)a.nchunks * SC::NP * QFRAG;
     int nt0 = wave;
     for (; nt0 + NW < full; nt0 += 2 * NW) {
         f32x4 hi[2][MTT], lo[2][MTT];
@@ -121,20 +117,20 @@ __device__ __forceinline__ void qlayer(const QLayerArgs &a, BAddr baddr) {
 #pragma unroll
             for (int mt = 0; mt < MTT; ++mt) { hi[h][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[h][mt] = hi[h][mt]; }
         const float *const w[2] = {a.W + nt0 * tstride, a.W + (nt0 + NW) * tstride};
-        qgemm_group<2, MTT, OUT_PLANES>(hi, lo, w, 0, a.nchunks, a.act, a.act_pl, baddr, lane);
+        qgemm_group<SC, 2, MTT, OUT_PLANES>(hi, lo, w, 0, a.nchunks, a.act, a.act_pl, baddr, lane);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) qlayer_store<MTT, OUT_PLANES>(a, nt0 + h * NW, mt, hi[h][mt] + lo[h][mt], lane);
+            for (int mt = 0; mt < MTT; ++mt) qlayer_store<SC, MTT, OUT_PLANES>(a, nt0 + h * NW, mt, SC::join(hi[h][mt], lo[h][mt]), lane, amax);
     }
     for (; nt0 < full; nt0 += NW) {
         f32x4 hi[1][MTT], lo[1][MTT];
 #pragma unroll
         for (int mt = 0; mt < MTT; ++mt) { hi[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[0][mt] = hi[0][mt]; }
         const float *const w[1] = {a.W + nt0 * tstride};
-        qgemm_group<1, MTT, OUT_PLANES>(hi, lo, w, 0, a.nchunks, a.act, a.act_pl, baddr, lane);
+        qgemm_group<SC, 1, MTT, OUT_PLANES>(hi, lo, w, 0, a.nchunks, a.act, a.act_pl, baddr, lane);
 #pragma unroll
-        for (int mt = 0; mt < MTT; ++mt) qlayer_store<MTT, OUT_PLANES>(a, nt0, mt, hi[0][mt] + lo[0][mt], lane);
+        for (int mt = 0; mt < MTT; ++mt) qlayer_store<SC, MTT, OUT_PLANES>(a, nt0, mt, SC::join(hi[0][mt], lo[0][mt]), lane, amax);
     }
     // leftover n-tiles (9 tiles on 8 waves): (n-tile, column tile) items, one 16 x 16 output tile each
     for (int item = wave; item < (a.ntiles - full) * MTT; item += NW) {
@@ -142,8 +138,8 @@ __device__ __forceinline__ void qlayer(const QLayerArgs &a, BAddr baddr) {
         f32x4 hi[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}}, lo[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
         const float *const w[1] = {a.W + nt * tstride};
         auto b1 = [&](int kgrp, int) { return baddr(kgrp, mt_w); };
-        qgemm_group<1, 1, OUT_PLANES>(hi, lo, w, 0, a.nchunks, a.act, a.act_pl, b1, lane);
-        qlayer_store<MTT, OUT_PLANES>(a, nt, mt_w, hi[0][0] + lo[0][0], lane);
+        qgemm_group<SC, 1, 1, OUT_PLANES>(hi, lo, w, 0, a.nchunks, a.act, a.act_pl, b1, lane);
+        qlayer_store<SC, MTT, OUT_PLANES>(a, nt, mt_w, SC::join(hi[0][0], lo[0][0]), lane, amax);
     }
 }
 

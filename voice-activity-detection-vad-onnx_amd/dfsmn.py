@@ -6,6 +6,7 @@ Activations use the frame-tiled "FT" layout documented in csrc/dfsmn.hip."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -78,6 +79,9 @@ class Iccrn:
         self.w = w
         self.d = {}
         self._cfb_cache = {}
+        self.arithmetic = None         # None = the module default (_lib.gemm_mode()); "f32" | "split" | "h2" (-> "split" here, see _arith)
+        env = os.environ.get("VADX_CFB_BACK", "")     # read once: the second half of the gated conv block as split products (opt-in, no faster)
+        self.cfb_back_split = env == "split"
         self.frame_stride = None       # None: every chunk on tiles of its own; forward() packs (packed_stride) for the duration of a pass
 
         def dev(name, arr):
@@ -155,11 +159,17 @@ class Iccrn:
                                                None if part0 is None else part0.data_ptr(),
                                                None if part1 is None else part1.data_ptr(), _lib.stream_ptr()))
 
+    def _arith(self):
+        """VADX_ARITH_* of the kernels that have a split form (lstm_f, cfb_front): the engine's / module's mode, "h2" mapped to bf16 x 3 --
+        the fp16 x 2 forms of these two kernels are not built yet."""
+        m = self.arithmetic or _lib.gemm_mode()
+        return _lib.ARITH["f32"] if m == "f32" else _lib.ARITH["split"]
+
     def lstm_f(self, prefix, inp, ln, out, F, tiles):
         arr = lambda n: (C.c_void_p * 2)(self._p(f"{prefix}.lstm2.{n}_l0"), self._p(f"{prefix}.lstm2.{n}_l0_reverse"))   # noqa: E731
         wi, wh, bi, bh = arr("weight_ih"), arr("weight_hh"), arr("bias_ih"), arr("bias_hh")
         _lib.check(self.lib.vadx_dfsmn_lstm_f(C.byref(inp), None if ln is None else C.byref(ln), C.byref(wi), C.byref(wh),
-                                              C.byref(bi), C.byref(bh), C.byref(out), F, tiles, _lib.stream_ptr()))
+                                              C.byref(bi), C.byref(bh), C.byref(out), F, tiles, _lib.stream_ptr(), self._arith()))
 
     # ---- CFB (:76-93) ---------------------------------------------------------------------------
     def _cfb_tables(self, name):
@@ -277,6 +287,8 @@ class Iccrn:
         have = a_part is not None and (b is None or b_part is not None)
         s0 = self.merged_stats(a_part, b_part if b is not None else None, tiles) if have else self.stats(a, b, F_BINS, tiles)
         cw, _keep = self._cfb_tables(name)
+        cw.front_arithmetic = self._arith()
+        cw.back_arithmetic = _lib.ARITH["split"] if (self.cfb_back_split and self._arith() == _lib.ARITH["split"]) else _lib.ARITH["f32"]
         st = _lib.stream_ptr()
         _lib.check(self.lib.vadx_dfsmn_cfb_front(C.byref(cw), C.byref(a), None if b is None else C.byref(b), s0.data_ptr(),
                                                  y1.data.data_ptr(), s1.data_ptr(), li.data.data_ptr(), sl.data_ptr(), tiles, st))

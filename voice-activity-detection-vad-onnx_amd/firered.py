@@ -45,7 +45,7 @@ class FireRedEngine:
         for k in ("idim", "R", "M", "H", "P", "N1", "S1", "N2", "S2", "odim"):
             setattr(cfg, k, int(c[k]))
         cfg.frames = self.T
-        self.cfg = cfg
+        self._cfg0 = cfg
         hw = _lib.FireRedWeightsHost()
         hw.fc1_w, hw.fc1_b, hw.fc2_w, hw.fc2_b = (w[k].ctypes.data for k in ("fc1_w", "fc1_b", "fc2_w", "fc2_b"))
         for r in range(c["R"]):
@@ -59,12 +59,36 @@ class FireRedEngine:
             hw.dnn_w[m], hw.dnn_b[m] = w[f"dnn{m}_w"].ctypes.data, w[f"dnn{m}_b"].ctypes.data
         hw.out_w, hw.out_b = w["out_w"].ctypes.data, w["out_b"].ctypes.data
         Lb = _lib.lib()
-        n = Lb.vadx_firered_packed_floats(C.byref(cfg))
-        if n == 0:
-            raise ValueError("FireRed config not supported by the HIP kernel (idim 80, H<=256, P<=128, frames<=112, odim<=4)")
-        packed = np.zeros(n, dtype=np.float32)
-        _lib.check(Lb.vadx_firered_pack_host(C.byref(cfg), C.byref(hw), packed.ctypes.data))
-        self.packed = torch.from_numpy(packed).to(self.device)
+        self._hw, self._w = hw, w            # (the host arrays behind hw's pointers stay alive with the engine)
+
+        def build(mode):
+            """(cfg, device blob) of one arithmetic: the blob carries the weight fragments of that arithmetic only"""
+            c = _lib.FireRedCfg.from_buffer_copy(self._cfg0)
+            c.arithmetic = _lib.GEMM_MODES[mode]
+            n = Lb.vadx_firered_packed_floats(C.byref(c))
+            if n == 0:
+                if mode != "f32":             # H / P outside the split kernel's shape: float32 MFMAs
+                    return build("f32")
+                raise ValueError("FireRed config not supported by the HIP kernel (idim 80, H<=256, P<=128, frames<=112, odim<=4)")
+            packed = np.zeros(n, dtype=np.float32)
+            _lib.check(Lb.vadx_firered_pack_host(C.byref(c), C.byref(hw), packed.ctypes.data))
+            return c, torch.from_numpy(packed).to(self.device)
+
+        def flag(c, blob):
+            f, a = C.c_uint32(0), C.c_float(0.0)
+            with torch.cuda.device(self.device):
+                _lib.check(Lb.vadx_firered_range_flag(C.byref(c), blob.data_ptr(), 1, C.byref(f), C.byref(a), _lib.stream_ptr()))
+            return int(f.value), float(a.value)
+        self.blobs = _lib.ArithBlobs(build, flag)
+        self.blobs.get()                     # pack now: an unsupported config raises here
+
+    @property
+    def cfg(self):
+        return self.blobs.get()[0]
+
+    @property
+    def packed(self):
+        return self.blobs.get()[1]
 
     def run(self, audio_i16, windows_per_clip=1):
         """audio int16 [B, W*L] -> probs f32 [B*W, odim, T] (each window stateless, as the reference)."""
@@ -74,10 +98,13 @@ class FireRedEngine:
         logmel = self.fe.logmel(audio_i16, windows_per_clip, self.L)
         nwin = logmel.shape[0]
         probs = t.empty((nwin, self.odim, self.T), dtype=t.float32, device=self.device)
-        with t.cuda.device(self.device):
-            _lib.check(_lib.lib().vadx_firered_run(C.byref(self.cfg), self.packed.data_ptr(), logmel.data_ptr(), nwin,
-                                                   probs.data_ptr(), _lib.stream_ptr()))
-        return probs
+
+        def launch(mode, cfg, packed):
+            with t.cuda.device(self.device):
+                _lib.check(_lib.lib().vadx_firered_run(C.byref(cfg), packed.data_ptr(), logmel.data_ptr(), nwin,
+                                                       probs.data_ptr(), _lib.stream_ptr()))
+            return probs
+        return self.blobs.guarded(launch)
 
     def run_from_host(self, host_i16, windows_per_clip=1, chunk_clips=256, feed=None):
         """`run` fed from HOST memory (int16 [B, W*L], ideally pinned: vadx.feed.pin), uploads overlapped with compute

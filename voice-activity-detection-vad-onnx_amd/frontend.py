@@ -40,12 +40,14 @@ class Frontend:
     """Device-resident packed tables for one preset and one window length."""
 
     def __init__(self, preset, window_len, device="cuda:0", n_mels=80, sample_rate=16000, in_sample_rate=16000, fold=None):
-        """fold: None = the fastest DFT product that holds the dense f32 product's error bound: kind 4 (the reference table times the
-        prepped samples as bf16 x 3 exactly split products, csrc/split3.h) where the geometry has it (hop 160, int16 preps), else the
-        folded f32 product the table admits (`vadx_frontend_fold_kind`), else the dense f32 product.  VADX_FRONTEND_FOLD overrides
-        process-wide: 0 = dense f32, 1 = the folded f32 product (round 3's default), 3 = opt into kind 3 (time x frequency fold: faster,
-        noisier on weak bands), 4 = the default.  False = dense f32 product (the table-level parity tests compare against it), True =
-        require a folded f32 product, 1 / 2 / 3 / 4 = that kind (pack_host refuses a kind the table does not admit).
+        """fold: None = the fastest DFT product that holds the dense f32 product's error bound: kind 5 (the reference table times the
+        prepped samples as fp16 x 2 split products, csrc/split2.h; the samples are bounded by the int16 input and pre-scaled exactly, so no
+        range check is involved) where the geometry has it (hop 160, int16 preps), else the folded f32 product the table admits
+        (`vadx_frontend_fold_kind`), else the dense f32 product.  VADX_FRONTEND_FOLD overrides process-wide: 0 = dense f32, 1 = the folded
+        f32 product (round 3's default), 3 = opt into kind 3 (time x frequency fold: faster, noisier on weak bands), 4 = the same dense
+        product on bf16 x 3 exactly split operands (round 4's default), 5 = the default.  False = dense f32 product (the table-level parity
+        tests compare against it), True = require a folded f32 product, 1 ... 5 = that kind (pack_host refuses a kind the
+        table does not admit).
         window_len = samples per window IN THE AUDIO BUFFER.  in_sample_rate != 16000 reproduces the exports built with
         IN_SAMPLE_RATE set (Export_NVIDIA_MarbleNet_VAD.py:237-254, FireRedVAD/Export_FireRedVAD.py:431-449): the graph itself
         resamples each window to 16 kHz with F.interpolate(linear, align_corners=False), before the pre-emphasis when the
@@ -91,12 +93,12 @@ class Frontend:
         cos_n, sin_n, fb_n = tables.as_np(cos_t), tables.as_np(sin_t), tables.as_np(fb)
         required = fold is True
         kind = int(fold) if (not isinstance(fold, bool) and isinstance(fold, int) and fold > 0) else None      # a specific kind
-        env = os.environ.get("VADX_FRONTEND_FOLD", "4")
+        env = os.environ.get("VADX_FRONTEND_FOLD", "5")
         from_env = False
         if fold is None:
             fold = env != "0" and p["mel"][0] != "zeros"
-            if fold and env in ("3", "4"):
-                kind, from_env = int(env), True               # opt-in: 3 = time x frequency fold, 4 = dense product on bf16 x 3 split operands, wherever they apply
+            if fold and env in ("3", "4", "5"):
+                kind, from_env = int(env), True               # 3 = time x frequency fold, 4 / 5 = dense product on bf16 x 3 / fp16 x 2 split operands, wherever they apply
         auto = lambda: int(L.vadx_frontend_fold_kind(C.byref(cfg), cos_n.ctypes.data, sin_n.ctypes.data, n_fft))      # noqa: E731
         cfg.fold = kind if kind else (auto() if fold else 0)
         if from_env:

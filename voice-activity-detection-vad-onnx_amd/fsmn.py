@@ -43,7 +43,7 @@ class FsmnEngine:
         dims.frames, dims.speech_2_noise_ratio = self.T, float(speech_2_noise_ratio)
         if w["in1_w"].shape[1] != 400 or w["l0_lin_w"].shape[0] != PROJ or w["l0_fir_w"].shape != (PROJ, 20):
             raise ValueError("FSMN weights: input dim 400, proj 128 and lorder 20 are fixed by the reference cache shape")
-        self.dims = dims
+        self._dims0 = dims
         hw = _lib.FsmnWeightsHost()
         for k in ("in1_w", "in1_b", "in2_w", "in2_b", "out1_w", "out1_b", "out2_w", "out2_b", "cmvn_means", "cmvn_vars"):
             setattr(hw, k, w[k].ctypes.data)
@@ -51,12 +51,37 @@ class FsmnEngine:
             hw.lin_w[l], hw.fir_w[l] = w[f"l{l}_lin_w"].ctypes.data, w[f"l{l}_fir_w"].ctypes.data
             hw.aff_w[l], hw.aff_b[l] = w[f"l{l}_aff_w"].ctypes.data, w[f"l{l}_aff_b"].ctypes.data
         Lb = _lib.lib()
-        n = Lb.vadx_fsmn_packed_floats(C.byref(dims))
-        if n == 0:
-            raise ValueError("FSMN dims not supported by the HIP kernel (affine dims <= 144, linear/output <= 256)")
-        packed = np.zeros(n, dtype=np.float32)
-        _lib.check(Lb.vadx_fsmn_pack_host(C.byref(dims), C.byref(hw), packed.ctypes.data))
-        self.packed = torch.from_numpy(packed).to(self.device)
+        self._hw, self._w = hw, w            # (the host arrays behind hw's pointers stay alive with the engine)
+
+        def build(mode):
+            """(dims, device blob) of one arithmetic: the blob carries the weight fragments of that arithmetic only"""
+            d = _lib.FsmnDims()
+            C.memmove(C.byref(d), C.byref(self._dims0), C.sizeof(d))
+            d.arithmetic = _lib.GEMM_MODES[mode]
+            n = Lb.vadx_fsmn_packed_floats(C.byref(d))
+            if n == 0:
+                if mode != "f32":             # dims outside the split tile: float32 MFMAs
+                    return build("f32")
+                raise ValueError("FSMN dims not supported by the HIP kernel (affine dims <= 144, linear/output <= 256)")
+            packed = np.zeros(n, dtype=np.float32)
+            _lib.check(Lb.vadx_fsmn_pack_host(C.byref(d), C.byref(hw), packed.ctypes.data))
+            return d, torch.from_numpy(packed).to(self.device)
+
+        def flag(d, blob):
+            f, a = C.c_uint32(0), C.c_float(0.0)
+            with torch.cuda.device(self.device):
+                _lib.check(Lb.vadx_fsmn_range_flag(C.byref(d), blob.data_ptr(), 1, C.byref(f), C.byref(a), _lib.stream_ptr()))
+            return int(f.value), float(a.value)
+        self.blobs = _lib.ArithBlobs(build, flag)
+        self.blobs.get()                     # pack now: unsupported dims raise here
+
+    @property
+    def dims(self):
+        return self.blobs.get()[0]
+
+    @property
+    def packed(self):
+        return self.blobs.get()[1]
 
     # ---- front-end + energy for a [B, N] int16 batch cut into W windows at `stride`
     def features(self, audio_i16, windows_per_clip, stride):
@@ -97,12 +122,15 @@ class FsmnEngine:
         psil = t.empty((B, self.T), dtype=t.float32, device=self.device) if return_psil else None
         pin = (C.c_void_p * 4)(*[c.data_ptr() for c in cin])
         pout = (C.c_void_p * 4)(*[c.data_ptr() for c in cout])
-        with t.cuda.device(self.device):
-            _lib.check(_lib.lib().vadx_fsmn_run(C.byref(self.dims), self.packed.data_ptr(), logmel.data_ptr(), db.data_ptr(),
-                                                C.byref(pin), C.byref(pout), thr.data_ptr(), nz.data_ptr(), B,
-                                                score.data_ptr(), noisy.data_ptr(),
-                                                None if psil is None else psil.data_ptr(), _lib.stream_ptr()))
-        return (score, cout, noisy, psil) if return_psil else (score, cout, noisy)
+
+        def launch(mode, dims, packed):
+            with t.cuda.device(self.device):
+                _lib.check(_lib.lib().vadx_fsmn_run(C.byref(dims), packed.data_ptr(), logmel.data_ptr(), db.data_ptr(),
+                                                    C.byref(pin), C.byref(pout), thr.data_ptr(), nz.data_ptr(), B,
+                                                    score.data_ptr(), noisy.data_ptr(),
+                                                    None if psil is None else psil.data_ptr(), _lib.stream_ptr()))
+            return (score, cout, noisy, psil) if return_psil else (score, cout, noisy)
+        return self.blobs.guarded(launch)
 
     # ---- whole clips
     def grid(self, look_backward_s=0.3):
@@ -128,11 +156,14 @@ class FsmnEngine:
         flags = t.empty((B, nflags), dtype=t.uint8, device=self.device)
         cache = t.empty((B, 4, PROJ, HIST), dtype=t.float32, device=self.device)
         trace = t.empty((B, W), dtype=t.float32, device=self.device) if return_noise else None
-        with t.cuda.device(self.device):
-            _lib.check(_lib.lib().vadx_fsmn_clips(C.byref(self.dims), self.packed.data_ptr(), logmel.data_ptr(),
-                                                  db.data_ptr(), B, W, C.byref(lp), cache.data_ptr(), flags.data_ptr(),
-                                                  None if trace is None else trace.data_ptr(), _lib.stream_ptr()))
-        return (flags, trace) if return_noise else flags
+
+        def launch(mode, dims, packed):
+            with t.cuda.device(self.device):
+                _lib.check(_lib.lib().vadx_fsmn_clips(C.byref(dims), packed.data_ptr(), logmel.data_ptr(),
+                                                      db.data_ptr(), B, W, C.byref(lp), cache.data_ptr(), flags.data_ptr(),
+                                                      None if trace is None else trace.data_ptr(), _lib.stream_ptr()))
+            return (flags, trace) if return_noise else flags
+        return self.blobs.guarded(launch)
 
     def flags_from_host(self, host_padded_i16, windows_per_clip, chunk_clips=256, feed=None, **loop_kw):
         """`flags` fed from HOST memory (int16 [B, (W-1)*stride + L], ideally pinned: vadx.feed.pin): chunks of clips are uploaded on
