@@ -58,6 +58,18 @@ def flop_frontend_frame_folded(n_bins, taps, n_mels=80):
 
 
 PEAK_SPLIT_TFLOPS = 2500.0 / 6.0      # f32-equivalent peak of bf16 x 3 split products: the dense bf16 MFMA peak / 6 (csrc/split3.h)
+PEAK_H2_TFLOPS = 2500.0 / 3.0         # f32-equivalent peak of fp16 x 2 split products: the dense fp16 MFMA peak / 3 (csrc/split2.h)
+PEAK_BY_ARITH = {"f32": 157.3, "split": PEAK_SPLIT_TFLOPS, "h2": PEAK_H2_TFLOPS}
+# what the chip sustains of a pipe's nominal peak when that pipe is kept busy (it clocks to its power budget; bench.py: SUSTAINED_OF_NOMINAL)
+SUSTAINED_OF_NOMINAL = {"f32": 0.87, "split": 0.80, "h2": 0.86}
+SUSTAINED_SOURCE = "profiles/r04_dvfs_probe.txt (f32, bf16), profiles/r05_f16x2_probe.txt (fp16)"
+
+
+def _with_sustained(r, sustained):
+    r["frac_of_sustained"] = r["achieved"] / (r["peak"] * sustained)
+    r["sustained_of_nominal"] = sustained
+    r["sustained_source"] = SUSTAINED_SOURCE
+    return r
 
 
 def _roof_frontend(frames, n_bins, taps, ms, tag, fold=None):
@@ -66,24 +78,34 @@ def _roof_frontend(frames, n_bins, taps, ms, tag, fold=None):
     split products' f32-equivalent peak (2500 / 6 TFLOP/s) and the mel GEMM at the f32-MFMA peak -- never 157.3 for the split part.
     fold 1 / 2 (folded f32 product): f32-MFMA flops issued + the f16 residual's flops at their f32 time equivalent (/16), against 157.3;
     `dense_equivalent_achieved` = what the reference's dense product would need."""
-    if fold is None:
-        fold = int(os.environ.get("VADX_FRONTEND_FOLD", "4"))
-    if fold == 4:
+    if fold is None:            # callers pass the engine's ACTUAL product kind (eng.fe.fold: the front-end falls back where a kind does not apply)
+        try:
+            fold = int(os.environ.get("VADX_FRONTEND_FOLD", "5"))
+        except ValueError:
+            fold = 5
+    if fold in (4, 5):
+        ar = "split" if fold == 4 else "h2"
         f_dft, f_rest = 2 * (2 * n_bins * taps), 3 * n_bins + 2 * 80 * n_bins
         total = frames * (f_dft + f_rest)
-        t_min = frames * (f_dft / PEAK_SPLIT_TFLOPS + f_rest / PEAK_F32_MFMA_TFLOPS)          # 1e-12 s
+        t_min = frames * (f_dft / PEAK_BY_ARITH[ar] + f_rest / PEAK_F32_MFMA_TFLOPS)          # 1e-12 s
+        t_sus = frames * (f_dft / (PEAK_BY_ARITH[ar] * SUSTAINED_OF_NOMINAL[ar]) + f_rest / (PEAK_F32_MFMA_TFLOPS * SUSTAINED_OF_NOMINAL["f32"]))
         r = _roof("frontend_split_kernel", total, ms, tag, "frontend_split_kernel",
-                  note="dense DFT product as bf16 x 3 split products: flops as the reference computes them; peak = the DFT part at 2500 / 6 "
-                       "TFLOP/s (f32-equivalent peak of the split products) + the power / mel part at the f32-MFMA peak")
+                  note=("dense DFT product as bf16 x 3 split products" if fold == 4 else "dense DFT product as fp16 x 2 split products") +
+                       ": flops as the reference computes them; peak = the DFT part at the f32-equivalent peak of the split products "
+                       "(2500 / 6 for bf16 x 3, 2500 / 3 for fp16 x 2 TFLOP/s) + the power / mel part at the f32-MFMA peak")
         r["peak"] = total / t_min
         r["frac"] = r["achieved"] / r["peak"]
-        r["arithmetic"] = "split"
+        r["frac_of_sustained"] = r["achieved"] / (total / t_sus)
+        r["sustained_source"] = SUSTAINED_SOURCE
+        r["arithmetic"] = ar
+        r["frontend_kind"] = fold
         r["dense_equivalent_achieved"] = r["achieved"]
         return r
     f32, f16 = flop_frontend_frame_folded(n_bins, taps)
     r = _roof("frontend_fold_kernel", frames * (f32 + f16 / 16.0), ms, tag, "frontend_fold_kernel",
               note="folded DFT product: algorithmic f32 flops of the fold (taps / 2 mirror pairs per table row; dense mel counted, the kernel's "
                    "banded mel issues fewer) + f16 residual flops / 16 (its MFMA rate is 16x); dense_equivalent = the reference's dense cos + sin product")
+    r["frontend_kind"] = fold
     r["f32_flop_per_launch"], r["f16_flop_per_launch"] = frames * f32, frames * f16
     r["dense_equivalent_achieved"] = frames * flop_frontend_frame(n_bins, taps) / (ms * 1e-3) / 1e12
     return r
@@ -306,24 +328,46 @@ def profiled_pass_traffic(tag):
     return best
 
 
-def _gemm_split():
+def _gemm_arith(eng=None):
+    """the arithmetic an engine's dense layers actually run ("f32" | "split" | "h2"): its ArithBlobs' mode (which falls back where a mode
+    cannot be packed), else the module default"""
     from vadx import _lib
-    return _lib.gemm_mode() == "split"
+    if eng is not None and hasattr(eng, "blobs"):
+        return eng.blobs.mode()
+    return _lib.gemm_mode()
 
 
 def _roof(kernel, flop, ms, tag=None, kernel_substr=None, note=None, split=False):
-    """split: the kernel's GEMMs run as bf16 x 3 split products -> priced against their f32-equivalent peak (2500 / 6), not 157.3"""
+    """split: False / "f32" = f32 MFMAs (peak 157.3); True / "split" = bf16 x 3 split products, priced against THEIR f32-equivalent peak
+    (2500 / 6); "h2" = fp16 x 2 split products (2500 / 3) -- never against 157.3"""
+    ar = {False: "f32", True: "split"}.get(split, split)
     ach = flop / (ms * 1e-3) / 1e12
     tr = profiled_kernel_traffic(tag, kernel_substr) if tag else None
-    peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-    r = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "arithmetic": "split" if split else "f32",
-         "frac": ach / peak, "flop_per_launch": flop, "ms": ms,
+    peak = PEAK_BY_ARITH[ar]
+    r = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "arithmetic": ar,
+         "frac": ach / peak, "frac_of_sustained": ach / (peak * SUSTAINED_OF_NOMINAL[ar]), "sustained_of_nominal": SUSTAINED_OF_NOMINAL[ar],
+         "flop_per_launch": flop, "ms": ms,
          "traffic": tr["bytes"] if tr else None, "traffic_unit": "B per pass (all launches of the kernel)",
          "traffic_source": tr["source"] if tr else None,
          "traffic_GBps": (tr["bytes"] / (ms * 1e-3) / 1e9) if tr else None}
     if note:
         r["note"] = note
     return r
+
+
+def _whole_pass_roof(nwin, flop_total, fle, groups, on_split, ms):
+    """The DFSMN pass against the peak of ITS pipe mix (as bench.encoder_roofline does for one kernel): the flops of the entry points that
+    run split products at 2500 / 6, everything else at 157.3 -- peak = total flops / the time the two pipes need at their own peaks."""
+    f_split = sum(nwin * fle[k] for k in groups if k in on_split and groups[k] > 0)
+    f_all = nwin * flop_total
+    f_f32 = max(f_all - f_split, 0.0)
+    t_min = f_split / PEAK_SPLIT_TFLOPS + f_f32 / PEAK_F32_MFMA_TFLOPS
+    t_sus = f_split / (PEAK_SPLIT_TFLOPS * SUSTAINED_OF_NOMINAL["split"]) + f_f32 / (PEAK_F32_MFMA_TFLOPS * SUSTAINED_OF_NOMINAL["f32"])
+    ach = f_all / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "all DFSMN launches", "achieved": ach, "peak": f_all / t_min, "unit": "TFLOP/s", "frac": ach / (f_all / t_min),
+            "frac_of_sustained": ach / (f_all / t_sus), "sustained_source": SUSTAINED_SOURCE, "arithmetic": "mix" if f_split else "f32",
+            "flop_per_launch": f_all, "flop_on_split_products": f_split, "ms": ms,
+            "note": "peak = the pass's pipe mix: flops of the split-product entry points at 2500 / 6 TFLOP/s, the rest at the f32-MFMA peak"}
 
 
 def bytes_dfsmn_pw_window(T=101, F=160, ch=20):
@@ -452,8 +496,9 @@ def fsmn_c3(torch, device, reps, cpu, clips=4096, log=lambda m: None):
                        f"{stride}, noise-floor feedback and look-ahead vote on device)",
            "clips": clips, "samples_per_clip": n, "windows_per_clip": W, "ms": ms,
            "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split,
-           "roofline": _roof("fsmn_clips_kernel", frames10 * flop_fsmn_frame(), net_ms, "fsmn", "fsmn_clips_kernel", split=_gemm_split()),
-           "roofline_frontend": _roof_frontend(frames10, 257, 400, split.get("vadx_frontend_logmel", ms), "fsmn"),
+           "roofline": _roof("fsmn_clips_kernel", frames10 * flop_fsmn_frame(), net_ms, "fsmn", "fsmn_clips_kernel", split=_gemm_arith(eng)),
+           "roofline_frontend": _roof_frontend(frames10, 257, 400, split.get("vadx_frontend_logmel", ms), "fsmn", fold=eng.fe.fold),
+           "range_fallbacks": eng.blobs.range_fallbacks,
            "hbm": _hbm(clips * (padded * 2 + (W * (eng.T - lb) + lb)), ms, "fsmn"), "cpu_baseline": None}
     # NOT the default path, reported beside it: the opt-in time x frequency fold of the front-end (VADX_FRONTEND_FOLD=3: a quarter of the
     # dense MACs, noisier on bands far below a frame's peak -- DESIGN 4c); the entry counts the silence flags that differ from the default path's on this batch
@@ -499,7 +544,7 @@ def marblenet_c4(torch, device, reps, cpu, clips=8192, log=lambda m: None, tag="
                        "-> per-20-ms speech probabilities",
            "clips": clips, "samples_per_clip": n, "ms": ms, "frames_per_s": clips * n / 512 / (ms * 1e-3),
            "kernel_ms": split, "kernel_calls": calls,
-           "roofline": _roof_frontend(clips * T, 257, 400, fe_ms, tag),
+           "roofline": _roof_frontend(clips * T, 257, 400, fe_ms, tag, fold=eng.frontend(n).fold),
            "roofline_net": _roof("marblenet encoder+decoder launches", clips * Tout * flop_marblenet_out_frame(), net_ms, tag, "vadx::marblenet::",
                                  note="sum of the encoder / classifier entries in kernel_ms (fused block pairs, single blocks, tail)"),
            "hbm": _hbm(clips * (n * 2 + 2 * Tout * 4), ms, tag), "cpu_baseline": None}
@@ -523,8 +568,9 @@ def firered_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None):
                        "speech probabilities",
            "clips": clips, "samples_per_clip": n, "ms": ms, "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split,
            "roofline": _roof("firered_kernel", frames10 * flop_firered_frame(), split.get("vadx_firered_run", ms), "firered",
-                             "firered_kernel", split=_gemm_split()),
-           "roofline_frontend": _roof_frontend(frames10, 201, 400, split.get("vadx_frontend_logmel", ms), "firered"),
+                             "firered_kernel", split=_gemm_arith(eng)),
+           "roofline_frontend": _roof_frontend(frames10, 201, 400, split.get("vadx_frontend_logmel", ms), "firered", fold=eng.fe.fold),
+           "range_fallbacks": eng.blobs.range_fallbacks,
            "hbm": _hbm(clips * (n * 2 + W * 98 * 4), ms, "firered"), "cpu_baseline": None}
     del audio
     if cpu:
@@ -551,9 +597,9 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
     groups = {"lstm_f": split.get("vadx_dfsmn_lstm_f", 0.0), "dft_f": split.get("vadx_dfsmn_dft_f", 0.0),
               "pw_conv": split.get("vadx_dfsmn_pw_conv", 0.0), "lstm_t": split.get("vadx_dfsmn_lstm_t", 0.0) + split.get("vadx_dfsmn_lstm_t_ex", 0.0),
               "cfb_front": split.get("vadx_dfsmn_cfb_front", 0.0), "cfb_back": split.get("vadx_dfsmn_cfb_back", 0.0)}
-    # entries whose matrix products run as bf16 x 3 split products (vadx_gemm_mode 1): priced against the f32-equivalent peak of that pipe
-    # (cfb_back's split form is opt-in, VADX_CFB_BACK=split: by default that half runs its f32-MFMA kernel)
-    on_split = ({"lstm_f", "cfb_front"} | ({"cfb_back"} if os.environ.get("VADX_CFB_BACK") == "split" else set())) if _gemm_split() else set()
+    # entries whose matrix products run as bf16 x 3 split products (these kernels have no fp16 x 2 form yet: "h2" maps to bf16 x 3 there):
+    # priced against the f32-equivalent peak of that pipe (cfb_back's split form is opt-in, VADX_CFB_BACK=split: by default it runs f32 MFMAs)
+    on_split = ({"lstm_f", "cfb_front"} | ({"cfb_back"} if os.environ.get("VADX_CFB_BACK") == "split" else set())) if _gemm_arith() != "f32" else set()
     dom = max(groups, key=groups.get)
     if dom == "pw_conv":                                     # (only the unfused chain is dominated by the HBM-bound pw_conv launches)
         dom = max((k for k in groups if k != "pw_conv"), key=groups.get)
@@ -566,7 +612,7 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
                              note="all launches of the entry point that takes the most time; flops as the reference computes them "
                                   "(the kernel issues more: 20 output channels pad to 32 MFMA rows)"),
            "roofline_by_entry": {k: _roof(f"vadx_dfsmn_{k}", nwin * fle[k], v, "dfsmn", k, split=k in on_split) for k, v in groups.items() if v > 0},
-           "roofline_whole_pass": _roof("all DFSMN launches", nwin * fl["total"], ms),
+           "roofline_whole_pass": _whole_pass_roof(nwin, fl["total"], fle, groups, on_split, ms),
            "hbm": _hbm(clips * (2 * padded * 2 + W * eng.T_A * 4), ms, "dfsmn"), "cpu_baseline": None}
     del near, far
     if cpu:

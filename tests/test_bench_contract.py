@@ -105,6 +105,12 @@ def test_bench_prints_one_contract_line():
     d = json.loads(lines[0])
     full = json.load(open(os.path.join(ROOT, "gpurun_out", "test_detail.json")))
     assert full["value"] == d["value"] and "instruction_mix" in full["roofline"]
+    # the additive VALU : MFMA ceiling model was measured for f32-input MFMAs: a kernel on split products never carries it
+    for key in ("roofline", "roofline_recurrent"):
+        mix = full[key].get("instruction_mix")
+        if mix is not None and full[key]["arithmetic"] != "f32":
+            assert mix["ceiling_frac"] is None and mix["model"].startswith("none"), (key, mix)
+        assert full[key]["frac_of_sustained"] >= full[key]["frac"]
     assert REQUIRED <= set(d)
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
