@@ -703,6 +703,10 @@ def run_all(torch, device, reps=3, cpu_budget_s=3.0, only=None, log=lambda m: No
             out[name] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
         log(f"{name} done")
+    if not only:
+        # whole-config decision records: the default arithmetic against the float32-MFMA set on the FULL BASELINE workloads (decision_records.py)
+        import decision_records
+        out["decision_records"] = decision_records.run_all(torch, device, log=log)
     return out
 
 

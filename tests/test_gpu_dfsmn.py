@@ -273,3 +273,11 @@ def test_packed_frame_layout_is_bitwise_the_unpacked_one(wts):
         y_p = dfsmn.from_ft(net.forward(x4, chunks, 101, pack=True), chunks)
         y_u = dfsmn.from_ft(net.forward(x4, chunks, 101, pack=False), chunks)
         assert torch.isfinite(y_u).all() and torch.equal(y_p, y_u), chunks
+
+
+def test_whole_config_decision_record():
+    """BASELINE config 5 (DFSMN half) at full size: silence flags of the default arithmetic (bf16 x 3 in these kernels) against float32 MFMAs."""
+    import decision_records
+    r = decision_records.dfsmn_c5(torch, torch.device("cuda", 0))
+    print(r)
+    assert r["unexcused"] == 0, r

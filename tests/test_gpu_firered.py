@@ -232,3 +232,11 @@ def test_device_stream_postprocessor_many_streams_equals_the_host_class(cfg):
             assert got[s_] == host[s_].process_batch(tracks[s_, pos:pos + size].copy()), (s_, pos)
         pos += size
     assert pos == n and any(len(x) for x in got)
+
+
+def test_whole_config_decision_record():
+    """BASELINE config 5 (FireRed half) at full size: segment lists of the default arithmetic against float32 MFMAs + dense float32 front-end."""
+    import decision_records
+    r = decision_records.firered_c5(torch, torch.device("cuda", 0))
+    print(r)
+    assert r["compared"] == 2048 and r["unexcused"] == 0, r

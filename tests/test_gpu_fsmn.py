@@ -270,3 +270,13 @@ def test_kind3_frontend_keeps_the_scores_and_decisions(monkeypatch):
     lm3, _ = eng3.features(clips, W, stride)
     assert np.array_equal(flags, flags3)
     assert float((lm - lm3).abs().max()) < 5e-3
+
+
+def test_whole_config_decision_record():
+    """BASELINE config 3 at full size: the 4 485 120 silence flags of the default arithmetic (fp16 x 2 dense layers, front-end kind 5) against
+    float32 MFMAs + the dense float32 front-end; every clip with a differing flag is replayed window by window and its first differing gate
+    output must sit on the score threshold."""
+    import decision_records
+    r = decision_records.fsmn_c3(torch, torch.device("cuda", 0))
+    print(r)
+    assert r["compared"] == 4096 * (15 * 71 + 30) and r["unexcused"] == 0, r

@@ -118,3 +118,11 @@ def test_fused_blocks_equal_the_per_sub_block_launches():
         assert slen == rlen and s1.shape == r1.shape
         np.testing.assert_allclose(s1.cpu().numpy(), r1.cpu().numpy(), rtol=0, atol=5e-6)
         np.testing.assert_allclose(s0.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=5e-6)
+
+
+def test_whole_config_decision_record():
+    """BASELINE config 4 at full size (8192 clips): segment lists with the default front-end (kind 5) against the dense float32 product."""
+    import decision_records
+    r = decision_records.marblenet_c4(torch, torch.device("cuda", 0))
+    print(r)
+    assert r["compared"] == 8192 and r["unexcused"] == 0, r

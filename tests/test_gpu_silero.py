@@ -466,3 +466,12 @@ def test_wrapper_8k_plumbing_and_refusal(golden, engine):
         m2(torch.zeros(1, 512), 8000)
     with pytest.raises(ValueError, match="16 kHz sub-graph"):
         silero.get_speech_timestamps(torch.zeros(4000), m2, sampling_rate=8000)
+
+
+def test_whole_config_decision_record():
+    """BASELINE config 2 at full size, the bench's own batch: segment tables of the default arithmetic (fp16 x 2) against the float32-MFMA
+    kernels -- every clip whose table differs must have a score within 2e-4 of a threshold, and the tracks agree within 1e-4."""
+    import decision_records
+    r = decision_records.silero_c2(torch, torch.device("cuda", 0))
+    print(r)
+    assert r["compared"] == 4096 and r["unexcused"] == 0 and r["max_abs_score_difference"] <= 1e-4, r
