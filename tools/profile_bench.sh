@@ -18,6 +18,7 @@ run fetch 2 1 --pmc FETCH_SIZE
 run write 2 1 --pmc WRITE_SIZE
 run sq    2 1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE
 run sq2   2 1 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+run mem   2 1 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys, collections
 csv.field_size_limit(1 << 30)
@@ -39,7 +40,7 @@ for f in glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True):
         acc[(short(row["Kernel_Name"]), int(row["Grid_Size_X"]))].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     p("# per (kernel, grid) dispatch durations from the kernel trace [ns]: n, mean, median, min, max")
     for (k, g), v in sorted(acc.items()): p(f"{k:46s} grid={g:10d} n={len(v):3d} mean={sum(v)/len(v):14.1f} median={sorted(v)[len(v)//2]:12d} min={min(v):12d} max={max(v):12d}")
-for name in ("fetch", "write", "sq", "sq2"):
+for name in ("fetch", "write", "sq", "sq2", "mem"):
     for f in glob.glob(out + f"/{name}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(f)):

@@ -78,6 +78,9 @@ __device__ __forceinline__ void split2x4(const f32x4 x, u32x2 &p0, u32x2 &p1, fl
     p1 = u32x2{__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)};
     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));      // v_max3_f32 with |.| modifiers
     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+    // (pinned here: nothing reads amax until the kernel's end, so the scheduler otherwise sinks the whole max chain behind the next GEMM and
+    //  keeps every x alive for it -- in silero_h2.hip that was 12 spilled registers per thread and 2.3 GB of scratch traffic per launch)
+    asm volatile("" : "+v"(amax));
 }
 // one float32 value -> its two fp16 terms
 __device__ __forceinline__ void split2x1(float x, unsigned short &h0, unsigned short &h1, float &amax) {
@@ -87,6 +90,7 @@ __device__ __forceinline__ void split2x1(float x, unsigned short &h0, unsigned s
     h0 = __builtin_bit_cast(unsigned short, a);
     h1 = __builtin_bit_cast(unsigned short, b);
     amax = __builtin_fmaxf(amax, __builtin_fabsf(x));
+    asm volatile("" : "+v"(amax));
 }
 
 // The three products of one K = 32 step for one (row tile, column tile): cross terms into `mid` (scale 2^11), h0 x h0 into `hi`.
