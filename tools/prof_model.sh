@@ -7,7 +7,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats"
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE -d "$OUT/sq" -o s -- python3 tools/prof_model.py "$M" 1 > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d "$OUT/sq2" -o s -- python3 tools/prof_model.py "$M" 1 > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum -d "$OUT/mem" -o s -- python3 tools/prof_model.py "$M" 1 > /dev/null 2>&1
-timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM -d "$OUT/sq3" -o s -- python3 tools/prof_model.py "$M" 1 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE WRITE_SIZE -d "$OUT/sq3" -o s -- python3 tools/prof_model.py "$M" 1 > /dev/null 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 csv.field_size_limit(1 << 30)

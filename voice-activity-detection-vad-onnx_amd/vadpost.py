@@ -204,8 +204,12 @@ class StreamVadPostprocessorBatch:
         self.streams, self.cap, self.frames_per_second = int(streams), cap, frames_per_second      # cap None: what a chunk can hold at most
         self.prm = _lib.StreamVadPostParams(int(smooth_window_size), float(np.float32(speech_threshold)), int(pad_start_frame),
                                             int(min_speech_frame), int(max_speech_frame), int(min_silence_frame))
+        # The device record's ring buffer holds 16 frames: a wider smoothing window runs the host class per stream (same results, the
+        # reference's own code path) instead of refusing what the reference accepts.
+        self._host = None
         if max(1, int(smooth_window_size)) > 16:
-            raise ValueError("smooth_window_size > 16 is outside the device kernel's ring buffer")
+            self._host = [StreamVadPostprocessor(smooth_window_size, speech_threshold, pad_start_frame, min_speech_frame, max_speech_frame,
+                                                 min_silence_frame, frames_per_second) for _ in range(self.streams)]
         self._C = C
         nbytes = _lib.lib().vadx_stream_vadpost_state_bytes(self.streams)
         self.state = t.zeros(nbytes, dtype=t.uint8, device=self.device)
@@ -213,9 +217,16 @@ class StreamVadPostprocessorBatch:
 
     def reset(self):
         self._fresh = True
+        for h in self._host or ():
+            h.reset()
 
     def process_batch(self, track, flush=True):
         t, C = self.torch, self._C
+        if self._host is not None:
+            tr = track.detach().cpu().numpy() if t.is_tensor(track) else np.asarray(track, dtype=np.float32)
+            if tr.ndim != 2 or tr.shape[0] != self.streams:
+                raise ValueError(f"track must be [{self.streams}, frames], got {tuple(tr.shape)}")
+            return [h.process_batch(tr[s]) for s, h in enumerate(self._host)]
         x = track if t.is_tensor(track) else t.from_numpy(np.ascontiguousarray(track, dtype=np.float32))
         x = x.to(device=self.device, dtype=t.float32)
         if x.dim() != 2 or x.shape[0] != self.streams:
@@ -224,7 +235,9 @@ class StreamVadPostprocessorBatch:
             return [[] for _ in range(self.streams)]
         if x.stride(1) != 1:
             x = x.contiguous()
-        cap = int(self.cap) if self.cap else int(x.shape[1]) // 2 + 2      # a segment takes a speech and a silence frame; + the open one
+        # worst case: max_speech_frame = 1 closes one segment per frame by forced splits; + the open one.  (The kernel advances the device
+        # state even when the table overflows, so the table must never be the thing that is too small.)
+        cap = max(int(self.cap) if self.cap else 0, int(x.shape[1]) + 1)
         segs = t.empty((self.streams, cap, 2), dtype=t.int32, device=self.device)
         counts = t.empty((self.streams,), dtype=t.int32, device=self.device)
         with t.cuda.device(self.device):
