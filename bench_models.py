@@ -141,6 +141,34 @@ def flop_marblenet_out_frame():
     return 2 * (mac + 2 * cin)
 
 
+def flop_marblenet_h2_out_frame():
+    """the part of flop_marblenet_out_frame() that runs as fp16 x 2 split products when the engine's mode is "h2": the 1x1 convs of the
+    three fused residual blocks (pointwise 0 / 1 + the residual branch; csrc/marblenet.hip: kgemm_h)"""
+    from vadx import weights
+    mac, cin = 0, 80
+    for bi, (filt, rep, _k, _s, _d, residual, _sep) in enumerate(weights.MARBLENET_BLOCKS):
+        block_cin = cin
+        for _ in range(rep):
+            mac += cin * filt if residual else 0
+            cin = filt
+        if residual:
+            mac += block_cin * filt
+    return 2 * mac
+
+
+def _roof_mix(kernel, flop, flop_h2, ms, tag=None, kernel_substr=None, note=None):
+    """A group of launches whose products run partly on fp16 x 2 split products and partly on f32 MFMAs, priced against the peak of ITS pipe
+    mix: peak = flops / (the time the two pipes need at their own peaks)"""
+    f_f32 = max(flop - flop_h2, 0.0)
+    t_min = flop_h2 / PEAK_BY_ARITH["h2"] + f_f32 / PEAK_BY_ARITH["f32"]
+    t_sus = flop_h2 / (PEAK_BY_ARITH["h2"] * SUSTAINED_OF_NOMINAL["h2"]) + f_f32 / (PEAK_BY_ARITH["f32"] * SUSTAINED_OF_NOMINAL["f32"])
+    r = _roof(kernel, flop, ms, tag, kernel_substr, note, split="f32")
+    r.update({"arithmetic": "mix" if flop_h2 else "f32", "peak": flop / t_min, "frac": r["achieved"] / (flop / t_min),
+              "frac_of_sustained": r["achieved"] / (flop / t_sus), "flop_on_split_products": flop_h2})
+    r.pop("sustained_of_nominal", None)
+    return r
+
+
 def flop_dfsmn_window(T=101, TA=51, F=160, ch=20):
     """One 16001-sample near+far window (Export_DFSMN_VAD.py:317-354), by stage."""
     def lstm(i, h, bi=False, layers=1):
@@ -545,8 +573,11 @@ def marblenet_c4(torch, device, reps, cpu, clips=8192, log=lambda m: None, tag="
            "clips": clips, "samples_per_clip": n, "ms": ms, "frames_per_s": clips * n / 512 / (ms * 1e-3),
            "kernel_ms": split, "kernel_calls": calls,
            "roofline": _roof_frontend(clips * T, 257, 400, fe_ms, tag, fold=eng.frontend(n).fold),
-           "roofline_net": _roof("marblenet encoder+decoder launches", clips * Tout * flop_marblenet_out_frame(), net_ms, tag, "vadx::marblenet::",
-                                 note="sum of the encoder / classifier entries in kernel_ms (fused block pairs, single blocks, tail)"),
+           "roofline_net": _roof_mix("marblenet encoder+decoder launches", clips * Tout * flop_marblenet_out_frame(),
+                                     clips * Tout * flop_marblenet_h2_out_frame() if eng.mode() == "h2" else 0.0, net_ms, tag, "vadx::marblenet::",
+                                     note="sum of the encoder / classifier entries in kernel_ms (fused block pairs, single blocks, tail); the fused "
+                                          "blocks' 1x1 convs run on fp16 x 2 split products (priced at 2500 / 3), everything else on f32 MFMAs"),
+           "encoder_arithmetic": eng.mode(), "range_fallbacks": eng.range_fallbacks,
            "hbm": _hbm(clips * (n * 2 + 2 * Tout * 4), ms, tag), "cpu_baseline": None}
     del audio
     if cpu:

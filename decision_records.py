@@ -155,11 +155,14 @@ def marblenet_c4(torch, device, clips=8192):
     audio = bm.synth_pcm16(torch, device, clips, n, seed=1404).cpu().numpy()
     w = weights.marblenet_synthetic(1234)
     eng = marblenet.MarbleNetEngine(w, device=device)
+    eng.arithmetic = "h2"                                                           # fused blocks' 1x1 convs on fp16 x 2 (the default)
     got_a, tr_a, _ = eng.detect(audio, return_probs=True)
     ref = marblenet.MarbleNetEngine(w, device=device)
-    ref._fe[n] = frontend.Frontend("marblenet", n, device=device, fold=False)      # the encoder is float32 MFMAs in both: the front-end is what differs
+    ref.arithmetic = "f32"
+    ref._fe[n] = frontend.Frontend("marblenet", n, device=device, fold=False)      # dense float32 front-end product
     got_b, tr_b, _ = ref.detect(audio, return_probs=True)
-    return _post_records("C4 MarbleNet", tr_a.cpu().numpy(), tr_b.cpu().numpy(), got_a, got_b, 0.5, 3, {"frontend_kind": int(eng.frontend(n).fold)})
+    return _post_records("C4 MarbleNet", tr_a.cpu().numpy(), tr_b.cpu().numpy(), got_a, got_b, 0.5, 3,
+                         {"frontend_kind": int(eng.frontend(n).fold), "encoder": eng.mode(), "range_fallbacks": eng.range_fallbacks})
 
 
 def firered_c5(torch, device, clips=2048):

@@ -398,9 +398,19 @@ int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w, const flo
  * vadx_sepconv_block (dw [c][kernel]; pw / res fragment-major, BatchNorm folded; biases padded to 16).
  * tail: block 5 (depthwise k 29, dilation 2, 64 -> 128) -> block 6 (plain 1x1, 128 -> 128) -> Linear(128 -> 2) -> softmax,
  * x [B][64][T] -> score0 / score1 [B][T] (dec_w [2][128], dec_b [2]); the 128-channel tensors never reach HBM. */
+/* cfg (may be NULL = float32 MFMAs): `arithmetic` VADX_ARITH_AUTO / VADX_ARITH_F32 -- pw0 / pw1 / res_w are fragment-major float32
+ * (vadx_frag_major_host); VADX_ARITH_F16X2 -- they are fp16 x 2 fragments (vadx_frag_h2_host) and the three 1x1 convs run as split
+ * products on the fp16 pipe (float32-class results, csrc/split2.h); `range_flag` then points at two device words {sticky flag, bits of the
+ * largest |operand|} that a launch raises when an activation left the fp16 range -- the caller reads them with the results and recomputes
+ * that batch on VADX_ARITH_F32 (MarbleNetEngine does).  VADX_ARITH_BF16X3 is refused (no such form of these kernels). */
+typedef struct vadx_marblenet_cfg {
+    int32_t arithmetic;       /* VADX_ARITH_* */
+    int32_t reserved;
+    void *range_flag;         /* device uint32_t[2], zeroed by the caller; required for VADX_ARITH_F16X2 */
+} vadx_marblenet_cfg;
 int vadx_marblenet_block2(int cin, int kernel, const float *dw0, const float *pw0, const float *b0, const float *dw1,
                           const float *pw1, const float *b1, const float *res_w, const float *res_b, const float *x,
-                          float *y, int batch, int frames, void *stream);
+                          float *y, int batch, int frames, void *stream, const vadx_marblenet_cfg *cfg);
 int vadx_marblenet_tail(const float *dw, const float *pw, const float *pb, const float *w6, const float *b6,
                         const float *dec_w, const float *dec_b, const float *x, float *score0, float *score1,
                         int batch, int frames, void *stream);
@@ -548,6 +558,12 @@ int vadx_ingest_pcm16(const int16_t *src, int64_t src_stride, int channels, int6
  * expect buffers converted with this helper.  dst holds vadx_frag_major_floats(rows, cols) floats. */
 size_t vadx_frag_major_floats(int rows, int cols);
 int vadx_frag_major_host(const float *src, int rows, int cols, float *dst);
+/* The fp16 x 2 counterpart for the entry points that take bare weight pointers and an `arithmetic` (vadx_marblenet_block2):
+ * [rows/16 tiles][cols/32 chunks][2 planes][64 lanes][8 fp16], lane 16q+i slot e = W[16*tile + i][32*chunk + 16*(e>>2) + 4*q + (e&3)]
+ * (round-to-nearest fp16 terms h0, h1 = (w - h0) * 2^11; csrc/split2.h).  dst holds vadx_frag_h2_floats(rows, cols) floats; *wmax_out
+ * (optional) receives the largest |w|; fails when a weight is outside the fp16 range (keep that matrix on VADX_ARITH_F32). */
+size_t vadx_frag_h2_floats(int rows, int cols);
+int vadx_frag_h2_host(const float *src, int rows, int cols, float *dst, float *wmax_out);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,28 @@ def test_pack_host_layout(lib):
     assert b"NULL" in lib.vadx_last_error()
 
 
+def test_fp16x2_fragment_packer_layout_and_range():
+    """vadx_frag_h2_host: the two round-to-nearest fp16 terms of every weight land in lane (q, i) slot e of their (tile, chunk) fragment pair with
+    k = 32 chunk + 16 (e >> 2) + 4 q + (e & 3); h0 + h1 2^-11 reproduces the weight to a float32 ulp; a weight outside the fp16 range is refused."""
+    from vadx import _lib
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal((20, 70)) * np.exp(rng.uniform(-6, 6, (20, 70)))).astype(np.float32)
+    fr = _lib.frag_h2(a)
+    assert fr is not None and fr.size == 2 * 3 * 2 * 256
+    h = fr.view(np.float16).reshape(2, 3, 2, 4, 16, 8)                      # tile, chunk, plane, q, i, e
+    back = np.zeros((32, 96), np.float64)
+    for q in range(4):
+        for e in range(8):
+            k = 16 * (e >> 2) + 4 * q + (e & 3)
+            for c in range(3):
+                back[:, 32 * c + k] = (h[:, c, 0, q, :, e].astype(np.float64) + h[:, c, 1, q, :, e].astype(np.float64) / 2048.0).reshape(32)
+    assert not back[20:].any() and not back[:, 70:].any()
+    err = np.abs(back[:20, :70] - a.astype(np.float64))
+    assert np.all(err <= np.abs(a) * 2.0 ** -23 + 2.0 ** -36), float((err / np.abs(a)).max())
+    a[3, 5] = 7e4
+    assert _lib.frag_h2(a) is None and b"fp16 range" in _lib.lib().vadx_last_error()
+
+
 def test_dfsmn_entry_points_validate_before_touching_the_device():
     """Argument checks of the ICCRN building blocks run on the host, before any HIP call: unsupported shapes / missing operands
     come back as VADX_EINVAL with a message (the pw_conv kernel is instantiated for the ICCRN's seven (co, cin, kf, mode) only)."""

@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 ATOL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["f32", "h2"])
+def gemm(request):
+    """Every test of this file runs on both arithmetics of the fused blocks' 1x1 convs: float32 MFMAs and fp16 x 2 split products (the default)."""
+    from vadx import _lib
+    prev = _lib.gemm_mode(request.param)
+    yield request.param
+    _lib.gemm_mode(prev)
+
+
 def T(x):
     return torch.from_numpy(np.ascontiguousarray(x))
 
@@ -120,8 +129,39 @@ def test_fused_blocks_equal_the_per_sub_block_launches():
         np.testing.assert_allclose(s0.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=5e-6)
 
 
-def test_whole_config_decision_record():
-    """BASELINE config 4 at full size (8192 clips): segment lists with the default front-end (kind 5) against the dense float32 product."""
+def test_fp16_range_protocol(gemm):
+    """fp16 x 2 has no float32 exponent range: with the prologue's 1x1 weights scaled so that block 1's input exceeds 65504 the fused block
+    raises the range flag, the engine recomputes the batch on float32 MFMAs and returns exactly their scores; weights that cannot be
+    packed as fp16 keep the engine on float32 from the start."""
+    if gemm != "h2":
+        pytest.skip("the range protocol belongs to the fp16 x 2 arithmetic")
+    w = dict(weights.marblenet_synthetic(7))
+    w["b0r0_pw"] = np.asarray(w["b0r0_pw"]) * 3e4
+    clips = T(weights.burst_clips(3, 16000, seed=5)).cuda()
+    eng = marblenet.MarbleNetEngine(w)
+    assert eng.mode() == "h2"
+    s0, s1, _ = eng.run(clips)
+    assert eng.range_fallbacks == 1 and int(eng._flag[0].item()) == 0
+    ref = marblenet.MarbleNetEngine(w)
+    ref.arithmetic = "f32"
+    r0, r1, _ = ref.run(clips)
+    assert torch.equal(s1, r1) and torch.equal(s0, r0) and ref.range_fallbacks == 0
+    ok = marblenet.MarbleNetEngine(weights.marblenet_synthetic(7))
+    ok.run(clips)
+    assert ok.mode() == "h2" and ok.range_fallbacks == 0                    # in-range audio and weights never flag
+    w2 = dict(weights.marblenet_synthetic(7))
+    pw = np.array(w2["b1r0_pw"], dtype=np.float32)
+    pw.flat[0] = 1e9                                                        # (BatchNorm folding scales it, still far outside fp16)
+    w2["b1r0_pw"] = pw
+    big = marblenet.MarbleNetEngine(w2)
+    assert not big.h2_ok and big.mode() == "f32"
+
+
+def test_whole_config_decision_record(gemm):
+    """BASELINE config 4 at full size (8192 clips): segment lists of the default set (front-end kind 5, fused blocks on fp16 x 2) against the
+    float32 set (dense float32 front-end product, float32 MFMAs)."""
+    if gemm != "h2":
+        pytest.skip("one run: the record sets both engines' arithmetic itself")
     import decision_records
     r = decision_records.marblenet_c4(torch, torch.device("cuda", 0))
     print(r)

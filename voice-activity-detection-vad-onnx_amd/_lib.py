@@ -43,6 +43,11 @@ class SileroWeightsHost(C.Structure):
                 ("lstm_b_hh", C.c_void_p), ("dec_w", C.c_void_p), ("dec_b", C.c_void_p)]
 
 
+class MarbleNetCfg(C.Structure):
+    """vadx_marblenet_cfg (include/vadx.h): arithmetic of the fused MarbleNet block launches + the fp16 x 2 range flag words"""
+    _fields_ = [("arithmetic", C.c_int32), ("reserved", C.c_int32), ("range_flag", C.c_void_p)]
+
+
 class SileroCfg(C.Structure):
     """vadx_silero_cfg (include/vadx.h): per-call configuration of the Silero launches"""
     _fields_ = [("arithmetic", C.c_int32), ("reserved", C.c_int32 * 3)]
@@ -175,7 +180,9 @@ SIGNATURES = {
     "vadx_vadpost_workspace_bytes": (_Z, [_I, _I]),
     "vadx_vadpost": (_I, [C.POINTER(VadPostParams), _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "vadx_sepconv_block": (_I, [C.POINTER(SepConvCfg), _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _I, _I, _P]),
-    "vadx_marblenet_block2": (_I, [_I, _I] + [_P] * 10 + [_I, _I, _P]),
+    "vadx_marblenet_block2": (_I, [_I, _I] + [_P] * 10 + [_I, _I, _P, C.POINTER(MarbleNetCfg)]),
+    "vadx_frag_h2_floats": (C.c_size_t, [_I, _I]),
+    "vadx_frag_h2_host": (_I, [_P, _I, _I, _P, _P]),
     "vadx_marblenet_tail": (_I, [_P] * 10 + [_I, _I, _P]),
     "vadx_frame_classifier": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vadx_dfsmn_frame_stats": (_I, [C.POINTER(FtView), C.POINTER(FtView), _I, _I, _P, _P]),
@@ -358,6 +365,19 @@ def frag_major(a):
         raise ValueError("frag_major expects a 2-D matrix")
     out = np.empty(lib().vadx_frag_major_floats(a.shape[0], a.shape[1]), dtype=np.float32)
     check(lib().vadx_frag_major_host(a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data))
+    return out
+
+
+def frag_h2(a):
+    """row-major float32 [rows][cols] -> fp16 x 2 fragments (include/vadx.h: vadx_frag_h2_host) as a float32-typed 1-D buffer, or None when
+    a weight lies outside the fp16 range (the caller keeps that matrix on float32)."""
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError("frag_h2 expects a 2-D matrix")
+    out = np.empty(lib().vadx_frag_h2_floats(a.shape[0], a.shape[1]), dtype=np.float32)
+    if lib().vadx_frag_h2_host(a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data, None) != 0:
+        return None
     return out
 
 

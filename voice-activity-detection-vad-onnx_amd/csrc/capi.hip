@@ -1,5 +1,6 @@
 // capi.hip -- error plumbing and the weight-layout helper shared by every libvadx entry point.
 #include "common.h"
+#include "split2.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -30,5 +31,30 @@ extern "C" int vadx_frag_major_host(const float *src, int rows, int cols, float 
     for (size_t e = 0; e < n; ++e) dst[e] = 0.f;
     for (int r = 0; r < rows; ++r)
         for (int k = 0; k < cols; ++k) dst[vadx::frag_index(ldw, r, k)] = src[(size_t)r * cols + k];
+    return VADX_OK;
+}
+
+// fp16 x 2 fragments of a [rows][cols] weight matrix for the kernels that split their own activation operand (marblenet.hip: kgemm_h):
+// [rows/16 tiles][cols/32 chunks][2 planes][64 lanes][8 fp16]; lane 16 q + i, slot e holds W[16 tile + i][32 chunk + 16 (e >> 2) + 4 q + (e & 3)]
+// -- the k-slot order in which those kernels read k-major float32 rows without bank conflicts.
+extern "C" size_t vadx_frag_h2_floats(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (size_t)((rows + 15) / 16) * (size_t)((cols + 31) / 32) * 2 * vadx::HFRAG;
+}
+
+extern "C" int vadx_frag_h2_host(const float *src, int rows, int cols, float *dst, float *wmax_out) {
+    VADX_REQUIRE(src && dst && rows > 0 && cols > 0, "vadx_frag_h2_host: bad argument");
+    const size_t n = vadx_frag_h2_floats(rows, cols);
+    const int nch = (cols + 31) / 32;
+    memset(dst, 0, n * sizeof(float));
+    float wmax = 0.f;
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < cols; ++k) {
+            const int kk = k & 31, q = (kk >> 2) & 3, e = ((kk >> 4) << 2) | (kk & 3);
+            const float a = vadx::hfrag_put(dst + (size_t)(((r / 16) * nch + k / 32) * 2) * vadx::HFRAG, r % 16, 8 * q + e, src[(size_t)r * cols + k]);
+            if (!(a <= wmax)) wmax = a;
+        }
+    if (wmax_out) *wmax_out = wmax;
+    VADX_REQUIRE(wmax <= vadx::H_MAX, "vadx_frag_h2_host: a weight (|w| = %g) is outside the fp16 range: keep this matrix on VADX_ARITH_F32", (double)wmax);
     return VADX_OK;
 }

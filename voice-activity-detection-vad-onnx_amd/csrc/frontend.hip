@@ -1141,6 +1141,9 @@ __device__ __forceinline__ int sq_slot(int b) { return b + 2 * ((b * 3277) >> 18
 constexpr int SQ_BLOCKS = 63 * 20 + 4 * 16;                                               // blocks of a 64-frame tile, taps <= 512
 constexpr int SQ_PLANE_BYTES = (SQ_BLOCKS + 2 * (SQ_BLOCKS / 80) + 2 + 7) / 8 * 8 * 16;
 constexpr int SQ_THREADS = 256, SQ_WAVES = SQ_THREADS / 64;
+#ifndef FE_RING
+#define FE_RING 2          /* table fragments requested FE_RING - 1 chunks ahead (layers_split.h: qgemm_group) */
+#endif
 static size_t split_lds_bytes(const Dev *d) {
     const size_t pw = (size_t)d->Fp * XF_LD * 4;
     return pw > 3 * (size_t)SQ_PLANE_BYTES ? pw : 3 * (size_t)SQ_PLANE_BYTES;
@@ -1215,7 +1218,7 @@ __device__ __forceinline__ void split_tile(const Dev &d, const float *__restrict
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { hi[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][mt] = hi[a][mt]; }
         const float *const w[2] = {tab + (size_t)(2 * bt) * tstride, tab + (size_t)(2 * bt + 1) * tstride};
-        vadx::qgemm_group<SC, 2, MT, true>(hi, lo, w, 0, d.s_nch, smem, SQ_PLANE_BYTES,
+        vadx::qgemm_group<SC, 2, MT, true, FE_RING>(hi, lo, w, 0, d.s_nch, smem, SQ_PLANE_BYTES,
                                        [=](int G, int mt) { return sq_slot(20 * (16 * mt + i) + G) * 16; }, lane);
         f32x4 p[MT];
 #pragma unroll

@@ -29,20 +29,22 @@ struct QLayerArgs {
 
 // One group of NT n-tiles x MTT column tiles.  baddr(kgrp, mt) -> byte offset (inside a plane) of this lane's 16-byte B block of
 // k-group kgrp in column tile mt, or of a block of zeros when kgrp lies beyond the layer's K.
-template <typename SC, int NT, int MTT, bool OUT_PLANES, typename BAddr>
+// RING: chunk kc + RING - 1 is requested before chunk kc's MFMAs issue (2 = one chunk ahead; a deeper ring costs NT * NP * 4 registers per
+// step and pays where few waves share a SIMD and a step's MFMAs are shorter than the L2 round trip).
+template <typename SC, int NT, int MTT, bool OUT_PLANES, int RING = 2, typename BAddr>
 __device__ __forceinline__ void qgemm_group(f32x4 (&hi)[NT][MTT], f32x4 (&lo)[NT][MTT], const float *const (&w)[NT], int kc0, int kc1,
                                             const unsigned char *act, int act_pl, BAddr baddr, int lane) {
     const int q = lane >> 4;
     constexpr int NP = SC::NP;
     typedef typename SC::frag frag;
-    frag a0[NT][NP], a1[NT][NP];
+    frag ar[RING][NT][NP];
     auto load_a = [&](int kc, frag (&a)[NT][NP]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
 #if defined(QG_WHATIF) && (QG_WHATIF & 1)
-                if (kc > kc0) { a[nt][p] = a0[nt][p]; continue; }     // what-if: the weight stream costs nothing
+                if (kc > kc0) { a[nt][p] = ar[0][nt][p]; continue; }     // what-if: the weight stream costs nothing
 #endif
                 a[nt][p] = SC::ld(w[nt] + (size_t)(kc * NP + p) * QFRAG, lane);
             }
@@ -65,15 +67,31 @@ __device__ __forceinline__ void qgemm_group(f32x4 (&hi)[NT][MTT], f32x4 (&lo)[NT
             }
         SC::template products<NT, MTT, OUT_PLANES>(a, b, hi, lo);
     };
-    load_a(kc0, a0);
-    for (int kc = kc0; kc < kc1; kc += 2) {
-        if (kc + 1 < kc1) load_a(kc + 1, a1);
-        __builtin_amdgcn_sched_barrier(0);      // the next chunk's fragments are requested before this chunk's MFMAs issue
-        step(kc, a0);
-        if (kc + 1 < kc1) {
-            if (kc + 2 < kc1) load_a(kc + 2, a0);
-            __builtin_amdgcn_sched_barrier(0);
-            step(kc + 1, a1);
+    if constexpr (RING == 2) {                      // (spelled out: this form allocates fewer registers than the general loop below)
+        load_a(kc0, ar[0]);
+        for (int kc = kc0; kc < kc1; kc += 2) {
+            if (kc + 1 < kc1) load_a(kc + 1, ar[1]);
+            __builtin_amdgcn_sched_barrier(0);      // the next chunk's fragments are requested before this chunk's MFMAs issue
+            step(kc, ar[0]);
+            if (kc + 1 < kc1) {
+                if (kc + 2 < kc1) load_a(kc + 2, ar[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                step(kc + 1, ar[1]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RING - 1; ++j)
+            if (kc0 + j < kc1) load_a(kc0 + j, ar[j]);
+        for (int kc = kc0; kc < kc1; kc += RING) {
+#pragma unroll
+            for (int j = 0; j < RING; ++j) {
+                if (kc + j < kc1) {
+                    if (kc + j + RING - 1 < kc1) load_a(kc + j + RING - 1, ar[(j + RING - 1) % RING]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    step(kc + j, ar[j]);
+                }
+            }
         }
     }
 }

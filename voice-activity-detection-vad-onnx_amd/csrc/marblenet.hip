@@ -10,6 +10,7 @@
 //   -> add, ReLU, coalesced store [B][C_out][T_out].
 #include "common.h"
 #include "layers.h"
+#include "split_scheme.h"
 
 // MB_EXP: development-only cycle accounting of jasper_block2_kernel (tools/exp_marblenet.py): per-section clock64 sums of thread 0
 #ifndef MB_EXP
@@ -262,9 +263,13 @@ __device__ __forceinline__ void kgemm(const KPre &p, int kdim, const float *act,
     for (int u = 0; u < 4; ++u) {
         if (u < nb) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+#if defined(MB_WHATIF) && (MB_WHATIF & 1)
+                if (j || (u & 1)) continue;                  // what-if: one MFMA in eight (the matrix time of an fp16 x 2 product)
+#endif
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = vadx::mfma16(ap[(16 * u + j) * lda + mt * 16], p.w[u][j], acc[mt]);
+            }
         }
     }
     float *dp = dst + (nt * 16 + i) * ldd + 4 * q;
@@ -284,12 +289,101 @@ __device__ __forceinline__ void kgemm(const KPre &p, int kdim, const float *act,
     }
 }
 
-template <int K>
+// The same GEMM on fp16 x 2 split products (split2.h): three v_mfma_f32_16x16x32_f16 per 32 channels and column tile instead of eight
+// v_mfma_f32_16x16x4_f32 -- on this kernel the f32 MFMAs shared the vector datapath with the depthwise filters (with one MFMA in eight
+// the three block launches ran 4.14 -> 2.72 ms).  The depthwise filters leave k-major float32 rows (a thread owns eight consecutive
+// frames of ONE channel), so there are no planes to read: a wave splits its own operand -- lane (q, i) reads the eight channels
+// 16 (e >> 2) + 4 q + (e & 3), e = 0..7, of frame i (the f32 kernel's conflict-free row pattern: quarters 4 rows = 16 banks apart),
+// splits them (3 VALU per value) and uses them as the A operand; the weights are the B operand, their fragments packed on the host in
+// the same k-slot order (vadx_frag_h2_host).  The four row-tile waves of a K half split the same values (4 x redundant, 28 VALU per
+// fragment): still a third of the datapath time of the f32 MFMAs they replace.
+struct KPreH { f16x8 w[2][2]; };         // [chunk of this wave's K half][plane]
+
+__device__ __forceinline__ KPreH kgemm_pre_h(const float *__restrict__ W, int kdim) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    asm volatile("" : "+v"(lane), "+v"(wave));
+    const int nt = wave & 3, kh = wave >> 2, nc = kdim >> 6;      // 32-k chunks per half: 1 (K = 64) or 2 (K = 128)
+    const float *base = W + (size_t)((nt * 2 * nc + kh * nc) * 2) * vadx::HFRAG;
+    KPreH p;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) p.w[u][pl] = vadx::ldh(base + (size_t)((u < nc ? u : nc - 1) * 2 + pl) * vadx::HFRAG, lane);      // unconditional, clamped
+    return p;
+}
+
+template <int MT>
+__device__ __forceinline__ void kgemm_h(const KPreH &p, int kdim, const float *act, int lda, int acol0, float *dst, int ldd,
+                                        const float *__restrict__ bias, bool relu, float &amax) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    asm volatile("" : "+v"(lane), "+v"(wave));
+    const int q = lane >> 4, i = lane & 15, nt = wave & 3, kh = wave >> 2, nc = kdim >> 6;
+    f32x4 hi[MT], mid[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { hi[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; mid[mt] = hi[mt]; }
+    const float *ap = act + (32 * kh * nc + 4 * q) * lda + acol0 + i;
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (u < nc) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 lo4, hi4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo4[j] = ap[(32 * u + j) * lda + mt * 16]; hi4[j] = ap[(32 * u + 16 + j) * lda + mt * 16]; }
+                u32x2 a0, a1, b0, b1;
+                vadx::split2x4(lo4, a0, a1, amax);
+                vadx::split2x4(hi4, b0, b1, amax);
+                const f16x8 x0 = __builtin_bit_cast(f16x8, u32x4_{a0[0], a0[1], b0[0], b0[1]});
+                const f16x8 x1 = __builtin_bit_cast(f16x8, u32x4_{a1[0], a1[1], b1[0], b1[1]});
+                mid[mt] = vadx::mfma_f16(x1, p.w[u][0], mid[mt]);
+                mid[mt] = vadx::mfma_f16(x0, p.w[u][1], mid[mt]);
+                hi[mt] = vadx::mfma_f16(x0, p.w[u][0], hi[mt]);
+            }
+        }
+    }
+    float *dp = dst + (nt * 16 + i) * ldd + 4 * q;
+    if (kh == 1)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4 *>(dp + mt * 16) = vadx::join2(hi[mt], mid[mt]);
+    __syncthreads();
+    if (kh == 0) {
+        const float b = bias[nt * 16 + i];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(dp + mt * 16);
+            const f32x4 own = vadx::join2(hi[mt], mid[mt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = (v[r] + own[r]) + b; if (relu) v[r] = fmaxf(v[r], 0.f); }
+            *reinterpret_cast<f32x4 *>(dp + mt * 16) = v;
+        }
+    }
+}
+
+// AR: 0 = float32 MFMAs (kgemm), 2 = fp16 x 2 split products (kgemm_h); one body for both
+template <int AR> struct KPreOf { typedef KPre type; };
+template <> struct KPreOf<vadx::VADX_AR_H2> { typedef KPreH type; };
+template <int AR>
+__device__ __forceinline__ typename KPreOf<AR>::type kpre(const float *__restrict__ W, int kdim) {
+    if constexpr (AR == vadx::VADX_AR_H2) return kgemm_pre_h(W, kdim);
+    else return kgemm_pre(W, kdim);
+}
+template <int AR, int MT>
+__device__ __forceinline__ void kmul(const typename KPreOf<AR>::type &p, int kdim, const float *act, int lda, int acol0, float *dst, int ldd,
+                                     const float *__restrict__ bias, bool relu, float &amax) {
+    if constexpr (AR == vadx::VADX_AR_H2) kgemm_h<MT>(p, kdim, act, lda, acol0, dst, ldd, bias, relu, amax);
+    else kgemm<MT>(p, kdim, act, lda, acol0, dst, ldd, bias, relu);
+}
+
+template <int K, int AR>
 __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     Blk2 c, const float *__restrict__ dw0, const float *__restrict__ pw0, const float *__restrict__ b0,
     const float *__restrict__ dw1, const float *__restrict__ pw1, const float *__restrict__ b1,
-    const float *__restrict__ rw, const float *__restrict__ rb, const float *__restrict__ x, float *__restrict__ y, int tiles) {
+    const float *__restrict__ rw, const float *__restrict__ rb, const float *__restrict__ x, float *__restrict__ y, int tiles,
+    unsigned *__restrict__ range_flag) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef typename KPreOf<AR>::type KP;
+    float amax = 0.f;
     constexpr int PAD = (K - 1) / 2, WIN0 = W1 + K - 1;
     const int IN_LD = c.in_ld;
     float *IN = lds, *H1 = IN + c.cinp * IN_LD, *ROUT = H1 + c.c1 * H_LD;
@@ -299,7 +393,7 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     const float *xb = x + (long long)b * c.cin * c.T;
     const int tin0 = t0 - 2 * PAD;
     MB_T0();
-    const KPre wres = kgemm_pre(rw, c.cinp);                 // in flight while the input tile is staged
+    const KP wres = kpre<AR>(rw, c.cinp);                    // in flight while the input tile is staged
     // ---- stage the block input (channel-first source: lane = time, wave = channel), unconditional clamped loads
     for (int ch0 = 0; ch0 < c.cinp; ch0 += 8 * (THREADS / 64)) {
         float v[8];
@@ -321,10 +415,10 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     // pointwise 0's weights: in flight through the residual GEMM and depthwise 0 -- except at K = 17, whose 24-value window + 17 taps +
     // 16 prefetched weight registers no longer fit the 80 VGPRs of six waves per SIMD (20 B of scratch per lane doubled the kernel's
     // HBM writes): there they are requested behind the filter
-    KPre wpw0;
-    if (K < 17) wpw0 = kgemm_pre(pw0, c.cinp);
+    KP wpw0;
+    if (K < 17) wpw0 = kpre<AR>(pw0, c.cinp);
     // residual 1x1 of the block input (frames t0 .. t0 + 31 sit at column 2 PAD), before the input is overwritten
-    kgemm<2>(wres, c.cinp, IN, IN_LD, 2 * PAD, ROUT, A_LD, rb, false);
+    kmul<AR, 2>(wres, c.cinp, IN, IN_LD, 2 * PAD, ROUT, A_LD, rb, false, amax);
     MB_ACC(1);
     __syncthreads();                // every residual operand is read: depthwise 0 may overwrite IN
     MB_ACC(7);
@@ -352,14 +446,14 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
             store8(row, o8);
         }
     }
-    if (K >= 17) wpw0 = kgemm_pre(pw0, c.cinp);
+    if (K >= 17) wpw0 = kpre<AR>(pw0, c.cinp);
     MB_ACC(2);
     __syncthreads();
     MB_ACC(7);
-    KPre wpw1;                                               // pointwise 1's weights: in flight through pointwise 0 and depthwise 1
-    if (K < 17) wpw1 = kgemm_pre(pw1, c.c1);
+    KP wpw1;                                                 // pointwise 1's weights: in flight through pointwise 0 and depthwise 1
+    if (K < 17) wpw1 = kpre<AR>(pw1, c.c1);
     // pointwise 0 + folded BN + ReLU on 48 columns
-    kgemm<3>(wpw0, c.cinp, D0, IN_LD, 0, H1, H_LD, b0, true);
+    kmul<AR, 3>(wpw0, c.cinp, D0, IN_LD, 0, H1, H_LD, b0, true, amax);
     MB_ACC(3);
     __syncthreads();
     MB_ACC(7);
@@ -386,11 +480,11 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
         }
         store8(D1 + ch * A_LD + m0, o8);                                // D1 sits in IN's region (D0 is dead since the barrier above)
     }
-    if (K >= 17) wpw1 = kgemm_pre(pw1, c.c1);
+    if (K >= 17) wpw1 = kpre<AR>(pw1, c.c1);
     MB_ACC(4);
     __syncthreads();                // every H1 read is done: OUT may overwrite it
     MB_ACC(7);
-    kgemm<2>(wpw1, c.c1, D1, A_LD, 0, OUT, A_LD, b1, false);
+    kmul<AR, 2>(wpw1, c.c1, D1, A_LD, 0, OUT, A_LD, b1, false, amax);
     MB_ACC(5);
     __syncthreads();
     MB_ACC(7);
@@ -400,6 +494,10 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
         if (t0 + m < c.T) yb[(long long)ch * c.T + t0 + m] = fmaxf(OUT[ch * A_LD + m] + ROUT[ch * A_LD + m], 0.f);
     }
     MB_ACC(6);
+    if (AR == vadx::VADX_AR_H2 && !(amax <= vadx::H_MAX)) {          // an operand left the fp16 range: the host recomputes this batch on float32
+        atomicOr(range_flag, 1u);
+        atomicMax(range_flag + 1, __float_as_uint(amax));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -563,8 +661,13 @@ extern "C" int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w
 
 extern "C" int vadx_marblenet_block2(int cin, int kernel, const float *dw0, const float *pw0, const float *b0, const float *dw1,
                                      const float *pw1, const float *b1, const float *res_w, const float *res_b, const float *x,
-                                     float *y, int batch, int frames, void *stream) {
+                                     float *y, int batch, int frames, void *stream, const vadx_marblenet_cfg *cfg) {
     VADX_REQUIRE(dw0 && pw0 && b0 && dw1 && pw1 && b1 && res_w && res_b && x && y, "vadx_marblenet_block2: NULL argument");
+    const int ar = vadx::arith_internal(cfg ? cfg->arithmetic : VADX_ARITH_AUTO, vadx::VADX_AR_F32);
+    VADX_REQUIRE(ar == vadx::VADX_AR_F32 || ar == vadx::VADX_AR_H2, "vadx_marblenet_block2: arithmetic must be AUTO / F32 (fragment-major weights) or "
+                 "F16X2 (vadx_frag_h2_host weights)");
+    VADX_REQUIRE(ar != vadx::VADX_AR_H2 || cfg->range_flag, "vadx_marblenet_block2: F16X2 needs cfg->range_flag (two device words)");
+    unsigned *flag = cfg ? static_cast<unsigned *>(cfg->range_flag) : nullptr;
     VADX_REQUIRE((cin == 64 || cin == 128) && (kernel == 13 || kernel == 15 || kernel == 17) && batch > 0 && frames > 0,
                  "vadx_marblenet_block2: built for the published MarbleNet 3x2x64 residual blocks (cin 64/128, 64 filters, kernel 13/15/17)");
     Blk2 c;
@@ -575,15 +678,21 @@ extern "C" int vadx_marblenet_block2(int cin, int kernel, const float *dw0, cons
     VADX_REQUIRE((long long)batch * tiles < (1LL << 31), "vadx_marblenet_block2: too many tiles");
     const size_t lds = ((size_t)c.cinp * c.in_ld + (size_t)c.c1 * H_LD + (size_t)c.c2 * A_LD) * sizeof(float);
     VADX_REQUIRE(c.cinp * c.in_ld >= c.c1 * A_LD, "vadx_marblenet_block2: the depthwise-1 output does not fit the input region");
-#define BLK2_LAUNCH(KK)                                                                                                        \
+#define BLK2_LAUNCH(KK, AR)                                                                                                    \
     do {                                                                                                                       \
-        VADX_DYN_LDS(jasper_block2_kernel<KK>, 128 * 1024);                                                                    \
-        hipLaunchKernelGGL(jasper_block2_kernel<KK>, dim3((unsigned)(batch * tiles)), dim3(THREADS), lds,                      \
-                           static_cast<hipStream_t>(stream), c, dw0, pw0, b0, dw1, pw1, b1, res_w, res_b, x, y, tiles);         \
+        VADX_DYN_LDS((jasper_block2_kernel<KK, AR>), 128 * 1024);                                                              \
+        hipLaunchKernelGGL((jasper_block2_kernel<KK, AR>), dim3((unsigned)(batch * tiles)), dim3(THREADS), lds,                \
+                           static_cast<hipStream_t>(stream), c, dw0, pw0, b0, dw1, pw1, b1, res_w, res_b, x, y, tiles, flag);   \
     } while (0)
-    if (kernel == 13) BLK2_LAUNCH(13);
-    else if (kernel == 15) BLK2_LAUNCH(15);
-    else BLK2_LAUNCH(17);
+    if (ar == vadx::VADX_AR_H2) {
+        if (kernel == 13) BLK2_LAUNCH(13, 2);
+        else if (kernel == 15) BLK2_LAUNCH(15, 2);
+        else BLK2_LAUNCH(17, 2);
+    } else {
+        if (kernel == 13) BLK2_LAUNCH(13, 0);
+        else if (kernel == 15) BLK2_LAUNCH(15, 0);
+        else BLK2_LAUNCH(17, 0);
+    }
 #undef BLK2_LAUNCH
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;

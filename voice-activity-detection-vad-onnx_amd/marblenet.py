@@ -51,11 +51,13 @@ class MarbleNetEngine:
                 last = r == rep - 1
                 cfg = _lib.SepConvCfg(cin, filt, k, stride, dil, 1 if sep else 0, block_cin if (residual and last) else 0, 1)
                 st = {"cfg": cfg, "dw": dev(w[p + "_dw"]) if sep else None, "pw": dev(_lib.frag_major(pw[:, :, 0])),
-                      "pb": dev(_pad16(pb, (0,))), "rw": None, "rb": None, "first": r == 0, "res": residual and last}
+                      "pb": dev(_pad16(pb, (0,))), "rw": None, "rb": None, "first": r == 0, "res": residual and last,
+                      "pw_host": _pad16(pw[:, :, 0], (0, 1)), "rw_host": None}
                 if residual and last:
                     rw, rb = _weights.fold_bn(np.asarray(w[f"b{bi}res_pw"])[:, :, None], None, w[f"b{bi}res_gamma"],
                                               w[f"b{bi}res_beta"], w[f"b{bi}res_mean"], w[f"b{bi}res_var"], eps)
                     st["rw"], st["rb"] = dev(_lib.frag_major(rw[:, :, 0])), dev(_pad16(rb, (0,)))
+                    st["rw_host"] = _pad16(rw[:, :, 0], (0, 1))
                 self.stages.append(st)
                 cin = filt
         self.cout = cin
@@ -63,6 +65,24 @@ class MarbleNetEngine:
         self._fe = {}
         # the published 3x2x64 layout runs on the fused kernels: one launch per residual block, one for blocks 5 + 6 + decoder
         self.fused = tuple(tuple(b) for b in blocks) == tuple(tuple(b) for b in _weights.MARBLENET_BLOCKS)
+        # fp16 x 2 split products for the 1x1 convs of the fused residual blocks (csrc/split2.h; include/vadx.h: vadx_marblenet_cfg)
+        self.arithmetic = None            # None = the module default (_lib.gemm_mode()); "h2" | "f32" ("split" has no form here: float32)
+        self.h2_ok = False
+        self.range_fallbacks = 0          # batches recomputed on float32 because an activation left the fp16 range
+        self._flag = torch.zeros(2, dtype=torch.int32, device=self.device)
+        if self.fused:
+            self.h2_ok = True
+            for k in range(1, 7):
+                st = self.stages[k]
+                for name in ("pw", "rw"):
+                    host = st[name + "_host"]
+                    frags = None if host is None else _lib.frag_h2(host)
+                    st[name + "_h"] = None if frags is None else dev(frags)
+                    self.h2_ok = self.h2_ok and (host is None or frags is not None)
+
+    def mode(self):
+        m = self.arithmetic or _lib.gemm_mode()
+        return "h2" if (m == "h2" and self.h2_ok) else "f32"
 
     def frontend(self, L):
         if L not in self._fe:
@@ -84,7 +104,13 @@ class MarbleNetEngine:
         block_in = None
         lib = _lib.lib()
         if self.fused:
-            return self._run_fused(x, N, T)
+            mode = self.mode()
+            out = self._run_fused(x, N, T, mode)
+            if mode == "h2" and int(self._flag[0].item()) != 0:      # (synchronises) an activation left the fp16 range: float32 MFMAs
+                self.range_fallbacks += 1
+                self._flag.zero_()
+                out = self._run_fused(x, N, T, "f32")
+            return out
         with t.cuda.device(self.device):
             for st in self.stages:
                 cfg = st["cfg"]
@@ -115,7 +141,7 @@ class MarbleNetEngine:
         f = feed or _feed.HostPcmFeed(self.device, host_i16.shape[1], chunk_clips)
         return _feed.cat_results(f.map([host_i16], lambda a: self.run(a, windows_per_clip, window_len)))
 
-    def _run_fused(self, x, N, T):
+    def _run_fused(self, x, N, T, mode="f32"):
         """Published layout: block 1 (stride 2, time-major log-mel in) through the per-sub-block entry, blocks 2-4 as one
         fused launch each (the tensor between a block's two sub-blocks stays in LDS), blocks 5 + 6 + Linear + softmax as one
         launch (nothing but the two scores per frame is written)."""
@@ -129,12 +155,14 @@ class MarbleNetEngine:
             cur = t.empty((N, cfg.cout, T1), dtype=t.float32, device=self.device)
             _lib.check(lib.vadx_sepconv_block(C.byref(cfg), p(s0["dw"]), p(s0["pw"]), p(s0["pb"]), None, None, x.data_ptr(),
                                               T * 80, 1, 80, T, None, cur.data_ptr(), N, T1, _lib.stream_ptr()))
+            mc = _lib.MarbleNetCfg(_lib.ARITH[mode], 0, self._flag.data_ptr())
+            sfx = "_h" if mode == "h2" else ""
             for k in (1, 3, 5):
                 a, b = st[k], st[k + 1]
                 y = t.empty((N, 64, T1), dtype=t.float32, device=self.device)
-                _lib.check(lib.vadx_marblenet_block2(a["cfg"].cin, a["cfg"].kernel, p(a["dw"]), p(a["pw"]), p(a["pb"]), p(b["dw"]),
-                                                     p(b["pw"]), p(b["pb"]), p(b["rw"]), p(b["rb"]), cur.data_ptr(), y.data_ptr(), N, T1,
-                                                     _lib.stream_ptr()))
+                _lib.check(lib.vadx_marblenet_block2(a["cfg"].cin, a["cfg"].kernel, p(a["dw"]), p(a["pw" + sfx]), p(a["pb"]), p(b["dw"]),
+                                                     p(b["pw" + sfx]), p(b["pb"]), p(b["rw" + sfx]), p(b["rb"]), cur.data_ptr(), y.data_ptr(),
+                                                     N, T1, _lib.stream_ptr(), C.byref(mc)))
                 cur = y
             s0o = t.empty((N, T1), dtype=t.float32, device=self.device)
             s1o = t.empty((N, T1), dtype=t.float32, device=self.device)
