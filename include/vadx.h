@@ -35,7 +35,9 @@ extern "C" {
  *    struct would have the new pointers read past its end -- the version check is the guard); vadx_stream_vadpost* (round 4).
  * 6: the arithmetic of an entry point comes WITH THE CALL (VADX_ARITH_* in a cfg / dims struct) instead of process-wide switches:
  *    vadx_silero_encoder_mode and vadx_gemm_mode are gone, every Silero launch takes a trailing `const vadx_silero_cfg *`;
- *    VADX_ARITH_F16X2 (fp16 x 2 split products) + vadx_silero_range_flag; the Silero packed blob grew the fp16 fragments (round 5). */
+ *    VADX_ARITH_F16X2 (fp16 x 2 split products) + vadx_silero_range_flag; the Silero packed blob grew the fp16 fragments;
+ *    vadx_sepconv_block / vadx_marblenet_block2 / vadx_marblenet_tail take a trailing `const vadx_marblenet_cfg *` (NULL = float32 MFMAs),
+ *    vadx_frag_h2_host / vadx_frag_h2_floats (round 5). */
 #define VADX_ABI_VERSION 6
 
 /* Arithmetic of the products whose one operand is a constant (every weight matrix, every DFT table) -- float32 RESULTS in all of them:
@@ -389,9 +391,11 @@ typedef struct vadx_sepconv_cfg {
 /* x: element (b, c, t) at x[b*xs_b + c*xs_c + t*xs_t] (lets the first block read the time-major
  * log-mel directly); xres [B][residual_cin][t_out]; y [B][cout][t_out].  Weights on the device:
  * dw_w [cin][kernel]; pw_w [cout_pad16][cin_pad16], pw_b [cout_pad16]; res_w [cout_pad16][rescin_pad16]. */
+struct vadx_marblenet_cfg;   /* below: arithmetic of the launch + the fp16 x 2 range flag words; NULL = float32 MFMAs */
 int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w, const float *pw_w, const float *pw_b,
                        const float *res_w, const float *res_b, const float *x, int64_t xs_b, int64_t xs_c,
-                       int64_t xs_t, int t_in, const float *xres, float *y, int batch, int t_out, void *stream);
+                       int64_t xs_t, int t_in, const float *xres, float *y, int batch, int t_out, void *stream,
+                       const struct vadx_marblenet_cfg *mcfg);
 /* Fused forms for the published MarbleNet 3x2x64 layout (what MarbleNetEngine launches; the per-sub-block entry above stays
  * for other Jasper stacks).  block2: one residual Jasper block = two separable sub-blocks (depthwise `kernel`, stride 1,
  * 64 filters each) + the residual 1x1 branch of the block input, x [B][cin][T] -> y [B][64][T]; weights as for
@@ -399,7 +403,7 @@ int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w, const flo
  * tail: block 5 (depthwise k 29, dilation 2, 64 -> 128) -> block 6 (plain 1x1, 128 -> 128) -> Linear(128 -> 2) -> softmax,
  * x [B][64][T] -> score0 / score1 [B][T] (dec_w [2][128], dec_b [2]); the 128-channel tensors never reach HBM. */
 /* cfg (may be NULL = float32 MFMAs): `arithmetic` VADX_ARITH_AUTO / VADX_ARITH_F32 -- pw0 / pw1 / res_w are fragment-major float32
- * (vadx_frag_major_host); VADX_ARITH_F16X2 -- they are fp16 x 2 fragments (vadx_frag_h2_host) and the three 1x1 convs run as split
+ * (vadx_frag_major_host); VADX_ARITH_F16X2 -- they are fp16 x 2 fragments (vadx_frag_h2_host, K_QUARTER for block2, K_PLAIN for tail's pw / w6) and the 1x1 convs run as split
  * products on the fp16 pipe (float32-class results, csrc/split2.h); `range_flag` then points at two device words {sticky flag, bits of the
  * largest |operand|} that a launch raises when an activation left the fp16 range -- the caller reads them with the results and recomputes
  * that batch on VADX_ARITH_F32 (MarbleNetEngine does).  VADX_ARITH_BF16X3 is refused (no such form of these kernels). */
@@ -413,7 +417,7 @@ int vadx_marblenet_block2(int cin, int kernel, const float *dw0, const float *pw
                           float *y, int batch, int frames, void *stream, const vadx_marblenet_cfg *cfg);
 int vadx_marblenet_tail(const float *dw, const float *pw, const float *pb, const float *w6, const float *b6,
                         const float *dec_w, const float *dec_b, const float *x, float *score0, float *score1,
-                        int batch, int frames, void *stream);
+                        int batch, int frames, void *stream, const vadx_marblenet_cfg *cfg);
 /* enc [B][C][T] -> softmax(Linear(C->2)) split into score0 / score1 [B][T]. */
 int vadx_frame_classifier(const float *enc, const float *dec_w, const float *dec_b, int batch, int channels,
                           int frames, float *score0, float *score1, void *stream);
@@ -558,12 +562,15 @@ int vadx_ingest_pcm16(const int16_t *src, int64_t src_stride, int channels, int6
  * expect buffers converted with this helper.  dst holds vadx_frag_major_floats(rows, cols) floats. */
 size_t vadx_frag_major_floats(int rows, int cols);
 int vadx_frag_major_host(const float *src, int rows, int cols, float *dst);
-/* The fp16 x 2 counterpart for the entry points that take bare weight pointers and an `arithmetic` (vadx_marblenet_block2):
- * [rows/16 tiles][cols/32 chunks][2 planes][64 lanes][8 fp16], lane 16q+i slot e = W[16*tile + i][32*chunk + 16*(e>>2) + 4*q + (e&3)]
- * (round-to-nearest fp16 terms h0, h1 = (w - h0) * 2^11; csrc/split2.h).  dst holds vadx_frag_h2_floats(rows, cols) floats; *wmax_out
- * (optional) receives the largest |w|; fails when a weight is outside the fp16 range (keep that matrix on VADX_ARITH_F32). */
+/* The fp16 x 2 counterpart for the entry points that take bare weight pointers and an `arithmetic` (vadx_marblenet_block2 / _tail):
+ * [rows/16 tiles][cols/32 chunks][2 planes][64 lanes][8 fp16], lane 16q+i slot e = W[16*tile + i][32*chunk + k(q, e)], round-to-nearest
+ * fp16 terms h0, h1 = (w - h0) * 2^11 (csrc/split2.h).  k_order: VADX_H2_K_PLAIN k = 8q + e (vadx_marblenet_tail's pw / w6),
+ * VADX_H2_K_QUARTER k = 16*(e>>2) + 4q + (e&3) (vadx_marblenet_block2's pw0 / pw1 / res_w).  dst holds vadx_frag_h2_floats(rows, cols)
+ * floats; *wmax_out (optional) receives the largest |w|; fails when a weight is outside the fp16 range (keep that matrix on VADX_ARITH_F32). */
+#define VADX_H2_K_PLAIN 0
+#define VADX_H2_K_QUARTER 1
 size_t vadx_frag_h2_floats(int rows, int cols);
-int vadx_frag_h2_host(const float *src, int rows, int cols, float *dst, float *wmax_out);
+int vadx_frag_h2_host(const float *src, int rows, int cols, int k_order, float *dst, float *wmax_out);
 
 #ifdef __cplusplus
 }

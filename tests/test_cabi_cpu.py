@@ -101,8 +101,9 @@ def test_fp16x2_fragment_packer_layout_and_range():
     from vadx import _lib
     rng = np.random.default_rng(3)
     a = (rng.standard_normal((20, 70)) * np.exp(rng.uniform(-6, 6, (20, 70)))).astype(np.float32)
-    fr = _lib.frag_h2(a)
+    fr = _lib.frag_h2(a, _lib.H2_K_QUARTER)
     assert fr is not None and fr.size == 2 * 3 * 2 * 256
+    plain = _lib.frag_h2(a).view(np.float16).reshape(2, 3, 2, 4, 16, 8)     # VADX_H2_K_PLAIN: k = 8 q + e
     h = fr.view(np.float16).reshape(2, 3, 2, 4, 16, 8)                      # tile, chunk, plane, q, i, e
     back = np.zeros((32, 96), np.float64)
     for q in range(4):
@@ -111,6 +112,8 @@ def test_fp16x2_fragment_packer_layout_and_range():
             for c in range(3):
                 back[:, 32 * c + k] = (h[:, c, 0, q, :, e].astype(np.float64) + h[:, c, 1, q, :, e].astype(np.float64) / 2048.0).reshape(32)
     assert not back[20:].any() and not back[:, 70:].any()
+    pb = (plain[:, :, 0].astype(np.float64) + plain[:, :, 1].astype(np.float64) / 2048.0).transpose(0, 3, 1, 2, 4).reshape(32, 96)
+    assert np.array_equal(pb, back)
     err = np.abs(back[:20, :70] - a.astype(np.float64))
     assert np.all(err <= np.abs(a) * 2.0 ** -23 + 2.0 ** -36), float((err / np.abs(a)).max())
     a[3, 5] = 7e4

@@ -179,11 +179,11 @@ SIGNATURES = {
     "vadx_stream_vadpost": (_I, [C.POINTER(StreamVadPostParams), _P, _L, _I, _I, _P, _I, _I, _P, _P, _I, _P]),
     "vadx_vadpost_workspace_bytes": (_Z, [_I, _I]),
     "vadx_vadpost": (_I, [C.POINTER(VadPostParams), _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
-    "vadx_sepconv_block": (_I, [C.POINTER(SepConvCfg), _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _I, _I, _P]),
+    "vadx_sepconv_block": (_I, [C.POINTER(SepConvCfg), _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _I, _I, _P, C.POINTER(MarbleNetCfg)]),
     "vadx_marblenet_block2": (_I, [_I, _I] + [_P] * 10 + [_I, _I, _P, C.POINTER(MarbleNetCfg)]),
     "vadx_frag_h2_floats": (C.c_size_t, [_I, _I]),
-    "vadx_frag_h2_host": (_I, [_P, _I, _I, _P, _P]),
-    "vadx_marblenet_tail": (_I, [_P] * 10 + [_I, _I, _P]),
+    "vadx_frag_h2_host": (_I, [_P, _I, _I, _I, _P, _P]),
+    "vadx_marblenet_tail": (_I, [_P] * 10 + [_I, _I, _P, C.POINTER(MarbleNetCfg)]),
     "vadx_frame_classifier": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vadx_dfsmn_frame_stats": (_I, [C.POINTER(FtView), C.POINTER(FtView), _I, _I, _P, _P]),
     "vadx_dfsmn_stats_merge": (_I, [_P, _P, _I, _P, _P]),
@@ -368,7 +368,10 @@ def frag_major(a):
     return out
 
 
-def frag_h2(a):
+H2_K_PLAIN, H2_K_QUARTER = 0, 1       # include/vadx.h: VADX_H2_K_*
+
+
+def frag_h2(a, k_order=H2_K_PLAIN):
     """row-major float32 [rows][cols] -> fp16 x 2 fragments (include/vadx.h: vadx_frag_h2_host) as a float32-typed 1-D buffer, or None when
     a weight lies outside the fp16 range (the caller keeps that matrix on float32)."""
     import numpy as np
@@ -376,7 +379,7 @@ def frag_h2(a):
     if a.ndim != 2:
         raise ValueError("frag_h2 expects a 2-D matrix")
     out = np.empty(lib().vadx_frag_h2_floats(a.shape[0], a.shape[1]), dtype=np.float32)
-    if lib().vadx_frag_h2_host(a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data, None) != 0:
+    if lib().vadx_frag_h2_host(a.ctypes.data, a.shape[0], a.shape[1], int(k_order), out.ctypes.data, None) != 0:
         return None
     return out
 

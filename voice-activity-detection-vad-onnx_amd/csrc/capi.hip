@@ -34,16 +34,19 @@ extern "C" int vadx_frag_major_host(const float *src, int rows, int cols, float 
     return VADX_OK;
 }
 
-// fp16 x 2 fragments of a [rows][cols] weight matrix for the kernels that split their own activation operand (marblenet.hip: kgemm_h):
-// [rows/16 tiles][cols/32 chunks][2 planes][64 lanes][8 fp16]; lane 16 q + i, slot e holds W[16 tile + i][32 chunk + 16 (e >> 2) + 4 q + (e & 3)]
-// -- the k-slot order in which those kernels read k-major float32 rows without bank conflicts.
+// fp16 x 2 fragments of a [rows][cols] weight matrix for the entry points that take bare weight pointers (include/vadx.h):
+// [rows/16 tiles][cols/32 chunks][2 planes][64 lanes][8 fp16]; lane 16 q + i, slot e holds W[16 tile + i][32 chunk + k(q, e)] with
+//   VADX_H2_K_PLAIN    k = 8 q + e                       (operand planes [k / 8][column][8]: layers_split.h)
+//   VADX_H2_K_QUARTER  k = 16 (e >> 2) + 4 q + (e & 3)   (the order in which marblenet.hip's kgemm_h reads k-major float32 rows without
+//                                                         bank conflicts)
 extern "C" size_t vadx_frag_h2_floats(int rows, int cols) {
     if (rows <= 0 || cols <= 0) return 0;
     return (size_t)((rows + 15) / 16) * (size_t)((cols + 31) / 32) * 2 * vadx::HFRAG;
 }
 
-extern "C" int vadx_frag_h2_host(const float *src, int rows, int cols, float *dst, float *wmax_out) {
+extern "C" int vadx_frag_h2_host(const float *src, int rows, int cols, int k_order, float *dst, float *wmax_out) {
     VADX_REQUIRE(src && dst && rows > 0 && cols > 0, "vadx_frag_h2_host: bad argument");
+    VADX_REQUIRE(k_order == VADX_H2_K_PLAIN || k_order == VADX_H2_K_QUARTER, "vadx_frag_h2_host: k_order must be VADX_H2_K_PLAIN or VADX_H2_K_QUARTER");
     const size_t n = vadx_frag_h2_floats(rows, cols);
     const int nch = (cols + 31) / 32;
     memset(dst, 0, n * sizeof(float));
@@ -51,7 +54,8 @@ extern "C" int vadx_frag_h2_host(const float *src, int rows, int cols, float *ds
     for (int r = 0; r < rows; ++r)
         for (int k = 0; k < cols; ++k) {
             const int kk = k & 31, q = (kk >> 2) & 3, e = ((kk >> 4) << 2) | (kk & 3);
-            const float a = vadx::hfrag_put(dst + (size_t)(((r / 16) * nch + k / 32) * 2) * vadx::HFRAG, r % 16, 8 * q + e, src[(size_t)r * cols + k]);
+            const float a = vadx::hfrag_put(dst + (size_t)(((r / 16) * nch + k / 32) * 2) * vadx::HFRAG, r % 16,
+                                            k_order == VADX_H2_K_QUARTER ? 8 * q + e : kk, src[(size_t)r * cols + k]);
             if (!(a <= wmax)) wmax = a;
         }
     if (wmax_out) *wmax_out = wmax;

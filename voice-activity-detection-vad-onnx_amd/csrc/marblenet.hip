@@ -11,6 +11,7 @@
 #include "common.h"
 #include "layers.h"
 #include "split_scheme.h"
+#include "layers_split.h"
 
 // MB_EXP: development-only cycle accounting of jasper_block2_kernel (tools/exp_marblenet.py): per-section clock64 sums of thread 0
 #ifndef MB_EXP
@@ -31,6 +32,7 @@ extern "C" int vadx_marblenet_debug_cycles(unsigned long long *out, int reset) {
 #endif
 
 #include <math.h>
+#include <type_traits>
 
 namespace vadx {
 namespace marblenet {
@@ -79,12 +81,54 @@ __device__ __forceinline__ void store8(float *dst, const float (&o)[8]) {
 // outputs of one channel, reads its (8-1)*stride + (k-1)*dil + 1 inputs and its k taps ONCE, and everything after
 // is FMAs on registers -- and every staging load is unconditional (index clamped, value selected): a guarded load
 // compiles to a branch plus a full wait, which used to serialise ~20 memory round trips per thread.
-template <int KT, int DT, int ST>
+// ---- fp16 x 2 helpers of the single-block kernels (prologue, tail): 128 output channels = eight row tiles, one per wave
+// split pass: k-major float32 rows src[ch][col] (ch < rows; beyond: zeros) -> B planes [kgroups][TILE][8] x 2 (item = (8 channels, frame):
+// eight conflict-free reads, 24 VALU, one 16-byte store per plane)
+__device__ __forceinline__ void split_rows_to_planes(const float *src, int ld, int rows, int kgroups, unsigned char *planes, float &amax) {
+    const int pl = kgroups * TILE * 16;
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    for (int it = threadIdx.x; it < kgroups * TILE; it += THREADS) {
+        const int kg = it / TILE, col = it - kg * TILE;
+        f32x4 lo4, hi4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo4[e] = 8 * kg + e < rows ? src[(8 * kg + e) * ld + col] : 0.f;
+            hi4[e] = 8 * kg + 4 + e < rows ? src[(8 * kg + 4 + e) * ld + col] : 0.f;
+        }
+        u32x2 a0, a1, b0, b1;
+        vadx::split2x4(lo4, a0, a1, amax);
+        vadx::split2x4(hi4, b0, b1, amax);
+        *reinterpret_cast<u32x4_ *>(planes + (kg * TILE + col) * 16) = u32x4_{a0[0], a0[1], b0[0], b0[1]};
+        *reinterpret_cast<u32x4_ *>(planes + pl + (kg * TILE + col) * 16) = u32x4_{a1[0], a1[1], b1[0], b1[1]};
+    }
+}
+// eight row tiles = one per wave, both column tiles of the 32-frame tile (layers_split.h's qlayer<> carries a paired-tile path that does
+// not fit the 80 registers of six waves per SIMD).  OUT_PLANES as in layers_split.h.
+template <bool OUT_PLANES>
+__device__ __forceinline__ void gemm8_h2(const vadx::QLayerArgs &a, float &amax) {
+    typedef vadx::SchemeH2 SC;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    asm volatile("" : "+v"(lane), "+v"(wave));
+    const int i = lane & 15;
+    f32x4 hi[1][2], lo[1][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { hi[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[0][mt] = hi[0][mt]; }
+    const float *const w[1] = {a.W + (size_t)wave * a.nchunks * SC::NP * vadx::QFRAG};
+    vadx::qgemm_group<SC, 1, 2, OUT_PLANES>(hi, lo, w, 0, a.nchunks, a.act, a.act_pl, [=](int kgrp, int mt) { return (kgrp * TILE + mt * 16 + i) * 16; }, lane);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) vadx::qlayer_store<SC, 2, OUT_PLANES>(a, wave, mt, SC::join(hi[0][mt], lo[0][mt]), lane, amax);
+}
+__device__ __forceinline__ void range_flag_words(unsigned *flag, float amax) {
+    if (!(amax <= vadx::H_MAX)) { atomicOr(flag, 1u); atomicMax(flag + 1, __float_as_uint(amax)); }
+}
+
+// AR = 2: the prologue form only (depthwise, no residual branch, 128 filters): filter -> split pass -> gemm8_h2 (fp16 x 2 split products)
+template <int KT, int DT, int ST, int AR = 0>
 __global__ __launch_bounds__(THREADS, 2) void sepconv_block_kernel(
     Cfg c, const float *__restrict__ dw_w, const float *__restrict__ pw_w, const float *__restrict__ pw_b,
     const float *__restrict__ res_w, const float *__restrict__ res_b, const float *__restrict__ x,
     long long xs_b, long long xs_c, long long xs_t, int T_in, const float *__restrict__ xres,
-    float *__restrict__ y, int T_out, int tiles) {
+    float *__restrict__ y, int T_out, int tiles, unsigned *__restrict__ range_flag) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int IN_LD = c.in_ld;
     float *IN = lds, *D = IN + c.cinp * IN_LD, *OUT = c.out_alias ? IN : D + (c.has_dw ? c.cinp * A_LD : 0), *RIN = OUT + c.coutp * A_LD,
@@ -191,7 +235,16 @@ __global__ __launch_bounds__(THREADS, 2) void sepconv_block_kernel(
         act = D;
         lda = A_LD;
     }
-    {
+    if constexpr (AR == vadx::VADX_AR_H2) {          // (launcher: has_dw, out_alias, no residual, coutp == 128; planes behind D)
+        float amax = 0.f;
+        const int kgroups = ((c.cinp + 31) / 32) * 4;
+        unsigned char *DP = reinterpret_cast<unsigned char *>(D + c.cinp * A_LD);
+        split_rows_to_planes(D, A_LD, c.cinp, kgroups, DP, amax);
+        __syncthreads();
+        gemm8_h2<false>(vadx::QLayerArgs{pw_w, c.coutp / 16, kgroups / 4, pw_b, c.relu ? 1 : 0, DP, kgroups * TILE * 16,
+                                         reinterpret_cast<unsigned char *>(OUT), 0, A_LD, nullptr}, amax);
+        range_flag_words(range_flag, amax);
+    } else {
         LayerArgs a{pw_w, c.cinp, c.coutp / 16, 1, c.cinp / 16, 0, 0, pw_b, (c.relu && !c.cres) ? 1 : 0,
                     act, lda, 0, OUT, A_LD, 0, nullptr, nullptr};
         layer<2, false>(a);
@@ -508,13 +561,19 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
 // ---------------------------------------------------------------------------------------------
 struct Tail { int cin, cmid, k, dil, in_ld, T; };
 
+// AR = 2 (fp16 x 2 split products, layers_split.h: qlayer): the two 1x1 convs are GEMM -> GEMM, so only the filter's k-major float32 output
+// needs a transposing split pass (item = (8 channels, frame): eight conflict-free reads, 24 VALU, one 16-byte store per plane into the dead
+// input tile's place); block 5's conv takes the weights as its A operand and stores its ReLU output straight into block 6's B planes
+// [channel / 8][frame][8] (8-byte stores, in H's place), block 6 takes the activations as A and stores float32 rows for the decoder.
+template <int AR>
 __global__ __launch_bounds__(THREADS, 6) void marblenet_tail_kernel(
     Tail c, const float *__restrict__ dw, const float *__restrict__ pw, const float *__restrict__ pb,
     const float *__restrict__ w6, const float *__restrict__ b6, const float *__restrict__ dec_w, const float *__restrict__ dec_b,
-    const float *__restrict__ x, float *__restrict__ s0, float *__restrict__ s1, int tiles) {
+    const float *__restrict__ x, float *__restrict__ s0, float *__restrict__ s1, int tiles, unsigned *__restrict__ range_flag) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int K = 29, DIL = 2, PAD = 28, WIN0 = TILE + 2 * PAD;
     const int IN_LD = c.in_ld;
+    float amax = 0.f;
     float *IN = lds, *D = IN + c.cin * IN_LD, *H = D + c.cin * A_LD, *OUT = IN;
     float *red = D;                                 // [16 parts][32 frames][2] once D is dead
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -558,14 +617,24 @@ __global__ __launch_bounds__(THREADS, 6) void marblenet_tail_kernel(
         store8(D + ch * A_LD + m0, o8);
     }
     __syncthreads();
-    {
-        LayerArgs a{pw, c.cin, c.cmid / 16, 1, c.cin / 16, 0, 0, pb, 1, D, A_LD, 0, H, A_LD, 0, nullptr, nullptr};
-        layer<2, false>(a);
-    }
-    __syncthreads();                // IN and D are dead
-    {
-        LayerArgs a{w6, c.cmid, c.cmid / 16, 1, c.cmid / 16, 0, 0, b6, 1, H, A_LD, 0, OUT, A_LD, 0, nullptr, nullptr};
-        layer<2, false>(a);
+    if constexpr (AR == vadx::VADX_AR_H2) {
+        unsigned char *DP = reinterpret_cast<unsigned char *>(IN), *HP = reinterpret_cast<unsigned char *>(H);      // the input tile is dead
+        const int dp_pl = (c.cin / 8) * TILE * 16, hp_pl = (c.cmid / 8) * TILE * 16;                                  // bytes per plane
+        split_rows_to_planes(D, A_LD, c.cin, c.cin / 8, DP, amax);
+        __syncthreads();
+        gemm8_h2<true>(vadx::QLayerArgs{pw, c.cmid / 16, c.cin / 32, pb, 1, DP, dp_pl, HP, hp_pl, TILE, nullptr}, amax);
+        __syncthreads();            // D and its planes are dead
+        gemm8_h2<false>(vadx::QLayerArgs{w6, c.cmid / 16, c.cmid / 32, b6, 1, HP, hp_pl, reinterpret_cast<unsigned char *>(OUT), 0, A_LD, nullptr}, amax);
+    } else {
+        {
+            LayerArgs a{pw, c.cin, c.cmid / 16, 1, c.cin / 16, 0, 0, pb, 1, D, A_LD, 0, H, A_LD, 0, nullptr, nullptr};
+            layer<2, false>(a);
+        }
+        __syncthreads();            // IN and D are dead
+        {
+            LayerArgs a{w6, c.cmid, c.cmid / 16, 1, c.cmid / 16, 0, 0, b6, 1, H, A_LD, 0, OUT, A_LD, 0, nullptr, nullptr};
+            layer<2, false>(a);
+        }
     }
     __syncthreads();
     {   // decoder: thread = (part of 8 channels, frame); partial logits meet in LDS and are summed in part order
@@ -590,6 +659,7 @@ __global__ __launch_bounds__(THREADS, 6) void marblenet_tail_kernel(
         s0[(long long)b * c.T + t0 + tid] = e0 * inv;
         s1[(long long)b * c.T + t0 + tid] = e1 * inv;
     }
+    if (AR == vadx::VADX_AR_H2) range_flag_words(range_flag, amax);
 }
 
 // decoder Linear(C -> 2) + softmax (wrapper :270-274): one thread per (clip, frame)
@@ -618,8 +688,12 @@ using namespace vadx::marblenet;
 
 extern "C" int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w, const float *pw_w, const float *pw_b,
                                   const float *res_w, const float *res_b, const float *x, int64_t xs_b, int64_t xs_c,
-                                  int64_t xs_t, int t_in, const float *xres, float *y, int batch, int t_out, void *stream) {
+                                  int64_t xs_t, int t_in, const float *xres, float *y, int batch, int t_out, void *stream,
+                                  const vadx_marblenet_cfg *mcfg) {
     VADX_REQUIRE(cfg && pw_w && pw_b && x && y, "vadx_sepconv_block: NULL argument");
+    const int ar = vadx::arith_internal(mcfg ? mcfg->arithmetic : VADX_ARITH_AUTO, vadx::VADX_AR_F32);
+    VADX_REQUIRE(ar == vadx::VADX_AR_F32 || ar == vadx::VADX_AR_H2, "vadx_sepconv_block: arithmetic must be AUTO / F32 or F16X2");
+    unsigned *flag = mcfg ? static_cast<unsigned *>(mcfg->range_flag) : nullptr;
     Cfg c;
     c.cin = cfg->cin; c.cout = cfg->cout; c.k = cfg->kernel; c.stride = cfg->stride; c.dil = cfg->dilation;
     c.has_dw = cfg->depthwise ? 1 : 0; c.cres = cfg->residual_cin; c.relu = cfg->relu ? 1 : 0;
@@ -632,22 +706,29 @@ extern "C" int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w
     {   const int width = (TILE - 1) * c.stride + (c.k - 1) * c.dil + 1;
         c.in_ld = c.has_dw ? (((width + 7) & ~7) + 4) : A_LD; }      // % 8 == 4; a plain 1x1 block feeds IN straight to the GEMM
     c.out_alias = out_aliases_in(c.cinp, c.coutp, c.cresp, c.in_ld, c.has_dw) ? 1 : 0;
-    const size_t lds_bytes = lds_floats(c.cinp, c.coutp, c.cresp, c.in_ld, c.has_dw) * sizeof(float);
+    size_t lds_bytes = lds_floats(c.cinp, c.coutp, c.cresp, c.in_ld, c.has_dw) * sizeof(float);
+    if (ar == vadx::VADX_AR_H2) {
+        VADX_REQUIRE(flag && c.has_dw && !c.cres && c.out_alias && c.coutp == 128 && c.k == 11 && c.dil == 1 && c.stride == 2,
+                     "vadx_sepconv_block: F16X2 is built for the MarbleNet prologue (depthwise k 11 stride 2, 128 filters, no residual; pw_w from "
+                     "vadx_frag_h2_host VADX_H2_K_PLAIN) and needs mcfg->range_flag");
+        lds_bytes += (size_t)((c.cinp + 31) / 32) * 4 * TILE * 16 * 2;      // the operand planes behind D
+    }
     VADX_REQUIRE(c.has_dw ? dw_w != nullptr : (c.k == 1 && c.stride == 1), "vadx_sepconv_block: plain conv must be k=1, stride 1");
     VADX_REQUIRE(!c.cres || (res_w && res_b && xres), "vadx_sepconv_block: residual branch needs res_w/res_b/xres");
     VADX_REQUIRE(batch > 0 && t_in > 0 && t_out > 0 && t_out == (t_in + 2 * c.pad - c.dil * (c.k - 1) - 1) / c.stride + 1,
                  "vadx_sepconv_block: t_out=%d inconsistent with t_in=%d", t_out, t_in);
     const int tiles = (t_out + TILE - 1) / TILE;
     VADX_REQUIRE((long long)batch * tiles < (1LL << 31), "vadx_sepconv_block: too many tiles");
-#define SEPCONV_LAUNCH(KT, DT, ST)                                                                                              \
+#define SEPCONV_LAUNCH(...)                                                                                                     \
     do {                                                                                                                        \
-        VADX_DYN_LDS((sepconv_block_kernel<KT, DT, ST>), 128 * 1024);                                                           \
-        hipLaunchKernelGGL((sepconv_block_kernel<KT, DT, ST>), dim3((unsigned)(batch * tiles)), dim3(THREADS),                  \
+        VADX_DYN_LDS((sepconv_block_kernel<__VA_ARGS__>), 128 * 1024);                                                          \
+        hipLaunchKernelGGL((sepconv_block_kernel<__VA_ARGS__>), dim3((unsigned)(batch * tiles)), dim3(THREADS),                 \
                            lds_bytes, static_cast<hipStream_t>(stream), c, dw_w, pw_w, pw_b, res_w, res_b, x,                   \
-                           (long long)xs_b, (long long)xs_c, (long long)xs_t, t_in, xres, y, t_out, tiles);                      \
+                           (long long)xs_b, (long long)xs_c, (long long)xs_t, t_in, xres, y, t_out, tiles, flag);                \
     } while (0)
     // the depthwise shapes of the published MarbleNet 3x2x64 get compile-time FIRs; anything else runs the generic kernel
-    if (c.has_dw && c.k == 11 && c.dil == 1 && c.stride == 2) SEPCONV_LAUNCH(11, 1, 2);
+    if (ar == vadx::VADX_AR_H2) SEPCONV_LAUNCH(11, 1, 2, 2);
+    else if (c.has_dw && c.k == 11 && c.dil == 1 && c.stride == 2) SEPCONV_LAUNCH(11, 1, 2);
     else if (c.has_dw && c.k == 13 && c.dil == 1 && c.stride == 1) SEPCONV_LAUNCH(13, 1, 1);
     else if (c.has_dw && c.k == 15 && c.dil == 1 && c.stride == 1) SEPCONV_LAUNCH(15, 1, 1);
     else if (c.has_dw && c.k == 17 && c.dil == 1 && c.stride == 1) SEPCONV_LAUNCH(17, 1, 1);
@@ -700,8 +781,13 @@ extern "C" int vadx_marblenet_block2(int cin, int kernel, const float *dw0, cons
 
 extern "C" int vadx_marblenet_tail(const float *dw, const float *pw, const float *pb, const float *w6, const float *b6,
                                    const float *dec_w, const float *dec_b, const float *x, float *score0, float *score1,
-                                   int batch, int frames, void *stream) {
+                                   int batch, int frames, void *stream, const vadx_marblenet_cfg *cfg) {
     VADX_REQUIRE(dw && pw && pb && w6 && b6 && dec_w && dec_b && x && score0 && score1, "vadx_marblenet_tail: NULL argument");
+    const int ar = vadx::arith_internal(cfg ? cfg->arithmetic : VADX_ARITH_AUTO, vadx::VADX_AR_F32);
+    VADX_REQUIRE(ar == vadx::VADX_AR_F32 || ar == vadx::VADX_AR_H2, "vadx_marblenet_tail: arithmetic must be AUTO / F32 (fragment-major weights) or "
+                 "F16X2 (vadx_frag_h2_host weights, VADX_H2_K_PLAIN)");
+    VADX_REQUIRE(ar != vadx::VADX_AR_H2 || cfg->range_flag, "vadx_marblenet_tail: F16X2 needs cfg->range_flag (two device words)");
+    unsigned *flag = cfg ? static_cast<unsigned *>(cfg->range_flag) : nullptr;
     VADX_REQUIRE(batch > 0 && frames > 0, "vadx_marblenet_tail: bad shape");
     Tail c;
     c.cin = 64; c.cmid = 128; c.k = 29; c.dil = 2; c.T = frames;
@@ -709,9 +795,15 @@ extern "C" int vadx_marblenet_tail(const float *dw, const float *pw, const float
     const int tiles = (frames + TILE - 1) / TILE;
     VADX_REQUIRE((long long)batch * tiles < (1LL << 31), "vadx_marblenet_tail: too many tiles");
     const size_t lds = ((size_t)c.cin * c.in_ld + (size_t)c.cin * A_LD + (size_t)c.cmid * A_LD) * sizeof(float);
-    VADX_DYN_LDS(marblenet_tail_kernel, 128 * 1024);
-    hipLaunchKernelGGL(marblenet_tail_kernel, dim3((unsigned)(batch * tiles)), dim3(THREADS), lds, static_cast<hipStream_t>(stream),
-                       c, dw, pw, pb, w6, b6, dec_w, dec_b, x, score0, score1, tiles);
+    if (ar == vadx::VADX_AR_H2) {
+        VADX_DYN_LDS(marblenet_tail_kernel<2>, 128 * 1024);
+        hipLaunchKernelGGL(marblenet_tail_kernel<2>, dim3((unsigned)(batch * tiles)), dim3(THREADS), lds, static_cast<hipStream_t>(stream),
+                           c, dw, pw, pb, w6, b6, dec_w, dec_b, x, score0, score1, tiles, flag);
+    } else {
+        VADX_DYN_LDS(marblenet_tail_kernel<0>, 128 * 1024);
+        hipLaunchKernelGGL(marblenet_tail_kernel<0>, dim3((unsigned)(batch * tiles)), dim3(THREADS), lds, static_cast<hipStream_t>(stream),
+                           c, dw, pw, pb, w6, b6, dec_w, dec_b, x, score0, score1, tiles, flag);
+    }
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
 }

@@ -754,19 +754,35 @@ __global__ __launch_bounds__(512, 2) void silero_lstm_h2_kernel(
 
     const float *gsrc = gx + (size_t)grp * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
     const size_t gstep = (size_t)G * GX_TILE_FLOATS;
-    f32x4 gcur[4], gnxt[4];
+    // gx (the encoder's gate pre-activations, 32 KB per step and workgroup out of HBM: 2.6 GB per launch at config 2 = 4.3 TB/s) is requested
+    // LH_GX_AHEAD steps ahead: with one step of lead a lone workgroup ran 1.42 us per step and the full grid 1.95 -- the loaded HBM's
+    // latency exceeds a step.  The ring is indexed statically (the step loop is unrolled by its depth).
+#ifndef LH_GX_AHEAD
+#define LH_GX_AHEAD 3
+#endif
+    constexpr int GA = LH_GX_AHEAD;
+    f32x4 gq[GA][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) gcur[g] = *reinterpret_cast<const f32x4 *>(gsrc + g * 256);
+    for (int j = 0; j < GA; ++j) {
+        const int tj = j < T ? j : T - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gq[j][g] = *reinterpret_cast<const f32x4 *>(gsrc + tj * gstep + g * 256);
+    }
 
     int cur = 0;
-    for (int t = 0; t < T; ++t) {
-        const int tn = (t + 1 < T) ? t + 1 : t;
+    for (int t0 = 0; t0 < T; t0 += GA) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gnxt[g] = *reinterpret_cast<const f32x4 *>(gsrc + tn * gstep + g * 256);
-
+    for (int j = 0; j < GA; ++j) {
+        const int t = t0 + j;
+        if (t >= T) break;
         f32x4 hi[4], mid[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { hi[g] = gcur[g]; mid[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int g = 0; g < 4; ++g) { hi[g] = gq[j][g]; mid[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        {
+            const int tn = (t + GA < T) ? t + GA : T - 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gq[j][g] = *reinterpret_cast<const f32x4 *>(gsrc + tn * gstep + g * 256);
+        }
         const unsigned char *hb = smem + cur * LH_HBUF;
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
@@ -802,8 +818,7 @@ __global__ __launch_bounds__(512, 2) void silero_lstm_h2_kernel(
             probs[b * probs_stride + t] = sigmoidf_(s);
         }
         cur = nxt;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gcur[g] = gnxt[g];
+    }
     }
     if (state_n != nullptr && bvalid) {
         *reinterpret_cast<f32x4 *>(state_n + b * 128 + u0) = h;

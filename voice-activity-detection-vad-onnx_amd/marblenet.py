@@ -72,11 +72,11 @@ class MarbleNetEngine:
         self._flag = torch.zeros(2, dtype=torch.int32, device=self.device)
         if self.fused:
             self.h2_ok = True
-            for k in range(1, 7):
+            for k in range(0, 9):             # prologue + blocks 5 / 6 of the tail launch (plane order), blocks 2-4 (kgemm_h's k order)
                 st = self.stages[k]
                 for name in ("pw", "rw"):
                     host = st[name + "_host"]
-                    frags = None if host is None else _lib.frag_h2(host)
+                    frags = None if host is None else _lib.frag_h2(host, _lib.H2_K_QUARTER if 1 <= k < 7 else _lib.H2_K_PLAIN)
                     st[name + "_h"] = None if frags is None else dev(frags)
                     self.h2_ok = self.h2_ok and (host is None or frags is not None)
 
@@ -125,7 +125,7 @@ class MarbleNetEngine:
                                                   None if st["rb"] is None else st["rb"].data_ptr(),
                                                   cur.data_ptr(), xs[0], xs[1], xs[2], cur_T,
                                                   block_in.data_ptr() if st["res"] else None, y.data_ptr(), N, t_out,
-                                                  _lib.stream_ptr()))
+                                                  _lib.stream_ptr(), None))
                 cur, cur_T = y, t_out
                 xs = (cfg.cout * t_out, t_out, 1)
             s0 = t.empty((N, cur_T), dtype=t.float32, device=self.device)
@@ -153,10 +153,10 @@ class MarbleNetEngine:
             pad = (cfg.dilation * (cfg.kernel - 1)) // 2
             T1 = (T + 2 * pad - cfg.dilation * (cfg.kernel - 1) - 1) // cfg.stride + 1
             cur = t.empty((N, cfg.cout, T1), dtype=t.float32, device=self.device)
-            _lib.check(lib.vadx_sepconv_block(C.byref(cfg), p(s0["dw"]), p(s0["pw"]), p(s0["pb"]), None, None, x.data_ptr(),
-                                              T * 80, 1, 80, T, None, cur.data_ptr(), N, T1, _lib.stream_ptr()))
             mc = _lib.MarbleNetCfg(_lib.ARITH[mode], 0, self._flag.data_ptr())
             sfx = "_h" if mode == "h2" else ""
+            _lib.check(lib.vadx_sepconv_block(C.byref(cfg), p(s0["dw"]), p(s0["pw" + sfx]), p(s0["pb"]), None, None, x.data_ptr(),
+                                              T * 80, 1, 80, T, None, cur.data_ptr(), N, T1, _lib.stream_ptr(), C.byref(mc)))
             for k in (1, 3, 5):
                 a, b = st[k], st[k + 1]
                 y = t.empty((N, 64, T1), dtype=t.float32, device=self.device)
@@ -166,9 +166,9 @@ class MarbleNetEngine:
                 cur = y
             s0o = t.empty((N, T1), dtype=t.float32, device=self.device)
             s1o = t.empty((N, T1), dtype=t.float32, device=self.device)
-            _lib.check(lib.vadx_marblenet_tail(p(st[7]["dw"]), p(st[7]["pw"]), p(st[7]["pb"]), p(st[8]["pw"]), p(st[8]["pb"]),
+            _lib.check(lib.vadx_marblenet_tail(p(st[7]["dw"]), p(st[7]["pw" + sfx]), p(st[7]["pb"]), p(st[8]["pw" + sfx]), p(st[8]["pb"]),
                                                self.dec_w.data_ptr(), self.dec_b.data_ptr(), cur.data_ptr(), s0o.data_ptr(),
-                                               s1o.data_ptr(), N, T1, _lib.stream_ptr()))
+                                               s1o.data_ptr(), N, T1, _lib.stream_ptr(), C.byref(mc)))
         return s0o, s1o, T1 - 1
 
     def detect(self, clips_i16, window_len=None, pad_noise=None, post=(3, 0.5, 10, 1000, 10, 3, 0), return_probs=False):
