@@ -383,19 +383,25 @@ def _roof(kernel, flop, ms, tag=None, kernel_substr=None, note=None, split=False
     return r
 
 
-def _whole_pass_roof(nwin, flop_total, fle, groups, on_split, ms):
+LSTM_T_H2_SHARE = 23200.0 / 28800.0     # of vadx_dfsmn_lstm_t's flops: the two-layer net (fp16 x 2 form) against the one-layer net (f32 MFMAs)
+
+
+def _whole_pass_roof(nwin, flop_total, fle, groups, on_split, ms, f_h2=0.0):
     """The DFSMN pass against the peak of ITS pipe mix (as bench.encoder_roofline does for one kernel): the flops of the entry points that
-    run split products at 2500 / 6, everything else at 157.3 -- peak = total flops / the time the two pipes need at their own peaks."""
+    run bf16 x 3 split products at 2500 / 6, those on fp16 x 2 (f_h2) at 2500 / 3, everything else at 157.3 -- peak = total flops / the time
+    the pipes need at their own peaks."""
     f_split = sum(nwin * fle[k] for k in groups if k in on_split and groups[k] > 0)
     f_all = nwin * flop_total
-    f_f32 = max(f_all - f_split, 0.0)
-    t_min = f_split / PEAK_SPLIT_TFLOPS + f_f32 / PEAK_F32_MFMA_TFLOPS
-    t_sus = f_split / (PEAK_SPLIT_TFLOPS * SUSTAINED_OF_NOMINAL["split"]) + f_f32 / (PEAK_F32_MFMA_TFLOPS * SUSTAINED_OF_NOMINAL["f32"])
+    f_f32 = max(f_all - f_split - f_h2, 0.0)
+    t_min = f_split / PEAK_SPLIT_TFLOPS + f_h2 / PEAK_H2_TFLOPS + f_f32 / PEAK_F32_MFMA_TFLOPS
+    t_sus = (f_split / (PEAK_SPLIT_TFLOPS * SUSTAINED_OF_NOMINAL["split"]) + f_h2 / (PEAK_H2_TFLOPS * SUSTAINED_OF_NOMINAL["h2"])
+             + f_f32 / (PEAK_F32_MFMA_TFLOPS * SUSTAINED_OF_NOMINAL["f32"]))
     ach = f_all / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "all DFSMN launches", "achieved": ach, "peak": f_all / t_min, "unit": "TFLOP/s", "frac": ach / (f_all / t_min),
             "frac_of_sustained": ach / (f_all / t_sus), "sustained_source": SUSTAINED_SOURCE, "arithmetic": "mix" if f_split else "f32",
-            "flop_per_launch": f_all, "flop_on_split_products": f_split, "ms": ms,
-            "note": "peak = the pass's pipe mix: flops of the split-product entry points at 2500 / 6 TFLOP/s, the rest at the f32-MFMA peak"}
+            "flop_per_launch": f_all, "flop_on_split_products": f_split, "flop_on_fp16x2_products": f_h2, "ms": ms,
+            "note": "peak = the pass's pipe mix: flops of the bf16 x 3 entry points at 2500 / 6 TFLOP/s, of the fp16 x 2 time LSTM at 2500 / 3, the rest "
+                    "at the f32-MFMA peak"}
 
 
 def bytes_dfsmn_pw_window(T=101, F=160, ch=20):
@@ -631,6 +637,11 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
     # entries whose matrix products run as bf16 x 3 split products (these kernels have no fp16 x 2 form yet: "h2" maps to bf16 x 3 there):
     # priced against the f32-equivalent peak of that pipe (cfb_back's split form is opt-in, VADX_CFB_BACK=split: by default it runs f32 MFMAs)
     on_split = ({"lstm_f", "cfb_front"} | ({"cfb_back"} if os.environ.get("VADX_CFB_BACK") == "split" else set())) if _gemm_arith() != "f32" else set()
+    f_h2_lstm_t = nwin * fle["lstm_t"] * LSTM_T_H2_SHARE if _gemm_arith() == "h2" else 0.0      # the two-layer time LSTM's fp16 x 2 form
+    by_entry = {k: _roof(f"vadx_dfsmn_{k}", nwin * fle[k], v, "dfsmn", k, split=k in on_split) for k, v in groups.items() if v > 0 and k != "lstm_t"}
+    if groups["lstm_t"] > 0:
+        by_entry["lstm_t"] = _roof_mix("vadx_dfsmn_lstm_t", nwin * fle["lstm_t"], f_h2_lstm_t, groups["lstm_t"], "dfsmn", "lstm_t",
+                                       note="two launches per pass: the two-layer net (fp16 x 2 split products) and the one-layer net (f32 MFMAs)")
     dom = max(groups, key=groups.get)
     if dom == "pw_conv":                                     # (only the unfused chain is dominated by the HBM-bound pw_conv launches)
         dom = max((k for k in groups if k != "pw_conv"), key=groups.get)
@@ -642,8 +653,9 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
            "roofline": _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fle[dom], groups[dom], "dfsmn", dom, split=dom in on_split,
                              note="all launches of the entry point that takes the most time; flops as the reference computes them "
                                   "(the kernel issues more: 20 output channels pad to 32 MFMA rows)"),
-           "roofline_by_entry": {k: _roof(f"vadx_dfsmn_{k}", nwin * fle[k], v, "dfsmn", k, split=k in on_split) for k, v in groups.items() if v > 0},
-           "roofline_whole_pass": _whole_pass_roof(nwin, fl["total"], fle, groups, on_split, ms),
+           "roofline_by_entry": by_entry,
+           "roofline_whole_pass": _whole_pass_roof(nwin, fl["total"], fle, groups, on_split, ms, f_h2_lstm_t),
+           "range_fallbacks": eng.range_fallbacks,
            "hbm": _hbm(clips * (2 * padded * 2 + W * eng.T_A * 4), ms, "dfsmn"), "cpu_baseline": None}
     del near, far
     if cpu:

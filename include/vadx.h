@@ -512,9 +512,14 @@ int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_ft_ln *ln, c
                       const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, void *stream);
 /* The same with an explicit frame stride between chunks (a multiple of 4): chunk c's frame t is column (c * frame_stride + t) % 16 of
  * tile (c * frame_stride + t) / 16.  vadx_dfsmn_lstm_t is frame_stride = 16 * ceil(frames / 16). */
+/* arithmetic (ABI 6): VADX_ARITH_AUTO / VADX_ARITH_F32 = float32 MFMAs; VADX_ARITH_F16X2 = the two-layer net (which = 0) as fp16 x 2 split
+ * products (csrc/split2.h; weights split by the kernel itself), range_flag = two zeroed device words {sticky flag, bits of the largest
+ * |operand|} raised when an input or weight left the fp16 range (the caller then recomputes on VADX_ARITH_F32); which = 1 runs float32
+ * MFMAs for every arithmetic. */
 int vadx_dfsmn_lstm_t_ex(int which, const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2], const float *const w_hh[2],
                          const float *const b_ih[2], const float *const b_hh[2], const float *wl, const float *bl,
-                         const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, int frame_stride, void *stream);
+                         const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, int frame_stride, void *stream,
+                         int arithmetic, void *range_flag);
 /* Copy an FT tensor [channels][F] of `chunks` windows between frame strides (both multiples of 4, >= frames): e.g. 112 -> 104 packs
  * 101-frame windows onto 6.5 tiles each (the per-frame kernels then process 7 % fewer tiles), 104 -> 112 unpacks the result.
  * dst holds ceil(chunks * dst_stride / 16) tiles. */

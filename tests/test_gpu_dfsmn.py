@@ -174,6 +174,31 @@ def test_sub_batching_and_batch_position_do_not_change_scores():
     assert torch.equal(rep[0], rep[1])                                    # position in the batch: bitwise
 
 
+def test_time_lstm_fp16_range_protocol(gemm):
+    """The two-layer time LSTM's fp16 x 2 form splits its weights and inputs itself and raises the engine's range flag when one lies outside
+    the fp16 range: the engine then sweeps the batch again with that kernel on float32 MFMAs and returns exactly those scores."""
+    if gemm != "h2":
+        pytest.skip("the range protocol belongs to the fp16 x 2 arithmetic")
+    w = dict(weights.dfsmn_synthetic(1234))
+    key = "iccrn.ch_lstm.lstm2.weight_ih_l0"
+    big = np.array(w[key], dtype=np.float32)
+    big[3, 2] = 1.0e6
+    w[key] = big
+    eng, ref = dfsmn.DfsmnEngine(w, sub_batch=960), dfsmn.DfsmnEngine(w, sub_batch=960)
+    ref.iccrn.lstm_t_h2 = False
+    lb, stride = eng.grid()
+    W = 2
+    n = (W - 1) * stride + eng.L
+    near = torch.from_numpy(weights.burst_clips(3, n, seed=31)).cuda()
+    far = torch.from_numpy(weights.burst_clips(3, n, seed=32)).cuda()
+    got, want = eng.run(near, far, W, stride), ref.run(near, far, W, stride)
+    assert eng.range_fallbacks == 1 and ref.range_fallbacks == 0 and int(eng.iccrn.range_flag[0].item()) == 0
+    assert torch.equal(got.nan_to_num(), want.nan_to_num())
+    ok = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234), sub_batch=960)
+    ok.run(near, far, W, stride)
+    assert ok.range_fallbacks == 0                                        # in-range weights and audio never flag
+
+
 def test_near_only_session_matches_reference_fixture(golden):
     """DFSMN/only_near_end_audio: one stream in, the far end replaced by the export's baked white-noise tensors
     (carried by the fixture), against what the reference wrapper produced."""

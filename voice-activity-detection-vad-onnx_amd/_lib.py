@@ -200,7 +200,7 @@ SIGNATURES = {
                                C.POINTER(FtView), _I, _I, _I, _P]),
     "vadx_dfsmn_lstm_t_ex": (_I, [_I, C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
                                   C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), _P, _P, C.POINTER(FtView),
-                                  C.POINTER(FtView), _I, _I, _I, _I, _P]),
+                                  C.POINTER(FtView), _I, _I, _I, _I, _P, _I, _P]),
     "vadx_dfsmn_ft_repack": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vadx_dfsmn_istft": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "vadx_dfsmn_vote": (_I, [_P, _I, _I, _I, _I, C.c_double, C.c_double, _P, _P]),

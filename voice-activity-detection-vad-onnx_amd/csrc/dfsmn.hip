@@ -11,9 +11,11 @@
 // fragment of step t is exactly the B fragment of step t+1 -- no LDS, no shuffles.
 #include "common.h"
 #include "split3.h"
+#include "split2.h"
 #include "layers.h"
 
 #include <math.h>
+#include <type_traits>
 #include <string.h>
 
 // DFSMN_EXP: development-only what-if switches (bit mask; results are wrong when set): 1 lstm_f without its output
@@ -1082,7 +1084,9 @@ __global__ __launch_bounds__(128 * NTILE) void lstm_t2_kernel(LstmTArgs p) {
                   LDS_FLOATS = OFF_HS + NTILE * 2 * HID * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = wave >> 1, layer = wave & 1, q = lane >> 4, i = lane & 15;
+    // (waves w and w + NTILE share a SIMD: one of each layer there -- with slot = wave >> 1, layer = wave & 1 two SIMDs carried two layer-1
+    //  waves, 220 MFMAs each, and two SIMDs two layer-0 waves of 150)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = wave % NTILE, layer = wave / NTILE, q = lane >> 4, i = lane & 15;
     const int groups = p.F / 16;
     // ---- one copy of the weights per workgroup: fragment (mt, s) of matrix W[4 HID][K], lane (q, i) <- W[grow(i) + 4 mt][4 s + q]
     auto stage_w = [&](float *dst, const float *W, int K, int nmt, bool gate_rows) {
@@ -1197,6 +1201,300 @@ __global__ __launch_bounds__(128 * NTILE) void lstm_t2_kernel(LstmTArgs p) {
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The two-layer time LSTM on fp16 x 2 split products (csrc/split2.h).  Same decomposition as lstm_t2_kernel (a wave pair per 16-bin
+// group, layer 1 one step behind layer 0, one barrier per step, every weight in LDS as per-lane A fragments), but a layer's step is ONE
+// GEMM over the concatenated operand [h ; x] with 32-k chunks: layer 0 [h0 (40) ; x (20)] = 2 chunks, layer 1 [h1 (40) ; h0 (40)] = 3,
+// i.e. 60 / 90 v_mfma_f32_16x16x32_f16 per step (960 / 1440 matrix cycles) instead of 150 / 200 v_mfma_f32_16x16x4_f32 (4800 / 6400); the
+// weights are 110 KB of fragments instead of 95 (bf16 x 3 needed 162 KB and did not fit: see the launch site).
+//   k-slot maps (same for the A fragments and the B operand; lane 16 g + n supplies slots e = 0..7 of group g for bin n):
+//     "own" chunk: slot (g, e) = the layer's h of unit 4 e + g -- the lane's OWN cell outputs of row tiles 0..7 (D rows 4 q + r of
+//                  row tile mt are the four gates of unit 4 mt + q: the new h is the next step's operand without cross-lane traffic);
+//     layer 0 chunk 1: e = 0, 1 -> own units 32 + g, 36 + g (row tiles 8, 9); e = 2..6 -> x channel 5 g + e - 2; e = 7 -> zero;
+//     layer 1 chunk 1: h0 of unit 4 e + g = layer 0's own chunk, which that wave leaves in LDS ALREADY SPLIT (two 16-byte stores);
+//     layer 1 chunk 2: e = 0, 1 -> own units of row tiles 8, 9; e = 2, 3 -> h0 of units 32 + g, 36 + g (layer 0's 4-byte "head"); rest zero.
+//   The output Linear takes layer 1's NEW own chunk and chunk 2 (its weights are zero on the h0 / empty slots).  Biases are the
+//   accumulators' initial value (exact float32 adds, as in the f32 kernel).  h lies in (-1, 1); x and the weights feed the range check.
+// ---------------------------------------------------------------------------------------------
+#ifndef LT_EXP
+#define LT_EXP 0         /* development what-ifs of lstm_t2h_kernel: 1 no transcendentals, 2 no MFMAs, 4 no per-step loads, 8 no stores, 16 one fragment read per GEMM */
+#endif
+template <int NPAIR>
+__device__ __forceinline__ void gemm_h2_lds(f32x4 *hi, f32x4 *mid, const unsigned char *w, int frag_stride2, const f16x8 (&b)[2]) {
+    // NPAIR pairs of row tiles against one chunk's operand b; fragment pair of row tile mt at w + mt * frag_stride2 (+ 1024 for plane 1).
+    // A pair's four fragments are requested while the previous pair's six MFMAs issue; the two tiles of a pair alternate so that no
+    // MFMA waits on the one before it.
+    f16x8 cur[2][2], nxt[2][2];
+    auto load = [&](int pr, f16x8 (&a)[2][2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) a[u][pl] = *reinterpret_cast<const f16x8 *>(w + (size_t)(2 * pr + u) * frag_stride2 + pl * 1024);
+    };
+    load(0, cur);
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr) {
+        if (pr + 1 < NPAIR && !(LT_EXP & 16)) load(pr + 1, nxt);
+        if (LT_EXP & 16) { nxt[0][0] = cur[0][0]; nxt[0][1] = cur[0][1]; nxt[1][0] = cur[1][0]; nxt[1][1] = cur[1][1]; }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(LT_EXP & 2)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) mid[2 * pr + u] = vadx::mfma_f16(cur[u][1], b[0], mid[2 * pr + u]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) mid[2 * pr + u] = vadx::mfma_f16(cur[u][0], b[1], mid[2 * pr + u]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) hi[2 * pr + u] = vadx::mfma_f16(cur[u][0], b[0], hi[2 * pr + u]);
+        } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) hi[2 * pr + u][0] += (float)cur[u][0][0] * (float)b[0][0];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) cur[u][pl] = nxt[u][pl];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void split8_h2(const float (&v)[8], f16x8 (&b)[2], float &amax) {
+    u32x2 a0, a1, c0, c1;
+    vadx::split2x4(f32x4{v[0], v[1], v[2], v[3]}, a0, a1, amax);
+    vadx::split2x4(f32x4{v[4], v[5], v[6], v[7]}, c0, c1, amax);
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    b[0] = __builtin_bit_cast(f16x8, u32x4_{a0[0], a0[1], c0[0], c0[1]});
+    b[1] = __builtin_bit_cast(f16x8, u32x4_{a1[0], a1[1], c1[0], c1[1]});
+}
+
+template <int OUT_MT, int MODE, int NTILE>
+__global__ __launch_bounds__(128 * NTILE) void lstm_t2h_kernel(LstmTArgs p, unsigned *__restrict__ range_flag) {
+    constexpr int IN = 20, HID = 40, MT = 10, FR = 1024;
+    constexpr int OFF_W0 = 0, OFF_W1 = OFF_W0 + MT * 2 * 2 * FR, OFF_WL = OFF_W1 + MT * 3 * 2 * FR, OFF_BIAS = OFF_WL + OUT_MT * 2 * 2 * FR,
+                  OFF_HS = OFF_BIAS + 2 * MT * 16 * 4, HS_BUF = 2 * FR + 2 * 256, LDS_BYTES = OFF_HS + NTILE * 2 * HS_BUF;
+    static_assert(LDS_BYTES <= 160 * 1024 && OFF_HS % 16 == 0, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = wave % NTILE, layer = wave / NTILE, q = lane >> 4, i = lane & 15;      // one wave of each layer per SIMD
+    const int groups = p.F / 16;
+    float amax = 0.f;
+    // ---- one copy of the weights per workgroup, split by the threads that stage them: fragment slot (tile, chunk, lane 16 g + r, e)
+    {
+        auto put = [&](int off, int frag, int l, int e, float wv) {
+            unsigned short h0, h1;
+            vadx::split2x1(wv, h0, h1, amax);
+            *reinterpret_cast<unsigned short *>(smem + off + (size_t)frag * 2 * FR + l * 16 + e * 2) = h0;
+            *reinterpret_cast<unsigned short *>(smem + off + (size_t)frag * 2 * FR + FR + l * 16 + e * 2) = h1;
+        };
+        for (int s2 = tid; s2 < MT * 2 * 512; s2 += blockDim.x) {           // layer 0: [h0 own | h0 tiles 8, 9 ; x ; 0]
+            const int e = s2 & 7, l = (s2 >> 3) & 63, frag = s2 >> 9, ch = frag & 1, mt = frag >> 1, g = l >> 4, r = l & 15;
+            const int row = (r & 3) * HID + (r >> 2) + 4 * mt;
+            float wv = 0.f;
+            if (ch == 0) wv = p.w_hh[0][(size_t)row * HID + 4 * e + g];
+            else if (e < 2) wv = p.w_hh[0][(size_t)row * HID + 4 * (8 + e) + g];
+            else if (e < 7) wv = p.w_ih[0][(size_t)row * IN + 5 * g + e - 2];
+            put(OFF_W0, frag, l, e, wv);
+        }
+        for (int s2 = tid; s2 < MT * 3 * 512; s2 += blockDim.x) {           // layer 1: [h1 own | h0 own | h1 tiles 8, 9 ; h0 tiles 8, 9 ; 0]
+            const int e = s2 & 7, l = (s2 >> 3) & 63, frag = s2 >> 9, ch = frag % 3, mt = frag / 3, g = l >> 4, r = l & 15;
+            const int row = (r & 3) * HID + (r >> 2) + 4 * mt;
+            float wv = 0.f;
+            if (ch == 0) wv = p.w_hh[1][(size_t)row * HID + 4 * e + g];
+            else if (ch == 1) wv = p.w_ih[1][(size_t)row * HID + 4 * e + g];
+            else if (e < 2) wv = p.w_hh[1][(size_t)row * HID + 4 * (8 + e) + g];
+            else if (e < 4) wv = p.w_ih[1][(size_t)row * HID + 4 * (8 + e - 2) + g];
+            put(OFF_W1, frag, l, e, wv);
+        }
+        for (int s2 = tid; s2 < OUT_MT * 2 * 512; s2 += blockDim.x) {       // output Linear: [h1 own | h1 tiles 8, 9 ; 0]
+            const int e = s2 & 7, l = (s2 >> 3) & 63, frag = s2 >> 9, ch = frag & 1, om = frag >> 1, g = l >> 4, r = l & 15;
+            // D row 4 qq + rr of row tile om is output 5 qq + rr (om = 0) / 5 qq + 4 (om = 1, rr = 0): five outputs per lane quarter
+            const int qq = r >> 2, rr = r & 3, row = om == 0 ? 5 * qq + rr : (rr == 0 ? 5 * qq + 4 : -1);
+            float wv = 0.f;
+            if (row >= 0 && row < p.out_ch) {
+                if (ch == 0) wv = p.wl[(size_t)row * HID + 4 * e + g];
+                else if (e < 2) wv = p.wl[(size_t)row * HID + 4 * (8 + e) + g];
+            }
+            put(OFF_WL, frag, l, e, wv);
+        }
+        float *bias = reinterpret_cast<float *>(smem + OFF_BIAS);
+        for (int e = tid; e < 2 * MT * 16; e += blockDim.x) {               // bias rows: [layer][mt][q][gate r]
+            const int l2 = e / (MT * 16), r = e & 3, qq = (e >> 2) & 3, mt = (e >> 4) % MT;
+            bias[e] = p.b_ih[l2][r * HID + 4 * mt + qq] + p.b_hh[l2][r * HID + 4 * mt + qq];
+        }
+        for (int e = tid; e < NTILE * 2 * HS_BUF / 4; e += blockDim.x) reinterpret_cast<unsigned *>(smem + OFF_HS)[e] = 0u;
+    }
+    __syncthreads();
+    const int unit = blockIdx.x * NTILE + slot;                           // this wave pair's (chunk, bin group)
+    const int total = p.nunits;
+    const bool live = unit < total;
+    const int uc = live ? unit : total - 1, chunk = uc / groups, f0 = (uc - chunk * groups) * 16;
+    unsigned char *hs = smem + OFF_HS + slot * 2 * HS_BUF;                // [2 buffers][plane 0 | plane 1 (1 KB each) | head 0 | head 1 (256 B each)]
+    const unsigned char *wbase = smem + (layer == 0 ? OFF_W0 : OFF_W1) + lane * 16;
+    constexpr int NCH0 = 2, NCH1 = 3;
+    const f32x4 *biasq = reinterpret_cast<const f32x4 *>(smem + OFF_BIAS + layer * MT * 16 * 4) + q;
+    float h[MT], c[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { h[mt] = 0.f; c[mt] = 0.f; }
+    f16x8 bown[2] = {f16x8{0, 0, 0, 0, 0, 0, 0, 0}, f16x8{0, 0, 0, 0, 0, 0, 0, 0}};      // own chunk of the next step (h = 0)
+    unsigned head_own[2] = {0u, 0u};                                                      // own units of row tiles 8, 9: two fp16 per plane
+    // Memory path: in the FT layout the 16 frames of a (channel, bin) row are contiguous, so a lane moves FOUR time steps per request:
+    // layer 0 loads the x rows of steps 4 k .. 4 k + 3 as one float4 per channel a group ahead (+ the LayerNorm statistics of the four
+    // frames), layer 1 loads `mul` the same way at the start of a group and stores its outputs as one float4 per channel at the group's
+    // end.  (As per-step 4-byte accesses -- the f32 kernel's way -- the loads and the stores each took 40 % of this kernel: what-ifs
+    // 24 -> 14 ms per 3840 windows without either.)  tp and the group starts are multiples of 4: a group never straddles a tile.
+    static_assert(OUT_MT == 2, "the 20 outputs sit as rows 5 q + j: j < 4 in row tile 0, j = 4 in row 4 q of row tile 1");
+    constexpr int NO = 5;
+    float lnw[5], lnb[5], blr[NO];
+    // (a wave is layer 0 or layer 1 for its whole life: the two roles' group registers share storage -- ioa = x of this group / mul,
+    //  iob = x of the next group / the outputs)
+    f32x4 ioa[5], iob[5], st_m = {0.f, 0.f, 0.f, 0.f}, st_i = {1.f, 1.f, 1.f, 1.f}, st_mn = st_m, st_in = st_i;
+    f32x4 (&xg)[5] = ioa, (&xg_n)[5] = iob, (&mg)[5] = ioa, (&og)[5] = iob;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        lnw[s] = p.ln.stats ? p.ln.w[(5 * q + s) * p.F + f0 + i] : 1.f;
+        lnb[s] = p.ln.stats ? p.ln.b[(5 * q + s) * p.F + f0 + i] : 0.f;
+        ioa[s] = layer == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{1.f, 1.f, 1.f, 1.f}; iob[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < NO; ++j) blr[j] = p.bl[5 * q + j];
+    auto group_pos = [&](int t0, int &tile, int &t16) {          // t0 = first step of a group (clamped into the clip)
+        const int tc = t0 >= p.T ? ((p.T - 1) & ~3) : t0, gfr = chunk * p.tp + tc;
+        tile = gfr >> 4; t16 = gfr & 15;
+    };
+    auto load_x_group = [&](int t0) {                            // layer 0: the next group's inputs
+        if ((LT_EXP & 4) && t0 > 0) return;
+        int tile, t16;
+        group_pos(t0, tile, t16);
+#pragma unroll
+        for (int s = 0; s < 5; ++s) xg_n[s] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + 5 * q + s, p.F, f0 + i) + t16);
+        if (p.ln.stats) {
+            const float *sp = p.ln.stats + ((size_t)tile * 16 + t16) * 2;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(sp), b2 = *reinterpret_cast<const f32x4 *>(sp + 4);
+            st_mn = f32x4{a[0], a[2], b2[0], b2[2]};
+            st_in = f32x4{a[1], a[3], b2[1], b2[3]};
+        }
+    };
+    auto load_mul_group = [&](int t0) {                          // layer 1, MODE 0: this group's multipliers (first used at the step's end)
+        if ((LT_EXP & 4) && t0 > 0) return;
+        int tile, t16;
+        group_pos(t0, tile, t16);
+#pragma unroll
+        for (int j = 0; j < NO; ++j) mg[j] = *reinterpret_cast<const f32x4 *>(p.mul.ptr + ft_idx(tile, p.mul.c_total, p.mul.c_off + 5 * q + j, p.F, f0 + i) + t16);
+    };
+    auto pick = [](const f32x4 &v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); };
+    if (layer == 0) load_x_group(0);
+    for (int it = 0; it < p.T + 1; ++it) {
+        const int t = it - layer;                            // this wave's time step
+        if (t >= 0 && t < p.T) {
+            const int j4 = t & 3;
+            unsigned char *hbuf = hs + (t & 1) * HS_BUF;
+            f16x8 bop[2][2];                                 // the operand chunks besides the own one (layer 0: one, layer 1: two)
+            if (layer == 0) {
+                if (j4 == 0) {
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) xg[s] = xg_n[s];
+                    st_m = st_mn; st_i = st_in;
+                    load_x_group(t + 4);
+                }
+                float v1[8];
+                v1[0] = 0.f; v1[1] = 0.f; v1[7] = 0.f;
+                const float mean_c = pick(st_m, j4), inv_c = pick(st_i, j4);
+#pragma unroll
+                for (int s = 0; s < 5; ++s) { const float xv = pick(xg[s], j4); v1[2 + s] = p.ln.stats ? (xv - mean_c) * inv_c * lnw[s] + lnb[s] : xv; }
+                split8_h2(v1, bop[0], amax);
+                {   // slots 0, 1 of chunk 1 = the own units of row tiles 8, 9 (split at the end of the previous step)
+                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                    u32x4_ w0 = __builtin_bit_cast(u32x4_, bop[0][0]), w1 = __builtin_bit_cast(u32x4_, bop[0][1]);
+                    w0[0] = head_own[0]; w1[0] = head_own[1];
+                    bop[0][0] = __builtin_bit_cast(f16x8, w0); bop[0][1] = __builtin_bit_cast(f16x8, w1);
+                }
+                bop[1][0] = bop[0][0]; bop[1][1] = bop[0][1];
+            } else {
+                if (MODE == 0 && j4 == 0) load_mul_group(t);
+                bop[0][0] = *reinterpret_cast<const f16x8 *>(hbuf + lane * 16);
+                bop[0][1] = *reinterpret_cast<const f16x8 *>(hbuf + FR + lane * 16);
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                const unsigned hd0 = *reinterpret_cast<const unsigned *>(hbuf + 2 * FR + lane * 4), hd1 = *reinterpret_cast<const unsigned *>(hbuf + 2 * FR + 256 + lane * 4);
+                bop[1][0] = __builtin_bit_cast(f16x8, u32x4_{head_own[0], hd0, 0u, 0u});
+                bop[1][1] = __builtin_bit_cast(f16x8, u32x4_{head_own[1], hd1, 0u, 0u});
+            }
+            // row tiles in two passes (0..5, 6..9): 48 accumulator registers instead of 80 -- the operands are fragments in registers, the
+            // cell update of the first pass touches nothing the second pass reads
+            auto pass = [&](auto t0_c, auto np_c) {
+                constexpr int T0 = decltype(t0_c)::value, NPR = decltype(np_c)::value;
+                f32x4 hi[2 * NPR], mid[2 * NPR];
+#pragma unroll
+                for (int u = 0; u < 2 * NPR; ++u) { hi[u] = biasq[(T0 + u) * 4]; mid[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                if (layer == 0) {
+                    gemm_h2_lds<NPR>(hi, mid, wbase + T0 * NCH0 * 2 * FR, NCH0 * 2 * FR, bown);
+                    gemm_h2_lds<NPR>(hi, mid, wbase + T0 * NCH0 * 2 * FR + 2 * FR, NCH0 * 2 * FR, bop[0]);
+                } else {
+                    gemm_h2_lds<NPR>(hi, mid, wbase + T0 * NCH1 * 2 * FR, NCH1 * 2 * FR, bown);
+                    gemm_h2_lds<NPR>(hi, mid, wbase + T0 * NCH1 * 2 * FR + 2 * FR, NCH1 * 2 * FR, bop[0]);
+                    gemm_h2_lds<NPR>(hi, mid, wbase + T0 * NCH1 * 2 * FR + 4 * FR, NCH1 * 2 * FR, bop[1]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2 * NPR; ++u) {
+                    const int mt = T0 + u;
+                    const f32x4 a = vadx::join2(hi[u], mid[u]);
+                    const bool lin = LT_EXP & 1;
+                    const float ig = lin ? a[0] * 0.1f : gate_sigmoid(a[0]), fg = lin ? a[1] * 0.1f : gate_sigmoid(a[1]);
+                    const float gg = lin ? a[2] * 0.1f : gate_tanh(a[2]), og2 = lin ? a[3] * 0.1f : gate_sigmoid(a[3]);
+                    c[mt] = fg * c[mt] + ig * gg;
+                    h[mt] = lin ? og2 * c[mt] * 0.1f : og2 * gate_tanh(c[mt]);
+                }
+            };
+            pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+            pass(std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
+            {   // the new h as the next step's operand: own chunk (row tiles 0..7) and the head (row tiles 8, 9)
+                float v0[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v0[e] = h[e];
+                split8_h2(v0, bown, amax);
+                unsigned short a0, a1, c0, c1;
+                vadx::split2x1(h[8], a0, a1, amax);
+                vadx::split2x1(h[9], c0, c1, amax);
+                head_own[0] = (unsigned)a0 | ((unsigned)c0 << 16);
+                head_own[1] = (unsigned)a1 | ((unsigned)c1 << 16);
+            }
+            if (layer == 0) {
+                *reinterpret_cast<f16x8 *>(hbuf + lane * 16) = bown[0];
+                *reinterpret_cast<f16x8 *>(hbuf + FR + lane * 16) = bown[1];
+                *reinterpret_cast<unsigned *>(hbuf + 2 * FR + lane * 4) = head_own[0];
+                *reinterpret_cast<unsigned *>(hbuf + 2 * FR + 256 + lane * 4) = head_own[1];
+            } else {
+                f32x4 yh[OUT_MT], ym[OUT_MT];
+#pragma unroll
+                for (int om = 0; om < OUT_MT; ++om) { yh[om] = f32x4{0.f, 0.f, 0.f, 0.f}; ym[om] = yh[om]; }
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                const f16x8 bt[2] = {__builtin_bit_cast(f16x8, u32x4_{head_own[0], 0u, 0u, 0u}), __builtin_bit_cast(f16x8, u32x4_{head_own[1], 0u, 0u, 0u})};
+                const unsigned char *wl = smem + OFF_WL + lane * 16;
+                gemm_h2_lds<OUT_MT / 2>(yh, ym, wl, 2 * 2 * FR, bown);
+                gemm_h2_lds<OUT_MT / 2>(yh, ym, wl + 2 * FR, 2 * 2 * FR, bt);
+                const f32x4 y0 = vadx::join2(yh[0], ym[0]), y1 = vadx::join2(yh[1], ym[1]);
+#pragma unroll
+                for (int j = 0; j < NO; ++j) {
+                    float v = (j < 4 ? y0[j < 4 ? j : 0] : y1[0]) + blr[j];
+                    if (MODE == 0) v *= pick(mg[j], j4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) og[j][k] = (j4 == k) ? v : og[j][k];
+                }
+                if ((j4 == 3 || t == p.T - 1) && live && !(LT_EXP & 8)) {        // the group's outputs leave together
+                    int tile, t16;
+                    group_pos(t - j4, tile, t16);
+#pragma unroll
+                    for (int j = 0; j < NO; ++j) {
+                        float *dst = p.out.ptr + ft_idx(tile, p.out.c_total, p.out.c_off + 5 * q + j, p.F, f0 + i) + t16;
+                        if (j4 == 3) *reinterpret_cast<f32x4 *>(dst) = og[j];
+                        else
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) if (k <= j4) dst[k] = og[j][k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!(amax <= vadx::H_MAX)) { atomicOr(range_flag, 1u); atomicMax(range_flag + 1, __float_as_uint(amax)); }
 }
 
 // Memory path.  In the FT layout one time step of a 16-bin group is 16 B out of each of IN*16 different 64-B rows, so
@@ -1603,13 +1901,17 @@ extern "C" int vadx_dfsmn_alpha_scale(const float *in, float *out, int chunks, i
 extern "C" int vadx_dfsmn_lstm_t(int which, const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2], const float *const w_hh[2],
                                  const float *const b_ih[2], const float *const b_hh[2], const float *wl, const float *bl,
                                  const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, void *stream) {
-    return vadx_dfsmn_lstm_t_ex(which, in, ln, w_ih, w_hh, b_ih, b_hh, wl, bl, mul, out, F, frames, chunks, ((frames + 15) / 16) * 16, stream);
+    return vadx_dfsmn_lstm_t_ex(which, in, ln, w_ih, w_hh, b_ih, b_hh, wl, bl, mul, out, F, frames, chunks, ((frames + 15) / 16) * 16, stream,
+                                VADX_ARITH_F32, nullptr);
 }
 
 extern "C" int vadx_dfsmn_lstm_t_ex(int which, const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2], const float *const w_hh[2],
                                     const float *const b_ih[2], const float *const b_hh[2], const float *wl, const float *bl,
-                                    const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, int frame_stride, void *stream) {
+                                    const vadx_ft_view *mul, const vadx_ft_view *out, int F, int frames, int chunks, int frame_stride, void *stream,
+                                    int arithmetic, void *range_flag) {
     VADX_REQUIRE(in && in->ptr && out && out->ptr && w_ih && w_hh && b_ih && b_hh && wl && bl, "vadx_dfsmn_lstm_t: bad argument");
+    VADX_REQUIRE(arithmetic == VADX_ARITH_AUTO || arithmetic == VADX_ARITH_F32 || (arithmetic == VADX_ARITH_F16X2 && range_flag),
+                 "vadx_dfsmn_lstm_t: arithmetic must be AUTO / F32, or F16X2 with two device words for the range flag");
     VADX_REQUIRE(F % 16 == 0 && frames > 0 && chunks > 0, "vadx_dfsmn_lstm_t: F must be a multiple of 16");
     VADX_REQUIRE(frame_stride % 4 == 0 && frame_stride >= ((frames + 3) / 4) * 4, "vadx_dfsmn_lstm_t: frame_stride must be a multiple of 4 covering the frames rounded up to 4");
     LstmTArgs p;
@@ -1635,8 +1937,17 @@ extern "C" int vadx_dfsmn_lstm_t_ex(int which, const vadx_ft_view *in, const vad
         // plane 2 of each layer's first two chunks in its waves' registers -- was built and measured: 27.6 ms per 3060 windows against
         // 26.4 with a dependent chain per row tile, 33.8 with the products tile-interleaved (184 B of scratch per lane in the step): 162 KB
         // of split weights do not fit beside the h exchange in LDS, and 80 resident registers leave the step no room.  Removed.)
-        VADX_DYN_LDS((lstm_t2_kernel<20, 40, 2, 0, NTILE>), lds2);
-        hipLaunchKernelGGL((lstm_t2_kernel<20, 40, 2, 0, NTILE>), dim3((grid + NTILE - 1) / NTILE), dim3(128 * NTILE), lds2, st, p);
+        // fp16 x 2 (lstm_t2h_kernel): half of bf16 x 3's products and 110 KB of fragments -- it fits, and the step is no longer bound by
+        // the matrix pipe.  (which = 1, the one-layer net, is bound by its memory path and stays on float32 MFMAs for every arithmetic.)
+        if (arithmetic == VADX_ARITH_F16X2) {
+            constexpr size_t ldsh = (size_t)(10 * 2 * 2 + 10 * 3 * 2 + 2 * 2 * 2) * 1024 + 2 * 10 * 16 * 4 + NTILE * 2 * (2 * 1024 + 2 * 256);
+            VADX_DYN_LDS((lstm_t2h_kernel<2, 0, NTILE>), ldsh);
+            hipLaunchKernelGGL((lstm_t2h_kernel<2, 0, NTILE>), dim3((grid + NTILE - 1) / NTILE), dim3(128 * NTILE), ldsh, st, p,
+                               static_cast<unsigned *>(range_flag));
+        } else {
+            VADX_DYN_LDS((lstm_t2_kernel<20, 40, 2, 0, NTILE>), lds2);
+            hipLaunchKernelGGL((lstm_t2_kernel<20, 40, 2, 0, NTILE>), dim3((grid + NTILE - 1) / NTILE), dim3(128 * NTILE), lds2, st, p);
+        }
     } else {                     // out_ch_lstm: in 40, hidden 20, 1 layer, Linear 20->40
         VADX_REQUIRE(in->c == 40, "vadx_dfsmn_lstm_t(1): in must have 40 channels");
         p.out_ch = 40;

@@ -79,7 +79,9 @@ class Iccrn:
         self.w = w
         self.d = {}
         self._cfb_cache = {}
-        self.arithmetic = None         # None = the module default (_lib.gemm_mode()); "f32" | "split" | "h2" (-> "split" here, see _arith)
+        self.arithmetic = None         # None = the module default (_lib.gemm_mode()); "f32" | "split" | "h2" (-> "split" in lstm_f / cfb, see _arith)
+        self.range_flag = t.zeros(2, dtype=t.int32, device=self.device)      # fp16 x 2 kernels (the two-layer time LSTM): {sticky flag, max |x| bits}
+        self.lstm_t_h2 = True          # cleared by DfsmnEngine.run while it recomputes a flagged batch
         env = os.environ.get("VADX_CFB_BACK", "")     # read once: the second half of the gated conv block as split products (opt-in, no faster)
         self.cfb_back_split = env == "split"
         self.frame_stride = None       # None: every chunk on tiles of its own; forward() packs (packed_stride) for the duration of a pass
@@ -341,10 +343,12 @@ class Iccrn:
         arr = lambda n: (C.c_void_p * 2)(*[self._p(f"{prefix}.lstm2.{n}_l{l}") if l < layers else None for l in range(2)])   # noqa: E731
         wi, wh, bi, bh = arr("weight_ih"), arr("weight_hh"), arr("bias_ih"), arr("bias_hh")
         stride = ft_tiles(frames) * 16 if self.frame_stride is None else self.frame_stride
+        h2 = (self.arithmetic or _lib.gemm_mode()) == "h2" and self.lstm_t_h2          # (only the two-layer net has the fp16 x 2 form)
         _lib.check(self.lib.vadx_dfsmn_lstm_t_ex(which, C.byref(inp), None if ln is None else C.byref(ln), C.byref(wi), C.byref(wh),
                                                  C.byref(bi), C.byref(bh), self._p(prefix + ".linear.weight"),
                                                  self._p(prefix + ".linear.bias"), None if mul is None else C.byref(mul),
-                                                 C.byref(out), F_BINS, frames, n_chunks, stride, _lib.stream_ptr()))
+                                                 C.byref(out), F_BINS, frames, n_chunks, stride, _lib.stream_ptr(),
+                                                 _lib.ARITH["h2" if h2 else "f32"], self.range_flag.data_ptr()))
 
     # ---- NET.forward (:226-249) without the ISTFT ------------------------------------------------
     def forward(self, x4, n_chunks, frames, pack=True):
@@ -407,6 +411,7 @@ class DfsmnEngine:
         w = _ck.resolve("dfsmn", weights)
         w = {k: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in w.items()}
         self.sub_batch = int(sub_batch)
+        self.range_fallbacks = 0       # batches recomputed because the fp16 x 2 time LSTM flagged an out-of-range operand
         self.iccrn = Iccrn(w, device)
         dev = lambda a: t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)     # noqa: E731
         self.alpha = [dev(w[k]) for k in ("alpha.linear1.weight", "alpha.linear1.bias", "alpha.linear2.weight", "alpha.linear2.bias")]
@@ -494,12 +499,24 @@ class DfsmnEngine:
         per = max(1, self.sub_batch // W)                  # clips per sub-batch (activations are ~30 MB per window)
         # (alternating the independent sub-batches over two or three side streams so that one's HBM-bound launches overlap another's
         # matrix-pipe-bound ones was measured: 2986 / 2985 ms against 2990 -- every launch fills the chip by itself)
-        for b0 in range(0, B, per):
-            nb = min(per, B - b0)
-            v, a = self._run_sub(near[b0:b0 + nb], None if far is None else far[b0:b0 + nb], W, ws)
-            vad[b0 * W:(b0 + nb) * W] = v
-            if return_aec:
-                aec_all[b0 * W:(b0 + nb) * W] = a
+        def sweep():
+            for b0 in range(0, B, per):
+                nb = min(per, B - b0)
+                v, a = self._run_sub(near[b0:b0 + nb], None if far is None else far[b0:b0 + nb], W, ws)
+                vad[b0 * W:(b0 + nb) * W] = v
+                if return_aec:
+                    aec_all[b0 * W:(b0 + nb) * W] = a
+        sweep()
+        net = self.iccrn
+        if (net.arithmetic or _lib.gemm_mode()) == "h2" and int(net.range_flag[0].item()) != 0:
+            # an input of the fp16 x 2 time LSTM left the fp16 range (one 4-byte read-back, synchronises): the batch again on float32 MFMAs
+            self.range_fallbacks += 1
+            net.range_flag.zero_()
+            net.lstm_t_h2 = False
+            try:
+                sweep()
+            finally:
+                net.lstm_t_h2 = True
         return (vad, aec_all) if return_aec else vad
 
     def run_from_host(self, host_near_i16, host_far_i16, windows_per_clip=1, win_stride=None, chunk_clips=64, feed=None):
