@@ -458,10 +458,12 @@ int vadx_dfsmn_pw_conv(int mode, const vadx_ft_view *a, const vadx_ft_view *b, c
 int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_ft_view *lo, const vadx_ft_ln *ln,
                      const float *tbl, const vadx_ft_view *out, int C, int tiles, float *part, void *stream);
 /* bi-LSTM (hidden 20) along F with the tile's 16 frames as the batch; in->c = 4 or 40; out 40 ch.  arithmetic: VADX_ARITH_* of the
- * 40-channel (CepsUnit) form -- AUTO = BF16X3, F32 = the float32-MFMA kernel; F16X2 is not built for this kernel and is refused. */
+ * 40-channel (CepsUnit) form -- AUTO = BF16X3, F32 = the float32-MFMA kernel, F16X2 = fp16 x 2 split products with range_flag = two
+ * zeroed device words {sticky flag, bits of the largest |operand|} (the caller recomputes a flagged batch on BF16X3 / F32); range_flag
+ * may be NULL for the other arithmetics. */
 int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2],
                       const float *const w_hh[2], const float *const b_ih[2], const float *const b_hh[2],
-                      const vadx_ft_view *out, int F, int tiles, void *stream, int arithmetic);
+                      const vadx_ft_view *out, int F, int tiles, void *stream, int arithmetic, void *range_flag);
 
 /* One gated conv block (CFB :76-93 with its CepsUnit :96-154) as two streaming launches around vadx_dfsmn_lstm_f
  * (csrc/dfsmn_cfb.hip): the block's 20-channel intermediates gx, r, lo, ceps never reach memory.

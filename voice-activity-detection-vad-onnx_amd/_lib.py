@@ -191,7 +191,7 @@ SIGNATURES = {
                                 C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtView), _I, _I, _I, _I, _I, _P, _P, _P]),
     "vadx_dfsmn_dft_f": (_I, [_I, C.POINTER(FtView), C.POINTER(FtView), C.POINTER(FtLn), _P, C.POINTER(FtView), _I, _I, _P, _P]),
     "vadx_dfsmn_lstm_f": (_I, [C.POINTER(FtView), C.POINTER(FtLn), C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2),
-                               C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), C.POINTER(FtView), _I, _I, _P, _I]),
+                               C.POINTER(C.c_void_p * 2), C.POINTER(C.c_void_p * 2), C.POINTER(FtView), _I, _I, _P, _I, _P]),
     "vadx_dfsmn_cfb_front": (_I, [C.POINTER(DfsmnCfbWeights), C.POINTER(FtView), C.POINTER(FtView), _P, _P, _P, _P, _P, _I, _P]),
     "vadx_dfsmn_cfb_back": (_I, [C.POINTER(DfsmnCfbWeights), _P, _P, _P, _P, C.POINTER(FtView), _P, _I, _P]),
     "vadx_dfsmn_alpha_scale": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),

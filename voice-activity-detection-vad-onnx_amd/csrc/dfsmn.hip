@@ -840,6 +840,16 @@ __device__ __forceinline__ void split3x8(const float (&v)[8], bf16x8 &p0, bf16x8
     p0 = c0.h; p1 = c1.h; p2 = c2.h;
 }
 
+// eight float32 values (the slots of one lane's chunk) -> the two fp16 planes of its B / A fragment
+__device__ __forceinline__ void split8_h2(const float (&v)[8], f16x8 (&b)[2], float &amax) {
+    u32x2 a0, a1, c0, c1;
+    vadx::split2x4(f32x4{v[0], v[1], v[2], v[3]}, a0, a1, amax);
+    vadx::split2x4(f32x4{v[4], v[5], v[6], v[7]}, c0, c1, amax);
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    b[0] = __builtin_bit_cast(f16x8, u32x4_{a0[0], a0[1], c0[0], c0[1]});
+    b[1] = __builtin_bit_cast(f16x8, u32x4_{a1[0], a1[1], c1[0], c1[1]});
+}
+
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void lstm_f_split_kernel(LstmFArgs p, int tiles) {
     constexpr int IN = 40, H = 20, MT = 5, NB = 2;
     constexpr int CH_FLOATS = NB * IN * 16, NLD = NB * IN / 16;
@@ -952,6 +962,118 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void l
     }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same kernel on fp16 x 2 split products (csrc/split2.h): both planes of the weights in registers (80 VGPRs, no LDS plane), three
+// v_mfma_f32_16x16x32_f16 per (row tile, chunk) = 30 per step instead of 60 bf16, 3 VALU per split value instead of 5.5.  h lies in
+// (-1, 1); the LayerNorm'd inputs and the weights feed the range check (vadx_dfsmn_lstm_f's range_flag).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void lstm_f_h2_kernel(LstmFArgs p, int tiles, unsigned *__restrict__ range_flag) {
+    constexpr int IN = 40, H = 20, MT = 5, NB = 2;
+    constexpr int CH_FLOATS = NB * IN * 16, NLD = NB * IN / 16;
+    __shared__ __attribute__((aligned(16))) float xs[2][2][CH_FLOATS];      // [direction][buffer]
+    const int lane = threadIdx.x & 63, dir = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    const int grow = (i & 3) * H + (i >> 2);          // A-fragment row i <-> gate (i&3), unit-in-quad (i>>2)
+    f16x8 wa[MT][2][2];                               // [row tile][chunk][plane]: 80 VGPRs, resident for every tile of this workgroup
+    float amax = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = grow + 4 * mt;
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v0[e] = e < 5 ? p.w_hh[dir][(size_t)row * H + 4 * e + q] : p.w_ih[dir][(size_t)row * IN + 3 * q + e - 5];
+            const int ch = 12 + 8 * q + e;
+            v1[e] = ch < IN ? p.w_ih[dir][(size_t)row * IN + ch] : (ch == IN ? p.b_ih[dir][row] + p.b_hh[dir][row] : 0.f);
+        }
+        split8_h2(v0, wa[mt][0], amax);
+        split8_h2(v1, wa[mt][1], amax);
+    }
+    const int tq = lane & 3;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    float h[MT], c[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { h[mt] = 0.f; c[mt] = 0.f; }
+    f32x4 ln_mean, ln_inv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ln_mean[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2];
+        ln_inv[r] = p.ln.stats[((size_t)tile * 16 + 4 * tq + r) * 2 + 1];
+    }
+    const int nchunk = (p.F + NB - 1) / NB;
+    auto bin_of = [&](int ck, int b) { const int st = ck * NB + b; return dir ? p.F - 1 - st : st; };
+    f32x4 pre[NLD];
+    float lw[NLD], lb[NLD];
+    auto request = [&](int ck) {
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int row = (lane >> 2) + 16 * r, b = row / IN, ch = row - b * IN, f = bin_of(ck, b);
+            const int fcl = f < 0 ? 0 : (f >= p.F ? p.F - 1 : f);        // unconditional (clamped) loads; bins past the end are never used
+            pre[r] = *reinterpret_cast<const f32x4 *>(p.in.ptr + ft_idx(tile, p.in.c_total, p.in.c_off + ch, p.F, fcl) + 4 * tq);
+            lw[r] = p.ln.w[ch * p.F + fcl]; lb[r] = p.ln.b[ch * p.F + fcl];
+        }
+    };
+    auto park = [&](float *dst) {
+#pragma unroll
+        for (int r = 0; r < NLD; ++r)
+            *reinterpret_cast<f32x4 *>(dst + ((lane >> 2) + 16 * r) * 16 + 4 * tq) = (pre[r] - ln_mean) * ln_inv * lw[r] + lb[r];
+    };
+    __builtin_amdgcn_wave_barrier();                  // the previous tile's last reads of xs precede this tile's first park
+    request(0);
+    park(xs[dir][0]);
+    if (nchunk > 1) request(1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const float *xb = xs[dir][ck & 1];
+        if (ck + 1 < nchunk) {
+            park(xs[dir][(ck + 1) & 1]);                  // the buffer last read by chunk ck - 1
+            if (ck + 2 < nchunk) request(ck + 2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll 1
+        for (int b = 0; b < NB; ++b) {
+            const int f = bin_of(ck, b);
+            if (f < 0 || f >= p.F) break;
+            const float *xrow = xb + b * IN * 16 + i;
+            float v0[8], v1[8];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) v0[e] = h[e];
+#pragma unroll
+            for (int e = 5; e < 8; ++e) v0[e] = xrow[(3 * q + e - 5) * 16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = 12 + 8 * q + e;               // (q is per-lane: clamp the read, select afterwards)
+                const float xv = xrow[(ch < IN ? ch : IN - 1) * 16];
+                v1[e] = ch < IN ? xv : (ch == IN ? 1.0f : 0.f);
+            }
+            f16x8 b0[2], b1[2];
+            split8_h2(v0, b0, amax);
+            split8_h2(v1, b1, amax);
+            // three products per (row tile, chunk): the two cross terms into `mid`, the leading one into `hi`; row tiles innermost so that
+            // consecutive MFMAs are independent
+            f32x4 hi[MT], mid[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { hi[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; mid[mt] = hi[mt]; }
+#define LF_TERM(ACC, CH, BF, AP, BP) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = vadx::mfma_f16(wa[mt][CH][AP], BF[BP], ACC[mt]);
+            LF_TERM(mid, 0, b0, 1, 0) LF_TERM(mid, 1, b1, 1, 0) LF_TERM(mid, 0, b0, 0, 1) LF_TERM(mid, 1, b1, 0, 1)
+            LF_TERM(hi, 0, b0, 0, 0) LF_TERM(hi, 1, b1, 0, 0)
+#undef LF_TERM
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 a = vadx::join2(hi[mt], mid[mt]);
+                const float ig = gate_sigmoid(a[0]), fg = gate_sigmoid(a[1]), gg = gate_tanh(a[2]), og = gate_sigmoid(a[3]);
+                c[mt] = fg * c[mt] + ig * gg;
+                h[mt] = og * gate_tanh(c[mt]);
+                p.out.ptr[ft_idx(tile, p.out.c_total, p.out.c_off + dir * H + 4 * mt + q, p.F, f) + i] = h[mt];
+            }
+        }
+    }
+    }
+    if (!(amax <= vadx::H_MAX)) { atomicOr(range_flag, 1u); atomicMax(range_flag + 1, __float_as_uint(amax)); }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // alpha_scale (DFSMN_VAD.forward :326-335): x4 = [mix_re, mix_im, |alpha| * far_re, |alpha| * far_im] with
@@ -1258,14 +1380,6 @@ __device__ __forceinline__ void gemm_h2_lds(f32x4 *hi, f32x4 *mid, const unsigne
     }
 }
 
-__device__ __forceinline__ void split8_h2(const float (&v)[8], f16x8 (&b)[2], float &amax) {
-    u32x2 a0, a1, c0, c1;
-    vadx::split2x4(f32x4{v[0], v[1], v[2], v[3]}, a0, a1, amax);
-    vadx::split2x4(f32x4{v[4], v[5], v[6], v[7]}, c0, c1, amax);
-    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-    b[0] = __builtin_bit_cast(f16x8, u32x4_{a0[0], a0[1], c0[0], c0[1]});
-    b[1] = __builtin_bit_cast(f16x8, u32x4_{a1[0], a1[1], c1[0], c1[1]});
-}
 
 template <int OUT_MT, int MODE, int NTILE>
 __global__ __launch_bounds__(128 * NTILE) void lstm_t2h_kernel(LstmTArgs p, unsigned *__restrict__ range_flag) {
@@ -1868,16 +1982,20 @@ extern "C" int vadx_dfsmn_dft_f(int inverse, const vadx_ft_view *in, const vadx_
 
 extern "C" int vadx_dfsmn_lstm_f(const vadx_ft_view *in, const vadx_ft_ln *ln, const float *const w_ih[2],
                                  const float *const w_hh[2], const float *const b_ih[2], const float *const b_hh[2],
-                                 const vadx_ft_view *out, int F, int tiles, void *stream, int arithmetic) {
+                                 const vadx_ft_view *out, int F, int tiles, void *stream, int arithmetic, void *range_flag) {
     VADX_REQUIRE(in && in->ptr && out && out->ptr && w_ih && w_hh && b_ih && b_hh && F > 0 && tiles > 0, "vadx_dfsmn_lstm_f: bad argument");
-    VADX_REQUIRE(arithmetic == VADX_ARITH_AUTO || arithmetic == VADX_ARITH_F32 || arithmetic == VADX_ARITH_BF16X3,
-                 "vadx_dfsmn_lstm_f: arithmetic=%d (this kernel has VADX_ARITH_F32 and VADX_ARITH_BF16X3)", arithmetic);
+    VADX_REQUIRE(arithmetic == VADX_ARITH_AUTO || arithmetic == VADX_ARITH_F32 || arithmetic == VADX_ARITH_BF16X3 ||
+                 (arithmetic == VADX_ARITH_F16X2 && range_flag),
+                 "vadx_dfsmn_lstm_f: arithmetic=%d (F32, BF16X3, or F16X2 with two device words for the range flag)", arithmetic);
     VADX_REQUIRE(in->c == 40 ? (ln && ln->stats && ln->w && ln->b) : !(ln && ln->stats),
                  "vadx_dfsmn_lstm_f: the 40-channel (CepsUnit) LSTM takes a LayerNorm, the 4-channel one does not");
     LstmFArgs p;
     p.in = mkview(in); p.ln = mkln(ln); p.out = mkvieww(out); p.F = F;
     for (int d = 0; d < 2; ++d) { p.w_ih[d] = w_ih[d]; p.w_hh[d] = w_hh[d]; p.b_ih[d] = b_ih[d]; p.b_hh[d] = b_hh[d]; }
     if (in->c == 4) hipLaunchKernelGGL(lstm_f_kernel<4>, dim3(tiles), dim3(128), 0, static_cast<hipStream_t>(stream), p);
+    else if (in->c == 40 && arithmetic == VADX_ARITH_F16X2)
+        hipLaunchKernelGGL(lstm_f_h2_kernel, dim3(tiles < 1024 ? tiles : 1024), dim3(128), 0, static_cast<hipStream_t>(stream), p, tiles,
+                           static_cast<unsigned *>(range_flag));
     else if (in->c == 40 && arithmetic != VADX_ARITH_F32)      // split products: persistent workgroups (each lane splits its weights once), four per CU
         hipLaunchKernelGGL(lstm_f_split_kernel, dim3(tiles < 1024 ? tiles : 1024), dim3(128), 0, static_cast<hipStream_t>(stream), p, tiles);
     else if (in->c == 40) hipLaunchKernelGGL(lstm_f_kernel<40>, dim3(tiles), dim3(128), 0, static_cast<hipStream_t>(stream), p);

@@ -81,7 +81,7 @@ class Iccrn:
         self._cfb_cache = {}
         self.arithmetic = None         # None = the module default (_lib.gemm_mode()); "f32" | "split" | "h2" (-> "split" in lstm_f / cfb, see _arith)
         self.range_flag = t.zeros(2, dtype=t.int32, device=self.device)      # fp16 x 2 kernels (the two-layer time LSTM): {sticky flag, max |x| bits}
-        self.lstm_t_h2 = True          # cleared by DfsmnEngine.run while it recomputes a flagged batch
+        self.lstm_t_h2 = True          # the two LSTMs' fp16 x 2 forms; cleared by DfsmnEngine.run while it recomputes a flagged batch
         env = os.environ.get("VADX_CFB_BACK", "")     # read once: the second half of the gated conv block as split products (opt-in, no faster)
         self.cfb_back_split = env == "split"
         self.frame_stride = None       # None: every chunk on tiles of its own; forward() packs (packed_stride) for the duration of a pass
@@ -170,8 +170,10 @@ class Iccrn:
     def lstm_f(self, prefix, inp, ln, out, F, tiles):
         arr = lambda n: (C.c_void_p * 2)(self._p(f"{prefix}.lstm2.{n}_l0"), self._p(f"{prefix}.lstm2.{n}_l0_reverse"))   # noqa: E731
         wi, wh, bi, bh = arr("weight_ih"), arr("weight_hh"), arr("bias_ih"), arr("bias_hh")
+        h2 = (self.arithmetic or _lib.gemm_mode()) == "h2" and self.lstm_t_h2 and inp.c == 40       # the CepsUnit form has the fp16 x 2 kernel
         _lib.check(self.lib.vadx_dfsmn_lstm_f(C.byref(inp), None if ln is None else C.byref(ln), C.byref(wi), C.byref(wh),
-                                              C.byref(bi), C.byref(bh), C.byref(out), F, tiles, _lib.stream_ptr(), self._arith()))
+                                              C.byref(bi), C.byref(bh), C.byref(out), F, tiles, _lib.stream_ptr(),
+                                              _lib.ARITH["h2"] if h2 else self._arith(), self.range_flag.data_ptr()))
 
     # ---- CFB (:76-93) ---------------------------------------------------------------------------
     def _cfb_tables(self, name):
