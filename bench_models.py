@@ -637,8 +637,12 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
     # entries whose matrix products run as bf16 x 3 split products (these kernels have no fp16 x 2 form yet: "h2" maps to bf16 x 3 there):
     # priced against the f32-equivalent peak of that pipe (cfb_back's split form is opt-in, VADX_CFB_BACK=split: by default it runs f32 MFMAs)
     on_split = ({"lstm_f", "cfb_front"} | ({"cfb_back"} if os.environ.get("VADX_CFB_BACK") == "split" else set())) if _gemm_arith() != "f32" else set()
-    f_h2_lstm_t = nwin * fle["lstm_t"] * LSTM_T_H2_SHARE if _gemm_arith() == "h2" else 0.0      # the two-layer time LSTM's fp16 x 2 form
-    by_entry = {k: _roof(f"vadx_dfsmn_{k}", nwin * fle[k], v, "dfsmn", k, split=k in on_split) for k, v in groups.items() if v > 0 and k != "lstm_t"}
+    h2 = _gemm_arith() == "h2"                               # the two LSTMs have fp16 x 2 forms (the CepsUnit's lstm_f, the two-layer lstm_t)
+    if h2:
+        on_split = on_split - {"lstm_f"}
+    f_h2_lstm_t = nwin * fle["lstm_t"] * LSTM_T_H2_SHARE if h2 else 0.0
+    by_entry = {k: _roof(f"vadx_dfsmn_{k}", nwin * fle[k], v, "dfsmn", k, split=("h2" if (h2 and k == "lstm_f") else k in on_split))
+                for k, v in groups.items() if v > 0 and k != "lstm_t"}
     if groups["lstm_t"] > 0:
         by_entry["lstm_t"] = _roof_mix("vadx_dfsmn_lstm_t", nwin * fle["lstm_t"], f_h2_lstm_t, groups["lstm_t"], "dfsmn", "lstm_t",
                                        note="two launches per pass: the two-layer net (fp16 x 2 split products) and the one-layer net (f32 MFMAs)")
@@ -650,11 +654,12 @@ def dfsmn_c5(torch, device, reps, cpu, clips=2048, log=lambda m: None, sub_batch
            "clip_pairs": clips, "samples_per_clip": n, "windows": nwin, "ms": ms,
            "frames_per_s": clips * n / 512 / (ms * 1e-3), "kernel_ms": split, "kernel_calls": calls,
            "flop_per_window": fl,
-           "roofline": _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fle[dom], groups[dom], "dfsmn", dom, split=dom in on_split,
+           "roofline": _roof(f"{dom} launches (vadx_dfsmn_{dom})", nwin * fle[dom], groups[dom], "dfsmn", dom,
+                             split=("h2" if (h2 and dom == "lstm_f") else dom in on_split),
                              note="all launches of the entry point that takes the most time; flops as the reference computes them "
                                   "(the kernel issues more: 20 output channels pad to 32 MFMA rows)"),
            "roofline_by_entry": by_entry,
-           "roofline_whole_pass": _whole_pass_roof(nwin, fl["total"], fle, groups, on_split, ms, f_h2_lstm_t),
+           "roofline_whole_pass": _whole_pass_roof(nwin, fl["total"], fle, groups, on_split, ms, f_h2_lstm_t + (nwin * fle["lstm_f"] if h2 else 0.0)),
            "range_fallbacks": eng.range_fallbacks,
            "hbm": _hbm(clips * (2 * padded * 2 + W * eng.T_A * 4), ms, "dfsmn"), "cpu_baseline": None}
     del near, far

@@ -37,7 +37,7 @@ extern "C" {
  *    vadx_silero_encoder_mode and vadx_gemm_mode are gone, every Silero launch takes a trailing `const vadx_silero_cfg *`;
  *    VADX_ARITH_F16X2 (fp16 x 2 split products) + vadx_silero_range_flag; the Silero packed blob grew the fp16 fragments;
  *    vadx_sepconv_block / vadx_marblenet_block2 / vadx_marblenet_tail take a trailing `const vadx_marblenet_cfg *` (NULL = float32 MFMAs),
- *    vadx_frag_h2_host / vadx_frag_h2_floats (round 5). */
+ *    vadx_frag_h2_host / vadx_frag_h2_floats; vadx_dfsmn_lstm_f and vadx_dfsmn_lstm_t_ex take (arithmetic, range_flag) (round 5). */
 #define VADX_ABI_VERSION 6
 
 /* Arithmetic of the products whose one operand is a constant (every weight matrix, every DFT table) -- float32 RESULTS in all of them:
