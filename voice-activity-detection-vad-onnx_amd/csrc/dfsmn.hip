@@ -2056,7 +2056,7 @@ extern "C" int vadx_dfsmn_lstm_t_ex(int which, const vadx_ft_view *in, const vad
         // 26.4 with a dependent chain per row tile, 33.8 with the products tile-interleaved (184 B of scratch per lane in the step): 162 KB
         // of split weights do not fit beside the h exchange in LDS, and 80 resident registers leave the step no room.  Removed.)
         // fp16 x 2 (lstm_t2h_kernel): half of bf16 x 3's products and 110 KB of fragments -- it fits, and the step is no longer bound by
-        // the matrix pipe.  (which = 1, the one-layer net, is bound by its memory path and stays on float32 MFMAs for every arithmetic.)
+        // the matrix pipe.
         if (arithmetic == VADX_ARITH_F16X2) {
             constexpr size_t ldsh = (size_t)(10 * 2 * 2 + 10 * 3 * 2 + 2 * 2 * 2) * 1024 + 2 * 10 * 16 * 4 + NTILE * 2 * (2 * 1024 + 2 * 256);
             VADX_DYN_LDS((lstm_t2h_kernel<2, 0, NTILE>), ldsh);
@@ -2069,6 +2069,11 @@ extern "C" int vadx_dfsmn_lstm_t_ex(int which, const vadx_ft_view *in, const vad
     } else {                     // out_ch_lstm: in 40, hidden 20, 1 layer, Linear 20->40
         VADX_REQUIRE(in->c == 40, "vadx_dfsmn_lstm_t(1): in must have 40 channels");
         p.out_ch = 40;
+        // (an fp16 x 2 form of this net -- a wave per 16-bin group, eight independent waves per workgroup sharing 29 KB of fragments, no
+        // barrier in the step loop, four time steps per memory request -- was built and measured: 14 ms per 3840 windows, the same as this
+        // kernel.  What-ifs on it: without transcendentals 0, without the loads - 3.4 ms, without the STORES - 7.4, without both - 10: the
+        // 40-channel output leaves as 16-byte quarters of 64-byte rows whose other quarters follow 4, 8 and 12 steps later; whole rows
+        // need 16 steps of staging = 40 KB per wave.  Removed; this kernel runs float32 MFMAs for every arithmetic.)
         hipLaunchKernelGGL((lstm_t_kernel<40, 20, 1, 3, 1, 4, 40>), dim3(grid), dim3(128), lds_bytes(40, 40, 20, 4, 1), st, p);
     }
     VADX_HIP_TRY(hipGetLastError());
