@@ -141,6 +141,22 @@ def test_dfsmn_entry_points_validate_before_touching_the_device():
     assert lib.vadx_dfsmn_lstm_t(0, C.byref(v(20, 20)), C.byref(ln), C.byref(two), C.byref(two), C.byref(two), C.byref(two), ptr, ptr,
                                  C.byref(v(20, 20)), C.byref(v(20, 20)), 150, 101, 1, None) == -1
     assert b"multiple of 16" in lib.vadx_last_error()
+    # the arithmetic rides with the call: F16X2 without the two range-flag words, or an arithmetic an entry point has no kernel for, is
+    # refused on the host
+    lt = lambda ar, flag: lib.vadx_dfsmn_lstm_t_ex(0, C.byref(v(20, 20)), C.byref(ln), C.byref(two), C.byref(two), C.byref(two), C.byref(two),   # noqa: E731
+                                                   ptr, ptr, C.byref(v(20, 20)), C.byref(v(20, 20)), 160, 101, 1, 104, None, ar, flag)
+    assert lt(_lib.ARITH["h2"], None) == -1 and b"range flag" in lib.vadx_last_error()
+    assert lt(_lib.ARITH["split"], ptr) == -1
+    lf = lambda ar, flag: lib.vadx_dfsmn_lstm_f(C.byref(v(40, 40)), C.byref(ln), C.byref(two), C.byref(two), C.byref(two), C.byref(two),         # noqa: E731
+                                                C.byref(v(40, 40)), 81, 4, None, ar, flag)
+    assert lf(_lib.ARITH["h2"], None) == -1 and b"range flag" in lib.vadx_last_error()
+    mc = _lib.MarbleNetCfg(_lib.ARITH["h2"], 0, None)
+    blk = lambda cfgp: lib.vadx_marblenet_block2(64, 15, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, 1, 32, None, cfgp)                 # noqa: E731
+    assert blk(C.byref(mc)) == -1 and b"range_flag" in lib.vadx_last_error()
+    mc.arithmetic = _lib.ARITH["split"]
+    assert blk(C.byref(mc)) == -1 and b"arithmetic" in lib.vadx_last_error()
+    assert lib.vadx_marblenet_tail(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, 1, 32, None, C.byref(mc)) == -1
+    assert lib.vadx_frag_h2_host(ptr, 16, 32, 7, ptr, None) == -1 and b"k_order" in lib.vadx_last_error()
 
 
 def test_weight_validation():
