@@ -1225,7 +1225,12 @@ extern "C" int vadx_silero_segments(const float *probs, int batch, int steps, co
     VADX_REQUIRE(batch > 0 && steps > 0 && cap > 0, "vadx_silero_segments: batch/steps/cap must be positive");
     VADX_REQUIRE(params->sampling_rate == 16000 || params->sampling_rate == 8000,
                  "Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates");
-    hipLaunchKernelGGL(silero_segments_kernel, dim3((batch + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream),
+    // SEG_CLIPS clips per wave: the state machine diverges per clip (a wave pays for every path its lanes take), and 64 clips per wave
+    // leave three quarters of the CUs without work at 4096 clips
+#ifndef SEG_CLIPS
+#define SEG_CLIPS 16
+#endif
+    hipLaunchKernelGGL(silero_segments_kernel, dim3((batch + SEG_CLIPS - 1) / SEG_CLIPS), dim3(SEG_CLIPS), 0, static_cast<hipStream_t>(stream),
                        probs, batch, steps, reinterpret_cast<const long long *>(n_samples), *params,
                        reinterpret_cast<long long *>(segments), counts, cap);
     VADX_HIP_TRY(hipGetLastError());
