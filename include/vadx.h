@@ -403,7 +403,7 @@ int vadx_sepconv_block(const vadx_sepconv_cfg *cfg, const float *dw_w, const flo
  * tail: block 5 (depthwise k 29, dilation 2, 64 -> 128) -> block 6 (plain 1x1, 128 -> 128) -> Linear(128 -> 2) -> softmax,
  * x [B][64][T] -> score0 / score1 [B][T] (dec_w [2][128], dec_b [2]); the 128-channel tensors never reach HBM. */
 /* cfg (may be NULL = float32 MFMAs): `arithmetic` VADX_ARITH_AUTO / VADX_ARITH_F32 -- pw0 / pw1 / res_w are fragment-major float32
- * (vadx_frag_major_host); VADX_ARITH_F16X2 -- they are fp16 x 2 fragments (vadx_frag_h2_host, K_QUARTER for block2, K_PLAIN for tail's pw / w6) and the 1x1 convs run as split
+ * (vadx_frag_major_host); VADX_ARITH_F16X2 -- they are fp16 x 2 fragments (vadx_frag_h2_host: K_QUARTER for block2 with cin = 128, K_PLAIN for block2 with cin = 64 and for tail's pw / w6) and the 1x1 convs run as split
  * products on the fp16 pipe (float32-class results, csrc/split2.h); `range_flag` then points at two device words {sticky flag, bits of the
  * largest |operand|} that a launch raises when an activation left the fp16 range -- the caller reads them with the results and recomputes
  * that batch on VADX_ARITH_F32 (MarbleNetEngine does).  VADX_ARITH_BF16X3 is refused (no such form of these kernels). */
@@ -572,7 +572,7 @@ int vadx_frag_major_host(const float *src, int rows, int cols, float *dst);
 /* The fp16 x 2 counterpart for the entry points that take bare weight pointers and an `arithmetic` (vadx_marblenet_block2 / _tail):
  * [rows/16 tiles][cols/32 chunks][2 planes][64 lanes][8 fp16], lane 16q+i slot e = W[16*tile + i][32*chunk + k(q, e)], round-to-nearest
  * fp16 terms h0, h1 = (w - h0) * 2^11 (csrc/split2.h).  k_order: VADX_H2_K_PLAIN k = 8q + e (vadx_marblenet_tail's pw / w6),
- * VADX_H2_K_QUARTER k = 16*(e>>2) + 4q + (e&3) (vadx_marblenet_block2's pw0 / pw1 / res_w).  dst holds vadx_frag_h2_floats(rows, cols)
+ * VADX_H2_K_QUARTER k = 16*(e>>2) + 4q + (e&3) (vadx_marblenet_block2's pw0 / pw1 / res_w when cin = 128; with cin = 64 they are K_PLAIN).  dst holds vadx_frag_h2_floats(rows, cols)
  * floats; *wmax_out (optional) receives the largest |w|; fails when a weight is outside the fp16 range (keep that matrix on VADX_ARITH_F32). */
 #define VADX_H2_K_PLAIN 0
 #define VADX_H2_K_QUARTER 1

@@ -111,10 +111,12 @@ def test_full_size_config4_properties():
     print(f"MarbleNet config-4 pass: {dt * 1e3:.1f} ms for 8192 x 5.59 s ({8192 * 89431 / 512 / dt / 1e6:.1f} M 512-hop frames/s)")
 
 
-def test_fused_blocks_equal_the_per_sub_block_launches():
+def test_fused_blocks_equal_the_per_sub_block_launches(gemm):
     """The fused residual-block / tail kernels against the ten per-sub-block launches they replace (same FIR order per element;
     the fused blocks sum each 1x1 conv's K in two halves, the per-sub-block launches in one run: scores agree to float32
-    round-off), including a clip shorter than one tile and a ragged last tile."""
+    round-off), including a clip shorter than one tile and a ragged last tile.  On "h2" the fused launches run fp16 x 2 split products
+    and the per-sub-block launches float32 MFMAs: the bound then also covers the two arithmetics' rounding (measured 5.1e-6 at worst)."""
+    atol = 5e-6 if gemm == "f32" else 2e-5
     w = weights.marblenet_synthetic(7)
     eng = marblenet.MarbleNetEngine(w)
     assert eng.fused
@@ -125,8 +127,8 @@ def test_fused_blocks_equal_the_per_sub_block_launches():
         r0, r1, rlen = eng.run(clips)
         eng.fused = True
         assert slen == rlen and s1.shape == r1.shape
-        np.testing.assert_allclose(s1.cpu().numpy(), r1.cpu().numpy(), rtol=0, atol=5e-6)
-        np.testing.assert_allclose(s0.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(s1.cpu().numpy(), r1.cpu().numpy(), rtol=0, atol=atol)
+        np.testing.assert_allclose(s0.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=atol)
 
 
 def test_fp16_range_protocol(gemm):

@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vadx  # noqa: E402,F401
-from vadx import firered, fsmn, marblenet, silero, weights  # noqa: E402
+from vadx import dfsmn, firered, fsmn, marblenet, silero, weights  # noqa: E402
 from vadx import timestamps as ts  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "firered"
@@ -29,10 +29,20 @@ elif which == "fsmn":
     W = (rows.shape[1] - 16000) // stride + 1
     big = torch.from_numpy(rows).cuda().repeat(32, 1)                                              # 1024 clips
     fn = lambda: eng.flags(big, W)     # noqa: E731
-else:
+elif which == "dfsmn":
+    eng = dfsmn.DfsmnEngine(weights.dfsmn_synthetic(1234), sub_batch=3072)
+    lb, stride = eng.grid()
+    W = -(-(160000 - eng.L) // stride) + 1
+    n = (W - 1) * stride + eng.L
+    near = torch.from_numpy(weights.burst_clips(32, n, seed=61)).cuda().repeat(4, 1)              # 128 clip pairs = 1920 windows
+    far = torch.from_numpy(weights.burst_clips(32, n, seed=62)).cuda().repeat(4, 1)
+    fn = lambda: eng.run(near, far, W, stride)      # noqa: E731
+elif which == "marblenet":
     eng = marblenet.MarbleNetEngine(weights.marblenet_synthetic(1234))
     big = torch.from_numpy(weights.burst_clips(64, 89431, seed=55)).cuda().repeat(32, 1)          # 2048 clips
     fn = lambda: eng.run(big)          # noqa: E731
+else:
+    raise SystemExit(f"unknown model {which!r}")
 for _ in range(reps):
     fn()
 torch.cuda.synchronize()

@@ -413,12 +413,71 @@ __device__ __forceinline__ void kgemm_h(const KPreH &p, int kdim, const float *a
     }
 }
 
+// ---- AR = 3: the plane form of the fp16 x 2 GEMMs, for the 64-channel blocks (their 40 KB leave room for 12 KB of planes at three
+// workgroups per CU; the 128-channel block sits at 53.2 KB and keeps kgemm_h).  The operand is split ONCE by a transposing pass (item = (8
+// channels, column): eight conflict-free reads, 24 VALU, one 16-byte store per plane) instead of by each of the four row-tile waves, and
+// with no split to share a wave takes a whole K: wave = (row tile, column-tile parity), no partial sums, no barrier inside the GEMM -- the
+// pass's barrier takes its place.  Weights: vadx_frag_h2_host, VADX_H2_K_PLAIN.
+__device__ __forceinline__ void split_rows_to_planes_n(const float *src, int ld, int col0, int kgroups, int ncol, unsigned char *planes, float &amax) {
+    const int pl = kgroups * ncol * 16;
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    for (int it = threadIdx.x; it < kgroups * ncol; it += THREADS) {
+        const int kg = it / ncol, col = it - kg * ncol;
+        f32x4 lo4, hi4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo4[e] = src[(8 * kg + e) * ld + col0 + col]; hi4[e] = src[(8 * kg + 4 + e) * ld + col0 + col]; }
+        u32x2 a0, a1, b0, b1;
+        vadx::split2x4(lo4, a0, a1, amax);
+        vadx::split2x4(hi4, b0, b1, amax);
+        *reinterpret_cast<u32x4_ *>(planes + (kg * ncol + col) * 16) = u32x4_{a0[0], a0[1], b0[0], b0[1]};
+        *reinterpret_cast<u32x4_ *>(planes + pl + (kg * ncol + col) * 16) = u32x4_{a1[0], a1[1], b1[0], b1[1]};
+    }
+}
+__device__ __forceinline__ KPreH kgemm_pre_p(const float *__restrict__ W) {      // K = 64: this wave's row tile, both chunks, both planes
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    asm volatile("" : "+v"(lane), "+v"(wave));
+    const float *base = W + (size_t)((wave & 3) * 2 * 2) * vadx::HFRAG;
+    KPreH p;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) p.w[u][pl] = vadx::ldh(base + (size_t)(u * 2 + pl) * vadx::HFRAG, lane);
+    return p;
+}
+template <int MT>
+__device__ __forceinline__ void pgemm(const KPreH &p, const unsigned char *planes, int ncol, float *dst, int ldd, const float *__restrict__ bias, bool relu) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    asm volatile("" : "+v"(lane), "+v"(wave));
+    const int q = lane >> 4, i = lane & 15, nt = wave & 3, mh = wave >> 2, plb = 8 * ncol * 16;
+    const float b = bias[nt * 16 + i];
+#pragma unroll
+    for (int mt0 = 0; mt0 < MT; mt0 += 2) {
+        const int mt = mt0 + mh;
+        if (mt < MT) {
+            f32x4 hi = {0.f, 0.f, 0.f, 0.f}, mid = hi;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned char *ap = planes + ((4 * u + q) * ncol + mt * 16 + i) * 16;
+                const f16x8 a0 = *reinterpret_cast<const f16x8 *>(ap), a1 = *reinterpret_cast<const f16x8 *>(ap + plb);
+                mid = vadx::mfma_f16(a1, p.w[u][0], mid);
+                hi = vadx::mfma_f16(a0, p.w[u][0], hi);
+                mid = vadx::mfma_f16(a0, p.w[u][1], mid);
+            }
+            f32x4 v = vadx::join2(hi, mid);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] += b; if (relu) v[r] = fmaxf(v[r], 0.f); }
+            *reinterpret_cast<f32x4 *>(dst + (nt * 16 + i) * ldd + mt * 16 + 4 * q) = v;
+        }
+    }
+}
 // AR: 0 = float32 MFMAs (kgemm), 2 = fp16 x 2 split products (kgemm_h); one body for both
 template <int AR> struct KPreOf { typedef KPre type; };
 template <> struct KPreOf<vadx::VADX_AR_H2> { typedef KPreH type; };
+template <> struct KPreOf<3> { typedef KPreH type; };          // 3 = fp16 x 2, plane form (pgemm)
 template <int AR>
 __device__ __forceinline__ typename KPreOf<AR>::type kpre(const float *__restrict__ W, int kdim) {
-    if constexpr (AR == vadx::VADX_AR_H2) return kgemm_pre_h(W, kdim);
+    if constexpr (AR == 3) return kgemm_pre_p(W);
+    else if constexpr (AR == vadx::VADX_AR_H2) return kgemm_pre_h(W, kdim);
     else return kgemm_pre(W, kdim);
 }
 template <int AR, int MT>
@@ -441,6 +500,7 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     const int IN_LD = c.in_ld;
     float *IN = lds, *H1 = IN + c.cinp * IN_LD, *ROUT = H1 + c.c1 * H_LD;
     float *D0 = IN, *D1 = IN, *OUT = H1;
+    unsigned char *PL = reinterpret_cast<unsigned char *>(ROUT + c.c2 * A_LD);      // AR = 3: operand planes [8 k-groups][<= 48 columns][8] x 2
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TILE;
     const float *xb = x + (long long)b * c.cin * c.T;
@@ -471,9 +531,16 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     KP wpw0;
     if (K < 17) wpw0 = kpre<AR>(pw0, c.cinp);
     // residual 1x1 of the block input (frames t0 .. t0 + 31 sit at column 2 PAD), before the input is overwritten
-    kmul<AR, 2>(wres, c.cinp, IN, IN_LD, 2 * PAD, ROUT, A_LD, rb, false, amax);
-    MB_ACC(1);
-    __syncthreads();                // every residual operand is read: depthwise 0 may overwrite IN
+    if constexpr (AR == 3) {
+        split_rows_to_planes_n(IN, IN_LD, 2 * PAD, 8, TILE, PL, amax);
+        __syncthreads();            // (the residual GEMM reads the planes only: depthwise 0 may overwrite IN behind this barrier)
+        pgemm<2>(wres, PL, TILE, ROUT, A_LD, rb, false);
+        MB_ACC(1);
+    } else {
+        kmul<AR, 2>(wres, c.cinp, IN, IN_LD, 2 * PAD, ROUT, A_LD, rb, false, amax);
+        MB_ACC(1);
+        __syncthreads();            // every residual operand is read: depthwise 0 may overwrite IN
+    }
     MB_ACC(7);
     // ---- depthwise 0 IN PLACE: register-window FIR, item = (channel, 8 outputs).  The six items of a channel are six neighbouring
     // lanes of ONE wave: a wave's window reads all precede its writes in program order (the FMAs in between depend on them), and
@@ -506,7 +573,13 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     KP wpw1;                                                 // pointwise 1's weights: in flight through pointwise 0 and depthwise 1
     if (K < 17) wpw1 = kpre<AR>(pw1, c.c1);
     // pointwise 0 + folded BN + ReLU on 48 columns
-    kmul<AR, 3>(wpw0, c.cinp, D0, IN_LD, 0, H1, H_LD, b0, true, amax);
+    if constexpr (AR == 3) {
+        split_rows_to_planes_n(D0, IN_LD, 0, 8, W1, PL, amax);       // (every wave is past the residual GEMM: the barrier behind depthwise 0)
+        __syncthreads();
+        pgemm<3>(wpw0, PL, W1, H1, H_LD, b0, true);
+    } else {
+        kmul<AR, 3>(wpw0, c.cinp, D0, IN_LD, 0, H1, H_LD, b0, true, amax);
+    }
     MB_ACC(3);
     __syncthreads();
     MB_ACC(7);
@@ -537,7 +610,13 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
     MB_ACC(4);
     __syncthreads();                // every H1 read is done: OUT may overwrite it
     MB_ACC(7);
-    kmul<AR, 2>(wpw1, c.c1, D1, A_LD, 0, OUT, A_LD, b1, false, amax);
+    if constexpr (AR == 3) {
+        split_rows_to_planes_n(D1, A_LD, 0, 8, TILE, PL, amax);
+        __syncthreads();
+        pgemm<2>(wpw1, PL, TILE, OUT, A_LD, b1, false);
+    } else {
+        kmul<AR, 2>(wpw1, c.c1, D1, A_LD, 0, OUT, A_LD, b1, false, amax);
+    }
     MB_ACC(5);
     __syncthreads();
     MB_ACC(7);
@@ -547,7 +626,7 @@ __global__ __launch_bounds__(THREADS, 6) void jasper_block2_kernel(
         if (t0 + m < c.T) yb[(long long)ch * c.T + t0 + m] = fmaxf(OUT[ch * A_LD + m] + ROUT[ch * A_LD + m], 0.f);
     }
     MB_ACC(6);
-    if (AR == vadx::VADX_AR_H2 && !(amax <= vadx::H_MAX)) {          // an operand left the fp16 range: the host recomputes this batch on float32
+    if (AR >= vadx::VADX_AR_H2 && !(amax <= vadx::H_MAX)) {          // an operand left the fp16 range: the host recomputes this batch on float32
         atomicOr(range_flag, 1u);
         atomicMax(range_flag + 1, __float_as_uint(amax));
     }
@@ -757,7 +836,8 @@ extern "C" int vadx_marblenet_block2(int cin, int kernel, const float *dw0, cons
     c.in_ld = width + ((4 - width % 8) + 8) % 8;             // smallest row stride >= width with stride % 8 == 4
     const int tiles = (frames + TILE - 1) / TILE;
     VADX_REQUIRE((long long)batch * tiles < (1LL << 31), "vadx_marblenet_block2: too many tiles");
-    const size_t lds = ((size_t)c.cinp * c.in_ld + (size_t)c.c1 * H_LD + (size_t)c.c2 * A_LD) * sizeof(float);
+    const bool planes = ar == vadx::VADX_AR_H2 && cin == 64;      // the plane form (AR = 3): 12 KB more, still three workgroups per CU
+    const size_t lds = ((size_t)c.cinp * c.in_ld + (size_t)c.c1 * H_LD + (size_t)c.c2 * A_LD) * sizeof(float) + (planes ? 2 * 8 * W1 * 16 : 0);
     VADX_REQUIRE(c.cinp * c.in_ld >= c.c1 * A_LD, "vadx_marblenet_block2: the depthwise-1 output does not fit the input region");
 #define BLK2_LAUNCH(KK, AR)                                                                                                    \
     do {                                                                                                                       \
@@ -765,7 +845,11 @@ extern "C" int vadx_marblenet_block2(int cin, int kernel, const float *dw0, cons
         hipLaunchKernelGGL((jasper_block2_kernel<KK, AR>), dim3((unsigned)(batch * tiles)), dim3(THREADS), lds,                \
                            static_cast<hipStream_t>(stream), c, dw0, pw0, b0, dw1, pw1, b1, res_w, res_b, x, y, tiles, flag);   \
     } while (0)
-    if (ar == vadx::VADX_AR_H2) {
+    if (planes) {
+        if (kernel == 13) BLK2_LAUNCH(13, 3);
+        else if (kernel == 15) BLK2_LAUNCH(15, 3);
+        else BLK2_LAUNCH(17, 3);
+    } else if (ar == vadx::VADX_AR_H2) {
         if (kernel == 13) BLK2_LAUNCH(13, 2);
         else if (kernel == 15) BLK2_LAUNCH(15, 2);
         else BLK2_LAUNCH(17, 2);

@@ -76,7 +76,9 @@ class MarbleNetEngine:
                 st = self.stages[k]
                 for name in ("pw", "rw"):
                     host = st[name + "_host"]
-                    frags = None if host is None else _lib.frag_h2(host, _lib.H2_K_QUARTER if 1 <= k < 7 else _lib.H2_K_PLAIN)
+                    # k order: the fused block whose input has 128 channels (stages 1, 2) splits its operand in the GEMM waves (K_QUARTER);
+                    # the 64-channel blocks, the prologue and the tail read operand planes (K_PLAIN)
+                    frags = None if host is None else _lib.frag_h2(host, _lib.H2_K_QUARTER if k in (1, 2) else _lib.H2_K_PLAIN)
                     st[name + "_h"] = None if frags is None else dev(frags)
                     self.h2_ok = self.h2_ok and (host is None or frags is not None)
 
