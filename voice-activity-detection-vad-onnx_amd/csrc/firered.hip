@@ -42,6 +42,8 @@ struct Dev {
     // split-product copies of the point-wise pairs (Hp = 256, Pp = 128 only): A fragments [n-tile][32-k chunk][np planes][QFRAG] of the ONE
     // arithmetic cfg->arithmetic names (split_scheme.h: np = 3 bf16 x 3, 2 fp16 x 2, 0 none = float32 MFMAs)
     int split_ok, arith, np, off_flag, q_fc1, q_fc2, q_bfc1[MAX_R], q_bfc2[MAX_R];
+    // M = 1: the dnn layer (P -> H, ReLU) and the output head (H -> odim, rows padded to Pp with zeros) as one more point-wise pair
+    int q_dnn0, q_head, off_headb;
 };
 
 static int r16(int x) { return (x + 15) & ~15; }
@@ -77,6 +79,7 @@ static int derive(const vadx_firered_cfg *c, Dev *d) {
         d->q_fc1 = take(16 * 3 * np * vadx::QFRAG);                // 80 mels -> 3 chunks of 32 (k-groups 10, 11 are zero rows)
         d->q_fc2 = take(8 * 8 * np * vadx::QFRAG);
         for (int r = 1; r < d->R; ++r) { d->q_bfc1[r] = take(16 * 4 * np * vadx::QFRAG); d->q_bfc2[r] = take(8 * 8 * np * vadx::QFRAG); }
+        if (d->M == 1) { d->q_dnn0 = take(16 * 4 * np * vadx::QFRAG); d->q_head = take(8 * 8 * np * vadx::QFRAG); d->off_headb = take(d->Pp); }
     }
     d->off_flag = take(4);
     d->total = o;
@@ -435,6 +438,22 @@ __global__ __launch_bounds__(THREADS, 2) void firered_kernel(Dev d, const float 
         __syncthreads();
         tk_fir += clock64() - tk_x;
     }
+    // One dnn layer (the published configuration): dnn (P -> H, ReLU) + output head (H -> odim) are one more point-wise pair on split
+    // products -- the head's rows padded to Pp with zeros (as many MFMAs as a block's second layer, at a third of the f32 MFMAs' cost) --
+    // over the whole window at once instead of tile by tile on float32 MFMAs; logits land in p[o][t].
+#ifndef FR_OLD_DNN
+#define FR_OLD_DNN 0        /* development: 1 = the float32 tile-by-tile dnn + head (A/B timing) */
+#endif
+    if (SPLIT && d.M == 1 && !FR_EXP && !FR_OLD_DNN) {
+        pointwise_pair_split<SC, 4>(d, Pk + d.q_dnn0, Pk + d.off_dnnb[0], d.Pp, mem, Pk + d.q_head, Pk + d.off_headb, false, p, h, amax);
+        __syncthreads();
+        for (int e = tid; e < d.odim * d.T; e += THREADS) {
+            const int o = e / d.T, t = e - o * d.T;
+            probs[((size_t)blockIdx.x * d.odim + o) * d.T + t] = sigmoidf_(p[o * M_LD + t]);
+        }
+        if (AR == vadx::VADX_AR_H2) vadx::range_flag_raise(Pk + d.off_flag, amax);
+        return;
+    }
     // dnns (P->H ReLU, then M-1 x H->H ReLU) and the 1x1 output conv + sigmoid, tile by tile
     float *h2 = p;                        // p is dead: second H-tile buffer for M > 1
     const bool dnn_resident = !FR_EXP && d.Hp == 256 && d.Pp == 128 && blockDim.x == 512;
@@ -725,6 +744,11 @@ extern "C" int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_fi
         for (int r = 1; r < d.R; ++r) {
             qmat(d.q_bfc1[r], d.Hp, 4, w->blk_fc1_w[r], d.H, d.P);
             qmat(d.q_bfc2[r], d.Pp, 8, w->blk_fc2_w[r], d.P, d.H);
+        }
+        if (d.M == 1) {
+            qmat(d.q_dnn0, d.Hp, 4, w->dnn_w[0], d.H, d.P);
+            qmat(d.q_head, d.Pp, 8, w->out_w, d.odim, d.H);
+            memcpy(p + d.off_headb, w->out_b, d.odim * sizeof(float));
         }
         VADX_REQUIRE(d.arith != vadx::VADX_AR_H2 || wmax <= vadx::H_MAX,
                      "vadx_firered_pack_host: a weight (|w| up to %g) is outside the fp16 range: pack with cfg->arithmetic = VADX_ARITH_BF16X3", wmax);
