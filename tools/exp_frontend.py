@@ -31,8 +31,8 @@ else:
     from vadx import _lib, frontend, weights
     h = _lib.lib()
     h.vadx_frontend_debug_cycles.argtypes = [C.c_void_p, C.c_int]
-    for preset, n, fold in (("marblenet", 89431, True), ("marblenet", 89431, 4), ("fsmn", 16000, True), ("fsmn", 16000, 4),
-                            ("firered", 16000, True), ("firered", 16000, 4)):
+    for preset, n, fold in (("marblenet", 89431, 5), ("marblenet", 89431, 4), ("fsmn", 16000, 5), ("fsmn", 16000, 4),
+                            ("firered", 16000, 5), ("firered", 16000, 4)):
         fe = frontend.Frontend(preset, n, fold=fold)
         clips = torch.from_numpy(weights.burst_clips(64, n, seed=5)).cuda().repeat(32 if n > 20000 else 256, 1)
         fe.logmel(clips); torch.cuda.synchronize()
@@ -42,7 +42,7 @@ else:
         a.record(); fe.logmel(clips); b.record(); torch.cuda.synchronize()
         h.vadx_frontend_debug_cycles(buf, 0)
         tot = sum(buf[:5])
-        print("%s (%s): %d clips x %d samples, %.2f ms" % (preset, {False: "dense", True: "folded", 4: "split dense"}[fold], clips.shape[0], n, a.elapsed_time(b)))
+        print("%s (%s): %d clips x %d samples, %.2f ms" % (preset, {False: "dense", True: "folded", 4: "bf16 x 3 split products", 5: "fp16 x 2 split products"}[fold], clips.shape[0], n, a.elapsed_time(b)))
         print("   sum of wave-0 clock deltas over workgroups / kernel time: %.1f M ticks per ms" % (tot / 1e6 / a.elapsed_time(b)))
         if buf[6]:
             print("   clock64 / wall_clock64 (100 MHz) over the workgroups: %.1f -> shader clock %.2f GHz" % (buf[5] / buf[6], buf[5] / buf[6] / 10.0))
