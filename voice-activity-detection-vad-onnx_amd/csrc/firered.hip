@@ -100,7 +100,10 @@ __device__ __forceinline__ void fsmn_memory_fast(const Dev &d, const float *__re
     // thread = (channel PAIR, eighth of the window): both channels ride in the two halves of v_pk_fma_f32 operands
     // (twice the f32 FMA rate of the scalar form; the per-channel summation order is unchanged).
     constexpr int LB = 19, LA = 20, SEG = 14, WIN = SEG + LB + LA;
-    const int cp = threadIdx.x >> 3, part = threadIdx.x & 7, ch = 2 * cp;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));       // per call: the clamped indices / in-range predicates below are invariant over the blocks, and hoisted out
+                                        // of the block loop they stayed live through the point-wise pairs and spilled (15 registers, the kernel's scratch)
+    const int cp = tid >> 3, part = tid & 7, ch = 2 * cp;
     if (ch >= d.Pp) return;
     f32x2 c[LB + 1 + LA];                       // c[j + LB], j = -19..20 ; c[LB] (j = 0) unused (zero)
     {   const f32x4 *w0 = reinterpret_cast<const f32x4 *>(Pk + d.off_win[r] + ch * 40), *w1 = w0 + 10;      // merged at pack time
