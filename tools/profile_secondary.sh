@@ -4,6 +4,7 @@
 set -u
 TAG=${1:-r02}; shift
 MODELS=${*:-"fsmn marblenet firered dfsmn"}
+export PASSES=${PASSES:-3}      # passes per rocprofv3 run, after the clock ramp of prof_secondary.py
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 for M in $MODELS; do
@@ -12,7 +13,7 @@ for M in $MODELS; do
   run() {  # name, extra rocprof args...
     local name=$1; shift
     timeout 900 rocprofv3 --kernel-trace --output-format csv "$@" -d "$OUT/$name" -o "$name" -- \
-        python3 tools/prof_secondary.py "$M" 2 > "$OUT/$name.out" 2> "$OUT/$name.err.log"
+        python3 tools/prof_secondary.py "$M" "$PASSES" > "$OUT/$name.out" 2> "$OUT/$name.err.log"
     echo "== $M $name rc=$? $(tail -1 "$OUT/$name.out")"
   }
   run stats --stats
@@ -24,7 +25,7 @@ for M in $MODELS; do
 import csv, glob, os, sys, collections
 csv.field_size_limit(1 << 30)
 out, model = sys.argv[1], sys.argv[2]
-PASSES = 2
+PASSES = int(os.environ.get('PASSES', '3'))
 summ = open(os.path.join(out, "SUMMARY.txt"), "w")
 def p(*a):
     s = " ".join(str(x) for x in a); print(s); summ.write(s + "\n")

@@ -71,6 +71,9 @@ extern "C" int vadx_silero_h2_debug_cycles(unsigned long long *out, int reset) {
 #ifndef H2_DUMP
 #define H2_DUMP 0
 #endif
+#ifndef H2_PK_NATURAL
+#define H2_PK_NATURAL 0
+#endif
 #if H2_DUMP
 __device__ unsigned *h2_dump_ptr;
 extern "C" int vadx_silero_h2_dump(unsigned *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(h2_dump_ptr), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
@@ -307,8 +310,13 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                     //  (four waves per SIMD) shared a CU, while the same binary was bit-exact at one workgroup per CU: tests/probes/h2_race.py,
                     //  DESIGN.md section 4e)
                     float e_, o_;
+#if H2_PK_NATURAL     // development only (tests/probes/pk_hazard.py): the plain-C sums the compiler turns into cross-swizzled v_pk_add_f32
+                    e_ = xa[f][k] + xb[f][k];
+                    o_ = xa[f][k] - xb[f][k];
+#else
                     asm volatile("v_add_f32 %0, %1, %2" : "=v"(e_) : "v"(xa[f][k]), "v"(xb[f][k]));
                     asm volatile("v_sub_f32 %0, %1, %2" : "=v"(o_) : "v"(xa[f][k]), "v"(xb[f][k]));
+#endif
                     ev[k] = e_;
                     ov[k] = o_;
                 }
