@@ -316,6 +316,8 @@ def compact_line(full, detail_path=None):
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                  "vs_baseline", "dtype", "data", "config", "per_gpu_value", "rtf_batch1")}
     line["kernel_ms"] = {k: r4(v) for k, v in full["kernel_ms"].items()}
+    if full.get("ms_per_step_by_arithmetic"):
+        line["ms_per_step_by_arithmetic"] = {k: r4(v) for k, v in full["ms_per_step_by_arithmetic"].items()}
     line["roofline"] = {"bound": ro["bound"], "kernel": ro["kernel"], "achieved": ro["achieved"], "peak": ro["peak"], "unit": ro["unit"],
                         "frac": ro["frac"], "traffic": ro["traffic"], "traffic_unit": ro["traffic_unit"],
                         "algorithmic_bytes_per_launch": ro["algorithmic_bytes_per_launch"], "traffic_ratio": r4(ro["traffic_ratio"]),
@@ -495,7 +497,11 @@ def main(argv=None):
     st = _lib.stream_ptr()
     cfg = eng.cfg()                     # the arithmetic rides with every call (include/vadx.h: vadx_silero_cfg)
 
-    def step(ev=None):
+    flag_w, amax_w = C.c_uint32(0), C.c_float(0.0)
+    guard = eng.mode()
+    range_flags_seen = [0]
+
+    def step(ev=None, cfg=cfg, guarded=(guard == "h2")):
         if ev:
             ev[0].record()
         _lib.check(L.vadx_silero_encode(eng.packed.data_ptr(), audio.data_ptr(), B, SAMPLES, _lib.row_stride(audio),
@@ -510,6 +516,11 @@ def main(argv=None):
                                           counts.data_ptr(), cap, st))
         if ev:
             ev[3].record()
+        if guarded:
+            # the fp16 x 2 arithmetic's range protocol is part of the step, as in SileroEngine._guarded and tests/c/cabi_silero.c: 8 bytes back
+            # + one stream synchronisation per step (the timed step used to skip it)
+            _lib.check(L.vadx_silero_range_flag(eng.packed.data_ptr(), 1, C.byref(flag_w), C.byref(amax_w), st))
+            range_flags_seen[0] += int(flag_w.value != 0)
 
     for _ in range(args.warmup):
         step()
@@ -540,10 +551,30 @@ def main(argv=None):
                  "committed_profile": profiled_launch_ms(enc_kernel_name()) if (B, T) == (CLIPS_PER_GPU, STEPS_PER_CLIP) else None}
     assert int(counts.max().item()) <= cap, "segment table overflow"
     assert bool(torch.isfinite(probs).all())
-    range_flag = eng.range_flag()       # fp16 x 2 kernels: no activation of the timed steps may have left the fp16 range (outside the timed region)
-    assert range_flag[0] == 0, f"fp16 range flag raised during the timed steps: {range_flag}"
+    range_flag = eng.range_flag()       # fp16 x 2 kernels: no activation of the timed steps may have left the fp16 range
+    assert range_flag[0] == 0 and range_flags_seen[0] == 0, f"fp16 range flag raised during the timed steps: {range_flag}, {range_flags_seen}"
     n_seg = int(counts.sum().item())
     probs_resident = probs.clone()
+    # the same step on every arithmetic, same run, same buffers: float32 MFMAs, bf16 x 3 (operands exact to float32's 24
+    # bits, float32's exponent range -- what a flagged batch is recomputed on) and fp16 x 2 with and without its per-step flag read
+    by_arith = {}
+    if not args.dry_run:
+        for name, mode, guarded in (("f32", "f32", False), ("bf16x3", "split", False), ("f16x2", "h2", True), ("f16x2_without_flag_read", "h2", False)):
+            if mode == "h2" and not eng.h2_ok:
+                continue
+            c_ = eng.cfg(mode)
+            for _ in range(2):
+                step(None, c_, guarded)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(args.steps):
+                step(None, c_, guarded)
+            torch.cuda.synchronize()
+            by_arith[name] = (time.perf_counter() - ta) / args.steps * 1e3
+        step(None, cfg, False)          # leave probs / segments as the headline arithmetic computed them
+        torch.cuda.synchronize()
+        assert bool(torch.equal(probs, probs_resident))
+        log("ms/step by arithmetic: " + ", ".join(f"{k} {v:.3f}" for k, v in by_arith.items()))
 
     frames_per_step = world * B * T
     value = frames_per_step * args.steps / elapsed
@@ -651,6 +682,9 @@ def main(argv=None):
                        "parallelism": f"clip-sharded x{world}, no collective"},
             "per_gpu_value": value / world, "rtf_batch1": rtf_b1,
             "kernel_ms": {enc_kernel: enc_ms, rec_kernel: rec_ms, "silero_segments_kernel": seg_ms},
+            "ms_per_step_by_arithmetic": by_arith,
+            "range_protocol": ("the timed step reads vadx_silero_range_flag after its launches (8 B + a stream synchronisation), as every caller of "
+                               "the fp16 x 2 arithmetic does" if enc_mode == "h2" else "none (this arithmetic has float32's exponent range)"),
             "encoder_launch_ms": enc_stats,
             "segments_found": n_seg,
             # achieved = the flops the kernel's algorithm needs (MFMA-issued: folded DFT, no padding taps) / its time;

@@ -141,15 +141,20 @@ def flop_marblenet_out_frame():
     return 2 * (mac + 2 * cin)
 
 
-def flop_marblenet_h2_out_frame():
-    """the part of flop_marblenet_out_frame() that runs as fp16 x 2 split products when the engine's mode is "h2": the 1x1 convs of the
-    three fused residual blocks (pointwise 0 / 1 + the residual branch; csrc/marblenet.hip: kgemm_h)"""
+def flop_marblenet_h2_out_frame(eng=None):
+    """the part of flop_marblenet_out_frame() that runs as fp16 x 2 split products when the engine's mode is "h2": EVERY 1x1 conv of the
+    published layout -- the prologue's point-wise conv, the point-wise + residual convs of the three fused blocks (kgemm_h / pgemm) and both
+    tail blocks (qgemm_group on planes); only the depthwise filters and the two-class decoder stay on the float32 pipes.  With an engine the
+    figure is read off the stage list its launches are fed from (MarbleNetEngine.h2_macs_per_out_frame: the stages that carry `_h`
+    fragments), so the two cannot drift (the prologue and tail, 44 % of these MACs, used to be priced at the f32 peak)."""
+    if eng is not None:
+        return 2 * eng.h2_macs_per_out_frame()
     from vadx import weights
     mac, cin = 0, 80
-    for bi, (filt, rep, _k, _s, _d, residual, _sep) in enumerate(weights.MARBLENET_BLOCKS):
+    for filt, rep, _k, _s, _d, residual, _sep in weights.MARBLENET_BLOCKS:
         block_cin = cin
         for _ in range(rep):
-            mac += cin * filt if residual else 0
+            mac += cin * filt
             cin = filt
         if residual:
             mac += block_cin * filt
@@ -580,9 +585,9 @@ def marblenet_c4(torch, device, reps, cpu, clips=8192, log=lambda m: None, tag="
            "kernel_ms": split, "kernel_calls": calls,
            "roofline": _roof_frontend(clips * T, 257, 400, fe_ms, tag, fold=eng.frontend(n).fold),
            "roofline_net": _roof_mix("marblenet encoder+decoder launches", clips * Tout * flop_marblenet_out_frame(),
-                                     clips * Tout * flop_marblenet_h2_out_frame() if eng.mode() == "h2" else 0.0, net_ms, tag, "vadx::marblenet::",
-                                     note="sum of the encoder / classifier entries in kernel_ms (fused block pairs, single blocks, tail); the fused "
-                                          "blocks' 1x1 convs run on fp16 x 2 split products (priced at 2500 / 3), everything else on f32 MFMAs"),
+                                     clips * Tout * flop_marblenet_h2_out_frame(eng) if eng.mode() == "h2" else 0.0, net_ms, tag, "vadx::marblenet::",
+                                     note="sum of the encoder / classifier entries in kernel_ms (prologue, fused block pairs, tail); every 1x1 conv "
+                                          "runs on fp16 x 2 split products (priced at 2500 / 3), the depthwise filters and the decoder on the f32 pipes"),
            "encoder_arithmetic": eng.mode(), "range_fallbacks": eng.range_fallbacks,
            "hbm": _hbm(clips * (n * 2 + 2 * Tout * 4), ms, tag), "cpu_baseline": None}
     del audio

@@ -37,8 +37,14 @@ extern "C" {
  *    vadx_silero_encoder_mode and vadx_gemm_mode are gone, every Silero launch takes a trailing `const vadx_silero_cfg *`;
  *    VADX_ARITH_F16X2 (fp16 x 2 split products) + vadx_silero_range_flag; the Silero packed blob grew the fp16 fragments;
  *    vadx_sepconv_block / vadx_marblenet_block2 / vadx_marblenet_tail take a trailing `const vadx_marblenet_cfg *` (NULL = float32 MFMAs),
- *    vadx_frag_h2_host / vadx_frag_h2_floats; vadx_dfsmn_lstm_f and vadx_dfsmn_lstm_t_ex take (arithmetic, range_flag) (round 5). */
-#define VADX_ABI_VERSION 6
+ *    vadx_frag_h2_host / vadx_frag_h2_floats; vadx_dfsmn_lstm_f and vadx_dfsmn_lstm_t_ex take (arithmetic, range_flag) (round 5).
+ * 7: no signature changed; three behaviours did (round 6).  (a) VADX_ARITH_AUTO of vadx_fsmn_dims / vadx_firered_cfg is BF16X3 (float32's
+ *    exponent range: nothing for the caller to check); F16X2 is an explicit request there, by callers that read the range flag.  Silero's AUTO
+ *    stays F16X2, and (b) a Silero workgroup whose activations left the fp16 range writes NaN instead of its gate pre-activations, so that the
+ *    scores of those clips are NaN for a caller that never reads vadx_silero_range_flag (tests/c/cabi_silero.c reads it).  (c) The pack_host
+ *    functions rebalance chains of affine layers by exact powers of two when a weight tensor sits outside [2^-10, 2^7) (csrc/rebalance.h) and
+ *    refuse F16X2 for a blob that keeps a weight tensor wholly below 2^-14. */
+#define VADX_ABI_VERSION 7
 
 /* Arithmetic of the products whose one operand is a constant (every weight matrix, every DFT table) -- float32 RESULTS in all of them:
  *   F32     v_mfma_f32_16x16x4_f32 on the float32 operands themselves;
@@ -46,7 +52,8 @@ extern "C" {
  *           accuracy at 6/16 of the matrix time, float32's exponent range;
  *   F16X2   operands represented to one float32 ulp by two round-to-nearest fp16 terms, three v_mfma_f32_16x16x32_f16 per K = 32 step
  *           (csrc/split2.h): float32-class accuracy at 3/16 of the matrix time; activations must stay inside the fp16 range (|x| <= 65504),
- *           which the kernels check (vadx_silero_range_flag);
+ *           which the kernels check (vadx_silero_range_flag / vadx_fsmn_range_flag / vadx_firered_range_flag: the caller reads the flag with
+ *           the results and recomputes a flagged batch on BF16X3 -- the RANGE PROTOCOL; tests/c/cabi_silero.c shows it);
  *   AUTO    the library's default for the entry point (what a zero-initialised cfg selects). */
 #define VADX_ARITH_AUTO   0
 #define VADX_ARITH_F32    1
@@ -74,7 +81,7 @@ typedef struct vadx_silero_weights_host {
 
 /* Per-call configuration of the Silero launches; NULL = all defaults.  Zero-initialise it. */
 typedef struct vadx_silero_cfg {
-    int32_t arithmetic;     /* VADX_ARITH_*: AUTO = F16X2.  The three kernel sets read the same packed blob and write the same workspace, so the
+    int32_t arithmetic;     /* VADX_ARITH_*: AUTO = F16X2 (run the range protocol: vadx_silero_range_flag below).  The three kernel sets read the same packed blob and write the same workspace, so the
                              * encoder and recurrent launches of one batch may even differ.  Replaces nothing in the reference: onnxruntime has
                              * one CPU kernel set. */
     int32_t reserved[3];    /* must be zero */
@@ -170,7 +177,10 @@ int vadx_silero_segments(const float *probs, int batch, int steps, const int64_t
  * range (|x| > 65504), or when the blob cannot run in this mode at all (a weight outside the range, an STFT basis without the DFT
  * symmetries).  This call copies the flag (0 = every result since the last reset is valid) and, when non-zero, the largest magnitude
  * seen to the host (it synchronises `stream`); reset != 0 clears it.  A flagged batch must be recomputed with VADX_ARITH_BF16X3, whose
- * bf16 terms have float32's range (vadx.silero.SileroEngine does so). */
+ * bf16 terms have float32's range (vadx.silero.SileroEngine and tests/c/cabi_silero.c do so).  A caller that skips this does not read
+ * plausible numbers: a flagged workgroup hands the recurrent kernel NaN, and the scores of its clips are NaN from that window on (ABI 7).
+ * The underflow side needs no protocol: pack_host rebalances layers whose weights sit outside [2^-10, 2^7) by exact powers of two
+ * (csrc/rebalance.h) and marks a blob with a weight tensor wholly below 2^-14 as unusable for this arithmetic (flag bit 1 on a launch). */
 int vadx_silero_range_flag(const float *packed, int reset, uint32_t *flag_host, float *amax_host, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -253,9 +263,11 @@ typedef struct vadx_fsmn_dims {          /* FunASR FSMN(input 400, proj 128, lor
     int   input_affine_dim, linear_dim, output_affine_dim, output_dim;   /* external config: 140/250/140/248 */
     int   frames;                         /* T = window_len // 160 + 1 (101) */
     float speech_2_noise_ratio;           /* FSMN/Export_FSMN_VAD.py:34,87-92 */
-    int   arithmetic;                     /* VADX_ARITH_* of the dense layers (0 = AUTO = F16X2).  The packed blob carries the weight fragments of
-                                           * THIS arithmetic only: pass the same dims to vadx_fsmn_pack_host and to every launch.  pack_host
-                                           * refuses F16X2 when a weight lies outside the fp16 range (pack BF16X3 then). */
+    int   arithmetic;                     /* VADX_ARITH_* of the dense layers (0 = AUTO = BF16X3: float32's exponent range, nothing to check; F16X2
+                                           * is for callers that read vadx_fsmn_range_flag with the results and recompute a flagged batch on
+                                           * BF16X3, as vadx.fsmn.FsmnEngine does).  The packed blob carries the weight fragments of THIS
+                                           * arithmetic only: pass the same dims to vadx_fsmn_pack_host and to every launch.  pack_host refuses
+                                           * F16X2 when a weight lies outside the fp16 range (pack BF16X3 then). */
 } vadx_fsmn_dims;
 
 typedef struct vadx_fsmn_weights_host {  /* torch layouts: Linear weight [out][in]; conv_left [128][20] */
@@ -311,8 +323,9 @@ int vadx_fsmn_clips(const vadx_fsmn_dims *dims, const float *packed, const float
 typedef struct vadx_firered_cfg {        /* checkpoint `args` (FireRedVAD/Export_FireRedVAD.py:336-337) */
     int idim, R, M, H, P, N1, S1, N2, S2, odim;
     int frames;                           /* frames per window: (L-400)//160+1 = 98 */
-    int arithmetic;                       /* VADX_ARITH_* of the point-wise layer pairs (0 = AUTO = F16X2 where H = 256, P = 128; float32 MFMAs
-                                           * elsewhere).  As vadx_fsmn_dims.arithmetic: the blob carries the fragments of this arithmetic only. */
+    int arithmetic;                       /* VADX_ARITH_* of the point-wise layer pairs (0 = AUTO = BF16X3 where H = 256, P = 128; float32 MFMAs
+                                           * elsewhere; F16X2 on request, with vadx_firered_range_flag).  As vadx_fsmn_dims.arithmetic: the blob
+                                           * carries the fragments of this arithmetic only. */
 } vadx_firered_cfg;
 
 typedef struct vadx_firered_weights_host {   /* torch layouts, 1x1 convs as [out][in] */

@@ -2,9 +2,13 @@
  * reference's Silero seam (OnnxWrapper / get_speech_timestamps, Silero/modeling_modified/utils_vad.py:116-119,
  * 350-372, 374-476) would do: pack the weights once, upload, run whole clips, segment on the device.
  *
- *   cabi_silero weights.bin audio.bin B N out.bin
- * weights.bin: the float32 tensors of vadx_silero_weights_host in declaration order; audio.bin: f32 [B][N];
+ *   cabi_silero weights.bin audio.bin B N out.bin [gain [unchecked]]
+ * weights.bin: the float32 tensors of vadx_silero_weights_host in declaration order; audio.bin: f32 [B][N] (multiplied by `gain`, default 1);
  * out.bin: probs f32 [B][T] | counts int32 [B] | segments int64 [B][CAP][2].
+ * The default arithmetic of the C ABI (cfg NULL / VADX_ARITH_AUTO = F16X2) has fp16's exponent range, so a caller runs the RANGE PROTOCOL of
+ * include/vadx.h: after the launches, vadx_silero_range_flag (8 bytes + one stream synchronisation); a non-zero flag means some activation
+ * left the fp16 range and the batch is recomputed on VADX_ARITH_BF16X3, whose terms have float32's range.  With a third extra argument
+ * ("unchecked") the client skips the protocol on purpose: the flagged clips' scores must then be NaN, never plausible numbers.
  * Built and driven by tests/test_gpu_cabi_c.py, which compares out.bin with the Python host path bit for bit. */
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
@@ -25,7 +29,9 @@ static float *read_floats(const char *path, size_t n) {
 }
 
 int main(int argc, char **argv) {
-    if (argc != 6) { fprintf(stderr, "usage: %s weights.bin audio.bin B N out.bin\n", argv[0]); return 1; }
+    if (argc < 6 || argc > 8) { fprintf(stderr, "usage: %s weights.bin audio.bin B N out.bin [gain [unchecked]]\n", argv[0]); return 1; }
+    const float gain = argc > 6 ? (float)atof(argv[6]) : 1.0f;
+    const int unchecked = argc > 7;
     const int B = atoi(argv[3]);
     const long long N = atoll(argv[4]);
     const int T = (int)((N + 511) / 512);
@@ -46,6 +52,7 @@ int main(int argc, char **argv) {
     CHECK_VADX(vadx_silero_pack_host(&hw, pk_host));
 
     float *audio_host = read_floats(argv[2], (size_t)B * (size_t)N);
+    for (size_t e = 0; e < (size_t)B * (size_t)N; ++e) audio_host[e] *= gain;
     hipStream_t stream;
     CHECK_HIP(hipStreamCreate(&stream));
     float *pk, *audio, *probs;
@@ -66,8 +73,21 @@ int main(int argc, char **argv) {
     CHECK_HIP(hipMemcpyAsync(audio, audio_host, (size_t)B * N * sizeof(float), hipMemcpyHostToDevice, stream));
     CHECK_HIP(hipMemcpyAsync(lens, lens_host, B * sizeof(int64_t), hipMemcpyHostToDevice, stream));
 
-    /* the two library calls of the hot path, stream-ordered behind the uploads */
+    /* the two library calls of the hot path, stream-ordered behind the uploads; cfg NULL = VADX_ARITH_AUTO = F16X2 ... */
     CHECK_VADX(vadx_silero_clips(pk, audio, B, N, N, probs, NULL, ws, ws_bytes, stream, NULL));
+    /* ... whose range protocol every caller of the default arithmetic runs: flag read (and cleared), recompute on BF16X3 if raised */
+    int fallbacks = 0;
+    if (!unchecked) {
+        uint32_t flag = 0;
+        float amax = 0.f;
+        CHECK_VADX(vadx_silero_range_flag(pk, 1, &flag, &amax, stream));
+        if (flag) {
+            vadx_silero_cfg exact = {VADX_ARITH_BF16X3, {0, 0, 0}};
+            CHECK_VADX(vadx_silero_clips(pk, audio, B, N, N, probs, NULL, ws, ws_bytes, stream, &exact));
+            fallbacks = 1;
+            fprintf(stderr, "range flag %u (largest |activation| %g): batch recomputed on VADX_ARITH_BF16X3\n", flag, (double)amax);
+        }
+    }
     vadx_silero_seg_params prm = {0.5, -1.0, 16000, 250.0, 1e30, 100.0, 30.0, 98.0, 1};
     CHECK_VADX(vadx_silero_segments(probs, B, T, lens, &prm, segs, counts, CAP, stream));
 
@@ -90,6 +110,8 @@ int main(int argc, char **argv) {
     fwrite(counts_host, sizeof(int32_t), B, f);
     fwrite(segs_host, sizeof(int64_t), (size_t)B * CAP * 2, f);
     fclose(f);
-    printf("ok: %d clips x %d windows, first clip %d segments\n", B, T, counts_host[0]);
+    size_t n_nan = 0;
+    for (size_t e = 0; e < (size_t)B * T; ++e) n_nan += probs_host[e] != probs_host[e];
+    printf("ok: %d clips x %d windows, first clip %d segments, range fallbacks %d, NaN scores %zu\n", B, T, counts_host[0], fallbacks, n_nan);
     return 0;
 }

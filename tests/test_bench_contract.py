@@ -49,6 +49,9 @@ def test_secondary_flop_formulas():
     assert bm.flop_fsmn_frame() == 2 * 426960                        # 400-140-250-(128 x4, 20-tap FIR)-140-248
     assert bm.flop_marblenet_out_frame() == 2 * 89456                # published 3x2x64 layout, per 20 ms output frame
     assert bm.flop_firered_frame() == 2 * 585984                     # placeholder dims of SURVEY appendix B
+    # on fp16 x 2 EVERY 1x1 conv of MarbleNet runs as split products: prologue 10240 + fused blocks 20480 + 12288 + 12288 + tail 8192 + 16384
+    # MACs per output frame (the prologue and tail were priced at the f32 peak, which doubled the reported frac)
+    assert bm.flop_marblenet_h2_out_frame() == 2 * 79872 < bm.flop_marblenet_out_frame()
     d = bm.flop_dfsmn_window()
     assert d["total"] == sum(v for k, v in d.items() if k not in ("total", "cfb_front", "cfb_back"))      # the fused kernels regroup pw_conv / dft_f work
     assert d["cfb_front"] + d["cfb_back"] < d["pw_conv"] + d["dft_f"] + d["lstm_f"]
@@ -147,3 +150,78 @@ def test_secondary_workloads_small():
             if key.startswith("roofline") and isinstance(ro, dict):
                 for r in (ro.values() if key == "roofline_by_entry" else [ro]):
                     assert 0 <= r["frac"] <= 1, (key, r)
+
+
+@pytest.mark.gpu
+def test_marblenet_h2_flops_follow_the_launched_fragments():
+    """bench_models prices as fp16 x 2 work exactly the 1x1 convs whose `_h` fragments MarbleNetEngine._run_fused hands to its launches."""
+    sys.path.insert(0, ROOT)
+    import vadx  # noqa: F401
+    import bench_models as bm
+    from vadx import marblenet, weights
+    eng = marblenet.MarbleNetEngine(weights.marblenet_synthetic(1234))
+    assert eng.h2_ok and bm.flop_marblenet_h2_out_frame(eng) == bm.flop_marblenet_h2_out_frame() == 2 * 79872
+
+
+SECONDARY_TAGS = ("fsmn", "marblenet", "firered", "dfsmn")
+# C-ABI entry point (vadx._lib.trace names) -> the kernels it launches on the default arithmetic, as rocprofv3 names them in SUMMARY.txt
+ENTRY_KERNELS = {
+    "fsmn": {"vadx_frontend_logmel": ["frontend_split_kernel<vadx::SchemeH2>"], "vadx_fsmn_clips": ["fsmn_clips_kernel<2>"],
+             "vadx_frontend_window_mean": ["window_mean_kernel"], "vadx_fsmn_energy": ["fsmn_energy_kernel"]},
+    "marblenet": {"vadx_frontend_logmel": ["frontend_split_kernel<vadx::SchemeH2>"], "vadx_sepconv_block": ["sepconv_block_kernel<11, 1, 2, 2>"],
+                  "vadx_marblenet_block2": ["jasper_block2_kernel<13, 2>", "jasper_block2_kernel<15, 3>", "jasper_block2_kernel<17, 3>"],
+                  "vadx_marblenet_tail": ["marblenet_tail_kernel<2>"]},
+    "firered": {"vadx_frontend_logmel": ["frontend_split_kernel<vadx::SchemeH2>"], "vadx_firered_run": ["firered_kernel<2>"]},
+}
+
+
+def _newest_summary(tag):
+    import glob
+    import re
+    paths = glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}", "SUMMARY.txt"))
+    return max(paths, key=lambda p: re.search(r"profiles/r(\d+)([a-z]?)_", p.replace(os.sep, "/")).groups())
+
+
+@pytest.mark.parametrize("tag", SECONDARY_TAGS)
+def test_secondary_traffic_comes_from_the_newest_profile(tag):
+    """BENCH_r05's traffic figures of configs 3 - 5 were round 4's, because the round-5 summaries (reduced batches,
+    tools/prof_model.sh) had no per-pass lines and the reader silently fell back.  The newest profiles/r*_<tag>/SUMMARY.txt must be a
+    BASELINE-size one that the reader accepts, and every kernel the bench looks up by name must be in it."""
+    sys.path.insert(0, ROOT)
+    import vadx  # noqa: F401
+    import bench_models as bm
+    newest = os.path.relpath(_newest_summary(tag), ROOT)
+    tr = bm.profiled_pass_traffic(tag)
+    assert tr is not None and tr["source"] == newest, (tr and tr["source"], newest)
+    text = open(os.path.join(ROOT, newest)).read()
+    assert "BASELINE-size workload" in text.splitlines()[0]
+    for kernels in ENTRY_KERNELS.get(tag, {}).values():
+        for k in kernels:
+            assert k in text, (tag, k)
+            rec = bm.profiled_kernel_traffic(tag, k)
+            assert rec is not None and rec["source"] == newest
+    if tag == "dfsmn":      # looked up by entry-group name in bench_models.dfsmn_c5
+        for k in ("cfb_front", "cfb_back", "lstm_f", "lstm_t", "pw_conv"):
+            rec = bm.profiled_kernel_traffic(tag, k)
+            assert rec is not None and rec["source"] == newest, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", [t for t in SECONDARY_TAGS if t in ENTRY_KERNELS])
+def test_profiled_kernels_are_the_ones_the_bench_pass_launches(tag):
+    """The entry points a bench pass goes through (vadx._lib.trace) are exactly those whose kernels the newest committed summary lists:
+    a renamed or replaced kernel makes the committed traffic figures stale, and this test red."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import vadx  # noqa: F401
+    import bench_models as bm
+    fn = {"fsmn": bm.fsmn_c3, "marblenet": bm.marblenet_c4, "firered": bm.firered_c5}[tag]
+    out = fn(torch, torch.device("cuda", 0), 1, 0, clips=32)
+    assert set(out["kernel_ms"]) == set(ENTRY_KERNELS[tag]), (sorted(out["kernel_ms"]), sorted(ENTRY_KERNELS[tag]))
+    text = open(_newest_summary(tag)).read()
+    for entry, kernels in ENTRY_KERNELS[tag].items():
+        for k in kernels:
+            assert k in text, (entry, k)
+    for key in ("roofline", "roofline_net"):
+        if key in out and out[key].get("traffic_source"):
+            assert out[key]["traffic_source"] == os.path.relpath(_newest_summary(tag), ROOT)

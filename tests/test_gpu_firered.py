@@ -42,6 +42,37 @@ def test_session_matches_reference_fixture(golden, seed):
         sess.run(None, {"audio": g[f"s{seed}_audio"].astype(np.float32)})
 
 
+@pytest.mark.parametrize("a,b", [("fc1", "fc2_w"), ("blk1_fc1", "blk1_fc2_w"), ("blk7_fc1", "blk7_fc2_w"), ("dnn0", "out_w")])
+@pytest.mark.parametrize("shift", [14, -12])
+def test_rescaled_network_and_lsb_audio(gemm, a, b, shift):
+    """layer a (weights and bias) x 2^-shift and the layer behind its ReLU x 2^shift is the same network; pack_host
+    rebalances the pair by exact powers of two (csrc/rebalance.h).  float32 MFMAs and bf16 x 3 return the original network's
+    probabilities bit for bit, fp16 x 2 to 2e-6, on silence, 1 - 3 LSB noise, an LSB-level tone and ordinary bursts; all within the
+    oracle's tolerance."""
+    w0 = weights.firered_synthetic(1234)
+    w1 = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in w0.items()}
+    w1[a + "_w"] = w1[a + "_w"] * np.float32(2.0 ** -shift)
+    w1[a + "_b"] = w1[a + "_b"] * np.float32(2.0 ** -shift)
+    w1[b] = w1[b] * np.float32(2.0 ** shift)
+    rng = np.random.default_rng(31)
+    clips = weights.burst_clips(6, 16000, seed=79)
+    clips[0] = 0
+    clips[1] = rng.integers(-1, 2, 16000)
+    clips[2] = rng.integers(-3, 4, 16000)
+    clips[3] = np.round(2.4 * np.sin(2 * np.pi * 440.0 / 16000 * np.arange(16000)))
+    clips = clips.astype(np.int16)
+    e0, e1 = firered.FireRedEngine(w0), firered.FireRedEngine(w1)
+    p0, p1 = e0.run(T(clips).cuda(), 1), e1.run(T(clips).cuda(), 1)
+    assert e1.blobs.mode() == gemm and e1.blobs.range_fallbacks == 0
+    if gemm in ("f32", "split"):
+        assert torch.equal(p0, p1)
+    else:
+        assert float((p0 - p1).abs().max()) <= 2e-6
+    fe = ofr.Frontend()
+    want = ofr.forward(fe, {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in w0.items()}, T(clips).unsqueeze(1))
+    np.testing.assert_allclose(p1.cpu().numpy().reshape(want.shape), want.numpy(), rtol=0, atol=ATOL)
+
+
 def test_vadpostprocessor_matches_reference(golden):
     g = golden("vadpost")
     n_cases = int(g["n_cases"])

@@ -77,6 +77,70 @@ def test_run_batched_streams_match_oracle():
         assert abs(float(oraw[b, i]) - 1.0) < 2 * ATOL or abs(float(odb[b, i]) - float(noise[b])) < 2 * ATOL
 
 
+def _quiet_and_loud_windows():
+    rng = np.random.default_rng(29)
+    clips = weights.burst_clips(6, 16000, seed=78)
+    clips[0] = 0
+    clips[1] = rng.integers(-1, 2, 16000)
+    clips[2] = rng.integers(-3, 4, 16000)
+    clips[3] = np.round(2.4 * np.sin(2 * np.pi * 440.0 / 16000 * np.arange(16000)))
+    return clips.astype(np.int16)
+
+
+@pytest.mark.parametrize("a,b", [("in1", "in2_w"), ("in2", "l0_lin_w"), ("l0_aff", "l1_lin_w"), ("l3_aff", "out1_w"), ("out1", "out2_w")])
+@pytest.mark.parametrize("shift", [14, -12])
+def test_rescaled_network_and_lsb_audio(gemm, a, b, shift):
+    """layer a (weights and bias) x 2^-shift and the next layer's weights x 2^shift is the same network (only ReLU, the
+    FIR + skip or nothing sits between them).  pack_host rebalances such pairs by exact powers of two (csrc/rebalance.h): float32 MFMAs and
+    bf16 x 3 return the original network's scores and caches bit for bit, fp16 x 2 to 2e-6 -- on windows of silence, 1 - 3 LSB noise, an
+    LSB-level tone and ordinary bursts -- and every arithmetic stays within the score tolerance of the oracle."""
+    w0 = weights.fsmn_synthetic(1234)
+    w1 = {k: np.array(v, copy=True) for k, v in w0.items()}
+    w1[a + "_w"] = w1[a + "_w"] * np.float32(2.0 ** -shift)
+    w1[a + "_b"] = w1[a + "_b"] * np.float32(2.0 ** -shift)
+    w1[b] = w1[b] * np.float32(2.0 ** shift)
+    e0, e1 = fsmn.FsmnEngine(w0), fsmn.FsmnEngine(w1)
+    clips = _quiet_and_loud_windows()
+    B = clips.shape[0]
+    rng = np.random.default_rng(4)
+    caches = [T((rng.standard_normal((B, 128, 19)) * 0.3).astype(np.float32)) for _ in range(4)]
+    noise = rng.uniform(1.0, 1.4, B).astype(np.float32)
+    thr = np.full(B, 1.0, np.float32)
+    s0, c0, _, p0 = e0.run(T(clips), caches, thr, noise, return_psil=True)
+    s1, c1, _, p1 = e1.run(T(clips), caches, thr, noise, return_psil=True)
+    assert e1.blobs.mode() == gemm and e1.blobs.range_fallbacks == 0
+    if gemm in ("f32", "split"):
+        assert torch.equal(p0, p1) and torch.equal(s0, s1) and all(torch.equal(x, y) for x, y in zip(c0, c1))
+    else:
+        assert float((p0 - p1).abs().max()) <= 2e-6
+        for x, y in zip(c0, c1):
+            assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(x.abs().max()))
+    fe = ofs.Frontend()
+    _, _, _, oraw, _ = ofs.forward(fe, {k: T(v) for k, v in w0.items()}, T(clips).unsqueeze(1), [c.unsqueeze(-1) for c in caches], thr, noise,
+                                   return_raw=True)
+    np.testing.assert_allclose(p1.cpu().numpy(), oraw.numpy() / 2, rtol=0, atol=ATOL)
+
+
+def test_tiny_projection_is_refused_for_fp16(gemm):
+    """A block's projection p is the FIR cache the reference's session hands back, so it cannot be carried at another scale: a checkpoint
+    whose lin_0 is x 2^-20 (and aff_0 x 2^20) keeps a weight tensor below the fp16 range after rebalancing -- pack_host refuses fp16 x 2 and
+    the engine runs bf16 x 3, with the oracle's scores."""
+    w0 = weights.fsmn_synthetic(1234)
+    w1 = {k: np.array(v, copy=True) for k, v in w0.items()}
+    w1["l0_lin_w"] = w1["l0_lin_w"] * np.float32(2.0 ** -20)
+    w1["l0_aff_w"] = w1["l0_aff_w"] * np.float32(2.0 ** 20)
+    e1 = fsmn.FsmnEngine(w1)
+    clips = _quiet_and_loud_windows()
+    B = clips.shape[0]
+    caches = [torch.zeros(B, 128, 19) for _ in range(4)]
+    noise, thr = np.full(B, 1.2, np.float32), np.full(B, 1.0, np.float32)
+    _, _, _, p1 = e1.run(T(clips), caches, thr, noise, return_psil=True)
+    assert e1.blobs.mode() == ("split" if gemm == "h2" else gemm)
+    _, _, _, oraw, _ = ofs.forward(ofs.Frontend(), {k: T(v) for k, v in w1.items()}, T(clips).unsqueeze(1), [c.unsqueeze(-1) for c in caches],
+                                   thr, noise, return_raw=True)
+    np.testing.assert_allclose(p1.cpu().numpy(), oraw.numpy() / 2, rtol=0, atol=ATOL)
+
+
 def test_session_named_tensor_contract():
     sess = fsmn.FsmnSession(weights.fsmn_synthetic(1234))
     ins, outs = sess.get_inputs(), sess.get_outputs()

@@ -18,7 +18,12 @@ LIB = os.path.join(HERE, "libvadx.so")
 TEST_HOOKS_SRC = os.path.join(ROOT, "tests", "hip")
 TEST_HOOKS_LIB = os.path.join(TEST_HOOKS_SRC, "libvadx_testhooks.so")
 SOURCES = ["capi.hip", "silero.hip", "silero_split.hip", "silero_h2.hip", "frontend.hip", "fsmn.hip", "firered.hip", "marblenet.hip", "dfsmn.hip", "dfsmn_cfb.hip", "ingest.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: the SLP vectoriser is what turns pairs of scalar float adds / multiplies into v_pk_*_f32 with swizzled sources; the
+# CROSS-swizzled form gives wrong sums inside silero_encode_h2_kernel (profiles/r06_pk_hazard.txt) and is banned from
+# the product (tests/test_cabi_cpu.py::test_no_cross_swizzled_packed_f32_in_product_kernels).  A/B over the five BASELINE configs on one box
+# (tools/ab_noslp.sh, twice each): 4.41 / 4.43 vs 4.41 / 4.46, 46.0 / 46.2 vs 45.6 / 45.4, 12.3 / 12.5 vs 12.2 / 12.4, 15.1 / 15.1 vs 15.1 / 15.4,
+# 2090 / 2106 vs 2098 / 2085 ms -- no difference outside the run-to-run spread.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 
 
 def _headers():

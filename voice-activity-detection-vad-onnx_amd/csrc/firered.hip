@@ -8,6 +8,7 @@
 //   mem [P][T] (block input / FSMN output, updated in place), p [P][T] (FSMN input), h [H][32] tile.
 // Pointwise convs = f32-MFMA GEMMs over 32-frame tiles (weights streamed from L2); the dilated
 // depthwise look-back / look-ahead FIRs + skip run on the VALU over the whole window once per block.
+#include "rebalance.h"
 #include "common.h"
 #include "layers.h"
 #include "split_scheme.h"
@@ -70,8 +71,10 @@ static int derive(const vadx_firered_cfg *c, Dev *d) {
     for (int m = 0; m < d->M; ++m) { d->off_dnn[m] = take(d->Hp * (m == 0 ? d->Pp : d->Hp)); d->off_dnnb[m] = take(d->Hp); }
     d->off_out = take(16 * d->Hp); d->off_outb = take(16);      // output head padded to one 16-row MFMA tile
     d->split_ok = d->Hp == 256 && d->Pp == 128;
-    // AUTO = fp16 x 2 where the split kernel applies, float32 MFMAs otherwise; an explicit split arithmetic elsewhere is refused
-    d->arith = vadx::arith_internal(c->arithmetic, d->split_ok ? vadx::VADX_AR_H2 : vadx::VADX_AR_F32);
+    // AUTO = bf16 x 3 where the split kernel applies (float32's exponent range: safe without the range protocol), float32 MFMAs otherwise;
+    // fp16 x 2 is an explicit request (VADX_ARITH_F16X2) by callers that read vadx_firered_range_flag, as FireRedEngine does; an explicit
+    // split arithmetic elsewhere is refused
+    d->arith = vadx::arith_internal(c->arithmetic, d->split_ok ? vadx::VADX_AR_B3 : vadx::VADX_AR_F32);
     if (d->arith < 0 || (d->arith != vadx::VADX_AR_F32 && !d->split_ok)) return -1;
     d->np = d->arith == vadx::VADX_AR_B3 ? 3 : (d->arith == vadx::VADX_AR_H2 ? 2 : 0);
     if (d->np) {
@@ -686,15 +689,49 @@ extern "C" size_t vadx_firered_packed_floats(const vadx_firered_cfg *cfg) {
     return (size_t)d.total;
 }
 
-extern "C" int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_firered_weights_host *w, float *p) {
+extern "C" int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_firered_weights_host *w_in, float *p) {
     Dev d;
-    VADX_REQUIRE(cfg && w && p, "vadx_firered_pack_host: NULL argument");
+    VADX_REQUIRE(cfg && w_in && p, "vadx_firered_pack_host: NULL argument");
     VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_firered_pack_host: unsupported config (idim 80, H<=256, P<=128, frames<=112, odim<=4)");
     memset(p, 0, sizeof(float) * d.total);
     auto mat = [&](int off, const float *src, int rows, int cols, int ld) {
         for (int r = 0; r < rows; ++r) memcpy(p + off + (size_t)r * ld, src + (size_t)r * cols, cols * sizeof(float));
     };
-    VADX_REQUIRE(w->fc1_w && w->fc1_b && w->fc2_w && w->fc2_b && w->out_w && w->out_b, "vadx_firered_pack_host: NULL weight pointer");
+    VADX_REQUIRE(w_in->fc1_w && w_in->fc1_b && w_in->fc2_w && w_in->fc2_b && w_in->out_w && w_in->out_b, "vadx_firered_pack_host: NULL weight pointer");
+    for (int r = 1; r < d.R; ++r)
+        VADX_REQUIRE(w_in->blk_fc1_w[r] && w_in->blk_fc1_b[r] && w_in->blk_fc2_w[r], "vadx_firered_pack_host: NULL block %d weight", r);
+    for (int m = 0; m < d.M; ++m) VADX_REQUIRE(w_in->dnn_w[m] && w_in->dnn_b[m], "vadx_firered_pack_host: NULL dnn %d weight", m);
+    // Exact power-of-two rebalancing of the point-wise pairs (csrc/rebalance.h; ordinary checkpoints pass through untouched).  The P-wide trunk
+    // carries the skip connections and the streaming caches (caches_in / caches_out of the reference's stream session), so it stays at its true
+    // scale and ends every segment: [fc1, fc2], [blk_fc1_r, blk_fc2_r], [dnn_0 .. dnn_(M-1), out] (sigmoid after out).
+    std::vector<float> r_fc1(w_in->fc1_w, w_in->fc1_w + (size_t)d.H * NMEL), r_fc1b(w_in->fc1_b, w_in->fc1_b + d.H);
+    std::vector<float> r_fc2(w_in->fc2_w, w_in->fc2_w + (size_t)d.P * d.H), r_fc2b(w_in->fc2_b, w_in->fc2_b + d.P);
+    std::vector<float> r_out(w_in->out_w, w_in->out_w + (size_t)d.odim * d.H), r_outb(w_in->out_b, w_in->out_b + d.odim);
+    std::vector<float> r_b1[16], r_b1b[16], r_b2[16], r_dnn[4], r_dnnb[4];
+    int reb_min = 1000;
+    vadx::rebalance_chain({{&r_fc1, &r_fc1b}, {&r_fc2, &r_fc2b}}, &reb_min);
+    vadx_firered_weights_host w_reb = *w_in;
+    w_reb.fc1_w = r_fc1.data(); w_reb.fc1_b = r_fc1b.data(); w_reb.fc2_w = r_fc2.data(); w_reb.fc2_b = r_fc2b.data();
+    for (int r = 1; r < d.R; ++r) {
+        r_b1[r].assign(w_in->blk_fc1_w[r], w_in->blk_fc1_w[r] + (size_t)d.H * d.P);
+        r_b1b[r].assign(w_in->blk_fc1_b[r], w_in->blk_fc1_b[r] + d.H);
+        r_b2[r].assign(w_in->blk_fc2_w[r], w_in->blk_fc2_w[r] + (size_t)d.P * d.H);
+        vadx::rebalance_chain({{&r_b1[r], &r_b1b[r]}, {&r_b2[r], nullptr}}, &reb_min);
+        w_reb.blk_fc1_w[r] = r_b1[r].data(); w_reb.blk_fc1_b[r] = r_b1b[r].data(); w_reb.blk_fc2_w[r] = r_b2[r].data();
+    }
+    {
+        std::vector<vadx::RebLayer> tail;
+        for (int m = 0; m < d.M; ++m) {
+            r_dnn[m].assign(w_in->dnn_w[m], w_in->dnn_w[m] + (size_t)d.H * (m == 0 ? d.P : d.H));
+            r_dnnb[m].assign(w_in->dnn_b[m], w_in->dnn_b[m] + d.H);
+            tail.push_back({&r_dnn[m], &r_dnnb[m]});
+            w_reb.dnn_w[m] = r_dnn[m].data(); w_reb.dnn_b[m] = r_dnnb[m].data();
+        }
+        tail.push_back({&r_out, &r_outb});
+        vadx::rebalance_chain(tail, &reb_min);
+        w_reb.out_w = r_out.data(); w_reb.out_b = r_outb.data();
+    }
+    const vadx_firered_weights_host *w = &w_reb;
     mat(d.off_fc1, w->fc1_w, d.H, NMEL, NMEL); memcpy(p + d.off_fc1b, w->fc1_b, d.H * sizeof(float));
     mat(d.off_fc2, w->fc2_w, d.P, d.H, d.Hp); memcpy(p + d.off_fc2b, w->fc2_b, d.P * sizeof(float));
     for (int r = 0; r < d.R; ++r) {
@@ -755,6 +792,9 @@ extern "C" int vadx_firered_pack_host(const vadx_firered_cfg *cfg, const vadx_fi
         }
         VADX_REQUIRE(d.arith != vadx::VADX_AR_H2 || wmax <= vadx::H_MAX,
                      "vadx_firered_pack_host: a weight (|w| up to %g) is outside the fp16 range: pack with cfg->arithmetic = VADX_ARITH_BF16X3", wmax);
+        VADX_REQUIRE(d.arith != vadx::VADX_AR_H2 || reb_min >= vadx::REB_REFUSE,
+                     "vadx_firered_pack_host: a weight tensor lies wholly below 2^%d (largest |w| < 2^%d after rebalancing), outside the fp16 range: pack "
+                     "with cfg->arithmetic = VADX_ARITH_BF16X3", vadx::REB_REFUSE, reb_min + 1);
     }
     return VADX_OK;
 }

@@ -11,6 +11,7 @@
 // energy gate and the look-ahead vote are VALU/LDS work.  In "clips" mode the workgroup walks the
 // overlapping windows of its clip in order, carrying the four FIR caches (global scratch = the
 // reference's cache_0..3 tensors) and the adaptive noise floor exactly like the reference loop.
+#include "rebalance.h"
 #include "common.h"
 #include "layers.h"
 #include "layers_split.h"
@@ -85,8 +86,10 @@ static int derive(const vadx_fsmn_dims *c, Dev *d) {
     d->off_out2 = take(d->Op * d->A2p); d->off_bo2 = take(d->Op);
     d->nch_A = (d->Ap + 31) / 32; d->nch_L = (d->Lp + 31) / 32; d->nch_A2 = (d->A2p + 31) / 32;
     d->split_ok = d->Ap <= 160 && d->A2p <= 160 && d->Lp <= 256 && d->Op <= 256;
-    // AUTO = fp16 x 2 where the split tile fits, float32 MFMAs otherwise; an explicit split arithmetic on dims outside the tile is refused
-    d->arith = vadx::arith_internal(c->arithmetic, d->split_ok ? vadx::VADX_AR_H2 : vadx::VADX_AR_F32);
+    // AUTO = bf16 x 3 where the split tile fits (float32's exponent range: safe for a caller that never reads the range flag -- the score
+    // gate's uint8 output has no NaN to be poisoned with), float32 MFMAs otherwise; fp16 x 2 is an explicit request (VADX_ARITH_F16X2) by
+    // callers that run the range protocol, as FsmnEngine does; an explicit split arithmetic on dims outside the tile is refused
+    d->arith = vadx::arith_internal(c->arithmetic, d->split_ok ? vadx::VADX_AR_B3 : vadx::VADX_AR_F32);
     if (d->arith < 0 || (d->arith != vadx::VADX_AR_F32 && !d->split_ok)) return -1;
     d->np = d->arith == vadx::VADX_AR_B3 ? 3 : (d->arith == vadx::VADX_AR_H2 ? 2 : 0);
     const int np = d->np;
@@ -671,16 +674,41 @@ extern "C" size_t vadx_fsmn_packed_floats(const vadx_fsmn_dims *dims) {
     return (size_t)d.total;
 }
 
-extern "C" int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_weights_host *w, float *p) {
+extern "C" int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_weights_host *w_in, float *p) {
     Dev d;
-    VADX_REQUIRE(dims && w && p, "vadx_fsmn_pack_host: NULL argument");
+    VADX_REQUIRE(dims && w_in && p, "vadx_fsmn_pack_host: NULL argument");
     VADX_REQUIRE(derive(dims, &d) == 0, "vadx_fsmn_pack_host: unsupported dims (affine <= 144, linear/output <= 256)");
     memset(p, 0, sizeof(float) * d.total);
     auto mat = [&](int off, const float *src, int rows, int cols, int ld) {
         for (int r = 0; r < rows; ++r) memcpy(p + off + (size_t)r * ld, src + (size_t)r * cols, cols * sizeof(float));
     };
-    VADX_REQUIRE(w->in1_w && w->in1_b && w->in2_w && w->in2_b && w->out1_w && w->out1_b && w->out2_w && w->out2_b &&
-                 w->cmvn_means && w->cmvn_vars, "vadx_fsmn_pack_host: NULL weight pointer");
+    VADX_REQUIRE(w_in->in1_w && w_in->in1_b && w_in->in2_w && w_in->in2_b && w_in->out1_w && w_in->out1_b && w_in->out2_w && w_in->out2_b &&
+                 w_in->cmvn_means && w_in->cmvn_vars, "vadx_fsmn_pack_host: NULL weight pointer");
+    for (int l = 0; l < NLAYER; ++l)
+        VADX_REQUIRE(w_in->lin_w[l] && w_in->fir_w[l] && w_in->aff_w[l] && w_in->aff_b[l], "vadx_fsmn_pack_host: NULL layer %d weight", l);
+    // Exact power-of-two rebalancing of the affine chains (csrc/rebalance.h; ordinary checkpoints pass through untouched).  The projection p of
+    // every FSMN block is visible outside the kernels (the FIR caches: cache_0..3 of the reference's session), so it stays at its true scale
+    // and ends a segment: [in1, in2, lin_0], [aff_l, lin_(l+1)], [aff_3, out1, out2] (softmax after out2).  FIR + skip, ReLU and the
+    // activation-free in1 -> in2 / out1 -> out2 pairs are positively homogeneous.
+    std::vector<float> r_in1(w_in->in1_w, w_in->in1_w + (size_t)d.A * 400), r_in1b(w_in->in1_b, w_in->in1_b + d.A);
+    std::vector<float> r_in2(w_in->in2_w, w_in->in2_w + (size_t)d.L * d.A), r_in2b(w_in->in2_b, w_in->in2_b + d.L);
+    std::vector<float> r_out1(w_in->out1_w, w_in->out1_w + (size_t)d.A2 * d.L), r_out1b(w_in->out1_b, w_in->out1_b + d.A2);
+    std::vector<float> r_out2(w_in->out2_w, w_in->out2_w + (size_t)d.O * d.A2), r_out2b(w_in->out2_b, w_in->out2_b + d.O);
+    std::vector<float> r_lin[NLAYER], r_aff[NLAYER], r_affb[NLAYER];
+    for (int l = 0; l < NLAYER; ++l) {
+        r_lin[l].assign(w_in->lin_w[l], w_in->lin_w[l] + (size_t)PROJ * d.L);
+        r_aff[l].assign(w_in->aff_w[l], w_in->aff_w[l] + (size_t)d.L * PROJ);
+        r_affb[l].assign(w_in->aff_b[l], w_in->aff_b[l] + d.L);
+    }
+    int reb_min = 1000;
+    vadx::rebalance_chain({{&r_in1, &r_in1b}, {&r_in2, &r_in2b}, {&r_lin[0], nullptr}}, &reb_min);
+    for (int l = 0; l + 1 < NLAYER; ++l) vadx::rebalance_chain({{&r_aff[l], &r_affb[l]}, {&r_lin[l + 1], nullptr}}, &reb_min);
+    vadx::rebalance_chain({{&r_aff[NLAYER - 1], &r_affb[NLAYER - 1]}, {&r_out1, &r_out1b}, {&r_out2, &r_out2b}}, &reb_min);
+    vadx_fsmn_weights_host w_reb = *w_in;
+    w_reb.in1_w = r_in1.data(); w_reb.in1_b = r_in1b.data(); w_reb.in2_w = r_in2.data(); w_reb.in2_b = r_in2b.data();
+    w_reb.out1_w = r_out1.data(); w_reb.out1_b = r_out1b.data(); w_reb.out2_w = r_out2.data(); w_reb.out2_b = r_out2b.data();
+    for (int l = 0; l < NLAYER; ++l) { w_reb.lin_w[l] = r_lin[l].data(); w_reb.aff_w[l] = r_aff[l].data(); w_reb.aff_b[l] = r_affb[l].data(); }
+    const vadx_fsmn_weights_host *w = &w_reb;
     mat(d.off_in1, w->in1_w, d.A, 400, 400); memcpy(p + d.off_b1, w->in1_b, d.A * sizeof(float));
     memcpy(p + d.off_mean, w->cmvn_means, 400 * sizeof(float)); memcpy(p + d.off_var, w->cmvn_vars, 400 * sizeof(float));
     mat(d.off_in2, w->in2_w, d.L, d.A, d.Ap); memcpy(p + d.off_b2, w->in2_b, d.L * sizeof(float));
@@ -735,6 +763,9 @@ extern "C" int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_w
     qmat(d.q_out2, d.Op, d.nch_A2, [&](int r, int k) { return (r < d.O && k < d.A2) ? w->out2_w[(size_t)r * d.A2 + k] : 0.f; });
     VADX_REQUIRE(d.arith != vadx::VADX_AR_H2 || wmax <= vadx::H_MAX,
                  "vadx_fsmn_pack_host: a weight (|w| up to %g) is outside the fp16 range: pack with dims->arithmetic = VADX_ARITH_BF16X3", wmax);
+    VADX_REQUIRE(d.arith != vadx::VADX_AR_H2 || reb_min >= vadx::REB_REFUSE,
+                 "vadx_fsmn_pack_host: a weight tensor lies wholly below 2^%d (largest |w| < 2^%d after rebalancing), outside the fp16 range: pack with "
+                 "dims->arithmetic = VADX_ARITH_BF16X3", vadx::REB_REFUSE, reb_min + 1);
     return VADX_OK;
 }
 

@@ -11,6 +11,7 @@
 //       in the VGPRs of its 8 waves for all T steps; h is exchanged through double-buffered LDS.
 //   silero_segments_kernel: get_speech_timestamps' state machine, one clip per thread.
 #include "silero_common.h"
+#include "rebalance.h"
 #include "split3.h"
 #include "split2.h"
 
@@ -822,12 +823,25 @@ using vadx::FRAG;
 
 extern "C" size_t vadx_silero_packed_floats(void) { return (size_t)PACKED_FLOATS; }
 
-extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p) {
-    VADX_REQUIRE(w && p, "vadx_silero_pack_host: NULL argument");
-    VADX_REQUIRE(w->stft_basis && w->lstm_w_ih && w->lstm_w_hh && w->lstm_b_ih && w->lstm_b_hh && w->dec_w && w->dec_b,
+extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w_in, float *p) {
+    VADX_REQUIRE(w_in && p, "vadx_silero_pack_host: NULL argument");
+    VADX_REQUIRE(w_in->stft_basis && w_in->lstm_w_ih && w_in->lstm_w_hh && w_in->lstm_b_ih && w_in->lstm_b_hh && w_in->dec_w && w_in->dec_b,
                  "vadx_silero_pack_host: NULL weight pointer");
-    for (int k = 0; k < 4; ++k) VADX_REQUIRE(w->enc_w[k] && w->enc_b[k], "vadx_silero_pack_host: NULL encoder weight %d", k);
+    for (int k = 0; k < 4; ++k) VADX_REQUIRE(w_in->enc_w[k] && w_in->enc_b[k], "vadx_silero_pack_host: NULL encoder weight %d", k);
     memset(p, 0, sizeof(float) * PACKED_FLOATS);
+    // conv1 -> ReLU -> conv2 -> ReLU -> conv3 -> ReLU -> conv4 -> ReLU -> W_ih is one chain of affine layers with only ReLU between them: exact
+    // power-of-two rebalancing (csrc/rebalance.h) when a layer's weights sit outside [2^-10, 2^7); ordinary checkpoints pass through untouched.
+    // gx (b_ih + b_hh, then the LSTM's non-linearities) stays at its true scale: W_ih is the segment's last layer.
+    static const size_t enc_nw[4] = {128 * 129 * 3, 64 * 128 * 3, 64 * 64 * 3, 128 * 64 * 3}, enc_nb[4] = {128, 64, 64, 128};
+    std::vector<float> rw[5], rb[4];
+    for (int k = 0; k < 4; ++k) { rw[k].assign(w_in->enc_w[k], w_in->enc_w[k] + enc_nw[k]); rb[k].assign(w_in->enc_b[k], w_in->enc_b[k] + enc_nb[k]); }
+    rw[4].assign(w_in->lstm_w_ih, w_in->lstm_w_ih + 512 * 128);
+    int reb_min = 1000;
+    vadx::rebalance_chain({{&rw[0], &rb[0]}, {&rw[1], &rb[1]}, {&rw[2], &rb[2]}, {&rw[3], &rb[3]}, {&rw[4], nullptr}}, &reb_min);
+    vadx_silero_weights_host w_reb = *w_in;
+    for (int k = 0; k < 4; ++k) { w_reb.enc_w[k] = rw[k].data(); w_reb.enc_b[k] = rb[k].data(); }
+    w_reb.lstm_w_ih = rw[4].data();
+    const vadx_silero_weights_host *w = &w_reb;
     // STFT basis rows regrouped per wave: [wave][re 16 bins | im 16 bins][256]
     for (int wv = 0; wv < 8; ++wv)
         for (int part = 0; part < 2; ++part)
@@ -1038,7 +1052,13 @@ extern "C" int vadx_silero_pack_host(const vadx_silero_weights_host *w, float *p
                     for (int k = 0; k < 32; ++k) hmax = fmaxf(hmax, vadx::hfrag_put(f2, i, k, w->lstm_w_hh[(size_t)(g * 128 + wv * 16 + i) * 128 + 32 * kc + k]));
             }
     // the fp16 x 2 kernels need the folded STFT pass and every weight inside the fp16 range (NaN fails the comparison too)
-    p[OFF_HFLAG] = (p[OFF_FOLD] != 0.f && hmax <= vadx::H_MAX) ? 1.f : 0.f;
+    // ... and no weight tensor wholly below the smallest normal fp16 once the chain is rebalanced (csrc/rebalance.h)
+    {
+        std::vector<float> whh(w->lstm_w_hh, w->lstm_w_hh + 512 * 128);
+        const int e = vadx::reb_exponent(whh);
+        if (e > -100000 && e < reb_min) reb_min = e;
+    }
+    p[OFF_HFLAG] = (p[OFF_FOLD] != 0.f && hmax <= vadx::H_MAX && reb_min >= vadx::REB_REFUSE) ? 1.f : 0.f;
     return VADX_OK;
 }
 

@@ -74,6 +74,16 @@ extern "C" int vadx_silero_h2_debug_cycles(unsigned long long *out, int reset) {
 #ifndef H2_PK_NATURAL
 #define H2_PK_NATURAL 0
 #endif
+// H2_PRIO: wave priority (s_setprio) inside the GEMM loops, 0 elsewhere: the SIMD's arbiter then prefers the waves that feed the matrix pipe over
+// co-resident waves in their VALU phases
+#ifndef H2_PRIO
+#define H2_PRIO 0
+#endif
+#define H2_PRIO_ON() do { if (H2_PRIO) __builtin_amdgcn_s_setprio(H2_PRIO); } while (0)
+#define H2_PRIO_OFF() do { if (H2_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+// (round 6, measured at config 2, built then removed: H2_PRIO = 1 -- 3.59 -> 3.85 ms, the waves in their VALU phases are starved and reach the
+//  barriers later; the second tile's samples requested at the start of the first tile's conv2 phase instead of in its own staging phase --
+//  3.59 -> 4.35 ms: the 24 registers do not exist beside conv2's, scratch 36 -> 148 B.)
 #if H2_DUMP
 __device__ unsigned *h2_dump_ptr;
 extern "C" int vadx_silero_h2_dump(unsigned *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(h2_dump_ptr), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
@@ -313,6 +323,9 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #if H2_PK_NATURAL     // development only (tests/probes/pk_hazard.py): the plain-C sums the compiler turns into cross-swizzled v_pk_add_f32
                     e_ = xa[f][k] + xb[f][k];
                     o_ = xa[f][k] - xb[f][k];
+#if H2_PK_NATURAL == 2      // ... and nothing may follow the sums for a few cycles
+                    asm volatile("s_nop 7" : "+v"(e_), "+v"(o_));
+#endif
 #else
                     asm volatile("v_add_f32 %0, %1, %2" : "=v"(e_) : "v"(xa[f][k]), "v"(xb[f][k]));
                     asm volatile("v_sub_f32 %0, %1, %2" : "=v"(o_) : "v"(xa[f][k]), "v"(xb[f][k]));
@@ -328,6 +341,10 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                 split2x4(ov, p0, p1, amax);
                 *reinterpret_cast<u32x2 *>(d + 2 * H2_EO_PL) = p0;
                 *reinterpret_cast<u32x2 *>(d + 3 * H2_EO_PL) = p1;
+#if H2_PK_NATURAL == 3       // ... and the samples stay in their registers until the frame's planes are stored (no early reuse of a source register)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) asm volatile("" :: "v"(xa[f][k]), "v"(xb[f][k]));
+#endif
 #if H2_DUMP
                 for (int k = 0; k < 4; ++k) acce_ += (__float_as_uint(ev[k]) * 5u + __float_as_uint(ov[k])) * (unsigned)(2 * (tid * 16 + f * 4 + k) + 1);
                 accr_ += (p0[0] * 3u + p0[1] * 7u + p1[0] * 11u + p1[1] * 13u) * (unsigned)(2 * (tid * 4 + f) + 1);
@@ -363,6 +380,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                     if (H2_XP_ON(0)) { a[s0_][0] = pre_s[s0_][0]; a[s0_][1] = pre_s[s0_][1]; }
                     else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
                 }
+                H2_PRIO_ON();
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {          // s8 = (class, part, chunk) in OFF_HSF's order
                     if (s8 + AH < 8) load_a2(a[(s8 + AH) % (AH + 1)], H2_W(wq + (s8 + AH) * 2 * HF), lane);
@@ -381,6 +399,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
                     for (int fr = 0; fr < 2; ++fr) hi[s8 >> 1][fr] = mfma_f16(ac[0], b[fr][0], hi[s8 >> 1][fr]);
                 }
+                H2_PRIO_OFF();
             }
             f16x8 ab[2][2];                               // the bin-64 piece's two chunks: requested before the magnitudes, used after them
             load_a2(ab[0], H2_W(wb), lane);
@@ -474,6 +493,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
             if (H2_XP_ON(1)) { a[s0_][0] = pre_1[s0_][0]; a[s0_][1] = pre_1[s0_][1]; }
             else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
         }
+        H2_PRIO_ON();
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             f16x8 b[4][2];
@@ -494,6 +514,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #undef H2_TERM
             }
         }
+        H2_PRIO_OFF();
         if (H2_XP_ON(2)) {   // conv2's first two sets
             const float *w2 = P + OFF_H2 + ((wave & 3) * 4 + 2 * (wave >> 2)) * (3 * 2 * HF);
             load_a2(pre_2[0], H2_W(w2), lane);
@@ -532,6 +553,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
             for (int s = 2; s < 6; ++s) load_a2(a[s % RING], H2_W(wq + s * 2 * HF), lane);
         }
+        H2_PRIO_ON();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f16x8 b[4][2];
@@ -551,6 +573,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #undef H2_TERM
             }
         }
+        H2_PRIO_OFF();
         f32x4 s2[2] = {join2(hi[0], mid[0]), join2(hi[1], mid[1])};
         float *exc = reinterpret_cast<float *>(smem + H2_EXC2);
         if (kh == 1) {
@@ -659,6 +682,10 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
             for (int r = 0; r < 4; ++r) y[r] = fmaxf(s[r], 0.f);
             store_h4(smem + H2_C4 + sb * H2_T4, H2_PL4, 4 * rt + q, i, y, amax);
         }
+        // nothing is split after this point: the workgroup's verdict on the fp16 range (one word per wave, read behind the barrier below)
+        const bool bad = !(amax <= H_MAX);
+        if (__ballot(bad) != 0ULL && lane == 0) reinterpret_cast<unsigned *>(scr)[128 + wave] = 1u;
+        else if (lane == 0) reinterpret_cast<unsigned *>(scr)[128 + wave] = 0u;
     }
     __syncthreads();
     H2_MARK(9);
@@ -681,6 +708,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
             if (H2_XP_ON(3)) { a[s0_][0] = pre_ih[s0_][0]; a[s0_][1] = pre_ih[s0_][1]; }
             else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
         }
+        H2_PRIO_ON();
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             f16x8 b[NSUB][2];
@@ -698,17 +726,25 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                 }
             }
         }
+        H2_PRIO_OFF();
 #pragma unroll
         for (int sb = 0; sb < NSUB; ++sb) {
             const long long tile_raw = (long long)blockIdx.x * NSUB + sb;
             const int tile_id = (int)(tile_raw < ntile ? tile_raw : ntile - 1);
             float *dst = gx + ((size_t)(tile_id / G) * Gws + g0 + tile_id % G) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
+            // a workgroup that split anything outside the fp16 range hands the recurrent kernel NaN, not numbers that look like gate
+            // pre-activations: a caller that never reads vadx_silero_range_flag gets NaN scores for these clips, not plausible ones
+            const unsigned *bw = reinterpret_cast<const unsigned *>(scr) + 128;
+            const bool poison = (bw[0] | bw[1] | bw[2] | bw[3] | bw[4] | bw[5] | bw[6] | bw[7]) != 0u;
+            const float qnan = __builtin_nanf("");
             if (tile_raw < ntile)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = join2(hi[sb][g], mid[sb][g]);
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4 *>(dst + g * 256) = poison ? f32x4{qnan, qnan, qnan, qnan} : join2(hi[sb][g], mid[sb][g]);
         }
     }
-    // ---- range check: anything split above the largest finite fp16 (or NaN) raises the blob's sticky flag
+    // ---- range check: anything split above the largest finite fp16 raises the blob's sticky flag.  (A NaN sample does not: v_max3_f32
+    // returns its non-NaN operands, so NaN never reaches amax -- it travels through the products instead.)
     if (!(amax <= H_MAX)) {
         unsigned *fl = reinterpret_cast<unsigned *>(const_cast<float *>(P)) + OFF_HFLAG + 1;
         atomicOr(fl, 1u);
@@ -739,6 +775,12 @@ __global__ __launch_bounds__(512, 2) void silero_lstm_h2_kernel(
     const long long b = (long long)grp * 16 + n;
     const bool bvalid = b < B;
     const int u0 = wave * 16 + 4 * q;             // this lane's 4 hidden units
+    if (ldg1(P + OFF_HFLAG) == 0.f) {   // uniform: this blob cannot run on fp16 x 2 (a weight outside the fp16 range): as the encoder, flag bit 1,
+        if (tid == 0 && grp == 0) atomicOr(reinterpret_cast<unsigned *>(const_cast<float *>(P)) + OFF_HFLAG + 1, 2u);      // and no plausible score
+        if (wave == 0 && lane < 16 && bvalid)
+            for (int t = 0; t < T; ++t) probs[b * probs_stride + t] = __builtin_nanf("");
+        return;
+    }
 
     f16x8 a[4][4][2];
     {
@@ -836,6 +878,16 @@ __global__ __launch_bounds__(512, 2) void silero_lstm_h2_kernel(
         unsigned *fl = reinterpret_cast<unsigned *>(const_cast<float *>(P)) + OFF_HFLAG + 1;
         atomicOr(fl, 1u);
         atomicMax(fl + 1, __float_as_uint(amax));
+    }
+    // ... and then this clip group's scores are NaN, not numbers (cf. the encoder's gx)
+    __syncthreads();
+    if (__ballot(!(amax <= H_MAX)) != 0ULL && lane == 0) reinterpret_cast<unsigned *>(part)[wave] = 1u;
+    else if (lane == 0) reinterpret_cast<unsigned *>(part)[wave] = 0u;
+    __syncthreads();
+    {
+        const unsigned *bw = reinterpret_cast<const unsigned *>(part);
+        if ((bw[0] | bw[1] | bw[2] | bw[3] | bw[4] | bw[5] | bw[6] | bw[7]) != 0u && wave == 0 && lane < 16 && bvalid)
+            for (int t = 0; t < T; ++t) probs[b * probs_stride + t] = __builtin_nanf("");
     }
 }
 

@@ -86,6 +86,17 @@ class MarbleNetEngine:
         m = self.arithmetic or _lib.gemm_mode()
         return "h2" if (m == "h2" and self.h2_ok) else "f32"
 
+    def h2_macs_per_out_frame(self):
+        """Multiply-accumulates per encoder output frame that run as fp16 x 2 split products when mode() is "h2": every 1x1 conv whose
+        `_h` fragments _run_fused hands to a launch (prologue, the fused blocks' point-wise + residual convs, both tail blocks).
+        bench_models.flop_marblenet_h2_out_frame prices exactly this set on the fp16 pipe."""
+        mac = 0
+        for st in self.stages:
+            for name in ("pw", "rw"):
+                if st.get(name + "_h") is not None:
+                    mac += (st["cfg"].cin if name == "pw" else st["cfg"].residual_cin) * st["cfg"].cout
+        return mac
+
     def frontend(self, L):
         if L not in self._fe:
             self._fe[L] = _frontend.Frontend("marblenet", L, device=self.device, in_sample_rate=self.in_sample_rate)
