@@ -125,7 +125,8 @@ def fsmn_c3(torch, device, clips=4096, max_replays=48):
     d = fa != fb
     rows_bad = np.flatnonzero(d.any(axis=1))
     loop = dict(one_minus_speech_threshold=1.0, noise_init_dB=30.0, snr_threshold=10.0)
-    unexc, worst, dscore = 0, 0.0, 0.0
+    # every differing clip must be examined: clips beyond the replay budget count as unexcused
+    unexc, worst, dscore = max(0, len(rows_bad) - max_replays), 0.0, 0.0
     for b in rows_bad[:max_replays]:
         r = _fsmn_first_difference(eng, ref, audio[b].cpu().numpy(), W, stride, eng.L, loop)
         if r is None:            # the per-window replay agrees: the difference came from the vote's own state -- cannot be excused by a score

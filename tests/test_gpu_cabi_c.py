@@ -58,23 +58,23 @@ def _run_client(tmp_path, exe, w, audio, *extra):
 
 def test_plain_c_client_runs_the_range_protocol(tmp_path):
     """the C ABI's default arithmetic (AUTO = F16X2) needs the caller's cooperation -- the example client now gives it.
-    Audio at 3000 x full scale drives an activation beyond 65504: the client reads vadx_silero_range_flag, recomputes on BF16X3 and ends
+    Audio at 100000 x full scale drives an activation beyond 65504: the client reads vadx_silero_range_flag, recomputes on BF16X3 and ends
     with exactly the scores the Python engine's guarded path returns; a client that SKIPS the protocol reads NaN for the flagged clips, never
     plausible numbers (the flagged workgroups poison their gx)."""
     exe = build_c_client(tmp_path)
     w = weights.silero_synthetic(1234)
     B, N = 37, 6000
     audio = weights.burst_clips(B, N, seed=78).astype(np.float32) * np.float32(0.000030517578)
-    audio[16:32] *= np.float32(1.0 / 3000.0)          # the second clip group stays inside the fp16 range after the x 3000 gain
-    probs, out, err = _run_client(tmp_path, exe, w, audio, "3000")
+    audio[16:32] *= np.float32(1.0 / 100000.0)        # the second clip group stays inside the fp16 range after the x 100000 gain
+    probs, out, err = _run_client(tmp_path, exe, w, audio, "100000")
     assert "range fallbacks 1" in out and "recomputed on VADX_ARITH_BF16X3" in err and "NaN scores 0" in out
     eng = silero.SileroEngine(w)
     prev = silero.encoder_mode("h2")
     n0 = eng.range_fallbacks
-    want = eng.clips(torch.from_numpy(audio * np.float32(3000.0)).cuda()).cpu().numpy()
+    want = eng.clips(torch.from_numpy(audio * np.float32(100000.0)).cuda()).cpu().numpy()
     assert eng.range_fallbacks == n0 + 1
     assert np.array_equal(probs, want)
-    bad, out2, _ = _run_client(tmp_path, exe, w, audio, "3000", "unchecked")
+    bad, out2, _ = _run_client(tmp_path, exe, w, audio, "100000", "unchecked")
     assert "range fallbacks 0" in out2
     # a flagged workgroup (two tiles) hands the recurrent kernel NaN: the loud clips end in NaN, NaN never turns back into a number, and every
     # FINITE score the unchecked caller reads is a correct one (an unflagged window on an unpoisoned state)
@@ -82,7 +82,7 @@ def test_plain_c_client_runs_the_range_protocol(tmp_path):
     isn = np.isnan(bad)
     assert (isn[:, 1:] >= isn[:, :-1]).all()
     silero.encoder_mode("split")
-    exact = eng.clips(torch.from_numpy(audio * np.float32(3000.0)).cuda()).cpu().numpy()
+    exact = eng.clips(torch.from_numpy(audio * np.float32(100000.0)).cuda()).cpu().numpy()
     silero.encoder_mode(prev)
     assert np.abs(np.where(isn, 0.0, bad - exact)).max() <= 1e-4
     quiet, out3, _ = _run_client(tmp_path, exe, w, audio)

@@ -27,7 +27,7 @@ def build(ids):
     os.makedirs(EXP, exist_ok=True)
     for n in ids:
         out = os.path.join(EXP, f"libvadx_exp{TAG}{n}.so")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-DVADX_EXP={n}",
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-shared", f"-DVADX_EXP={n}",
                f"-DVADX_SILERO_ENCODER_DEFAULT={MODE}"] + DEFS
         cmd += [os.path.join(PKG, "csrc", s) for s in SRC] + ["-o", out]
         subprocess.check_call(cmd)

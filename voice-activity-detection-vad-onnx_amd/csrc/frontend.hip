@@ -1284,6 +1284,9 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void frontend_split_kernel(
     const int widx = blockIdx.x / tiles, tile = blockIdx.x - widx * tiles;
     const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
     const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
+#if FE_WHATIF & 16      // what-if: every workgroup stages window 0 of clip 0 (L2-warm samples): what a perfect prefetch of the samples could save
+    win = audio;
+#endif
     float *out_win = out + (size_t)widx * d.frames * d.out_stride;
     const float mean = means ? means[widx] : 0.f;
 #if FE_EXP

@@ -79,11 +79,14 @@ extern "C" int vadx_silero_h2_debug_cycles(unsigned long long *out, int reset) {
 #ifndef H2_PRIO
 #define H2_PRIO 0
 #endif
+
 #define H2_PRIO_ON() do { if (H2_PRIO) __builtin_amdgcn_s_setprio(H2_PRIO); } while (0)
 #define H2_PRIO_OFF() do { if (H2_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 // (round 6, measured at config 2, built then removed: H2_PRIO = 1 -- 3.59 -> 3.85 ms, the waves in their VALU phases are starved and reach the
 //  barriers later; the second tile's samples requested at the start of the first tile's conv2 phase instead of in its own staging phase --
-//  3.59 -> 4.35 ms: the 24 registers do not exist beside conv2's, scratch 36 -> 148 B.)
+//  3.59 -> 4.35 ms: the 24 registers do not exist beside conv2's, scratch 36 -> 148 B; a persistent grid of 512 workgroups walking the tile
+//  pairs, the upper half started 0 / 24 000 / 48 000 / 72 000 shader cycles late so that a CU's two workgroups run a fixed fraction of a tile
+//  period apart -- 3.55 -> 3.60 / 3.60 / 3.60 / 3.61 ms: no offset beats the dispatcher's own staggering.)
 #if H2_DUMP
 __device__ unsigned *h2_dump_ptr;
 extern "C" int vadx_silero_h2_dump(unsigned *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(h2_dump_ptr), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         return;
     }
     H2_T0();
+    const long long blk = blockIdx.x;
+    {
     // Cross-phase fragment prefetch: the first sets of a phase's weight stream are requested BEFORE the barrier that ends the phase in front of
     // it (global loads stay in flight across s_barrier, which only waits for lgkmcnt), so the L2 round trip that used to open every phase
     // runs under the previous phase's epilogue.  pre_* = those sets, named per consumer.
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
     // per tile: nothing derived from the thread index is hoisted out of the tile loop (see silero_split.hip)
     // the workgroup's tiles: an odd tile count leaves the last workgroup's last slot without work -- it recomputes the last tile (the
     // barriers are workgroup-wide) and stores nothing
-    const long long tile_raw = (long long)blockIdx.x * NSUB + sub;
+    const long long tile_raw = blk * NSUB + sub;
     const int tile_id = (int)(tile_raw < ntile ? tile_raw : ntile - 1);
     const int grp = tile_id % G, t = tile_id / G;
 
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         H2_PRIO_OFF();
 #pragma unroll
         for (int sb = 0; sb < NSUB; ++sb) {
-            const long long tile_raw = (long long)blockIdx.x * NSUB + sb;
+            const long long tile_raw = blk * NSUB + sb;
             const int tile_id = (int)(tile_raw < ntile ? tile_raw : ntile - 1);
             float *dst = gx + ((size_t)(tile_id / G) * Gws + g0 + tile_id % G) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
             // a workgroup that split anything outside the fp16 range hands the recurrent kernel NaN, not numbers that look like gate
@@ -743,6 +748,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                     *reinterpret_cast<f32x4 *>(dst + g * 256) = poison ? f32x4{qnan, qnan, qnan, qnan} : join2(hi[sb][g], mid[sb][g]);
         }
     }
+    }      // blk
     // ---- range check: anything split above the largest finite fp16 raises the blob's sticky flag.  (A NaN sample does not: v_max3_f32
     // returns its non-NaN operands, so NaN never reaches amax -- it travels through the products instead.)
     if (!(amax <= H_MAX)) {
@@ -790,7 +796,9 @@ __global__ __launch_bounds__(512, 2) void silero_lstm_h2_kernel(
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) load_a2(a[g][kc], wq + (g * 4 + kc) * 2 * HF, lane);
     }
-    const f32x4 dw = ldg4(P + OFF_DW + u0);
+    // the decoder's ReLU as (h + |h|) / 2 with the 1/2 folded into its weights: the same value bit for bit (both scalings are exact), but a NaN
+    // state stays NaN in the score -- fmaxf(h, 0) would turn it into 0 and a poisoned clip (see the encoder's gx) into a plausible number
+    const f32x4 dwh = ldg4(P + OFF_DW + u0) * 0.5f;
     const float db = P[OFF_DB];
 
     float amax = 0.f;
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(512, 2) void silero_lstm_h2_kernel(
             const float gg = gate_tanh(fmaf(mid[2][r], H1_INV, hi[2][r])), og = gate_sigmoid(fmaf(mid[3][r], H1_INV, hi[3][r]));
             c[r] = fg * c[r] + ig * gg;
             h[r] = og * gate_tanh(c[r]);
-            dpart = fmaf(dw[r], fmaxf(h[r], 0.f), dpart);
+            dpart = fmaf(dwh[r], h[r] + __builtin_fabsf(h[r]), dpart);
         }
         const int nxt = cur ^ 1;
         store_h4(smem + nxt * LH_HBUF, LH_HPL, 4 * wave + q, n, h, amax);

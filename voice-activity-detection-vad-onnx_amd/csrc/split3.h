@@ -60,7 +60,12 @@ typedef const __attribute__((address_space(1))) bf16x8 *global_bf16x8_ptr;
 __device__ __forceinline__ bf16x8 ldq(const float *frag, int lane) { return *((global_bf16x8_ptr)(frag) + lane); }
 
 // four float32 values (consecutive k of one column) -> their three planes, four bf16 (8 bytes) each
+// (fp contraction is OFF inside the splits, as in split2.h: with it the multiply that PRODUCED x is folded into the residual -- x - t0 becomes
+//  fma(a, b, -t0) on the unrounded product -- and the planes then encode a value that is not the float32 x the caller also keeps, e.g. the
+//  LSTM state a later launch resumes from.  The SLP vectoriser used to hide this by turning the subtractions into packed adds; the library is
+//  built without it now: tests/test_gpu_silero.py::test_spanned_schedule_is_bitwise_identical[split-*] caught the one-ulp differences.)
 __device__ __forceinline__ void split3x4(const f32x4 x, u32x2 &p0, u32x2 &p1, u32x2 &p2) {
+#pragma clang fp contract(off)
     unsigned xb[4], r1b[4], r2b[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -78,6 +83,7 @@ __device__ __forceinline__ void split3x4(const f32x4 x, u32x2 &p0, u32x2 &p1, u3
 
 // two float32 values (consecutive k of one column) -> their three planes, two bf16 (4 bytes) each
 __device__ __forceinline__ void split3x2(float x0, float x1, unsigned &p0, unsigned &p1, unsigned &p2) {
+#pragma clang fp contract(off)
     const unsigned a = __float_as_uint(x0), b = __float_as_uint(x1);
     const float ra = x0 - __uint_as_float(a & 0xffff0000u), rb = x1 - __uint_as_float(b & 0xffff0000u);
     const unsigned a1 = __float_as_uint(ra), b1 = __float_as_uint(rb);
@@ -89,6 +95,7 @@ __device__ __forceinline__ void split3x2(float x0, float x1, unsigned &p0, unsig
 
 // one float32 value -> its three bf16 terms
 __device__ __forceinline__ void split3x1(float x, unsigned short &h0, unsigned short &h1, unsigned short &h2) {
+#pragma clang fp contract(off)
     const unsigned xb = __float_as_uint(x);
     const float r1 = x - __uint_as_float(xb & 0xffff0000u);
     const unsigned r1b = __float_as_uint(r1);

@@ -211,8 +211,10 @@ class StreamVadPostprocessorBatch:
             self._host = [StreamVadPostprocessor(smooth_window_size, speech_threshold, pad_start_frame, min_speech_frame, max_speech_frame,
                                                  min_silence_frame, frames_per_second) for _ in range(self.streams)]
         self._C = C
-        nbytes = _lib.lib().vadx_stream_vadpost_state_bytes(self.streams)
-        self.state = t.zeros(nbytes, dtype=t.uint8, device=self.device)
+        self.state = None                  # device record of the streams' state; the host path keeps its state in the host objects
+        if self._host is None:
+            nbytes = _lib.lib().vadx_stream_vadpost_state_bytes(self.streams)
+            self.state = t.zeros(nbytes, dtype=t.uint8, device=self.device)
         self._fresh = True
 
     def reset(self):
@@ -223,10 +225,18 @@ class StreamVadPostprocessorBatch:
     def process_batch(self, track, flush=True):
         t, C = self.torch, self._C
         if self._host is not None:
-            tr = track.detach().cpu().numpy() if t.is_tensor(track) else np.asarray(track, dtype=np.float32)
+            tr = track.detach().to(dtype=t.float32).cpu().numpy() if t.is_tensor(track) else np.asarray(track, dtype=np.float32)
             if tr.ndim != 2 or tr.shape[0] != self.streams:
                 raise ValueError(f"track must be [{self.streams}, frames], got {tuple(tr.shape)}")
-            return [h.process_batch(tr[s]) for s, h in enumerate(self._host)]
+            out = []
+            for s_, h in enumerate(self._host):
+                found = h.process_batch(tr[s_])
+                # the reference's class always reports the segment still open after the chunk's last frame; flush=False (as the device path's
+                # flush flag) leaves it to the chunk that ends it
+                if not flush and found and h.last_speech_start_frame > 0:
+                    found = found[:-1]
+                out.append(found)
+            return out
         x = track if t.is_tensor(track) else t.from_numpy(np.ascontiguousarray(track, dtype=np.float32))
         x = x.to(device=self.device, dtype=t.float32)
         if x.dim() != 2 or x.shape[0] != self.streams:
@@ -245,8 +255,10 @@ class StreamVadPostprocessorBatch:
                                                       self.state.data_ptr(), 1 if self._fresh else 0, 1 if flush else 0,
                                                       segs.data_ptr(), counts.data_ptr(), cap, _lib.stream_ptr()))
         self._fresh = False
-        cn, sg = counts.cpu().numpy(), segs.cpu().numpy()
+        cn = counts.cpu().numpy()
         if int(cn.max()) > cap:
             raise _lib.VadxError(f"stream post-processor: {int(cn.max())} segments in one chunk exceed cap={cap}")
+        used = int(cn.max())                # the table is sized for the worst case (one segment per frame); only its used prefix travels
+        sg = segs[:, :used].cpu().numpy() if used else np.zeros((self.streams, 0, 2), np.int32)
         inv_fps = 1.0 / self.frames_per_second
         return [[(int(a) * inv_fps, int(b) * inv_fps) for a, b in sg[s, :cn[s]].tolist()] for s in range(self.streams)]
