@@ -50,6 +50,10 @@
 #define H2_AHI 2      // W_ih (two tiles per workgroup)
 #endif
 #define H2_W(addr) (H2_SKIP(13) ? (P + vadx::silero::OFF_H1) : (addr))
+// bit 15: the SECOND tile of a workgroup takes its conv1 / conv2 fragments from one L1-resident address (bit 12: its STFT fragments too): an upper
+// bound on what sharing those weight streams between the two tiles of a workgroup (one pass over 128 columns) could save
+#define H2_W12(addr) (((H2_SKIP(15) && sub == 1) || H2_SKIP(13)) ? (P + vadx::silero::OFF_H1) : (addr))
+#define H2_WS(addr) (((H2_SKIP(12) && sub == 1) || H2_SKIP(13)) ? (P + vadx::silero::OFF_H1) : (addr))
 #if (VADX_EXP >> 14) & 1
 __device__ unsigned long long h2_dbg[16];
 #define H2_T0() long long h2_t_ = __builtin_readcyclecounter(); const long long h2_c0_ = h2_t_, h2_w0_ = wall_clock64()
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         H2_IDS();
         const float *wq = P + OFF_HSF + (size_t)(wave & 3) * (2 * 2 * 2 * 2 * HF);
 #pragma unroll
-        for (int s0_ = 0; s0_ < H2_AHS; ++s0_) load_a2(pre_s[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+        for (int s0_ = 0; s0_ < H2_AHS; ++s0_) load_a2(pre_s[s0_], H2_WS(wq + s0_ * 2 * HF), lane);
     }
     __syncthreads();
     H2_MARK(0);
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                 H2_PRIO_ON();
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {          // s8 = (class, part, chunk) in OFF_HSF's order
-                    if (s8 + AH < 8) load_a2(a[(s8 + AH) % (AH + 1)], H2_W(wq + (s8 + AH) * 2 * HF), lane);
+                    if (s8 + AH < 8) load_a2(a[(s8 + AH) % (AH + 1)], H2_WS(wq + (s8 + AH) * 2 * HF), lane);
                     f16x8 b[2][2];
 #pragma unroll
                     for (int fr = 0; fr < 2; ++fr) {
@@ -407,12 +411,12 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                 H2_PRIO_OFF();
             }
             f16x8 ab[2][2];                               // the bin-64 piece's two chunks: requested before the magnitudes, used after them
-            load_a2(ab[0], H2_W(wb), lane);
-            load_a2(ab[1], H2_W(wb + 2 * HF), lane);
+            load_a2(ab[0], H2_WS(wb), lane);
+            load_a2(ab[1], H2_WS(wb + 2 * HF), lane);
             if (H2_XP_ON(1)) {   // conv1's first two sets
                 const float *w1 = P + OFF_H1 + wave * (4 * 3 * 2 * HF);
-                load_a2(pre_1[0], H2_W(w1), lane);
-                load_a2(pre_1[1], H2_W(w1 + 2 * HF), lane);
+                load_a2(pre_1[0], H2_W12(w1), lane);
+                load_a2(pre_1[1], H2_W12(w1 + 2 * HF), lane);
             }
 #pragma unroll
             for (int fr = 0; fr < 2; ++fr) {
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const int s = kc * 3 + tap;
-                if (s + AH < 12) load_a2(a[(s + AH) % (AH + 1)], H2_W(wq + (s + AH) * 2 * HF), lane);
+                if (s + AH < 12) load_a2(a[(s + AH) % (AH + 1)], H2_W12(wq + (s + AH) * 2 * HF), lane);
                 const f16x8 (&ac)[2] = a[s % (AH + 1)];
                 // three products per (frame, tap), frames innermost so that consecutive MFMAs hit different accumulators
 #define H2_TERM(AP, BP, ACC)                                                                  \
@@ -522,8 +526,8 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         H2_PRIO_OFF();
         if (H2_XP_ON(2)) {   // conv2's first two sets
             const float *w2 = P + OFF_H2 + ((wave & 3) * 4 + 2 * (wave >> 2)) * (3 * 2 * HF);
-            load_a2(pre_2[0], H2_W(w2), lane);
-            load_a2(pre_2[1], H2_W(w2 + 2 * HF), lane);
+            load_a2(pre_2[0], H2_W12(w2), lane);
+            load_a2(pre_2[1], H2_W12(w2 + 2 * HF), lane);
         }
         __syncthreads();          // every wave is done reading the |X| planes: conv1's output may now overwrite them
         H2_MARK(5);
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         }
         if (RING == 6) {
 #pragma unroll
-            for (int s = 2; s < 6; ++s) load_a2(a[s % RING], H2_W(wq + s * 2 * HF), lane);
+            for (int s = 2; s < 6; ++s) load_a2(a[s % RING], H2_W12(wq + s * 2 * HF), lane);
         }
         H2_PRIO_ON();
 #pragma unroll
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const int s = kk * 3 + tap;
-                if (RING == 3 && s + 2 < 6) load_a2(a[(s + 2) % RING], H2_W(wq + (s + 2) * 2 * HF), lane);
+                if (RING == 3 && s + 2 < 6) load_a2(a[(s + 2) % RING], H2_W12(wq + (s + 2) * 2 * HF), lane);
                 const f16x8 (&ac)[2] = a[s % RING];
 #define H2_TERM(AP, BP, ACC)                                                                  \
     _Pragma("unroll") for (int o = 0; o < 2; ++o) {                                           \
