@@ -819,6 +819,9 @@ __global__ __launch_bounds__(512, 2) void silero_lstm_h2_kernel(
     // gx (the encoder's gate pre-activations, 32 KB per step and workgroup out of HBM: 2.6 GB per launch at config 2 = 4.3 TB/s) is requested
     // LH_GX_AHEAD steps ahead: with one step of lead a lone workgroup ran 1.42 us per step and the full grid 1.95 -- the loaded HBM's
     // latency exceeds a step.  The ring is indexed statically (the step loop is unrolled by its depth).
+// (round 6, measured, removed: gate-major MFMA order -- a gate's twelve products finish before the next gate's start, so that its non-linearity
+//  runs under the next gate's MFMAs, all four B fragment pairs held in registers -- 0.590 -> 0.597 ms with gx two steps ahead, 0.65 with three
+//  (44 B of scratch): the compiler interleaves v_exp / v_rcp with the MFMAs as intended, the step is no shorter.)
 #ifndef LH_GX_AHEAD
 #define LH_GX_AHEAD 3
 #endif
@@ -846,6 +849,7 @@ __global__ __launch_bounds__(512, 2) void silero_lstm_h2_kernel(
             for (int g = 0; g < 4; ++g) gq[j][g] = *reinterpret_cast<const f32x4 *>(gsrc + tn * gstep + g * 256);
         }
         const unsigned char *hb = smem + cur * LH_HBUF;
+        float dpart = 0.f;
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             f16x8 bb[2];
@@ -858,7 +862,6 @@ __global__ __launch_bounds__(512, 2) void silero_lstm_h2_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) hi[g] = mfma_f16(a[g][kc][0], bb[0], hi[g]);
         }
-        float dpart = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float ig = gate_sigmoid(fmaf(mid[0][r], H1_INV, hi[0][r])), fg = gate_sigmoid(fmaf(mid[1][r], H1_INV, hi[1][r]));
