@@ -510,11 +510,11 @@ def main(argv=None):
             ev[1].record()
         _lib.check(L.vadx_silero_recur(eng.packed.data_ptr(), ws.data_ptr(), ws.numel(), B, T, None,
                                        probs.data_ptr(), None, st, cfg))
-        if ev:
+        if ev and len(ev) > 2:
             ev[2].record()
         _lib.check(L.vadx_silero_segments(probs.data_ptr(), B, T, lens.data_ptr(), C.byref(prm), segs.data_ptr(),
                                           counts.data_ptr(), cap, st))
-        if ev:
+        if ev and len(ev) > 2:
             ev[3].record()
         if guarded:
             # the fp16 x 2 arithmetic's range protocol is part of the step, as in SileroEngine._guarded and tests/c/cabi_silero.c: 8 bytes back
@@ -530,7 +530,10 @@ def main(argv=None):
     def fence():
         shard.fence(dist, torch.cuda.synchronize)
 
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    # the timed steps carry the HIP events of the DOMINANT kernel only (roofline.achieved is its mean launch duration over the timed region);
+    # the other two kernels' durations come from an event-bracketed pass right behind it: every event between two launches is a marker the queue
+    # waits on, and with the per-step flag read draining the queue their cost (0.1 - 0.2 ms per step) would sit in the headline
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -541,8 +544,12 @@ def main(argv=None):
 
     log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    rec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
-    seg_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
+    ev4 = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(max(3, min(args.steps, 10)))]
+    for e4 in ev4:
+        step(e4, cfg, False)
+    torch.cuda.synchronize()
+    rec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev4]))
+    seg_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev4]))
     # (the contract's `roofline.achieved` is on the AVERAGE launch duration; the median and the extremes go to the detail file so that a
     #  profile taken on another box can be compared with the middle of this run, not with a mean that one slow launch moved)
     enc_all = sorted(e[0].elapsed_time(e[1]) for e in events)

@@ -59,7 +59,7 @@ static int derive(const vadx_firered_cfg *c, Dev *d) {
     d->odim = c->odim; d->T = c->frames; d->Hp = r16(c->H); d->Pp = r16(c->P);
     if (d->Hp > MAXH || d->Pp > MAXP) return -1;
     int o = 0;
-    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    auto take = [&](int n) { int r = o; o += (n + 255) & ~255; return r; };      // every section on a 1 KiB boundary (a wave's fragment load = 1 KiB = 16 lines)
     d->off_fc1 = take(d->Hp * NMEL); d->off_fc1b = take(d->Hp);
     d->off_fc2 = take(d->Pp * d->Hp); d->off_fc2b = take(d->Pp);
     for (int r = 0; r < d->R; ++r) {

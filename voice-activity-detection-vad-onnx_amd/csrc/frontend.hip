@@ -378,7 +378,7 @@ static int derive(const vadx_frontend_cfg *c, Dev *d) {
         }
         d->s_nch = (c->taps + 31) / 32;
         d->s_nbt = (c->n_bins + 15) / 16;
-        d->off_fold = d->off_mel + d->n_mels * d->Fp;
+        d->off_fold = (d->off_mel + d->n_mels * d->Fp + 255) / 256 * 256;      // fragments on 1 KiB boundaries: a wave's 1 KiB load touches 16 lines, not 17
         d->off_plan = d->off_fold + d->s_nbt * 2 * d->s_nch * d->s_np * vadx::QFRAG;
         d->tiles64 = c->frames / TF_FOLD;
         const int rem64 = c->frames - d->tiles64 * TF_FOLD;

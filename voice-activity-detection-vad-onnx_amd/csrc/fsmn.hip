@@ -75,7 +75,7 @@ static int derive(const vadx_fsmn_dims *c, Dev *d) {
     d->ratio = c->speech_2_noise_ratio;
     if (d->Ap > BUFB_ROWS || d->A2p > BUFB_ROWS || d->Lp > BUFA_ROWS || d->Op > BUFA_ROWS) return -1;
     int o = 0;
-    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    auto take = [&](int n) { int r = o; o += (n + 255) & ~255; return r; };      // every section on a 1 KiB boundary (a wave's fragment load = 1 KiB = 16 lines)
     d->off_in1 = take(d->Ap * 400); d->off_b1 = take(d->Ap); d->off_mean = take(400); d->off_var = take(400);
     d->off_in2 = take(d->Lp * d->Ap); d->off_b2 = take(d->Lp);
     for (int l = 0; l < NLAYER; ++l) {

@@ -40,7 +40,13 @@ constexpr int OFF_FOLD = OFF_B64 + 256 + 4;        // [1] (+3 pad)  1.0 = folded
 // time they save is cheap on this pipe), its input channels in the order the STFT pass leaves them: slot s <= 64 = bin s,
 // slot 64 + k = bin 128 - k (k = 1..63); bin 128 (Nyquist) stays a VALU term.
 constexpr int QF = 256;                                   // = vadx::QFRAG
-constexpr int OFF_Q1 = OFF_FOLD + 4;                      // [8 oc tiles][4 chunks][3 taps][3 planes][QF]
+// (every fragment section below starts on a 1 KiB boundary of the blob -- VADX_FRAG_ALIGN floats; a wave's fragment load is 64 lanes x 16 B =
+//  1 KiB contiguous, and until round 6 the sections sat 48 B past a 64-byte line: every load touched 17 lines instead of 16, every 16-lane quarter
+//  5 instead of 4 -- a quarter more L1 traffic for the kernel whose binding resource turned out to be L1 throughput)
+#ifndef VADX_FRAG_ALIGN
+#define VADX_FRAG_ALIGN 256
+#endif
+constexpr int OFF_Q1 = (OFF_FOLD + 4 + VADX_FRAG_ALIGN - 1) / VADX_FRAG_ALIGN * VADX_FRAG_ALIGN;      // [8 oc tiles][4 chunks][3 taps][3 planes][QF]
 constexpr int OFF_Q1N = OFF_Q1 + 8 * 4 * 3 * 3 * QF;      // [128 oc][4]: taps 0..2 of input channel 128 (+1 pad), f32
 constexpr int OFF_Q2 = OFF_Q1N + 128 * 4;                 // [4 oc tiles][4 chunks][3 taps][3 planes][QF]
 constexpr int OFF_Q3 = OFF_Q2 + 4 * 4 * 3 * 3 * QF;       // [4 oc tiles][2 taps (1, 2)][2 chunks][3 planes][QF]

@@ -52,7 +52,10 @@
 #define H2_W(addr) (H2_SKIP(13) ? (P + vadx::silero::OFF_H1) : (addr))
 // bit 15: the SECOND tile of a workgroup takes its conv1 / conv2 fragments from one L1-resident address (bit 12: its STFT fragments too): an upper
 // bound on what sharing those weight streams between the two tiles of a workgroup (one pass over 128 columns) could save
-#define H2_W12(addr) (((H2_SKIP(15) && sub == 1) || H2_SKIP(13)) ? (P + vadx::silero::OFF_H1) : (addr))
+#define H2_W12(addr) ((((H2_SKIP(15) || H2_SKIP(11)) && sub == 1) || H2_SKIP(13)) ? (P + vadx::silero::OFF_H1) : (addr))
+// bit 11: ... and every lane reads the SAME 16 bytes (one L1 access per load instead of sixteen): what removing those loads altogether -- the
+// second tile multiplying the fragments the first tile's pass already holds -- could save if L1 request throughput is the limit
+#define H2_L12 ((H2_SKIP(11) && sub == 1) ? 0 : lane)
 #define H2_WS(addr) (((H2_SKIP(12) && sub == 1) || H2_SKIP(13)) ? (P + vadx::silero::OFF_H1) : (addr))
 #if (VADX_EXP >> 14) & 1
 __device__ unsigned long long h2_dbg[16];
@@ -77,6 +80,28 @@ extern "C" int vadx_silero_h2_debug_cycles(unsigned long long *out, int reset) {
 #endif
 #ifndef H2_PK_NATURAL
 #define H2_PK_NATURAL 0
+#endif
+// H2_TRACE (development, tools/h2_trace.py): sixteen workgroups spread over the grid record the shader clock of lane 0 of every wave right before
+// and right after each barrier (H2_SYNC(k): marks 2 k, 2 k + 1; the per-tile barriers at + 32 per tile of the workgroup) -- a timeline of
+// where the waves of a workgroup wait, with a few stores per phase as the only perturbation
+#ifndef H2_TRACE
+#define H2_TRACE 0
+#endif
+#ifndef H2_PAIR_T
+#define H2_PAIR_T 1
+#endif
+#if H2_TRACE
+__device__ unsigned long long h2_trace_buf[16][8][128];
+extern "C" int vadx_silero_h2_trace(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(h2_trace_buf), sizeof(unsigned long long) * 16 * 8 * 128) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[16 * 8 * 128]; if (hipMemcpyToSymbol(HIP_SYMBOL(h2_trace_buf), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define H2_TR(m) do { if (h2_tr_slot >= 0 && (threadIdx.x & 63) == 0) h2_trace_buf[h2_tr_slot][threadIdx.x >> 6][(m) + h2_tr_off] = __builtin_readcyclecounter(); } while (0)
+#define H2_SYNC(k) do { H2_TR(2 * (k)); __syncthreads(); H2_TR(2 * (k) + 1); } while (0)
+#else
+#define H2_TR(m) do {} while (0)
+#define H2_SYNC(k) __syncthreads()
 #endif
 // H2_PRIO: wave priority (s_setprio) inside the GEMM loops, 0 elsewhere: the SIMD's arbiter then prefers the waves that feed the matrix pipe over
 // co-resident waves in their VALU phases
@@ -169,6 +194,11 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 
     int tid0 = threadIdx.x;
     const long long ntile = (long long)G * T;
+#if H2_TRACE
+    const int h2_tr_slot = (blockIdx.x % 2503u == 1201u && blockIdx.x / 2503u < 16u) ? (int)(blockIdx.x / 2503u) : -1;
+    int h2_tr_off = 0;
+    H2_TR(126);
+#endif
     float amax = 0.f;                   // running max |x| of everything this thread splits
     if (ldg1(P + OFF_HFLAG) == 0.f) {   // uniform: this blob cannot run on fp16 x 2 (basis without the fold, a weight outside the range)
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(reinterpret_cast<unsigned *>(const_cast<float *>(P)) + OFF_HFLAG + 1, 2u);
@@ -185,9 +215,23 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
     // per tile: nothing derived from the thread index is hoisted out of the tile loop (see silero_split.hip)
     // the workgroup's tiles: an odd tile count leaves the last workgroup's last slot without work -- it recomputes the last tile (the
     // barriers are workgroup-wide) and stores nothing
+    // a workgroup's NSUB tiles are CONSECUTIVE WINDOWS of one clip group (H2_PAIR_T: window t = NSUB * (blk / G) + sub of group blk % G): the
+    // second tile's samples are the next 2 KB of the same sixteen rows -- same pages, same DRAM rows as the loads the first tile has just made --
+    // instead of sixteen rows 10 MB away (adjacent groups of one window, the round-5 order)
+#if H2_PAIR_T
+    const int grp = (int)(blk % G), t_raw = (int)(blk / G) * NSUB + sub;
+    const bool tile_valid = t_raw < T;
+    const int t = tile_valid ? t_raw : T - 1;
+    const int tile_id = t * G + grp;
+    (void)tile_id;
+#else
     const long long tile_raw = blk * NSUB + sub;
     const int tile_id = (int)(tile_raw < ntile ? tile_raw : ntile - 1);
     const int grp = tile_id % G, t = tile_id / G;
+#endif
+#if H2_TRACE
+    h2_tr_off = 32 * sub;
+#endif
 
     // ---------------- phase 0: the 16 windows (576 samples each) + right reflect pad of 64, even / odd samples in separate planes of the
     // clip row (as silero_encode_kernel stages them for the folded pass)
@@ -219,15 +263,19 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                         const f32x4 v = xv[k2][j];
                         *reinterpret_cast<float2 *>(row + 2 * f) = float2{v[0], v[2]};
                         *reinterpret_cast<float2 *>(row + X_ODD + 2 * f) = float2{v[1], v[3]};
-                        if (f >= 127) {                                               // samples 508..575: reflect pad (0, 64)
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) {
-                                const int pp = 4 * f + jj;
-                                if (pp >= 511 && pp <= 574) row[xslot(1150 - pp)] = v[jj];
-                            }
-                        }
                     }
                 }
+                // right reflect pad (0, 64): padded sample 1150 - p = sample p for p = 511 .. 574.  p = 512 + 4 lane + jj sits in the third load of
+                // lanes 0 .. 15 (slot parity = parity of jj, plane index 319 - 2 lane - ...), p = 511 in the second load of lane 63 -- spelled out:
+                // the generic per-element test cost ~40 VALU instructions per clip for sixteen lanes' worth of stores
+                if (lane < 16) {
+                    const f32x4 v = xv[k2][2];
+                    row[319 - 2 * lane] = v[0];
+                    row[X_ODD + 318 - 2 * lane] = v[1];
+                    row[318 - 2 * lane] = v[2];
+                    if (lane < 15) row[X_ODD + 317 - 2 * lane] = v[3];
+                }
+                if (lane == 63) row[X_ODD + 319] = xv[k2][1][3];
             }
         } else {        // edge windows, short clips, groups past the batch: clamped unconditional loads, patched per element
             f32x4 x4[5];
@@ -276,7 +324,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
         for (int s0_ = 0; s0_ < H2_AHS; ++s0_) load_a2(pre_s[s0_], H2_WS(wq + s0_ * 2 * HF), lane);
     }
-    __syncthreads();
+    H2_SYNC(0);
     H2_MARK(0);
 
     // ---------------- phase 1: the folded STFT on split products -> magnitudes -> the two fp16 planes of conv1's input.
@@ -314,7 +362,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                 atomicAdd(h2_dump_ptr + (size_t)tile_id * 4 + 0, acc_);
             }
 #endif
-            __syncthreads();          // every sample is in registers: the operand planes may overwrite X
+            H2_SYNC(1);          // every sample is in registers: the operand planes may overwrite X
             H2_MARK(1);
 #if H2_DUMP
             unsigned accr_ = 0, acce_ = 0;
@@ -363,7 +411,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
             atomicAdd(h2_dump_ptr + (size_t)tile_id * 4 + 2, acce_);
             atomicAdd(h2_dump_ptr + (size_t)tile_id * 4 + 3, accr_);
 #endif
-            __syncthreads();
+            H2_SYNC(2);
             H2_MARK(2);
             H2_SUM(1, 0, 65536);
             // ---- the wave's GEMM: (class, part) = (E re, E im, O re, O im) x two chunks x its two frames
@@ -415,8 +463,8 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
             load_a2(ab[1], H2_WS(wb + 2 * HF), lane);
             if (H2_XP_ON(1)) {   // conv1's first two sets
                 const float *w1 = P + OFF_H1 + wave * (4 * 3 * 2 * HF);
-                load_a2(pre_1[0], H2_W12(w1), lane);
-                load_a2(pre_1[1], H2_W12(w1 + 2 * HF), lane);
+                load_a2(pre_1[0], H2_W12(w1), H2_L12);
+                load_a2(pre_1[1], H2_W12(w1 + 2 * HF), H2_L12);
             }
 #pragma unroll
             for (int fr = 0; fr < 2; ++fr) {
@@ -443,7 +491,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                 b64[fr] = fmaf(bmid[0], H1_INV, bhi[0]);
             }
         }
-        __syncthreads();          // every wave is done reading the operand planes: the |X| planes may overwrite them
+        H2_SYNC(3);          // every wave is done reading the operand planes: the |X| planes may overwrite them
         H2_MARK(3);
         {
             H2_IDS();             // (fresh indices: the store offsets below must not be computed -- and parked -- in front of the GEMM)
@@ -458,7 +506,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                 if (q == 0) b64p[(wave * 2 + fr) * 16 + i] = b64[fr];
             }
         }
-        __syncthreads();
+        H2_SYNC(4);
         if (tid < 64) {                                                       // bin 64: frame tid / 16, clip tid % 16
             const int f = tid >> 4, c = tid & 15;
             const float *pp = b64p + ((f >> 1) * 8 + (f & 1)) * 16 + c;       // waves 4 (f >> 1) + (class, part), part fastest
@@ -466,7 +514,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
             store_h1(smem + f * H2_FR128, H2_PL128, 64, c, mag_sqrt(re * re + im * im), amax);
         }
     }
-    __syncthreads();
+    H2_SYNC(5);
     H2_MARK(4);
 
     // ---------------- phase 2: conv1 129->128, k3 s1 p1, ReLU -- direct: out[f] = sum_tap W[tap] in[f + tap - 1], wave = 16 output channels
@@ -511,7 +559,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const int s = kc * 3 + tap;
-                if (s + AH < 12) load_a2(a[(s + AH) % (AH + 1)], H2_W12(wq + (s + AH) * 2 * HF), lane);
+                if (s + AH < 12) load_a2(a[(s + AH) % (AH + 1)], H2_W12(wq + (s + AH) * 2 * HF), H2_L12);
                 const f16x8 (&ac)[2] = a[s % (AH + 1)];
                 // three products per (frame, tap), frames innermost so that consecutive MFMAs hit different accumulators
 #define H2_TERM(AP, BP, ACC)                                                                  \
@@ -526,10 +574,10 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         H2_PRIO_OFF();
         if (H2_XP_ON(2)) {   // conv2's first two sets
             const float *w2 = P + OFF_H2 + ((wave & 3) * 4 + 2 * (wave >> 2)) * (3 * 2 * HF);
-            load_a2(pre_2[0], H2_W12(w2), lane);
-            load_a2(pre_2[1], H2_W12(w2 + 2 * HF), lane);
+            load_a2(pre_2[0], H2_W12(w2), H2_L12);
+            load_a2(pre_2[1], H2_W12(w2 + 2 * HF), H2_L12);
         }
-        __syncthreads();          // every wave is done reading the |X| planes: conv1's output may now overwrite them
+        H2_SYNC(6);          // every wave is done reading the |X| planes: conv1's output may now overwrite them
         H2_MARK(5);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
@@ -540,7 +588,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
             store_h4(smem + f * H2_FR128, H2_PL128, 4 * rt + q, i, y, amax);
         }
     }
-    __syncthreads();
+    H2_SYNC(7);
     H2_MARK(6);
 
     // ---------------- phase 3: conv2 128->64, k3 s2 p1, ReLU: out frame o reads in frames 2 o - 1 .. 2 o + 1; wave = (16 channels, half of K)
@@ -560,7 +608,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         }
         if (RING == 6) {
 #pragma unroll
-            for (int s = 2; s < 6; ++s) load_a2(a[s % RING], H2_W12(wq + s * 2 * HF), lane);
+            for (int s = 2; s < 6; ++s) load_a2(a[s % RING], H2_W12(wq + s * 2 * HF), H2_L12);
         }
         H2_PRIO_ON();
 #pragma unroll
@@ -571,7 +619,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const int s = kk * 3 + tap;
-                if (RING == 3 && s + 2 < 6) load_a2(a[(s + 2) % RING], H2_W12(wq + (s + 2) * 2 * HF), lane);
+                if (RING == 3 && s + 2 < 6) load_a2(a[(s + 2) % RING], H2_W12(wq + (s + 2) * 2 * HF), H2_L12);
                 const f16x8 (&ac)[2] = a[s % RING];
 #define H2_TERM(AP, BP, ACC)                                                                  \
     _Pragma("unroll") for (int o = 0; o < 2; ++o) {                                           \
@@ -589,7 +637,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
             for (int o = 0; o < 2; ++o) *reinterpret_cast<f32x4 *>(exc + ((rt * 2 + o) * 64 + lane) * 4) = s2[o];
         }
-        __syncthreads();
+        H2_SYNC(8);
         if (kh == 0) {
             const f32x4 bias = ldg4(P + OFF_B2 + 16 * rt + 4 * q);
 #pragma unroll
@@ -602,10 +650,13 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
             }
         }
     }
-    __syncthreads();
+    H2_SYNC(9);
     H2_MARK(7);
     }      // sub
 
+#if H2_TRACE
+    h2_tr_off = 64 - 2 * 10;          // the joint tail's barriers (H2_SYNC(10) ...) land at marks 64 ...
+#endif
     constexpr int AHEAD = NSUB > 1 ? H2_AHI : 3;      // W_ih's stream runs this many steps ahead
     f16x8 pre_3[2][2], pre_4[2][2], pre_ih[AHEAD][2];
     {   H2_IDS();
@@ -640,7 +691,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
             for (int sb = 0; sb < NSUB; ++sb) *reinterpret_cast<f32x4 *>(exc + ((sb * 4 + rt) * 64 + lane) * 4) = join2(hi[sb], mid[sb]);
         }
-        __syncthreads();
+        H2_SYNC(10);
         if (th == 0) {
             const f32x4 bias = ldg4(P + OFF_B3 + 16 * rt + 4 * q);
 #pragma unroll
@@ -653,7 +704,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
             }
         }
     }
-    __syncthreads();
+    H2_SYNC(11);
     H2_MARK(8);
 
     // ---------------- phase 5: conv4 64->128, k3 s1 p1, ReLU (one frame in / out: centre tap only), both tiles
@@ -696,7 +747,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         if (__ballot(bad) != 0ULL && lane == 0) reinterpret_cast<unsigned *>(scr)[128 + wave] = 1u;
         else if (lane == 0) reinterpret_cast<unsigned *>(scr)[128 + wave] = 0u;
     }
-    __syncthreads();
+    H2_SYNC(12);
     H2_MARK(9);
 
     // ---------------- phase 6: LSTM input projection for the workgroup's tiles at once, gate-major (D rows = hidden units
@@ -738,18 +789,29 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         H2_PRIO_OFF();
 #pragma unroll
         for (int sb = 0; sb < NSUB; ++sb) {
+#if H2_PAIR_T
+            const int grp_s = (int)(blk % G), t_s = (int)(blk / G) * NSUB + sb;
+            const long long tile_raw = t_s < T ? 0 : ntile;          // (valid / not, for the test below)
+            float *dst = gx + ((size_t)(t_s < T ? t_s : T - 1) * Gws + g0 + grp_s) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
+#else
             const long long tile_raw = blk * NSUB + sb;
             const int tile_id = (int)(tile_raw < ntile ? tile_raw : ntile - 1);
             float *dst = gx + ((size_t)(tile_id / G) * Gws + g0 + tile_id % G) * GX_TILE_FLOATS + (size_t)wave * 4 * 256 + lane * 4;
+#endif
             // a workgroup that split anything outside the fp16 range hands the recurrent kernel NaN, not numbers that look like gate
             // pre-activations: a caller that never reads vadx_silero_range_flag gets NaN scores for these clips, not plausible ones
             const unsigned *bw = reinterpret_cast<const unsigned *>(scr) + 128;
-            const bool poison = (bw[0] | bw[1] | bw[2] | bw[3] | bw[4] | bw[5] | bw[6] | bw[7]) != 0u;
-            const float qnan = __builtin_nanf("");
-            if (tile_raw < ntile)
+            const bool poison = __builtin_amdgcn_readfirstlane((int)(bw[0] | bw[1] | bw[2] | bw[3] | bw[4] | bw[5] | bw[6] | bw[7])) != 0;
+            if (tile_raw < ntile) {
+                if (!poison) {           // (workgroup-uniform: a branch, not 32 selects)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4 *>(dst + g * 256) = poison ? f32x4{qnan, qnan, qnan, qnan} : join2(hi[sb][g], mid[sb][g]);
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = join2(hi[sb][g], mid[sb][g]);
+                } else {
+                    const float qnan = __builtin_nanf("");
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 256) = f32x4{qnan, qnan, qnan, qnan};
+                }
+            }
         }
     }
     }      // blk
@@ -762,6 +824,10 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
     }
     H2_MARK(10);
     H2_CLK();
+#if H2_TRACE
+    h2_tr_off = 0;
+    H2_TR(127);
+#endif
 }
 
 // ---- persistent LSTM on fp16 x 2 products ------------------------------------------------------
@@ -924,7 +990,7 @@ int silero_encode_h2_launch(const float *packed, const S *src, float in_scale, l
     constexpr int NS = VADX_H2_NSUB;
     constexpr int LDS = (H2_R1 + NS * H2_T2 > 65536 ? H2_R1 + NS * H2_T2 : 65536) + H2_LDS_PAD;
     VADX_DYN_LDS((silero_encode_h2_kernel<S, NS>), LDS);
-    const long long nblk = ((long long)G * steps + NS - 1) / NS;
+    const long long nblk = H2_PAIR_T ? (long long)G * ((steps + NS - 1) / NS) : ((long long)G * steps + NS - 1) / NS;
     hipLaunchKernelGGL((silero_encode_h2_kernel<S, NS>), dim3((unsigned)nblk), dim3(H2_THREADS), LDS, static_cast<hipStream_t>(stream),
                        packed, src, in_scale, n_valid, row_stride, origin, batch, G, steps, Gws, first_group, gx);
     VADX_HIP_TRY(hipGetLastError());

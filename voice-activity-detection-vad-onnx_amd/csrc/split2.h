@@ -81,6 +81,8 @@ __device__ __forceinline__ void split2x4(const f32x4 x, u32x2 &p0, u32x2 &p1, fl
     // (pinned here: nothing reads amax until the kernel's end, so the scheduler otherwise sinks the whole max chain behind the next GEMM and
     //  keeps every x alive for it -- in silero_h2.hip that was 12 spilled registers per thread and 2.3 GB of scratch traffic per launch)
     asm volatile("" : "+v"(amax));
+    // (round 6, measured, not kept: (x - h0) 2^11 as fma(h0, -2^11, x 2^11) with the fp16 -> f32 conversion inside v_fma_mix_f32 -- the same
+    //  bits in 12 instead of 14 VALU instructions per four values -- Silero encoder 3.57 -> 3.76 - 3.81 ms, recurrent kernel 0.577 -> 0.559)
 }
 // one float32 value -> its two fp16 terms
 __device__ __forceinline__ void split2x1(float x, unsigned short &h0, unsigned short &h1, float &amax) {
