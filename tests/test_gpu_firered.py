@@ -153,6 +153,40 @@ def test_full_size_config5_properties():
     print(f"FireRed config-5 pass (incl. host pad/upload): {dt * 1e3:.1f} ms for 2048 x 10 s")
 
 
+_ORACLE_C5 = {}
+
+
+def test_config5_scores_and_segments_against_the_oracle(gemm):
+    """BASELINE config 5 (FireRed half) on the bench's OWN batch (bench_models.synth_pcm16, seed 1505: 2048 unique 10 s clips): 64 clips spread
+    over the batch against oracle.firered.run_clip on the same int16 samples -- scores within 1e-4, segment lists equal unless a smoothed
+    frame sits on the threshold (conftest.chain_or_threshold).  Three arithmetics."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench_models as bm
+    w = weights.firered_synthetic(1234)
+    eng = firered.FireRedEngine(w)
+    audio = bm.synth_pcm16(torch, torch.device("cuda:0"), 2048, 160000, seed=1505).cpu().numpy()
+    got, track, dec = eng.detect(audio, return_probs=True)
+    assert eng.blobs.mode() == gemm and eng.blobs.range_fallbacks == 0
+    idx = [int(k * 32 + (k * 5) % 32) for k in range(64)]
+    if "ref" not in _ORACLE_C5:
+        fe = ofr.Frontend()
+        ow = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in w.items()}
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        _ORACLE_C5["ref"] = [ofr.run_clip(fe, ow, audio[b], np.zeros(10)) for b in idx]
+    full = 0
+    for b, (want_seg, want_p, want_dec) in zip(idx, _ORACLE_C5["ref"]):
+        tr = track[b].cpu().numpy()
+        assert tr.shape[0] == want_p.shape[0]
+        np.testing.assert_allclose(tr, want_p, rtol=0, atol=ATOL)
+        d2 = opp.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0).process(tr)          # the oracle's post-processor on the DEVICE scores
+        assert np.array_equal(dec[b].cpu().numpy(), d2)
+        if chain_or_threshold(opp.VadPostprocessor(5, 0.4, 20, 2000, 20, 5, 0), tr, want_p, d2, want_dec, got[b], want_seg):
+            full += 1
+            assert [(int(s * 16000), int(e * 16000)) for s, e in got[b]] == [(int(s * 16000), int(e * 16000)) for s, e in want_seg]
+    assert full >= len(idx) - 2, full
+
+
 # ------------------------------------------------------------------ Stream-VAD (cache-carrying chunk kernel)
 STREAM_CFGS = {1234: dict(weights.FIRERED_CFG, N2=0, S2=0),
                7: dict(weights.FIRERED_CFG, R=3, M=2, H=64, P=32, N1=8, S1=2, N2=0, S2=0)}

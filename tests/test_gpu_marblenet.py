@@ -111,6 +111,40 @@ def test_full_size_config4_properties():
     print(f"MarbleNet config-4 pass: {dt * 1e3:.1f} ms for 8192 x 5.59 s ({8192 * 89431 / 512 / dt / 1e6:.1f} M 512-hop frames/s)")
 
 
+_ORACLE_C4 = {}
+
+
+def test_config4_scores_and_segments_against_the_oracle(gemm):
+    """BASELINE config 4 on the bench's OWN batch (bench_models.synth_pcm16, seed 1404: 8192 unique clips of 89 431 samples, one dynamic-axis
+    window each): 64 clips spread over the batch against oracle.marblenet.run_clip on the same int16 samples -- scores within 1e-4, device
+    decisions == the oracle post-processor on the device scores, segment lists equal unless a smoothed frame sits on the threshold."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench_models as bm
+    post = (3, 0.5, 10, 1000, 10, 3, 0)
+    w = weights.marblenet_synthetic(1234)
+    eng = marblenet.MarbleNetEngine(w)
+    audio = bm.synth_pcm16(torch, torch.device("cuda:0"), 8192, 89431, seed=1404).cpu().numpy()
+    got, track, dec = eng.detect(audio, window_len=None, return_probs=True)
+    assert eng.mode() == ("h2" if gemm == "h2" else "f32") and eng.range_fallbacks == 0
+    idx = [int(k * 128 + (k * 11) % 128) for k in range(64)]
+    if "ref" not in _ORACLE_C4:
+        fe = omb.Frontend()
+        ow = {k: T(v) for k, v in w.items()}
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        _ORACLE_C4["ref"] = [omb.run_clip(fe, ow, audio[b], window=None, pad_noise=None) for b in idx]
+    full = 0
+    for b, (want_seg, want_p, want_dec) in zip(idx, _ORACLE_C4["ref"]):
+        tr = track[b].cpu().numpy()
+        assert tr.shape[0] == want_p.shape[0]
+        np.testing.assert_allclose(tr, want_p, rtol=0, atol=ATOL)
+        opost = opp.VadPostprocessor(*post, frame_shift_s=0.02, frame_length_s=None)
+        d2 = opost.process(tr)
+        assert np.array_equal(dec[b].cpu().numpy(), d2)
+        full += chain_or_threshold(opost, tr, want_p, d2, want_dec, got[b], want_seg)
+    assert full >= len(idx) - 2, full
+
+
 def test_fused_blocks_equal_the_per_sub_block_launches(gemm):
     """The fused residual-block / tail kernels against the ten per-sub-block launches they replace (same FIR order per element;
     the fused blocks sum each 1x1 conv's K in two halves, the per-sub-block launches in one run: scores agree to float32
