@@ -55,7 +55,9 @@
 #define H2_W12(addr) ((((H2_SKIP(15) || H2_SKIP(11)) && sub == 1) || H2_SKIP(13)) ? (P + vadx::silero::OFF_H1) : (addr))
 // bit 11: ... and every lane reads the SAME 16 bytes (one L1 access per load instead of sixteen): what removing those loads altogether -- the
 // second tile multiplying the fragments the first tile's pass already holds -- could save if L1 request throughput is the limit
-#define H2_L12 ((H2_SKIP(11) && sub == 1) ? 0 : lane)
+#define H2_L12 (((H2_SKIP(11) && sub == 1) || H2_SKIP(10)) ? 0 : lane)
+// bit 10: EVERY fragment load reads one 16-byte piece (all lanes the same address): the kernel without its L1 request stream
+#define H2_LN (H2_SKIP(10) ? 0 : lane)
 #define H2_WS(addr) (((H2_SKIP(12) && sub == 1) || H2_SKIP(13)) ? (P + vadx::silero::OFF_H1) : (addr))
 #if (VADX_EXP >> 14) & 1
 __device__ unsigned long long h2_dbg[16];
@@ -174,7 +176,7 @@ __device__ __forceinline__ void load_b2(f16x8 (&b)[2], const unsigned char *base
     b[1] = *reinterpret_cast<const f16x8 *>(s + plane_stride);
 }
 __device__ __forceinline__ void load_a2(f16x8 (&a)[2], const float *frag2, int lane) {
-    a[0] = ldh(frag2, lane);
+    a[0] = ldh(frag2, H2_LN);
     a[1] = ldh(frag2 + HF, lane);
 }
 
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         H2_IDS();
         const float *wq = P + OFF_HSF + (size_t)(wave & 3) * (2 * 2 * 2 * 2 * HF);
 #pragma unroll
-        for (int s0_ = 0; s0_ < H2_AHS; ++s0_) load_a2(pre_s[s0_], H2_WS(wq + s0_ * 2 * HF), lane);
+        for (int s0_ = 0; s0_ < H2_AHS; ++s0_) load_a2(pre_s[s0_], H2_WS(wq + s0_ * 2 * HF), H2_LN);
     }
     H2_SYNC(0);
     H2_MARK(0);
@@ -435,12 +437,12 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
                 for (int s0_ = 0; s0_ < AH; ++s0_) {
                     if (H2_XP_ON(0)) { a[s0_][0] = pre_s[s0_][0]; a[s0_][1] = pre_s[s0_][1]; }
-                    else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+                    else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), H2_LN);
                 }
                 H2_PRIO_ON();
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {          // s8 = (class, part, chunk) in OFF_HSF's order
-                    if (s8 + AH < 8) load_a2(a[(s8 + AH) % (AH + 1)], H2_WS(wq + (s8 + AH) * 2 * HF), lane);
+                    if (s8 + AH < 8) load_a2(a[(s8 + AH) % (AH + 1)], H2_WS(wq + (s8 + AH) * 2 * HF), H2_LN);
                     f16x8 b[2][2];
 #pragma unroll
                     for (int fr = 0; fr < 2; ++fr) {
@@ -459,8 +461,8 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                 H2_PRIO_OFF();
             }
             f16x8 ab[2][2];                               // the bin-64 piece's two chunks: requested before the magnitudes, used after them
-            load_a2(ab[0], H2_WS(wb), lane);
-            load_a2(ab[1], H2_WS(wb + 2 * HF), lane);
+            load_a2(ab[0], H2_WS(wb), H2_LN);
+            load_a2(ab[1], H2_WS(wb + 2 * HF), H2_LN);
             if (H2_XP_ON(1)) {   // conv1's first two sets
                 const float *w1 = P + OFF_H1 + wave * (4 * 3 * 2 * HF);
                 load_a2(pre_1[0], H2_W12(w1), H2_L12);
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
         for (int s0_ = 0; s0_ < AH; ++s0_) {
             if (H2_XP_ON(1)) { a[s0_][0] = pre_1[s0_][0]; a[s0_][1] = pre_1[s0_][1]; }
-            else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+            else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), H2_LN);
         }
         H2_PRIO_ON();
 #pragma unroll
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (H2_XP_ON(2)) { a[s][0] = pre_2[s][0]; a[s][1] = pre_2[s][1]; }
-            else load_a2(a[s], H2_W(wq + s * 2 * HF), lane);
+            else load_a2(a[s], H2_W(wq + s * 2 * HF), H2_LN);
         }
         if (RING == 6) {
 #pragma unroll
@@ -662,8 +664,8 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
     {   H2_IDS();
         // conv3's two sets (not requested inside the tile loop: a value that only the last iteration defines would be carried, and spilled, around it)
         const float *w3 = P + OFF_H3 + ((wave & 3) * 2 + (wave >> 2)) * (2 * 2 * HF);
-        load_a2(pre_3[0], H2_W(w3), lane);
-        load_a2(pre_3[1], H2_W(w3 + 2 * HF), lane);
+        load_a2(pre_3[0], H2_W(w3), H2_LN);
+        load_a2(pre_3[1], H2_W(w3 + 2 * HF), H2_LN);
     }
     // ---------------- phase 4: conv3 64->64, k3 s2 p1, ReLU (one output frame; tap 0 reads padding), both tiles: wave = (16 channels, tap 1 | 2)
     {
@@ -674,8 +676,8 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         for (int sb = 0; sb < NSUB; ++sb) { hi[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; mid[sb] = hi[sb]; }
         if (H2_XP_ON(3)) {   // conv4's two sets
             const float *w4 = P + OFF_H4 + wave * (2 * 2 * HF);
-            load_a2(pre_4[0], H2_W(w4), lane);
-            load_a2(pre_4[1], H2_W(w4 + 2 * HF), lane);
+            load_a2(pre_4[0], H2_W(w4), H2_LN);
+            load_a2(pre_4[1], H2_W(w4 + 2 * HF), H2_LN);
         }
         const f16x8 (&a)[2][2] = pre_3;
 #pragma unroll
@@ -718,12 +720,12 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         if (H2_XP_ON(3)) {   // W_ih's first sets
             const float *wi = P + OFF_HIH + wave * (4 * 4 * 2 * HF);
 #pragma unroll
-            for (int s0_ = 0; s0_ < AHEAD; ++s0_) load_a2(pre_ih[s0_], H2_W(wi + s0_ * 2 * HF), lane);
+            for (int s0_ = 0; s0_ < AHEAD; ++s0_) load_a2(pre_ih[s0_], H2_W(wi + s0_ * 2 * HF), H2_LN);
         }
         if (!H2_XP_ON(3)) {
             const float *w4 = P + OFF_H4 + wave * (2 * 2 * HF);
-            load_a2(pre_4[0], H2_W(w4), lane);
-            load_a2(pre_4[1], H2_W(w4 + 2 * HF), lane);
+            load_a2(pre_4[0], H2_W(w4), H2_LN);
+            load_a2(pre_4[1], H2_W(w4 + 2 * HF), H2_LN);
         }
         const f16x8 (&a)[2][2] = pre_4;
 #pragma unroll
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
         for (int s0_ = 0; s0_ < AHEAD; ++s0_) {
             if (H2_XP_ON(3)) { a[s0_][0] = pre_ih[s0_][0]; a[s0_][1] = pre_ih[s0_][1]; }
-            else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), lane);
+            else load_a2(a[s0_], H2_W(wq + s0_ * 2 * HF), H2_LN);
         }
         H2_PRIO_ON();
 #pragma unroll
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int s = kc * 4 + g;
-                if (s + AHEAD < 16) load_a2(a[(s + AHEAD) % (AHEAD + 1)], H2_W(wq + (s + AHEAD) * 2 * HF), lane);
+                if (s + AHEAD < 16) load_a2(a[(s + AHEAD) % (AHEAD + 1)], H2_W(wq + (s + AHEAD) * 2 * HF), H2_LN);
                 const f16x8 (&ac)[2] = a[s % (AHEAD + 1)];
                 if (!H2_SKIP(6)) {
 #define H2_TERM(AP, BP, ACC) _Pragma("unroll") for (int sb = 0; sb < NSUB; ++sb) ACC[sb][g] = mfma_f16(ac[AP], b[sb][BP], ACC[sb][g]);
