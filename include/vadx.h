@@ -240,6 +240,13 @@ int vadx_frontend_pack_host(const vadx_frontend_cfg *cfg, const float *cos_tab, 
 int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host,
                          const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
                          int windows_per_clip, float *means_ws, float *out, void *stream);
+/* vadx_frontend_logmel with the window means (prep 0 / 2) GIVEN by the caller instead of computed into a workspace, and the kernel that
+ * computes them (mean of scale * x over each window: exact integer sum, one float32 rounding). */
+int vadx_frontend_logmel_means(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host,
+                               const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
+                               int windows_per_clip, const float *means, float *out, void *stream);
+int vadx_frontend_window_means(const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch, int windows_per_clip,
+                               int window_len, float scale, float *means, void *stream);
 
 /* DFSMN variants of the fused front-end (DFSMN/.../Export_DFSMN_VAD.py:322-325, 338-348):
  *   prep 3: near stream  a = k1*x - mean, pre-emphasis 0.97 keeping a[0]        (int16 source + means)
@@ -289,6 +296,12 @@ int vadx_fsmn_pack_host(const vadx_fsmn_dims *dims, const vadx_fsmn_weights_host
 int vadx_fsmn_energy(const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
                      int windows_per_clip, int window_len, int frames, const float *means, float *db,
                      void *stream);
+/* The window means (prep 0: exact integer sum / window_len, what vadx_frontend_logmel computes into its workspace) AND the energy term above
+ * in ONE pass over the PCM: means f32 [batch*windows_per_clip], db f32 [batch*windows_per_clip][frames].  Feed the means to
+ * vadx_frontend_logmel_means.  (Windows that do not start on 16-byte boundaries or whose length is not a multiple of 32 take the two
+ * separate kernels.)  Replaces nothing more than vadx_fsmn_energy does: FSMN/Export_FSMN_VAD.py:76-79, 93-97. */
+int vadx_fsmn_window_stats(const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch, int windows_per_clip,
+                           int window_len, int frames, float *means, float *db, void *stream);
 
 /* One ORT-boundary call for `batch` independent streams, after the front-end:
  *   feeds   audio -> (logmel [B][T][80], db [B][T]); cache_0..3 f32 [B][128][19];

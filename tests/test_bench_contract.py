@@ -166,8 +166,8 @@ def test_marblenet_h2_flops_follow_the_launched_fragments():
 SECONDARY_TAGS = ("fsmn", "marblenet", "firered", "dfsmn")
 # C-ABI entry point (vadx._lib.trace names) -> the kernels it launches on the default arithmetic, as rocprofv3 names them in SUMMARY.txt
 ENTRY_KERNELS = {
-    "fsmn": {"vadx_frontend_logmel": ["frontend_split_kernel<vadx::SchemeH2>", "window_mean_kernel"], "vadx_fsmn_clips": ["fsmn_clips_kernel<2>"],
-             "vadx_fsmn_energy": ["fsmn_energy_kernel"]},
+    "fsmn": {"vadx_frontend_logmel_means": ["frontend_split_kernel<vadx::SchemeH2>"], "vadx_fsmn_clips": ["fsmn_clips_kernel<2>"],
+             "vadx_fsmn_window_stats": ["fsmn_stats_kernel"]},
     "marblenet": {"vadx_frontend_logmel": ["frontend_split_kernel<vadx::SchemeH2>"], "vadx_sepconv_block": ["sepconv_block_kernel<11, 1, 2, 2>"],
                   "vadx_marblenet_block2": ["jasper_block2_kernel<13, 2>", "jasper_block2_kernel<15, 3>", "jasper_block2_kernel<17, 3>"],
                   "vadx_marblenet_tail": ["marblenet_tail_kernel<2>"]},

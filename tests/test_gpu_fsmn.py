@@ -141,6 +141,37 @@ def test_tiny_projection_is_refused_for_fp16(gemm):
     np.testing.assert_allclose(p1.cpu().numpy(), oraw.numpy() / 2, rtol=0, atol=ATOL)
 
 
+def test_window_stats_one_pass_equals_the_two_kernels(gemm):
+    """vadx_fsmn_window_stats (round 6: window means + frame energies in one pass over the PCM) against the two kernels it replaces: the
+    means bit for bit (exact integer sum), the energies to float32 rounding of another summation order -- on silence, +-1 LSB noise, full-scale
+    noise and bursts, two window grids; rows that do not start on 16-byte boundaries take the two-kernel path and are bitwise the old result."""
+    import ctypes as C
+    if gemm != "h2":
+        pytest.skip("independent of the dense-layer arithmetic")
+    L = _lib.lib()
+    rng = np.random.default_rng(41)
+    for B, W, stride, pad in ((5, 15, 11040, 0), (3, 4, 16000, 0), (4, 15, 11040, 3)):
+        n = (W - 1) * stride + 16000
+        clips = weights.burst_clips(B, n + pad, seed=B + W)
+        clips[0] = 0
+        clips[1] = rng.integers(-1, 2, n + pad)
+        clips[2] = rng.integers(-32768, 32768, n + pad)
+        a = torch.from_numpy(clips).cuda()
+        view = a[:, pad:] if pad else a              # pad = 3: rows start 6 bytes past a 16-byte boundary
+        m0 = torch.empty(B * W, dtype=torch.float32, device="cuda"); d0 = torch.empty((B * W, 101), dtype=torch.float32, device="cuda")
+        m1 = torch.empty_like(m0); d1 = torch.empty_like(d0)
+        st = _lib.stream_ptr()
+        _lib.check(L.vadx_frontend_window_means(view.data_ptr(), a.stride(0), stride, B, W, 16000, C.c_float(1.0), m0.data_ptr(), st))
+        _lib.check(L.vadx_fsmn_energy(view.data_ptr(), a.stride(0), stride, B, W, 16000, 101, m0.data_ptr(), d0.data_ptr(), st))
+        _lib.check(L.vadx_fsmn_window_stats(view.data_ptr(), a.stride(0), stride, B, W, 16000, 101, m1.data_ptr(), d1.data_ptr(), st))
+        assert torch.equal(m0, m1)
+        if pad:
+            assert torch.equal(d0, d1)
+        else:
+            assert float((d0 - d1).abs().max()) <= 8e-6        # a few float32 ulps of values around 15 (measured 3.8e-6): another summation order
+        assert bool(torch.isfinite(d1).all())
+
+
 def test_session_named_tensor_contract():
     sess = fsmn.FsmnSession(weights.fsmn_synthetic(1234))
     ins, outs = sess.get_inputs(), sess.get_outputs()

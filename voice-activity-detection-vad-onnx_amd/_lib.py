@@ -163,6 +163,9 @@ SIGNATURES = {
     "vadx_fsmn_range_flag": (_I, [C.POINTER(FsmnDims), _P, _I, _P, _P, _P]),
     "vadx_fsmn_pack_host": (_I, [C.POINTER(FsmnDims), C.POINTER(FsmnWeightsHost), _P]),
     "vadx_fsmn_energy": (_I, [_P, _L, _L, _I, _I, _I, _I, _P, _P, _P]),
+    "vadx_fsmn_window_stats": (_I, [_P, _L, _L, _I, _I, _I, _I, _P, _P, _P]),
+    "vadx_frontend_logmel_means": (_I, [C.POINTER(FrontendCfg), _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
+    "vadx_frontend_window_means": (_I, [_P, _L, _L, _I, _I, _I, C.c_float, _P, _P]),
     "vadx_fsmn_run": (_I, [C.POINTER(FsmnDims), _P, _P, _P, C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p * 4),
                            _P, _P, _I, _P, _P, _P, _P]),
     "vadx_fsmn_clips": (_I, [C.POINTER(FsmnDims), _P, _P, _P, _I, _I, C.POINTER(FsmnLoopParams), _P, _P, _P, _P]),

@@ -1579,9 +1579,34 @@ extern "C" int vadx_frontend_fold_kind(const vadx_frontend_cfg *cfg, const float
     return best;
 }
 
+extern "C" int vadx_frontend_window_means(const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch, int windows_per_clip,
+                                          int window_len, float scale, float *means, void *stream) {
+    VADX_REQUIRE(audio && means && batch > 0 && windows_per_clip > 0 && window_len > 0, "vadx_frontend_window_means: bad argument");
+    const long long nwin = (long long)batch * windows_per_clip;
+    hipLaunchKernelGGL(window_mean_kernel, dim3((unsigned)((nwin + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), audio,
+                       (long long)row_stride, (long long)win_stride, windows_per_clip, (int)nwin, window_len, scale, means);
+    VADX_HIP_TRY(hipGetLastError());
+    return VADX_OK;
+}
+
+static int logmel_impl(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host, const int16_t *audio, int64_t row_stride,
+                       int64_t win_stride, int batch, int windows_per_clip, float *means_ws, bool means_given, float *out, void *stream);
+
 extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host,
                                     const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
                                     int windows_per_clip, float *means_ws, float *out, void *stream) {
+    return logmel_impl(cfg, packed, mel_kb_host, audio, row_stride, win_stride, batch, windows_per_clip, means_ws, false, out, stream);
+}
+
+extern "C" int vadx_frontend_logmel_means(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host,
+                                          const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch,
+                                          int windows_per_clip, const float *means, float *out, void *stream) {
+    VADX_REQUIRE(means, "vadx_frontend_logmel_means: NULL means");
+    return logmel_impl(cfg, packed, mel_kb_host, audio, row_stride, win_stride, batch, windows_per_clip, const_cast<float *>(means), true, out, stream);
+}
+
+static int logmel_impl(const vadx_frontend_cfg *cfg, const float *packed, const int32_t *mel_kb_host, const int16_t *audio, int64_t row_stride,
+                       int64_t win_stride, int batch, int windows_per_clip, float *means_ws, bool means_given, float *out, void *stream) {
     Dev d;
     VADX_REQUIRE(cfg && packed && mel_kb_host && audio && out, "vadx_frontend_logmel: NULL argument");
     VADX_REQUIRE(derive(cfg, &d) == 0, "vadx_frontend_logmel: unsupported geometry");
@@ -1596,10 +1621,12 @@ extern "C" int vadx_frontend_logmel(const vadx_frontend_cfg *cfg, const float *p
     VADX_REQUIRE(nwin * (d.tiles32 + d.tiles16) < (1LL << 31), "vadx_frontend_logmel: too many tiles");
     const float *means = nullptr;
     if (cfg->prep != 1 && cfg->prep < 6) {
-        const float scale = (cfg->prep == 2) ? cfg->k1 : 1.0f;
-        hipLaunchKernelGGL(window_mean_kernel, dim3((unsigned)((nwin + 3) / 4)), dim3(256), 0, st, audio, (long long)row_stride,
-                           (long long)win_stride, windows_per_clip, (int)nwin, cfg->window_len, scale, means_ws);
-        VADX_HIP_TRY(hipGetLastError());
+        if (!means_given) {             // (vadx_frontend_logmel_means: the caller computed them, e.g. with vadx_fsmn_window_stats)
+            const float scale = (cfg->prep == 2) ? cfg->k1 : 1.0f;
+            hipLaunchKernelGGL(window_mean_kernel, dim3((unsigned)((nwin + 3) / 4)), dim3(256), 0, st, audio, (long long)row_stride,
+                               (long long)win_stride, windows_per_clip, (int)nwin, cfg->window_len, scale, means_ws);
+            VADX_HIP_TRY(hipGetLastError());
+        }
         means = means_ws;
     }
     if (d.fold == 4 || d.fold == 5) {

@@ -662,6 +662,74 @@ __global__ void fsmn_energy_kernel(const int16_t *__restrict__ audio, long long 
     }
 }
 
+// Window mean AND frame energies in one pass over the PCM (round 6; replaces window_mean_kernel + fsmn_energy_kernel for the aligned case: the two
+// read every window from memory once each, and the energy kernel visited every sample 3.2 times -- 512-sample frames at a hop of 160).
+// One workgroup of 256 threads per window: a thread keeps its (up to) eight 16-byte runs of samples in registers, the workgroup sums them as
+// integers (the mean, exactly as window_mean_kernel computes it), then every run contributes sum(y^2) of its eight prepped samples ONCE; four
+// neighbouring lanes add up to a 32-sample granule, and a frame is sixteen consecutive granules (512 = 16 x 32, 160 = 5 x 32).
+// Same formula as fsmn_energy_kernel, another summation order: the dB values agree to float32 rounding (1e-7 relative).
+constexpr int ST_THREADS = 256, ST_MAXIT = 8, ST_MAXGRAN = (ST_THREADS * ST_MAXIT * 8) / 32;       // windows up to 16 384 samples
+__global__ __launch_bounds__(ST_THREADS) void fsmn_stats_kernel(const int16_t *__restrict__ audio, long long row_stride, long long win_stride,
+                                                                int windows_per_clip, int window_len, int T, float inv_ref,
+                                                                float *__restrict__ means, float *__restrict__ db) {
+    __shared__ float gran[ST_MAXGRAN];
+    __shared__ long long wsum[ST_THREADS / 64];
+    const int widx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = widx / windows_per_clip, w = widx - b * windows_per_clip;
+    const int16_t *win = audio + (long long)b * row_stride + (long long)w * win_stride;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const int nrun = window_len / 8;
+    s16x8 x[ST_MAXIT];
+    long long s = 0;
+#pragma unroll
+    for (int it = 0; it < ST_MAXIT; ++it) {
+        const int r = it * ST_THREADS + tid;
+        x[it] = *reinterpret_cast<const s16x8 *>(win + 8 * (r < nrun ? r : nrun - 1));
+        if (r < nrun)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += x[it][e];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    long long tot = 0;
+#pragma unroll
+    for (int k = 0; k < ST_THREADS / 64; ++k) tot += wsum[k];
+    const float mean = (float)((double)tot / (double)window_len);
+    if (tid == 0) means[widx] = mean;
+#pragma unroll
+    for (int it = 0; it < ST_MAXIT; ++it) {
+        const int r = it * ST_THREADS + tid;
+        // the sample in front of this run: the previous lane's last sample (the previous run), the first lane of a wave reads it from memory
+        float prev = (float)__shfl_up((int)x[it][7], 1);
+        if (lane == 0) prev = (float)win[r > 0 ? 8 * (r < nrun ? r : nrun - 1) - 1 : 0];
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = __fsub_rn((float)x[it][e], mean);
+            float y = a;
+            if (e > 0 || r > 0) y = __fsub_rn(a, __fmul_rn(0.97f, __fsub_rn(prev, mean)));
+            y = __fmul_rn(y, inv_ref);
+            acc = fmaf(y, y, acc);
+            prev = (float)x[it][e];
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if ((lane & 3) == 0 && r < nrun) gran[r >> 2] = acc;
+    }
+    __syncthreads();
+    const int nfr = (window_len - 512) / 160 + 1;
+    float *out = db + (size_t)widx * T;
+    for (int f = tid; f < T; f += ST_THREADS) {
+        const int ff = f < nfr ? f : nfr - 1;          // last value repeated up to T frames
+        float e = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) e += gran[5 * ff + j];
+        out[f] = log10f(e + 0.00002f);
+    }
+}
+
 }  // namespace fsmn
 }  // namespace vadx
 
@@ -805,6 +873,27 @@ extern "C" int vadx_fsmn_energy(const int16_t *audio, int64_t row_stride, int64_
                        windows_per_clip, window_len, 512, 160, frames, means, inv_ref, db);
     VADX_HIP_TRY(hipGetLastError());
     return VADX_OK;
+}
+
+extern "C" int vadx_fsmn_window_stats(const int16_t *audio, int64_t row_stride, int64_t win_stride, int batch, int windows_per_clip,
+                                      int window_len, int frames, float *means, float *db, void *stream) {
+    VADX_REQUIRE(audio && means && db, "vadx_fsmn_window_stats: NULL argument");
+    VADX_REQUIRE(batch > 0 && windows_per_clip > 0 && window_len >= 512 && frames > 0, "vadx_fsmn_window_stats: bad shape");
+    const float inv_ref = (float)(1.0 / (sqrt((double)window_len) * 2e-5));
+    const long long nwin = (long long)batch * windows_per_clip;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the one-pass kernel reads 16-byte runs: every window must start on a 16-byte boundary and hold a whole number of 32-sample granules
+    const bool aligned = (reinterpret_cast<uintptr_t>(audio) & 15) == 0 && (row_stride & 7) == 0 && (win_stride & 7) == 0 &&
+                         window_len % 32 == 0 && window_len <= ST_THREADS * ST_MAXIT * 8;
+    if (aligned) {
+        hipLaunchKernelGGL(fsmn_stats_kernel, dim3((unsigned)nwin), dim3(ST_THREADS), 0, st, audio, (long long)row_stride, (long long)win_stride,
+                           windows_per_clip, window_len, frames, inv_ref, means, db);
+        VADX_HIP_TRY(hipGetLastError());
+        return VADX_OK;
+    }
+    int rc = vadx_frontend_window_means(audio, row_stride, win_stride, batch, windows_per_clip, window_len, 1.0f, means, stream);
+    if (rc != VADX_OK) return rc;
+    return vadx_fsmn_energy(audio, row_stride, win_stride, batch, windows_per_clip, window_len, frames, means, db, stream);
 }
 
 extern "C" int vadx_fsmn_run(const vadx_fsmn_dims *dims, const float *packed, const float *logmel, const float *db,

@@ -95,11 +95,12 @@ class FsmnEngine:
         db = t.empty((B * W, self.T), dtype=t.float32, device=self.device)
         L = _lib.lib()
         with t.cuda.device(self.device):
-            _lib.check(L.vadx_frontend_logmel(C.byref(fe.cfg), fe.packed.data_ptr(), fe.mel_kb.ctypes.data, a.data_ptr(),
-                                              _lib.row_stride(a), int(stride), B, W, means.data_ptr(), logmel.data_ptr(),
-                                              _lib.stream_ptr()))
-            _lib.check(L.vadx_fsmn_energy(a.data_ptr(), _lib.row_stride(a), int(stride), B, W, self.L, self.T, means.data_ptr(),
-                                          db.data_ptr(), _lib.stream_ptr()))
+            # window means + frame energies in one pass over the PCM, then the log-mel front-end with those means
+            _lib.check(L.vadx_fsmn_window_stats(a.data_ptr(), _lib.row_stride(a), int(stride), B, W, self.L, self.T, means.data_ptr(),
+                                                db.data_ptr(), _lib.stream_ptr()))
+            _lib.check(L.vadx_frontend_logmel_means(C.byref(fe.cfg), fe.packed.data_ptr(), fe.mel_kb.ctypes.data, a.data_ptr(),
+                                                    _lib.row_stride(a), int(stride), B, W, means.data_ptr(), logmel.data_ptr(),
+                                                    _lib.stream_ptr()))
         return logmel, db
 
     def run(self, audio_i16, caches, thr, noise_db, return_psil=False):
