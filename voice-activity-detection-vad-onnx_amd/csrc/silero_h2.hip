@@ -58,6 +58,12 @@
 #define H2_L12 (((H2_SKIP(11) && sub == 1) || H2_SKIP(10)) ? 0 : lane)
 // bit 10: EVERY fragment load reads one 16-byte piece (all lanes the same address): the kernel without its L1 request stream
 #define H2_LN (H2_SKIP(10) ? 0 : lane)
+// bit 9: the W_ih fragments alone as single L1 accesses from one address (what a W_ih pass over more columns per fragment could approach);
+// bit 8: the STFT's
+#define H2_WIH(addr) ((H2_SKIP(9) || H2_SKIP(13)) ? (P + vadx::silero::OFF_H1) : (addr))
+#define H2_LIH ((H2_SKIP(9) || H2_SKIP(10)) ? 0 : lane)
+#define H2_WST(addr) ((H2_SKIP(8) || (H2_SKIP(12) && sub == 1) || H2_SKIP(13)) ? (P + vadx::silero::OFF_H1) : (addr))
+#define H2_LST ((H2_SKIP(8) || H2_SKIP(10)) ? 0 : lane)
 #define H2_WS(addr) (((H2_SKIP(12) && sub == 1) || H2_SKIP(13)) ? (P + vadx::silero::OFF_H1) : (addr))
 #if (VADX_EXP >> 14) & 1
 __device__ unsigned long long h2_dbg[16];
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         H2_IDS();
         const float *wq = P + OFF_HSF + (size_t)(wave & 3) * (2 * 2 * 2 * 2 * HF);
 #pragma unroll
-        for (int s0_ = 0; s0_ < H2_AHS; ++s0_) load_a2(pre_s[s0_], H2_WS(wq + s0_ * 2 * HF), H2_LN);
+        for (int s0_ = 0; s0_ < H2_AHS; ++s0_) load_a2(pre_s[s0_], H2_WST(wq + s0_ * 2 * HF), H2_LST);
     }
     H2_SYNC(0);
     H2_MARK(0);
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                 H2_PRIO_ON();
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {          // s8 = (class, part, chunk) in OFF_HSF's order
-                    if (s8 + AH < 8) load_a2(a[(s8 + AH) % (AH + 1)], H2_WS(wq + (s8 + AH) * 2 * HF), H2_LN);
+                    if (s8 + AH < 8) load_a2(a[(s8 + AH) % (AH + 1)], H2_WST(wq + (s8 + AH) * 2 * HF), H2_LST);
                     f16x8 b[2][2];
 #pragma unroll
                     for (int fr = 0; fr < 2; ++fr) {
@@ -461,8 +467,8 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
                 H2_PRIO_OFF();
             }
             f16x8 ab[2][2];                               // the bin-64 piece's two chunks: requested before the magnitudes, used after them
-            load_a2(ab[0], H2_WS(wb), H2_LN);
-            load_a2(ab[1], H2_WS(wb + 2 * HF), H2_LN);
+            load_a2(ab[0], H2_WST(wb), H2_LST);
+            load_a2(ab[1], H2_WST(wb + 2 * HF), H2_LST);
             if (H2_XP_ON(1)) {   // conv1's first two sets
                 const float *w1 = P + OFF_H1 + wave * (4 * 3 * 2 * HF);
                 load_a2(pre_1[0], H2_W12(w1), H2_L12);
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
         if (H2_XP_ON(3)) {   // W_ih's first sets
             const float *wi = P + OFF_HIH + wave * (4 * 4 * 2 * HF);
 #pragma unroll
-            for (int s0_ = 0; s0_ < AHEAD; ++s0_) load_a2(pre_ih[s0_], H2_W(wi + s0_ * 2 * HF), H2_LN);
+            for (int s0_ = 0; s0_ < AHEAD; ++s0_) load_a2(pre_ih[s0_], H2_WIH(wi + s0_ * 2 * HF), H2_LIH);
         }
         if (!H2_XP_ON(3)) {
             const float *w4 = P + OFF_H4 + wave * (2 * 2 * HF);
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(H2_THREADS, H2_WAVES_PER_SIMD) void silero_encode_h
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int s = kc * 4 + g;
-                if (s + AHEAD < 16) load_a2(a[(s + AHEAD) % (AHEAD + 1)], H2_W(wq + (s + AHEAD) * 2 * HF), H2_LN);
+                if (s + AHEAD < 16) load_a2(a[(s + AHEAD) % (AHEAD + 1)], H2_WIH(wq + (s + AHEAD) * 2 * HF), H2_LIH);
                 const f16x8 (&ac)[2] = a[s % (AHEAD + 1)];
                 if (!H2_SKIP(6)) {
 #define H2_TERM(AP, BP, ACC) _Pragma("unroll") for (int sb = 0; sb < NSUB; ++sb) ACC[sb][g] = mfma_f16(ac[AP], b[sb][BP], ACC[sb][g]);
